@@ -1,0 +1,415 @@
+"""Model compiler: MuJoCo-XML (+ binary STL hulls) -> compiled KPM blob.
+
+The reference hands its humanoid to MuJoCo as
+``assets/mujoco_models/humanoid_smpl_neutral_mesh*.xml`` (reference
+``uhc/khrylib/rl/envs/common/mujoco_env.py:16-44``) and lets ``libmujoco`` compile it
+(``mujoco_py.load_model_from_path``).  MuJoCo is not part of this engine, so the
+compile step is done here: this module parses the same XML (``coordinate="global"``,
+``angle="degree"``, ``inertiafromgeom="true"``; XML ``:2,11-16``) and the binary STL
+convex hulls under ``geom/``, and emits every constant the HIP simulator needs:
+
+* kinematic tree (parents, local offsets), per-body mass / COM / inertia from the
+  mesh at density 1000 kg/m^3 (exact polyhedral integration),
+* dof tables in MuJoCo's ``qM`` sparse layout (dof_parent, dof_madr, armature),
+* hull vertices per body (for hull-vs-plane collision) and bounding radii,
+* stable-PD gains / torque limits / RFC parameters from ``config/uhc/uhc.yml:81-156``,
+* constraint-model constants evaluated at ``qpos0`` (body/dof ``invweight0``,
+  ``meaninertia``) the soft-contact model needs,
+* free objects (chair, box, table, Can, step) geoms, recorded for later rounds.
+
+Blob layout ("KPM1", little endian):
+    u32 magic 'KPM1' | u32 version | u32 n_entries | entries[n] | payload
+    entry = char name[32] | u32 dtype (0=f64, 1=i32) | u32 pad | u64 count | u64 byte offset
+Both the product loader (``csrc/kp_model.hpp``) and the oracle loader
+(``oracle/kp_oracle.c``) parse this format independently.
+
+Usage:  python -m kinpoly_amd.model_compiler <model.xml> <uhc.yml> <out.kpm>
+"""
+from __future__ import annotations
+
+import math
+import os
+import struct
+import sys
+import xml.etree.ElementTree as ET
+
+import numpy as np
+
+KPM_MAGIC = 0x314D504B  # 'KPM1'
+KPM_VERSION = 3
+
+# MuJoCo 2.1.0 defaults that the reference never overrides [MJ-ext]
+MJ_DEFAULTS = dict(
+    gravity=(0.0, 0.0, -9.81),
+    density=1000.0,
+    solref=(0.02, 1.0),
+    solimp=(0.9, 0.95, 0.001, 0.5, 2.0),
+    geom_friction=(1.0, 0.005, 0.0001),
+    impratio=1.0,
+    solver_iterations=100,
+    solver_tolerance=1e-8,
+)
+
+
+# --------------------------------------------------------------------------- STL / inertia
+def read_binary_stl(path: str) -> np.ndarray:
+    """Return triangles [n,3,3] (float64) of a binary STL file."""
+    with open(path, "rb") as f:
+        buf = f.read()
+    (ntri,) = struct.unpack_from("<I", buf, 80)
+    assert len(buf) >= 84 + 50 * ntri, f"truncated STL {path}"
+    rec = np.frombuffer(buf, dtype=np.dtype([("n", "<f4", 3), ("v", "<f4", (3, 3)), ("a", "<u2")]),
+                        count=ntri, offset=84)
+    return rec["v"].astype(np.float64)
+
+
+def polyhedron_mass_props(tris: np.ndarray, density: float):
+    """Exact mass, COM and inertia-about-COM of a closed triangle mesh.
+
+    Signed tetrahedra against the vertex centroid; |volume| per tetra so that the triangle
+    winding does not matter for a convex hull (what MuJoCo 2.1's mesh compiler does for
+    meshes, [MJ-ext]).  Inertia returned as full 3x3 in the mesh frame about the COM.
+    """
+    ref = tris.reshape(-1, 3).mean(axis=0)
+    a = tris[:, 0] - ref
+    b = tris[:, 1] - ref
+    c = tris[:, 2] - ref
+    vol6 = np.abs(np.einsum("ij,ij->i", a, np.cross(b, c)))  # 6 * tetra volume
+    vol = vol6 / 6.0
+    V = vol.sum()
+    cent = (a + b + c) / 4.0  # tetra centroid (4th vertex at origin=ref)
+    com_rel = (vol[:, None] * cent).sum(axis=0) / V
+    # second-moment integral over each tetra with one vertex at the origin:
+    #   int x x^T dV = V/20 * (sum_i v_i v_i^T + (sum_i v_i)(sum_i v_i)^T), v_0 = 0
+    s = a + b + c
+    C = np.zeros((3, 3))
+    for va in (a, b, c):
+        C += np.einsum("i,ij,ik->jk", vol / 20.0, va, va)
+    C += np.einsum("i,ij,ik->jk", vol / 20.0, s, s)
+    # shift covariance to the COM
+    C -= V * np.outer(com_rel, com_rel)
+    inertia = (np.trace(C) * np.eye(3) - C) * density
+    return V * density, ref + com_rel, inertia
+
+
+# --------------------------------------------------------------------------- XML parsing
+def _floats(s, n=None):
+    v = [float(x) for x in s.replace(",", " ").split()]
+    if n is not None:
+        assert len(v) == n, (s, n)
+    return v
+
+
+def euler_deg_to_mat(e):
+    """MuJoCo default eulerseq 'xyz' (intrinsic): R = Rx * Ry * Rz."""
+    ax, ay, az = [math.radians(x) for x in e]
+    cx, sx, cy, sy, cz, sz = math.cos(ax), math.sin(ax), math.cos(ay), math.sin(ay), math.cos(az), math.sin(az)
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    return Rx @ Ry @ Rz
+
+
+def parse_xml(xml_path: str):
+    root = ET.parse(xml_path).getroot()
+    comp = root.find("compiler").attrib
+    assert comp.get("coordinate") == "global" and comp.get("angle") == "degree"
+    assert comp.get("inertiafromgeom") == "true"
+    dflt = root.find("default")
+    jd = dflt.find("joint").attrib
+    gd = dflt.find("geom").attrib
+    opt = root.find("option").attrib
+    base = os.path.dirname(os.path.abspath(xml_path))
+    meshes = {}
+    for m in root.find("asset").findall("mesh"):
+        f = m.attrib["file"]
+        name = m.attrib.get("name", os.path.splitext(os.path.basename(f))[0])
+        meshes[name] = os.path.join(base, f)
+
+    wb = root.find("worldbody")
+    floor = None
+    for g in wb.findall("geom"):
+        if g.attrib.get("type") == "plane":
+            floor = dict(gd)
+            floor.update(g.attrib)
+    assert floor is not None
+
+    bodies = []  # humanoid bodies in DFS order
+    objects = []
+
+    def walk(elem, parent):
+        idx = len(bodies)
+        gpos = np.array(_floats(elem.attrib["pos"], 3))
+        joints = []
+        for j in elem.findall("joint"):
+            a = dict(jd)
+            a.update(j.attrib)
+            joints.append(a)
+        geoms = []
+        for g in elem.findall("geom"):
+            a = dict(gd)
+            a.update(g.attrib)
+            geoms.append(a)
+        bodies.append(dict(name=elem.attrib["name"], parent=parent, gpos=gpos, joints=joints, geoms=geoms))
+        for ch in elem.findall("body"):
+            walk(ch, idx)
+
+    for top in wb.findall("body"):
+        jn = top.findall("joint")
+        is_humanoid = any(g.attrib.get("type") == "mesh" for g in top.findall("geom"))
+        if is_humanoid:
+            walk(top, -1)
+        else:
+            geoms = []
+            for g in top.findall("geom"):
+                a = dict(gd)
+                a.update(g.attrib)
+                geoms.append(a)
+            objects.append(dict(name=top.attrib["name"], geoms=geoms, free=len(jn) == 1 and jn[0].attrib.get("type") == "free"))
+    return dict(bodies=bodies, objects=objects, meshes=meshes, floor=floor, timestep=float(opt["timestep"]),
+                joint_default=jd, geom_default=gd)
+
+
+# --------------------------------------------------------------------------- dynamics at qpos0 (numpy, host)
+def _mass_matrix_qpos0(parent, gpos, com_g, mass, inertia_w, dof_body, dof_axis, dof_is_trans, armature):
+    """Dense M(qpos0) = sum_b Jv^T m Jv + Jw^T I Jw  (kinetic-energy form; host-only, runs once)."""
+    nb, nv = len(parent), len(dof_body)
+    # ancestor mask
+    anc = np.zeros((nb, nb), bool)
+    for b in range(nb):
+        k = b
+        while k >= 0:
+            anc[b, k] = True
+            k = parent[k]
+    M = np.zeros((nv, nv))
+    Js = []
+    for b in range(nb):
+        Jv = np.zeros((3, nv))
+        Jw = np.zeros((3, nv))
+        for d in range(nv):
+            if not anc[b, dof_body[d]]:
+                continue
+            ax = dof_axis[d]
+            if dof_is_trans[d]:
+                Jv[:, d] = ax
+            else:
+                Jw[:, d] = ax
+                Jv[:, d] = np.cross(ax, com_g[b] - gpos[dof_body[d]])
+        M += mass[b] * Jv.T @ Jv + Jw.T @ inertia_w[b] @ Jw
+        Js.append((Jv, Jw))
+    M += np.diag(armature)
+    return M, Js
+
+
+def compile_model(xml_path: str, uhc_yml: str | None = None) -> dict:
+    import yaml
+
+    px = parse_xml(xml_path)
+    bodies = px["bodies"]
+    nb = len(bodies)
+    density = MJ_DEFAULTS["density"]
+
+    parent = np.array([b["parent"] for b in bodies], np.int32)
+    gpos = np.stack([b["gpos"] for b in bodies])
+    body_pos = gpos.copy()
+    for i in range(nb):
+        if parent[i] >= 0:
+            body_pos[i] = gpos[i] - gpos[parent[i]]  # all rest quats are identity (XML quat="1 0 0 0")
+
+    mass = np.zeros(nb)
+    ipos = np.zeros((nb, 3))
+    inertia = np.zeros((nb, 3, 3))
+    verts_all, vert_adr, rbound = [], [0], np.zeros(nb)
+    for i, b in enumerate(bodies):
+        assert len(b["geoms"]) == 1 and b["geoms"][0]["type"] == "mesh"
+        tris = read_binary_stl(px["meshes"][b["geoms"][0]["mesh"]])
+        m, com, I = polyhedron_mass_props(tris, density)
+        mass[i], ipos[i], inertia[i] = m, com - gpos[i], I
+        v = np.unique(tris.reshape(-1, 3), axis=0) - gpos[i]  # hull vertices in the body frame
+        verts_all.append(v)
+        vert_adr.append(vert_adr[-1] + len(v))
+        rbound[i] = np.linalg.norm(v, axis=1).max()
+    verts = np.concatenate(verts_all)
+
+    # ---- dofs: free root (3 trans world axes + 3 rot body axes) then 3 hinges (z,y,x) per body
+    dof_body, dof_axis, dof_trans, arm, jrange, jlimited = [], [], [], [], [], []
+    for i, b in enumerate(bodies):
+        for j in b["joints"]:
+            if j["type"] == "free":
+                for k in range(3):
+                    dof_body.append(i); dof_axis.append(np.eye(3)[k]); dof_trans.append(1); arm.append(float(j.get("armature", 0)))
+                for k in range(3):
+                    dof_body.append(i); dof_axis.append(np.eye(3)[k]); dof_trans.append(0); arm.append(float(j.get("armature", 0)))
+            else:
+                assert j["type"] == "hinge"
+                assert np.allclose(_floats(j["pos"], 3), b["gpos"])  # hinge anchored at the body origin
+                dof_body.append(i); dof_axis.append(np.array(_floats(j["axis"], 3))); dof_trans.append(0)
+                arm.append(float(j["armature"]))
+                r = _floats(j["range"], 2)
+                jrange.append([math.radians(r[0]), math.radians(r[1])])
+                jlimited.append(1 if j.get("limited", "false") == "true" else 0)
+    nv = len(dof_body)
+    dof_body = np.array(dof_body, np.int32)
+    dof_axis = np.stack(dof_axis)
+    # hinge order inside each body must be z, y, x
+    for i in range(1, nb):
+        ax = dof_axis[6 + 3 * (i - 1): 9 + 3 * (i - 1)]
+        assert np.allclose(ax, np.eye(3)[[2, 1, 0]]), f"unexpected hinge order in body {i}"
+    # dof tree in MuJoCo layout: dof_parent = previous dof in the chain
+    last_dof_of_body = {}
+    dof_parent = np.full(nv, -1, np.int32)
+    for d in range(nv):
+        b = dof_body[d]
+        if d > 0 and dof_body[d - 1] == b:
+            dof_parent[d] = d - 1
+        elif parent[b] >= 0:
+            dof_parent[d] = last_dof_of_body[parent[b]]
+        last_dof_of_body[b] = d
+    dof_depth = np.zeros(nv, np.int32)
+    for d in range(nv):
+        dof_depth[d] = 0 if dof_parent[d] < 0 else dof_depth[dof_parent[d]] + 1
+    dof_madr = np.zeros(nv + 1, np.int32)
+    for d in range(nv):
+        dof_madr[d + 1] = dof_madr[d] + dof_depth[d] + 1
+    nM = int(dof_madr[nv])
+
+    # subtree sizes (bodies are in DFS order => subtree(b) = [b, b+size))
+    subtree = np.ones(nb, np.int32)
+    for i in range(nb - 1, 0, -1):
+        subtree[parent[i]] += subtree[i]
+    body_depth = np.zeros(nb, np.int32)
+    for i in range(1, nb):
+        body_depth[i] = body_depth[parent[i]] + 1
+
+    # ---- qpos0 constants for the constraint model [MJ-ext: engine_setconst.c set0]
+    com_g = gpos + ipos
+    M0, Js = _mass_matrix_qpos0(parent, gpos, com_g, mass, inertia, dof_body, dof_axis, dof_trans, np.array(arm))
+    Minv = np.linalg.inv(M0)
+    body_invw = np.zeros((nb, 2))
+    for b in range(nb):
+        Jv, Jw = Js[b]
+        A = np.vstack([Jv, Jw]) @ Minv @ np.vstack([Jv, Jw]).T
+        body_invw[b, 0] = np.trace(A[:3, :3]) / 3.0
+        body_invw[b, 1] = np.trace(A[3:, 3:]) / 3.0
+    dinv = np.diag(Minv).copy()
+    dof_invw = dinv.copy()
+    dof_invw[0:3] = dinv[0:3].mean()
+    dof_invw[3:6] = dinv[3:6].mean()
+    meaninertia = float(np.diag(M0).mean())
+
+    # ---- floor
+    fl = px["floor"]
+    floor_friction = _floats(fl["friction"]) if "friction" in fl else list(MJ_DEFAULTS["geom_friction"])
+    geom_margin = float(px["geom_default"].get("margin", 0.0))
+    # contact friction = elementwise max of the pair, margin = max of the pair [MJ-ext]
+    fric = np.maximum(np.array(floor_friction), np.array(MJ_DEFAULTS["geom_friction"]))
+    condim = max(int(fl.get("condim", 3)), int(px["geom_default"].get("condim", 3)))
+
+    # ---- controller gains (uhc.yml joint_params; reference copycat_config.py:133-146)
+    nu = nv - 6
+    kp = np.zeros(nu); kd = np.zeros(nu); tlim = np.zeros(nu); a_scale = np.ones(nu)
+    rfc_scale, rfc_lim = 100.0, 100.0
+    base_rot = [0.7071, 0.7071, 0.0, 0.0]
+    if uhc_yml is not None:
+        cfg = yaml.safe_load(open(uhc_yml))
+        jp = cfg["joint_params"]
+        names = [f"{b['name']}_{a}" for b in bodies[1:] for a in "zyx"]
+        assert [r[0] for r in jp] == names, "uhc.yml joint order differs from the XML dof order"
+        kp = np.array([r[1] for r in jp], float)
+        kd = np.array([r[2] for r in jp], float)
+        a_scale = np.array([r[4] for r in jp], float)
+        tlim = np.array([r[5] for r in jp], float)
+        rfc_scale = float(cfg.get("residual_force_scale", 200.0))
+        rfc_lim = float(cfg.get("residual_force_lim", 100.0))
+        base_rot = cfg.get("data_specs", {}).get("base_rot", base_rot)
+    diffw = np.ones(nb)
+
+    # ---- free objects (recorded; dynamics of objects is a later-round row)
+    obj_geoms = []
+    for oi, ob in enumerate(px["objects"]):
+        for g in ob["geoms"]:
+            typ = {"box": 0, "cylinder": 1}[g["type"]]
+            size = _floats(g["size"]) + [0.0]
+            R = euler_deg_to_mat(_floats(g.get("euler", "0 0 0"), 3))
+            obj_geoms.append([oi, typ, *size[:3], *_floats(g.get("pos", "0 0 0"), 3), *R.reshape(-1), float(g["mass"])])
+    obj_geoms = np.array(obj_geoms, float).reshape(-1, 18)
+
+    model = dict(
+        dims=np.array([nb, nv, nv + 1, nu, nM, len(verts), len(px["objects"]), len(obj_geoms), condim], np.int32),
+        body_parent=parent, body_depth=body_depth, body_subtree=subtree,
+        body_pos=body_pos, body_ipos=ipos, body_mass=mass,
+        body_inertia=np.stack([inertia[:, 0, 0], inertia[:, 1, 1], inertia[:, 2, 2],
+                               inertia[:, 0, 1], inertia[:, 0, 2], inertia[:, 1, 2]], axis=1),
+        body_gpos0=gpos, body_rbound=rbound, body_diffw=diffw,
+        body_invweight0=body_invw, dof_invweight0=dof_invw,
+        dof_body=dof_body, dof_parent=dof_parent, dof_depth=dof_depth, dof_madr=dof_madr,
+        dof_armature=np.array(arm), jnt_range=np.array(jrange), jnt_limited=np.array(jlimited, np.int32),
+        vert_adr=np.array(vert_adr, np.int32), verts=verts,
+        kp=kp, kd=kd, torque_lim=tlim, a_scale=a_scale,
+        opt=np.array([px["timestep"], *MJ_DEFAULTS["gravity"], *MJ_DEFAULTS["solref"], *MJ_DEFAULTS["solimp"],
+                      *fric, geom_margin, MJ_DEFAULTS["impratio"], meaninertia,
+                      rfc_scale, rfc_lim, *base_rot,
+                      MJ_DEFAULTS["solver_iterations"], MJ_DEFAULTS["solver_tolerance"]], float),
+        obj_geoms=obj_geoms,
+        M0=M0,
+    )
+    model["_names"] = [b["name"] for b in bodies]
+    return model
+
+
+# opt[] index map (shared with the C side: kp_model.hpp / kp_oracle.c)
+OPT_FIELDS = ["timestep", "gx", "gy", "gz", "solref_tc", "solref_dr", "solimp_d0", "solimp_dw", "solimp_w",
+              "solimp_mid", "solimp_pow", "fric_slide", "fric_spin", "fric_roll", "margin", "impratio",
+              "meaninertia", "rfc_scale", "rfc_lim", "base_rot_w", "base_rot_x", "base_rot_y", "base_rot_z",
+              "solver_iter", "solver_tol"]
+
+
+def write_kpm(model: dict, path: str):
+    entries = [(k, np.ascontiguousarray(v)) for k, v in model.items() if not k.startswith("_")]
+    hdr = 12 + 56 * len(entries)
+    off = (hdr + 7) // 8 * 8
+    table, blobs = [], []
+    for name, arr in entries:
+        if arr.dtype.kind == "f":
+            arr = arr.astype("<f8"); dt = 0
+        else:
+            arr = arr.astype("<i4"); dt = 1
+        raw = arr.tobytes()
+        table.append(struct.pack("<32sIIQQ", name.encode(), dt, 0, arr.size, off))
+        blobs.append((off, raw))
+        off = (off + len(raw) + 7) // 8 * 8
+    with open(path, "wb") as f:
+        f.write(struct.pack("<III", KPM_MAGIC, KPM_VERSION, len(entries)))
+        for t in table:
+            f.write(t)
+        for o, raw in blobs:
+            f.seek(o)
+            f.write(raw)
+        f.truncate(off)
+
+
+def read_kpm(path: str) -> dict:
+    buf = open(path, "rb").read()
+    magic, ver, n = struct.unpack_from("<III", buf, 0)
+    assert magic == KPM_MAGIC, "not a KPM blob"
+    out = {"_version": ver}
+    for i in range(n):
+        name, dt, _, cnt, off = struct.unpack_from("<32sIIQQ", buf, 12 + 56 * i)
+        name = name.split(b"\0")[0].decode()
+        out[name] = np.frombuffer(buf, dtype="<f8" if dt == 0 else "<i4", count=cnt, offset=off).copy()
+    return out
+
+
+DEFAULT_KPM = os.path.join(os.path.dirname(__file__), "assets", "smpl_humanoid.kpm")
+
+
+def main(argv):
+    xml, yml, out = argv[1], argv[2], argv[3]
+    m = compile_model(xml, yml if yml != "-" else None)
+    write_kpm(m, out)
+    print(f"wrote {out}: nbody={m['dims'][0]} nv={m['dims'][1]} nM={m['dims'][4]} nvert={m['dims'][5]} "
+          f"mass={m['body_mass'].sum():.3f} kg")
+
+
+if __name__ == "__main__":
+    main(sys.argv)

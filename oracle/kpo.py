@@ -1,0 +1,149 @@
+"""ctypes wrapper around oracle/_build/libkp_oracle.so (CPU fp64 oracle).
+
+TEST INFRASTRUCTURE ONLY -- see the header of kp_oracle.c.  Imported by tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg; never by kinpoly_amd/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "libkp_oracle.so")
+DEFAULT_KPM = os.path.join(os.path.dirname(_HERE), "kinpoly_amd", "assets", "smpl_humanoid.kpm")
+NQ, NV, NU, NB, NM = 76, 75, 69, 24, 1221
+
+
+def build(force: bool = False):
+    src = os.path.join(_HERE, "kp_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        P, D, I = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)
+        L.kpo_model_load.restype = P; L.kpo_model_load.argtypes = [C.c_char_p]
+        L.kpo_model_free.argtypes = [P]
+        L.kpo_model_set_flags.argtypes = [P, C.c_int, C.c_int]
+        L.kpo_model_set_gravity.argtypes = [P, C.c_double]
+        L.kpo_data_new.restype = P
+        L.kpo_data_free.argtypes = [P]
+        for f in ("kpo_forward", "kpo_step"):
+            getattr(L, f).argtypes = [P, P]
+        L.kpo_reset.argtypes = [P, P, D, D]
+        L.kpo_fullM.argtypes = [P, P, D]
+        L.kpo_compute_torque.argtypes = [P, P, D, D, D]
+        L.kpo_rfc_implicit.argtypes = [P, P, D]
+        L.kpo_do_simulation.argtypes = [P, P, D, D, C.c_int]
+        L.kpo_set_qpos_qvel.argtypes = [P, D, D]
+        L.kpo_set_ctrl.argtypes = [P, D, D]
+        L.kpo_solveM.argtypes = [P, P, D]
+        L.kpo_get_contacts.argtypes = [P, I, D, D]
+        L.kpo_rollout_batch.argtypes = [P, C.c_int, D, D, D, D, C.c_int, C.c_int]
+        for g in ("ncon", "nefc", "niter"):
+            getattr(L, "kpo_get_" + g).argtypes = [P]; getattr(L, "kpo_get_" + g).restype = C.c_int
+        for f in _FIELDS:
+            getattr(L, "kpo_get_" + f).argtypes = [P, D]
+        _lib = L
+    return _lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+_FIELDS = dict(qpos=NQ, qvel=NV, xpos=72, xquat=96, xipos=72, qM=NM, qfrc_bias=NV, qacc=NV, qacc_smooth=NV,
+               subtree_com=3, ctrl=NU, qfrc_applied=NV, qfrc_constraint=NV, cvel=144)
+
+
+class OracleSim:
+    """One scalar fp64 environment."""
+
+    def __init__(self, kpm: str = DEFAULT_KPM, contact=True, limits=True, gravity=None):
+        L = lib()
+        self.L = L
+        self.m = L.kpo_model_load(kpm.encode())
+        assert self.m, f"cannot load {kpm}"
+        L.kpo_model_set_flags(self.m, int(contact), int(limits))
+        if gravity is not None:
+            L.kpo_model_set_gravity(self.m, float(gravity))
+        self.d = L.kpo_data_new()
+
+    def __del__(self):
+        try:
+            self.L.kpo_data_free(self.d); self.L.kpo_model_free(self.m)
+        except Exception:
+            pass
+
+    def reset(self, qpos, qvel):
+        qpos = np.ascontiguousarray(qpos, np.float64); qvel = np.ascontiguousarray(qvel, np.float64)
+        self.L.kpo_reset(self.m, self.d, _dp(qpos), _dp(qvel))
+
+    def set_state_raw(self, qpos, qvel):
+        qpos = np.ascontiguousarray(qpos, np.float64); qvel = np.ascontiguousarray(qvel, np.float64)
+        self.L.kpo_set_qpos_qvel(self.d, _dp(qpos), _dp(qvel))
+
+    def set_ctrl(self, ctrl, applied6=None):
+        ctrl = np.ascontiguousarray(ctrl, np.float64)
+        a = None if applied6 is None else np.ascontiguousarray(applied6, np.float64)
+        self.L.kpo_set_ctrl(self.d, _dp(ctrl), None if a is None else _dp(a))
+
+    def forward(self):
+        self.L.kpo_forward(self.m, self.d)
+
+    def step(self):
+        self.L.kpo_step(self.m, self.d)
+
+    def get(self, name):
+        out = np.zeros(_FIELDS[name])
+        getattr(self.L, "kpo_get_" + name)(self.d, _dp(out))
+        return out
+
+    def fullM(self):
+        M = np.zeros((NV, NV)); self.L.kpo_fullM(self.m, self.d, _dp(M)); return M
+
+    def solveM(self, x):
+        x = np.array(x, np.float64); self.L.kpo_solveM(self.m, self.d, _dp(x)); return x
+
+    def compute_torque(self, ctrl, target_qpos):
+        ctrl = np.ascontiguousarray(ctrl, np.float64); tq = np.ascontiguousarray(target_qpos, np.float64)
+        out = np.zeros(NU); self.L.kpo_compute_torque(self.m, self.d, _dp(ctrl), _dp(tq), _dp(out)); return out
+
+    def rfc_implicit(self, vf):
+        vf = np.ascontiguousarray(vf, np.float64); self.L.kpo_rfc_implicit(self.m, self.d, _dp(vf))
+
+    def do_simulation(self, action, target_qpos, n_frames=15):
+        a = np.ascontiguousarray(action, np.float64); tq = np.ascontiguousarray(target_qpos, np.float64)
+        self.L.kpo_do_simulation(self.m, self.d, _dp(a), _dp(tq), n_frames)
+
+    def contacts(self):
+        n = self.L.kpo_get_ncon(self.d)
+        body = np.zeros(64, np.int32); pos = np.zeros((64, 3)); dist = np.zeros(64)
+        self.L.kpo_get_contacts(self.d, body.ctypes.data_as(C.POINTER(C.c_int)), _dp(pos), _dp(dist))
+        return body[:n], pos[:n], dist[:n]
+
+    @property
+    def nefc(self):
+        return self.L.kpo_get_nefc(self.d)
+
+    @property
+    def niter(self):
+        return self.L.kpo_get_niter(self.d)
+
+    def rollout_batch(self, qpos, qvel, action, target, n_steps, n_frames=15):
+        """CPU-baseline driver: n envs sequentially on ONE core (the reference is one env per process)."""
+        qpos = np.ascontiguousarray(qpos, np.float64).copy(); qvel = np.ascontiguousarray(qvel, np.float64).copy()
+        a = np.ascontiguousarray(action, np.float64); t = np.ascontiguousarray(target, np.float64)
+        self.L.kpo_rollout_batch(self.m, qpos.shape[0], _dp(qpos), _dp(qvel), _dp(a), _dp(t), n_steps, n_frames)
+        return qpos, qvel
