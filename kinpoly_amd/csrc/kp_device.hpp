@@ -1,0 +1,131 @@
+// kp_device.hpp -- device-side math + the per-env LDS layout of the fused substep kernel (gfx950).
+//
+// One workgroup = one environment.  All per-env dynamics state lives in LDS for the whole control
+// step (15 substeps); HBM is touched only at kernel entry (qpos/qvel/action/target) and exit
+// (qpos/qvel + stale kinematics for the observation kernels).  Lanes map to bodies (24), dofs (75),
+// sparse-M entries (1221), hull vertices (<=64 per hull) or constraint rows depending on the phase.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace kp {
+
+constexpr int D_NB = 24, D_NV = 75, D_NQ = 76, D_NU = 69, D_NM = 1221, D_MAXDEPTH = 30;
+constexpr int D_MAXCON = 64;          // must equal MAXCON in oracle/kp_oracle.c
+constexpr int D_CON_PER_GEOM = 3;     // must equal CON_PER_GEOM in oracle/kp_oracle.c
+constexpr int D_NLEV = 9;             // body tree depth levels (Pelvis .. Hand)
+
+struct DevTables {
+    const float *body_pos, *body_ipos, *body_mass, *body_inertia, *body_rbound, *body_invw;
+    const float *dof_armature, *jnt_lo, *jnt_hi, *lim_invw;
+    const float *kp, *kd, *tlim, *ascale;
+    const float *verts;
+    const uint16_t *vert_adr, *dof_madr, *anc_madr;
+    const uint8_t *dof_depth, *dof_body, *dof_nsub, *m_row, *m_col, *anc_dof;
+    const int8_t *body_parent;
+    const uint8_t *body_depth, *body_subtree, *lev_start, *lev_body, *jnt_limited;
+};
+
+struct Params {
+    float h, gx, gy, gz;
+    float K, B;                                 // solref -> stiffness / damping of the reference acceleration
+    float imp_d0, imp_dw, imp_w, imp_mid, imp_pow;
+    float mu, margin;
+    float scale;                                // 1 / (meaninertia * nv)
+    float rfc_scale, rfc_lim;
+    float br_inv[4];                            // inverse(base_rot) as the reference computes it (conj / |q|^2)
+    float tol;
+    int max_iter, contact, limits, stale;
+};
+
+// ------------------------------------------------------------------ LDS layout (floats)
+struct __attribute__((aligned(16))) EnvLds {
+    float qpos[76], qvel[76], tq[76], act[76];
+    float xpos[72], xquat[96], xmat[216], xipos[72];
+    float cinert[240], crb[240];
+    float cdof[450];
+    float sv[144], sa[144], sw[144];
+    float f6[450];
+    float K[504];
+    float qM[1224], qLD[1224];
+    float diaginv[76];
+    float bias[76], smooth[76], qacc_s[76], qacc[76], grad[76], search[76], Mv[76], mres[76], warm[76], x[76];
+    float ctrl[72];
+    float applied[8];
+    float con_pos[D_MAXCON * 3], con_dist[D_MAXCON], con_D[D_MAXCON];
+    int con_body[D_MAXCON];
+    int con_start[D_NB + 1];
+    float aref[D_MAXCON * 4], jar[D_MAXCON * 4], jv[D_MAXCON * 4];
+    float lim_sgn[72], lim_aref[72], lim_D[72], lim_jar[72], lim_jv[72];
+    float red[16];
+    int ncon, nlim, flag;
+};
+
+// ------------------------------------------------------------------ small math
+struct V3 { float x, y, z; };
+struct Q4 { float w, x, y, z; };
+__device__ __forceinline__ V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 operator*(float s, V3 a) { return V3{s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+__device__ __forceinline__ V3 ld3(const float* p) { return V3{p[0], p[1], p[2]}; }
+__device__ __forceinline__ void st3(float* p, V3 a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; }
+__device__ __forceinline__ Q4 qmul(Q4 a, Q4 b) {
+    return Q4{a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+              a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x, a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
+}
+__device__ __forceinline__ Q4 qnormalize(Q4 q) {
+    float n = sqrtf(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+    if (n < 1e-15f) return Q4{1.f, 0.f, 0.f, 0.f};
+    float r = 1.0f / n;
+    return Q4{q.w * r, q.x * r, q.y * r, q.z * r};
+}
+__device__ __forceinline__ void q2mat(Q4 q, float* m) {
+    float w = q.w, x = q.x, y = q.y, z = q.z;
+    m[0] = w * w + x * x - y * y - z * z; m[1] = 2 * (x * y - w * z); m[2] = 2 * (x * z + w * y);
+    m[3] = 2 * (x * y + w * z); m[4] = w * w - x * x + y * y - z * z; m[5] = 2 * (y * z - w * x);
+    m[6] = 2 * (x * z - w * y); m[7] = 2 * (y * z + w * x); m[8] = w * w - x * x - y * y + z * z;
+}
+__device__ __forceinline__ V3 qrot(Q4 q, V3 v) {  // R(q) v for a unit quaternion
+    V3 u = v3(q.x, q.y, q.z);
+    V3 t = 2.0f * cross(u, v);
+    return v + q.w * t + cross(u, t);
+}
+__device__ __forceinline__ V3 mulmat(const float* m, V3 v) {
+    return V3{m[0] * v.x + m[1] * v.y + m[2] * v.z, m[3] * v.x + m[4] * v.y + m[5] * v.z, m[6] * v.x + m[7] * v.y + m[8] * v.z};
+}
+// spatial vectors are [ang(3); lin(3)] about the env's reference point o = root body origin
+struct S6 { V3 a, l; };
+__device__ __forceinline__ S6 lds6(const float* p) { return S6{ld3(p), ld3(p + 3)}; }
+__device__ __forceinline__ void sts6(float* p, S6 s) { st3(p, s.a); st3(p + 3, s.l); }
+__device__ __forceinline__ S6 operator+(S6 a, S6 b) { return S6{a.a + b.a, a.l + b.l}; }
+__device__ __forceinline__ S6 operator*(float s, S6 a) { return S6{s * a.a, s * a.l}; }
+__device__ __forceinline__ float dot6(S6 a, S6 b) { return dot(a.a, b.a) + dot(a.l, b.l); }
+__device__ __forceinline__ S6 cross_motion(S6 v, S6 s) { return S6{cross(v.a, s.a), cross(v.a, s.l) + cross(v.l, s.a)}; }
+__device__ __forceinline__ S6 cross_force(S6 v, S6 f) { return S6{cross(v.a, f.a) + cross(v.l, f.l), cross(v.a, f.l)}; }
+// inert = [Ixx Iyy Izz Ixy Ixz Iyz | h(3) = m r | m]
+__device__ __forceinline__ S6 inert_mul(const float* I, S6 v) {
+    V3 h = ld3(I + 6);
+    float m = I[9];
+    V3 Iw = V3{I[0] * v.a.x + I[3] * v.a.y + I[4] * v.a.z, I[3] * v.a.x + I[1] * v.a.y + I[5] * v.a.z,
+               I[4] * v.a.x + I[5] * v.a.y + I[2] * v.a.z};
+    return S6{Iw + cross(h, v.l), m * v.l - cross(h, v.a)};
+}
+// symmetric 6x6 (21 floats, row-major upper: (0,0)(0,1)..(0,5)(1,1)..) times 6-vector
+__device__ __forceinline__ int sym6_idx(int r, int c) { return r <= c ? r * 6 - r * (r - 1) / 2 + (c - r) : c * 6 - c * (c - 1) / 2 + (r - c); }
+
+__device__ __forceinline__ float impedance(const Params& P, float pos) {
+    float x = fabsf(pos) / P.imp_w;
+    if (x >= 1.0f) return P.imp_dw;
+    if (x <= 0.0f) return P.imp_d0;
+    float y;
+    if (P.imp_pow == 2.0f) y = x <= P.imp_mid ? x * x / P.imp_mid : 1.0f - (1.0f - x) * (1.0f - x) / (1.0f - P.imp_mid);
+    else if (P.imp_pow == 1.0f) y = x;
+    else y = x <= P.imp_mid ? powf(x, P.imp_pow) / powf(P.imp_mid, P.imp_pow - 1.0f)
+                            : 1.0f - powf(1.0f - x, P.imp_pow) / powf(1.0f - P.imp_mid, P.imp_pow - 1.0f);
+    return P.imp_d0 + y * (P.imp_dw - P.imp_d0);
+}
+
+}  // namespace kp

@@ -1,0 +1,202 @@
+// kp_obs_kernels.hpp -- the Python-side arithmetic of HumanoidAREnv.step() around the physics:
+//   k_step_kin     HumanoidAREnv.step_ar                kin_poly/envs/humanoid_ar_v1.py:216-241
+//   k_target_fk    Humanoid.qpos_fk / forward_kinematics kin_poly/utils/numpy_smpl_humanoid.py:180-249
+//   k_obs_cc       HumanoidEnv.get_full_obs_v1 (+ZFilter) uhc/envs/humanoid_im.py:144-233, zfilter.py:58-67
+//   k_bquat        HumanoidEnv.get_body_quat            uhc/envs/humanoid_im.py:342-354
+// Quaternion helpers restate uhc/khrylib/utils/math.py:102-198 and transformation.py (Gohlke).
+#pragma once
+#include "kp_device.hpp"
+
+namespace kp {
+
+// ---- reference quaternion helpers (w,x,y,z); these do NOT assume unit quaternions where the reference does not
+__device__ __forceinline__ Q4 q_inverse(Q4 q) {  // quaternion_inverse: conj / dot
+    float n = q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z;
+    return Q4{q.w / n, -q.x / n, -q.y / n, -q.z / n};
+}
+__device__ __forceinline__ void q_matrix(Q4 q, float* m) {  // quaternion_matrix: normalises by dot, identity if ~0
+    float n = q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z;
+    if (n < 8.881784197001252e-16f) { m[0] = m[4] = m[8] = 1.f; m[1] = m[2] = m[3] = m[5] = m[6] = m[7] = 0.f; return; }
+    float s = sqrtf(2.0f / n);
+    float w = q.w * s, x = q.x * s, y = q.y * s, z = q.z * s;
+    m[0] = 1.f - y * y - z * z; m[1] = x * y - z * w; m[2] = x * z + y * w;
+    m[3] = x * y + z * w; m[4] = 1.f - x * x - z * z; m[5] = y * z - x * w;
+    m[6] = x * z - y * w; m[7] = y * z + x * w; m[8] = 1.f - x * x - y * y;
+}
+__device__ __forceinline__ V3 q_mul_vec(Q4 q, V3 v) { float m[9]; q_matrix(q, m); return mulmat(m, v); }            // quat_mul_vec
+__device__ __forceinline__ V3 q_tmul_vec(Q4 q, V3 v) {                                                              // transform_vec(.., 'root')
+    float m[9]; q_matrix(q, m);
+    return V3{m[0] * v.x + m[3] * v.y + m[6] * v.z, m[1] * v.x + m[4] * v.y + m[7] * v.z, m[2] * v.x + m[5] * v.y + m[8] * v.z};
+}
+__device__ __forceinline__ Q4 q_heading(Q4 q) {  // get_heading_q
+    float n = sqrtf(q.w * q.w + q.z * q.z);
+    return Q4{q.w / n, 0.f, 0.f, q.z / n};
+}
+__device__ __forceinline__ float heading_angle(Q4 q) {  // get_heading
+    float w = q.w, z = q.z;
+    if (z < 0.f) { w = -w; z = -z; }
+    float n = sqrtf(w * w + z * z);
+    return 2.0f * acosf(fminf(1.0f, fmaxf(-1.0f, w / n)));
+}
+__device__ __forceinline__ Q4 q_from_expmap(V3 e) {  // quat_from_expmap + quaternion_about_axis
+    float angle = sqrtf(dot(e, e));
+    V3 axis = angle < 1e-12f ? v3(1.f, 0.f, 0.f) : (1.0f / angle) * e;
+    float sn, cs; sincosf(0.5f * angle, &sn, &cs);
+    float ql = sqrtf(dot(axis, axis));
+    float k = ql > 8.881784197001252e-16f ? sn / ql : 1.0f;
+    return Q4{cs, axis.x * k, axis.y * k, axis.z * k};
+}
+// local hinge rotation: Gohlke quaternion_from_euler(tz, ty, tx, 'rzyx') = qz (x) qy (x) qx
+__device__ __forceinline__ Q4 q_euler_rzyx(float tz, float ty, float tx) {
+    float sz, cz, sy, cy, sx, cx;
+    sincosf(0.5f * tz, &sz, &cz); sincosf(0.5f * ty, &sy, &cy); sincosf(0.5f * tx, &sx, &cx);
+    return qmul(qmul(Q4{cz, 0.f, 0.f, sz}, Q4{cy, 0.f, sy, 0.f}), Q4{cx, sx, 0.f, 0.f});
+}
+// the reference's "bquat" quirk: quaternion_from_euler(a0, a1, a2) with default 'sxyz' on (tz, ty, tx)
+__device__ __forceinline__ Q4 q_euler_sxyz(float ai, float aj, float ak) {
+    float si, ci, sj, cj, sk, ck;
+    sincosf(0.5f * ai, &si, &ci); sincosf(0.5f * aj, &sj, &cj); sincosf(0.5f * ak, &sk, &ck);
+    float cc = ci * ck, cs = ci * sk, sc = si * ck, ss = si * sk;
+    return Q4{cj * cc + sj * ss, cj * sc - sj * cs, cj * ss + sj * cc, cj * cs - sj * sc};
+}
+
+// ---------------------------------------------------------------- step_ar: one thread per env
+__global__ void k_step_kin(int n, const float* __restrict__ qpos, const float* __restrict__ act, float* __restrict__ next_qpos, float dt) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const float* q = qpos + (size_t)e * D_NQ;
+    const float* a = act + (size_t)e * 80;
+    float* o = next_qpos + (size_t)e * D_NQ;
+    Q4 rot = Q4{q[3], q[4], q[5], q[6]};
+    Q4 hq = q_heading(rot);
+    V3 linv = q_mul_vec(hq, v3(a[74], a[75], a[76]));
+    o[0] = q[0] + linv.x * dt; o[1] = q[1] + linv.y * dt;
+    o[2] = a[0];
+    V3 angv = q_mul_vec(rot, v3(a[77], a[78], a[79]));
+    Q4 nr = qmul(q_from_expmap(dt * angv), rot);
+    o[3] = nr.w; o[4] = nr.x; o[5] = nr.y; o[6] = nr.z;
+    for (int j = 0; j < D_NU; j++) o[7 + j] = a[5 + j];
+}
+
+// ---------------------------------------------------------------- target FK: one thread per env (24-body chain in registers/scratch)
+struct TargetBufs { float *qpos, *wbpos, *wbquat, *bquat, *com; };
+__global__ void k_target_fk(int n, const float* __restrict__ tq, const uint8_t* __restrict__ mask, TargetBufs B,
+                            const float* __restrict__ body_pos, const float* __restrict__ body_ipos, const int8_t* __restrict__ parent) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    if (mask && !mask[e]) return;
+    const float* q = tq + (size_t)e * D_NQ;
+    float* oq = B.qpos + (size_t)e * D_NQ;
+    float wq[D_NB][4], wp[D_NB][3];
+    Q4 rq = Q4{q[3], q[4], q[5], q[6]};
+    float rn = sqrtf(rq.w * rq.w + rq.x * rq.x + rq.y * rq.y + rq.z * rq.z);
+    rq = Q4{rq.w / rn, rq.x / rn, rq.y / rn, rq.z / rn};  // fix_quat: root_rotations /= norm (no zero guard in the reference)
+    for (int i = 0; i < D_NQ; i++) oq[i] = q[i];
+    oq[3] = rq.w; oq[4] = rq.x; oq[5] = rq.y; oq[6] = rq.z;
+    for (int b = 0; b < D_NB; b++) {
+        Q4 wqb; V3 pos;
+        float* obq = B.bquat + (size_t)e * 96 + 4 * b;
+        if (b == 0) {
+            wqb = rq; pos = v3(q[0], q[1], q[2]);
+            obq[0] = rq.w; obq[1] = rq.x; obq[2] = rq.y; obq[3] = rq.z;
+        } else {
+            int p = parent[b];
+            const float* ang = q + 7 + 3 * (b - 1);
+            Q4 pq = Q4{wq[p][0], wq[p][1], wq[p][2], wq[p][3]};
+            pos = q_mul_vec(pq, ld3(body_pos + 3 * b)) + v3(wp[p][0], wp[p][1], wp[p][2]);
+            wqb = qmul(pq, q_euler_rzyx(ang[0], ang[1], ang[2]));
+            Q4 bq = q_euler_sxyz(ang[0], ang[1], ang[2]);
+            obq[0] = bq.w; obq[1] = bq.x; obq[2] = bq.y; obq[3] = bq.z;
+        }
+        wq[b][0] = wqb.w; wq[b][1] = wqb.x; wq[b][2] = wqb.y; wq[b][3] = wqb.z;
+        wp[b][0] = pos.x; wp[b][1] = pos.y; wp[b][2] = pos.z;
+        st3(B.wbpos + (size_t)e * 72 + 3 * b, pos);
+        float* owq = B.wbquat + (size_t)e * 96 + 4 * b;
+        owq[0] = wqb.w; owq[1] = wqb.x; owq[2] = wqb.y; owq[3] = wqb.z;
+        st3(B.com + (size_t)e * 72 + 3 * b, q_mul_vec(wqb, ld3(body_ipos + 3 * b)) + pos);
+    }
+}
+
+// ---------------------------------------------------------------- get_body_quat: thread per (env, body)
+__global__ void k_bquat(int n, const float* __restrict__ qpos, float* __restrict__ out) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * D_NB) return;
+    int e = t / D_NB, b = t - e * D_NB;
+    const float* q = qpos + (size_t)e * D_NQ;
+    Q4 r;
+    if (b == 0) r = Q4{q[3], q[4], q[5], q[6]};
+    else r = q_euler_sxyz(q[7 + 3 * (b - 1)], q[8 + 3 * (b - 1)], q[9 + 3 * (b - 1)]);
+    float* o = out + (size_t)t * 4;
+    o[0] = r.w; o[1] = r.x; o[2] = r.y; o[3] = r.z;
+}
+
+// ---------------------------------------------------------------- get_full_obs_v1 (+ ZFilter): one wave per env, staged in LDS
+struct ObsCcArgs {
+    int n;
+    const float *qpos, *qvel, *xpos, *xquat, *xipos;   // sim state (qpos/qvel fresh, x* stale)
+    const float *t_qpos, *t_wbpos, *t_wbquat, *t_com;  // target dict
+    float br_inv[4];
+    const float *zf_mean, *zf_std; float clip;
+    float* out;
+};
+__global__ __launch_bounds__(64) void k_obs_cc(ObsCcArgs A) {
+    __shared__ float ob[784];
+    const int e = blockIdx.x, tid = threadIdx.x;
+    if (e >= A.n) return;
+    const float* qpos = A.qpos + (size_t)e * D_NQ;
+    const float* qvel = A.qvel + (size_t)e * D_NV;
+    const float* tq = A.t_qpos + (size_t)e * D_NQ;
+    const Q4 rq = Q4{qpos[3], qpos[4], qpos[5], qpos[6]};
+    const Q4 binv = Q4{A.br_inv[0], A.br_inv[1], A.br_inv[2], A.br_inv[3]};
+    const Q4 crq = qmul(rq, binv);                      // remove_base_rot
+    const Q4 hq = q_heading(crq);
+    const Q4 trq = qmul(Q4{tq[3], tq[4], tq[5], tq[6]}, binv);
+    const V3 root = v3(qpos[0], qpos[1], qpos[2]);
+    if (tid == 0) {
+        ob[0] = hq.w; ob[1] = hq.x; ob[2] = hq.y; ob[3] = hq.z;
+        Q4 dh = qmul(q_inverse(hq), crq);               // de_heading(curr_root_quat)
+        ob[78] = qpos[2]; ob[79] = dh.w; ob[80] = dh.x; ob[81] = dh.y; ob[82] = dh.z;
+        Q4 dq = qmul(trq, q_inverse(crq));
+        ob[152] = tq[2] - qpos[2]; ob[153] = dq.w; ob[154] = dq.x; ob[155] = dq.y; ob[156] = dq.z;
+        V3 v = q_tmul_vec(crq, q_tmul_vec(rq, v3(qvel[0], qvel[1], qvel[2])));  // transformed twice (:150, :173)
+        ob[226] = v.x; ob[227] = v.y; ob[228] = v.z;
+        float rel_h = heading_angle(trq) - heading_angle(crq);
+        if (rel_h > 3.14159265358979f) rel_h -= 6.28318530717959f;
+        if (rel_h < -3.14159265358979f) rel_h += 6.28318530717959f;
+        ob[301] = rel_h;
+        V3 rp = q_tmul_vec(crq, v3(trq.w, trq.x, trq.y) - root);  // sic: quaternion components used as a position (:187)
+        ob[302] = rp.x; ob[303] = rp.y;
+    }
+    for (int i = tid; i < 74; i += 64) ob[4 + i] = tq[2 + i];
+    for (int i = tid; i < 69; i += 64) { ob[83 + i] = qpos[7 + i]; ob[157 + i] = tq[7 + i] - qpos[7 + i]; }
+    for (int i = tid; i < 72; i += 64) ob[229 + i] = qvel[3 + i];
+    if (tid < D_NB) {
+        const int b = tid;
+        const float* xp = A.xpos + (size_t)e * 72 + 3 * b;
+        const float* xi = A.xipos + (size_t)e * 72 + 3 * b;
+        const float* xq = A.xquat + (size_t)e * 96;
+        V3 cj = ld3(xp), ci = ld3(xi);
+        V3 tj = ld3(A.t_wbpos + (size_t)e * 72 + 3 * b), tc = ld3(A.t_com + (size_t)e * 72 + 3 * b);
+        st3(ob + 304 + 3 * b, q_tmul_vec(crq, cj - root));
+        st3(ob + 376 + 3 * b, q_tmul_vec(crq, tj - cj));
+        st3(ob + 448 + 3 * b, q_tmul_vec(crq, ci - root));
+        st3(ob + 520 + 3 * b, q_tmul_vec(crq, tc - ci));
+        const float* twq = A.t_wbquat + (size_t)e * 96 + 4 * b;
+        Q4 tqt = Q4{twq[0], twq[1], twq[2], twq[3]};
+        Q4 cq = (xq[0] == 0.f) ? tqt : Q4{xq[4 * b], xq[4 * b + 1], xq[4 * b + 2], xq[4 * b + 3]};
+        Q4 r1 = qmul(q_inverse(hq), cq), r2 = qmul(q_inverse(cq), tqt);
+        float* o1 = ob + 592 + 4 * b; o1[0] = r1.w; o1[1] = r1.x; o1[2] = r1.y; o1[3] = r1.z;
+        float* o2 = ob + 688 + 4 * b; o2[0] = r2.w; o2[1] = r2.x; o2[2] = r2.y; o2[3] = r2.z;
+    }
+    __syncthreads();
+    for (int i = tid; i < 784; i += 64) {
+        float v = ob[i];
+        if (A.zf_mean) {
+            v = (v - A.zf_mean[i]) / (A.zf_std[i] + 1e-8f);
+            if (A.clip > 0.f) v = fminf(fmaxf(v, -A.clip), A.clip);
+        }
+        A.out[(size_t)e * 784 + i] = v;
+    }
+}
+
+}  // namespace kp

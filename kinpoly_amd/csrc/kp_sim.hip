@@ -1,0 +1,355 @@
+// kp_sim.hip -- host side of libkinpoly_sim.so: model upload, per-env state buffers, kernel launches,
+// and the extern "C" entry points declared in include/kinpoly_sim.h.  No torch types anywhere.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/kinpoly_sim.h"
+#include "kp_model.hpp"
+#include "kp_obs_kernels.hpp"
+#include "kp_step_kernel.hpp"
+
+namespace {
+thread_local std::string g_err;
+int fail(const std::string& m) { g_err = m; return -1; }
+#define HIP_OK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+#define HIP_OK_NULL(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fail(std::string(#expr) + ": " + hipGetErrorString(e_)); return nullptr; } } while (0)
+}  // namespace
+
+struct kp_model {
+    kp::HostModel h;
+    int contact = 1, limits = 1, stale = 1, solver_iter = 12, threads = 64;
+    double solver_tol = 1e-6, gravity_z = -9.81;
+};
+
+struct kp_sim {
+    const kp_model* model = nullptr;
+    int n = 0, device = 0;
+    hipStream_t stream = nullptr;
+    std::vector<void*> allocs;
+    kp::DevTables T{};
+    kp::Params P{};
+    float *qpos = nullptr, *qvel = nullptr, *qpos_d = nullptr, *qvel_d = nullptr, *warm = nullptr;
+    float *xpos = nullptr, *xquat = nullptr, *xipos = nullptr, *scratch = nullptr;
+    float *t_qpos = nullptr, *t_wbpos = nullptr, *t_wbquat = nullptr, *t_bquat = nullptr, *t_com = nullptr;
+    int* diag = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+};
+
+namespace {
+
+template <typename T, typename S>
+const T* upload(kp_sim* s, const std::vector<S>& src, bool* ok) {
+    std::vector<T> tmp(src.size());
+    for (size_t i = 0; i < src.size(); i++) tmp[i] = (T)src[i];
+    void* d = nullptr;
+    if (hipMalloc(&d, std::max<size_t>(sizeof(T) * tmp.size(), 16)) != hipSuccess) { *ok = false; return nullptr; }
+    s->allocs.push_back(d);
+    if (hipMemcpy(d, tmp.data(), sizeof(T) * tmp.size(), hipMemcpyHostToDevice) != hipSuccess) { *ok = false; return nullptr; }
+    return (const T*)d;
+}
+
+float* dalloc(kp_sim* s, size_t count, bool* ok) {
+    void* d = nullptr;
+    if (hipMalloc(&d, sizeof(float) * count) != hipSuccess) { *ok = false; return nullptr; }
+    s->allocs.push_back(d);
+    hipMemset(d, 0, sizeof(float) * count);
+    return (float*)d;
+}
+
+bool build_tables(kp_sim* s) {
+    const kp::HostModel& m = s->model->h;
+    using namespace kp;
+    bool ok = true;
+    auto& T = s->T;
+    T.body_pos = upload<float>(s, m.body_pos, &ok); T.body_ipos = upload<float>(s, m.body_ipos, &ok);
+    T.body_mass = upload<float>(s, m.body_mass, &ok); T.body_inertia = upload<float>(s, m.body_inertia, &ok);
+    T.body_rbound = upload<float>(s, m.body_rbound, &ok);
+    std::vector<double> invw(NB), liminvw(NU), lo(NU), hi(NU);
+    for (int b = 0; b < NB; b++) invw[b] = m.body_invweight0[2 * b];
+    for (int j = 0; j < NU; j++) { liminvw[j] = m.dof_invweight0[6 + j]; lo[j] = m.jnt_range[2 * j]; hi[j] = m.jnt_range[2 * j + 1]; }
+    T.body_invw = upload<float>(s, invw, &ok); T.lim_invw = upload<float>(s, liminvw, &ok);
+    T.jnt_lo = upload<float>(s, lo, &ok); T.jnt_hi = upload<float>(s, hi, &ok);
+    T.dof_armature = upload<float>(s, m.dof_armature, &ok);
+    T.kp = upload<float>(s, m.kp, &ok); T.kd = upload<float>(s, m.kd, &ok); T.tlim = upload<float>(s, m.torque_lim, &ok);
+    T.ascale = upload<float>(s, m.a_scale, &ok);
+    T.verts = upload<float>(s, m.verts, &ok);
+    T.vert_adr = upload<uint16_t>(s, m.vert_adr, &ok); T.dof_madr = upload<uint16_t>(s, m.dof_madr, &ok);
+    T.dof_depth = upload<uint8_t>(s, m.dof_depth, &ok); T.dof_body = upload<uint8_t>(s, m.dof_body, &ok);
+    T.body_parent = upload<int8_t>(s, m.body_parent, &ok); T.body_depth = upload<uint8_t>(s, m.body_depth, &ok);
+    T.body_subtree = upload<uint8_t>(s, m.body_subtree, &ok); T.jnt_limited = upload<uint8_t>(s, m.jnt_limited, &ok);
+    // ancestor tables: a-th ancestor (a = 0 is the dof itself) of every dof, as dof id and as qM address
+    std::vector<int> anc_madr(NV * MAXDEPTH, 0), anc_dof(NV * MAXDEPTH, 0), m_row(NM), m_col(NM), nsub(NV, 0);
+    for (int k = 0; k < NV; k++) {
+        int a = 0;
+        for (int j = k; j >= 0; j = m.dof_parent[j], a++) {
+            anc_madr[k * MAXDEPTH + a] = m.dof_madr[j]; anc_dof[k * MAXDEPTH + a] = j;
+            m_row[m.dof_madr[k] + a] = k; m_col[m.dof_madr[k] + a] = j;
+            if (j != k) nsub[j]++;
+        }
+    }
+    for (int j = 0; j < NV; j++)  // descendants of a dof must be the contiguous range (j, j+nsub]
+        for (int i = j + 1; i <= j + nsub[j]; i++) {
+            bool desc = false;
+            for (int p = m.dof_parent[i]; p >= 0; p = m.dof_parent[p]) if (p == j) desc = true;
+            if (!desc) return false;
+        }
+    T.anc_madr = upload<uint16_t>(s, anc_madr, &ok); T.anc_dof = upload<uint8_t>(s, anc_dof, &ok);
+    T.m_row = upload<uint8_t>(s, m_row, &ok); T.m_col = upload<uint8_t>(s, m_col, &ok); T.dof_nsub = upload<uint8_t>(s, nsub, &ok);
+    std::vector<int> lev_start(D_NLEV + 2, 0), lev_body;
+    for (int lev = 0; lev <= D_NLEV; lev++) {
+        lev_start[lev] = (int)lev_body.size();
+        for (int b = 0; b < NB; b++) if (m.body_depth[b] == lev) lev_body.push_back(b);
+    }
+    lev_start[D_NLEV + 1] = (int)lev_body.size();
+    if ((int)lev_body.size() != NB || lev_start[D_NLEV] != NB) return false;  // tree deeper than D_NLEV levels
+    T.lev_start = upload<uint8_t>(s, lev_start, &ok); T.lev_body = upload<uint8_t>(s, lev_body, &ok);
+    // scalar parameters
+    auto& P = s->P;
+    const auto& o = m.opt;
+    auto clampimp = [](double v) { return std::min(0.9999, std::max(0.0001, v)); };
+    P.h = (float)o[OPT_TIMESTEP]; P.gx = (float)o[OPT_GX]; P.gy = (float)o[OPT_GY]; P.gz = (float)s->model->gravity_z;
+    double tc = std::max(o[OPT_SOLREF_TC], 2 * o[OPT_TIMESTEP]), dr = o[OPT_SOLREF_DR], dmax = clampimp(o[OPT_IMP_DW]);
+    P.K = (float)(1.0 / (dmax * dmax * tc * tc * dr * dr)); P.B = (float)(2.0 / (dmax * tc));
+    P.imp_d0 = (float)clampimp(o[OPT_IMP_D0]); P.imp_dw = (float)dmax; P.imp_w = (float)o[OPT_IMP_W];
+    P.imp_mid = (float)clampimp(o[OPT_IMP_MID]); P.imp_pow = (float)std::max(1.0, o[OPT_IMP_POW]);
+    P.mu = (float)o[OPT_FRIC]; P.margin = (float)o[OPT_MARGIN];
+    P.scale = (float)(1.0 / (o[OPT_MEANINERTIA] * NV));
+    P.rfc_scale = (float)o[OPT_RFC_SCALE]; P.rfc_lim = (float)o[OPT_RFC_LIM];
+    double bn = o[OPT_BR_W] * o[OPT_BR_W] + o[OPT_BR_X] * o[OPT_BR_X] + o[OPT_BR_Y] * o[OPT_BR_Y] + o[OPT_BR_Z] * o[OPT_BR_Z];
+    P.br_inv[0] = (float)(o[OPT_BR_W] / bn); P.br_inv[1] = (float)(-o[OPT_BR_X] / bn);
+    P.br_inv[2] = (float)(-o[OPT_BR_Y] / bn); P.br_inv[3] = (float)(-o[OPT_BR_Z] / bn);
+    P.tol = (float)s->model->solver_tol; P.max_iter = s->model->solver_iter;
+    P.contact = s->model->contact; P.limits = s->model->limits; P.stale = s->model->stale;
+    return ok;
+}
+
+int launch_step(kp_sim* s, const float* action, int nsub, const uint8_t* mask, bool time_it) {
+    kp::StepArgs A;
+    A.T = s->T; A.P = s->P; A.n_envs = s->n; A.n_substeps = nsub;
+    A.qpos = s->qpos; A.qvel = s->qvel; A.qpos_d = s->qpos_d; A.qvel_d = s->qvel_d; A.warm = s->warm;
+    A.target_qpos = s->t_qpos; A.action = action; A.env_mask = mask;
+    A.xpos = s->xpos; A.xquat = s->xquat; A.xipos = s->xipos; A.diag = s->diag;
+    size_t lds = sizeof(kp::EnvLds);
+    if (time_it) HIP_OK(hipEventRecord(s->ev0, s->stream));
+    switch (s->model->threads) {
+        case 64: hipLaunchKernelGGL(kp::kp_step_kernel<64>, dim3(s->n), dim3(64), lds, s->stream, A); break;
+        case 128: hipLaunchKernelGGL(kp::kp_step_kernel<128>, dim3(s->n), dim3(128), lds, s->stream, A); break;
+        case 256: hipLaunchKernelGGL(kp::kp_step_kernel<256>, dim3(s->n), dim3(256), lds, s->stream, A); break;
+        default: return fail("threads_per_env must be 64, 128 or 256");
+    }
+    HIP_OK(hipGetLastError());
+    if (time_it) { HIP_OK(hipEventRecord(s->ev1, s->stream)); s->timed = true; }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* kp_last_error(void) { return g_err.c_str(); }
+const char* kp_version(void) { return "kinpoly_sim 0.1 (gfx950)"; }
+
+kp_model* kp_model_load(const char* path) {
+    kp_model* m = new kp_model();
+    if (!kp::load_kpm(path, m->h)) { fail("kp_model_load: " + m->h.error); delete m; return nullptr; }
+    m->gravity_z = m->h.opt[kp::OPT_GZ];
+    return m;
+}
+void kp_model_free(kp_model* m) { delete m; }
+
+int kp_model_set_option(kp_model* m, const char* name, double v) {
+    if (!m || !name) return fail("kp_model_set_option: null argument");
+    std::string k(name);
+    if (k == "contact") m->contact = v != 0;
+    else if (k == "limits") m->limits = v != 0;
+    else if (k == "gravity_z") m->gravity_z = v;
+    else if (k == "stale_kinematics") m->stale = v != 0;
+    else if (k == "solver_iter") m->solver_iter = (int)v;
+    else if (k == "solver_tol") m->solver_tol = v;
+    else if (k == "threads_per_env") { if (v != 64 && v != 128 && v != 256) return fail("threads_per_env must be 64, 128 or 256"); m->threads = (int)v; }
+    else return fail("kp_model_set_option: unknown option " + k);
+    return 0;
+}
+double kp_model_get_option(const kp_model* m, const char* name) {
+    std::string k(name ? name : "");
+    if (!m) return NAN;
+    if (k == "contact") return m->contact;
+    if (k == "limits") return m->limits;
+    if (k == "gravity_z") return m->gravity_z;
+    if (k == "stale_kinematics") return m->stale;
+    if (k == "solver_iter") return m->solver_iter;
+    if (k == "solver_tol") return m->solver_tol;
+    if (k == "threads_per_env") return m->threads;
+    if (k == "timestep") return m->h.opt[kp::OPT_TIMESTEP];
+    if (k == "lds_bytes_per_env") return (double)sizeof(kp::EnvLds);
+    return NAN;
+}
+
+kp_sim* kp_sim_create(const kp_model* m, int n_envs, int device_id, void* stream) {
+    if (!m || n_envs <= 0) { fail("kp_sim_create: bad arguments"); return nullptr; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { fail("kp_sim_create: no HIP device available (the simulator has no CPU fallback)"); return nullptr; }
+    HIP_OK_NULL(hipSetDevice(device_id));
+    kp_sim* s = new kp_sim();
+    s->model = m; s->n = n_envs; s->device = device_id; s->stream = (hipStream_t)stream;
+    bool ok = build_tables(s);
+    size_t N = n_envs;
+    s->qpos = dalloc(s, N * 76, &ok); s->qvel = dalloc(s, N * 75, &ok); s->qpos_d = dalloc(s, N * 76, &ok);
+    s->qvel_d = dalloc(s, N * 75, &ok); s->warm = dalloc(s, N * 75, &ok);
+    s->xpos = dalloc(s, N * 72, &ok); s->xquat = dalloc(s, N * 96, &ok); s->xipos = dalloc(s, N * 72, &ok);
+    s->t_qpos = dalloc(s, N * 76, &ok); s->t_wbpos = dalloc(s, N * 72, &ok); s->t_wbquat = dalloc(s, N * 96, &ok);
+    s->t_bquat = dalloc(s, N * 96, &ok); s->t_com = dalloc(s, N * 72, &ok);
+    s->scratch = dalloc(s, N * 96, &ok);
+    s->diag = (int*)dalloc(s, N * 4, &ok);
+    if (!ok || hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) {
+        fail("kp_sim_create: device allocation / table build failed");
+        kp_sim_destroy(s);
+        return nullptr;
+    }
+    return s;
+}
+
+void kp_sim_destroy(kp_sim* s) {
+    if (!s) return;
+    hipSetDevice(s->device);
+    hipStreamSynchronize(s->stream);
+    for (void* p : s->allocs) hipFree(p);
+    if (s->ev0) hipEventDestroy(s->ev0);
+    if (s->ev1) hipEventDestroy(s->ev1);
+    delete s;
+}
+int kp_sim_n_envs(const kp_sim* s) { return s ? s->n : -1; }
+
+// masked row copy kernel (set_state writes only the masked envs)
+__global__ void k_copy_rows(int n, int dim, const float* __restrict__ src, float* __restrict__ dst, float* __restrict__ dst2,
+                            const uint8_t* __restrict__ mask) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)n * dim) return;
+    int e = (int)(t / dim);
+    if (mask && !mask[e]) return;
+    float v = src ? src[t] : 0.f;
+    dst[t] = v;
+    if (dst2) dst2[t] = v;
+}
+
+int kp_sim_set_state(kp_sim* s, const float* qpos, const float* qvel, const uint8_t* mask) {
+    if (!s || !qpos || !qvel) return fail("kp_sim_set_state: null argument");
+    HIP_OK(hipSetDevice(s->device));
+    int n = s->n;
+    hipLaunchKernelGGL(k_copy_rows, dim3((n * 76 + 255) / 256), dim3(256), 0, s->stream, n, 76, qpos, s->qpos, s->qpos_d, mask);
+    hipLaunchKernelGGL(k_copy_rows, dim3((n * 75 + 255) / 256), dim3(256), 0, s->stream, n, 75, qvel, s->qvel, s->qvel_d, mask);
+    hipLaunchKernelGGL(k_copy_rows, dim3((n * 75 + 255) / 256), dim3(256), 0, s->stream, n, 75, (const float*)nullptr, s->warm, (float*)nullptr, mask);
+    HIP_OK(hipGetLastError());
+    return launch_step(s, nullptr, 0, mask, false);  // sim.forward(): derived quantities at the new state
+}
+
+int kp_sim_set_target(kp_sim* s, const float* tq, const uint8_t* mask) {
+    if (!s || !tq) return fail("kp_sim_set_target: null argument");
+    HIP_OK(hipSetDevice(s->device));
+    kp::TargetBufs B{s->t_qpos, s->t_wbpos, s->t_wbquat, s->t_bquat, s->t_com};
+    hipLaunchKernelGGL(kp::k_target_fk, dim3((s->n + 63) / 64), dim3(64), 0, s->stream, s->n, tq, mask, B, s->T.body_pos, s->T.body_ipos, s->T.body_parent);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int kp_sim_step_ctrl(kp_sim* s, const float* action, int nsub, const uint8_t* mask) {
+    if (!s || !action || nsub <= 0) return fail("kp_sim_step_ctrl: bad arguments");
+    HIP_OK(hipSetDevice(s->device));
+    return launch_step(s, action, nsub, mask, true);
+}
+
+int kp_sim_step_kin(kp_sim* s, const float* act, float* next_qpos) {
+    if (!s || !act || !next_qpos) return fail("kp_sim_step_kin: null argument");
+    HIP_OK(hipSetDevice(s->device));
+    hipLaunchKernelGGL(kp::k_step_kin, dim3((s->n + 63) / 64), dim3(64), 0, s->stream, s->n, s->qpos, act, next_qpos, 1.0f / 30.0f);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int kp_sim_obs_cc(kp_sim* s, float* out, const float* zf_mean, const float* zf_std, float clip) {
+    if (!s || !out) return fail("kp_sim_obs_cc: null argument");
+    if ((zf_mean == nullptr) != (zf_std == nullptr)) return fail("kp_sim_obs_cc: pass both zf_mean and zf_std or neither");
+    HIP_OK(hipSetDevice(s->device));
+    kp::ObsCcArgs A;
+    A.n = s->n; A.qpos = s->qpos; A.qvel = s->qvel; A.xpos = s->xpos; A.xquat = s->xquat; A.xipos = s->xipos;
+    A.t_qpos = s->t_qpos; A.t_wbpos = s->t_wbpos; A.t_wbquat = s->t_wbquat; A.t_com = s->t_com;
+    for (int k = 0; k < 4; k++) A.br_inv[k] = s->P.br_inv[k];
+    A.zf_mean = zf_mean; A.zf_std = zf_std; A.clip = clip; A.out = out;
+    hipLaunchKernelGGL(kp::k_obs_cc, dim3(s->n), dim3(64), 0, s->stream, A);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int kp_field_dim(int f) {
+    switch (f) {
+        case KP_QPOS: case KP_TARGET_QPOS: case KP_QPOS_D: return 76;
+        case KP_QVEL: case KP_QVEL_D: return 75;
+        case KP_XPOS: case KP_XIPOS: case KP_TARGET_WBPOS: case KP_TARGET_COM: return 72;
+        case KP_XQUAT: case KP_BQUAT: case KP_TARGET_WBQUAT: case KP_TARGET_BQUAT: return 96;
+        case KP_HEAD: return 7;
+        default: return -1;
+    }
+}
+
+__global__ void k_head(int n, const float* __restrict__ xpos, const float* __restrict__ xquat, float* __restrict__ out) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const int hb = 13;  // Head (model._body_name2id['Head'] - 1)
+    for (int k = 0; k < 3; k++) out[(size_t)e * 7 + k] = xpos[(size_t)e * 72 + 3 * hb + k];
+    for (int k = 0; k < 4; k++) out[(size_t)e * 7 + 3 + k] = xquat[(size_t)e * 96 + 4 * hb + k];
+}
+
+int kp_sim_get(kp_sim* s, int field, float* out) {
+    if (!s || !out) return fail("kp_sim_get: null argument");
+    HIP_OK(hipSetDevice(s->device));
+    const float* src = nullptr;
+    switch (field) {
+        case KP_QPOS: src = s->qpos; break;
+        case KP_QVEL: src = s->qvel; break;
+        case KP_XPOS: src = s->xpos; break;
+        case KP_XQUAT: src = s->xquat; break;
+        case KP_XIPOS: src = s->xipos; break;
+        case KP_TARGET_QPOS: src = s->t_qpos; break;
+        case KP_TARGET_WBPOS: src = s->t_wbpos; break;
+        case KP_TARGET_WBQUAT: src = s->t_wbquat; break;
+        case KP_TARGET_BQUAT: src = s->t_bquat; break;
+        case KP_TARGET_COM: src = s->t_com; break;
+        case KP_QPOS_D: src = s->qpos_d; break;
+        case KP_QVEL_D: src = s->qvel_d; break;
+        case KP_BQUAT:
+            hipLaunchKernelGGL(kp::k_bquat, dim3((s->n * 24 + 255) / 256), dim3(256), 0, s->stream, s->n, s->qpos, out);
+            HIP_OK(hipGetLastError());
+            return 0;
+        case KP_HEAD:
+            hipLaunchKernelGGL(k_head, dim3((s->n + 255) / 256), dim3(256), 0, s->stream, s->n, s->xpos, s->xquat, out);
+            HIP_OK(hipGetLastError());
+            return 0;
+        default: return fail("kp_sim_get: unknown field");
+    }
+    HIP_OK(hipMemcpyAsync(out, src, sizeof(float) * (size_t)s->n * kp_field_dim(field), hipMemcpyDeviceToDevice, s->stream));
+    return 0;
+}
+
+int kp_sim_diag(kp_sim* s, int32_t* out_host) {
+    if (!s || !out_host) return fail("kp_sim_diag: null argument");
+    HIP_OK(hipSetDevice(s->device));
+    HIP_OK(hipStreamSynchronize(s->stream));
+    HIP_OK(hipMemcpy(out_host, s->diag, sizeof(int) * 4 * (size_t)s->n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+double kp_sim_last_step_seconds(kp_sim* s) {
+    if (!s || !s->timed) return -1.0;
+    if (hipEventSynchronize(s->ev1) != hipSuccess) return -1.0;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, s->ev0, s->ev1) != hipSuccess) return -1.0;
+    return ms * 1e-3;
+}
+
+}  // extern "C"

@@ -1,0 +1,173 @@
+"""ctypes binding of libkinpoly_sim.so (include/kinpoly_sim.h) for torch device tensors.
+
+This is the thin host layer: tensors in, tensors out, every call enqueued on torch's current
+HIP stream.  There is NO CPU fallback: if the extension or a HIP device is missing, construction
+fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+from . import build as _build
+
+NQ, NV, NU, NBODY = 76, 75, 69, 24
+CC_OBS_DIM, AR_OBS_DIM, KIN_ACTION_DIM, CC_ACTION_DIM = 784, 105, 80, 75
+DEFAULT_KPM = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets", "smpl_humanoid.kpm")
+
+FIELDS = dict(qpos=0, qvel=1, xpos=2, xquat=3, xipos=4, bquat=5, head=6, target_qpos=7, target_wbpos=8,
+              target_wbquat=9, target_bquat=10, target_com=11, qpos_d=12, qvel_d=13)
+
+_lib = None
+
+# every symbol include/kinpoly_sim.h declares (tests check the .so exports all of them)
+ABI_SYMBOLS = [
+    "kp_model_load", "kp_model_free", "kp_model_set_option", "kp_model_get_option", "kp_sim_create", "kp_sim_destroy",
+    "kp_sim_n_envs", "kp_sim_set_state", "kp_sim_set_target", "kp_sim_step_ctrl", "kp_sim_step_kin", "kp_sim_obs_cc",
+    "kp_field_dim", "kp_sim_get", "kp_sim_diag", "kp_sim_last_step_seconds", "kp_last_error", "kp_version",
+]
+
+
+class KinPolyNativeError(RuntimeError):
+    pass
+
+
+def load_library(path: str | None = None):
+    """dlopen the in-tree extension (never builds implicitly on a GPU box: the .so must be there)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = path or _build.LIB
+    if not os.path.exists(path):
+        raise KinPolyNativeError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                 "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    L = C.CDLL(path)
+    P, F, U8 = C.c_void_p, C.c_void_p, C.c_void_p
+    L.kp_model_load.restype = P; L.kp_model_load.argtypes = [C.c_char_p]
+    L.kp_model_free.argtypes = [P]
+    L.kp_model_set_option.argtypes = [P, C.c_char_p, C.c_double]; L.kp_model_set_option.restype = C.c_int
+    L.kp_model_get_option.argtypes = [P, C.c_char_p]; L.kp_model_get_option.restype = C.c_double
+    L.kp_sim_create.restype = P; L.kp_sim_create.argtypes = [P, C.c_int, C.c_int, C.c_void_p]
+    L.kp_sim_destroy.argtypes = [P]
+    L.kp_sim_n_envs.argtypes = [P]; L.kp_sim_n_envs.restype = C.c_int
+    L.kp_sim_set_state.argtypes = [P, F, F, U8]; L.kp_sim_set_state.restype = C.c_int
+    L.kp_sim_set_target.argtypes = [P, F, U8]; L.kp_sim_set_target.restype = C.c_int
+    L.kp_sim_step_ctrl.argtypes = [P, F, C.c_int, U8]; L.kp_sim_step_ctrl.restype = C.c_int
+    L.kp_sim_step_kin.argtypes = [P, F, F]; L.kp_sim_step_kin.restype = C.c_int
+    L.kp_sim_obs_cc.argtypes = [P, F, F, F, C.c_float]; L.kp_sim_obs_cc.restype = C.c_int
+    L.kp_field_dim.argtypes = [C.c_int]; L.kp_field_dim.restype = C.c_int
+    L.kp_sim_get.argtypes = [P, C.c_int, F]; L.kp_sim_get.restype = C.c_int
+    L.kp_sim_diag.argtypes = [P, C.c_void_p]; L.kp_sim_diag.restype = C.c_int
+    L.kp_sim_last_step_seconds.argtypes = [P]; L.kp_sim_last_step_seconds.restype = C.c_double
+    L.kp_last_error.restype = C.c_char_p
+    L.kp_version.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise KinPolyNativeError(f"{what}: {load_library().kp_last_error().decode()}")
+
+
+class KpModel:
+    def __init__(self, kpm_path: str = DEFAULT_KPM, **options):
+        self.L = load_library()
+        self.h = self.L.kp_model_load(kpm_path.encode())
+        if not self.h:
+            raise KinPolyNativeError(f"kp_model_load: {self.L.kp_last_error().decode()}")
+        for k, v in options.items():
+            self.set_option(k, v)
+
+    def set_option(self, name, value):
+        _check(self.L.kp_model_set_option(self.h, name.encode(), float(value)), "kp_model_set_option")
+
+    def get_option(self, name):
+        return self.L.kp_model_get_option(self.h, name.encode())
+
+    def __del__(self):
+        try:
+            self.L.kp_model_free(self.h)
+        except Exception:
+            pass
+
+
+def _ptr(t: torch.Tensor | None, n, dim, dtype=torch.float32):
+    if t is None:
+        return None
+    if not t.is_cuda or t.dtype != dtype or not t.is_contiguous() or tuple(t.shape) != (n, dim):
+        raise ValueError(f"expected contiguous {dtype} device tensor of shape ({n}, {dim}), got {t.dtype} {tuple(t.shape)} on {t.device}")
+    return C.c_void_p(t.data_ptr())
+
+
+def _mask_ptr(m: torch.Tensor | None, n):
+    if m is None:
+        return None
+    if not m.is_cuda or m.dtype != torch.uint8 or tuple(m.shape) != (n,) or not m.is_contiguous():
+        raise ValueError("env_mask must be a contiguous uint8 device tensor of shape (n_envs,)")
+    return C.c_void_p(m.data_ptr())
+
+
+class KpSim:
+    """N batched environments on one GPU (one kp_sim handle)."""
+
+    def __init__(self, model: KpModel, n_envs: int, device: int | torch.device = 0):
+        if not torch.cuda.is_available():
+            raise KinPolyNativeError("no HIP device visible: the simulator has no CPU fallback")
+        self.model = model
+        self.L = model.L
+        self.n = int(n_envs)
+        self.device = torch.device("cuda", device if isinstance(device, int) else (device.index or 0))
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            self.h = self.L.kp_sim_create(model.h, self.n, self.device.index, C.c_void_p(stream))
+        if not self.h:
+            raise KinPolyNativeError(f"kp_sim_create: {self.L.kp_last_error().decode()}")
+
+    def __del__(self):
+        try:
+            self.L.kp_sim_destroy(self.h)
+        except Exception:
+            pass
+
+    def _new(self, dim):
+        return torch.empty((self.n, dim), dtype=torch.float32, device=self.device)
+
+    def set_state(self, qpos, qvel, env_mask=None):
+        _check(self.L.kp_sim_set_state(self.h, _ptr(qpos, self.n, NQ), _ptr(qvel, self.n, NV), _mask_ptr(env_mask, self.n)), "kp_sim_set_state")
+
+    def set_target(self, target_qpos, env_mask=None):
+        _check(self.L.kp_sim_set_target(self.h, _ptr(target_qpos, self.n, NQ), _mask_ptr(env_mask, self.n)), "kp_sim_set_target")
+
+    def step_ctrl(self, cc_action, n_substeps=15, env_mask=None):
+        _check(self.L.kp_sim_step_ctrl(self.h, _ptr(cc_action, self.n, CC_ACTION_DIM), int(n_substeps), _mask_ptr(env_mask, self.n)), "kp_sim_step_ctrl")
+
+    def step_kin(self, kin_action, out=None):
+        out = self._new(NQ) if out is None else out
+        _check(self.L.kp_sim_step_kin(self.h, _ptr(kin_action, self.n, KIN_ACTION_DIM), _ptr(out, self.n, NQ)), "kp_sim_step_kin")
+        return out
+
+    def obs_cc(self, out=None, zf_mean=None, zf_std=None, clip=0.0):
+        out = self._new(CC_OBS_DIM) if out is None else out
+        zm = None if zf_mean is None else C.c_void_p(zf_mean.data_ptr())
+        zs = None if zf_std is None else C.c_void_p(zf_std.data_ptr())
+        _check(self.L.kp_sim_obs_cc(self.h, _ptr(out, self.n, CC_OBS_DIM), zm, zs, float(clip)), "kp_sim_obs_cc")
+        return out
+
+    def get(self, field: str, out=None):
+        fid = FIELDS[field]
+        dim = self.L.kp_field_dim(fid)
+        out = self._new(dim) if out is None else out
+        _check(self.L.kp_sim_get(self.h, fid, _ptr(out, self.n, dim)), "kp_sim_get")
+        return out
+
+    def diag(self) -> np.ndarray:
+        out = np.zeros((self.n, 4), np.int32)
+        _check(self.L.kp_sim_diag(self.h, out.ctypes.data_as(C.c_void_p)), "kp_sim_diag")
+        return out
+
+    def last_step_seconds(self) -> float:
+        return self.L.kp_sim_last_step_seconds(self.h)
