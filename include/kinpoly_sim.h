@@ -72,6 +72,49 @@ int kp_sim_step_kin(kp_sim*, const float* kin_action, float* next_qpos);
  * (zfilter.py:58-67): pass mean/std [784] device pointers or NULL, clip <= 0 disables clipping. */
 int kp_sim_obs_cc(kp_sim*, float* out, const float* zf_mean, const float* zf_std, float clip);
 
+/* per-episode context rows the env reads each step (ar_context, humanoid_ar_v1.py:84-88).
+ * Arrays are [N, T, dim] device pointers; cur_t is int32 [N] (env.cur_t).  obj_qpos [N,7] may be NULL
+ * (then get_obj_qpos() == [0,0,0,1,0,0,0], :465-466). */
+typedef struct {
+    int T;
+    const float* head_pose;               /* [N,T,7]  ar_context['head_pose'] */
+    const float* head_vels;               /* [N,T,6]  ar_context['head_vels'] */
+    const float* obj_head_relative_poses; /* [N,T,7]  */
+    const float* action_one_hot;          /* [N,4]    ar_context['action_one_hot'][0] */
+    const float* gt_bquat;                /* [N,T,96] ar_context['bquat'] (GT clip) */
+    const float* gt_wbpos;                /* [N,T,72] gt_targets['wbpos'] */
+    const float* obj_qpos;                /* [N,7] or NULL */
+    const int32_t* cur_t;                 /* [N] */
+} kp_ctx;
+
+/* records prev_bquat / prev_hpos at the top of HumanoidAREnv.step (humanoid_ar_v1.py:246-249) */
+int kp_sim_step_begin(kp_sim*);
+
+/* get_ar_obs_v1() [N,105]   (humanoid_ar_v1.py:133-214; use_head, use_action, use_obj on; use_vel/of/context off) */
+int kp_sim_obs_ar(kp_sim*, const kp_ctx* ctx, float* out);
+
+/* termination (calc_body_diff / calc_body_gt_diff, :435-458, thresholds :53-54) and the reward
+ * dynamic_supervision_v1 (kin_poly/core/reward_function.py:931-995) for the state after do_simulation,
+ * with ctx->cur_t already incremented.  reward [N], info [N,6], fail uint8 [N], diffs [N,2]. */
+typedef struct {
+    float w_hp, w_hq, w_p, w_jp, w_act_p, w_act_v;
+    float k_hp, k_hq, k_p, k_jp, k_act_p, k_act_v;
+    float dt;                  /* env.dt = 1/30 */
+    float body_diff_thresh;    /* 10  */
+    float body_diff_gt_thresh; /* 12  */
+    int use_gt_term;           /* mode == "train" and not wild (:303-306) */
+} kp_reward_cfg;
+int kp_sim_term_reward(kp_sim*, const kp_ctx* ctx, const kp_reward_cfg* cfg, float* reward, float* info, uint8_t* fail, float* diffs);
+
+/* estimate_advantages before normalisation (uhc/khrylib/rl/core/common.py:5-20) on an env-major
+ * [N,T] layout (each env's T rows contiguous, time increasing).  All pointers device, float32. */
+int kp_gae(int n_envs, int T, const float* rewards, const float* masks, const float* values, float gamma, float tau,
+           float* advantages, float* returns, void* hip_stream);
+
+/* restore a complete simulator state (what MjSimState + the derived arrays would hold): qpos/qvel and the
+ * state (qpos_d/qvel_d) the stale derived quantities belong to; runs the forward pass on the latter. */
+int kp_sim_set_full_state(kp_sim*, const float* qpos, const float* qvel, const float* qpos_d, const float* qvel_d, const uint8_t* env_mask);
+
 /* read-outs of the mujoco-py data fields the env uses (humanoid_im.py:342-416, humanoid_ar_v1.py:460-512) */
 typedef enum {
     KP_QPOS = 0,        /* data.qpos[:76]                    [N,76]  */
@@ -87,7 +130,9 @@ typedef enum {
     KP_TARGET_BQUAT = 10,  /* target['bquat']                [N,96]  */
     KP_TARGET_COM = 11,    /* target['body_com']             [N,72]  */
     KP_QPOS_D = 12,     /* state the derived quantities were computed at (x_14 after a control step) */
-    KP_QVEL_D = 13
+    KP_QVEL_D = 13,
+    KP_PREV_BQUAT = 14, /* env.prev_bquat                    [N,96] */
+    KP_PREV_HPOS = 15   /* env.prev_hpos                     [N,7]  */
 } kp_field;
 int kp_field_dim(int field);
 int kp_sim_get(kp_sim*, int field, float* out);

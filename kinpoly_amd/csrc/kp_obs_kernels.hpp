@@ -177,10 +177,12 @@ __global__ __launch_bounds__(64) void k_obs_cc(ObsCcArgs A) {
         const float* xq = A.xquat + (size_t)e * 96;
         V3 cj = ld3(xp), ci = ld3(xi);
         V3 tj = ld3(A.t_wbpos + (size_t)e * 72 + 3 * b), tc = ld3(A.t_com + (size_t)e * 72 + 3 * b);
-        st3(ob + 304 + 3 * b, q_tmul_vec(crq, cj - root));
-        st3(ob + 376 + 3 * b, q_tmul_vec(crq, tj - cj));
-        st3(ob + 448 + 3 * b, q_tmul_vec(crq, ci - root));
-        st3(ob + 520 + 3 * b, q_tmul_vec(crq, tc - ci));
+        // transform_vec_batch returns a (3, 24) array that the reference ravel()s: component-major blocks
+        V3 p1 = q_tmul_vec(crq, cj - root), p2 = q_tmul_vec(crq, tj - cj), p3 = q_tmul_vec(crq, ci - root), p4 = q_tmul_vec(crq, tc - ci);
+        ob[304 + b] = p1.x; ob[328 + b] = p1.y; ob[352 + b] = p1.z;
+        ob[376 + b] = p2.x; ob[400 + b] = p2.y; ob[424 + b] = p2.z;
+        ob[448 + b] = p3.x; ob[472 + b] = p3.y; ob[496 + b] = p3.z;
+        ob[520 + b] = p4.x; ob[544 + b] = p4.y; ob[568 + b] = p4.z;
         const float* twq = A.t_wbquat + (size_t)e * 96 + 4 * b;
         Q4 tqt = Q4{twq[0], twq[1], twq[2], twq[3]};
         Q4 cq = (xq[0] == 0.f) ? tqt : Q4{xq[4 * b], xq[4 * b + 1], xq[4 * b + 2], xq[4 * b + 3]};

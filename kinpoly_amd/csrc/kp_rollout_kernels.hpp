@@ -1,0 +1,152 @@
+// kp_rollout_kernels.hpp -- per-step bookkeeping of the kinematic-policy env and the rollout driver:
+//   k_obs_ar       HumanoidAREnv.get_ar_obs_v1        kin_poly/envs/humanoid_ar_v1.py:133-214 (kin_poly.yml flags)
+//   k_term_reward  calc_body_diff / calc_body_gt_diff  kin_poly/envs/humanoid_ar_v1.py:435-458
+//                  dynamic_supervision_v1              kin_poly/core/reward_function.py:931-995
+//   k_snapshot     prev_bquat / prev_hpos records      kin_poly/envs/humanoid_ar_v1.py:246-249
+//   k_gae          estimate_advantages (un-normalised) uhc/khrylib/rl/core/common.py:5-25
+// One thread per environment: these are O(100)-flop gathers; the physics kernel dominates the step.
+#pragma once
+#include "kp_obs_kernels.hpp"
+
+namespace kp {
+
+struct CtxDev {  // mirrors kp_ctx in include/kinpoly_sim.h
+    int T;
+    const float *head_pose, *head_vels, *obj_rel, *action_one_hot, *gt_bquat, *gt_wbpos, *obj_qpos;
+    const int* cur_t;
+};
+
+__device__ __forceinline__ V3 tv_heading(V3 v, Q4 q) { return q_tmul_vec(q_heading(q), v); }  // transform_vec(v, q, 'heading')
+
+__global__ void k_obs_ar(int n, CtxDev C, const float* __restrict__ qpos, const float* __restrict__ xpos, const float* __restrict__ xquat,
+                         float* __restrict__ out) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const float* q = qpos + (size_t)e * D_NQ;
+    float* o = out + (size_t)e * 105;
+    int t = C.cur_t[e];
+    t = t < 0 ? 0 : (t >= C.T ? C.T - 1 : t);
+    const int hb = 13;
+    Q4 rq = Q4{q[3], q[4], q[5], q[6]};
+    Q4 dh = qmul(q_inverse(q_heading(rq)), rq);  // de_heading(qpos[3:7]) -- no base_rot removal here (:140-141)
+    o[0] = q[2]; o[1] = dh.w; o[2] = dh.x; o[3] = dh.y; o[4] = dh.z;
+    for (int j = 0; j < D_NU; j++) o[5 + j] = q[7 + j];
+    V3 hpos = ld3(xpos + (size_t)e * 72 + 3 * hb);
+    const float* hq4 = xquat + (size_t)e * 96 + 4 * hb;
+    Q4 hrot = Q4{hq4[0], hq4[1], hq4[2], hq4[3]};
+    const float* hp = C.head_pose + ((size_t)e * C.T + t) * 7;
+    const float* hv = C.head_vels + ((size_t)e * C.T + t) * 6;
+    const float* orl = C.obj_rel + ((size_t)e * C.T + t) * 7;
+    const float* oh = C.action_one_hot + (size_t)e * 4;
+    st3(o + 74, tv_heading(ld3(hp) - hpos, hrot));
+    Q4 dr = qmul(q_inverse(Q4{hp[3], hp[4], hp[5], hp[6]}), hrot);
+    o[77] = dr.w; o[78] = dr.x; o[79] = dr.y; o[80] = dr.z;
+    float ohs = oh[0] + oh[1] + oh[2] + oh[3];
+    V3 opos = v3(0.f, 0.f, 0.f); Q4 orot = Q4{1.f, 0.f, 0.f, 0.f};   // get_obj_qpos: [0,0,0,1,0,0,0] when no action (:465-466)
+    if (ohs != 0.f && C.obj_qpos) { const float* ob = C.obj_qpos + (size_t)e * 7; opos = ld3(ob); orot = Q4{ob[3], ob[4], ob[5], ob[6]}; }
+    st3(o + 81, tv_heading(opos - hpos, hrot));
+    Q4 ol = qmul(q_inverse(q_heading(hrot)), orot);
+    o[84] = ol.w; o[85] = ol.x; o[86] = ol.y; o[87] = ol.z;
+    o[88] = hv[3]; o[89] = hv[4]; o[90] = hv[5];
+    o[91] = hv[0]; o[92] = hv[1]; o[93] = hv[2];
+    for (int k = 0; k < 7; k++) o[94 + k] = orl[k];
+    for (int k = 0; k < 4; k++) o[101 + k] = oh[k];
+}
+
+__global__ void k_snapshot(int n, const float* __restrict__ qpos, const float* __restrict__ xpos, const float* __restrict__ xquat,
+                           float* __restrict__ prev_bquat, float* __restrict__ prev_hpos) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * D_NB) return;
+    int e = t / D_NB, b = t - e * D_NB;
+    const float* q = qpos + (size_t)e * D_NQ;
+    Q4 r = b == 0 ? Q4{q[3], q[4], q[5], q[6]} : q_euler_sxyz(q[7 + 3 * (b - 1)], q[8 + 3 * (b - 1)], q[9 + 3 * (b - 1)]);
+    float* o = prev_bquat + (size_t)t * 4;
+    o[0] = r.w; o[1] = r.x; o[2] = r.y; o[3] = r.z;
+    if (b == 13) {
+        for (int k = 0; k < 3; k++) prev_hpos[(size_t)e * 7 + k] = xpos[(size_t)e * 72 + 39 + k];
+        for (int k = 0; k < 4; k++) prev_hpos[(size_t)e * 7 + 3 + k] = xquat[(size_t)e * 96 + 52 + k];
+    }
+}
+
+__device__ __forceinline__ float quat_norm_v2(Q4 q) {  // multi_quat_norm_v2 of one quaternion
+    float a = fabsf(q.w) - 1.0f;
+    return sqrtf(a * a + q.x * q.x + q.y * q.y + q.z * q.z);
+}
+__device__ __forceinline__ V3 rot_from_quat(Q4 q) {  // rotation_from_quaternion (transformation.py:348-356)
+    if (1.0f - fabsf(q.w) < 1e-8f) return v3(0.f, 0.f, 0.f);
+    float s = sqrtf(1.0f - q.w * q.w), ang = 2.0f * acosf(q.w);
+    return (ang / s) * v3(q.x, q.y, q.z);
+}
+
+struct RewardW { float w_hp, w_hq, w_p, w_jp, w_act_p, w_act_v, k_hp, k_hq, k_p, k_jp, k_act_p, k_act_v, dt, thresh, gt_thresh; int use_gt; };
+
+// inputs are AFTER do_simulation and cur_t += 1: qpos fresh, xpos/xquat stale (as the reference reads them)
+__global__ void k_term_reward(int n, CtxDev C, RewardW W, const float* __restrict__ qpos, const float* __restrict__ xpos,
+                              const float* __restrict__ xquat, const float* __restrict__ t_wbpos, const float* __restrict__ t_bquat,
+                              const float* __restrict__ prev_bquat, const float* __restrict__ prev_hpos, const float* __restrict__ diffw,
+                              float* __restrict__ reward, float* __restrict__ info, uint8_t* __restrict__ fail, float* __restrict__ diffs) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    int t = C.cur_t[e];
+    t = t < 1 ? 1 : (t >= C.T ? C.T - 1 : t);
+    const float* q = qpos + (size_t)e * D_NQ;
+    const float* xp = xpos + (size_t)e * 72;
+    const float* xq = xquat + (size_t)e * 96;
+    const float* hp = C.head_pose + ((size_t)e * C.T + t) * 7;
+    const float* gtb = C.gt_bquat + ((size_t)e * C.T + t) * 96;
+    const float* gtp = C.gt_bquat + ((size_t)e * C.T + t - 1) * 96;
+    const float* gtw = C.gt_wbpos + ((size_t)e * C.T + t) * 72;
+    // head terms
+    V3 hd = ld3(xp + 39) - ld3(hp);
+    float hp_r = expf(-W.k_hp * dot(hd, hd));
+    Q4 hq = qmul(Q4{xq[52], xq[53], xq[54], xq[55]}, q_inverse(Q4{hp[3], hp[4], hp[5], hp[6]}));
+    float hqd = quat_norm_v2(hq);
+    float hq_r = expf(-W.k_hq * hqd * hqd);
+    float pq = 0.f, pp = 0.f, pg = 0.f, vel2 = 0.f, bd = 0.f, bgd = 0.f;
+    for (int b = 0; b < D_NB; b++) {
+        Q4 cb = b == 0 ? Q4{q[3], q[4], q[5], q[6]} : q_euler_sxyz(q[7 + 3 * (b - 1)], q[8 + 3 * (b - 1)], q[9 + 3 * (b - 1)]);
+        const float* tb = t_bquat + (size_t)e * 96 + 4 * b;
+        pq += quat_norm_v2(qmul(cb, q_inverse(Q4{tb[0], tb[1], tb[2], tb[3]})));
+        V3 dpos = ld3(xp + 3 * b) - ld3(t_wbpos + (size_t)e * 72 + 3 * b);
+        float dn = sqrtf(dot(dpos, dpos));
+        pp += dn;
+        float wgt = diffw ? diffw[b] : 1.0f;
+        bd += wgt * dn;
+        V3 dg = ld3(xp + 3 * b) - ld3(gtw + 3 * b);
+        bgd += wgt * sqrtf(dot(dg, dg));
+        Q4 g = Q4{gtb[4 * b], gtb[4 * b + 1], gtb[4 * b + 2], gtb[4 * b + 3]};
+        Q4 gpv = Q4{gtp[4 * b], gtp[4 * b + 1], gtp[4 * b + 2], gtp[4 * b + 3]};
+        pg += quat_norm_v2(qmul(g, q_inverse(cb)));
+        const float* pb = prev_bquat + (size_t)e * 96 + 4 * b;
+        V3 cv = (1.0f / W.dt) * rot_from_quat(qmul(cb, q_inverse(Q4{pb[0], pb[1], pb[2], pb[3]})));
+        V3 gv = (1.0f / W.dt) * rot_from_quat(qmul(g, q_inverse(gpv)));
+        V3 dv = cv - gv;
+        vel2 += dot(dv, dv);
+    }
+    pq *= (1.0f / 24.0f); pp *= (1.0f / 24.0f); pg *= (1.0f / 24.0f);
+    float p_r = expf(-W.k_p * pq * pq), jp_r = expf(-W.k_jp * pp * pp);
+    float gt_r = expf(-W.k_act_p * pg), av_r = expf(-W.k_act_v * vel2);
+    reward[e] = W.w_hp * hp_r + W.w_hq * hq_r + W.w_p * p_r + W.w_jp * jp_r + W.w_act_p * gt_r + W.w_act_v * av_r;
+    float* inf = info + (size_t)e * 6;
+    inf[0] = hp_r; inf[1] = hq_r; inf[2] = p_r; inf[3] = jp_r; inf[4] = gt_r; inf[5] = av_r;
+    fail[e] = (bd > W.thresh) || (W.use_gt && bgd > W.gt_thresh) || !(bd == bd);
+    diffs[2 * e] = bd; diffs[2 * e + 1] = bgd;
+}
+
+// reverse scan per env over an env-major [N, T] layout (time contiguous per env), masks cut episodes
+__global__ void k_gae(int n, int T, const float* __restrict__ rewards, const float* __restrict__ masks, const float* __restrict__ values,
+                      float gamma, float tau, float* __restrict__ adv, float* __restrict__ ret) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    float prev_v = 0.f, prev_a = 0.f;
+    for (int t = T - 1; t >= 0; t--) {
+        size_t i = (size_t)e * T + t;
+        float m = masks[i], v = values[i];
+        float delta = rewards[i] + gamma * prev_v * m - v;
+        float a = delta + gamma * tau * prev_a * m;
+        adv[i] = a; ret[i] = v + a;
+        prev_v = v; prev_a = a;
+    }
+}
+
+}  // namespace kp

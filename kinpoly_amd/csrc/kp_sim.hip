@@ -11,6 +11,7 @@
 #include "../../include/kinpoly_sim.h"
 #include "kp_model.hpp"
 #include "kp_obs_kernels.hpp"
+#include "kp_rollout_kernels.hpp"
 #include "kp_step_kernel.hpp"
 
 namespace {
@@ -35,6 +36,7 @@ struct kp_sim {
     kp::Params P{};
     float *qpos = nullptr, *qvel = nullptr, *qpos_d = nullptr, *qvel_d = nullptr, *warm = nullptr;
     float *xpos = nullptr, *xquat = nullptr, *xipos = nullptr, *scratch = nullptr;
+    float *prev_bquat = nullptr, *prev_hpos = nullptr, *diffw = nullptr;
     float *t_qpos = nullptr, *t_wbpos = nullptr, *t_wbquat = nullptr, *t_bquat = nullptr, *t_com = nullptr;
     int* diag = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -78,6 +80,7 @@ bool build_tables(kp_sim* s) {
     T.dof_armature = upload<float>(s, m.dof_armature, &ok);
     T.kp = upload<float>(s, m.kp, &ok); T.kd = upload<float>(s, m.kd, &ok); T.tlim = upload<float>(s, m.torque_lim, &ok);
     T.ascale = upload<float>(s, m.a_scale, &ok);
+    s->diffw = const_cast<float*>(upload<float>(s, m.body_diffw, &ok));
     T.verts = upload<float>(s, m.verts, &ok);
     T.vert_adr = upload<uint16_t>(s, m.vert_adr, &ok); T.dof_madr = upload<uint16_t>(s, m.dof_madr, &ok);
     T.dof_depth = upload<uint8_t>(s, m.dof_depth, &ok); T.dof_body = upload<uint8_t>(s, m.dof_body, &ok);
@@ -206,6 +209,7 @@ kp_sim* kp_sim_create(const kp_model* m, int n_envs, int device_id, void* stream
     s->t_qpos = dalloc(s, N * 76, &ok); s->t_wbpos = dalloc(s, N * 72, &ok); s->t_wbquat = dalloc(s, N * 96, &ok);
     s->t_bquat = dalloc(s, N * 96, &ok); s->t_com = dalloc(s, N * 72, &ok);
     s->scratch = dalloc(s, N * 96, &ok);
+    s->prev_bquat = dalloc(s, N * 96, &ok); s->prev_hpos = dalloc(s, N * 7, &ok);
     s->diag = (int*)dalloc(s, N * 4, &ok);
     if (!ok || hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) {
         fail("kp_sim_create: device allocation / table build failed");
@@ -291,8 +295,8 @@ int kp_field_dim(int f) {
         case KP_QPOS: case KP_TARGET_QPOS: case KP_QPOS_D: return 76;
         case KP_QVEL: case KP_QVEL_D: return 75;
         case KP_XPOS: case KP_XIPOS: case KP_TARGET_WBPOS: case KP_TARGET_COM: return 72;
-        case KP_XQUAT: case KP_BQUAT: case KP_TARGET_WBQUAT: case KP_TARGET_BQUAT: return 96;
-        case KP_HEAD: return 7;
+        case KP_XQUAT: case KP_BQUAT: case KP_TARGET_WBQUAT: case KP_TARGET_BQUAT: case KP_PREV_BQUAT: return 96;
+        case KP_HEAD: case KP_PREV_HPOS: return 7;
         default: return -1;
     }
 }
@@ -322,6 +326,8 @@ int kp_sim_get(kp_sim* s, int field, float* out) {
         case KP_TARGET_COM: src = s->t_com; break;
         case KP_QPOS_D: src = s->qpos_d; break;
         case KP_QVEL_D: src = s->qvel_d; break;
+        case KP_PREV_BQUAT: src = s->prev_bquat; break;
+        case KP_PREV_HPOS: src = s->prev_hpos; break;
         case KP_BQUAT:
             hipLaunchKernelGGL(kp::k_bquat, dim3((s->n * 24 + 255) / 256), dim3(256), 0, s->stream, s->n, s->qpos, out);
             HIP_OK(hipGetLastError());
@@ -334,6 +340,61 @@ int kp_sim_get(kp_sim* s, int field, float* out) {
     }
     HIP_OK(hipMemcpyAsync(out, src, sizeof(float) * (size_t)s->n * kp_field_dim(field), hipMemcpyDeviceToDevice, s->stream));
     return 0;
+}
+
+static kp::CtxDev to_dev(const kp_ctx* c) {
+    kp::CtxDev d;
+    d.T = c->T; d.head_pose = c->head_pose; d.head_vels = c->head_vels; d.obj_rel = c->obj_head_relative_poses;
+    d.action_one_hot = c->action_one_hot; d.gt_bquat = c->gt_bquat; d.gt_wbpos = c->gt_wbpos; d.obj_qpos = c->obj_qpos; d.cur_t = c->cur_t;
+    return d;
+}
+
+int kp_sim_step_begin(kp_sim* s) {
+    if (!s) return fail("kp_sim_step_begin: null argument");
+    HIP_OK(hipSetDevice(s->device));
+    hipLaunchKernelGGL(kp::k_snapshot, dim3((s->n * 24 + 255) / 256), dim3(256), 0, s->stream, s->n, s->qpos, s->xpos, s->xquat, s->prev_bquat, s->prev_hpos);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int kp_sim_obs_ar(kp_sim* s, const kp_ctx* c, float* out) {
+    if (!s || !c || !out || !c->head_pose || !c->head_vels || !c->obj_head_relative_poses || !c->action_one_hot || !c->cur_t || c->T < 1)
+        return fail("kp_sim_obs_ar: bad arguments");
+    HIP_OK(hipSetDevice(s->device));
+    hipLaunchKernelGGL(kp::k_obs_ar, dim3((s->n + 63) / 64), dim3(64), 0, s->stream, s->n, to_dev(c), s->qpos, s->xpos, s->xquat, out);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int kp_sim_term_reward(kp_sim* s, const kp_ctx* c, const kp_reward_cfg* w, float* reward, float* info, uint8_t* failp, float* diffs) {
+    if (!s || !c || !w || !reward || !info || !failp || !diffs || !c->head_pose || !c->gt_bquat || !c->gt_wbpos || !c->cur_t || c->T < 2)
+        return fail("kp_sim_term_reward: bad arguments");
+    HIP_OK(hipSetDevice(s->device));
+    kp::RewardW W{w->w_hp, w->w_hq, w->w_p, w->w_jp, w->w_act_p, w->w_act_v, w->k_hp, w->k_hq, w->k_p, w->k_jp, w->k_act_p, w->k_act_v,
+                  w->dt, w->body_diff_thresh, w->body_diff_gt_thresh, w->use_gt_term};
+    hipLaunchKernelGGL(kp::k_term_reward, dim3((s->n + 63) / 64), dim3(64), 0, s->stream, s->n, to_dev(c), W, s->qpos, s->xpos, s->xquat,
+                       s->t_wbpos, s->t_bquat, s->prev_bquat, s->prev_hpos, s->diffw, reward, info, failp, diffs);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int kp_gae(int n, int T, const float* rewards, const float* masks, const float* values, float gamma, float tau, float* adv, float* ret, void* stream) {
+    if (n <= 0 || T <= 0 || !rewards || !masks || !values || !adv || !ret) return fail("kp_gae: bad arguments");
+    hipLaunchKernelGGL(kp::k_gae, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, n, T, rewards, masks, values, gamma, tau, adv, ret);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int kp_sim_set_full_state(kp_sim* s, const float* qpos, const float* qvel, const float* qpos_d, const float* qvel_d, const uint8_t* mask) {
+    if (!s || !qpos || !qvel || !qpos_d || !qvel_d) return fail("kp_sim_set_full_state: null argument");
+    HIP_OK(hipSetDevice(s->device));
+    int n = s->n;
+    hipLaunchKernelGGL(k_copy_rows, dim3((n * 76 + 255) / 256), dim3(256), 0, s->stream, n, 76, qpos, s->qpos, (float*)nullptr, mask);
+    hipLaunchKernelGGL(k_copy_rows, dim3((n * 75 + 255) / 256), dim3(256), 0, s->stream, n, 75, qvel, s->qvel, (float*)nullptr, mask);
+    hipLaunchKernelGGL(k_copy_rows, dim3((n * 76 + 255) / 256), dim3(256), 0, s->stream, n, 76, qpos_d, s->qpos_d, (float*)nullptr, mask);
+    hipLaunchKernelGGL(k_copy_rows, dim3((n * 75 + 255) / 256), dim3(256), 0, s->stream, n, 75, qvel_d, s->qvel_d, (float*)nullptr, mask);
+    HIP_OK(hipGetLastError());
+    return launch_step(s, nullptr, 0, mask, false);
 }
 
 int kp_sim_diag(kp_sim* s, int32_t* out_host) {

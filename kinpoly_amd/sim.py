@@ -19,7 +19,7 @@ CC_OBS_DIM, AR_OBS_DIM, KIN_ACTION_DIM, CC_ACTION_DIM = 784, 105, 80, 75
 DEFAULT_KPM = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets", "smpl_humanoid.kpm")
 
 FIELDS = dict(qpos=0, qvel=1, xpos=2, xquat=3, xipos=4, bquat=5, head=6, target_qpos=7, target_wbpos=8,
-              target_wbquat=9, target_bquat=10, target_com=11, qpos_d=12, qvel_d=13)
+              target_wbquat=9, target_bquat=10, target_com=11, qpos_d=12, qvel_d=13, prev_bquat=14, prev_hpos=15)
 
 _lib = None
 
@@ -28,7 +28,25 @@ ABI_SYMBOLS = [
     "kp_model_load", "kp_model_free", "kp_model_set_option", "kp_model_get_option", "kp_sim_create", "kp_sim_destroy",
     "kp_sim_n_envs", "kp_sim_set_state", "kp_sim_set_target", "kp_sim_step_ctrl", "kp_sim_step_kin", "kp_sim_obs_cc",
     "kp_field_dim", "kp_sim_get", "kp_sim_diag", "kp_sim_last_step_seconds", "kp_last_error", "kp_version",
+    "kp_sim_step_begin", "kp_sim_obs_ar", "kp_sim_term_reward", "kp_gae", "kp_sim_set_full_state",
 ]
+
+
+class KpCtx(C.Structure):
+    """mirror of kp_ctx (include/kinpoly_sim.h)"""
+    _fields_ = [("T", C.c_int), ("head_pose", C.c_void_p), ("head_vels", C.c_void_p), ("obj_head_relative_poses", C.c_void_p),
+                ("action_one_hot", C.c_void_p), ("gt_bquat", C.c_void_p), ("gt_wbpos", C.c_void_p), ("obj_qpos", C.c_void_p),
+                ("cur_t", C.c_void_p)]
+
+
+class KpRewardCfg(C.Structure):
+    """mirror of kp_reward_cfg; defaults = config/statear/kin_poly.yml:72-86, humanoid_ar_v1.py:53-54"""
+    _fields_ = [(k, C.c_float) for k in ("w_hp", "w_hq", "w_p", "w_jp", "w_act_p", "w_act_v", "k_hp", "k_hq", "k_p", "k_jp", "k_act_p",
+                                          "k_act_v", "dt", "body_diff_thresh", "body_diff_gt_thresh")] + [("use_gt_term", C.c_int)]
+
+    @classmethod
+    def default(cls, use_gt_term=True):
+        return cls(0.15, 0.15, 0.2, 0.2, 0.2, 0.1, 45.0, 45.0, 50.0, 50.0, 5.0, 0.005, 1.0 / 30.0, 10.0, 12.0, int(use_gt_term))
 
 
 class KinPolyNativeError(RuntimeError):
@@ -62,6 +80,11 @@ def load_library(path: str | None = None):
     L.kp_sim_get.argtypes = [P, C.c_int, F]; L.kp_sim_get.restype = C.c_int
     L.kp_sim_diag.argtypes = [P, C.c_void_p]; L.kp_sim_diag.restype = C.c_int
     L.kp_sim_last_step_seconds.argtypes = [P]; L.kp_sim_last_step_seconds.restype = C.c_double
+    L.kp_sim_step_begin.argtypes = [P]; L.kp_sim_step_begin.restype = C.c_int
+    L.kp_sim_obs_ar.argtypes = [P, C.POINTER(KpCtx), F]; L.kp_sim_obs_ar.restype = C.c_int
+    L.kp_sim_term_reward.argtypes = [P, C.POINTER(KpCtx), C.POINTER(KpRewardCfg), F, F, U8, F]; L.kp_sim_term_reward.restype = C.c_int
+    L.kp_gae.argtypes = [C.c_int, C.c_int, F, F, F, C.c_float, C.c_float, F, F, C.c_void_p]; L.kp_gae.restype = C.c_int
+    L.kp_sim_set_full_state.argtypes = [P, F, F, F, F, U8]; L.kp_sim_set_full_state.restype = C.c_int
     L.kp_last_error.restype = C.c_char_p
     L.kp_version.restype = C.c_char_p
     _lib = L
@@ -164,6 +187,40 @@ class KpSim:
         _check(self.L.kp_sim_get(self.h, fid, _ptr(out, self.n, dim)), "kp_sim_get")
         return out
 
+    def set_full_state(self, qpos, qvel, qpos_d, qvel_d, env_mask=None):
+        _check(self.L.kp_sim_set_full_state(self.h, _ptr(qpos, self.n, NQ), _ptr(qvel, self.n, NV), _ptr(qpos_d, self.n, NQ),
+                                            _ptr(qvel_d, self.n, NV), _mask_ptr(env_mask, self.n)), "kp_sim_set_full_state")
+
+    def step_begin(self):
+        _check(self.L.kp_sim_step_begin(self.h), "kp_sim_step_begin")
+
+    def make_ctx(self, T, head_pose, head_vels, obj_rel, action_one_hot, gt_bquat, gt_wbpos, cur_t, obj_qpos=None) -> "KpCtx":
+        n = self.n
+        for t, shp in ((head_pose, (n, T, 7)), (head_vels, (n, T, 6)), (obj_rel, (n, T, 7)), (action_one_hot, (n, 4)),
+                       (gt_bquat, (n, T, 96)), (gt_wbpos, (n, T, 72))):
+            if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous() or tuple(t.shape) != shp:
+                raise ValueError(f"context tensor must be contiguous float32 on device with shape {shp}, got {tuple(t.shape)}")
+        if cur_t.dtype != torch.int32 or tuple(cur_t.shape) != (n,) or not cur_t.is_cuda:
+            raise ValueError("cur_t must be an int32 device tensor [n_envs]")
+        ctx = KpCtx(int(T), head_pose.data_ptr(), head_vels.data_ptr(), obj_rel.data_ptr(), action_one_hot.data_ptr(), gt_bquat.data_ptr(),
+                    gt_wbpos.data_ptr(), None if obj_qpos is None else obj_qpos.data_ptr(), cur_t.data_ptr())
+        ctx._keep = (head_pose, head_vels, obj_rel, action_one_hot, gt_bquat, gt_wbpos, obj_qpos, cur_t)
+        return ctx
+
+    def obs_ar(self, ctx: "KpCtx", out=None):
+        out = self._new(AR_OBS_DIM) if out is None else out
+        _check(self.L.kp_sim_obs_ar(self.h, C.byref(ctx), _ptr(out, self.n, AR_OBS_DIM)), "kp_sim_obs_ar")
+        return out
+
+    def term_reward(self, ctx: "KpCtx", cfg: "KpRewardCfg", reward=None, info=None, fail=None, diffs=None):
+        reward = torch.empty(self.n, device=self.device) if reward is None else reward
+        info = self._new(6) if info is None else info
+        fail = torch.empty(self.n, dtype=torch.uint8, device=self.device) if fail is None else fail
+        diffs = self._new(2) if diffs is None else diffs
+        _check(self.L.kp_sim_term_reward(self.h, C.byref(ctx), C.byref(cfg), C.c_void_p(reward.data_ptr()), _ptr(info, self.n, 6),
+                                         C.c_void_p(fail.data_ptr()), _ptr(diffs, self.n, 2)), "kp_sim_term_reward")
+        return reward, info, fail, diffs
+
     def diag(self) -> np.ndarray:
         out = np.zeros((self.n, 4), np.int32)
         _check(self.L.kp_sim_diag(self.h, out.ctypes.data_as(C.c_void_p)), "kp_sim_diag")
@@ -171,3 +228,17 @@ class KpSim:
 
     def last_step_seconds(self) -> float:
         return self.L.kp_sim_last_step_seconds(self.h)
+
+
+def gae(rewards: torch.Tensor, masks: torch.Tensor, values: torch.Tensor, gamma: float, tau: float):
+    """estimate_advantages before normalisation on env-major [N, T] float32 device tensors (k_gae)."""
+    L = load_library()
+    n, T = rewards.shape
+    for t in (rewards, masks, values):
+        if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous() or tuple(t.shape) != (n, T):
+            raise ValueError("gae: expected contiguous float32 device tensors [N, T]")
+    adv = torch.empty_like(rewards); ret = torch.empty_like(rewards)
+    stream = torch.cuda.current_stream(rewards.device).cuda_stream
+    _check(L.kp_gae(n, T, C.c_void_p(rewards.data_ptr()), C.c_void_p(masks.data_ptr()), C.c_void_p(values.data_ptr()), float(gamma), float(tau),
+                    C.c_void_p(adv.data_ptr()), C.c_void_p(ret.data_ptr()), C.c_void_p(stream)), "kp_gae")
+    return adv, ret

@@ -1,0 +1,250 @@
+"""GPU parity tests (run on a real MI355X with -m gpu): the HIP path, called through the C ABI of
+libkinpoly_sim.so, against the fp64 oracle and the committed golden fixtures.
+
+Tolerances (fp32 device vs fp64 oracle; north_star: per-step pose error <= 1e-3 rad):
+  * one control step (15 substeps): |dqpos| <= 2e-5, well inside the 1e-3 rad budget;
+  * pure arithmetic kernels (FK, obs, step_ar): 2e-5 absolute on O(1) quantities.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from kinpoly_amd.model_compiler import DEFAULT_KPM, read_kpm  # noqa: E402
+from oracle import np_oracle as O  # noqa: E402
+from oracle.kpo import OracleSim  # noqa: E402
+
+KPM = read_kpm(DEFAULT_KPM)
+BODY_POS, BODY_IPOS, PARENT = KPM["body_pos"].reshape(24, 3), KPM["body_ipos"].reshape(24, 3), KPM["body_parent"]
+STD = np.load(os.path.join(os.path.dirname(__file__), "golden", "standing_neutral.npz"))
+
+
+@pytest.fixture(scope="module")
+def kp():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no HIP device is visible")
+    from kinpoly_amd import sim as kpsim
+    return kpsim
+
+
+def dev(a):
+    return torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device="cuda")
+
+
+def make_states(n, seed, lift=0.0, vel=0.5, noise=0.2):
+    rng = np.random.default_rng(seed)
+    qpos = np.tile(STD["qpos"], (n, 1))
+    qpos[:, 2] += lift
+    qpos[:, 7:] += np.clip(rng.normal(size=(n, 69)) * noise, -np.pi, np.pi)
+    qvel = rng.normal(size=(n, 75)) * vel
+    return qpos, qvel
+
+
+def run_pair(kp, n, nsub, steps, contact, lift, act_scale, threads=64, seed=1):
+    qpos, qvel = make_states(n, seed, lift=lift)
+    rng = np.random.default_rng(seed + 1)
+    action = rng.normal(size=(n, 75)) * act_scale
+    target = np.tile(STD["qpos"], (n, 1)); target[:, 7:] += rng.normal(size=(n, 69)) * 0.1
+    model = kp.KpModel(contact=contact, threads_per_env=threads)
+    sim = kp.KpSim(model, n)
+    sim.set_state(dev(qpos), dev(qvel)); sim.set_target(dev(target))
+    a = dev(action)
+    for _ in range(steps):
+        sim.step_ctrl(a, nsub)
+    out = {k: sim.get(k).cpu().numpy().astype(np.float64) for k in ("qpos", "qvel", "xpos", "xquat", "xipos", "qpos_d")}
+    out["diag"] = sim.diag()
+    ref = {k: [] for k in ("qpos", "qvel", "xpos", "xquat", "xipos")}
+    o = OracleSim(contact=bool(contact))
+    for e in range(n):
+        o.reset(qpos[e], qvel[e])
+        for _ in range(steps):
+            o.do_simulation(action[e], target[e], nsub)
+        for k in ref:
+            ref[k].append(o.get(k))
+    return out, {k: np.stack(v) for k, v in ref.items()}
+
+
+def test_abi_loads_and_errors(kp):
+    L = kp.load_library()
+    assert b"kinpoly_sim" in L.kp_version()
+    m = kp.KpModel()
+    assert m.get_option("timestep") == pytest.approx(0.00222222222)
+    with pytest.raises(kp.KinPolyNativeError):
+        m.set_option("no_such_option", 1)
+    with pytest.raises(kp.KinPolyNativeError):
+        kp.KpModel("/nonexistent.kpm")
+
+
+@pytest.mark.parametrize("threads", [64, 128, 256])
+def test_freefall_matches_oracle(kp, threads):
+    """BASELINE.json configs[1]: free fall, no contact (ABA/CRBA correctness)."""
+    out, ref = run_pair(kp, 32, 15, 2, contact=0, lift=10.0, act_scale=0.0, threads=threads)
+    assert out["diag"][:, 2].max() == 0
+    assert np.abs(out["qpos"] - ref["qpos"]).max() < 2e-5
+    assert np.abs(out["qvel"] - ref["qvel"]).max() < 5e-4
+    assert np.abs(out["xpos"] - ref["xpos"]).max() < 2e-5      # stale (x_14) kinematics
+    assert np.abs(out["xipos"] - ref["xipos"]).max() < 2e-5
+    assert np.abs(np.abs((out["xquat"].reshape(-1, 4) * ref["xquat"].reshape(-1, 4)).sum(1)) - 1).max() < 1e-6
+
+
+def test_spd_rfc_control_matches_oracle(kp):
+    out, ref = run_pair(kp, 32, 15, 3, contact=0, lift=10.0, act_scale=0.5)
+    assert np.abs(out["qpos"] - ref["qpos"]).max() < 5e-5
+    assert np.abs(out["qvel"] - ref["qvel"]).max() < 2e-3
+
+
+def test_contact_matches_oracle(kp):
+    out, ref = run_pair(kp, 32, 15, 1, contact=1, lift=0.0, act_scale=0.3)
+    assert out["diag"][:, 3].max() >= 6          # feet are on the floor
+    assert np.abs(out["qpos"] - ref["qpos"]).max() < 5e-5
+    assert np.abs(out["qvel"] - ref["qvel"]).max() < 5e-3
+
+
+def test_contact_ten_control_steps(kp):
+    """1/3 s of standing-with-contact; trajectories stay within the 1e-3 rad budget of north_star."""
+    out, ref = run_pair(kp, 16, 15, 10, contact=1, lift=0.0, act_scale=0.2)
+    err = np.abs(out["qpos"] - ref["qpos"]).max(axis=1)
+    assert np.median(err) < 1e-4
+    assert err.max() < 1e-3
+
+
+def test_freefall_invariants_4096(kp):
+    """Size-independent properties at BASELINE scale: COM acceleration = g, finite state, unit quaternions."""
+    n = 4096
+    qpos, qvel = make_states(n, 7, lift=10.0)
+    model = kp.KpModel(contact=0)
+    sim = kp.KpSim(model, n)
+    sim.set_state(dev(qpos), dev(qvel)); sim.set_target(dev(qpos))
+    a = torch.zeros((n, 75), device="cuda")
+    mass = torch.tensor(KPM["body_mass"], dtype=torch.float32, device="cuda")
+    coms = []
+    for _ in range(4):
+        sim.step_ctrl(a, 15)
+        xi = sim.get("xipos").view(n, 24, 3)
+        coms.append(((xi * mass[None, :, None]).sum(1) / mass.sum()).double().cpu().numpy())
+    assert sim.diag()[:, 2].max() == 0
+    dt = 15 * KPM["opt"][0]
+    acc = (coms[3] - 2 * coms[2] + coms[1]) / dt ** 2
+    assert np.abs(acc[:, 2].mean() + 9.81) < 2e-2
+    assert np.abs(acc[:, :2]).mean() < 2e-2
+    q = sim.get("qpos")[:, 3:7]
+    assert (q.norm(dim=1) - 1).abs().max().item() < 1e-5
+
+
+def test_target_fk_matches_golden(kp, golden):
+    g = golden("fk")
+    n = len(g["qpos_in"])
+    sim = kp.KpSim(kp.KpModel(), n)
+    sim.set_target(dev(g["qpos_in"]))
+    for field, key in (("target_qpos", "qpos"), ("target_wbpos", "wbpos"), ("target_wbquat", "wbquat"), ("target_bquat", "bquat"), ("target_com", "body_com")):
+        got = sim.get(field).cpu().numpy().astype(np.float64)
+        np.testing.assert_allclose(got, g[key].reshape(n, -1), atol=2e-5, rtol=0, err_msg=field)
+
+
+def test_step_kin_and_bquat_match_golden(kp, golden):
+    g = golden("env_funcs")
+    n = len(g["qpos"])
+    sim = kp.KpSim(kp.KpModel(), n)
+    sim.set_state(dev(g["qpos"]), dev(g["qvel"]))
+    nxt = sim.step_kin(dev(g["kin_action"])).cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(nxt, g["next_qpos"], atol=2e-5, rtol=0)
+    bq = sim.get("bquat").cpu().numpy().astype(np.float64)
+    # set_state normalises the root quaternion in place like mj_kinematics; the fixture's qpos are unit already
+    np.testing.assert_allclose(bq, g["bquat"], atol=2e-5, rtol=0)
+
+
+def test_obs_cc_matches_pinned_oracle(kp, golden):
+    """784-d UHC observation: HIP kernel vs oracle/np_oracle.obs_cc (pinned to the reference by
+    tests/test_oracle_golden.py) on the simulator's own fresh qpos/qvel and stale kinematics."""
+    g = golden("env_funcs")
+    n = len(g["qpos"])
+    rng = np.random.default_rng(5)
+    sim = kp.KpSim(kp.KpModel(), n)
+    sim.set_state(dev(g["qpos"]), dev(g["qvel"])); sim.set_target(dev(g["target_qpos"]))
+    sim.step_ctrl(dev(rng.normal(size=(n, 75)) * 0.2), 15)
+    obs = sim.obs_cc().cpu().numpy().astype(np.float64)
+    rd = {k: sim.get(k).cpu().numpy().astype(np.float64) for k in ("qpos", "qvel", "xpos", "xquat", "xipos", "target_qpos")}
+    for i in range(n):
+        t = O.qpos_fk(rd["target_qpos"][i], BODY_POS, BODY_IPOS, PARENT)
+        want = O.obs_cc(rd["qpos"][i], rd["qvel"][i], rd["xpos"][i].reshape(24, 3), rd["xquat"][i].reshape(24, 4), rd["xipos"][i].reshape(24, 3), t)
+        np.testing.assert_allclose(obs[i], want, atol=1e-4, rtol=1e-5)
+    # ZFilter + clip path
+    zg = golden("gae_zfilter")
+    ob2 = sim.obs_cc(zf_mean=dev(zg["zf_mean"]), zf_std=dev(zg["zf_std"]), clip=5.0).cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(ob2, np.clip((obs - zg["zf_mean"]) / (zg["zf_std"] + 1e-8), -5, 5), atol=2e-4, rtol=1e-4)
+
+
+def test_env_mask_and_reset(kp):
+    n = 8
+    qpos, qvel = make_states(n, 11, lift=10.0)
+    sim = kp.KpSim(kp.KpModel(contact=0), n)
+    sim.set_state(dev(qpos), dev(qvel)); sim.set_target(dev(qpos))
+    mask = torch.tensor([1, 0, 1, 0, 1, 0, 1, 0], dtype=torch.uint8, device="cuda")
+    sim.step_ctrl(torch.zeros((n, 75), device="cuda"), 15, env_mask=mask)
+    q = sim.get("qpos").cpu().numpy()
+    assert np.allclose(q[1::2], qpos[1::2].astype(np.float32), atol=1e-6)      # masked-out envs untouched
+    assert np.abs(q[0::2, 2] - qpos[0::2, 2]).min() > 1e-4                    # stepped envs moved
+    sim.set_state(dev(qpos), dev(qvel), env_mask=mask)
+    q2 = sim.get("qpos").cpu().numpy()
+    assert np.allclose(q2[0::2], qpos[0::2].astype(np.float32), atol=1e-6)
+
+
+def _ctx_from_golden(kp, sim, g, n, T=6):
+    """Per-env context of length T whose row cur_t carries the fixture's rows."""
+    rng = np.random.default_rng(9)
+    t = g["t"].astype(np.int32)
+    head_pose = rng.normal(size=(n, T, 7)); head_vels = rng.normal(size=(n, T, 6)); obj_rel = rng.normal(size=(n, T, 7))
+    gt_bquat = np.tile(np.array([1.0, 0, 0, 0]), (n, T, 24)); gt_wbpos = rng.normal(size=(n, T, 72))
+    for i in range(n):
+        head_pose[i, t[i]] = g["head_pose"][i]; head_vels[i, t[i]] = g["head_vels"][i]; obj_rel[i, t[i]] = g["obj_rel"][i]
+        gt_bquat[i, t[i]] = g["gt_bquat"][i]; gt_bquat[i, t[i] - 1] = g["gt_prev_bquat"][i]; gt_wbpos[i, t[i]] = g["gt_wbpos"][i].reshape(-1)
+    cur_t = torch.tensor(t, dtype=torch.int32, device="cuda")
+    ctx = sim.make_ctx(T, dev(head_pose), dev(head_vels), dev(obj_rel), dev(g["action_one_hot"]), dev(gt_bquat), dev(gt_wbpos), cur_t,
+                       obj_qpos=dev(g["obj_qpos"][:, :7]))
+    return ctx, dict(head_pose=head_pose, head_vels=head_vels, obj_rel=obj_rel, gt_bquat=gt_bquat, gt_wbpos=gt_wbpos, t=t)
+
+
+def test_obs_ar_and_reward_match_pinned_oracle(kp, golden):
+    g = golden("ar_obs_reward")
+    n = len(g["qpos"])
+    rng = np.random.default_rng(6)
+    sim = kp.KpSim(kp.KpModel(), n)
+    sim.set_state(dev(g["qpos"]), dev(g["qvel"])); sim.set_target(dev(g["target_qpos"]))
+    sim.step_begin()
+    sim.step_ctrl(dev(rng.normal(size=(n, 75)) * 0.2), 15)
+    ctx, c = _ctx_from_golden(kp, sim, g, n)
+    obs = sim.obs_ar(ctx).cpu().numpy().astype(np.float64)
+    rew, info, fail, diffs = sim.term_reward(ctx, kp.KpRewardCfg.default())
+    rew, info, fail, diffs = rew.cpu().numpy(), info.cpu().numpy(), fail.cpu().numpy(), diffs.cpu().numpy()
+    rd = {k: sim.get(k).cpu().numpy().astype(np.float64) for k in ("qpos", "xpos", "xquat", "target_qpos", "prev_bquat", "prev_hpos")}
+    # prev snapshots are the pre-step body quats / head pose
+    np.testing.assert_allclose(rd["prev_bquat"], np.stack([O.get_body_quat(q) for q in g["qpos"]]), atol=2e-5)
+    for i in range(n):
+        t = c["t"][i]
+        xpos, xquat = rd["xpos"][i].reshape(24, 3), rd["xquat"][i].reshape(24, 4)
+        want = O.obs_ar(rd["qpos"][i], xpos, xquat, c["head_pose"][i, t], c["head_vels"][i, t], c["obj_rel"][i, t], g["action_one_hot"][i], g["obj_qpos"][i][:7])
+        np.testing.assert_allclose(obs[i], want, atol=5e-5, rtol=1e-5)
+        tgt = O.qpos_fk(rd["target_qpos"][i], BODY_POS, BODY_IPOS, PARENT)
+        head = np.concatenate([xpos[13], xquat[13]])
+        r, inf = O.dynamic_supervision_v1(head, rd["prev_hpos"][i], O.get_body_quat(rd["qpos"][i]), rd["prev_bquat"][i], xpos, tgt, c["head_pose"][i, t],
+                                          c["gt_bquat"][i, t], c["gt_bquat"][i, t - 1], 1.0 / 30.0, O.REWARD_WEIGHTS)
+        np.testing.assert_allclose(info[i], inf, atol=2e-4, rtol=2e-3)
+        assert abs(rew[i] - r) < 2e-4
+        bd = O.calc_body_diff(xpos, tgt["wbpos"]); bgd = O.calc_body_diff(xpos, c["gt_wbpos"][i, t].reshape(24, 3))
+        np.testing.assert_allclose(diffs[i], [bd, bgd], rtol=1e-5, atol=1e-4)
+        assert bool(fail[i]) == bool(bd > 10 or bgd > 12)
+
+
+def test_gae_matches_golden(kp, golden):
+    g = golden("gae_zfilter")
+    # the fixture is one flat batch; as an env-major layout it is a single env with T = B rows
+    r, m, v = (dev(g[k].reshape(1, -1)) for k in ("rewards", "masks", "values"))
+    adv, ret = kp.gae(r, m, v, 0.95, 0.95)
+    adv = adv.double().cpu().numpy().reshape(-1, 1); ret = ret.double().cpu().numpy().reshape(-1, 1)
+    np.testing.assert_allclose(ret, g["ret"], atol=2e-5)
+    advn = (adv - adv.mean()) / adv.std(ddof=1)
+    np.testing.assert_allclose(advn, g["adv"], atol=5e-5)

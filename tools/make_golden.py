@@ -1,0 +1,333 @@
+"""Generate tests/golden/*.npz by IMPORTING the reference's Python (this container only).
+
+The reference tree (/root/reference) is imported with stub modules for its GUI / MuJoCo / IO
+dependencies; its pure-Python functions on the rollout path are then run
+on seeded inputs and (inputs, outputs) are written as small .npz fixtures.  Only data is
+committed -- no reference source.  MuJoCo-side inputs (body_xpos, qM, qfrc_bias, ...) are supplied
+from this repo's fp64 oracle so that the fixtures are physically plausible; for the functions under
+test they are just inputs.
+
+Run from a scratch cwd (reference Config classes mkdir under cwd):
+    cd /tmp && python /root/repo/tools/make_golden.py
+"""
+import os
+import sys
+import types
+from unittest.mock import MagicMock
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+OUT = os.path.join(REPO, "tests", "golden")
+sys.dont_write_bytecode = True
+
+
+class Pkg(MagicMock):
+    __path__ = []
+
+
+for m in ['cv2', 'OpenGL', 'OpenGL.GL', 'gym', 'gym.envs', 'gym.envs.mujoco', 'gym.envs.mujoco.mujoco_env', 'gym.utils',
+          'gym.spaces', 'glfw', 'torchvision', 'torchvision.models', 'torchvision.transforms', 'skimage', 'skimage.util',
+          'skimage.util.shape', 'mujoco_py', 'mujoco_py.builder', 'mujoco_py.generated', 'mujoco_py.generated.const',
+          'mujoco_py.utils', 'mujoco_py.functions', 'wandb', 'lxml', 'lxml.etree', 'ipdb', 'torchgeometry', 'smplx', 'imageio']:
+    sys.modules[m] = Pkg()
+sys.path.insert(0, REF)
+sys.path.insert(0, REPO)
+
+import torch  # noqa: E402
+
+torch.set_default_dtype(torch.float64)
+
+from uhc.khrylib.utils.math import (de_heading, get_heading, get_heading_q, quat_from_expmap, quat_mul_vec,  # noqa: E402
+                                     transform_vec, transform_vec_batch, multi_quat_diff, get_angvel_fd)
+from uhc.khrylib.utils.transformation import (quaternion_from_euler, quaternion_inverse, quaternion_matrix,  # noqa: E402
+                                               quaternion_multiply, rotation_from_quaternion)
+from uhc.khrylib.utils.zfilter import ZFilter  # noqa: E402
+from uhc.khrylib.rl.core.common import estimate_advantages  # noqa: E402
+import uhc.envs.humanoid_im as him  # noqa: E402
+import kin_poly.envs.humanoid_ar_v1 as har  # noqa: E402
+import kin_poly.utils.numpy_smpl_humanoid as nsh  # noqa: E402
+from kin_poly.utils.math_utils import multi_quat_norm_v2  # noqa: E402
+from kin_poly.core.reward_function import dynamic_supervision_v1  # noqa: E402
+from uhc.core.policy_mcp import PolicyMCP  # noqa: E402
+from uhc.khrylib.rl.core.critic import Value  # noqa: E402
+from uhc.khrylib.models.mlp import MLP  # noqa: E402
+
+from kinpoly_amd.model_compiler import read_kpm  # noqa: E402
+from oracle.kpo import OracleSim  # noqa: E402
+
+KPM = read_kpm(os.path.join(REPO, "kinpoly_amd", "assets", "smpl_humanoid.kpm"))
+STD = np.load(os.path.join(OUT, "standing_neutral.npz"))
+NB = 24
+NAMES = ["Pelvis", "L_Hip", "L_Knee", "L_Ankle", "L_Toe", "R_Hip", "R_Knee", "R_Ankle", "R_Toe", "Torso", "Spine", "Chest",
+         "Neck", "Head", "L_Thorax", "L_Shoulder", "L_Elbow", "L_Wrist", "L_Hand", "R_Thorax", "R_Shoulder", "R_Elbow",
+         "R_Wrist", "R_Hand"]
+
+
+def fake_mj_model():
+    m = types.SimpleNamespace()
+    m.body_pos = np.vstack([np.zeros((1, 3)), KPM["body_pos"].reshape(NB, 3)])
+    m.body_ipos = np.vstack([np.zeros((1, 3)), KPM["body_ipos"].reshape(NB, 3)])
+    m.body_parentid = np.concatenate([[0], KPM["body_parent"] + 1])
+    m.body_names = ["world"] + NAMES
+    m._body_name2id = {n: i for i, n in enumerate(m.body_names)}
+    m.nv = 75
+    m.opt = types.SimpleNamespace(timestep=KPM["opt"][0])
+    return m
+
+
+def rand_quat(rng):
+    q = rng.normal(size=4)
+    return q / np.linalg.norm(q)
+
+
+def rand_qpos(rng, scale=0.4):
+    q = STD["qpos"].copy()
+    q[:2] += rng.normal(size=2) * 0.5
+    q[2] += rng.normal() * 0.1
+    q[3:7] = rand_quat(rng) if rng.random() < 0.5 else quaternion_multiply(q[3:7], quat_from_expmap(rng.normal(size=3) * 0.3))
+    q[7:] += rng.normal(size=69) * scale
+    return q
+
+
+def gen_quat_utils():
+    rng = np.random.default_rng(100)
+    n = 64
+    q0 = np.stack([rand_quat(rng) for _ in range(n)]); q1 = np.stack([rand_quat(rng) * rng.uniform(0.5, 2.0) for _ in range(n)])
+    v = rng.normal(size=(n, 3)); e = rng.normal(size=(n, 3)); eul = rng.uniform(-np.pi, np.pi, size=(n, 3))
+    # literal inputs of the reference's own self-check (kin_poly/utils/torch_utils.py:446-460)
+    q1[0] = [1.522, 0.560, 0.161, 0.623]; v[0] = [1.2363, 4.41412, 7.2432]
+    out = dict(q0=q0, q1=q1, v=v, e=e, eul=eul)
+    out["mul"] = np.stack([quaternion_multiply(a, b) for a, b in zip(q1, q0)])
+    out["inv"] = np.stack([quaternion_inverse(a) for a in q1])
+    out["mat"] = np.stack([quaternion_matrix(a)[:3, :3] for a in q1])
+    out["qmulvec"] = np.stack([quat_mul_vec(a, b) for a, b in zip(q1, v)])
+    out["tv_root"] = np.stack([transform_vec(b, a, 'root') for a, b in zip(q1, v)])
+    out["tv_heading"] = np.stack([transform_vec(b, a, 'heading') for a, b in zip(q1, v)])
+    out["heading_q"] = np.stack([get_heading_q(a) for a in q1])
+    out["heading"] = np.array([get_heading(a) for a in q1])
+    out["de_heading"] = np.stack([de_heading(a) for a in q1])
+    out["expmap"] = np.stack([quat_from_expmap(a) for a in e])
+    out["euler_rzyx"] = np.stack([quaternion_from_euler(a[0], a[1], a[2], 'rzyx') for a in eul])
+    out["euler_sxyz"] = np.stack([quaternion_from_euler(a[0], a[1], a[2]) for a in eul])
+    out["rot_from_quat"] = np.stack([rotation_from_quaternion(a) for a in q0])
+    out["quat_norm_v2"] = multi_quat_norm_v2(q0.reshape(-1))
+    np.savez(os.path.join(OUT, "quat_utils.npz"), **out)
+
+
+def make_humanoid():
+    nsh.load_model_from_path = lambda f: fake_mj_model()
+    return nsh.Humanoid(model_file="unused.xml")
+
+
+def gen_fk(hum):
+    rng = np.random.default_rng(101)
+    qs = [STD["qpos"].copy()] + [rand_qpos(rng, 0.6) for _ in range(32)]
+    qs[3][3:7] *= 1.7  # un-normalised root quaternion (step_ar emits those)
+    res = [hum.qpos_fk(q.copy()) for q in qs]
+    np.savez(os.path.join(OUT, "fk.npz"), qpos_in=np.stack(qs), qpos=np.stack([r["qpos"] for r in res]),
+             wbpos=np.stack([r["wbpos"] for r in res]), wbquat=np.stack([r["wbquat"] for r in res]),
+             bquat=np.stack([r["bquat"] for r in res]), body_com=np.stack([r["body_com"] for r in res]))
+
+
+class FakeData:
+    pass
+
+
+def oracle_data(qpos, qvel, stale_steps=1):
+    """data.* as mujoco-py exposes them after a control step: derived arrays one substep stale."""
+    o = OracleSim()
+    o.reset(qpos, qvel)
+    for _ in range(stale_steps):
+        o.step()
+    d = FakeData()
+    d.qpos = np.concatenate([o.get("qpos"), np.zeros(35)])
+    d.qvel = np.concatenate([o.get("qvel"), np.zeros(30)])
+    d.body_xpos = np.vstack([np.zeros((1, 3)), o.get("xpos").reshape(NB, 3), np.zeros((5, 3))])
+    d.body_xquat = np.vstack([[[1, 0, 0, 0]], o.get("xquat").reshape(NB, 4), np.tile([1., 0, 0, 0], (5, 1))])
+    d.xipos = np.vstack([np.zeros((1, 3)), o.get("xipos").reshape(NB, 3), np.zeros((5, 3))])
+    d.qfrc_bias = np.concatenate([o.get("qfrc_bias"), np.zeros(30)])
+    d.qfrc_applied = np.zeros(105)
+    d.ctrl = np.zeros(69)
+    d.qM = None
+    d._M = o.fullM()
+    d.get_body_xipos = lambda name: d.xipos[["world"] + NAMES == name] if False else d.xipos[(["world"] + NAMES).index(name)]
+    return d
+
+
+def make_env(cls):
+    env = cls.__new__(cls)
+    env.model = fake_mj_model()
+    env.qpos_lim, env.qvel_lim, env.body_lim = 76, 75, 25
+    env.base_rot = [0.7071, 0.7071, 0.0, 0.0]
+    env.no_root = False
+    env.sim_iter = 15
+    env.rfc_rate = 1
+    env.ndof, env.vf_dim, env.meta_pd_dim = 69, 6, 0
+    cc = types.SimpleNamespace(obs_coord='root', obs_vel='full', action_v=1, meta_pd=False, meta_pd_joint=False,
+                               a_scale=KPM["a_scale"].copy(), jkp=KPM["kp"].copy(), jkd=KPM["kd"].copy(),
+                               torque_lim=KPM["torque_lim"].copy(), residual_force_scale=100.0, residual_force_lim=100.0,
+                               residual_force=True, residual_force_mode='implicit', action_type='position', obs_v=1,
+                               env_term_body='body', env_episode_len=100000)
+    env.cc_cfg = cc
+    env.body_qposaddr = {n: (7 + 3 * (i - 1), 10 + 3 * (i - 1)) for i, n in enumerate(NAMES) if i > 0}
+    env.jpos_diffw = np.ones((24, 1))
+    return env
+
+
+def patch_fullM():
+    def mj_fullM(model, M, qM_unused):
+        M[:] = 0
+        full = np.zeros((model.nv, model.nv))
+        full[:75, :75] = patch_fullM.M
+        M[:] = full.ravel()
+    him.mjf.mj_fullM = mj_fullM
+
+
+def gen_env_fixtures(hum):
+    rng = np.random.default_rng(102)
+    n = 24
+    rec = {k: [] for k in ["qpos", "qvel", "xpos", "xquat", "xipos", "target_qpos", "obs_cc", "bquat", "M", "bias", "ctrl",
+                           "torque", "rfc", "kin_action", "next_qpos", "body_diff", "head"]}
+    env = make_env(har.HumanoidAREnv)
+    env.smpl_humanoid = hum
+    env.pose_delta = False
+    patch_fullM()
+    for i in range(n):
+        q0 = rand_qpos(rng, 0.3); v0 = rng.normal(size=75) * 0.5
+        d = oracle_data(q0, v0)
+        if i == 5:
+            d.body_xquat[1, 0] = 0.0  # exercises the cur_quat[0,0]==0 fallback (humanoid_im.py:219-220)
+        env.data = d
+        env.model.nv = 75
+        tq = rand_qpos(rng, 0.3)
+        if i % 3 == 0:
+            tq[7:] += 2 * np.pi * rng.integers(-1, 2, size=69)  # exercises the 2*pi unwrap loops (:442-445)
+        env.target = hum.qpos_fk(tq.copy())
+        rec["qpos"].append(d.qpos[:76].copy()); rec["qvel"].append(d.qvel[:75].copy())
+        rec["xpos"].append(d.body_xpos[1:25].copy()); rec["xquat"].append(d.body_xquat[1:25].copy()); rec["xipos"].append(d.xipos[1:25].copy())
+        rec["target_qpos"].append(env.target["qpos"].copy())
+        rec["obs_cc"].append(env.get_full_obs_v1())
+        rec["bquat"].append(env.get_body_quat())
+        rec["head"].append(env.get_head())
+        rec["body_diff"].append(env.calc_body_diff())
+        # SPD torque + RFC with this M / bias
+        patch_fullM.M = d._M
+        ctrl = rng.normal(size=75) * 0.5
+        env.model.nv = 75
+        d.qfrc_bias = d.qfrc_bias[:75]
+        torque = env.compute_torque(ctrl.copy(), i_iter=0)
+        d.qfrc_applied = np.zeros(75)
+        env.rfc_implicit(ctrl[69:75].copy())
+        rec["M"].append(d._M); rec["bias"].append(d.qfrc_bias[:75].copy()); rec["ctrl"].append(ctrl)
+        rec["torque"].append(torque); rec["rfc"].append(d.qfrc_applied[:6].copy())
+        # step_ar
+        a = rng.normal(size=80) * 0.5
+        a[1:5] = rand_quat(rng)
+        rec["kin_action"].append(a); rec["next_qpos"].append(env.step_ar(a.copy()))
+    np.savez(os.path.join(OUT, "env_funcs.npz"), **{k: np.stack(v) for k, v in rec.items()})
+
+
+def gen_ar_obs_reward(hum):
+    rng = np.random.default_rng(103)
+    n, T = 12, 6
+    env = make_env(har.HumanoidAREnv)
+    env.smpl_humanoid = hum
+    env.kin_cfg = types.SimpleNamespace(use_context=False, use_of=False, use_head=True, use_vel=False, use_obj=True, use_action=True,
+                                        policy_specs={'reward_weights': dict(w_hp=0.15, w_hq=0.15, w_p=0.2, w_jp=0.2, w_act_p=0.2, w_act_v=0.1,
+                                                                            k_hp=45, k_hq=45, k_p=50, k_jp=50, k_act_p=5, k_act_v=0.005)})
+    env.ar_model_v = 1
+    env.policy_v = 1
+    env.action_index_map = [0, 7, 21, 28]; env.action_len = [7, 14, 7, 7]
+    env.frame_skip = 15  # dt is a property: model.opt.timestep * frame_skip
+    env.end_reward = 0.0
+    rec = {k: [] for k in ["qpos", "qvel", "xpos", "xquat", "xipos", "t", "head_pose", "head_vels", "obj_rel", "action_one_hot",
+                           "obs_ar", "target_qpos", "prev_bquat", "prev_hpos", "gt_bquat", "gt_prev_bquat", "gt_wbpos", "reward",
+                           "reward_info", "body_diff", "body_gt_diff", "obj_qpos"]}
+    for i in range(n):
+        q0 = rand_qpos(rng, 0.2); v0 = rng.normal(size=75) * 0.3
+        d = oracle_data(q0, v0)
+        one_hot = np.zeros(4)
+        if i % 4 == 1:
+            one_hot[0] = 1.0
+            d.qpos[76:83] = np.concatenate([rng.normal(size=3), rand_quat(rng)])
+        env.data = d
+        t = int(rng.integers(1, T - 1))
+        env.cur_t = t
+        gt_qpos = np.stack([rand_qpos(rng, 0.2) for _ in range(T)])
+        gt = hum.qpos_fk_batch(gt_qpos)
+        ctx = dict(action_one_hot=np.tile(one_hot, (T, 1)), head_pose=np.concatenate([rng.normal(size=(T, 3)), np.stack([rand_quat(rng) for _ in range(T)])], 1),
+                   head_vels=rng.normal(size=(T, 6)), obj_head_relative_poses=rng.normal(size=(T, 7)), qpos=gt_qpos, bquat=gt["bquat"].reshape(T, -1))
+        env.ar_context = ctx
+        env.gt_targets = gt
+        tq = rand_qpos(rng, 0.2)
+        env.target = hum.qpos_fk(tq.copy())
+        env.prev_bquat = hum.qpos_fk(rand_qpos(rng, 0.2))["bquat"].reshape(-1)
+        env.prev_hpos = np.concatenate([d.body_xpos[14] + rng.normal(size=3) * 0.01, rand_quat(rng)])
+        rec["qpos"].append(d.qpos[:76].copy()); rec["qvel"].append(d.qvel[:75].copy()); rec["obj_qpos"].append(d.qpos[76:111].copy())
+        rec["xpos"].append(d.body_xpos[1:25].copy()); rec["xquat"].append(d.body_xquat[1:25].copy()); rec["xipos"].append(d.xipos[1:25].copy())
+        rec["t"].append(t); rec["head_pose"].append(ctx["head_pose"][t]); rec["head_vels"].append(ctx["head_vels"][t])
+        rec["obj_rel"].append(ctx["obj_head_relative_poses"][t]); rec["action_one_hot"].append(one_hot)
+        rec["obs_ar"].append(env.get_ar_obs_v1())
+        rec["target_qpos"].append(env.target["qpos"].copy()); rec["prev_bquat"].append(env.prev_bquat.copy()); rec["prev_hpos"].append(env.prev_hpos.copy())
+        rec["gt_bquat"].append(ctx["bquat"][t]); rec["gt_prev_bquat"].append(ctx["bquat"][t - 1]); rec["gt_wbpos"].append(gt["wbpos"][t])
+        r, info = dynamic_supervision_v1(env, None, None, {"end": False})
+        rec["reward"].append(r); rec["reward_info"].append(info)
+        rec["body_diff"].append(env.calc_body_diff()); rec["body_gt_diff"].append(env.calc_body_gt_diff())
+    np.savez(os.path.join(OUT, "ar_obs_reward.npz"), **{k: np.stack(v) for k, v in rec.items()})
+
+
+def gen_gae_zfilter():
+    rng = np.random.default_rng(104)
+    B = 257
+    rewards = rng.uniform(0, 1, size=(B, 1)); values = rng.normal(size=(B, 1))
+    masks = np.ones((B, 1)); masks[rng.choice(B, 9, replace=False)] = 0; masks[-1] = 0
+    adv, ret = estimate_advantages(torch.tensor(rewards), torch.tensor(masks), torch.tensor(values), 0.95, 0.95)
+    zf = ZFilter((784,), clip=5)
+    xs = rng.normal(size=(50, 784)) * rng.uniform(0.1, 3, size=784) + rng.normal(size=784)
+    for x in xs:
+        zf(x)
+    x = rng.normal(size=784) * 4
+    np.savez(os.path.join(OUT, "gae_zfilter.npz"), rewards=rewards, values=values, masks=masks, adv=adv.numpy(), ret=ret.numpy(),
+             zf_mean=zf.rs.mean, zf_std=zf.rs.std, zf_x=x, zf_y=zf(x, update=False))
+
+
+def seeded_state_dict(module, seed):
+    rng = np.random.default_rng(seed)
+    sd = {}
+    for k, v in module.state_dict().items():
+        fan_in = v.shape[-1] if v.dim() > 1 else v.shape[0]
+        sd[k] = torch.tensor(rng.standard_normal(tuple(v.shape)) / np.sqrt(max(fan_in, 1)))
+    return sd
+
+
+def gen_policies():
+    cfg = types.SimpleNamespace(policy_hsize=[512, 256], policy_htype='relu', fix_std=True, log_std=-2.3, num_primitive=8)
+    cfg.get = lambda k, dflt=None: getattr(cfg, k, dflt)
+    pol = PolicyMCP(cfg, action_dim=75, state_dim=784)
+    pol.load_state_dict(seeded_state_dict(pol, 7))
+    val = Value(MLP(105, [512, 256], 'relu'))
+    val.load_state_dict(seeded_state_dict(val, 8))
+    rng = np.random.default_rng(105)
+    x = np.clip(rng.normal(size=(16, 784)) * 1.5, -5, 5); s = rng.normal(size=(16, 105))
+    with torch.no_grad():
+        mean = pol.forward(torch.tensor(x)).loc.numpy()
+        w = pol.composer(torch.tensor(x)).numpy()
+        v = val(torch.tensor(s)).numpy()
+    np.savez(os.path.join(OUT, "policies.npz"), mcp_seed=7, value_seed=8, x=x, mcp_mean=mean, mcp_weights=w, s=s, value=v,
+             mcp_keys=np.array(list(pol.state_dict().keys())), value_keys=np.array(list(val.state_dict().keys())))
+
+
+if __name__ == "__main__":
+    np.savez(os.path.join(OUT, "standing_neutral.npz"), **{k: v for k, v in
+             __import__("joblib").load(os.path.join(REF, "sample_data/standing_neutral.pkl")).items() if k in ("qpos", "qvel")})
+    hum = make_humanoid()
+    gen_quat_utils()
+    gen_fk(hum)
+    gen_env_fixtures(hum)
+    gen_ar_obs_reward(hum)
+    gen_gae_zfilter()
+    gen_policies()
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
