@@ -61,6 +61,11 @@ int kp_sim_set_state(kp_sim*, const float* qpos, const float* qvel, const uint8_
  * target_qpos [N,76] is copied; the target dict {qpos, wbpos, wbquat, bquat, body_com} is kept on device. */
 int kp_sim_set_target(kp_sim*, const float* target_qpos, const uint8_t* env_mask);
 
+/* Humanoid.qpos_fk_batch(qpos) (numpy_smpl_humanoid.py:124-178) on n_rows arbitrary rows, used by
+ * load_context for the GT clip (humanoid_ar_v1.py:87): qpos [n_rows,76] -> qpos_out [n_rows,76] (root quat
+ * normalised), wbpos [n_rows,72], wbquat [n_rows,96], bquat [n_rows,96], body_com [n_rows,72]; outputs may be NULL. */
+int kp_sim_fk(kp_sim*, int n_rows, const float* qpos, float* qpos_out, float* wbpos, float* wbquat, float* bquat, float* body_com);
+
 /* HumanoidEnv.do_simulation(cc_action, n_substeps)   (humanoid_im.py:506-533): per substep stable-PD
  * torque (compute_torque :433-480), clip, rfc_implicit (:497-504), sim.step() (:527).  cc_action [N,75]. */
 int kp_sim_step_ctrl(kp_sim*, const float* cc_action, int n_substeps, const uint8_t* env_mask);
@@ -145,6 +150,12 @@ int kp_sim_diag(kp_sim*, int32_t* out_host);
 /* seconds the last kp_sim_step_ctrl launch took, measured with HIP events on the sim's stream
  * (synchronises); -1 if none recorded. */
 double kp_sim_last_step_seconds(kp_sim*);
+
+/* Launch-duration statistics of kp_sim_step_ctrl: every launch after kp_sim_timing_reset() is bracketed
+ * by a HIP event pair on the sim's stream (up to 4096 launches, no host sync while recording).
+ * kp_sim_timing_mean_seconds() synchronises once and returns the mean duration (count in *n_launches). */
+int kp_sim_timing_reset(kp_sim*);
+double kp_sim_timing_mean_seconds(kp_sim*, int* n_launches);
 
 const char* kp_last_error(void);
 const char* kp_version(void);

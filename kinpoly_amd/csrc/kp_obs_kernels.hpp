@@ -91,11 +91,14 @@ __global__ void k_target_fk(int n, const float* __restrict__ tq, const uint8_t* 
     Q4 rq = Q4{q[3], q[4], q[5], q[6]};
     float rn = sqrtf(rq.w * rq.w + rq.x * rq.x + rq.y * rq.y + rq.z * rq.z);
     rq = Q4{rq.w / rn, rq.x / rn, rq.y / rn, rq.z / rn};  // fix_quat: root_rotations /= norm (no zero guard in the reference)
-    for (int i = 0; i < D_NQ; i++) oq[i] = q[i];
-    oq[3] = rq.w; oq[4] = rq.x; oq[5] = rq.y; oq[6] = rq.z;
+    if (B.qpos) {
+        for (int i = 0; i < D_NQ; i++) oq[i] = q[i];
+        oq[3] = rq.w; oq[4] = rq.x; oq[5] = rq.y; oq[6] = rq.z;
+    }
     for (int b = 0; b < D_NB; b++) {
         Q4 wqb; V3 pos;
-        float* obq = B.bquat + (size_t)e * 96 + 4 * b;
+        float dummy[4];
+        float* obq = B.bquat ? B.bquat + (size_t)e * 96 + 4 * b : dummy;
         if (b == 0) {
             wqb = rq; pos = v3(q[0], q[1], q[2]);
             obq[0] = rq.w; obq[1] = rq.x; obq[2] = rq.y; obq[3] = rq.z;
@@ -110,10 +113,9 @@ __global__ void k_target_fk(int n, const float* __restrict__ tq, const uint8_t* 
         }
         wq[b][0] = wqb.w; wq[b][1] = wqb.x; wq[b][2] = wqb.y; wq[b][3] = wqb.z;
         wp[b][0] = pos.x; wp[b][1] = pos.y; wp[b][2] = pos.z;
-        st3(B.wbpos + (size_t)e * 72 + 3 * b, pos);
-        float* owq = B.wbquat + (size_t)e * 96 + 4 * b;
-        owq[0] = wqb.w; owq[1] = wqb.x; owq[2] = wqb.y; owq[3] = wqb.z;
-        st3(B.com + (size_t)e * 72 + 3 * b, q_mul_vec(wqb, ld3(body_ipos + 3 * b)) + pos);
+        if (B.wbpos) st3(B.wbpos + (size_t)e * 72 + 3 * b, pos);
+        if (B.wbquat) { float* owq = B.wbquat + (size_t)e * 96 + 4 * b; owq[0] = wqb.w; owq[1] = wqb.x; owq[2] = wqb.y; owq[3] = wqb.z; }
+        if (B.com) st3(B.com + (size_t)e * 72 + 3 * b, q_mul_vec(wqb, ld3(body_ipos + 3 * b)) + pos);
     }
 }
 

@@ -41,6 +41,10 @@ struct kp_sim {
     int* diag = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    std::vector<hipEvent_t> ring;  // event pairs of the recorded launches
+    int ring_used = 0;
+    bool ring_on = false;
+    hipEvent_t last0 = nullptr, last1 = nullptr;
 };
 
 namespace {
@@ -139,7 +143,17 @@ int launch_step(kp_sim* s, const float* action, int nsub, const uint8_t* mask, b
     A.target_qpos = s->t_qpos; A.action = action; A.env_mask = mask;
     A.xpos = s->xpos; A.xquat = s->xquat; A.xipos = s->xipos; A.diag = s->diag;
     size_t lds = sizeof(kp::EnvLds);
-    if (time_it) HIP_OK(hipEventRecord(s->ev0, s->stream));
+    hipEvent_t e0 = s->ev0, e1 = s->ev1;
+    if (time_it && s->ring_on && s->ring_used < 4096) {
+        if ((int)s->ring.size() < 2 * (s->ring_used + 1)) {
+            hipEvent_t a, b;
+            HIP_OK(hipEventCreate(&a)); HIP_OK(hipEventCreate(&b));
+            s->ring.push_back(a); s->ring.push_back(b);
+        }
+        e0 = s->ring[2 * s->ring_used]; e1 = s->ring[2 * s->ring_used + 1];
+        s->ring_used++;
+    }
+    if (time_it) HIP_OK(hipEventRecord(e0, s->stream));
     switch (s->model->threads) {
         case 64: hipLaunchKernelGGL(kp::kp_step_kernel<64>, dim3(s->n), dim3(64), lds, s->stream, A); break;
         case 128: hipLaunchKernelGGL(kp::kp_step_kernel<128>, dim3(s->n), dim3(128), lds, s->stream, A); break;
@@ -147,7 +161,10 @@ int launch_step(kp_sim* s, const float* action, int nsub, const uint8_t* mask, b
         default: return fail("threads_per_env must be 64, 128 or 256");
     }
     HIP_OK(hipGetLastError());
-    if (time_it) { HIP_OK(hipEventRecord(s->ev1, s->stream)); s->timed = true; }
+    if (time_it) {
+        HIP_OK(hipEventRecord(e1, s->stream));
+        s->last0 = e0; s->last1 = e1; s->timed = true;
+    }
     return 0;
 }
 
@@ -224,6 +241,7 @@ void kp_sim_destroy(kp_sim* s) {
     hipSetDevice(s->device);
     hipStreamSynchronize(s->stream);
     for (void* p : s->allocs) hipFree(p);
+    for (hipEvent_t e : s->ring) hipEventDestroy(e);
     if (s->ev0) hipEventDestroy(s->ev0);
     if (s->ev1) hipEventDestroy(s->ev1);
     delete s;
@@ -258,6 +276,16 @@ int kp_sim_set_target(kp_sim* s, const float* tq, const uint8_t* mask) {
     HIP_OK(hipSetDevice(s->device));
     kp::TargetBufs B{s->t_qpos, s->t_wbpos, s->t_wbquat, s->t_bquat, s->t_com};
     hipLaunchKernelGGL(kp::k_target_fk, dim3((s->n + 63) / 64), dim3(64), 0, s->stream, s->n, tq, mask, B, s->T.body_pos, s->T.body_ipos, s->T.body_parent);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int kp_sim_fk(kp_sim* s, int n_rows, const float* qpos, float* qpos_out, float* wbpos, float* wbquat, float* bquat, float* com) {
+    if (!s || !qpos || n_rows <= 0) return fail("kp_sim_fk: bad arguments");
+    HIP_OK(hipSetDevice(s->device));
+    kp::TargetBufs B{qpos_out, wbpos, wbquat, bquat, com};
+    hipLaunchKernelGGL(kp::k_target_fk, dim3((n_rows + 63) / 64), dim3(64), 0, s->stream, n_rows, qpos, (const uint8_t*)nullptr, B,
+                       s->T.body_pos, s->T.body_ipos, s->T.body_parent);
     HIP_OK(hipGetLastError());
     return 0;
 }
@@ -407,10 +435,30 @@ int kp_sim_diag(kp_sim* s, int32_t* out_host) {
 
 double kp_sim_last_step_seconds(kp_sim* s) {
     if (!s || !s->timed) return -1.0;
-    if (hipEventSynchronize(s->ev1) != hipSuccess) return -1.0;
+    if (hipEventSynchronize(s->last1) != hipSuccess) return -1.0;
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, s->ev0, s->ev1) != hipSuccess) return -1.0;
+    if (hipEventElapsedTime(&ms, s->last0, s->last1) != hipSuccess) return -1.0;
     return ms * 1e-3;
+}
+
+int kp_sim_timing_reset(kp_sim* s) {
+    if (!s) return fail("kp_sim_timing_reset: null argument");
+    s->ring_used = 0; s->ring_on = true;
+    return 0;
+}
+
+double kp_sim_timing_mean_seconds(kp_sim* s, int* n_launches) {
+    if (n_launches) *n_launches = 0;
+    if (!s || s->ring_used == 0) return -1.0;
+    if (hipStreamSynchronize(s->stream) != hipSuccess) return -1.0;
+    double tot = 0.0;
+    for (int i = 0; i < s->ring_used; i++) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s->ring[2 * i], s->ring[2 * i + 1]) != hipSuccess) return -1.0;
+        tot += ms;
+    }
+    if (n_launches) *n_launches = s->ring_used;
+    return tot * 1e-3 / s->ring_used;
 }
 
 }  // extern "C"

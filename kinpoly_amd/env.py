@@ -1,0 +1,283 @@
+"""Batched `HumanoidAREnv` on the HIP simulator + a single-env facade with the reference surface.
+
+`BatchedHumanoidAREnv` runs N environments in lock-step on one GPU; its `step()` is the batched
+restatement of HumanoidAREnv.step (kin_poly/envs/humanoid_ar_v1.py:243-323):
+
+    step_begin        prev_bquat / prev_hpos snapshots                     :246-249
+    step_kin          next_qpos = step_ar(a)                               :252  (216-241)
+    set_target        target = smpl_humanoid.qpos_fk(next_qpos)            :256
+    obs_cc (+ZFilter) cc_obs = cc_running_state(get_cc_obs(), update=False):265-266
+    cc_policy         cc_action = cc_policy.select_action(cc_obs, mean)    :267-268
+    step_ctrl         do_simulation(cc_action, frame_skip=15)              :286
+    cur_t += 1; term_reward: fail / end / done                             :288-316
+    obs_ar            obs = get_ar_obs_v1()                                :322
+
+All tensors stay on the device; nothing here touches the CPU oracle.
+`HumanoidAREnv` wraps a 1-env batch and speaks numpy float64, so the callers in
+kin_poly/core/agent_ar.py:463-611 and scripts/eval_ar_policy.py:178-222 can use it unchanged.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import sim as kpsim
+from .nets import PolicyMCP
+
+CTX_KEYS = ("qpos", "head_pose", "head_vels", "obj_head_relative_poses", "action_one_hot", "init_qpos", "init_qvel")
+
+
+class RunningState:
+    """Device view of the reference's ZFilter/RunningStat (uhc/khrylib/utils/zfilter.py) used with update=False."""
+
+    def __init__(self, mean, std, clip=5.0, device="cuda"):
+        self.mean = torch.as_tensor(mean, dtype=torch.float32, device=device).contiguous()
+        self.std = torch.as_tensor(std, dtype=torch.float32, device=device).contiguous()
+        self.clip = float(clip)
+
+    @classmethod
+    def identity(cls, dim=784, clip=5.0, device="cuda"):
+        return cls(np.zeros(dim), np.ones(dim), clip, device)
+
+
+class BatchedHumanoidAREnv:
+    def __init__(self, n_envs, device=0, kpm_path=kpsim.DEFAULT_KPM, cc_policy: PolicyMCP | None = None,
+                 cc_running_state: RunningState | None = None, mode="train", wild=False, joint_controller=False,
+                 env_episode_len=100000, body_diff_thresh=10.0, body_diff_gt_thresh=12.0, model_options=None, seed=0):
+        self.n = int(n_envs)
+        self.model = kpsim.KpModel(kpm_path, **(model_options or {}))
+        self.sim = kpsim.KpSim(self.model, self.n, device)
+        self.device = self.sim.device
+        self.mode, self.wild, self.joint_controller = mode, wild, joint_controller
+        self.env_episode_len = env_episode_len
+        self.frame_skip = 15
+        self.dt = self.model.get_option("timestep") * self.frame_skip
+        self.cc_policy = (cc_policy if cc_policy is not None else PolicyMCP()).to(self.device).float()
+        self.cc_running_state = cc_running_state if cc_running_state is not None else RunningState.identity(device=self.device)
+        self.reward_cfg = kpsim.KpRewardCfg.default(use_gt_term=(mode == "train" and not wild))
+        self.reward_cfg.body_diff_thresh = body_diff_thresh
+        self.reward_cfg.body_diff_gt_thresh = body_diff_gt_thresh
+        self.gen = torch.Generator(device=self.device)
+        self.gen.manual_seed(seed)
+        self.cur_t = torch.zeros(self.n, dtype=torch.int32, device=self.device)
+        self.ctx = None
+        self.ctx_len = None
+        self._ctx_struct = None
+        self.end_reward = 0.0
+        self.action_dim, self.obs_dim, self.cc_action_dim = 80, kpsim.AR_OBS_DIM, kpsim.CC_ACTION_DIM
+        # persistent I/O buffers (no per-step allocation)
+        f = lambda d: torch.empty((self.n, d), dtype=torch.float32, device=self.device)  # noqa: E731
+        self._next_qpos, self._cc_obs, self._obs = f(76), f(784), f(105)
+        self._reward, self._info, self._diffs = torch.empty(self.n, device=self.device), f(6), f(2)
+        self._fail = torch.empty(self.n, dtype=torch.uint8, device=self.device)
+
+    # ------------------------------------------------------------------ reference surface
+    def seed(self, seed):
+        self.gen.manual_seed(int(seed))
+        return [seed]
+
+    def set_mode(self, mode):
+        self.mode = mode
+        self.reward_cfg.use_gt_term = int(mode == "train" and not self.wild)
+
+    def load_context(self, ctx: dict, env_mask: torch.Tensor | None = None):
+        """ctx tensors are [N, T, .] (action_one_hot [N, T, 4] or [N, 4]; init_qpos/init_qvel [N, .]).
+        With env_mask (bool [N]) only those envs' rows are replaced (T must match)."""
+        T = ctx["qpos"].shape[1]
+        new = {k: ctx[k].to(self.device, torch.float32) for k in CTX_KEYS}
+        if new["action_one_hot"].dim() == 3:
+            new["action_one_hot"] = new["action_one_hot"][:, 0]
+        if "obj_pose" in ctx:
+            new["obj_pose"] = ctx["obj_pose"].to(self.device, torch.float32)
+        if self.ctx is None or env_mask is None or self.ctx["qpos"].shape[1] != T:
+            if env_mask is not None and self.ctx is not None:
+                raise ValueError("masked load_context needs the same clip length T")
+            self.ctx = {k: v.contiguous().clone() for k, v in new.items()}
+            rows = self.ctx["qpos"].reshape(-1, 76).contiguous()
+            gt = self.sim.fk(rows)
+            self.ctx["gt_bquat"] = gt["bquat"].view(self.n, T, 96).contiguous()
+            self.ctx["gt_wbpos"] = gt["wbpos"].view(self.n, T, 72).contiguous()
+        else:
+            m = env_mask.to(self.device, torch.bool)
+            idx = m.nonzero(as_tuple=True)[0]
+            if idx.numel():
+                for k, v in new.items():
+                    self.ctx[k][idx] = v[idx]
+                rows = self.ctx["qpos"][idx].reshape(-1, 76).contiguous()
+                # qpos_fk_batch works on any row count; pad through a temp sim-independent call
+                gt = self.sim.fk(rows)
+                self.ctx["gt_bquat"][idx] = gt["bquat"].view(-1, T, 96)
+                self.ctx["gt_wbpos"][idx] = gt["wbpos"].view(-1, T, 72)
+        self.ctx_len = T - 1
+        c = self.ctx
+        self._ctx_struct = self.sim.make_ctx(T, c["head_pose"], c["head_vels"], c["obj_head_relative_poses"], c["action_one_hot"],
+                                             c["gt_bquat"], c["gt_wbpos"], self.cur_t)
+
+    def reset(self, env_mask: torch.Tensor | None = None):
+        """sim.reset(); cur_t = 0; reset_model(): state <- ar_context init_qpos/init_qvel, target = FK(init) (:334-387)."""
+        m8 = None if env_mask is None else env_mask.to(self.device, torch.uint8).contiguous()
+        if env_mask is None:
+            self.cur_t.zero_()
+        else:
+            self.cur_t.masked_fill_(env_mask.to(self.device, torch.bool), 0)
+        self.sim.set_state(self.ctx["init_qpos"], self.ctx["init_qvel"], m8)
+        self.sim.set_target(self.ctx["init_qpos"], m8)
+        return self.sim.obs_ar(self._ctx_struct, self._obs)
+
+    def step(self, a: torch.Tensor):
+        sim = self.sim
+        sim.step_begin()
+        sim.step_kin(a, self._next_qpos)
+        sim.set_target(self._next_qpos)
+        rs = self.cc_running_state
+        cc_obs = sim.obs_cc(self._cc_obs, rs.mean, rs.std, rs.clip)
+        mean_action = self.mode == "test" or (self.mode == "train" and self.joint_controller)
+        with torch.no_grad():
+            cc_action = self.cc_policy.select_action(cc_obs, mean_action, self.gen).contiguous()
+        sim.step_ctrl(cc_action, self.frame_skip)
+        self.cur_t += 1
+        reward, info6, fail, diffs = sim.term_reward(self._ctx_struct, self.reward_cfg, self._reward, self._info, self._fail, self._diffs)
+        end = (self.cur_t >= self.env_episode_len) | (self.cur_t >= self.ctx_len)
+        done = fail.bool() | end
+        obs = sim.obs_ar(self._ctx_struct, self._obs)
+        info = {"fail": fail.bool(), "end": end, "percent": self.cur_t.float() / self.ctx_len, "cc_action": cc_action, "cc_state": cc_obs,
+                "custom_reward": reward, "custom_info": info6, "body_diff": diffs}
+        return obs, torch.ones(self.n, device=self.device), done, info
+
+    # getters (device tensors; reference names)
+    def get_humanoid_qpos(self):
+        return self.sim.get("qpos")
+
+    def get_humanoid_qvel(self):
+        return self.sim.get("qvel")
+
+    def get_head(self):
+        return self.sim.get("head")
+
+    def get_body_quat(self):
+        return self.sim.get("bquat")
+
+    def get_wbody_pos(self):
+        return self.sim.get("xpos")
+
+    def get_wbody_quat(self):
+        return self.sim.get("xquat")
+
+    def get_body_com(self):
+        return self.sim.get("xipos")
+
+    @property
+    def target(self):
+        g = self.sim.get
+        return {"qpos": g("target_qpos"), "wbpos": g("target_wbpos"), "wbquat": g("target_wbquat"), "bquat": g("target_bquat"),
+                "body_com": g("target_com")}
+
+
+def standing_context(n, T, std_qpos, std_qvel, sim: kpsim.KpSim, headings: torch.Tensor | None = None):
+    """Synthetic per-env context of SURVEY.md section 8(d) config 3: the standing clip repeated T frames, objects
+    absent (obj_pose = [0,0,0,1,0,0,0], action_one_hot = 0; kin_poly/data_process/process_smpl.py:223-225),
+    head_vels = 0, obj_head_relative_poses by the rule of process_smpl.py:110-135.  Optional per-env heading
+    rotation (radians) about z."""
+    dev = sim.device
+    q = torch.tensor(std_qpos, dtype=torch.float32, device=dev).repeat(n, 1)
+    if headings is not None:
+        h = headings.to(dev, torch.float32)
+        hq = torch.stack([torch.cos(h / 2), torch.zeros_like(h), torch.zeros_like(h), torch.sin(h / 2)], 1)
+        w0, x0, y0, z0 = q[:, 3], q[:, 4], q[:, 5], q[:, 6]
+        w1, x1, y1, z1 = hq.unbind(1)
+        q[:, 3:7] = torch.stack([w1 * w0 - x1 * x0 - y1 * y0 - z1 * z0, w1 * x0 + x1 * w0 + y1 * z0 - z1 * y0,
+                                 w1 * y0 - x1 * z0 + y1 * w0 + z1 * x0, w1 * z0 + x1 * y0 - y1 * x0 + z1 * w0], 1)
+    fk = sim.fk(q.contiguous())
+    head = torch.cat([fk["wbpos"].view(n, 24, 3)[:, 13], fk["wbquat"].view(n, 24, 4)[:, 13]], 1)  # [n,7]
+    # object [0,0,0 | 1,0,0,0] relative to the head in the head's heading frame
+    hw, hz = head[:, 3], head[:, 6]
+    hn = torch.sqrt(hw * hw + hz * hz)
+    c, s = hw / hn, hz / hn                       # heading quaternion (c,0,0,s)
+    cos_t, sin_t = c * c - s * s, 2 * c * s       # rotation by the heading angle
+    d = -head[:, :3]
+    loc = torch.stack([cos_t * d[:, 0] + sin_t * d[:, 1], -sin_t * d[:, 0] + cos_t * d[:, 1], d[:, 2]], 1)  # R^T d
+    objq = torch.stack([c, torch.zeros_like(c), torch.zeros_like(c), -s], 1)                               # inverse(heading) (x) identity
+    obj_rel = torch.cat([loc, objq], 1)
+    rep = lambda x: x.unsqueeze(1).repeat(1, T, 1).contiguous()  # noqa: E731
+    return {"qpos": rep(q), "head_pose": rep(head), "head_vels": torch.zeros((n, T, 6), device=dev), "obj_head_relative_poses": rep(obj_rel),
+            "action_one_hot": torch.zeros((n, 4), device=dev), "init_qpos": q.contiguous(),
+            "init_qvel": torch.tensor(std_qvel, dtype=torch.float32, device=dev).repeat(n, 1).contiguous()}
+
+
+class HumanoidAREnv:
+    """Single-environment facade with the reference constructor and numpy float64 I/O
+    (kin_poly/envs/humanoid_ar_v1.py:28).  `cfg` / `cc_cfg` are duck-typed: only `policy_specs` thresholds,
+    `joint_controller`, `env_episode_len` are read if present; a trained UHC checkpoint can be passed as
+    `cc_state=(policy_dict, running_state mean, std)`."""
+
+    def __init__(self, cfg=None, cc_cfg=None, init_context=None, cc_iter=-1, mode="train", wild=False, ar_mode=False, cc_state=None, device=0):
+        ps = getattr(cfg, "policy_specs", {}) or {}
+        pol = PolicyMCP()
+        rs = None
+        if cc_state is not None:
+            pol.load_state_dict(cc_state[0])
+            rs = RunningState(cc_state[1], cc_state[2], 5.0, torch.device("cuda", device))
+        self.b = BatchedHumanoidAREnv(1, device, cc_policy=pol, cc_running_state=rs, mode=mode, wild=wild,
+                                      joint_controller=bool(getattr(cfg, "joint_controller", False)),
+                                      env_episode_len=int(getattr(cc_cfg, "env_episode_len", 100000)),
+                                      body_diff_thresh=ps.get("body_diff_thresh", 10), body_diff_gt_thresh=ps.get("body_diff_gt_thresh", 12))
+        self.kin_cfg, self.cc_cfg, self.ar_mode = cfg, cc_cfg, ar_mode
+        self.cc_policy, self.cc_running_state = self.b.cc_policy, self.b.cc_running_state
+        self.dt, self.end_reward = self.b.dt, 0.0
+        self.prev_bquat = self.prev_hpos = self.prev_qpos = self.prev_qvel = None
+        if init_context is not None:
+            self.load_context(init_context)
+
+    def seed(self, seed):
+        self.np_random = np.random.RandomState(seed)
+        return self.b.seed(seed)
+
+    def set_mode(self, mode):
+        self.b.set_mode(mode)
+
+    @property
+    def cur_t(self):
+        return int(self.b.cur_t[0])
+
+    def load_context(self, data_dict):
+        """data_dict: tensors [1, T, .] as produced by PolicyAR.init_context (policy_ar.py:124-182)."""
+        self.ar_context = {k: (v[0].detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)[0]) for k, v in data_dict.items()}
+        self.ar_context["len"] = self.ar_context["qpos"].shape[0] - 1
+        ctx = {k: torch.as_tensor(np.asarray(self.ar_context[k]), dtype=torch.float32)[None] for k in
+               ("qpos", "head_pose", "head_vels", "obj_head_relative_poses", "action_one_hot")}
+        key_q, key_v = ("ar_qpos", "ar_qvel") if self.ar_mode else ("init_qpos", "init_qvel")
+        iq, iv = self.ar_context[key_q], self.ar_context[key_v]
+        ctx["init_qpos"] = torch.as_tensor(iq[0] if iq.ndim == 2 else iq, dtype=torch.float32)[None]
+        ctx["init_qvel"] = torch.as_tensor(iv[0] if iv.ndim == 2 else iv, dtype=torch.float32)[None]
+        self.b.load_context(ctx)
+
+    def reset(self):
+        return self.b.reset()[0].double().cpu().numpy()
+
+    def step(self, a):
+        self.prev_qpos, self.prev_qvel = self.get_humanoid_qpos(), self.get_humanoid_qvel()
+        obs, r, done, info = self.b.step(torch.as_tensor(np.asarray(a), dtype=torch.float32, device=self.b.device)[None].contiguous())
+        self.prev_bquat = self.b.sim.get("prev_bquat")[0].double().cpu().numpy()
+        self.prev_hpos = self.b.sim.get("prev_hpos")[0].double().cpu().numpy()
+        out_info = {"fail": bool(info["fail"][0]), "end": bool(info["end"][0]), "percent": float(info["percent"][0]),
+                    "cc_action": info["cc_action"][0].double().cpu().numpy(), "cc_state": info["cc_state"][0].double().cpu().numpy()}
+        self._last_reward = (float(info["custom_reward"][0]), info["custom_info"][0].double().cpu().numpy())
+        return obs[0].double().cpu().numpy(), 1.0, bool(done[0]), out_info
+
+    def _g(self, name):
+        return self.b.sim.get(name)[0].double().cpu().numpy()
+
+    def get_humanoid_qpos(self): return self._g("qpos")
+    def get_humanoid_qvel(self): return self._g("qvel")
+    def get_head(self): return self._g("head")
+    def get_body_quat(self): return self._g("bquat")
+    def get_wbody_pos(self): return self._g("xpos")
+    def get_wbody_quat(self): return self._g("xquat")
+    def get_body_com(self): return self._g("xipos")
+
+    def get_obj_qpos(self, action_one_hot=None):
+        return np.array([0, 0, 0, 1, 0, 0, 0.0]) if action_one_hot is not None else np.zeros(35)
+
+    @property
+    def target(self):
+        return {k: v[0].double().cpu().numpy() for k, v in self.b.target.items()}

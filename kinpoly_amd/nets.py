@@ -1,0 +1,158 @@
+"""Policy / value networks of the rollout path, batched over environments on the GPU.
+
+Parameter names mirror the reference modules so the reference's checkpoints (`policy_dict`,
+`value_dict`, `cc_dict`; kin_poly/core/agent_ar.py:341-364) load with `load_state_dict`:
+
+  MLP          uhc/khrylib/models/mlp.py:5-25          (affine_layers.N.{weight,bias})
+  Value        uhc/khrylib/rl/core/critic.py:5-18      (net, value_head)
+  PolicyMCP    uhc/core/policy_mcp.py:9-38             (nets.K.0 = MLP, nets.K.1 = Linear, composer.0 = MLP)
+  KinPolicy    kin_poly/models/traj_ar_smpl_net.py:48-53,333-343 + policy_ar.py:317-320
+               (action_rnn.rnn_f = GRUCell, action_mlp, action_fc; fixed log_std, kin_poly.yml:38)
+
+The GEMMs run through hipBLASLt (MFMA) via torch; PolicyMCP fuses its 8 primitive MLPs + composer
+into three batched GEMMs instead of 9 x 3 small ones.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+
+class MLP(nn.Module):
+    def __init__(self, input_dim, hidden_dims=(128, 128), activation="tanh"):
+        super().__init__()
+        self.activation = {"tanh": torch.tanh, "relu": torch.relu, "sigmoid": torch.sigmoid}[activation]
+        self.out_dim = hidden_dims[-1]
+        self.affine_layers = nn.ModuleList()
+        last = input_dim
+        for nh in hidden_dims:
+            self.affine_layers.append(nn.Linear(last, nh))
+            last = nh
+
+    def forward(self, x):
+        for affine in self.affine_layers:
+            x = self.activation(affine(x))
+        return x
+
+
+class Value(nn.Module):
+    def __init__(self, net, net_out_dim=None):
+        super().__init__()
+        self.net = net
+        self.value_head = nn.Linear(net.out_dim if net_out_dim is None else net_out_dim, 1)
+        self.value_head.weight.data.mul_(0.1)
+        self.value_head.bias.data.mul_(0.0)
+
+    def forward(self, x):
+        return self.value_head(self.net(x))
+
+
+class PolicyMCP(nn.Module):
+    """Multiplicative-compositional UHC controller: sum_k softmax(composer(x))_k * net_k(x)."""
+
+    def __init__(self, state_dim=784, action_dim=75, policy_hsize=(512, 256), policy_htype="relu", num_primitive=8,
+                 composer_dim=(300, 200), log_std=-2.3, fix_std=True):
+        super().__init__()
+        self.type = "gaussian"
+        self.num_primitive = num_primitive
+        self.nets = nn.ModuleList()
+        for _ in range(num_primitive):
+            action_mean = nn.Linear(policy_hsize[-1], action_dim)
+            action_mean.weight.data.mul_(0.1)
+            action_mean.bias.data.mul_(0.0)
+            self.nets.append(nn.Sequential(MLP(state_dim, policy_hsize, policy_htype), action_mean))
+        self.composer = nn.Sequential(MLP(state_dim, list(composer_dim) + [num_primitive], policy_htype), nn.Softmax(dim=1))
+        self.action_log_std = nn.Parameter(torch.ones(1, action_dim) * log_std, requires_grad=not fix_std)
+        self._fused = None
+
+    def _fuse(self):
+        """[K*h1, in], [K, h1, h2], [K, h2, A] stacked weights (rebuilt when parameters change version)."""
+        ver = tuple(p._version for p in self.parameters())
+        if self._fused is None or self._fused[0] != ver:
+            w1 = torch.cat([n[0].affine_layers[0].weight for n in self.nets], 0)
+            b1 = torch.cat([n[0].affine_layers[0].bias for n in self.nets], 0)
+            w2 = torch.stack([n[0].affine_layers[1].weight.t() for n in self.nets], 0)
+            b2 = torch.stack([n[0].affine_layers[1].bias for n in self.nets], 0)
+            w3 = torch.stack([n[1].weight.t() for n in self.nets], 0)
+            b3 = torch.stack([n[1].bias for n in self.nets], 0)
+            self._fused = (ver, tuple(t.detach().contiguous() for t in (w1, b1, w2, b2, w3, b3)))
+        return self._fused[1]
+
+    def action_mean(self, x):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            x_all = torch.stack([net(x) for net in self.nets], dim=1)  # training path: plain modules
+        else:
+            w1, b1, w2, b2, w3, b3 = self._fuse()
+            K = self.num_primitive
+            h = torch.relu(torch.addmm(b1, x, w1.t()))                   # [N, K*h1]
+            h = h.view(x.shape[0], K, -1).transpose(0, 1)                # [K, N, h1]
+            h = torch.relu(torch.baddbmm(b2.unsqueeze(1), h, w2))        # [K, N, h2]
+            x_all = torch.baddbmm(b3.unsqueeze(1), h, w3).transpose(0, 1)  # [N, K, A]
+        weight = self.composer(x)
+        return torch.sum(weight[:, :, None] * x_all, dim=1)
+
+    def forward(self, x):
+        mean = self.action_mean(x)
+        return mean, self.action_log_std.expand_as(mean)
+
+    def select_action(self, x, mean_action=False, generator=None):
+        mean, log_std = self.forward(x)
+        if mean_action:
+            return mean
+        return mean + torch.exp(log_std) * torch.randn(mean.shape, device=mean.device, dtype=mean.dtype, generator=generator)
+
+
+class _StepRNN(nn.Module):
+    """RNN(cell_type='gru') in 'step' mode (uhc/khrylib/models/rnn.py:5-36) with a batched hidden state."""
+
+    def __init__(self, input_dim, out_dim):
+        super().__init__()
+        self.rnn_f = nn.GRUCell(input_dim, out_dim)
+
+
+class KinPolicy(nn.Module):
+    """The per-step part of PolicyAR / TrajARNet: h <- GRUCell(x, h); MLP([x, h]); fc -> 80-d action."""
+
+    def __init__(self, state_dim=105, action_dim=80, rnn_hdim=1024, mlp_hsize=(1024, 512, 256), htype="relu", log_std=-3.2):
+        super().__init__()
+        self.state_dim, self.action_dim, self.rnn_hdim = state_dim, action_dim, rnn_hdim
+        self.action_rnn = _StepRNN(state_dim, rnn_hdim)
+        self.action_mlp = MLP(rnn_hdim + state_dim, mlp_hsize, htype)
+        self.action_fc = nn.Linear(mlp_hsize[-1], action_dim)
+        self.action_log_std = nn.Parameter(torch.ones(1, action_dim) * log_std, requires_grad=False)
+
+    def init_hidden(self, n, device=None):
+        return torch.zeros((n, self.rnn_hdim), device=device or self.action_fc.weight.device, dtype=self.action_fc.weight.dtype)
+
+    def get_action(self, state, hx):
+        hx = self.action_rnn.rnn_f(state, hx)
+        x = torch.cat((state, hx), dim=1)
+        return self.action_fc(self.action_mlp(x)), hx
+
+    def select_action(self, state, hx, mean_action=False, generator=None):
+        mean, hx = self.get_action(state, hx)
+        if mean_action:
+            return mean, hx
+        noise = torch.randn(mean.shape, device=mean.device, dtype=mean.dtype, generator=generator)
+        return mean + torch.exp(self.action_log_std) * noise, hx
+
+    def log_prob(self, mean, action):
+        """DiagGaussian.log_prob summed over the action dims (uhc/khrylib/rl/core/distributions.py:22-23)."""
+        log_std = self.action_log_std
+        var = torch.exp(2 * log_std)
+        return (-(action - mean) ** 2 / (2 * var) - 0.5 * math.log(2 * math.pi) - log_std).sum(1, keepdim=True)
+
+    def unroll(self, states, episode_start):
+        """Training-time forward over an env-major rollout [N, T, state_dim]: re-runs the GRU through time,
+        zeroing the hidden state where `episode_start[n, t]` (what initialize_rnn + the padded [T_max,
+        n_episodes] re-pack do in the reference, policy_ar.py:104-122,216-234).  Returns means [N, T, A]."""
+        N, T, _ = states.shape
+        hx = self.init_hidden(N, states.device)
+        outs = []
+        for t in range(T):
+            hx = hx * (~episode_start[:, t]).to(hx.dtype).unsqueeze(1)
+            mean, hx = self.get_action(states[:, t], hx)
+            outs.append(mean)
+        return torch.stack(outs, 1)

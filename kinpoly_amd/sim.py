@@ -28,7 +28,8 @@ ABI_SYMBOLS = [
     "kp_model_load", "kp_model_free", "kp_model_set_option", "kp_model_get_option", "kp_sim_create", "kp_sim_destroy",
     "kp_sim_n_envs", "kp_sim_set_state", "kp_sim_set_target", "kp_sim_step_ctrl", "kp_sim_step_kin", "kp_sim_obs_cc",
     "kp_field_dim", "kp_sim_get", "kp_sim_diag", "kp_sim_last_step_seconds", "kp_last_error", "kp_version",
-    "kp_sim_step_begin", "kp_sim_obs_ar", "kp_sim_term_reward", "kp_gae", "kp_sim_set_full_state",
+    "kp_sim_step_begin", "kp_sim_obs_ar", "kp_sim_term_reward", "kp_gae", "kp_sim_set_full_state", "kp_sim_fk",
+    "kp_sim_timing_reset", "kp_sim_timing_mean_seconds",
 ]
 
 
@@ -85,6 +86,9 @@ def load_library(path: str | None = None):
     L.kp_sim_term_reward.argtypes = [P, C.POINTER(KpCtx), C.POINTER(KpRewardCfg), F, F, U8, F]; L.kp_sim_term_reward.restype = C.c_int
     L.kp_gae.argtypes = [C.c_int, C.c_int, F, F, F, C.c_float, C.c_float, F, F, C.c_void_p]; L.kp_gae.restype = C.c_int
     L.kp_sim_set_full_state.argtypes = [P, F, F, F, F, U8]; L.kp_sim_set_full_state.restype = C.c_int
+    L.kp_sim_timing_reset.argtypes = [P]; L.kp_sim_timing_reset.restype = C.c_int
+    L.kp_sim_timing_mean_seconds.argtypes = [P, C.POINTER(C.c_int)]; L.kp_sim_timing_mean_seconds.restype = C.c_double
+    L.kp_sim_fk.argtypes = [P, C.c_int, F, F, F, F, F, F]; L.kp_sim_fk.restype = C.c_int
     L.kp_last_error.restype = C.c_char_p
     L.kp_version.restype = C.c_char_p
     _lib = L
@@ -191,6 +195,17 @@ class KpSim:
         _check(self.L.kp_sim_set_full_state(self.h, _ptr(qpos, self.n, NQ), _ptr(qvel, self.n, NV), _ptr(qpos_d, self.n, NQ),
                                             _ptr(qvel_d, self.n, NV), _mask_ptr(env_mask, self.n)), "kp_sim_set_full_state")
 
+    def fk(self, qpos_rows: torch.Tensor):
+        """qpos_fk_batch on [R,76] rows -> dict(qpos, wbpos, wbquat, bquat, body_com) of device tensors."""
+        R = qpos_rows.shape[0]
+        if not qpos_rows.is_cuda or qpos_rows.dtype != torch.float32 or not qpos_rows.is_contiguous() or qpos_rows.shape[1] != NQ:
+            raise ValueError("fk: expected contiguous float32 device tensor [R,76]")
+        out = {k: torch.empty((R, d), dtype=torch.float32, device=self.device) for k, d in
+               (("qpos", 76), ("wbpos", 72), ("wbquat", 96), ("bquat", 96), ("body_com", 72))}
+        _check(self.L.kp_sim_fk(self.h, R, C.c_void_p(qpos_rows.data_ptr()), *[C.c_void_p(out[k].data_ptr()) for k in
+                                ("qpos", "wbpos", "wbquat", "bquat", "body_com")]), "kp_sim_fk")
+        return out
+
     def step_begin(self):
         _check(self.L.kp_sim_step_begin(self.h), "kp_sim_step_begin")
 
@@ -225,6 +240,14 @@ class KpSim:
         out = np.zeros((self.n, 4), np.int32)
         _check(self.L.kp_sim_diag(self.h, out.ctypes.data_as(C.c_void_p)), "kp_sim_diag")
         return out
+
+    def timing_reset(self):
+        _check(self.L.kp_sim_timing_reset(self.h), "kp_sim_timing_reset")
+
+    def timing_mean_seconds(self):
+        n = C.c_int(0)
+        t = self.L.kp_sim_timing_mean_seconds(self.h, C.byref(n))
+        return t, n.value
 
     def last_step_seconds(self) -> float:
         return self.L.kp_sim_last_step_seconds(self.h)

@@ -1,0 +1,65 @@
+"""world_size-2 gloo tests (CPU) of the multi-GPU exchange step: the all-gather of advantages/returns for
+the global normalisation and the gradient all-reduce (kinpoly_amd/rollout.py)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from kinpoly_amd.rollout import _allreduce_grads, env_shard, normalize_advantages_global
+    g = torch.Generator().manual_seed(123)
+    full_adv = torch.randn(2 * 64 * 10, generator=g); full_ret = torch.randn(2 * 64 * 10, generator=g)
+    n = full_adv.numel() // world
+    adv, ret = full_adv[rank * n:(rank + 1) * n].view(64, 10), full_ret[rank * n:(rank + 1) * n].view(64, 10)
+    nadv, _, all_ret = normalize_advantages_global(adv, ret)
+    want = ((full_adv - full_adv.mean()) / full_adv.std())[rank * n:(rank + 1) * n].view(64, 10)
+    ok1 = torch.allclose(nadv, want, atol=1e-6) and torch.allclose(all_ret, full_ret)
+    lin = torch.nn.Linear(4, 3)
+    torch.manual_seed(rank)
+    lin(torch.randn(8, 4)).sum().backward()
+    local = [p.grad.clone() for p in lin.parameters()]
+    gathered = [None] * world
+    dist.all_gather_object(gathered, [x.numpy() for x in local])
+    _allreduce_grads(list(lin.parameters()))
+    ok2 = all(np.allclose(p.grad.numpy(), np.mean([gathered[r][i] for r in range(world)], 0), atol=1e-6) for i, p in enumerate(lin.parameters()))
+    ids, seed = env_shard(rank, world, 4096)
+    ok3 = ids[0] == rank * 4096 and len(ids) == 4096 and seed == 4 + rank
+    q.put((rank, bool(ok1), bool(ok2), bool(ok3)))
+    dist.destroy_process_group()
+
+
+def test_allgather_normalisation_and_grad_allreduce_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(r[0] for r in res) == [0, 1]
+    for r in res:
+        assert r[1] and r[2] and r[3], r
+
+
+def test_single_process_normalisation_matches_reference_golden(golden):
+    from kinpoly_amd.rollout import normalize_advantages_global
+    from oracle import np_oracle as O
+    g = golden("gae_zfilter")
+    adv_raw, ret = O.estimate_advantages(g["rewards"], g["masks"], g["values"], 0.95, 0.95)
+    # undo the oracle's normalisation to feed raw advantages: recompute raw via returns - values
+    raw = torch.tensor(g["ret"] - g["values"])
+    nadv, _, _ = normalize_advantages_global(raw, torch.tensor(g["ret"]))
+    np.testing.assert_allclose(nadv.numpy(), g["adv"], atol=1e-10)
