@@ -653,7 +653,7 @@ __global__ __launch_bounds__(NT) void kp_step_kernel(StepArgs A) {
     for (int i = tid; i < 96; i += NT) A.xquat[(size_t)env * 96 + i] = s.xquat[i];
     if (bad) atomicOr(&s.flag, 1);
     KP_SYNC();
-    if (tid == 0 && A.diag) { int* dg = A.diag + 4 * (size_t)env; dg[0] = s.ncon; dg[1] = niter_total; dg[2] = s.flag; dg[3] = maxcon; }
+    if (tid == 0 && A.diag && A.n_substeps > 0) { int* dg = A.diag + 4 * (size_t)env; dg[0] = s.ncon; dg[1] = niter_total; dg[2] = s.flag; dg[3] = maxcon; }
 }
 
 }  // namespace kp
