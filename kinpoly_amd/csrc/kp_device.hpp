@@ -3,14 +3,15 @@
 // One workgroup = one environment.  All per-env dynamics state lives in LDS for the whole control
 // step (15 substeps); HBM is touched only at kernel entry (qpos/qvel/action/target) and exit
 // (qpos/qvel + stale kinematics for the observation kernels).  Lanes map to bodies (24), dofs (75),
-// sparse-M entries (1221), hull vertices (<=64 per hull) or constraint rows depending on the phase.
+// hull vertices (<=64 per hull) or contacts depending on the phase.  The layout is sized so that
+// 8 environments fit in the 160 KiB LDS of one CU.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace kp {
 
-constexpr int D_NB = 24, D_NV = 75, D_NQ = 76, D_NU = 69, D_NM = 1221, D_MAXDEPTH = 30;
+constexpr int D_NB = 24, D_NV = 75, D_NQ = 76, D_NU = 69;
 constexpr int D_MAXCON = 64;          // must equal MAXCON in oracle/kp_oracle.c
 constexpr int D_CON_PER_GEOM = 3;     // must equal CON_PER_GEOM in oracle/kp_oracle.c
 constexpr int D_NLEV = 9;             // body tree depth levels (Pelvis .. Hand)
@@ -20,8 +21,8 @@ struct DevTables {
     const float *dof_armature, *jnt_lo, *jnt_hi, *lim_invw;
     const float *kp, *kd, *tlim, *ascale;
     const float *verts;
-    const uint16_t *vert_adr, *dof_madr, *anc_madr;
-    const uint8_t *dof_depth, *dof_body, *dof_nsub, *m_row, *m_col, *anc_dof;
+    const uint16_t *vert_adr;
+    const uint8_t *dof_body;
     const int8_t *body_parent;
     const uint8_t *body_depth, *body_subtree, *lev_start, *lev_body, *jnt_limited;
 };
@@ -38,26 +39,26 @@ struct Params {
     int max_iter, contact, limits, stale;
 };
 
-// ------------------------------------------------------------------ LDS layout (floats)
+// ------------------------------------------------------------------ LDS layout (floats): ~19.8 KB
 struct __attribute__((aligned(16))) EnvLds {
     float qpos[76], qvel[76], tq[76], act[76];
-    float xpos[72], xquat[96], xmat[216], xipos[72];
-    float cinert[240], crb[240];
-    float cdof[450];
-    float sv[144], sa[144], sw[144];
-    float f6[450];
-    float K[504];
-    float qM[1224], qLD[1224];
-    float diaginv[76];
-    float bias[76], smooth[76], qacc_s[76], qacc[76], grad[76], search[76], Mv[76], mres[76], warm[76], x[76];
+    float xpos[72], xquat[96], xipos[72];
+    float cinert[240];                    // body spatial inertia about o, world axes (10 floats / body)
+    float cdof[450];                      // motion axis of every dof [ang; lin] about o
+    float sv[144], sa[144], sw[144];      // per-body spatial scratch (velocity / acceleration / wrench)
+    float U[450], Dinv[76], uj[76];       // articulated-body pass: U_j = IA s_j, 1/D_j, u_j
+    float IAa[504], pAa[144];             // articulated inertia / bias force handed to the parent
+    float arm[76];                        // dof armature
+    float bias[76], smooth[76], qacc_s[76], qacc[76], grad[76], search[76], Mv[76], mres[76], x[76], extra[76];
     float ctrl[72];
     float applied[8];
     float con_pos[D_MAXCON * 3], con_dist[D_MAXCON], con_D[D_MAXCON];
     int con_body[D_MAXCON];
     int con_start[D_NB + 1];
-    float aref[D_MAXCON * 4], jar[D_MAXCON * 4], jv[D_MAXCON * 4];
+    float jar3[D_MAXCON * 3], jv3[D_MAXCON * 3];   // contact-frame (normal, t1, t2) residuals J qacc - aref and J search
     float lim_sgn[72], lim_aref[72], lim_D[72], lim_jar[72], lim_jv[72];
-    float red[16];
+    float red[8];
+    unsigned char bpar[D_NB], bsub[D_NB], bdep[D_NB], dbody[76];
     int ncon, nlim, flag;
 };
 
@@ -113,8 +114,6 @@ __device__ __forceinline__ S6 inert_mul(const float* I, S6 v) {
                I[4] * v.a.x + I[5] * v.a.y + I[2] * v.a.z};
     return S6{Iw + cross(h, v.l), m * v.l - cross(h, v.a)};
 }
-// symmetric 6x6 (21 floats, row-major upper: (0,0)(0,1)..(0,5)(1,1)..) times 6-vector
-__device__ __forceinline__ int sym6_idx(int r, int c) { return r <= c ? r * 6 - r * (r - 1) / 2 + (c - r) : c * 6 - c * (c - 1) / 2 + (r - c); }
 
 __device__ __forceinline__ float impedance(const Params& P, float pos) {
     float x = fabsf(pos) / P.imp_w;

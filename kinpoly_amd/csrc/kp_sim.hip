@@ -86,28 +86,21 @@ bool build_tables(kp_sim* s) {
     T.ascale = upload<float>(s, m.a_scale, &ok);
     s->diffw = const_cast<float*>(upload<float>(s, m.body_diffw, &ok));
     T.verts = upload<float>(s, m.verts, &ok);
-    T.vert_adr = upload<uint16_t>(s, m.vert_adr, &ok); T.dof_madr = upload<uint16_t>(s, m.dof_madr, &ok);
-    T.dof_depth = upload<uint8_t>(s, m.dof_depth, &ok); T.dof_body = upload<uint8_t>(s, m.dof_body, &ok);
+    T.vert_adr = upload<uint16_t>(s, m.vert_adr, &ok);
+    T.dof_body = upload<uint8_t>(s, m.dof_body, &ok);
     T.body_parent = upload<int8_t>(s, m.body_parent, &ok); T.body_depth = upload<uint8_t>(s, m.body_depth, &ok);
     T.body_subtree = upload<uint8_t>(s, m.body_subtree, &ok); T.jnt_limited = upload<uint8_t>(s, m.jnt_limited, &ok);
-    // ancestor tables: a-th ancestor (a = 0 is the dof itself) of every dof, as dof id and as qM address
-    std::vector<int> anc_madr(NV * MAXDEPTH, 0), anc_dof(NV * MAXDEPTH, 0), m_row(NM), m_col(NM), nsub(NV, 0);
-    for (int k = 0; k < NV; k++) {
-        int a = 0;
-        for (int j = k; j >= 0; j = m.dof_parent[j], a++) {
-            anc_madr[k * MAXDEPTH + a] = m.dof_madr[j]; anc_dof[k * MAXDEPTH + a] = j;
-            m_row[m.dof_madr[k] + a] = k; m_col[m.dof_madr[k] + a] = j;
-            if (j != k) nsub[j]++;
-        }
+    // layout assumptions of the kernels: bodies in DFS order (subtree(b) = [b, b + size)), body b > 0 owns dofs 6+3(b-1)..+2
+    for (int b = 1; b < NB; b++) {
+        if (m.body_parent[b] >= b) return false;
+        for (int j = 0; j < 3; j++) if (m.dof_body[6 + 3 * (b - 1) + j] != b) return false;
     }
-    for (int j = 0; j < NV; j++)  // descendants of a dof must be the contiguous range (j, j+nsub]
-        for (int i = j + 1; i <= j + nsub[j]; i++) {
+    for (int b = 0; b < NB; b++)
+        for (int k = b + 1; k < NB; k++) {
             bool desc = false;
-            for (int p = m.dof_parent[i]; p >= 0; p = m.dof_parent[p]) if (p == j) desc = true;
-            if (!desc) return false;
+            for (int p = m.body_parent[k]; p >= 0; p = m.body_parent[p]) if (p == b) desc = true;
+            if (desc != (k < b + m.body_subtree[b])) return false;
         }
-    T.anc_madr = upload<uint16_t>(s, anc_madr, &ok); T.anc_dof = upload<uint8_t>(s, anc_dof, &ok);
-    T.m_row = upload<uint8_t>(s, m_row, &ok); T.m_col = upload<uint8_t>(s, m_col, &ok); T.dof_nsub = upload<uint8_t>(s, nsub, &ok);
     std::vector<int> lev_start(D_NLEV + 2, 0), lev_body;
     for (int lev = 0; lev <= D_NLEV; lev++) {
         lev_start[lev] = (int)lev_body.size();

@@ -5,13 +5,18 @@
 //   compute_torque / compute_desired_accel   uhc/envs/humanoid_im.py:418-480
 //   rfc_implicit                              uhc/envs/humanoid_im.py:497-504
 //   sim.step()  (MuJoCo mj_step)              uhc/envs/humanoid_im.py:527         [MJ-ext]
-// The arithmetic mirrors oracle/kp_oracle.c (fp64) in fp32; what differs is the organisation:
-//   * spatial quantities are taken about the root body origin (not the subtree COM) so that
-//     kinematics, velocities and bias forces come out of ONE level-synchronous tree pass;
-//   * J v, J^T f and J^T D J are never materialised: contact rows act on bodies, so J v is a
-//     spatial-velocity tree pass, J^T f a wrench subtree sum, and the Newton Hessian M + J^T D J is a
-//     composite-inertia pass with a 6x6 "contact inertia" per body (same sparsity as M);
-//   * the tree-sparse L^T D L factorisation runs rank-1 updates with lanes over ancestor pairs.
+// The arithmetic follows oracle/kp_oracle.c (fp64) in fp32, organised MATRIX-FREE for a wavefront:
+//   * every spatial quantity is expressed in ONE world-aligned frame at the root body origin, so tree
+//     recursions need no coordinate transforms: parents and children simply add;
+//   * kinematics, velocities and bias forces (RNE) come out of one level-synchronous pass (9 levels);
+//   * every linear solve -- (M + K_d h) for the stable-PD controller, M for the smooth acceleration,
+//     M + J^T D J for the Newton step of the contact solver -- is an articulated-body (ABA) pass:
+//     leaves->root articulated inertia + bias, root->leaves accelerations.  K_d h and joint-limit terms
+//     enter as extra joint armature, active contact rows as a per-body 6x6 "contact inertia" D w w^T.
+//     The joint-space mass matrix is never formed or factorised (the reference materialises a dense
+//     105x105 M and a Cholesky factor per substep);
+//   * J v is read off the spatial accelerations the ABA forward pass leaves behind, J^T f and M v are a
+//     body-wrench subtree sum projected on the dofs.
 #pragma once
 #include "kp_device.hpp"
 
@@ -47,10 +52,23 @@ __device__ __forceinline__ float block_sum(EnvLds& s, float v, int tid) {
     return v;
 }
 
+__device__ __forceinline__ constexpr int s6i(int r, int c) { return r <= c ? (r * (13 - r)) / 2 + (c - r) : (c * (13 - c)) / 2 + (r - c); }
+
+// contact row e (0..3) of the pyramid in the plane frame n=(0,0,1), t1=(0,1,0), t2=(-1,0,0): dir = n +- mu t
+__device__ __forceinline__ V3 row_dir(int e, float mu) {
+    float sg = (e & 1) ? -mu : mu;
+    return (e < 2) ? v3(0.f, sg, 1.f) : v3(-sg, 0.f, 1.f);
+}
+// row value from contact-frame components (n, t1, t2)
+__device__ __forceinline__ float row_val(int e, float mu, float jn, float jt1, float jt2) {
+    float sg = (e & 1) ? -mu : mu;
+    return jn + sg * (e < 2 ? jt1 : jt2);
+}
+__device__ __forceinline__ V3 to_frame(V3 v) { return v3(v.z, v.y, -v.x); }  // (n, t1, t2) components of a world vector
+
 // ---------------------------------------------------------------- kinematics + velocities + bias (one tree pass)
 template <int NT>
-__device__ void forward_kin_bias(EnvLds& s, const DevTables& T, const Params& P, int tid) {
-    int depth = tid < D_NB ? T.body_depth[tid] : -1;
+__device__ void forward_kin_bias(EnvLds& s, const DevTables& T, const Params& P, int depth, int tid) {
     for (int lev = 0; lev < D_NLEV; lev++) {
         if (depth == lev) {
             const int b = tid;
@@ -74,10 +92,10 @@ __device__ void forward_kin_bias(EnvLds& s, const DevTables& T, const Params& P,
                 cv = S6{ww, vl};
                 ca = S6{v3(0.f, 0.f, 0.f), v3(-P.gx, -P.gy, -P.gz) + cross(vl, ww)};
             } else {
-                const int p = T.body_parent[b];
+                const int p = s.bpar[b];
                 o = ld3(s.xpos);
-                pos = ld3(s.xpos + 3 * p) + mulmat(s.xmat + 9 * p, ld3(T.body_pos + 3 * b));
                 q = Q4{s.xquat[4 * p], s.xquat[4 * p + 1], s.xquat[4 * p + 2], s.xquat[4 * p + 3]};
+                pos = ld3(s.xpos + 3 * p) + qrot(q, ld3(T.body_pos + 3 * b));
                 cv = lds6(s.sv + 6 * p); ca = lds6(s.sa + 6 * p);
                 V3 r = o - pos;
 #pragma unroll
@@ -98,8 +116,6 @@ __device__ void forward_kin_bias(EnvLds& s, const DevTables& T, const Params& P,
             float R[9]; q2mat(q, R);
             st3(s.xpos + 3 * b, pos);
             s.xquat[4 * b] = q.w; s.xquat[4 * b + 1] = q.x; s.xquat[4 * b + 2] = q.y; s.xquat[4 * b + 3] = q.z;
-#pragma unroll
-            for (int k = 0; k < 9; k++) s.xmat[9 * b + k] = R[k];
             V3 xi = pos + mulmat(R, ld3(T.body_ipos + 3 * b));
             st3(s.xipos + 3 * b, xi);
             // inertia about o in world axes
@@ -128,94 +144,108 @@ __device__ void forward_kin_bias(EnvLds& s, const DevTables& T, const Params& P,
     }
     // subtree sums of the body wrenches -> sa (cacc no longer needed), then project on the dofs
     for (int it = tid; it < D_NB * 6; it += NT) {
-        int b = it / 6, c = it - 6 * b, n = T.body_subtree[b];
+        int b = it / 6, c = it - 6 * b, n = s.bsub[b];
         float acc = 0.f;
         for (int k = b; k < b + n; k++) acc += s.sw[6 * k + c];
         s.sa[it] = acc;
     }
     KP_SYNC();
-    for (int d = tid; d < D_NV; d += NT) s.bias[d] = dot6(lds6(s.cdof + 6 * d), lds6(s.sa + 6 * T.dof_body[d]));
+    for (int d = tid; d < D_NV; d += NT) s.bias[d] = dot6(lds6(s.cdof + 6 * d), lds6(s.sa + 6 * s.dbody[d]));
     KP_SYNC();
 }
 
-// ---------------------------------------------------------------- composite inertia -> sparse M (mj_crb)
+// ---------------------------------------------------------------- articulated-body solve
+// out = (M + diag(s.extra) [+ J^T D_active J])^-1 rhs.  Leaves s.sv[b] = sum over ancestor dofs cdof_d out_d
+// (the spatial "acceleration" of every body induced by out).  rhs/out are LDS vectors (may alias).
 template <int NT>
-__device__ void crb_mass_matrix(EnvLds& s, const DevTables& T, int tid) {
-    for (int it = tid; it < D_NB * 10; it += NT) {
-        int b = it / 10, c = it - 10 * b, n = T.body_subtree[b];
-        float acc = 0.f;
-        for (int k = b; k < b + n; k++) acc += s.cinert[10 * k + c];
-        s.crb[it] = acc;
-    }
-    KP_SYNC();
-    for (int d = tid; d < D_NV; d += NT) sts6(s.f6 + 6 * d, inert_mul(s.crb + 10 * T.dof_body[d], lds6(s.cdof + 6 * d)));
-    KP_SYNC();
-    for (int e = tid; e < D_NM; e += NT) {
-        int i = T.m_row[e], j = T.m_col[e];
-        float v = dot6(lds6(s.cdof + 6 * j), lds6(s.f6 + 6 * i));
-        if (i == j) v += T.dof_armature[i];
-        s.qM[e] = v;
-    }
-    KP_SYNC();
-}
-
-// ---------------------------------------------------------------- tree-sparse L^T D L of s.qLD (rows left unscaled, 1/D in diaginv)
-template <int NT>
-struct PairTable {
-    static constexpr int NP = (D_MAXDEPTH * (D_MAXDEPTH - 1) / 2 + NT - 1) / NT;  // 435 ancestor pairs max
-    int u[NP], a[NP];
-    __device__ void init(int tid) {
-#pragma unroll
-        for (int n = 0; n < NP; n++) {
-            int t = tid + n * NT;
-            int uu = (int)((1.0f + sqrtf(8.0f * t + 1.0f)) * 0.5f);
-            while (uu * (uu - 1) / 2 > t) uu--;
-            while ((uu + 1) * uu / 2 <= t) uu++;
-            u[n] = uu; a[n] = t - uu * (uu - 1) / 2 + 1;
-        }
-    }
-};
-
-template <int NT>
-__device__ void factor_sparse(EnvLds& s, const DevTables& T, const PairTable<NT>& pt, int tid) {
-    for (int k = D_NV - 1; k > 0; k--) {
-        const int D = T.dof_depth[k], adr = T.dof_madr[k];
-        const float dinv = 1.0f / s.qLD[adr];
-#pragma unroll
-        for (int n = 0; n < PairTable<NT>::NP; n++) {
-            int u = pt.u[n], a = pt.a[n];
-            if (u <= D) {
-                int tgt = T.anc_madr[k * D_MAXDEPTH + a] + (u - a);
-                s.qLD[tgt] -= s.qLD[adr + a] * dinv * s.qLD[adr + u];
+__device__ void aba_solve(EnvLds& s, const Params& P, const float* rhs, float* out, bool contact_inertia, int depth, int tid) {
+    for (int lev = D_NLEV - 1; lev >= 0; lev--) {
+        if (depth == lev) {
+            const int b = tid;
+            float IA[21], pA[6];
+            {
+                const float* ci = s.cinert + 10 * b;
+                const float hx = ci[6], hy = ci[7], hz = ci[8], m = ci[9];
+                IA[s6i(0, 0)] = ci[0]; IA[s6i(0, 1)] = ci[3]; IA[s6i(0, 2)] = ci[4]; IA[s6i(0, 3)] = 0.f; IA[s6i(0, 4)] = -hz; IA[s6i(0, 5)] = hy;
+                IA[s6i(1, 1)] = ci[1]; IA[s6i(1, 2)] = ci[5]; IA[s6i(1, 3)] = hz; IA[s6i(1, 4)] = 0.f; IA[s6i(1, 5)] = -hx;
+                IA[s6i(2, 2)] = ci[2]; IA[s6i(2, 3)] = -hy; IA[s6i(2, 4)] = hx; IA[s6i(2, 5)] = 0.f;
+                IA[s6i(3, 3)] = m; IA[s6i(3, 4)] = 0.f; IA[s6i(3, 5)] = 0.f; IA[s6i(4, 4)] = m; IA[s6i(4, 5)] = 0.f; IA[s6i(5, 5)] = m;
             }
+#pragma unroll
+            for (int k = 0; k < 6; k++) pA[k] = 0.f;
+            if (contact_inertia) {
+                const V3 o = ld3(s.xpos);
+                for (int c = s.con_start[b]; c < s.con_start[b + 1]; c++) {
+                    V3 p = ld3(s.con_pos + 3 * c) - o;
+                    const float Dc = s.con_D[c], jn = s.jar3[3 * c], jt1 = s.jar3[3 * c + 1], jt2 = s.jar3[3 * c + 2];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        if (row_val(e, P.mu, jn, jt1, jt2) < 0.f) {
+                            V3 dir = row_dir(e, P.mu);
+                            V3 mm = cross(p, dir);
+                            float w[6] = {mm.x, mm.y, mm.z, dir.x, dir.y, dir.z};
+#pragma unroll
+                            for (int r = 0; r < 6; r++)
+#pragma unroll
+                                for (int cc = r; cc < 6; cc++) IA[s6i(r, cc)] += Dc * w[r] * w[cc];
+                        }
+                    }
+                }
+            }
+            const int nsub = s.bsub[b];
+            for (int k = b + 1; k < b + nsub; k += s.bsub[k]) {
+#pragma unroll
+                for (int i = 0; i < 21; i++) IA[i] += s.IAa[21 * k + i];
+#pragma unroll
+                for (int i = 0; i < 6; i++) pA[i] += s.pAa[6 * k + i];
+            }
+            const int nd = b == 0 ? 6 : 3, d0 = b == 0 ? 0 : 6 + 3 * (b - 1);
+            for (int j = nd - 1; j >= 0; j--) {
+                const int d = d0 + j;
+                float sj[6], Uv[6];
+#pragma unroll
+                for (int k = 0; k < 6; k++) sj[k] = s.cdof[6 * d + k];
+                float D = s.arm[d] + s.extra[d], u = rhs[d];
+#pragma unroll
+                for (int r = 0; r < 6; r++) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int c = 0; c < 6; c++) acc += IA[s6i(r, c)] * sj[c];
+                    Uv[r] = acc;
+                    D += sj[r] * acc;
+                    u -= sj[r] * pA[r];
+                }
+                const float Dinv = 1.0f / D, ud = u * Dinv;
+#pragma unroll
+                for (int k = 0; k < 6; k++) s.U[6 * d + k] = Uv[k];
+                s.Dinv[d] = Dinv; s.uj[d] = u;
+#pragma unroll
+                for (int r = 0; r < 6; r++) {
+                    const float ur = Uv[r] * Dinv;
+#pragma unroll
+                    for (int c = r; c < 6; c++) IA[s6i(r, c)] -= ur * Uv[c];
+                    pA[r] += Uv[r] * ud;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 21; i++) s.IAa[21 * b + i] = IA[i];
+#pragma unroll
+            for (int i = 0; i < 6; i++) s.pAa[6 * b + i] = pA[i];
         }
-        if (tid == 0) s.diaginv[k] = dinv;
         KP_SYNC();
     }
-    if (tid == 0) s.diaginv[0] = 1.0f / s.qLD[0];
-    KP_SYNC();
-}
-
-// x <- (L^T D L)^-1 x, x = s.x
-template <int NT>
-__device__ void solve_sparse(EnvLds& s, const DevTables& T, const uint8_t* __restrict__ anc_dof, int tid) {
-    for (int i = D_NV - 1; i > 0; i--) {
-        const int D = T.dof_depth[i], adr = T.dof_madr[i];
-        const float xi = s.x[i] * s.diaginv[i];
-        for (int c = tid + 1; c <= D; c += NT) {
-            int j = anc_dof[i * D_MAXDEPTH + c];
-            s.x[j] -= s.qLD[adr + c] * xi;
-        }
-        KP_SYNC();
-    }
-    for (int i = tid; i < D_NV; i += NT) s.x[i] *= s.diaginv[i];
-    KP_SYNC();
-    for (int j = 0; j < D_NV - 1; j++) {
-        const int n = T.dof_nsub[j], dj = T.dof_depth[j];
-        const float xj = s.x[j];
-        for (int i = j + 1 + tid; i <= j + n; i += NT) {
-            int c = T.dof_depth[i] - dj;
-            s.x[i] -= s.qLD[T.dof_madr[i] + c] * s.diaginv[i] * xj;
+    for (int lev = 0; lev < D_NLEV; lev++) {
+        if (depth == lev) {
+            const int b = tid;
+            S6 a = b == 0 ? S6{v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f)} : lds6(s.sv + 6 * s.bpar[b]);
+            const int nd = b == 0 ? 6 : 3, d0 = b == 0 ? 0 : 6 + 3 * (b - 1);
+            for (int j = 0; j < nd; j++) {
+                const int d = d0 + j;
+                float qdd = (s.uj[d] - dot6(lds6(s.U + 6 * d), a)) * s.Dinv[d];
+                out[d] = qdd;
+                a = a + qdd * lds6(s.cdof + 6 * d);
+            }
+            sts6(s.sv + 6 * b, a);
         }
         KP_SYNC();
     }
@@ -223,10 +253,7 @@ __device__ void solve_sparse(EnvLds& s, const DevTables& T, const uint8_t* __res
 
 // ---------------------------------------------------------------- stable-PD torque + residual force (reference controller)
 template <int NT>
-__device__ void spd_torque_rfc(EnvLds& s, const DevTables& T, const Params& P, const PairTable<NT>& pt,
-                               const uint8_t* __restrict__ anc_dof, int tid) {
-    for (int e = tid; e < D_NM; e += NT) s.qLD[e] = s.qM[e];
-    KP_SYNC();
+__device__ void spd_torque_rfc(EnvLds& s, const DevTables& T, const Params& P, int depth, int tid) {
     for (int i = tid; i < D_NV; i += NT) {
         float ep = 0.f, kp = 0.f, kd = 0.f;
         if (i >= 6) {
@@ -237,14 +264,13 @@ __device__ void spd_torque_rfc(EnvLds& s, const DevTables& T, const Params& P, c
             float target = base + s.act[j] * T.ascale[j];
             kp = T.kp[j]; kd = T.kd[j];
             ep = q + s.qvel[i] * P.h - target;
-            s.qLD[T.dof_madr[i]] += kd * P.h;
         }
+        s.extra[i] = kd * P.h;                      // (M + K_d dt): K_d dt is extra joint armature
         s.search[i] = ep;
         s.x[i] = -s.bias[i] - kp * ep - kd * s.qvel[i];
     }
     KP_SYNC();
-    factor_sparse<NT>(s, T, pt, tid);
-    solve_sparse<NT>(s, T, anc_dof, tid);
+    aba_solve<NT>(s, P, s.x, s.x, false, depth, tid);
     for (int j = tid; j < D_NU; j += NT) {
         int i = j + 6;
         float tq = -T.kp[j] * s.search[i] - T.kd[j] * (s.qvel[i] + s.x[i] * P.h);
@@ -267,14 +293,16 @@ __device__ void spd_torque_rfc(EnvLds& s, const DevTables& T, const Params& P, c
 template <int NT>
 __device__ void collide_plane(EnvLds& s, const DevTables& T, const Params& P, int tid) {
     if (tid < 64) {
-        bool near = (tid < D_NB) && P.contact && !(s.xpos[3 * (tid < D_NB ? tid : 0) + 2] - T.body_rbound[tid < D_NB ? tid : 0] > P.margin);
+        const int bb = tid < D_NB ? tid : 0;
+        bool near = (tid < D_NB) && P.contact && !(s.xpos[3 * bb + 2] - T.body_rbound[bb] > P.margin);
         unsigned long long mask = __ballot(near);
         int ncon = 0;
         for (int b = 0; b < D_NB; b++) {
             if (tid == 0) s.con_start[b] = ncon;
             if (!((mask >> b) & 1ull)) continue;
             const int vadr = T.vert_adr[b], nvb = T.vert_adr[b + 1] - vadr;
-            const float* R = s.xmat + 9 * b;
+            float R[9];
+            q2mat(Q4{s.xquat[4 * b], s.xquat[4 * b + 1], s.xquat[4 * b + 2], s.xquat[4 * b + 3]}, R);
             V3 v = v3(0.f, 0.f, 0.f);
             float dist = 3.0e38f;
             if (tid < nvb) { v = ld3(T.verts + 3 * (vadr + tid)); dist = s.xpos[3 * b + 2] + R[6] * v.x + R[7] * v.y + R[8] * v.z; }
@@ -304,12 +332,7 @@ __device__ void collide_plane(EnvLds& s, const DevTables& T, const Params& P, in
     KP_SYNC();
 }
 
-// contact row e (0..3) direction for the plane frame n=(0,0,1), t1=(0,1,0), t2=(-1,0,0): dir = n +- mu t
-__device__ __forceinline__ V3 row_dir(int e, float mu) {
-    float sg = (e & 1) ? -mu : mu;
-    return (e < 2) ? v3(0.f, sg, 1.f) : v3(-sg, 0.f, 1.f);
-}
-
+// efc_D and the reference acceleration of every constraint row.  aref (contact-frame 3-vector) goes to jv3.
 template <int NT>
 __device__ void make_constraint(EnvLds& s, const DevTables& T, const Params& P, int tid) {
     const V3 o = ld3(s.xpos);
@@ -320,10 +343,9 @@ __device__ void make_constraint(EnvLds& s, const DevTables& T, const Params& P, 
         float dA = T.body_invw[b] * (1.0f + P.mu * P.mu);
         float Rn = fmaxf(1e-15f, (1.0f - imp) * dA / imp);
         s.con_D[c] = 1.0f / (2.0f * P.mu * P.mu * Rn);
-        S6 cv = lds6(s.sv + 6 * b);
-        V3 vpt = cv.l + cross(cv.a, ld3(s.con_pos + 3 * c) - o);
-#pragma unroll
-        for (int e = 0; e < 4; e++) s.aref[4 * c + e] = -P.B * dot(row_dir(e, P.mu), vpt) - P.K * imp * r;
+        S6 cv = lds6(s.sv + 6 * b);                         // sv still holds cvel from forward_kin_bias
+        V3 vf = to_frame(cv.l + cross(cv.a, ld3(s.con_pos + 3 * c) - o));
+        s.jv3[3 * c] = -P.B * vf.x - P.K * imp * r; s.jv3[3 * c + 1] = -P.B * vf.y; s.jv3[3 * c + 2] = -P.B * vf.z;
     }
     for (int j = tid; j < D_NU; j += NT) {
         float sgn = 0.f, aref = 0.f, Dl = 0.f;
@@ -343,48 +365,26 @@ __device__ void make_constraint(EnvLds& s, const DevTables& T, const Params& P, 
     KP_SYNC();
 }
 
-// spatial "velocity" of every body induced by a generalized vector:  sv[b] = sum over ancestor dofs cdof_d * vec[d]
+// contact-frame residuals of all rows for the spatial accelerations in sv:  out3 = frame^T (point accel) [- aref]
 template <int NT>
-__device__ void spatial_accumulate(EnvLds& s, const DevTables& T, const float* vec, int tid) {
-    for (int lev = 0; lev < D_NLEV; lev++) {
-        int l0 = T.lev_start[lev], nl = T.lev_start[lev + 1] - l0;
-        for (int it = tid; it < nl * 6; it += NT) {
-            int b = T.lev_body[l0 + it / 6], c = it % 6;
-            float acc;
-            if (b == 0) {
-                acc = 0.f;
-#pragma unroll
-                for (int d = 0; d < 6; d++) acc += s.cdof[6 * d + c] * vec[d];
-            } else {
-                acc = s.sv[6 * T.body_parent[b] + c];
-                int d0 = 6 + 3 * (b - 1);
-#pragma unroll
-                for (int d = d0; d < d0 + 3; d++) acc += s.cdof[6 * d + c] * vec[d];
-            }
-            s.sv[6 * b + c] = acc;
-        }
-        KP_SYNC();
-    }
-}
-
-// rows: out[r] = w_r . sv[body_r] (- aref if sub_aref); limits likewise
-template <int NT>
-__device__ void eval_rows(EnvLds& s, const float* vec, float* rows, float* lim_rows, bool sub_aref, const Params& P, int tid) {
+__device__ void eval_rows(EnvLds& s, const float* vec, float* out3, float* lim_rows, bool sub_aref, int tid) {
     const V3 o = ld3(s.xpos);
-    for (int r = tid; r < 4 * s.ncon; r += NT) {
-        int c = r >> 2;
+    for (int c = tid; c < s.ncon; c += NT) {
         S6 S = lds6(s.sv + 6 * s.con_body[c]);
-        V3 vpt = S.l + cross(S.a, ld3(s.con_pos + 3 * c) - o);
-        rows[r] = dot(row_dir(r & 3, P.mu), vpt) - (sub_aref ? s.aref[r] : 0.f);
+        V3 a = to_frame(S.l + cross(S.a, ld3(s.con_pos + 3 * c) - o));
+        if (sub_aref) { a.x -= s.jv3[3 * c]; a.y -= s.jv3[3 * c + 1]; a.z -= s.jv3[3 * c + 2]; }
+        out3[3 * c] = a.x; out3[3 * c + 1] = a.y; out3[3 * c + 2] = a.z;
     }
-    for (int j = tid; j < D_NU; j += NT) lim_rows[j] = s.lim_sgn[j] * vec[6 + j] - (sub_aref ? s.lim_aref[j] : 0.f);
+    for (int j = tid; j < D_NU; j += NT) {
+        float sg = s.lim_sgn[j];
+        lim_rows[j] = sg != 0.f ? sg * vec[6 + j] - (sub_aref ? s.lim_aref[j] : 0.f) : 0.f;
+    }
     KP_SYNC();
 }
 
-// out = M vec (with_inertia) - J^T f(jar) (with_forces);  sv must hold spatial_accumulate(vec) when with_inertia
+// out = M vec (with_inertia; sv must hold the spatial accelerations of vec) - J^T f(jar) (with_forces)
 template <int NT>
-__device__ void wrench_project(EnvLds& s, const DevTables& T, const Params& P, const float* vec, float* out,
-                               bool with_inertia, bool with_forces, int tid) {
+__device__ void wrench_project(EnvLds& s, const Params& P, const float* vec, float* out, bool with_inertia, bool with_forces, int tid) {
     if (tid < D_NB) {
         const int b = tid;
         S6 W = with_inertia ? inert_mul(s.cinert + 10 * b, lds6(s.sv + 6 * b)) : S6{v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f)};
@@ -392,9 +392,9 @@ __device__ void wrench_project(EnvLds& s, const DevTables& T, const Params& P, c
             const V3 o = ld3(s.xpos);
             for (int c = s.con_start[b]; c < s.con_start[b + 1]; c++) {
                 V3 F = v3(0.f, 0.f, 0.f);
-                float Dc = s.con_D[c];
+                const float Dc = s.con_D[c], jn = s.jar3[3 * c], jt1 = s.jar3[3 * c + 1], jt2 = s.jar3[3 * c + 2];
 #pragma unroll
-                for (int e = 0; e < 4; e++) { float jr = s.jar[4 * c + e]; if (jr < 0.f) F = F + (-Dc * jr) * row_dir(e, P.mu); }
+                for (int e = 0; e < 4; e++) { float x = row_val(e, P.mu, jn, jt1, jt2); if (x < 0.f) F = F + (-Dc * x) * row_dir(e, P.mu); }
                 V3 p = ld3(s.con_pos + 3 * c) - o;
                 W.a = W.a - cross(p, F); W.l = W.l - F;
             }
@@ -403,128 +403,63 @@ __device__ void wrench_project(EnvLds& s, const DevTables& T, const Params& P, c
     }
     KP_SYNC();
     for (int it = tid; it < D_NB * 6; it += NT) {
-        int b = it / 6, c = it - 6 * b, n = T.body_subtree[b];
+        int b = it / 6, c = it - 6 * b, n = s.bsub[b];
         float acc = 0.f;
         for (int k = b; k < b + n; k++) acc += s.sw[6 * k + c];
         s.sa[it] = acc;
     }
     KP_SYNC();
     for (int d = tid; d < D_NV; d += NT) {
-        float v = dot6(lds6(s.cdof + 6 * d), lds6(s.sa + 6 * T.dof_body[d]));
-        if (with_inertia) v += T.dof_armature[d] * vec[d];
+        float v = dot6(lds6(s.cdof + 6 * d), lds6(s.sa + 6 * s.dbody[d]));
+        if (with_inertia) v += s.arm[d] * vec[d];
         if (with_forces && d >= 6) { float jr = s.lim_jar[d - 6]; if (jr < 0.f) v -= s.lim_sgn[d - 6] * (-s.lim_D[d - 6] * jr); }
         out[d] = v;
     }
     KP_SYNC();
 }
 
-// Newton Hessian H = M + J^T D_active J  -> s.qLD   (contact "inertia" composite pass)
-template <int NT>
-__device__ void assemble_hessian(EnvLds& s, const DevTables& T, const Params& P, int tid) {
-    if (tid < D_NB) {
-        const int b = tid;
-        float Kb[21];
-#pragma unroll
-        for (int k = 0; k < 21; k++) Kb[k] = 0.f;
-        const V3 o = ld3(s.xpos);
-        for (int c = s.con_start[b]; c < s.con_start[b + 1]; c++) {
-            V3 p = ld3(s.con_pos + 3 * c) - o;
-            float Dc = s.con_D[c];
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                if (s.jar[4 * c + e] < 0.f) {
-                    V3 dir = row_dir(e, P.mu);
-                    V3 m = cross(p, dir);
-                    float w[6] = {m.x, m.y, m.z, dir.x, dir.y, dir.z};
-                    int k = 0;
-#pragma unroll
-                    for (int r = 0; r < 6; r++)
-#pragma unroll
-                        for (int cc = r; cc < 6; cc++) Kb[k++] += Dc * w[r] * w[cc];
-                }
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 21; k++) s.K[21 * b + k] = Kb[k];
-    }
-    KP_SYNC();
-    float* Ksub = s.qLD;  // scratch: qLD is rewritten below
-    for (int it = tid; it < D_NB * 21; it += NT) {
-        int b = it / 21, c = it - 21 * b, n = T.body_subtree[b];
-        float acc = 0.f;
-        for (int k = b; k < b + n; k++) acc += s.K[21 * k + c];
-        Ksub[it] = acc;
-    }
-    KP_SYNC();
-    for (int d = tid; d < D_NV; d += NT) {
-        const float* Kd = Ksub + 21 * T.dof_body[d];
-        float cd[6], f[6];
-#pragma unroll
-        for (int k = 0; k < 6; k++) cd[k] = s.cdof[6 * d + k];
-#pragma unroll
-        for (int r = 0; r < 6; r++) {
-            float acc = 0.f;
-#pragma unroll
-            for (int c = 0; c < 6; c++) acc += Kd[sym6_idx(r, c)] * cd[c];
-            f[r] = acc;
-        }
-#pragma unroll
-        for (int k = 0; k < 6; k++) s.f6[6 * d + k] = f[k];
-    }
-    KP_SYNC();
-    for (int e = tid; e < D_NM; e += NT) {
-        int i = T.m_row[e], j = T.m_col[e];
-        float v = s.qM[e] + dot6(lds6(s.cdof + 6 * j), lds6(s.f6 + 6 * i));
-        if (i == j && i >= 6 && s.lim_jar[i - 6] < 0.f) v += s.lim_D[i - 6];
-        s.qLD[e] = v;
-    }
-    KP_SYNC();
-}
-
 // primal cost at the current (qacc, mres, jar):  0.5 mres.(qacc - qacc_s) + sum 0.5 D jar_-^2
 template <int NT>
-__device__ float primal_cost(EnvLds& s, int tid) {
+__device__ float primal_cost(EnvLds& s, const Params& P, const float* qacc, int tid) {
     float c = 0.f;
-    for (int i = tid; i < D_NV; i += NT) c += 0.5f * s.mres[i] * (s.qacc[i] - s.qacc_s[i]);
-    for (int r = tid; r < 4 * s.ncon; r += NT) { float x = s.jar[r]; if (x < 0.f) c += 0.5f * s.con_D[r >> 2] * x * x; }
+    for (int i = tid; i < D_NV; i += NT) c += 0.5f * s.mres[i] * (qacc[i] - s.qacc_s[i]);
+    for (int k = tid; k < s.ncon; k += NT) {
+        const float Dc = s.con_D[k], jn = s.jar3[3 * k], jt1 = s.jar3[3 * k + 1], jt2 = s.jar3[3 * k + 2];
+#pragma unroll
+        for (int e = 0; e < 4; e++) { float x = row_val(e, P.mu, jn, jt1, jt2); if (x < 0.f) c += 0.5f * Dc * x * x; }
+    }
     for (int j = tid; j < D_NU; j += NT) { float x = s.lim_jar[j]; if (x < 0.f) c += 0.5f * s.lim_D[j] * x * x; }
     return block_sum<NT>(s, c, tid);
 }
 
-// constraint solve: Newton on the primal problem, exact line search.  Returns iterations used.
+// constraint solve: Newton on the primal problem (mj_solNewton) with an exact line search.  Returns iterations.
+// On entry sv holds the spatial accelerations of qacc_s (left by the smooth aba_solve), jv3 holds aref.
 template <int NT>
-__device__ int solve_constraints(EnvLds& s, const DevTables& T, const Params& P, const PairTable<NT>& pt,
-                                 const uint8_t* __restrict__ anc_dof, int tid) {
-    // start from qacc_smooth: M qacc_s = qfrc_smooth  =>  mres = 0
+__device__ int solve_constraints(EnvLds& s, const Params& P, int depth, int tid) {
     for (int i = tid; i < D_NV; i += NT) { s.qacc[i] = s.qacc_s[i]; s.mres[i] = 0.f; }
-    for (int j = tid; j < D_NU; j += NT) s.lim_jar[j] = 0.f;
     KP_SYNC();
     if (s.ncon == 0 && s.nlim == 0) return 0;
-    spatial_accumulate<NT>(s, T, s.qacc, tid);
-    eval_rows<NT>(s, s.qacc, s.jar, s.lim_jar, true, P, tid);
-    // inactive limit rows must never look active
-    for (int j = tid; j < D_NU; j += NT) if (s.lim_sgn[j] == 0.f) s.lim_jar[j] = 0.f;
-    KP_SYNC();
-    float cost = primal_cost<NT>(s, tid);
+    // start from qacc_smooth (M qacc_s = qfrc_smooth => mres = 0)
+    eval_rows<NT>(s, s.qacc_s, s.jar3, s.lim_jar, true, tid);
+    float cost = primal_cost<NT>(s, P, s.qacc, tid);
     int it = 0;
     for (; it < P.max_iter; it++) {
         // gradient = mres - J^T f
-        wrench_project<NT>(s, T, P, nullptr, s.grad, false, true, tid);
+        wrench_project<NT>(s, P, nullptr, s.grad, false, true, tid);
         float g2 = 0.f;
-        for (int i = tid; i < D_NV; i += NT) { float g = s.mres[i] + s.grad[i]; s.grad[i] = g; g2 += g * g; }
+        for (int i = tid; i < D_NV; i += NT) {
+            float g = s.mres[i] + s.grad[i];
+            s.grad[i] = g; g2 += g * g;
+            s.x[i] = -g;
+            s.extra[i] = (i >= 6 && s.lim_jar[i - 6] < 0.f) ? s.lim_D[i - 6] : 0.f;
+        }
         g2 = block_sum<NT>(s, g2, tid);
         KP_SYNC();
         if (P.scale * sqrtf(g2) < P.tol) break;
-        assemble_hessian<NT>(s, T, P, tid);
-        factor_sparse<NT>(s, T, pt, tid);
-        for (int i = tid; i < D_NV; i += NT) s.x[i] = -s.grad[i];
-        KP_SYNC();
-        solve_sparse<NT>(s, T, anc_dof, tid);
-        for (int i = tid; i < D_NV; i += NT) s.search[i] = s.x[i];
-        KP_SYNC();
-        spatial_accumulate<NT>(s, T, s.search, tid);
-        eval_rows<NT>(s, s.search, s.jv, s.lim_jv, false, P, tid);
-        wrench_project<NT>(s, T, P, s.search, s.Mv, true, false, tid);
+        // search = -H^-1 grad,  H = M + J^T D_active J : articulated-body pass with contact inertia
+        aba_solve<NT>(s, P, s.x, s.search, true, depth, tid);
+        eval_rows<NT>(s, s.search, s.jv3, s.lim_jv, false, tid);           // aref (in jv3) is folded into jar3 by now
+        wrench_project<NT>(s, P, s.search, s.Mv, true, false, tid);
         // exact line search on phi(alpha)
         float g0 = 0.f, h0 = 0.f;
         for (int i = tid; i < D_NV; i += NT) { g0 += s.search[i] * s.mres[i]; h0 += s.search[i] * s.Mv[i]; }
@@ -532,9 +467,15 @@ __device__ int solve_constraints(EnvLds& s, const DevTables& T, const Params& P,
         float alpha = 0.f, lo = 0.f, hi = 3.0e38f;
         for (int ls = 0; ls < 20; ls++) {
             float d1 = 0.f, d2 = 0.f;
-            for (int r = tid; r < 4 * s.ncon; r += NT) {
-                float jv = s.jv[r], x = s.jar[r] + alpha * jv;
-                if (x < 0.f) { float Dc = s.con_D[r >> 2]; d1 += Dc * x * jv; d2 += Dc * jv * jv; }
+            for (int k = tid; k < s.ncon; k += NT) {
+                const float Dc = s.con_D[k];
+                const float vn = s.jv3[3 * k], vt1 = s.jv3[3 * k + 1], vt2 = s.jv3[3 * k + 2];
+                const float jn = s.jar3[3 * k] + alpha * vn, jt1 = s.jar3[3 * k + 1] + alpha * vt1, jt2 = s.jar3[3 * k + 2] + alpha * vt2;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    float x = row_val(e, P.mu, jn, jt1, jt2);
+                    if (x < 0.f) { float jv = row_val(e, P.mu, vn, vt1, vt2); d1 += Dc * x * jv; d2 += Dc * jv * jv; }
+                }
             }
             for (int j = tid; j < D_NU; j += NT) {
                 if (s.lim_sgn[j] != 0.f) { float jv = s.lim_jv[j], x = s.lim_jar[j] + alpha * jv; if (x < 0.f) { d1 += s.lim_D[j] * x * jv; d2 += s.lim_D[j] * jv * jv; } }
@@ -551,10 +492,10 @@ __device__ int solve_constraints(EnvLds& s, const DevTables& T, const Params& P,
         }
         if (!(alpha > 0.f)) break;
         for (int i = tid; i < D_NV; i += NT) { s.qacc[i] += alpha * s.search[i]; s.mres[i] += alpha * s.Mv[i]; }
-        for (int r = tid; r < 4 * s.ncon; r += NT) s.jar[r] += alpha * s.jv[r];
+        for (int k = tid; k < 3 * s.ncon; k += NT) s.jar3[k] += alpha * s.jv3[k];
         for (int j = tid; j < D_NU; j += NT) if (s.lim_sgn[j] != 0.f) s.lim_jar[j] += alpha * s.lim_jv[j];
         KP_SYNC();
-        float newcost = primal_cost<NT>(s, tid);
+        float newcost = primal_cost<NT>(s, P, s.qacc, tid);
         float improvement = P.scale * (cost - newcost);
         cost = newcost;
         if (improvement < P.tol) { it++; break; }
@@ -572,17 +513,19 @@ __global__ __launch_bounds__(NT) void kp_step_kernel(StepArgs A) {
     if (A.env_mask && !A.env_mask[env]) return;
     const DevTables& T = A.T;
     const Params& P = A.P;
-    const uint8_t* anc_dof = T.anc_dof;
-    PairTable<NT> pt; pt.init(tid);
+    const int depth = tid < D_NB ? T.body_depth[tid] : -1;
 
     // ---- load: derived state first (the state the last forward pass ran on), then the real state
     for (int i = tid; i < D_NQ; i += NT) { s.qpos[i] = A.qpos_d[(size_t)env * D_NQ + i]; s.tq[i] = A.target_qpos ? A.target_qpos[(size_t)env * D_NQ + i] : 0.f; }
-    for (int i = tid; i < D_NV; i += NT) { s.qvel[i] = A.qvel_d[(size_t)env * D_NV + i]; s.act[i] = A.action ? A.action[(size_t)env * D_NV + i] : 0.f; s.warm[i] = A.warm[(size_t)env * D_NV + i]; }
+    for (int i = tid; i < D_NV; i += NT) {
+        s.qvel[i] = A.qvel_d[(size_t)env * D_NV + i]; s.act[i] = A.action ? A.action[(size_t)env * D_NV + i] : 0.f;
+        s.arm[i] = T.dof_armature[i]; s.dbody[i] = T.dof_body[i]; s.extra[i] = 0.f; s.qacc[i] = 0.f;
+    }
+    if (tid < D_NB) { s.bpar[tid] = (unsigned char)(T.body_parent[tid] < 0 ? 0 : T.body_parent[tid]); s.bsub[tid] = T.body_subtree[tid]; s.bdep[tid] = T.body_depth[tid]; }
     if (tid < 8) s.applied[tid] = 0.f;
     if (tid == 0) { s.ncon = 0; s.nlim = 0; s.flag = 0; }
     KP_SYNC();
-    forward_kin_bias<NT>(s, T, P, tid);
-    if (A.n_substeps > 0 && P.stale) crb_mass_matrix<NT>(s, T, tid);
+    forward_kin_bias<NT>(s, T, P, depth, tid);
     float qd_save_q[(D_NQ + NT - 1) / NT], qd_save_v[(D_NV + NT - 1) / NT];
 #pragma unroll
     for (int n = 0; n < (D_NQ + NT - 1) / NT; n++) { int i = tid + n * NT; qd_save_q[n] = i < D_NQ ? s.qpos[i] : 0.f; }
@@ -596,31 +539,27 @@ __global__ __launch_bounds__(NT) void kp_step_kernel(StepArgs A) {
     }
     int niter_total = 0, maxcon = 0;
     for (int sub = 0; sub < A.n_substeps; sub++) {
-        if (P.stale) spd_torque_rfc<NT>(s, T, P, pt, anc_dof, tid);
+        // stale mode: the controller sees M / bias of the previous forward pass (cinert, cdof, bias still in LDS)
+        if (P.stale) spd_torque_rfc<NT>(s, T, P, depth, tid);
         // ---- mj_forward at the current state
 #pragma unroll
         for (int n = 0; n < (D_NQ + NT - 1) / NT; n++) { int i = tid + n * NT; if (i < D_NQ) qd_save_q[n] = s.qpos[i]; }
 #pragma unroll
         for (int n = 0; n < (D_NV + NT - 1) / NT; n++) { int i = tid + n * NT; if (i < D_NV) qd_save_v[n] = s.qvel[i]; }
-        forward_kin_bias<NT>(s, T, P, tid);
-        crb_mass_matrix<NT>(s, T, tid);
-        if (!P.stale) spd_torque_rfc<NT>(s, T, P, pt, anc_dof, tid);
+        forward_kin_bias<NT>(s, T, P, depth, tid);
         collide_plane<NT>(s, T, P, tid);
-        make_constraint<NT>(s, T, P, tid);
+        make_constraint<NT>(s, T, P, tid);                 // needs sv = cvel: before any aba_solve
+        if (!P.stale) spd_torque_rfc<NT>(s, T, P, depth, tid);
         for (int i = tid; i < D_NV; i += NT) {
             float f = -s.bias[i] + (i < 6 ? s.applied[i] : s.ctrl[i - 6]);
-            s.smooth[i] = f; s.x[i] = f;
+            s.smooth[i] = f; s.extra[i] = 0.f;
         }
-        for (int e = tid; e < D_NM; e += NT) s.qLD[e] = s.qM[e];
         KP_SYNC();
-        factor_sparse<NT>(s, T, pt, tid);
-        solve_sparse<NT>(s, T, anc_dof, tid);
-        for (int i = tid; i < D_NV; i += NT) s.qacc_s[i] = s.x[i];
-        KP_SYNC();
-        niter_total += solve_constraints<NT>(s, T, P, pt, anc_dof, tid);
+        aba_solve<NT>(s, P, s.smooth, s.qacc_s, false, depth, tid);   // qacc_smooth = M^-1 qfrc_smooth; sv = its spatial accel
+        niter_total += solve_constraints<NT>(s, P, depth, tid);
         maxcon = max(maxcon, s.ncon);
         // ---- semi-implicit Euler (mj_Euler, no damping)
-        for (int i = tid; i < D_NV; i += NT) { float v = s.qvel[i] + P.h * s.qacc[i]; s.qvel[i] = v; s.warm[i] = s.qacc[i]; }
+        for (int i = tid; i < D_NV; i += NT) s.qvel[i] += P.h * s.qacc[i];
         KP_SYNC();
         for (int j = tid; j < D_NU; j += NT) s.qpos[7 + j] += P.h * s.qvel[6 + j];
         if (tid == 0) {
@@ -639,12 +578,12 @@ __global__ __launch_bounds__(NT) void kp_step_kernel(StepArgs A) {
         for (int n = 0; n < (D_NQ + NT - 1) / NT; n++) { int i = tid + n * NT; if (i < D_NQ) qd_save_q[n] = s.qpos[i]; }
 #pragma unroll
         for (int n = 0; n < (D_NV + NT - 1) / NT; n++) { int i = tid + n * NT; if (i < D_NV) qd_save_v[n] = s.qvel[i]; }
-        forward_kin_bias<NT>(s, T, P, tid);
+        forward_kin_bias<NT>(s, T, P, depth, tid);
     }
     // ---- store
     bool bad = false;
     for (int i = tid; i < D_NQ; i += NT) { float v = s.qpos[i]; bad |= !(fabsf(v) < 1e10f); if (A.n_substeps > 0) A.qpos[(size_t)env * D_NQ + i] = v; }
-    for (int i = tid; i < D_NV; i += NT) { float v = s.qvel[i]; bad |= !(fabsf(v) < 1e10f); if (A.n_substeps > 0) { A.qvel[(size_t)env * D_NV + i] = v; A.warm[(size_t)env * D_NV + i] = s.warm[i]; } }
+    for (int i = tid; i < D_NV; i += NT) { float v = s.qvel[i]; bad |= !(fabsf(v) < 1e10f); if (A.n_substeps > 0) { A.qvel[(size_t)env * D_NV + i] = v; A.warm[(size_t)env * D_NV + i] = s.qacc[i]; } }
 #pragma unroll
     for (int n = 0; n < (D_NQ + NT - 1) / NT; n++) { int i = tid + n * NT; if (i < D_NQ) A.qpos_d[(size_t)env * D_NQ + i] = qd_save_q[n]; }
 #pragma unroll
