@@ -618,6 +618,8 @@ GETTER(qpos, qpos, NQ_MAX) GETTER(qvel, qvel, NV_MAX) GETTER(xpos, xpos, 72) GET
 GETTER(qM, qM, NM_MAX) GETTER(qfrc_bias, qfrc_bias, NV_MAX) GETTER(qacc, qacc, NV_MAX) GETTER(qacc_smooth, qacc_smooth, NV_MAX)
 GETTER(subtree_com, subtree_com, 3) GETTER(ctrl, ctrl, 69) GETTER(qfrc_applied, qfrc_applied, NV_MAX) GETTER(qfrc_constraint, qfrc_constraint, NV_MAX)
 GETTER(cvel, cvel, 144)
+void kpo_get_efc(const kpo_data *d, double *force, double *D, double *aref) { memcpy(force, d->efc_force, 8 * d->nefc); memcpy(D, d->efc_D, 8 * d->nefc); memcpy(aref, d->efc_aref, 8 * d->nefc); }
+void kpo_get_efc_J(const kpo_data *d, double *J) { for (int e = 0; e < d->nefc; e++) memcpy(J + (size_t)e * NV_MAX, d->efc_J[e], 8 * NV_MAX); }
 int kpo_get_ncon(const kpo_data *d) { return d->ncon; }
 int kpo_get_nefc(const kpo_data *d) { return d->nefc; }
 int kpo_get_niter(const kpo_data *d) { return d->solver_niter; }

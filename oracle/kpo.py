@@ -50,6 +50,8 @@ def lib():
         L.kpo_set_ctrl.argtypes = [P, D, D]
         L.kpo_solveM.argtypes = [P, P, D]
         L.kpo_get_contacts.argtypes = [P, I, D, D]
+        L.kpo_get_efc.argtypes = [P, D, D, D]
+        L.kpo_get_efc_J.argtypes = [P, D]
         L.kpo_rollout_batch.argtypes = [P, C.c_int, D, D, D, D, C.c_int, C.c_int]
         for g in ("ncon", "nefc", "niter"):
             getattr(L, "kpo_get_" + g).argtypes = [P]; getattr(L, "kpo_get_" + g).restype = C.c_int
@@ -132,6 +134,12 @@ class OracleSim:
         body = np.zeros(64, np.int32); pos = np.zeros((64, 3)); dist = np.zeros(64)
         self.L.kpo_get_contacts(self.d, body.ctypes.data_as(C.POINTER(C.c_int)), _dp(pos), _dp(dist))
         return body[:n], pos[:n], dist[:n]
+
+    def efc(self):
+        n = self.nefc
+        f, D, a, J = np.zeros(max(n, 1)), np.zeros(max(n, 1)), np.zeros(max(n, 1)), np.zeros((max(n, 1), NV))
+        self.L.kpo_get_efc(self.d, _dp(f), _dp(D), _dp(a)); self.L.kpo_get_efc_J(self.d, _dp(J))
+        return f[:n], D[:n], a[:n], J[:n]
 
     @property
     def nefc(self):
