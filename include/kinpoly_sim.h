@@ -157,6 +157,11 @@ double kp_sim_last_step_seconds(kp_sim*);
 int kp_sim_timing_reset(kp_sim*);
 double kp_sim_timing_mean_seconds(kp_sim*, int* n_launches);
 
+/* Diagnostic: mean shader-clock cycles per environment the last kp_sim_step_ctrl spent in each phase
+ * {stable-PD, kinematics+bias, collision, constraint set-up, smooth solve, contact solve, integrate, total}.
+ * Collected only if the environment variable KP_PROFILE=1 was set at kp_sim_create.  Synchronises. */
+int kp_sim_phase_cycles(kp_sim*, double* out8_host);
+
 const char* kp_last_error(void);
 const char* kp_version(void);
 

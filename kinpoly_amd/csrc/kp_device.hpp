@@ -25,6 +25,7 @@ struct DevTables {
     const uint8_t *dof_body;
     const int8_t *body_parent;
     const uint8_t *body_depth, *body_subtree, *lev_start, *lev_body, *jnt_limited;
+    const uint32_t *sched8;   // [64][9] static tree schedule of the 8-lanes-per-body passes (see Lane8)
 };
 
 struct Params {
@@ -47,7 +48,8 @@ struct __attribute__((aligned(16))) EnvLds {
     float cdof[450];                      // motion axis of every dof [ang; lin] about o
     float sv[144], sa[144], sw[144];      // per-body spatial scratch (velocity / acceleration / wrench)
     float U[450], Dinv[76], uj[76];       // articulated-body pass: U_j = IA s_j, 1/D_j, u_j
-    float IAa[504], pAa[144];             // articulated inertia / bias force handed to the parent
+    float IAa[25 * 22], pAa[25 * 6];      // articulated inertia / bias force handed to the parent; slot 21 of a record and
+                                          // record 24 are kept 0 so that padded / absent operands load a zero without exec masking
     float arm[76];                        // dof armature
     float bias[76], smooth[76], qacc_s[76], qacc[76], grad[76], search[76], Mv[76], mres[76], x[76], extra[76];
     float ctrl[72];
@@ -58,7 +60,7 @@ struct __attribute__((aligned(16))) EnvLds {
     float jar3[D_MAXCON * 3], jv3[D_MAXCON * 3];   // contact-frame (normal, t1, t2) residuals J qacc - aref and J search
     float lim_sgn[72], lim_aref[72], lim_D[72], lim_jar[72], lim_jv[72];
     float red[8];
-    unsigned char bpar[D_NB], bsub[D_NB], bdep[D_NB], dbody[76];
+    unsigned char bpar[D_NB], bsub[D_NB], levb[D_NB], levs[12], dbody[76];
     int ncon, nlim, flag;
 };
 

@@ -39,6 +39,7 @@ struct kp_sim {
     float *prev_bquat = nullptr, *prev_hpos = nullptr, *diffw = nullptr;
     float *t_qpos = nullptr, *t_wbpos = nullptr, *t_wbquat = nullptr, *t_bquat = nullptr, *t_com = nullptr;
     int* diag = nullptr;
+    unsigned long long* prof = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     std::vector<hipEvent_t> ring;  // event pairs of the recorded launches
@@ -109,6 +110,26 @@ bool build_tables(kp_sim* s) {
     lev_start[D_NLEV + 1] = (int)lev_body.size();
     if ((int)lev_body.size() != NB || lev_start[D_NLEV] != NB) return false;  // tree deeper than D_NLEV levels
     T.lev_start = upload<uint8_t>(s, lev_start, &ok); T.lev_body = upload<uint8_t>(s, lev_body, &ok);
+    // static schedule of the 8-lanes-per-body tree passes: lane = 8 * slot + row; per level one word
+    //   body | parent << 5 | child0 << 10 | child1 << 15 | child2 << 20 | active << 25      (31 = none)
+    std::vector<unsigned> sched(64 * D_NLEV, 0);
+    for (int lev = 0; lev < D_NLEV; lev++) {
+        int nb = lev_start[lev + 1] - lev_start[lev];
+        if (nb > 8) return false;
+        for (int slot = 0; slot < 8; slot++)
+            for (int r = 0; r < 8; r++) {
+                unsigned w = 0;
+                if (slot < nb) {
+                    int b = lev_body[lev_start[lev] + slot];
+                    int ch[3] = {31, 31, 31}, nc = 0;
+                    for (int k = b + 1; k < NB; k++) if (m.body_parent[k] == b) { if (nc >= 3) return false; ch[nc++] = k; }
+                    int par = m.body_parent[b] < 0 ? 31 : m.body_parent[b];
+                    w = (unsigned)b | ((unsigned)par << 5) | ((unsigned)ch[0] << 10) | ((unsigned)ch[1] << 15) | ((unsigned)ch[2] << 20) | (1u << 25);
+                }
+                sched[(8 * slot + r) * D_NLEV + lev] = w;
+            }
+    }
+    T.sched8 = upload<uint32_t>(s, sched, &ok);
     // scalar parameters
     auto& P = s->P;
     const auto& o = m.opt;
@@ -134,7 +155,7 @@ int launch_step(kp_sim* s, const float* action, int nsub, const uint8_t* mask, b
     A.T = s->T; A.P = s->P; A.n_envs = s->n; A.n_substeps = nsub;
     A.qpos = s->qpos; A.qvel = s->qvel; A.qpos_d = s->qpos_d; A.qvel_d = s->qvel_d; A.warm = s->warm;
     A.target_qpos = s->t_qpos; A.action = action; A.env_mask = mask;
-    A.xpos = s->xpos; A.xquat = s->xquat; A.xipos = s->xipos; A.diag = s->diag;
+    A.xpos = s->xpos; A.xquat = s->xquat; A.xipos = s->xipos; A.diag = s->diag; A.prof = s->prof;
     size_t lds = sizeof(kp::EnvLds);
     hipEvent_t e0 = s->ev0, e1 = s->ev1;
     if (time_it && s->ring_on && s->ring_used < 4096) {
@@ -221,6 +242,7 @@ kp_sim* kp_sim_create(const kp_model* m, int n_envs, int device_id, void* stream
     s->scratch = dalloc(s, N * 96, &ok);
     s->prev_bquat = dalloc(s, N * 96, &ok); s->prev_hpos = dalloc(s, N * 7, &ok);
     s->diag = (int*)dalloc(s, N * 4, &ok);
+    if (const char* e = std::getenv("KP_PROFILE")) if (e[0] == '1') s->prof = (unsigned long long*)dalloc(s, N * 16, &ok);
     if (!ok || hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) {
         fail("kp_sim_create: device allocation / table build failed");
         kp_sim_destroy(s);
@@ -432,6 +454,17 @@ double kp_sim_last_step_seconds(kp_sim* s) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, s->last0, s->last1) != hipSuccess) return -1.0;
     return ms * 1e-3;
+}
+
+int kp_sim_phase_cycles(kp_sim* s, double* out) {
+    if (!s || !out) return fail("kp_sim_phase_cycles: null argument");
+    if (!s->prof) return fail("kp_sim_phase_cycles: create the simulator with KP_PROFILE=1");
+    HIP_OK(hipSetDevice(s->device));
+    HIP_OK(hipStreamSynchronize(s->stream));
+    std::vector<unsigned long long> h((size_t)s->n * 8);
+    HIP_OK(hipMemcpy(h.data(), s->prof, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 8; k++) { double acc = 0; for (int e = 0; e < s->n; e++) acc += (double)h[(size_t)e * 8 + k]; out[k] = acc / s->n; }
+    return 0;
 }
 
 int kp_sim_timing_reset(kp_sim* s) {

@@ -35,12 +35,25 @@ struct StepArgs {
     // outputs: kinematics of the last forward pass (x_14 in stale mode)
     float *xpos, *xquat, *xipos;
     int* diag;  // [N,4]: ncon (last substep), newton iterations (sum), flags, max ncon
+    unsigned long long* prof;  // optional [N,8] shader-clock cycles per phase (kp_sim_phase_cycles)
 };
+
+// wave-wide sum without LDS traffic: xor butterflies inside each 16-lane row with DPP (quad_perm, row_half_mirror,
+// row_mirror), then the four row sums are combined through v_readlane.  Every lane gets the same bits.
+__device__ __forceinline__ float wave_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // xor 1
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // xor 2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // half mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row mirror
+    const int vi = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 48));
+    return (r0 + r1) + (r2 + r3);
+}
 
 template <int NT>
 __device__ __forceinline__ float block_sum(EnvLds& s, float v, int tid) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v = wave_sum(v);
     if (NT > 64) {
         KP_SYNC();
         if ((tid & 63) == 0) s.red[tid >> 6] = v;
@@ -66,19 +79,28 @@ __device__ __forceinline__ float row_val(int e, float mu, float jn, float jt1, f
 }
 __device__ __forceinline__ V3 to_frame(V3 v) { return v3(v.z, v.y, -v.x); }  // (n, t1, t2) components of a world vector
 
-// ---------------------------------------------------------------- kinematics + velocities + bias (one tree pass)
+// ---------------------------------------------------------------- kinematics + velocities + bias
+// Three phases so that the level-serial chain stays short:
+//   0. half-angle sin/cos of all 69 hinge angles, one lane per hinge (scratch: s.U, free outside the ABA passes);
+//   K. level-synchronous chain (lane = body): world pose, motion axes cdof, spatial velocity cvel and the
+//      velocity-product acceleration cacc (mj_kinematics + mj_comVel + the forward half of mj_rne);
+//   B. body-parallel (24 lanes at once): COM, world inertia about o, body wrench I a + v x* I v; then subtree
+//      sums and projection on the dofs (backward half of mj_rne) -> qfrc_bias.
 template <int NT>
-__device__ void forward_kin_bias(EnvLds& s, const DevTables& T, const Params& P, int depth, int tid) {
+__device__ __forceinline__ void forward_kin_bias(EnvLds& s, const DevTables& T, const Params& P, int depth, V3 bpos, int tid) {
+    float* sc = s.U;
+    for (int i = tid; i < D_NU; i += NT) { float sn, cs; sincosf(0.5f * s.qpos[7 + i], &sn, &cs); sc[2 * i] = sn; sc[2 * i + 1] = cs; }
+    KP_SYNC();
     for (int lev = 0; lev < D_NLEV; lev++) {
         if (depth == lev) {
             const int b = tid;
             S6 cv, ca;
-            V3 pos, o;
+            V3 pos;
             Q4 q;
             if (b == 0) {
                 q = qnormalize(Q4{s.qpos[3], s.qpos[4], s.qpos[5], s.qpos[6]});
                 s.qpos[3] = q.w; s.qpos[4] = q.x; s.qpos[5] = q.y; s.qpos[6] = q.z;
-                pos = ld3(s.qpos); o = pos;
+                pos = ld3(s.qpos);
                 float R[9]; q2mat(q, R);
                 V3 vl = ld3(s.qvel), wb = ld3(s.qvel + 3);
                 V3 ww = mulmat(R, wb);
@@ -93,55 +115,65 @@ __device__ void forward_kin_bias(EnvLds& s, const DevTables& T, const Params& P,
                 ca = S6{v3(0.f, 0.f, 0.f), v3(-P.gx, -P.gy, -P.gz) + cross(vl, ww)};
             } else {
                 const int p = s.bpar[b];
-                o = ld3(s.xpos);
+                const int d0 = 6 + 3 * (b - 1);
+                // one LDS round: parent pose / velocity / acceleration, own joint state
+                const V3 o = ld3(s.xpos);
                 q = Q4{s.xquat[4 * p], s.xquat[4 * p + 1], s.xquat[4 * p + 2], s.xquat[4 * p + 3]};
-                pos = ld3(s.xpos + 3 * p) + qrot(q, ld3(T.body_pos + 3 * b));
+                const V3 ppos = ld3(s.xpos + 3 * p);
                 cv = lds6(s.sv + 6 * p); ca = lds6(s.sa + 6 * p);
-                V3 r = o - pos;
+                const float qd0 = s.qvel[d0], qd1 = s.qvel[d0 + 1], qd2 = s.qvel[d0 + 2];
+                const float sn0 = sc[2 * (d0 - 6)], cs0 = sc[2 * (d0 - 6) + 1], sn1 = sc[2 * (d0 - 5)], cs1 = sc[2 * (d0 - 5) + 1];
+                const float sn2 = sc[2 * (d0 - 4)], cs2 = sc[2 * (d0 - 4) + 1];
+                pos = ppos + qrot(q, bpos);
+                const V3 r = o - pos;
+                const float qds[3] = {qd0, qd1, qd2}, sns[3] = {sn0, sn1, sn2}, css[3] = {cs0, cs1, cs2};
 #pragma unroll
                 for (int j = 0; j < 3; j++) {
-                    const int d = 6 + 3 * (b - 1) + j;
-                    V3 e = j == 0 ? v3(0.f, 0.f, 1.f) : (j == 1 ? v3(0.f, 1.f, 0.f) : v3(1.f, 0.f, 0.f));
-                    V3 axis = qrot(q, e);
-                    S6 cd = S6{axis, cross(axis, r)};
-                    sts6(s.cdof + 6 * d, cd);
-                    S6 cdd = cross_motion(cv, cd);
-                    float qd = s.qvel[d];
-                    cv = cv + qd * cd; ca = ca + qd * cdd;
-                    float sn, cs; sincosf(0.5f * s.qpos[d + 1], &sn, &cs);
-                    q = qmul(q, Q4{cs, e.x * sn, e.y * sn, e.z * sn});
+                    const V3 e = j == 0 ? v3(0.f, 0.f, 1.f) : (j == 1 ? v3(0.f, 1.f, 0.f) : v3(1.f, 0.f, 0.f));
+                    const V3 axis = qrot(q, e);
+                    const S6 cd = S6{axis, cross(axis, r)};
+                    sts6(s.cdof + 6 * (d0 + j), cd);
+                    const S6 cdd = cross_motion(cv, cd);
+                    cv = cv + qds[j] * cd; ca = ca + qds[j] * cdd;
+                    q = qmul(q, Q4{css[j], e.x * sns[j], e.y * sns[j], e.z * sns[j]});
                 }
                 q = qnormalize(q);
             }
-            float R[9]; q2mat(q, R);
             st3(s.xpos + 3 * b, pos);
             s.xquat[4 * b] = q.w; s.xquat[4 * b + 1] = q.x; s.xquat[4 * b + 2] = q.y; s.xquat[4 * b + 3] = q.z;
-            V3 xi = pos + mulmat(R, ld3(T.body_ipos + 3 * b));
-            st3(s.xipos + 3 * b, xi);
-            // inertia about o in world axes
-            const float* Ib = T.body_inertia + 6 * b;
-            float I3[9] = {Ib[0], Ib[3], Ib[4], Ib[3], Ib[1], Ib[5], Ib[4], Ib[5], Ib[2]};
-            float Tm[9], W[9];
-#pragma unroll
-            for (int i = 0; i < 3; i++)
-#pragma unroll
-                for (int j = 0; j < 3; j++) Tm[3 * i + j] = R[3 * i] * I3[j] + R[3 * i + 1] * I3[3 + j] + R[3 * i + 2] * I3[6 + j];
-#pragma unroll
-            for (int i = 0; i < 3; i++)
-#pragma unroll
-                for (int j = 0; j < 3; j++) W[3 * i + j] = Tm[3 * i] * R[3 * j] + Tm[3 * i + 1] * R[3 * j + 1] + Tm[3 * i + 2] * R[3 * j + 2];
-            V3 rr = xi - o;
-            float mass = T.body_mass[b], r2 = dot(rr, rr);
-            float* ci = s.cinert + 10 * b;
-            ci[0] = W[0] + mass * (r2 - rr.x * rr.x); ci[1] = W[4] + mass * (r2 - rr.y * rr.y); ci[2] = W[8] + mass * (r2 - rr.z * rr.z);
-            ci[3] = W[1] - mass * rr.x * rr.y; ci[4] = W[2] - mass * rr.x * rr.z; ci[5] = W[5] - mass * rr.y * rr.z;
-            ci[6] = mass * rr.x; ci[7] = mass * rr.y; ci[8] = mass * rr.z; ci[9] = mass;
             sts6(s.sv + 6 * b, cv); sts6(s.sa + 6 * b, ca);
-            S6 f = inert_mul(ci, ca) + cross_force(cv, inert_mul(ci, cv));
-            sts6(s.sw + 6 * b, f);
         }
         KP_SYNC();
     }
+    if (tid < D_NB) {
+        const int b = tid;
+        const V3 o = ld3(s.xpos), pos = ld3(s.xpos + 3 * b);
+        float R[9];
+        q2mat(Q4{s.xquat[4 * b], s.xquat[4 * b + 1], s.xquat[4 * b + 2], s.xquat[4 * b + 3]}, R);
+        const S6 cv = lds6(s.sv + 6 * b), ca = lds6(s.sa + 6 * b);
+        const V3 xi = pos + mulmat(R, ld3(T.body_ipos + 3 * b));
+        st3(s.xipos + 3 * b, xi);
+        const float* Ib = T.body_inertia + 6 * b;
+        float I3[9] = {Ib[0], Ib[3], Ib[4], Ib[3], Ib[1], Ib[5], Ib[4], Ib[5], Ib[2]};
+        float Tm[9], W[9];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) Tm[3 * i + j] = R[3 * i] * I3[j] + R[3 * i + 1] * I3[3 + j] + R[3 * i + 2] * I3[6 + j];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) W[3 * i + j] = Tm[3 * i] * R[3 * j] + Tm[3 * i + 1] * R[3 * j + 1] + Tm[3 * i + 2] * R[3 * j + 2];
+        const V3 rr = xi - o;
+        const float mass = T.body_mass[b], r2 = dot(rr, rr);
+        float* ci = s.cinert + 10 * b;
+        ci[0] = W[0] + mass * (r2 - rr.x * rr.x); ci[1] = W[4] + mass * (r2 - rr.y * rr.y); ci[2] = W[8] + mass * (r2 - rr.z * rr.z);
+        ci[3] = W[1] - mass * rr.x * rr.y; ci[4] = W[2] - mass * rr.x * rr.z; ci[5] = W[5] - mass * rr.y * rr.z;
+        ci[6] = mass * rr.x; ci[7] = mass * rr.y; ci[8] = mass * rr.z; ci[9] = mass;
+        const S6 f = inert_mul(ci, ca) + cross_force(cv, inert_mul(ci, cv));
+        sts6(s.sw + 6 * b, f);
+    }
+    KP_SYNC();
     // subtree sums of the body wrenches -> sa (cacc no longer needed), then project on the dofs
     for (int it = tid; it < D_NB * 6; it += NT) {
         int b = it / 6, c = it - 6 * b, n = s.bsub[b];
@@ -154,106 +186,214 @@ __device__ void forward_kin_bias(EnvLds& s, const DevTables& T, const Params& P,
     KP_SYNC();
 }
 
-// ---------------------------------------------------------------- articulated-body solve
+// ---------------------------------------------------------------- articulated-body solve, 8 lanes per body
+// Lane layout inside a tree level: tid = 8 * slot + r; slot = index of the body within the level (<= 5 bodies),
+// r = row of the 6x6 articulated inertia (rows 6, 7 are zero padding).  A lane keeps its row in "XOR order":
+// register k holds column r ^ KX[k], KX = {0,1,2,3,7,6,5,4}.  With that order the three DPP exchanges
+// quad_perm[1,0,3,2] (xor 1), quad_perm[2,3,0,1] (xor 2) and row_half_mirror (xor 7) implement both the
+// 8-lane sum and the 8-lane all-gather (7 moves) with results already aligned to the row registers, so the
+// rank-1 updates  IA -= U U^T / D  need no LDS round trip.
+__device__ __forceinline__ float dpp_x1(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)); }
+__device__ __forceinline__ float dpp_x2(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)); }
+__device__ __forceinline__ float dpp_x7(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true)); }
+__device__ __forceinline__ float sum8(float v) { v += dpp_x1(v); v += dpp_x2(v); v += dpp_x7(v); return v; }
+__device__ __forceinline__ void gather8(float v, float* g) {
+    g[0] = v; g[1] = dpp_x1(v); g[2] = dpp_x2(g[0]); g[3] = dpp_x2(g[1]);
+    g[4] = dpp_x7(g[0]); g[5] = dpp_x7(g[1]); g[6] = dpp_x7(g[2]); g[7] = dpp_x7(g[3]);
+}
+__device__ __forceinline__ float rcp_nr(float d) { float r = __builtin_amdgcn_rcpf(d); return r * (2.0f - d * r); }
+
+struct Lane8 {
+    int slot, r;
+    int col[8];      // column held by register k
+    int ciidx[8];    // index into the 10-float body inertia giving IA[r][col[k]] (times cisgn)
+    float cisgn[8];
+    int idx21[8];    // index into the 21-float symmetric storage
+    unsigned long long sb, sp, sc0, sc1, sc2;  // 5 bits per level: body, parent, children (31 = none) of this lane's slot
+    __device__ __forceinline__ void init(int tid, const uint32_t* __restrict__ sched8) {
+        slot = tid >> 3; r = tid & 7;
+        sb = sp = sc0 = sc1 = sc2 = 0ull;
+#pragma unroll
+        for (int l = 0; l < D_NLEV; l++) {
+            const unsigned w = tid < 64 ? sched8[tid * D_NLEV + l] : 0u;
+            const bool act = (w >> 25) & 1u;
+            sb |= (unsigned long long)(act ? (w & 31u) : 31u) << (5 * l);
+            sp |= (unsigned long long)(act ? ((w >> 5) & 31u) : 31u) << (5 * l);
+            const unsigned k0 = (w >> 10) & 31u, k1 = (w >> 15) & 31u, k2 = (w >> 20) & 31u;   // absent child -> zero record 24
+            sc0 |= (unsigned long long)((act && k0 != 31u) ? k0 : 24u) << (5 * l);
+            sc1 |= (unsigned long long)((act && k1 != 31u) ? k1 : 24u) << (5 * l);
+            sc2 |= (unsigned long long)((act && k2 != 31u) ? k2 : 24u) << (5 * l);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int kx = k < 4 ? k : 11 - k;
+            const int c = r ^ kx;
+            col[k] = c;
+            int idx = 0; float sg = 0.f;
+            if (r < 6 && c < 6) {
+                if (r < 3 && c < 3) { idx = (r == c) ? r : r + c + 2; sg = 1.f; }
+                else if (r >= 3 && c >= 3) { idx = 9; sg = (r == c) ? 1.f : 0.f; }
+                else {
+                    const int a = r < 3 ? r : c, l = (r < 3 ? c : r) - 3;   // [h]x(a, l)
+                    if (a != l) { idx = 6 + (3 - a - l); sg = (l == (a + 2) % 3) ? 1.f : -1.f; }
+                }
+            }
+            ciidx[k] = idx; cisgn[k] = sg;
+            const int rr = r < c ? r : c, cc = r < c ? c : r;
+            idx21[k] = (r < 6 && c < 6) ? (rr * (13 - rr)) / 2 + (cc - rr) : 21;   // 21 = the always-zero slot of a record
+        }
+    }
+};
+
 // out = (M + diag(s.extra) [+ J^T D_active J])^-1 rhs.  Leaves s.sv[b] = sum over ancestor dofs cdof_d out_d
 // (the spatial "acceleration" of every body induced by out).  rhs/out are LDS vectors (may alias).
+// eliminate the three dofs d0+2, d0+1, d0 of one body from its articulated inertia (row r in XOR order)
+__device__ __forceinline__ void aba_elim3(EnvLds& s, const Lane8& L, const float* rhs, int d0, bool store_ok, float* IAx, float& pA) {
+    const int r = L.r;
+    const bool rowok = r < 6;
+    float sxa[3][8], dsc[3], rh[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const int d = d0 + j;
+#pragma unroll
+        for (int k = 0; k < 8; k++) sxa[j][k] = s.cdof[6 * d + min(L.col[k], 5)];   // padding needs no mask: its IA entries and U are exact zeros
+        dsc[j] = s.arm[d] + s.extra[d];
+        rh[j] = rhs[d];
+    }
+    float Uo[3], Do[3], uo[3];
+#pragma unroll
+    for (int j = 2; j >= 0; j--) {
+        float Ur = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; k++) Ur += IAx[k] * sxa[j][k];
+        const float sr = sxa[j][0];
+        const float dsum = sum8(sr * Ur), usum = sum8(sr * pA);
+        const float D = dsc[j] + dsum, u = rh[j] - usum;
+        const float Dinv = rcp_nr(D);
+        float Ux[8];
+        gather8(Ur, Ux);
+        const float ur = Ur * Dinv;
+#pragma unroll
+        for (int k = 0; k < 8; k++) IAx[k] -= ur * Ux[k];
+        pA += Ur * (u * Dinv);
+        Uo[j] = Ur; Do[j] = Dinv; uo[j] = u;
+    }
+    if (store_ok && rowok) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) s.U[6 * (d0 + j) + r] = Uo[j];
+    }
+    if (store_ok && r == 0) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) { s.Dinv[d0 + j] = Do[j]; s.uj[d0 + j] = uo[j]; }
+    }
+}
+
+__device__ __forceinline__ float aba_fwd3(EnvLds& s, const Lane8& L, float* out, int d0, bool store_ok, float a) {
+    const int r = L.r;
+    const int rc = r < 6 ? r : 5;
+    const float rmask = r < 6 ? 1.f : 0.f;
+    float Ud[3], sd[3], ujd[3], Did[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const int d = d0 + j;
+        Ud[j] = rmask * s.U[6 * d + rc]; sd[j] = s.cdof[6 * d + rc];
+        ujd[j] = s.uj[d]; Did[j] = s.Dinv[d];
+    }
+    float qo[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const float qdd = (ujd[j] - sum8(Ud[j] * a)) * Did[j];
+        qo[j] = qdd;
+        a += qdd * sd[j];
+    }
+    if (store_ok && r == 0) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) out[d0 + j] = qo[j];
+    }
+    return a;
+}
+
 template <int NT>
-__device__ void aba_solve(EnvLds& s, const Params& P, const float* rhs, float* out, bool contact_inertia, int depth, int tid) {
+__device__ __forceinline__ void aba_solve(EnvLds& s, const Params& P, const Lane8& L, const float* rhs, float* out, bool contact_inertia, int tid) {
+    const int r = L.r;
+    const bool rowok = r < 6;
+#pragma nounroll
     for (int lev = D_NLEV - 1; lev >= 0; lev--) {
-        if (depth == lev) {
-            const int b = tid;
-            float IA[21], pA[6];
-            {
-                const float* ci = s.cinert + 10 * b;
-                const float hx = ci[6], hy = ci[7], hz = ci[8], m = ci[9];
-                IA[s6i(0, 0)] = ci[0]; IA[s6i(0, 1)] = ci[3]; IA[s6i(0, 2)] = ci[4]; IA[s6i(0, 3)] = 0.f; IA[s6i(0, 4)] = -hz; IA[s6i(0, 5)] = hy;
-                IA[s6i(1, 1)] = ci[1]; IA[s6i(1, 2)] = ci[5]; IA[s6i(1, 3)] = hz; IA[s6i(1, 4)] = 0.f; IA[s6i(1, 5)] = -hx;
-                IA[s6i(2, 2)] = ci[2]; IA[s6i(2, 3)] = -hy; IA[s6i(2, 4)] = hx; IA[s6i(2, 5)] = 0.f;
-                IA[s6i(3, 3)] = m; IA[s6i(3, 4)] = 0.f; IA[s6i(3, 5)] = 0.f; IA[s6i(4, 4)] = m; IA[s6i(4, 5)] = 0.f; IA[s6i(5, 5)] = m;
+        const int sh = 5 * lev;
+        const int bq = (int)((L.sb >> sh) & 31ull), c0 = (int)((L.sc0 >> sh) & 31ull), c1 = (int)((L.sc1 >> sh) & 31ull), c2 = (int)((L.sc2 >> sh) & 31ull);
+        const bool active = bq != 31;
+        const int b = active ? bq : 0;
+        // ---- one LDS round: body inertia row + children rows (the per-dof operands are fetched by aba_elim3 in the same round)
+        float IAx[8];
+        float pA;
+        {
+            const float* ci = s.cinert + 10 * b;
+            const float* r0 = s.IAa + 22 * c0; const float* r1 = s.IAa + 22 * c1; const float* r2 = s.IAa + 22 * c2;
+#pragma unroll
+            for (int k = 0; k < 8; k++) IAx[k] = (L.cisgn[k] * ci[L.ciidx[k]] + r0[L.idx21[k]]) + (r1[L.idx21[k]] + r2[L.idx21[k]]);
+            const int pr = rowok ? r : 6 * 24;                 // padding rows read the zero record
+            pA = (s.pAa[rowok ? 6 * c0 + r : pr] + s.pAa[rowok ? 6 * c1 + r : pr]) + s.pAa[rowok ? 6 * c2 + r : pr];
+        }
+        if (contact_inertia && active && s.con_start[b + 1] > s.con_start[b]) {
+            const V3 o = ld3(s.xpos);
+            float Krow[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const float mu = P.mu, mu2 = P.mu * P.mu;
+            for (int c = s.con_start[b]; c < s.con_start[b + 1]; c++) {
+                const V3 p = ld3(s.con_pos + 3 * c) - o;
+                const float Dc = s.con_D[c], jn = s.jar3[3 * c], jt1 = s.jar3[3 * c + 1], jt2 = s.jar3[3 * c + 2];
+                const float a0 = row_val(0, mu, jn, jt1, jt2) < 0.f, a1 = row_val(1, mu, jn, jt1, jt2) < 0.f;
+                const float a2 = row_val(2, mu, jn, jt1, jt2) < 0.f, a3 = row_val(3, mu, jn, jt1, jt2) < 0.f;
+                // G = sum_e a_e dir_e dir_e^T, dirs (0, mu, 1), (0, -mu, 1), (-mu, 0, 1), (mu, 0, 1)
+                const float gxx = mu2 * (a2 + a3), gyy = mu2 * (a0 + a1), gzz = a0 + a1 + a2 + a3, gxz = mu * (a3 - a2), gyz = mu * (a0 - a1);
+                V3 Pr;  // row r of P = [[p]x ; 1]:  K = D P G P^T, row r = [p x q ; q] with q = D (P_r G)
+                if (r == 0) Pr = v3(0.f, -p.z, p.y); else if (r == 1) Pr = v3(p.z, 0.f, -p.x); else if (r == 2) Pr = v3(-p.y, p.x, 0.f);
+                else Pr = v3(r == 3 ? 1.f : 0.f, r == 4 ? 1.f : 0.f, r == 5 ? 1.f : 0.f);
+                const V3 q = v3(Dc * (Pr.x * gxx + Pr.z * gxz), Dc * (Pr.y * gyy + Pr.z * gyz), Dc * (Pr.x * gxz + Pr.y * gyz + Pr.z * gzz));
+                const V3 pq = cross(p, q);
+                Krow[0] += pq.x; Krow[1] += pq.y; Krow[2] += pq.z; Krow[3] += q.x; Krow[4] += q.y; Krow[5] += q.z;
             }
 #pragma unroll
-            for (int k = 0; k < 6; k++) pA[k] = 0.f;
-            if (contact_inertia) {
-                const V3 o = ld3(s.xpos);
-                for (int c = s.con_start[b]; c < s.con_start[b + 1]; c++) {
-                    V3 p = ld3(s.con_pos + 3 * c) - o;
-                    const float Dc = s.con_D[c], jn = s.jar3[3 * c], jt1 = s.jar3[3 * c + 1], jt2 = s.jar3[3 * c + 2];
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        if (row_val(e, P.mu, jn, jt1, jt2) < 0.f) {
-                            V3 dir = row_dir(e, P.mu);
-                            V3 mm = cross(p, dir);
-                            float w[6] = {mm.x, mm.y, mm.z, dir.x, dir.y, dir.z};
-#pragma unroll
-                            for (int r = 0; r < 6; r++)
-#pragma unroll
-                                for (int cc = r; cc < 6; cc++) IA[s6i(r, cc)] += Dc * w[r] * w[cc];
-                        }
-                    }
-                }
+            for (int k = 0; k < 8; k++) {
+                const int c = L.col[k];
+                float v = Krow[0];
+                v = c == 1 ? Krow[1] : v; v = c == 2 ? Krow[2] : v; v = c == 3 ? Krow[3] : v; v = c == 4 ? Krow[4] : v; v = c == 5 ? Krow[5] : v;
+                if (rowok && c < 6) IAx[k] += v;
             }
-            const int nsub = s.bsub[b];
-            for (int k = b + 1; k < b + nsub; k += s.bsub[k]) {
+        }
+        if (lev == 0) {
+            aba_elim3(s, L, rhs, 3, active, IAx, pA);
+            aba_elim3(s, L, rhs, 0, active, IAx, pA);
+        } else {
+            aba_elim3(s, L, rhs, 6 + 3 * (b - 1) < 6 ? 6 : 6 + 3 * (b - 1), active, IAx, pA);
+        }
+        if (active && rowok) {
 #pragma unroll
-                for (int i = 0; i < 21; i++) IA[i] += s.IAa[21 * k + i];
-#pragma unroll
-                for (int i = 0; i < 6; i++) pA[i] += s.pAa[6 * k + i];
-            }
-            const int nd = b == 0 ? 6 : 3, d0 = b == 0 ? 0 : 6 + 3 * (b - 1);
-            for (int j = nd - 1; j >= 0; j--) {
-                const int d = d0 + j;
-                float sj[6], Uv[6];
-#pragma unroll
-                for (int k = 0; k < 6; k++) sj[k] = s.cdof[6 * d + k];
-                float D = s.arm[d] + s.extra[d], u = rhs[d];
-#pragma unroll
-                for (int r = 0; r < 6; r++) {
-                    float acc = 0.f;
-#pragma unroll
-                    for (int c = 0; c < 6; c++) acc += IA[s6i(r, c)] * sj[c];
-                    Uv[r] = acc;
-                    D += sj[r] * acc;
-                    u -= sj[r] * pA[r];
-                }
-                const float Dinv = 1.0f / D, ud = u * Dinv;
-#pragma unroll
-                for (int k = 0; k < 6; k++) s.U[6 * d + k] = Uv[k];
-                s.Dinv[d] = Dinv; s.uj[d] = u;
-#pragma unroll
-                for (int r = 0; r < 6; r++) {
-                    const float ur = Uv[r] * Dinv;
-#pragma unroll
-                    for (int c = r; c < 6; c++) IA[s6i(r, c)] -= ur * Uv[c];
-                    pA[r] += Uv[r] * ud;
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 21; i++) s.IAa[21 * b + i] = IA[i];
-#pragma unroll
-            for (int i = 0; i < 6; i++) s.pAa[6 * b + i] = pA[i];
+            for (int k = 0; k < 8; k++) if (L.col[k] < 6 && r <= L.col[k]) s.IAa[22 * b + L.idx21[k]] = IAx[k];
+            s.pAa[6 * b + r] = pA;
         }
         KP_SYNC();
     }
+#pragma nounroll
     for (int lev = 0; lev < D_NLEV; lev++) {
-        if (depth == lev) {
-            const int b = tid;
-            S6 a = b == 0 ? S6{v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f)} : lds6(s.sv + 6 * s.bpar[b]);
-            const int nd = b == 0 ? 6 : 3, d0 = b == 0 ? 0 : 6 + 3 * (b - 1);
-            for (int j = 0; j < nd; j++) {
-                const int d = d0 + j;
-                float qdd = (s.uj[d] - dot6(lds6(s.U + 6 * d), a)) * s.Dinv[d];
-                out[d] = qdd;
-                a = a + qdd * lds6(s.cdof + 6 * d);
-            }
-            sts6(s.sv + 6 * b, a);
+        const int sh = 5 * lev;
+        const int bq = (int)((L.sb >> sh) & 31ull), par = (int)((L.sp >> sh) & 31ull);
+        const bool active = bq != 31;
+        const int b = active ? bq : 0;
+        float a = (rowok && par != 31) ? s.sv[6 * (par == 31 ? 0 : par) + r] : 0.f;
+        if (lev == 0) {
+            a = aba_fwd3(s, L, out, 0, active, a);
+            a = aba_fwd3(s, L, out, 3, active, a);
+        } else {
+            a = aba_fwd3(s, L, out, b == 0 ? 6 : 6 + 3 * (b - 1), active, a);
         }
+        if (active && rowok) s.sv[6 * b + r] = a;
         KP_SYNC();
     }
 }
 
 // ---------------------------------------------------------------- stable-PD torque + residual force (reference controller)
 template <int NT>
-__device__ void spd_torque_rfc(EnvLds& s, const DevTables& T, const Params& P, int depth, int tid) {
+__device__ __forceinline__ void spd_torque_rfc(EnvLds& s, const DevTables& T, const Params& P, const Lane8& L8, int depth, int tid) {
     for (int i = tid; i < D_NV; i += NT) {
         float ep = 0.f, kp = 0.f, kd = 0.f;
         if (i >= 6) {
@@ -270,7 +410,7 @@ __device__ void spd_torque_rfc(EnvLds& s, const DevTables& T, const Params& P, i
         s.x[i] = -s.bias[i] - kp * ep - kd * s.qvel[i];
     }
     KP_SYNC();
-    aba_solve<NT>(s, P, s.x, s.x, false, depth, tid);
+    aba_solve<NT>(s, P, L8, s.x, s.x, false, tid);
     for (int j = tid; j < D_NU; j += NT) {
         int i = j + 6;
         float tq = -T.kp[j] * s.search[i] - T.kd[j] * (s.qvel[i] + s.x[i] * P.h);
@@ -291,7 +431,7 @@ __device__ void spd_torque_rfc(EnvLds& s, const DevTables& T, const Params& P, i
 
 // ---------------------------------------------------------------- hull-vs-plane collision (wave 0; lane = hull vertex)
 template <int NT>
-__device__ void collide_plane(EnvLds& s, const DevTables& T, const Params& P, int tid) {
+__device__ __forceinline__ void collide_plane(EnvLds& s, const DevTables& T, const Params& P, int tid) {
     if (tid < 64) {
         const int bb = tid < D_NB ? tid : 0;
         bool near = (tid < D_NB) && P.contact && !(s.xpos[3 * bb + 2] - T.body_rbound[bb] > P.margin);
@@ -334,7 +474,7 @@ __device__ void collide_plane(EnvLds& s, const DevTables& T, const Params& P, in
 
 // efc_D and the reference acceleration of every constraint row.  aref (contact-frame 3-vector) goes to jv3.
 template <int NT>
-__device__ void make_constraint(EnvLds& s, const DevTables& T, const Params& P, int tid) {
+__device__ __forceinline__ void make_constraint(EnvLds& s, const DevTables& T, const Params& P, int tid) {
     const V3 o = ld3(s.xpos);
     for (int c = tid; c < s.ncon; c += NT) {
         int b = s.con_body[c];
@@ -367,7 +507,7 @@ __device__ void make_constraint(EnvLds& s, const DevTables& T, const Params& P, 
 
 // contact-frame residuals of all rows for the spatial accelerations in sv:  out3 = frame^T (point accel) [- aref]
 template <int NT>
-__device__ void eval_rows(EnvLds& s, const float* vec, float* out3, float* lim_rows, bool sub_aref, int tid) {
+__device__ __forceinline__ void eval_rows(EnvLds& s, const float* vec, float* out3, float* lim_rows, bool sub_aref, int tid) {
     const V3 o = ld3(s.xpos);
     for (int c = tid; c < s.ncon; c += NT) {
         S6 S = lds6(s.sv + 6 * s.con_body[c]);
@@ -384,7 +524,7 @@ __device__ void eval_rows(EnvLds& s, const float* vec, float* out3, float* lim_r
 
 // out = M vec (with_inertia; sv must hold the spatial accelerations of vec) - J^T f(jar) (with_forces)
 template <int NT>
-__device__ void wrench_project(EnvLds& s, const Params& P, const float* vec, float* out, bool with_inertia, bool with_forces, int tid) {
+__device__ __forceinline__ void wrench_project(EnvLds& s, const Params& P, const float* vec, float* out, bool with_inertia, bool with_forces, int tid) {
     if (tid < D_NB) {
         const int b = tid;
         S6 W = with_inertia ? inert_mul(s.cinert + 10 * b, lds6(s.sv + 6 * b)) : S6{v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f)};
@@ -420,28 +560,64 @@ __device__ void wrench_project(EnvLds& s, const Params& P, const float* vec, flo
 
 // primal cost at the current (qacc, mres, jar):  0.5 mres.(qacc - qacc_s) + sum 0.5 D jar_-^2
 template <int NT>
-__device__ float primal_cost(EnvLds& s, const Params& P, const float* qacc, int tid) {
+__device__ __forceinline__ float primal_cost(EnvLds& s, const Params& P, const float* qacc, const float* mres, const float* jar3, const float* lim_jar, int tid) {
     float c = 0.f;
-    for (int i = tid; i < D_NV; i += NT) c += 0.5f * s.mres[i] * (qacc[i] - s.qacc_s[i]);
+    if (mres) for (int i = tid; i < D_NV; i += NT) c += 0.5f * mres[i] * (qacc[i] - s.qacc_s[i]);
     for (int k = tid; k < s.ncon; k += NT) {
-        const float Dc = s.con_D[k], jn = s.jar3[3 * k], jt1 = s.jar3[3 * k + 1], jt2 = s.jar3[3 * k + 2];
+        const float Dc = s.con_D[k], jn = jar3[3 * k], jt1 = jar3[3 * k + 1], jt2 = jar3[3 * k + 2];
 #pragma unroll
         for (int e = 0; e < 4; e++) { float x = row_val(e, P.mu, jn, jt1, jt2); if (x < 0.f) c += 0.5f * Dc * x * x; }
     }
-    for (int j = tid; j < D_NU; j += NT) { float x = s.lim_jar[j]; if (x < 0.f) c += 0.5f * s.lim_D[j] * x * x; }
+    for (int j = tid; j < D_NU; j += NT) { float x = lim_jar[j]; if (x < 0.f) c += 0.5f * s.lim_D[j] * x * x; }
     return block_sum<NT>(s, c, tid);
+}
+
+// spatial "acceleration" of every body induced by a generalized vector (what aba_solve leaves in sv)
+template <int NT>
+__device__ __forceinline__ void spatial_accumulate(EnvLds& s, const float* vec, int depth, int tid) {
+    for (int lev = 0; lev < D_NLEV; lev++) {
+        if (depth == lev) {
+            const int b = tid;
+            S6 a = b == 0 ? S6{v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f)} : lds6(s.sv + 6 * s.bpar[b]);
+            const int nd = b == 0 ? 6 : 3, d0 = b == 0 ? 0 : 6 + 3 * (b - 1);
+            for (int j = 0; j < nd; j++) a = a + vec[d0 + j] * lds6(s.cdof + 6 * (d0 + j));
+            sts6(s.sv + 6 * b, a);
+        }
+        KP_SYNC();
+    }
 }
 
 // constraint solve: Newton on the primal problem (mj_solNewton) with an exact line search.  Returns iterations.
 // On entry sv holds the spatial accelerations of qacc_s (left by the smooth aba_solve), jv3 holds aref.
 template <int NT>
-__device__ int solve_constraints(EnvLds& s, const Params& P, int depth, int tid) {
-    for (int i = tid; i < D_NV; i += NT) { s.qacc[i] = s.qacc_s[i]; s.mres[i] = 0.f; }
-    KP_SYNC();
-    if (s.ncon == 0 && s.nlim == 0) return 0;
-    // start from qacc_smooth (M qacc_s = qfrc_smooth => mres = 0)
+__device__ __forceinline__ int solve_constraints(EnvLds& s, const Params& P, const Lane8& L8, int depth, int tid) {
+    if (s.ncon == 0 && s.nlim == 0) {
+        for (int i = tid; i < D_NV; i += NT) s.qacc[i] = s.qacc_s[i];
+        KP_SYNC();
+        return 0;
+    }
+    // candidate A: qacc_smooth (M qacc_s = qfrc_smooth => Gauss term 0); sv holds its spatial accelerations
     eval_rows<NT>(s, s.qacc_s, s.jar3, s.lim_jar, true, tid);
-    float cost = primal_cost<NT>(s, P, s.qacc, tid);
+    float cost = primal_cost<NT>(s, P, nullptr, nullptr, s.jar3, s.lim_jar, tid);
+    // candidate B: warm start = s.qacc (qacc of the previous substep / control step), mj_fwdConstraint's rule
+    {
+        float* wj3 = s.U;      // scratch: U / x are rewritten by the next aba_solve
+        float* wlim = s.x;
+        spatial_accumulate<NT>(s, s.qacc, depth, tid);
+        eval_rows<NT>(s, s.qacc, wj3, wlim, true, tid);
+        wrench_project<NT>(s, P, s.qacc, s.Mv, true, false, tid);
+        for (int i = tid; i < D_NV; i += NT) s.mres[i] = s.Mv[i] - s.smooth[i];
+        KP_SYNC();
+        float cw = primal_cost<NT>(s, P, s.qacc, s.mres, wj3, wlim, tid);
+        if (cw < cost) {
+            cost = cw;
+            for (int k = tid; k < 3 * s.ncon; k += NT) s.jar3[k] = wj3[k];
+            for (int j = tid; j < D_NU; j += NT) s.lim_jar[j] = wlim[j];
+        } else {
+            for (int i = tid; i < D_NV; i += NT) { s.qacc[i] = s.qacc_s[i]; s.mres[i] = 0.f; }
+        }
+        KP_SYNC();
+    }
     int it = 0;
     for (; it < P.max_iter; it++) {
         // gradient = mres - J^T f
@@ -457,7 +633,7 @@ __device__ int solve_constraints(EnvLds& s, const Params& P, int depth, int tid)
         KP_SYNC();
         if (P.scale * sqrtf(g2) < P.tol) break;
         // search = -H^-1 grad,  H = M + J^T D_active J : articulated-body pass with contact inertia
-        aba_solve<NT>(s, P, s.x, s.search, true, depth, tid);
+        aba_solve<NT>(s, P, L8, s.x, s.search, true, tid);
         eval_rows<NT>(s, s.search, s.jv3, s.lim_jv, false, tid);           // aref (in jv3) is folded into jar3 by now
         wrench_project<NT>(s, P, s.search, s.Mv, true, false, tid);
         // exact line search on phi(alpha)
@@ -495,7 +671,7 @@ __device__ int solve_constraints(EnvLds& s, const Params& P, int depth, int tid)
         for (int k = tid; k < 3 * s.ncon; k += NT) s.jar3[k] += alpha * s.jv3[k];
         for (int j = tid; j < D_NU; j += NT) if (s.lim_sgn[j] != 0.f) s.lim_jar[j] += alpha * s.lim_jv[j];
         KP_SYNC();
-        float newcost = primal_cost<NT>(s, P, s.qacc, tid);
+        float newcost = primal_cost<NT>(s, P, s.qacc, s.mres, s.jar3, s.lim_jar, tid);
         float improvement = P.scale * (cost - newcost);
         cost = newcost;
         if (improvement < P.tol) { it++; break; }
@@ -505,7 +681,7 @@ __device__ int solve_constraints(EnvLds& s, const Params& P, int depth, int tid)
 
 // ---------------------------------------------------------------- the kernel
 template <int NT>
-__global__ __launch_bounds__(NT) void kp_step_kernel(StepArgs A) {
+__global__ __launch_bounds__(NT, (NT == 64 ? 2 : 1)) void kp_step_kernel(StepArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     EnvLds& s = *reinterpret_cast<EnvLds*>(smem_raw);
     const int env = blockIdx.x, tid = threadIdx.x;
@@ -514,18 +690,24 @@ __global__ __launch_bounds__(NT) void kp_step_kernel(StepArgs A) {
     const DevTables& T = A.T;
     const Params& P = A.P;
     const int depth = tid < D_NB ? T.body_depth[tid] : -1;
+    Lane8 L8; L8.init(tid, T.sched8);
+    const V3 bpos = tid < D_NB ? ld3(T.body_pos + 3 * tid) : v3(0.f, 0.f, 0.f);
 
     // ---- load: derived state first (the state the last forward pass ran on), then the real state
     for (int i = tid; i < D_NQ; i += NT) { s.qpos[i] = A.qpos_d[(size_t)env * D_NQ + i]; s.tq[i] = A.target_qpos ? A.target_qpos[(size_t)env * D_NQ + i] : 0.f; }
     for (int i = tid; i < D_NV; i += NT) {
         s.qvel[i] = A.qvel_d[(size_t)env * D_NV + i]; s.act[i] = A.action ? A.action[(size_t)env * D_NV + i] : 0.f;
-        s.arm[i] = T.dof_armature[i]; s.dbody[i] = T.dof_body[i]; s.extra[i] = 0.f; s.qacc[i] = 0.f;
+        s.arm[i] = T.dof_armature[i]; s.dbody[i] = T.dof_body[i]; s.extra[i] = 0.f; s.qacc[i] = A.warm[(size_t)env * D_NV + i];
     }
-    if (tid < D_NB) { s.bpar[tid] = (unsigned char)(T.body_parent[tid] < 0 ? 0 : T.body_parent[tid]); s.bsub[tid] = T.body_subtree[tid]; s.bdep[tid] = T.body_depth[tid]; }
+    if (tid < D_NB) { s.bpar[tid] = (unsigned char)(T.body_parent[tid] < 0 ? 0 : T.body_parent[tid]); s.bsub[tid] = T.body_subtree[tid]; s.levb[tid] = T.lev_body[tid]; }
+    if (tid < D_NLEV + 2) s.levs[tid] = T.lev_start[tid];
     if (tid < 8) s.applied[tid] = 0.f;
+    if (tid < 25) s.IAa[22 * tid + 21] = 0.f;
+    if (tid < 22) s.IAa[22 * 24 + tid] = 0.f;
+    if (tid < 6) s.pAa[6 * 24 + tid] = 0.f;
     if (tid == 0) { s.ncon = 0; s.nlim = 0; s.flag = 0; }
     KP_SYNC();
-    forward_kin_bias<NT>(s, T, P, depth, tid);
+    forward_kin_bias<NT>(s, T, P, depth, bpos, tid);
     float qd_save_q[(D_NQ + NT - 1) / NT], qd_save_v[(D_NV + NT - 1) / NT];
 #pragma unroll
     for (int n = 0; n < (D_NQ + NT - 1) / NT; n++) { int i = tid + n * NT; qd_save_q[n] = i < D_NQ ? s.qpos[i] : 0.f; }
@@ -538,25 +720,36 @@ __global__ __launch_bounds__(NT) void kp_step_kernel(StepArgs A) {
         KP_SYNC();
     }
     int niter_total = 0, maxcon = 0;
+    unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
+    const bool prof = A.prof != nullptr;
+#define KP_T(i) if (prof) { t1 = __builtin_readcyclecounter(); pc[i] += t1 - t0; t0 = t1; }
+    const unsigned long long tstart = prof ? __builtin_readcyclecounter() : 0;
     for (int sub = 0; sub < A.n_substeps; sub++) {
+        if (prof) t0 = __builtin_readcyclecounter();
         // stale mode: the controller sees M / bias of the previous forward pass (cinert, cdof, bias still in LDS)
-        if (P.stale) spd_torque_rfc<NT>(s, T, P, depth, tid);
+        if (P.stale) spd_torque_rfc<NT>(s, T, P, L8, depth, tid);
+        KP_T(0)
         // ---- mj_forward at the current state
 #pragma unroll
         for (int n = 0; n < (D_NQ + NT - 1) / NT; n++) { int i = tid + n * NT; if (i < D_NQ) qd_save_q[n] = s.qpos[i]; }
 #pragma unroll
         for (int n = 0; n < (D_NV + NT - 1) / NT; n++) { int i = tid + n * NT; if (i < D_NV) qd_save_v[n] = s.qvel[i]; }
-        forward_kin_bias<NT>(s, T, P, depth, tid);
+        forward_kin_bias<NT>(s, T, P, depth, bpos, tid);
+        KP_T(1)
         collide_plane<NT>(s, T, P, tid);
+        KP_T(2)
         make_constraint<NT>(s, T, P, tid);                 // needs sv = cvel: before any aba_solve
-        if (!P.stale) spd_torque_rfc<NT>(s, T, P, depth, tid);
+        KP_T(3)
+        if (!P.stale) spd_torque_rfc<NT>(s, T, P, L8, depth, tid);
         for (int i = tid; i < D_NV; i += NT) {
             float f = -s.bias[i] + (i < 6 ? s.applied[i] : s.ctrl[i - 6]);
             s.smooth[i] = f; s.extra[i] = 0.f;
         }
         KP_SYNC();
-        aba_solve<NT>(s, P, s.smooth, s.qacc_s, false, depth, tid);   // qacc_smooth = M^-1 qfrc_smooth; sv = its spatial accel
-        niter_total += solve_constraints<NT>(s, P, depth, tid);
+        aba_solve<NT>(s, P, L8, s.smooth, s.qacc_s, false, tid);   // qacc_smooth = M^-1 qfrc_smooth; sv = its spatial accel
+        KP_T(4)
+        niter_total += solve_constraints<NT>(s, P, L8, depth, tid);
+        KP_T(5)
         maxcon = max(maxcon, s.ncon);
         // ---- semi-implicit Euler (mj_Euler, no damping)
         for (int i = tid; i < D_NV; i += NT) s.qvel[i] += P.h * s.qacc[i];
@@ -572,13 +765,18 @@ __global__ __launch_bounds__(NT) void kp_step_kernel(StepArgs A) {
             s.qpos[3] = q.w; s.qpos[4] = q.x; s.qpos[5] = q.y; s.qpos[6] = q.z;
         }
         KP_SYNC();
+        KP_T(6)
+    }
+    if (prof && tid == 0 && A.n_substeps > 0) {
+        pc[7] = __builtin_readcyclecounter() - tstart;
+        for (int k = 0; k < 8; k++) A.prof[8 * (size_t)env + k] = pc[k];
     }
     if (A.n_substeps > 0 && !P.stale) {  // fresh mode: outputs are the kinematics of the final state
 #pragma unroll
         for (int n = 0; n < (D_NQ + NT - 1) / NT; n++) { int i = tid + n * NT; if (i < D_NQ) qd_save_q[n] = s.qpos[i]; }
 #pragma unroll
         for (int n = 0; n < (D_NV + NT - 1) / NT; n++) { int i = tid + n * NT; if (i < D_NV) qd_save_v[n] = s.qvel[i]; }
-        forward_kin_bias<NT>(s, T, P, depth, tid);
+        forward_kin_bias<NT>(s, T, P, depth, bpos, tid);
     }
     // ---- store
     bool bad = false;

@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "kp_sim_n_envs", "kp_sim_set_state", "kp_sim_set_target", "kp_sim_step_ctrl", "kp_sim_step_kin", "kp_sim_obs_cc",
     "kp_field_dim", "kp_sim_get", "kp_sim_diag", "kp_sim_last_step_seconds", "kp_last_error", "kp_version",
     "kp_sim_step_begin", "kp_sim_obs_ar", "kp_sim_term_reward", "kp_gae", "kp_sim_set_full_state", "kp_sim_fk",
-    "kp_sim_timing_reset", "kp_sim_timing_mean_seconds",
+    "kp_sim_timing_reset", "kp_sim_timing_mean_seconds", "kp_sim_phase_cycles",
 ]
 
 
@@ -88,6 +88,7 @@ def load_library(path: str | None = None):
     L.kp_sim_set_full_state.argtypes = [P, F, F, F, F, U8]; L.kp_sim_set_full_state.restype = C.c_int
     L.kp_sim_timing_reset.argtypes = [P]; L.kp_sim_timing_reset.restype = C.c_int
     L.kp_sim_timing_mean_seconds.argtypes = [P, C.POINTER(C.c_int)]; L.kp_sim_timing_mean_seconds.restype = C.c_double
+    L.kp_sim_phase_cycles.argtypes = [P, C.POINTER(C.c_double)]; L.kp_sim_phase_cycles.restype = C.c_int
     L.kp_sim_fk.argtypes = [P, C.c_int, F, F, F, F, F, F]; L.kp_sim_fk.restype = C.c_int
     L.kp_last_error.restype = C.c_char_p
     L.kp_version.restype = C.c_char_p
@@ -248,6 +249,11 @@ class KpSim:
         n = C.c_int(0)
         t = self.L.kp_sim_timing_mean_seconds(self.h, C.byref(n))
         return t, n.value
+
+    def phase_cycles(self):
+        out = (C.c_double * 8)()
+        _check(self.L.kp_sim_phase_cycles(self.h, out), "kp_sim_phase_cycles")
+        return dict(zip(("spd", "kin_bias", "collide", "constraint", "smooth", "contact", "integrate", "total"), list(out)))
 
     def last_step_seconds(self) -> float:
         return self.L.kp_sim_last_step_seconds(self.h)
