@@ -69,7 +69,7 @@ class PolicyMCP(nn.Module):
 
     def _fuse(self):
         """[K*h1, in], [K, h1, h2], [K, h2, A] stacked weights (rebuilt when parameters change version)."""
-        ver = tuple(p._version for p in self.parameters())
+        ver = tuple((p._version, p.data_ptr(), p.dtype, p.device) for p in self.parameters())
         if self._fused is None or self._fused[0] != ver:
             w1 = torch.cat([n[0].affine_layers[0].weight for n in self.nets], 0)
             b1 = torch.cat([n[0].affine_layers[0].bias for n in self.nets], 0)

@@ -1,0 +1,120 @@
+"""GPU: the batched HumanoidAREnv (kinpoly_amd/env.py) end to end against the composed oracle, the single-env
+numpy facade, the vectorised sampler and one PPO update."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from kinpoly_amd.model_compiler import DEFAULT_KPM, read_kpm  # noqa: E402
+from oracle import np_oracle as O  # noqa: E402
+from oracle.kpo import OracleSim  # noqa: E402
+
+KPM = read_kpm(DEFAULT_KPM)
+BP, BI, PAR = KPM["body_pos"].reshape(24, 3), KPM["body_ipos"].reshape(24, 3), KPM["body_parent"]
+STD = np.load(os.path.join(os.path.dirname(__file__), "golden", "standing_neutral.npz"))
+
+
+def _mk_env(n, T=12, mode="test", seed=0):
+    from kinpoly_amd.env import BatchedHumanoidAREnv, standing_context
+    torch.manual_seed(seed)
+    env = BatchedHumanoidAREnv(n, 0, mode=mode, seed=seed)
+    rng = np.random.default_rng(seed)
+    headings = torch.tensor(rng.uniform(-np.pi, np.pi, size=n), dtype=torch.float32)
+    ctx = standing_context(n, T, STD["qpos"], STD["qvel"], env.sim, headings)
+    env.load_context(ctx)
+    return env, ctx
+
+
+def test_env_step_matches_composed_oracle():
+    """One full HumanoidAREnv.step (test mode => mean UHC action) vs step_ar + qpos_fk + obs_cc + PolicyMCP (fp64) +
+    do_simulation (C oracle) + obs_ar + reward, all on the CPU in fp64."""
+    n = 8
+    env, ctx = _mk_env(n)
+    obs0 = env.reset().double().cpu().numpy()
+    rng = np.random.default_rng(3)
+    q0 = ctx["init_qpos"].double().cpu().numpy(); v0 = ctx["init_qvel"].double().cpu().numpy()
+    head_pose = ctx["head_pose"].double().cpu().numpy(); head_vels = ctx["head_vels"].double().cpu().numpy()
+    obj_rel = ctx["obj_head_relative_poses"].double().cpu().numpy()
+    gt_qpos = ctx["qpos"].double().cpu().numpy()
+    # kinematic action close to the current pose (what a trained policy emits)
+    a = np.zeros((n, 80))
+    for i in range(n):
+        cur = q0[i].copy(); cur[3:7] = O.de_heading(cur[3:7])
+        a[i, :74] = cur[2:] + rng.normal(size=74) * 0.02
+        a[i, 74:] = rng.normal(size=6) * 0.1
+    obs, _, done, info = env.step(torch.tensor(a, dtype=torch.float32, device=env.device))
+    obs = obs.double().cpu().numpy(); cc_action = info["cc_action"].double().cpu().numpy(); cc_state = info["cc_state"].double().cpu().numpy()
+    rew = info["custom_reward"].double().cpu().numpy()
+    import copy
+    mcp = copy.deepcopy(env.cc_policy).double().cpu()
+    sim = OracleSim()
+    for i in range(n):
+        sim.reset(q0[i], v0[i])
+        x = {k: sim.get(k) for k in ("qpos", "qvel", "xpos", "xquat", "xipos")}
+        xp, xq, xi = x["xpos"].reshape(24, 3), x["xquat"].reshape(24, 4), x["xipos"].reshape(24, 3)
+        want0 = O.obs_ar(x["qpos"], xp, xq, head_pose[i, 0], head_vels[i, 0], obj_rel[i, 0], np.zeros(4), None)
+        np.testing.assert_allclose(obs0[i], want0, atol=5e-5)
+        prev_bquat = O.get_body_quat(x["qpos"]); prev_h = np.concatenate([xp[13], xq[13]])
+        tgt = O.qpos_fk(O.step_ar(x["qpos"], a[i]), BP, BI, PAR)
+        cco = O.zfilter(O.obs_cc(x["qpos"], x["qvel"], xp, xq, xi, tgt), 0.0, 1.0, 5.0)
+        np.testing.assert_allclose(cc_state[i], cco, atol=2e-4)
+        with torch.no_grad():
+            cca = mcp.action_mean(torch.tensor(cco)[None])[0].numpy()
+        np.testing.assert_allclose(cc_action[i], cca, atol=2e-3)        # fp32 GEMMs vs fp64
+        sim.do_simulation(cc_action[i], tgt["qpos"], 15)               # same action => isolates the physics
+        x = {k: sim.get(k) for k in ("qpos", "qvel", "xpos", "xquat", "xipos")}
+        xp, xq = x["xpos"].reshape(24, 3), x["xquat"].reshape(24, 4)
+        np.testing.assert_allclose(env.sim.get("qpos")[i].double().cpu().numpy(), x["qpos"], atol=1e-4)
+        want = O.obs_ar(x["qpos"], xp, xq, head_pose[i, 1], head_vels[i, 1], obj_rel[i, 1], np.zeros(4), None)
+        np.testing.assert_allclose(obs[i], want, atol=2e-4)
+        gt = O.qpos_fk(gt_qpos[i, 1], BP, BI, PAR); gtp = O.qpos_fk(gt_qpos[i, 0], BP, BI, PAR)
+        r, _ = O.dynamic_supervision_v1(np.concatenate([xp[13], xq[13]]), prev_h, O.get_body_quat(x["qpos"]), prev_bquat, xp, tgt, head_pose[i, 1],
+                                        gt["bquat"].reshape(-1), gtp["bquat"].reshape(-1), 1 / 30, O.REWARD_WEIGHTS)
+        assert abs(rew[i] - r) < 2e-3
+    assert not bool(done.any()) and int(env.cur_t[0]) == 1
+
+
+def test_single_env_facade_numpy_surface():
+    from kinpoly_amd.env import HumanoidAREnv, standing_context
+    import types
+    cfg = types.SimpleNamespace(policy_specs={"body_diff_thresh": 10, "body_diff_gt_thresh": 12}, joint_controller=False)
+    env = HumanoidAREnv(cfg, types.SimpleNamespace(env_episode_len=100000), None, mode="test")
+    ctx = standing_context(1, 10, STD["qpos"], STD["qvel"], env.b.sim)
+    env.load_context({k: v.cpu() for k, v in ctx.items()} | {"action_one_hot": ctx["action_one_hot"].cpu()[:, None].repeat(1, 10, 1)})
+    env.seed(4)
+    obs = env.reset()
+    assert obs.shape == (105,) and obs.dtype == np.float64
+    cur = env.get_humanoid_qpos(); cur[3:7] = O.de_heading(cur[3:7])
+    a = np.concatenate([cur[2:], np.zeros(6)])
+    obs2, r, done, info = env.step(a)
+    assert obs2.shape == (105,) and r == 1.0 and isinstance(done, bool)
+    assert info["cc_action"].shape == (75,) and info["cc_state"].shape == (784,) and 0 < info["percent"] <= 1
+    assert env.get_humanoid_qpos().shape == (76,) and env.get_head().shape == (7,) and env.get_body_quat().shape == (96,)
+    assert env.target["wbpos"].shape == (72,) and env.cur_t == 1 and abs(env.dt - 1 / 30) < 1e-6
+
+
+def test_sampler_autoreset_and_ppo_update():
+    from kinpoly_amd.nets import KinPolicy, MLP, Value
+    from kinpoly_amd.rollout import PPOTrainer, VectorSampler
+    n, T = 64, 12
+    env, _ = _mk_env(n, T=8, mode="train", seed=1)      # clip length 8 => episodes end every 7 steps
+    torch.manual_seed(1)
+    policy = KinPolicy().to(env.device); value = Value(MLP(105, (512, 256), "relu")).to(env.device)
+    sampler = VectorSampler(env, policy, record_qpos=True)
+    batch = sampler.sample(T)
+    assert batch.states.shape == (n, T, 105) and torch.isfinite(batch.states).all() and torch.isfinite(batch.rewards).all()
+    m = batch.masks.cpu().numpy()
+    assert (m[:, -1] == 0).all() and (m == 0).sum() >= n          # horizon cut + at least one episode end per env
+    es = batch.episode_start.cpu().numpy()
+    assert es[:, 0].all() and (es[:, 1:] == (m[:, :-1] == 0)).all()
+    assert (batch.rewards >= 0).all() and (batch.rewards <= 1.0001).all()
+    # the step right after an auto-reset starts from the clip's initial state
+    assert torch.allclose(batch.curr_qpos[:, 0], batch.curr_qpos[torch.arange(n), (torch.tensor(m[:, :-1] == 0).float().argmax(1) + 1).to(env.device)], atol=1e-5)
+    tr = PPOTrainer(policy, value, num_optim_epoch=2)
+    before = [p.detach().clone() for p in policy.parameters() if p.requires_grad]
+    stats = tr.update(batch)
+    assert np.isfinite(stats["value_loss"]) and np.isfinite(stats["surr_loss"])
+    assert any((a - b).abs().max() > 0 for a, b in zip(before, [p for p in policy.parameters() if p.requires_grad]))
