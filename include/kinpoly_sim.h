@@ -61,6 +61,12 @@ int kp_sim_set_state(kp_sim*, const float* qpos, const float* qvel, const uint8_
  * target_qpos [N,76] is copied; the target dict {qpos, wbpos, wbquat, bquat, body_com} is kept on device. */
 int kp_sim_set_target(kp_sim*, const float* target_qpos, const uint8_t* env_mask);
 
+/* object block of set_state: obj_qpos [N,35] = data.qpos[76:111] as reset_model builds it with convert_obj_qpos
+ * (humanoid_ar_v1.py:377-381, 479-496: inactive objects parked at [(i+1)*100, 100, 0]).  Objects within 50 m of the
+ * origin become collision geometry for the humanoid hulls (chair, box, table, Can, step: boxes / cylinders of the XML,
+ * :190-214).  THIS ROUND the objects are static obstacles: their own dynamics (pushable box) is not integrated. */
+int kp_sim_set_objects(kp_sim*, const float* obj_qpos, const uint8_t* env_mask);
+
 /* Humanoid.qpos_fk_batch(qpos) (numpy_smpl_humanoid.py:124-178) on n_rows arbitrary rows, used by
  * load_context for the GT clip (humanoid_ar_v1.py:87): qpos [n_rows,76] -> qpos_out [n_rows,76] (root quat
  * normalised), wbpos [n_rows,72], wbquat [n_rows,96], bquat [n_rows,96], body_com [n_rows,72]; outputs may be NULL. */
@@ -137,7 +143,8 @@ typedef enum {
     KP_QPOS_D = 12,     /* state the derived quantities were computed at (x_14 after a control step) */
     KP_QVEL_D = 13,
     KP_PREV_BQUAT = 14, /* env.prev_bquat                    [N,96] */
-    KP_PREV_HPOS = 15   /* env.prev_hpos                     [N,7]  */
+    KP_PREV_HPOS = 15,  /* env.prev_hpos                     [N,7]  */
+    KP_OBJ_QPOS = 16    /* get_obj_qpos() = data.qpos[76:111] [N,35] */
 } kp_field;
 int kp_field_dim(int field);
 int kp_sim_get(kp_sim*, int field, float* out);

@@ -64,6 +64,15 @@ struct __attribute__((aligned(16))) EnvLds {
     int ncon, nlim, flag;
 };
 
+// extension used only by the kernel instantiation that simulates object contact (kp_step_kernel<NT, true>)
+constexpr int D_MAXGEOM = 8;            // must equal MAXGEOM in oracle/kp_oracle.c
+struct __attribute__((aligned(16))) EnvLdsObj : EnvLds {
+    float con_n[D_MAXCON * 3];          // contact normal (world), pointing from the object / floor into the hull
+    float con_iw2[D_MAXCON];            // invweight0 of the second body (0 for the floor)
+    float geom[D_MAXGEOM * 17];         // type, size[3], pos[3], mat[9], invweight  (world frame)
+    int ngeom;
+};
+
 // ------------------------------------------------------------------ small math
 struct V3 { float x, y, z; };
 struct Q4 { float w, x, y, z; };

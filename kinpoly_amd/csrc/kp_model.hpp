@@ -18,9 +18,9 @@ constexpr int NB = 24, NV = 75, NQ = 76, NU = 69, NM = 1221, MAXDEPTH = 30;
 
 struct HostModel {
     int nb = 0, nv = 0, nq = 0, nu = 0, nM = 0, nvert = 0;
-    std::vector<int> body_parent, body_depth, body_subtree, dof_body, dof_parent, dof_depth, dof_madr, jnt_limited, vert_adr;
+    std::vector<int> body_parent, body_depth, body_subtree, dof_body, dof_parent, dof_depth, dof_madr, jnt_limited, vert_adr, obj_geom_adr;
     std::vector<double> body_pos, body_ipos, body_mass, body_inertia, body_rbound, body_invweight0, dof_invweight0,
-        dof_armature, jnt_range, verts, kp, kd, torque_lim, a_scale, opt, body_diffw;
+        dof_armature, jnt_range, verts, kp, kd, torque_lim, a_scale, opt, body_diffw, obj_geoms, obj_mass;
     std::string error;
 };
 
@@ -61,6 +61,9 @@ inline bool load_kpm(const char* path, HostModel& m) {
     KPF(body_rbound, "body_rbound") KPF(body_invweight0, "body_invweight0") KPF(dof_invweight0, "dof_invweight0")
     KPF(dof_armature, "dof_armature") KPF(jnt_range, "jnt_range") KPF(verts, "verts")
     KPF(kp, "kp") KPF(kd, "kd") KPF(torque_lim, "torque_lim") KPF(a_scale, "a_scale") KPF(opt, "opt") KPF(body_diffw, "body_diffw")
+    // free objects (optional): [ngeom, 18] = object id, type, size3, local pos3, local R9, mass; adr [nobj + 1]
+    if (!kpm_get(buf, "obj_geoms", &m.obj_geoms, nullptr) || !kpm_get(buf, "obj_geom_adr", nullptr, &m.obj_geom_adr) ||
+        !kpm_get(buf, "obj_mass", &m.obj_mass, nullptr)) { m.obj_geoms.clear(); m.obj_geom_adr.clear(); m.obj_mass.clear(); }
 #undef KPF
 #undef KPI
     if (m.opt.size() < 25) { m.error = "opt too short"; return false; }

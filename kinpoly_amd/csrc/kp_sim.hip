@@ -40,6 +40,10 @@ struct kp_sim {
     float *t_qpos = nullptr, *t_wbpos = nullptr, *t_wbquat = nullptr, *t_bquat = nullptr, *t_com = nullptr;
     int* diag = nullptr;
     unsigned long long* prof = nullptr;
+    float *obj_qpos = nullptr, *geoms = nullptr;      // [N,35], [N,8,17]
+    int* ngeom = nullptr;
+    const float* d_obj_geoms = nullptr; const float* d_obj_mass = nullptr; int n_obj_geoms = 0, n_obj = 0;
+    bool has_objects = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     std::vector<hipEvent_t> ring;  // event pairs of the recorded launches
@@ -156,7 +160,9 @@ int launch_step(kp_sim* s, const float* action, int nsub, const uint8_t* mask, b
     A.qpos = s->qpos; A.qvel = s->qvel; A.qpos_d = s->qpos_d; A.qvel_d = s->qvel_d; A.warm = s->warm;
     A.target_qpos = s->t_qpos; A.action = action; A.env_mask = mask;
     A.xpos = s->xpos; A.xquat = s->xquat; A.xipos = s->xipos; A.diag = s->diag; A.prof = s->prof;
-    size_t lds = sizeof(kp::EnvLds);
+    A.geoms = s->geoms; A.ngeom = s->ngeom;
+    const bool obj = s->has_objects;
+    size_t lds = obj ? sizeof(kp::EnvLdsObj) : sizeof(kp::EnvLds);
     hipEvent_t e0 = s->ev0, e1 = s->ev1;
     if (time_it && s->ring_on && s->ring_used < 4096) {
         if ((int)s->ring.size() < 2 * (s->ring_used + 1)) {
@@ -168,12 +174,15 @@ int launch_step(kp_sim* s, const float* action, int nsub, const uint8_t* mask, b
         s->ring_used++;
     }
     if (time_it) HIP_OK(hipEventRecord(e0, s->stream));
+#define KP_LAUNCH(NT_) do { if (obj) hipLaunchKernelGGL((kp::kp_step_kernel<NT_, true>), dim3(s->n), dim3(NT_), lds, s->stream, A); \
+                            else hipLaunchKernelGGL((kp::kp_step_kernel<NT_, false>), dim3(s->n), dim3(NT_), lds, s->stream, A); } while (0)
     switch (s->model->threads) {
-        case 64: hipLaunchKernelGGL(kp::kp_step_kernel<64>, dim3(s->n), dim3(64), lds, s->stream, A); break;
-        case 128: hipLaunchKernelGGL(kp::kp_step_kernel<128>, dim3(s->n), dim3(128), lds, s->stream, A); break;
-        case 256: hipLaunchKernelGGL(kp::kp_step_kernel<256>, dim3(s->n), dim3(256), lds, s->stream, A); break;
+        case 64: KP_LAUNCH(64); break;
+        case 128: KP_LAUNCH(128); break;
+        case 256: KP_LAUNCH(256); break;
         default: return fail("threads_per_env must be 64, 128 or 256");
     }
+#undef KP_LAUNCH
     HIP_OK(hipGetLastError());
     if (time_it) {
         HIP_OK(hipEventRecord(e1, s->stream));
@@ -242,6 +251,11 @@ kp_sim* kp_sim_create(const kp_model* m, int n_envs, int device_id, void* stream
     s->scratch = dalloc(s, N * 96, &ok);
     s->prev_bquat = dalloc(s, N * 96, &ok); s->prev_hpos = dalloc(s, N * 7, &ok);
     s->diag = (int*)dalloc(s, N * 4, &ok);
+    s->obj_qpos = dalloc(s, N * 35, &ok); s->geoms = dalloc(s, N * kp::D_MAXGEOM * 17, &ok); s->ngeom = (int*)dalloc(s, N, &ok);
+    if (!m->h.obj_geoms.empty()) {
+        s->d_obj_geoms = upload<float>(s, m->h.obj_geoms, &ok); s->d_obj_mass = upload<float>(s, m->h.obj_mass, &ok);
+        s->n_obj_geoms = (int)(m->h.obj_geoms.size() / 18); s->n_obj = (int)m->h.obj_mass.size();
+    }
     if (const char* e = std::getenv("KP_PROFILE")) if (e[0] == '1') s->prof = (unsigned long long*)dalloc(s, N * 16, &ok);
     if (!ok || hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) {
         fail("kp_sim_create: device allocation / table build failed");
@@ -295,6 +309,47 @@ int kp_sim_set_target(kp_sim* s, const float* tq, const uint8_t* mask) {
     return 0;
 }
 
+// world-frame geoms of the objects that are not parked (thread per env)
+__global__ void k_set_objects(int n, const float* __restrict__ obj_qpos_in, const uint8_t* __restrict__ mask, float* __restrict__ obj_qpos,
+                              float* __restrict__ geoms, int* __restrict__ ngeom, const float* __restrict__ og, const float* __restrict__ omass,
+                              int n_og, int n_obj) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    if (mask && !mask[e]) return;
+    int ng = 0;
+    for (int i = 0; i < 35; i++) obj_qpos[(size_t)e * 35 + i] = obj_qpos_in[(size_t)e * 35 + i];
+    for (int gi = 0; gi < n_og && ng < kp::D_MAXGEOM; gi++) {
+        const float* g = og + 18 * gi;
+        const int oi = (int)g[0];
+        if (oi >= n_obj || oi >= 5) continue;
+        const float* pose = obj_qpos_in + (size_t)e * 35 + 7 * oi;
+        if (sqrtf(pose[0] * pose[0] + pose[1] * pose[1] + pose[2] * pose[2]) > 50.0f) continue;
+        kp::Q4 q = kp::qnormalize(kp::Q4{pose[3], pose[4], pose[5], pose[6]});
+        float R[9], Rg[9];
+        kp::q2mat(q, R);
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Rg[3 * i + j] = R[3 * i] * g[8 + j] + R[3 * i + 1] * g[11 + j] + R[3 * i + 2] * g[14 + j];
+        kp::V3 p = kp::mulmat(R, kp::ld3(g + 5));
+        float* o = geoms + ((size_t)e * kp::D_MAXGEOM + ng) * 17;
+        o[0] = g[1]; o[1] = g[2]; o[2] = g[3]; o[3] = g[4];
+        o[4] = pose[0] + p.x; o[5] = pose[1] + p.y; o[6] = pose[2] + p.z;
+        for (int k = 0; k < 9; k++) o[7 + k] = Rg[k];
+        o[16] = 1.0f / omass[oi];
+        ng++;
+    }
+    ngeom[e] = ng;
+}
+
+int kp_sim_set_objects(kp_sim* s, const float* obj_qpos, const uint8_t* mask) {
+    if (!s || !obj_qpos) return fail("kp_sim_set_objects: null argument");
+    if (!s->d_obj_geoms) return fail("kp_sim_set_objects: the model blob has no object geoms");
+    HIP_OK(hipSetDevice(s->device));
+    hipLaunchKernelGGL(k_set_objects, dim3((s->n + 63) / 64), dim3(64), 0, s->stream, s->n, obj_qpos, mask, s->obj_qpos, s->geoms, s->ngeom,
+                       s->d_obj_geoms, s->d_obj_mass, s->n_obj_geoms, s->n_obj);
+    HIP_OK(hipGetLastError());
+    s->has_objects = true;
+    return 0;
+}
+
 int kp_sim_fk(kp_sim* s, int n_rows, const float* qpos, float* qpos_out, float* wbpos, float* wbquat, float* bquat, float* com) {
     if (!s || !qpos || n_rows <= 0) return fail("kp_sim_fk: bad arguments");
     HIP_OK(hipSetDevice(s->device));
@@ -340,6 +395,7 @@ int kp_field_dim(int f) {
         case KP_XPOS: case KP_XIPOS: case KP_TARGET_WBPOS: case KP_TARGET_COM: return 72;
         case KP_XQUAT: case KP_BQUAT: case KP_TARGET_WBQUAT: case KP_TARGET_BQUAT: case KP_PREV_BQUAT: return 96;
         case KP_HEAD: case KP_PREV_HPOS: return 7;
+        case KP_OBJ_QPOS: return 35;
         default: return -1;
     }
 }
@@ -371,6 +427,7 @@ int kp_sim_get(kp_sim* s, int field, float* out) {
         case KP_QVEL_D: src = s->qvel_d; break;
         case KP_PREV_BQUAT: src = s->prev_bquat; break;
         case KP_PREV_HPOS: src = s->prev_hpos; break;
+        case KP_OBJ_QPOS: src = s->obj_qpos; break;
         case KP_BQUAT:
             hipLaunchKernelGGL(kp::k_bquat, dim3((s->n * 24 + 255) / 256), dim3(256), 0, s->stream, s->n, s->qpos, out);
             HIP_OK(hipGetLastError());

@@ -18,6 +18,8 @@
 //   * J v is read off the spatial accelerations the ABA forward pass leaves behind, J^T f and M v are a
 //     body-wrench subtree sum projected on the dofs.
 #pragma once
+#include <type_traits>
+
 #include "kp_device.hpp"
 
 namespace kp {
@@ -36,6 +38,8 @@ struct StepArgs {
     float *xpos, *xquat, *xipos;
     int* diag;  // [N,4]: ncon (last substep), newton iterations (sum), flags, max ncon
     unsigned long long* prof;  // optional [N,8] shader-clock cycles per phase (kp_sim_phase_cycles)
+    const float* geoms;        // OBJ kernels: [N, D_MAXGEOM, 17] world-frame object geoms
+    const int* ngeom;          // OBJ kernels: [N]
 };
 
 // wave-wide sum without LDS traffic: xor butterflies inside each 16-lane row with DPP (quad_perm, row_half_mirror,
@@ -78,6 +82,21 @@ __device__ __forceinline__ float row_val(int e, float mu, float jn, float jt1, f
     return jn + sg * (e < 2 ? jt1 : jt2);
 }
 __device__ __forceinline__ V3 to_frame(V3 v) { return v3(v.z, v.y, -v.x); }  // (n, t1, t2) components of a world vector
+
+// contact frame (n, t1, t2).  Floor-only kernels: the constant plane frame; OBJ kernels: mju_makeFrame of the stored normal.
+struct Frame { V3 n, t1, t2; };
+template <bool OBJ>
+__device__ __forceinline__ Frame contact_frame(const EnvLds& s, int c) {
+    if (!OBJ) return Frame{v3(0.f, 0.f, 1.f), v3(0.f, 1.f, 0.f), v3(-1.f, 0.f, 0.f)};
+    const float* cn = static_cast<const EnvLdsObj&>(s).con_n + 3 * c;
+    const V3 n = ld3(cn);
+    V3 y = fabsf(n.y) < 0.5f ? v3(0.f, 1.f, 0.f) : v3(0.f, 0.f, 1.f);
+    y = y - dot(n, y) * n;
+    y = (1.0f / sqrtf(dot(y, y))) * y;
+    return Frame{n, y, cross(n, y)};
+}
+__device__ __forceinline__ V3 frame_comp(const Frame& f, V3 v) { return v3(dot(f.n, v), dot(f.t1, v), dot(f.t2, v)); }
+__device__ __forceinline__ V3 frame_world(const Frame& f, V3 c) { return c.x * f.n + c.y * f.t1 + c.z * f.t2; }
 
 // ---------------------------------------------------------------- kinematics + velocities + bias
 // Three phases so that the level-serial chain stays short:
@@ -313,7 +332,7 @@ __device__ __forceinline__ float aba_fwd3(EnvLds& s, const Lane8& L, float* out,
     return a;
 }
 
-template <int NT>
+template <int NT, bool OBJ>
 __device__ __forceinline__ void aba_solve(EnvLds& s, const Params& P, const Lane8& L, const float* rhs, float* out, bool contact_inertia, int tid) {
     const int r = L.r;
     const bool rowok = r < 6;
@@ -343,12 +362,14 @@ __device__ __forceinline__ void aba_solve(EnvLds& s, const Params& P, const Lane
                 const float Dc = s.con_D[c], jn = s.jar3[3 * c], jt1 = s.jar3[3 * c + 1], jt2 = s.jar3[3 * c + 2];
                 const float a0 = row_val(0, mu, jn, jt1, jt2) < 0.f, a1 = row_val(1, mu, jn, jt1, jt2) < 0.f;
                 const float a2 = row_val(2, mu, jn, jt1, jt2) < 0.f, a3 = row_val(3, mu, jn, jt1, jt2) < 0.f;
-                // G = sum_e a_e dir_e dir_e^T, dirs (0, mu, 1), (0, -mu, 1), (-mu, 0, 1), (mu, 0, 1)
-                const float gxx = mu2 * (a2 + a3), gyy = mu2 * (a0 + a1), gzz = a0 + a1 + a2 + a3, gxz = mu * (a3 - a2), gyz = mu * (a0 - a1);
+                // G = sum_e a_e dir_e dir_e^T with dir_e = n +- mu t1, n +- mu t2; in frame coordinates (n, t1, t2):
+                const float gnn = a0 + a1 + a2 + a3, g11 = mu2 * (a0 + a1), g22 = mu2 * (a2 + a3), gn1 = mu * (a0 - a1), gn2 = mu * (a2 - a3);
+                const Frame fr = contact_frame<OBJ>(s, c);
                 V3 Pr;  // row r of P = [[p]x ; 1]:  K = D P G P^T, row r = [p x q ; q] with q = D (P_r G)
                 if (r == 0) Pr = v3(0.f, -p.z, p.y); else if (r == 1) Pr = v3(p.z, 0.f, -p.x); else if (r == 2) Pr = v3(-p.y, p.x, 0.f);
                 else Pr = v3(r == 3 ? 1.f : 0.f, r == 4 ? 1.f : 0.f, r == 5 ? 1.f : 0.f);
-                const V3 q = v3(Dc * (Pr.x * gxx + Pr.z * gxz), Dc * (Pr.y * gyy + Pr.z * gyz), Dc * (Pr.x * gxz + Pr.y * gyz + Pr.z * gzz));
+                const V3 pf = frame_comp(fr, Pr);
+                const V3 q = frame_world(fr, v3(Dc * (gnn * pf.x + gn1 * pf.y + gn2 * pf.z), Dc * (gn1 * pf.x + g11 * pf.y), Dc * (gn2 * pf.x + g22 * pf.z)));
                 const V3 pq = cross(p, q);
                 Krow[0] += pq.x; Krow[1] += pq.y; Krow[2] += pq.z; Krow[3] += q.x; Krow[4] += q.y; Krow[5] += q.z;
             }
@@ -392,7 +413,7 @@ __device__ __forceinline__ void aba_solve(EnvLds& s, const Params& P, const Lane
 }
 
 // ---------------------------------------------------------------- stable-PD torque + residual force (reference controller)
-template <int NT>
+template <int NT, bool OBJ>
 __device__ __forceinline__ void spd_torque_rfc(EnvLds& s, const DevTables& T, const Params& P, const Lane8& L8, int depth, int tid) {
     for (int i = tid; i < D_NV; i += NT) {
         float ep = 0.f, kp = 0.f, kd = 0.f;
@@ -410,7 +431,7 @@ __device__ __forceinline__ void spd_torque_rfc(EnvLds& s, const DevTables& T, co
         s.x[i] = -s.bias[i] - kp * ep - kd * s.qvel[i];
     }
     KP_SYNC();
-    aba_solve<NT>(s, P, L8, s.x, s.x, false, tid);
+    aba_solve<NT, OBJ>(s, P, L8, s.x, s.x, false, tid);
     for (int j = tid; j < D_NU; j += NT) {
         int i = j + 6;
         float tq = -T.kp[j] * s.search[i] - T.kd[j] * (s.qvel[i] + s.x[i] * P.h);
@@ -430,41 +451,88 @@ __device__ __forceinline__ void spd_torque_rfc(EnvLds& s, const DevTables& T, co
 }
 
 // ---------------------------------------------------------------- hull-vs-plane collision (wave 0; lane = hull vertex)
-template <int NT>
+// signed distance + outward normal (world) of a static box (type 0) / z-axis cylinder (type 1) at world point x
+__device__ __forceinline__ float geom_sdf(const float* g, V3 x, V3& nw) {
+    const float* R = g + 7;
+    const V3 r = x - ld3(g + 4);
+    const V3 l = v3(R[0] * r.x + R[3] * r.y + R[6] * r.z, R[1] * r.x + R[4] * r.y + R[7] * r.z, R[2] * r.x + R[5] * r.y + R[8] * r.z);
+    V3 nl; float dist;
+    if (g[0] == 0.f) {
+        const V3 q = v3(fabsf(l.x) - g[1], fabsf(l.y) - g[2], fabsf(l.z) - g[3]);
+        const V3 o = v3(fmaxf(q.x, 0.f), fmaxf(q.y, 0.f), fmaxf(q.z, 0.f));
+        const float len = sqrtf(dot(o, o)), mx = fmaxf(q.x, fmaxf(q.y, q.z));
+        dist = len + fminf(mx, 0.f);
+        const V3 sg = v3(l.x < 0.f ? -1.f : 1.f, l.y < 0.f ? -1.f : 1.f, l.z < 0.f ? -1.f : 1.f);
+        if (len > 0.f) nl = v3(o.x / len * sg.x, o.y / len * sg.y, o.z / len * sg.z);
+        else if (q.x >= q.y && q.x >= q.z) nl = v3(sg.x, 0.f, 0.f);           // first maximal axis, like the oracle's argmax
+        else if (q.y >= q.z) nl = v3(0.f, sg.y, 0.f);
+        else nl = v3(0.f, 0.f, sg.z);
+    } else {
+        const float rr = sqrtf(l.x * l.x + l.y * l.y), ux = rr > 1e-12f ? l.x / rr : 1.f, uy = rr > 1e-12f ? l.y / rr : 0.f;
+        const float qr = rr - g[1], qz = fabsf(l.z) - g[2], sz = l.z < 0.f ? -1.f : 1.f;
+        const float orr = fmaxf(qr, 0.f), oz = fmaxf(qz, 0.f), len = sqrtf(orr * orr + oz * oz), mx = fmaxf(qr, qz);
+        dist = len + fminf(mx, 0.f);
+        if (len > 0.f) nl = v3(orr * ux / len, orr * uy / len, oz * sz / len);
+        else if (qr > qz) nl = v3(ux, uy, 0.f);
+        else nl = v3(0.f, 0.f, sz);
+    }
+    nw = mulmat(R, nl);
+    return dist;
+}
+
+template <int NT, bool OBJ>
 __device__ __forceinline__ void collide_plane(EnvLds& s, const DevTables& T, const Params& P, int tid) {
     if (tid < 64) {
         const int bb = tid < D_NB ? tid : 0;
-        bool near = (tid < D_NB) && P.contact && !(s.xpos[3 * bb + 2] - T.body_rbound[bb] > P.margin);
+        bool near = (tid < D_NB) && !(s.xpos[3 * bb + 2] - T.body_rbound[bb] > P.margin);
         unsigned long long mask = __ballot(near);
         int ncon = 0;
+        const int ngeom = OBJ ? static_cast<EnvLdsObj&>(s).ngeom : 0;
         for (int b = 0; b < D_NB; b++) {
             if (tid == 0) s.con_start[b] = ncon;
-            if (!((mask >> b) & 1ull)) continue;
+            if (!P.contact) continue;
             const int vadr = T.vert_adr[b], nvb = T.vert_adr[b + 1] - vadr;
+            const float rb = T.body_rbound[b];
+            const V3 xb = ld3(s.xpos + 3 * b);
             float R[9];
-            q2mat(Q4{s.xquat[4 * b], s.xquat[4 * b + 1], s.xquat[4 * b + 2], s.xquat[4 * b + 3]}, R);
-            V3 v = v3(0.f, 0.f, 0.f);
-            float dist = 3.0e38f;
-            if (tid < nvb) { v = ld3(T.verts + 3 * (vadr + tid)); dist = s.xpos[3 * b + 2] + R[6] * v.x + R[7] * v.y + R[8] * v.z; }
-            bool cand = dist < P.margin;
-            for (int r = 0; r < D_CON_PER_GEOM; r++) {
-                float dmin = cand ? dist : 3.0e38f;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) dmin = fminf(dmin, __shfl_xor(dmin, o, 64));
-                if (!(dmin < P.margin)) break;
-                int idx = (cand && dist == dmin) ? tid : 64;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) idx = min(idx, __shfl_xor(idx, o, 64));
-                if (ncon < D_MAXCON) {
-                    if (tid == idx) {
-                        V3 w = mulmat(R, v);
-                        s.con_pos[3 * ncon] = s.xpos[3 * b] + w.x; s.con_pos[3 * ncon + 1] = s.xpos[3 * b + 1] + w.y;
-                        s.con_pos[3 * ncon + 2] = s.xpos[3 * b + 2] + w.z - 0.5f * dist;
-                        s.con_dist[ncon] = dist; s.con_body[ncon] = b;
-                    }
-                    ncon++;
+            bool have_R = false;
+            V3 v = v3(0.f, 0.f, 0.f), xw = v3(0.f, 0.f, 0.f);
+            for (int gi = -1; gi < ngeom; gi++) {
+                const float* g = gi < 0 ? nullptr : static_cast<EnvLdsObj&>(s).geom + 17 * gi;
+                if (gi < 0) { if (!((mask >> b) & 1ull)) continue; }
+                else {
+                    const V3 dx = xb - ld3(g + 4);
+                    const float gr = g[0] == 0.f ? sqrtf(g[1] * g[1] + g[2] * g[2] + g[3] * g[3]) : sqrtf(g[1] * g[1] + g[2] * g[2]);
+                    if (sqrtf(dot(dx, dx)) - rb - gr > P.margin) continue;
                 }
-                if (tid == idx) cand = false;
+                if (!have_R) {
+                    q2mat(Q4{s.xquat[4 * b], s.xquat[4 * b + 1], s.xquat[4 * b + 2], s.xquat[4 * b + 3]}, R);
+                    if (tid < nvb) { v = ld3(T.verts + 3 * (vadr + tid)); xw = xb + mulmat(R, v); }
+                    have_R = true;
+                }
+                float dist = 3.0e38f;
+                V3 nrm = v3(0.f, 0.f, 1.f);
+                if (tid < nvb) dist = gi < 0 ? xb.z + (R[6] * v.x + R[7] * v.y + R[8] * v.z) : geom_sdf(g, xw, nrm);
+                bool cand = dist < P.margin;
+                for (int r = 0; r < D_CON_PER_GEOM; r++) {
+                    float dmin = cand ? dist : 3.0e38f;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) dmin = fminf(dmin, __shfl_xor(dmin, o, 64));
+                    if (!(dmin < P.margin)) break;
+                    int idx = (cand && dist == dmin) ? tid : 64;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) idx = min(idx, __shfl_xor(idx, o, 64));
+                    if (ncon < D_MAXCON) {
+                        if (tid == idx) {
+                            const V3 w = mulmat(R, v);
+                            st3(s.con_pos + 3 * ncon, xb + w - (0.5f * dist) * nrm);
+                            s.con_dist[ncon] = dist; s.con_body[ncon] = b;
+                            if (OBJ) { st3(static_cast<EnvLdsObj&>(s).con_n + 3 * ncon, nrm); static_cast<EnvLdsObj&>(s).con_iw2[ncon] = gi < 0 ? 0.f : g[16]; }
+                        }
+                        ncon++;
+                    }
+                    if (tid == idx) cand = false;
+                }
             }
         }
         if (tid == 0) { s.con_start[D_NB] = ncon; s.ncon = ncon; s.nlim = 0; }
@@ -473,18 +541,18 @@ __device__ __forceinline__ void collide_plane(EnvLds& s, const DevTables& T, con
 }
 
 // efc_D and the reference acceleration of every constraint row.  aref (contact-frame 3-vector) goes to jv3.
-template <int NT>
+template <int NT, bool OBJ>
 __device__ __forceinline__ void make_constraint(EnvLds& s, const DevTables& T, const Params& P, int tid) {
     const V3 o = ld3(s.xpos);
     for (int c = tid; c < s.ncon; c += NT) {
         int b = s.con_body[c];
         float r = s.con_dist[c] - P.margin;
         float imp = impedance(P, r);
-        float dA = T.body_invw[b] * (1.0f + P.mu * P.mu);
+        float dA = (T.body_invw[b] + (OBJ ? static_cast<EnvLdsObj&>(s).con_iw2[c] : 0.f)) * (1.0f + P.mu * P.mu);
         float Rn = fmaxf(1e-15f, (1.0f - imp) * dA / imp);
         s.con_D[c] = 1.0f / (2.0f * P.mu * P.mu * Rn);
         S6 cv = lds6(s.sv + 6 * b);                         // sv still holds cvel from forward_kin_bias
-        V3 vf = to_frame(cv.l + cross(cv.a, ld3(s.con_pos + 3 * c) - o));
+        V3 vf = frame_comp(contact_frame<OBJ>(s, c), cv.l + cross(cv.a, ld3(s.con_pos + 3 * c) - o));
         s.jv3[3 * c] = -P.B * vf.x - P.K * imp * r; s.jv3[3 * c + 1] = -P.B * vf.y; s.jv3[3 * c + 2] = -P.B * vf.z;
     }
     for (int j = tid; j < D_NU; j += NT) {
@@ -506,12 +574,12 @@ __device__ __forceinline__ void make_constraint(EnvLds& s, const DevTables& T, c
 }
 
 // contact-frame residuals of all rows for the spatial accelerations in sv:  out3 = frame^T (point accel) [- aref]
-template <int NT>
+template <int NT, bool OBJ>
 __device__ __forceinline__ void eval_rows(EnvLds& s, const float* vec, float* out3, float* lim_rows, bool sub_aref, int tid) {
     const V3 o = ld3(s.xpos);
     for (int c = tid; c < s.ncon; c += NT) {
         S6 S = lds6(s.sv + 6 * s.con_body[c]);
-        V3 a = to_frame(S.l + cross(S.a, ld3(s.con_pos + 3 * c) - o));
+        V3 a = frame_comp(contact_frame<OBJ>(s, c), S.l + cross(S.a, ld3(s.con_pos + 3 * c) - o));
         if (sub_aref) { a.x -= s.jv3[3 * c]; a.y -= s.jv3[3 * c + 1]; a.z -= s.jv3[3 * c + 2]; }
         out3[3 * c] = a.x; out3[3 * c + 1] = a.y; out3[3 * c + 2] = a.z;
     }
@@ -523,7 +591,7 @@ __device__ __forceinline__ void eval_rows(EnvLds& s, const float* vec, float* ou
 }
 
 // out = M vec (with_inertia; sv must hold the spatial accelerations of vec) - J^T f(jar) (with_forces)
-template <int NT>
+template <int NT, bool OBJ>
 __device__ __forceinline__ void wrench_project(EnvLds& s, const Params& P, const float* vec, float* out, bool with_inertia, bool with_forces, int tid) {
     if (tid < D_NB) {
         const int b = tid;
@@ -531,10 +599,12 @@ __device__ __forceinline__ void wrench_project(EnvLds& s, const Params& P, const
         if (with_forces) {
             const V3 o = ld3(s.xpos);
             for (int c = s.con_start[b]; c < s.con_start[b + 1]; c++) {
-                V3 F = v3(0.f, 0.f, 0.f);
                 const float Dc = s.con_D[c], jn = s.jar3[3 * c], jt1 = s.jar3[3 * c + 1], jt2 = s.jar3[3 * c + 2];
+                float fe[4];
 #pragma unroll
-                for (int e = 0; e < 4; e++) { float x = row_val(e, P.mu, jn, jt1, jt2); if (x < 0.f) F = F + (-Dc * x) * row_dir(e, P.mu); }
+                for (int e = 0; e < 4; e++) { float x = row_val(e, P.mu, jn, jt1, jt2); fe[e] = x < 0.f ? -Dc * x : 0.f; }
+                // sum_e f_e (n +- mu t_k) in frame coordinates, then to world
+                const V3 F = frame_world(contact_frame<OBJ>(s, c), v3(fe[0] + fe[1] + fe[2] + fe[3], P.mu * (fe[0] - fe[1]), P.mu * (fe[2] - fe[3])));
                 V3 p = ld3(s.con_pos + 3 * c) - o;
                 W.a = W.a - cross(p, F); W.l = W.l - F;
             }
@@ -589,7 +659,7 @@ __device__ __forceinline__ void spatial_accumulate(EnvLds& s, const float* vec, 
 
 // constraint solve: Newton on the primal problem (mj_solNewton) with an exact line search.  Returns iterations.
 // On entry sv holds the spatial accelerations of qacc_s (left by the smooth aba_solve), jv3 holds aref.
-template <int NT>
+template <int NT, bool OBJ>
 __device__ __forceinline__ int solve_constraints(EnvLds& s, const Params& P, const Lane8& L8, int depth, int tid) {
     if (s.ncon == 0 && s.nlim == 0) {
         for (int i = tid; i < D_NV; i += NT) s.qacc[i] = s.qacc_s[i];
@@ -597,15 +667,15 @@ __device__ __forceinline__ int solve_constraints(EnvLds& s, const Params& P, con
         return 0;
     }
     // candidate A: qacc_smooth (M qacc_s = qfrc_smooth => Gauss term 0); sv holds its spatial accelerations
-    eval_rows<NT>(s, s.qacc_s, s.jar3, s.lim_jar, true, tid);
+    eval_rows<NT, OBJ>(s, s.qacc_s, s.jar3, s.lim_jar, true, tid);
     float cost = primal_cost<NT>(s, P, nullptr, nullptr, s.jar3, s.lim_jar, tid);
     // candidate B: warm start = s.qacc (qacc of the previous substep / control step), mj_fwdConstraint's rule
     {
         float* wj3 = s.U;      // scratch: U / x are rewritten by the next aba_solve
         float* wlim = s.x;
         spatial_accumulate<NT>(s, s.qacc, depth, tid);
-        eval_rows<NT>(s, s.qacc, wj3, wlim, true, tid);
-        wrench_project<NT>(s, P, s.qacc, s.Mv, true, false, tid);
+        eval_rows<NT, OBJ>(s, s.qacc, wj3, wlim, true, tid);
+        wrench_project<NT, OBJ>(s, P, s.qacc, s.Mv, true, false, tid);
         for (int i = tid; i < D_NV; i += NT) s.mres[i] = s.Mv[i] - s.smooth[i];
         KP_SYNC();
         float cw = primal_cost<NT>(s, P, s.qacc, s.mres, wj3, wlim, tid);
@@ -621,7 +691,7 @@ __device__ __forceinline__ int solve_constraints(EnvLds& s, const Params& P, con
     int it = 0;
     for (; it < P.max_iter; it++) {
         // gradient = mres - J^T f
-        wrench_project<NT>(s, P, nullptr, s.grad, false, true, tid);
+        wrench_project<NT, OBJ>(s, P, nullptr, s.grad, false, true, tid);
         float g2 = 0.f;
         for (int i = tid; i < D_NV; i += NT) {
             float g = s.mres[i] + s.grad[i];
@@ -633,9 +703,9 @@ __device__ __forceinline__ int solve_constraints(EnvLds& s, const Params& P, con
         KP_SYNC();
         if (P.scale * sqrtf(g2) < P.tol) break;
         // search = -H^-1 grad,  H = M + J^T D_active J : articulated-body pass with contact inertia
-        aba_solve<NT>(s, P, L8, s.x, s.search, true, tid);
-        eval_rows<NT>(s, s.search, s.jv3, s.lim_jv, false, tid);           // aref (in jv3) is folded into jar3 by now
-        wrench_project<NT>(s, P, s.search, s.Mv, true, false, tid);
+        aba_solve<NT, OBJ>(s, P, L8, s.x, s.search, true, tid);
+        eval_rows<NT, OBJ>(s, s.search, s.jv3, s.lim_jv, false, tid);           // aref (in jv3) is folded into jar3 by now
+        wrench_project<NT, OBJ>(s, P, s.search, s.Mv, true, false, tid);
         // exact line search on phi(alpha)
         float g0 = 0.f, h0 = 0.f;
         for (int i = tid; i < D_NV; i += NT) { g0 += s.search[i] * s.mres[i]; h0 += s.search[i] * s.Mv[i]; }
@@ -680,10 +750,10 @@ __device__ __forceinline__ int solve_constraints(EnvLds& s, const Params& P, con
 }
 
 // ---------------------------------------------------------------- the kernel
-template <int NT>
+template <int NT, bool OBJ>
 __global__ __launch_bounds__(NT, (NT == 64 ? 2 : 1)) void kp_step_kernel(StepArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    EnvLds& s = *reinterpret_cast<EnvLds*>(smem_raw);
+    typename std::conditional<OBJ, EnvLdsObj, EnvLds>::type& s = *reinterpret_cast<typename std::conditional<OBJ, EnvLdsObj, EnvLds>::type*>(smem_raw);
     const int env = blockIdx.x, tid = threadIdx.x;
     if (env >= A.n_envs) return;
     if (A.env_mask && !A.env_mask[env]) return;
@@ -706,6 +776,10 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 2 : 1)) void kp_step_kernel(StepArg
     if (tid < 22) s.IAa[22 * 24 + tid] = 0.f;
     if (tid < 6) s.pAa[6 * 24 + tid] = 0.f;
     if (tid == 0) { s.ncon = 0; s.nlim = 0; s.flag = 0; }
+    if constexpr (OBJ) {
+        for (int i = tid; i < D_MAXGEOM * 17; i += NT) s.geom[i] = A.geoms[(size_t)env * D_MAXGEOM * 17 + i];
+        if (tid == 0) s.ngeom = A.ngeom[env];
+    }
     KP_SYNC();
     forward_kin_bias<NT>(s, T, P, depth, bpos, tid);
     float qd_save_q[(D_NQ + NT - 1) / NT], qd_save_v[(D_NV + NT - 1) / NT];
@@ -727,7 +801,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 2 : 1)) void kp_step_kernel(StepArg
     for (int sub = 0; sub < A.n_substeps; sub++) {
         if (prof) t0 = __builtin_readcyclecounter();
         // stale mode: the controller sees M / bias of the previous forward pass (cinert, cdof, bias still in LDS)
-        if (P.stale) spd_torque_rfc<NT>(s, T, P, L8, depth, tid);
+        if (P.stale) spd_torque_rfc<NT, OBJ>(s, T, P, L8, depth, tid);
         KP_T(0)
         // ---- mj_forward at the current state
 #pragma unroll
@@ -736,19 +810,19 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 2 : 1)) void kp_step_kernel(StepArg
         for (int n = 0; n < (D_NV + NT - 1) / NT; n++) { int i = tid + n * NT; if (i < D_NV) qd_save_v[n] = s.qvel[i]; }
         forward_kin_bias<NT>(s, T, P, depth, bpos, tid);
         KP_T(1)
-        collide_plane<NT>(s, T, P, tid);
+        collide_plane<NT, OBJ>(s, T, P, tid);
         KP_T(2)
-        make_constraint<NT>(s, T, P, tid);                 // needs sv = cvel: before any aba_solve
+        make_constraint<NT, OBJ>(s, T, P, tid);                 // needs sv = cvel: before any aba_solve
         KP_T(3)
-        if (!P.stale) spd_torque_rfc<NT>(s, T, P, L8, depth, tid);
+        if (!P.stale) spd_torque_rfc<NT, OBJ>(s, T, P, L8, depth, tid);
         for (int i = tid; i < D_NV; i += NT) {
             float f = -s.bias[i] + (i < 6 ? s.applied[i] : s.ctrl[i - 6]);
             s.smooth[i] = f; s.extra[i] = 0.f;
         }
         KP_SYNC();
-        aba_solve<NT>(s, P, L8, s.smooth, s.qacc_s, false, tid);   // qacc_smooth = M^-1 qfrc_smooth; sv = its spatial accel
+        aba_solve<NT, OBJ>(s, P, L8, s.smooth, s.qacc_s, false, tid);   // qacc_smooth = M^-1 qfrc_smooth; sv = its spatial accel
         KP_T(4)
-        niter_total += solve_constraints<NT>(s, P, L8, depth, tid);
+        niter_total += solve_constraints<NT, OBJ>(s, P, L8, depth, tid);
         KP_T(5)
         maxcon = max(maxcon, s.ncon);
         // ---- semi-implicit Euler (mj_Euler, no damping)

@@ -41,10 +41,12 @@ class RunningState:
 
 
 class BatchedHumanoidAREnv:
-    def __init__(self, n_envs, device=0, kpm_path=kpsim.DEFAULT_KPM, cc_policy: PolicyMCP | None = None,
+    def __init__(self, n_envs, device=0, kpm_path=None, cc_policy: PolicyMCP | None = None,
                  cc_running_state: RunningState | None = None, mode="train", wild=False, joint_controller=False,
                  env_episode_len=100000, body_diff_thresh=10.0, body_diff_gt_thresh=12.0, model_options=None, seed=0):
         self.n = int(n_envs)
+        if kpm_path is None:  # agent_ar.py:165-169: mocap training uses ..._all_step.xml, --wild uses ..._all.xml
+            kpm_path = kpsim.DEFAULT_KPM if wild else kpsim.STEP_KPM
         self.model = kpsim.KpModel(kpm_path, **(model_options or {}))
         self.sim = kpsim.KpSim(self.model, self.n, device)
         self.device = self.sim.device
@@ -62,6 +64,8 @@ class BatchedHumanoidAREnv:
         self.cur_t = torch.zeros(self.n, dtype=torch.int32, device=self.device)
         self.ctx = None
         self.ctx_len = None
+        self.obj_qpos = None      # [N,35] = data.qpos[76:111] (convert_obj_qpos)
+        self.obj7 = None          # [N,7]  = get_obj_qpos(action_one_hot)
         self._ctx_struct = None
         self.end_reward = 0.0
         self.action_dim, self.obs_dim, self.cc_action_dim = 80, kpsim.AR_OBS_DIM, kpsim.CC_ACTION_DIM
@@ -110,8 +114,12 @@ class BatchedHumanoidAREnv:
                 self.ctx["gt_wbpos"][idx] = gt["wbpos"].view(-1, T, 72)
         self.ctx_len = T - 1
         c = self.ctx
+        if "obj_pose" in c and bool((c["action_one_hot"].sum(1) > 0).any()):
+            self.obj_qpos, self.obj7 = convert_obj_qpos(c["action_one_hot"], c["obj_pose"][:, 0])
+        else:
+            self.obj_qpos = self.obj7 = None
         self._ctx_struct = self.sim.make_ctx(T, c["head_pose"], c["head_vels"], c["obj_head_relative_poses"], c["action_one_hot"],
-                                             c["gt_bquat"], c["gt_wbpos"], self.cur_t)
+                                             c["gt_bquat"], c["gt_wbpos"], self.cur_t, obj_qpos=self.obj7)
 
     def reset(self, env_mask: torch.Tensor | None = None):
         """sim.reset(); cur_t = 0; reset_model(): state <- ar_context init_qpos/init_qvel, target = FK(init) (:334-387)."""
@@ -120,6 +128,8 @@ class BatchedHumanoidAREnv:
             self.cur_t.zero_()
         else:
             self.cur_t.masked_fill_(env_mask.to(self.device, torch.bool), 0)
+        if self.obj_qpos is not None:
+            self.sim.set_objects(self.obj_qpos, m8)
         self.sim.set_state(self.ctx["init_qpos"], self.ctx["init_qvel"], m8)
         self.sim.set_target(self.ctx["init_qpos"], m8)
         return self.sim.obs_ar(self._ctx_struct, self._obs)
@@ -171,6 +181,27 @@ class BatchedHumanoidAREnv:
         g = self.sim.get
         return {"qpos": g("target_qpos"), "wbpos": g("target_wbpos"), "wbquat": g("target_wbquat"), "bquat": g("target_bquat"),
                 "body_com": g("target_com")}
+
+
+ACTION_INDEX_MAP, ACTION_LEN = (0, 7, 21, 28), (7, 14, 7, 7)   # sit / push / avoid / step  (humanoid_ar_v1.py:37-39)
+
+
+def convert_obj_qpos(action_one_hot: torch.Tensor, obj_pose0: torch.Tensor):
+    """HumanoidAREnv.convert_obj_qpos (humanoid_ar_v1.py:479-496) batched: every object parked at [(i+1)*100, 100, 0]
+    with a zero quaternion, the active action's slice overwritten by obj_pose.  Returns ([N,35], [N,7] active slice)."""
+    n, dev = action_one_hot.shape[0], action_one_hot.device
+    blk = torch.zeros((n, 35), device=dev)
+    for i in range(5):
+        blk[:, 7 * i] = (i + 1) * 100.0; blk[:, 7 * i + 1] = 100.0
+    obj7 = torch.tensor([0.0, 0, 0, 1, 0, 0, 0], device=dev).repeat(n, 1)
+    for a in range(4):
+        m = action_one_hot[:, a] > 0
+        if bool(m.any()):
+            st, ln = ACTION_INDEX_MAP[a], ACTION_LEN[a]
+            ln = min(ln, obj_pose0.shape[1])
+            blk[m, st:st + ln] = obj_pose0[m, :ln]
+            obj7[m] = blk[m, st:st + 7]
+    return blk.contiguous(), obj7.contiguous()
 
 
 def standing_context(n, T, std_qpos, std_qvel, sim: kpsim.KpSim, headings: torch.Tensor | None = None):

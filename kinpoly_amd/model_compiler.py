@@ -36,7 +36,7 @@ import xml.etree.ElementTree as ET
 import numpy as np
 
 KPM_MAGIC = 0x314D504B  # 'KPM1'
-KPM_VERSION = 3
+KPM_VERSION = 4
 
 # MuJoCo 2.1.0 defaults that the reference never overrides [MJ-ext]
 MJ_DEFAULTS = dict(
@@ -333,6 +333,12 @@ def compile_model(xml_path: str, uhc_yml: str | None = None) -> dict:
             R = euler_deg_to_mat(_floats(g.get("euler", "0 0 0"), 3))
             obj_geoms.append([oi, typ, *size[:3], *_floats(g.get("pos", "0 0 0"), 3), *R.reshape(-1), float(g["mass"])])
     obj_geoms = np.array(obj_geoms, float).reshape(-1, 18)
+    nobj = len(px["objects"])
+    obj_geom_adr = np.zeros(nobj + 1, np.int32)
+    obj_mass = np.zeros(nobj)
+    for g in obj_geoms:
+        obj_geom_adr[int(g[0]) + 1:] += 1
+        obj_mass[int(g[0])] += g[17]
 
     model = dict(
         dims=np.array([nb, nv, nv + 1, nu, nM, len(verts), len(px["objects"]), len(obj_geoms), condim], np.int32),
@@ -350,7 +356,7 @@ def compile_model(xml_path: str, uhc_yml: str | None = None) -> dict:
                       *fric, geom_margin, MJ_DEFAULTS["impratio"], meaninertia,
                       rfc_scale, rfc_lim, *base_rot,
                       MJ_DEFAULTS["solver_iterations"], MJ_DEFAULTS["solver_tolerance"]], float),
-        obj_geoms=obj_geoms,
+        obj_geoms=obj_geoms, obj_geom_adr=obj_geom_adr, obj_mass=obj_mass,
         M0=M0,
     )
     model["_names"] = [b["name"] for b in bodies]
@@ -400,7 +406,8 @@ def read_kpm(path: str) -> dict:
     return out
 
 
-DEFAULT_KPM = os.path.join(os.path.dirname(__file__), "assets", "smpl_humanoid.kpm")
+DEFAULT_KPM = os.path.join(os.path.dirname(__file__), "assets", "smpl_humanoid.kpm")            # humanoid_smpl_neutral_mesh_all.xml
+STEP_KPM = os.path.join(os.path.dirname(__file__), "assets", "smpl_humanoid_step.kpm")          # ..._all_step.xml (mocap training, agent_ar.py:168)
 
 
 def main(argv):

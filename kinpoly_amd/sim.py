@@ -17,9 +17,10 @@ from . import build as _build
 NQ, NV, NU, NBODY = 76, 75, 69, 24
 CC_OBS_DIM, AR_OBS_DIM, KIN_ACTION_DIM, CC_ACTION_DIM = 784, 105, 80, 75
 DEFAULT_KPM = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets", "smpl_humanoid.kpm")
+STEP_KPM = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets", "smpl_humanoid_step.kpm")
 
 FIELDS = dict(qpos=0, qvel=1, xpos=2, xquat=3, xipos=4, bquat=5, head=6, target_qpos=7, target_wbpos=8,
-              target_wbquat=9, target_bquat=10, target_com=11, qpos_d=12, qvel_d=13, prev_bquat=14, prev_hpos=15)
+              target_wbquat=9, target_bquat=10, target_com=11, qpos_d=12, qvel_d=13, prev_bquat=14, prev_hpos=15, obj_qpos=16)
 
 _lib = None
 
@@ -29,7 +30,7 @@ ABI_SYMBOLS = [
     "kp_sim_n_envs", "kp_sim_set_state", "kp_sim_set_target", "kp_sim_step_ctrl", "kp_sim_step_kin", "kp_sim_obs_cc",
     "kp_field_dim", "kp_sim_get", "kp_sim_diag", "kp_sim_last_step_seconds", "kp_last_error", "kp_version",
     "kp_sim_step_begin", "kp_sim_obs_ar", "kp_sim_term_reward", "kp_gae", "kp_sim_set_full_state", "kp_sim_fk",
-    "kp_sim_timing_reset", "kp_sim_timing_mean_seconds", "kp_sim_phase_cycles",
+    "kp_sim_timing_reset", "kp_sim_timing_mean_seconds", "kp_sim_phase_cycles", "kp_sim_set_objects",
 ]
 
 
@@ -89,6 +90,7 @@ def load_library(path: str | None = None):
     L.kp_sim_timing_reset.argtypes = [P]; L.kp_sim_timing_reset.restype = C.c_int
     L.kp_sim_timing_mean_seconds.argtypes = [P, C.POINTER(C.c_int)]; L.kp_sim_timing_mean_seconds.restype = C.c_double
     L.kp_sim_phase_cycles.argtypes = [P, C.POINTER(C.c_double)]; L.kp_sim_phase_cycles.restype = C.c_int
+    L.kp_sim_set_objects.argtypes = [P, F, U8]; L.kp_sim_set_objects.restype = C.c_int
     L.kp_sim_fk.argtypes = [P, C.c_int, F, F, F, F, F, F]; L.kp_sim_fk.restype = C.c_int
     L.kp_last_error.restype = C.c_char_p
     L.kp_version.restype = C.c_char_p
@@ -166,6 +168,9 @@ class KpSim:
 
     def set_state(self, qpos, qvel, env_mask=None):
         _check(self.L.kp_sim_set_state(self.h, _ptr(qpos, self.n, NQ), _ptr(qvel, self.n, NV), _mask_ptr(env_mask, self.n)), "kp_sim_set_state")
+
+    def set_objects(self, obj_qpos, env_mask=None):
+        _check(self.L.kp_sim_set_objects(self.h, _ptr(obj_qpos, self.n, 35), _mask_ptr(env_mask, self.n)), "kp_sim_set_objects")
 
     def set_target(self, target_qpos, env_mask=None):
         _check(self.L.kp_sim_set_target(self.h, _ptr(target_qpos, self.n, NQ), _mask_ptr(env_mask, self.n)), "kp_sim_set_target")

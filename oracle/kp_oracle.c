@@ -35,6 +35,7 @@
 #define MAXCON 64
 #define MAXEFC (MAXCON * 4 + 2 * 69)
 #define CON_PER_GEOM 3
+#define MAXGEOM 8
 #define MJ_MINVAL 1e-15
 #define MJ_MINIMP 0.0001
 #define MJ_MAXIMP 0.9999
@@ -59,7 +60,11 @@ typedef struct {
     int enable_contact, enable_limits;
 } kpo_model;
 
+/* static collision geometry of the active objects (chair / box / table / Can / step), world frame */
+typedef struct { int type; double size[3], pos[3], mat[9], invw, rbound; } kpo_geom;
+
 typedef struct {
+    int ngeom; kpo_geom geom[MAXGEOM];   /* survives kpo_reset */
     double qpos[NQ_MAX], qvel[NV_MAX];
     double ctrl[69], qfrc_applied[NV_MAX];
     /* derived (state of the last forward pass) */
@@ -75,7 +80,7 @@ typedef struct {
     /* contacts */
     int ncon;
     int con_body[MAXCON];
-    double con_pos[MAXCON][3], con_dist[MAXCON], con_frame[MAXCON][9];
+    double con_pos[MAXCON][3], con_dist[MAXCON], con_frame[MAXCON][9], con_invw2[MAXCON];
     /* constraint rows */
     int nefc;
     double efc_J[MAXEFC][NV_MAX], efc_aref[MAXEFC], efc_D[MAXEFC], efc_force[MAXEFC];
@@ -340,32 +345,79 @@ static void kpo_vel_bias(const kpo_model *m, kpo_data *d) {
 /* hull-vs-plane narrow phase.  Engine rule (documented in DESIGN.md): per hull, the up-to-3
  * deepest vertices with dist < margin, ties broken by vertex index; contact point is the midpoint
  * between the vertex and its projection; frame = MuJoCo mju_makeFrame of the plane normal. [MJ-ext] */
+/* signed distance + outward normal (world) of a static box / cylinder geom at world point x.
+ * Engine rule for hull-vs-primitive contacts: the reference leaves these to MuJoCo's general convex
+ * narrow phase (libccd), which cannot be restated verifiably; here every hull VERTEX is tested against the
+ * primitive's exact signed-distance field and the <= 3 deepest vertices with dist < margin make contacts. */
+static double kpo_geom_sdf(const kpo_geom *g, const double *x, double *nw) {
+    double r[3] = {x[0] - g->pos[0], x[1] - g->pos[1], x[2] - g->pos[2]}, l[3], nl[3], dist;
+    for (int k = 0; k < 3; k++) l[k] = g->mat[k] * r[0] + g->mat[3 + k] * r[1] + g->mat[6 + k] * r[2];   /* R^T r */
+    if (g->type == 0) {
+        double q[3], o[3], len2 = 0, mx = -1e300; int am = 0;
+        for (int k = 0; k < 3; k++) { q[k] = fabs(l[k]) - g->size[k]; o[k] = q[k] > 0 ? q[k] : 0; len2 += o[k] * o[k]; if (q[k] > mx) { mx = q[k]; am = k; } }
+        double len = sqrt(len2);
+        dist = len + (mx < 0 ? mx : 0);
+        if (len > 0) for (int k = 0; k < 3; k++) nl[k] = o[k] / len * (l[k] < 0 ? -1.0 : 1.0);
+        else { nl[0] = nl[1] = nl[2] = 0; nl[am] = l[am] < 0 ? -1.0 : 1.0; }
+    } else {
+        double rr = sqrt(l[0] * l[0] + l[1] * l[1]), ux = rr > 1e-12 ? l[0] / rr : 1.0, uy = rr > 1e-12 ? l[1] / rr : 0.0;
+        double qr = rr - g->size[0], qz = fabs(l[2]) - g->size[1], sz = l[2] < 0 ? -1.0 : 1.0;
+        double orr = qr > 0 ? qr : 0, oz = qz > 0 ? qz : 0, len = sqrt(orr * orr + oz * oz), mx = qr > qz ? qr : qz;
+        dist = len + (mx < 0 ? mx : 0);
+        if (len > 0) { nl[0] = orr * ux / len; nl[1] = orr * uy / len; nl[2] = oz * sz / len; }
+        else if (qr > qz) { nl[0] = ux; nl[1] = uy; nl[2] = 0; }
+        else { nl[0] = nl[1] = 0; nl[2] = sz; }
+    }
+    mat_mulvec(nw, g->mat, nl);
+    return dist;
+}
+/* mju_makeFrame: x-axis given, y from (0,1,0) or (0,0,1) made orthogonal, z = x cross y  [MJ-ext] */
+static void kpo_make_frame(double *fr) {
+    double *x = fr, *y = fr + 3, *z = fr + 6;
+    if (fabs(x[1]) < 0.5) { y[0] = 0; y[1] = 1; y[2] = 0; } else { y[0] = 0; y[1] = 0; y[2] = 1; }
+    double dp = v3_dot(x, y);
+    for (int k = 0; k < 3; k++) y[k] -= dp * x[k];
+    double n = sqrt(v3_dot(y, y));
+    for (int k = 0; k < 3; k++) y[k] /= n;
+    v3_cross(z, x, y);
+}
+
+/* narrow phase.  Engine rule (documented in DESIGN.md): per (hull, plane|primitive) pair, the up-to-3
+ * deepest hull vertices with dist < margin, ties broken by vertex index; contact point is the midpoint
+ * between the vertex and its projection; contacts are emitted body by body: floor first, then geoms. [MJ-ext] */
 static void kpo_collide(const kpo_model *m, kpo_data *d) {
     d->ncon = 0;
     if (!m->enable_contact) return;
     for (int b = 0; b < m->nb; b++) {
-        if (d->xpos[b][2] - m->body_rbound[b] > m->margin) continue;
-        int best[CON_PER_GEOM]; double bd[CON_PER_GEOM]; int nbest = 0;
-        for (int v = m->vert_adr[b]; v < m->vert_adr[b + 1]; v++) {
-            double w[3]; mat_mulvec(w, d->xmat[b], m->verts + 3 * v);
-            double dist = d->xpos[b][2] + w[2];
-            if (dist >= m->margin) continue;
-            int pos = nbest;
-            while (pos > 0 && dist < bd[pos - 1]) pos--;
-            if (pos >= CON_PER_GEOM) continue;
-            int last = nbest < CON_PER_GEOM ? nbest : CON_PER_GEOM - 1;
-            for (int k = last; k > pos; k--) { best[k] = best[k - 1]; bd[k] = bd[k - 1]; }
-            best[pos] = v; bd[pos] = dist;
-            if (nbest < CON_PER_GEOM) nbest++;
-        }
-        for (int k = 0; k < nbest && d->ncon < MAXCON; k++) {
-            int c = d->ncon++;
-            double w[3]; mat_mulvec(w, d->xmat[b], m->verts + 3 * best[k]);
-            d->con_body[c] = b; d->con_dist[c] = bd[k];
-            d->con_pos[c][0] = d->xpos[b][0] + w[0]; d->con_pos[c][1] = d->xpos[b][1] + w[1];
-            d->con_pos[c][2] = d->xpos[b][2] + w[2] - 0.5 * bd[k];
-            static const double fr[9] = {0, 0, 1, 0, 1, 0, -1, 0, 0};
-            memcpy(d->con_frame[c], fr, 72);
+        for (int gi = -1; gi < d->ngeom; gi++) {
+            const kpo_geom *g = gi < 0 ? NULL : &d->geom[gi];
+            if (!g) { if (d->xpos[b][2] - m->body_rbound[b] > m->margin) continue; }
+            else {
+                double dx[3] = {d->xpos[b][0] - g->pos[0], d->xpos[b][1] - g->pos[1], d->xpos[b][2] - g->pos[2]};
+                if (sqrt(v3_dot(dx, dx)) - m->body_rbound[b] - g->rbound > m->margin) continue;
+            }
+            int best[CON_PER_GEOM]; double bd[CON_PER_GEOM], bn[CON_PER_GEOM][3]; int nbest = 0;
+            for (int v = m->vert_adr[b]; v < m->vert_adr[b + 1]; v++) {
+                double w[3], nrm[3] = {0, 0, 1}, dist; mat_mulvec(w, d->xmat[b], m->verts + 3 * v);
+                double xw[3] = {d->xpos[b][0] + w[0], d->xpos[b][1] + w[1], d->xpos[b][2] + w[2]};
+                dist = g ? kpo_geom_sdf(g, xw, nrm) : xw[2];
+                if (dist >= m->margin) continue;
+                int pos = nbest;
+                while (pos > 0 && dist < bd[pos - 1]) pos--;
+                if (pos >= CON_PER_GEOM) continue;
+                int last = nbest < CON_PER_GEOM ? nbest : CON_PER_GEOM - 1;
+                for (int k = last; k > pos; k--) { best[k] = best[k - 1]; bd[k] = bd[k - 1]; memcpy(bn[k], bn[k - 1], 24); }
+                best[pos] = v; bd[pos] = dist; memcpy(bn[pos], nrm, 24);
+                if (nbest < CON_PER_GEOM) nbest++;
+            }
+            for (int k = 0; k < nbest && d->ncon < MAXCON; k++) {
+                int c = d->ncon++;
+                double w[3]; mat_mulvec(w, d->xmat[b], m->verts + 3 * best[k]);
+                d->con_body[c] = b; d->con_dist[c] = bd[k]; d->con_invw2[c] = g ? g->invw : 0.0;
+                for (int a = 0; a < 3; a++) d->con_pos[c][a] = d->xpos[b][a] + w[a] - 0.5 * bd[k] * bn[k][a];
+                memcpy(d->con_frame[c], bn[k], 24);
+                kpo_make_frame(d->con_frame[c]);
+            }
         }
     }
 }
@@ -418,7 +470,7 @@ static void kpo_make_constraint(const kpo_model *m, kpo_data *d) {
         }
         const double *fr = d->con_frame[c];
         double mu = m->friction[0]; /* impratio 1 */
-        double tran = m->body_invweight0[b][0];
+        double tran = m->body_invweight0[b][0] + d->con_invw2[c];
         double imp = kpo_impedance(m, d->con_dist[c] - m->margin);
         double dA = tran + mu * mu * tran;
         double Rn = fmax(MJ_MINVAL, (1 - imp) * dA / imp);
@@ -555,7 +607,9 @@ void kpo_step(const kpo_model *m, kpo_data *d) {
 
 /* set_state + sim.forward()  (mujoco_env.py:97-103); sim.reset() zeroes ctrl / qfrc_applied / warmstart */
 void kpo_reset(const kpo_model *m, kpo_data *d, const double *qpos, const double *qvel) {
+    int ng = d->ngeom; kpo_geom gsave[MAXGEOM]; memcpy(gsave, d->geom, sizeof(gsave));
     memset(d, 0, sizeof(*d));
+    d->ngeom = ng; memcpy(d->geom, gsave, sizeof(gsave));
     memcpy(d->qpos, qpos, sizeof(double) * m->nq); memcpy(d->qvel, qvel, sizeof(double) * m->nv);
     kpo_forward(m, d);
 }
@@ -609,6 +663,16 @@ void kpo_do_simulation(const kpo_model *m, kpo_data *d, const double *action, co
         for (int j = 0; j < m->nu; j++) { double t = torque[j]; if (t > m->torque_lim[j]) t = m->torque_lim[j]; if (t < -m->torque_lim[j]) t = -m->torque_lim[j]; d->ctrl[j] = t; }
         kpo_rfc_implicit(m, d, action + m->nu);
         kpo_step(m, d);
+    }
+}
+
+/* n x 17 doubles: type (0 box, 1 cylinder), size[3], pos[3], mat[9] (world), invweight of the owning object */
+void kpo_set_geoms(kpo_data *d, int n, const double *p) {
+    d->ngeom = n > MAXGEOM ? MAXGEOM : n;
+    for (int i = 0; i < d->ngeom; i++, p += 17) {
+        kpo_geom *g = &d->geom[i];
+        g->type = (int)p[0]; memcpy(g->size, p + 1, 24); memcpy(g->pos, p + 4, 24); memcpy(g->mat, p + 7, 72); g->invw = p[16];
+        g->rbound = g->type == 0 ? sqrt(v3_dot(g->size, g->size)) : sqrt(g->size[0] * g->size[0] + g->size[1] * g->size[1]);
     }
 }
 

@@ -50,6 +50,7 @@ def lib():
         L.kpo_set_ctrl.argtypes = [P, D, D]
         L.kpo_solveM.argtypes = [P, P, D]
         L.kpo_get_contacts.argtypes = [P, I, D, D]
+        L.kpo_set_geoms.argtypes = [P, C.c_int, D]
         L.kpo_get_efc.argtypes = [P, D, D, D]
         L.kpo_get_efc_J.argtypes = [P, D]
         L.kpo_rollout_batch.argtypes = [P, C.c_int, D, D, D, D, C.c_int, C.c_int]
@@ -100,6 +101,11 @@ class OracleSim:
         ctrl = np.ascontiguousarray(ctrl, np.float64)
         a = None if applied6 is None else np.ascontiguousarray(applied6, np.float64)
         self.L.kpo_set_ctrl(self.d, _dp(ctrl), None if a is None else _dp(a))
+
+    def set_geoms(self, packed):
+        """packed [n,17]: type, size3, pos3, R9 (world), invweight (see object_geoms())."""
+        g = np.ascontiguousarray(packed, np.float64).reshape(-1, 17)
+        self.L.kpo_set_geoms(self.d, g.shape[0], _dp(g))
 
     def forward(self):
         self.L.kpo_forward(self.m, self.d)
@@ -155,3 +161,25 @@ class OracleSim:
         a = np.ascontiguousarray(action, np.float64); t = np.ascontiguousarray(target, np.float64)
         self.L.kpo_rollout_batch(self.m, qpos.shape[0], _dp(qpos), _dp(qvel), _dp(a), _dp(t), n_steps, n_frames)
         return qpos, qvel
+
+
+def object_geoms(kpm: dict, obj_qpos35, max_dist=50.0):
+    """World-frame collision geoms [n,17] of the objects that are not parked (convert_obj_qpos parks inactive
+    objects at [(i+1)*100, 100, 0] with a zero quaternion, kin_poly/envs/humanoid_ar_v1.py:479-496)."""
+    og = kpm["obj_geoms"].reshape(-1, 18); mass = kpm["obj_mass"]
+    out = []
+    for gi in range(og.shape[0]):
+        oi = int(og[gi, 0])
+        pose = np.asarray(obj_qpos35[7 * oi: 7 * oi + 7], float)
+        if np.linalg.norm(pose[:3]) > max_dist:
+            continue
+        q = pose[3:7]; n = np.linalg.norm(q)
+        q = np.array([1.0, 0, 0, 0]) if n < 1e-15 else q / n
+        w, x, y, z = q
+        R = np.array([[w * w + x * x - y * y - z * z, 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                      [2 * (x * y + w * z), w * w - x * x + y * y - z * z, 2 * (y * z - w * x)],
+                      [2 * (x * z - w * y), 2 * (y * z + w * x), w * w - x * x - y * y + z * z]])
+        Rg = R @ og[gi, 8:17].reshape(3, 3)
+        pos = pose[:3] + R @ og[gi, 5:8]
+        out.append(np.concatenate([[og[gi, 1]], og[gi, 2:5], pos, Rg.reshape(-1), [1.0 / mass[oi]]]))
+    return np.array(out).reshape(-1, 17)

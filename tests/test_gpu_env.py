@@ -118,3 +118,35 @@ def test_sampler_autoreset_and_ppo_update():
     stats = tr.update(batch)
     assert np.isfinite(stats["value_loss"]) and np.isfinite(stats["surr_loss"])
     assert any((a - b).abs().max() > 0 for a, b in zip(before, [p for p in policy.parameters() if p.requires_grad]))
+
+
+def test_env_with_step_object():
+    """action_one_hot = 'step': the step box becomes collision geometry and enters the AR observation."""
+    from kinpoly_amd.env import BatchedHumanoidAREnv, standing_context
+    n, T = 4, 6
+    env = BatchedHumanoidAREnv(n, 0, mode="test", seed=0)
+    ctx = standing_context(n, T, STD["qpos"], STD["qvel"], env.sim)
+    one_hot = torch.zeros((n, 4), device=env.device); one_hot[:2, 3] = 1.0          # envs 0, 1: "step"
+    pose = torch.tensor([STD["qpos"][0], STD["qpos"][1], 0.23 - 0.21, 1.0, 0, 0, 0], device=env.device).repeat(n, 1)  # box top 1 cm under the floor level
+    pose[0, 2] = 0.23 - 0.195                                                     # env 0: box top 5 mm above the floor => feet rest on it
+    ctx["action_one_hot"] = one_hot
+    ctx["obj_pose"] = pose.unsqueeze(1).repeat(1, T, 1).contiguous()
+    env.load_context(ctx)
+    obs = env.reset().double().cpu().numpy()
+    rd = {k: env.sim.get(k).double().cpu().numpy() for k in ("qpos", "xpos", "xquat", "obj_qpos")}
+    assert np.allclose(rd["obj_qpos"][0, 28:35], pose[0].cpu().numpy(), atol=1e-6) and rd["obj_qpos"][2, 28] == 500.0
+    c = {k: v.double().cpu().numpy() for k, v in env.ctx.items()}
+    for i in range(n):
+        want = O.obs_ar(rd["qpos"][i], rd["xpos"][i].reshape(24, 3), rd["xquat"][i].reshape(24, 4), c["head_pose"][i, 0], c["head_vels"][i, 0],
+                        c["obj_head_relative_poses"][i, 0], c["action_one_hot"][i], rd["obj_qpos"][i, 28:35])
+        np.testing.assert_allclose(obs[i], want, atol=5e-5)
+    a = torch.zeros((n, 80), device=env.device)
+    q0 = env.sim.get("qpos")
+    for i in range(n):
+        cur = q0[i].double().cpu().numpy(); cur[3:7] = O.de_heading(cur[3:7]); a[i, :74] = torch.tensor(cur[2:], dtype=torch.float32)
+    for _ in range(3):
+        env.step(a)
+    dg = env.sim.diag()
+    assert dg[:, 2].max() == 0
+    z = env.sim.get("qpos")[:, 2].cpu().numpy()
+    assert z[0] > z[2] + 0.002        # env 0 stands on the raised box, env 2 (no object) on the floor
