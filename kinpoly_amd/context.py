@@ -1,0 +1,177 @@
+"""Per-episode context pipeline, batched over environments: the vectorised `PolicyAR.init_context`
+(kin_poly/models/policy_ar.py:124-182) on top of `TrajARNet.init_states / forward`
+(kin_poly/models/traj_ar_smpl_net.py:157-201, 346-383).
+
+Per episode the reference (i) runs a context GRU over the whole clip and predicts the initial pose / velocity,
+(ii) rolls the kinematic policy over the whole clip (T GRU steps + T forward-kinematics calls), (iii) smooths the
+rolled-out joint angles with a Gaussian (sigma = 1 frame) and re-runs FK.  Here all N environments' clips go
+through these three stages together: the GRUs are [N, .] GEMMs, and the kinematic roll-out reuses the HIP
+kernels of the rollout path (`step_kin`, forward kinematics, `obs_ar`) on a second, physics-free `KpSim`.
+
+Parameter names mirror the reference module (`action_rnn.rnn_f`, `action_mlp`, `action_fc`, `context_rnn.rnn_f`,
+`context_mlp`, `context_fc`) so `policy_dict['traj_ar_net.*']` of a reference checkpoint loads directly.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+from . import sim as kpsim
+from .nets import MLP, KinPolicy, _StepRNN
+
+
+def quat_mul(a, b):
+    """Gohlke quaternion_multiply(a, b), batched (w, x, y, z)."""
+    w1, x1, y1, z1 = a.unbind(-1); w0, x0, y0, z0 = b.unbind(-1)
+    return torch.stack([-x1 * x0 - y1 * y0 - z1 * z0 + w1 * w0, x1 * w0 + y1 * z0 - z1 * y0 + w1 * x0,
+                        -x1 * z0 + y1 * w0 + z1 * x0 + w1 * y0, x1 * y0 - y1 * x0 + z1 * w0 + w1 * z0], -1)
+
+
+def quat_inv(q):
+    return torch.cat([q[..., :1], -q[..., 1:]], -1) / (q * q).sum(-1, keepdim=True)
+
+
+def heading_q(q):
+    h = torch.zeros_like(q); h[..., 0] = q[..., 0]; h[..., 3] = q[..., 3]
+    return h / h.norm(dim=-1, keepdim=True)
+
+
+def quat_rotate_t(q, v):
+    """transform_vec_batch(v, q, 'root'): R(q)^T v with R normalised by |q|^2."""
+    qn = q / q.norm(dim=-1, keepdim=True)
+    qc = torch.cat([qn[..., :1], -qn[..., 1:]], -1)
+    u = qc[..., 1:]
+    t = 2.0 * torch.cross(u, v, dim=-1)
+    return v + qc[..., :1] * t + torch.cross(u, t, dim=-1)
+
+
+def get_qvel_fd_batch(cur_qpos, next_qpos, dt):
+    """kin_poly/utils/torch_utils.py:315-331 (transform=None)."""
+    v = (next_qpos[:, :3] - cur_qpos[:, :3]) / dt
+    qrel = quat_mul(next_qpos[:, 3:7], quat_inv(cur_qpos[:, 3:7]))
+    w = qrel[:, 0].clamp(-1.0, 1.0)
+    s = torch.sqrt((1 - w * w).clamp_min(0.0))                  # sin(acos(w)); rotation_from_quaternion_batch (:109-130)
+    small = s < 1e-5
+    s = s.clamp_min(1e-30)
+    axis = torch.where(small[:, None], torch.tensor([1.0, 0.0, 0.0], device=w.device, dtype=w.dtype).expand_as(qrel[:, 1:]), qrel[:, 1:] / s[:, None])
+    angle = torch.where(small, torch.zeros_like(w), 2 * torch.acos(w))
+    angle = torch.where(angle > math.pi, angle - 2 * math.pi, angle)
+    angle = torch.where(angle < -math.pi, angle + 2 * math.pi, angle)
+    rv = quat_rotate_t(cur_qpos[:, 3:7], axis * angle[:, None] / dt)
+    return torch.cat([v, rv, (next_qpos[:, 7:] - cur_qpos[:, 7:]) / dt], 1)
+
+
+def gaussian_filter1d_time(x, sigma=1.0, truncate=4.0):
+    """scipy.ndimage.gaussian_filter1d(x, sigma, axis=time) with its default 'reflect' boundary, for x [N, T, C]."""
+    r = int(truncate * sigma + 0.5)
+    k = torch.arange(-r, r + 1, device=x.device, dtype=x.dtype)
+    w = torch.exp(-0.5 * (k / sigma) ** 2); w = w / w.sum()
+    T = x.shape[1]
+    idx = torch.arange(-r, T + r, device=x.device)
+    period = 2 * T
+    idx = idx % period
+    idx = torch.where(idx >= T, period - 1 - idx, idx)          # half-sample symmetric extension (d c b a | a b c d | d c b a)
+    xp = x[:, idx]                                              # [N, T + 2r, C]
+    return sum(w[j] * xp[:, j:j + T] for j in range(2 * r + 1))
+
+
+class TrajARNet(KinPolicy):
+    """KinPolicy (the per-step part) + the context network of TrajARNet."""
+
+    def __init__(self, state_dim=105, action_dim=80, context_dim=17, rnn_hdim=1024, mlp_hsize=(1024, 512, 256), htype="relu", log_std=-3.2):
+        super().__init__(state_dim, action_dim, rnn_hdim, mlp_hsize, htype, log_std)
+        self.context_dim, self.init_dim = context_dim, action_dim + 75
+        self.context_rnn = _StepRNN(context_dim, rnn_hdim)
+        self.context_mlp = MLP(rnn_hdim, mlp_hsize, htype)
+        self.context_fc = nn.Linear(mlp_hsize[-1], self.init_dim)
+
+    def get_context_feat(self, data):
+        """get_context_feat (:138-167): GRU over [obj_head_relative_poses, head_vels, action_one_hot] -> [N, T, rnn_hdim]."""
+        one_hot = data["action_one_hot"]
+        T = data["head_vels"].shape[1]
+        if one_hot.dim() == 2:
+            one_hot = one_hot[:, None].expand(-1, T, -1)
+        feat = torch.cat([data["obj_head_relative_poses"], data["head_vels"], one_hot], 2)
+        hx = torch.zeros((feat.shape[0], self.rnn_hdim), device=feat.device, dtype=feat.dtype)
+        outs = []
+        for t in range(T):
+            hx = self.context_rnn.rnn_f(feat[:, t], hx)
+            outs.append(hx)
+        return torch.stack(outs, 1)
+
+    def init_states(self, data):
+        """init_states (:180-201) + init_pred_qpos (:169-178): -> (init_qpos [N,76], init_qvel [N,75], context_feat_rnn)."""
+        ctx = self.get_context_feat(data)
+        init = self.context_fc(self.context_mlp(ctx.mean(1)))
+        pred, vel = init[:, :self.action_dim], init[:, self.action_dim:]
+        q0 = data["qpos"][:, 0]
+        pred_qpos = torch.cat([q0[:, :2], pred[:, :74]], 1)
+        root = quat_mul(heading_q(q0[:, 3:7]), pred_qpos[:, 3:7])
+        pred_qpos = torch.cat([pred_qpos[:, :3], root / root.norm(dim=1, keepdim=True), pred_qpos[:, 7:]], 1)
+        return pred_qpos, vel, ctx
+
+    @torch.no_grad()
+    def rollout(self, data, kin_sim: kpsim.KpSim, init_qpos, init_qvel, dt=1.0 / 30.0):
+        """TrajARNet.forward (:346-383) in test mode: kinematic roll-out of the whole clip.
+        Returns ar_qpos [N,T,76], ar_qvel [N,T,75] (after fix_qvel), action [N,T,80]."""
+        N, T = data["qpos"].shape[:2]
+        dev = init_qpos.device
+        one_hot = data["action_one_hot"] if data["action_one_hot"].dim() == 2 else data["action_one_hot"][:, 0]
+        cur_t = torch.zeros(N, dtype=torch.int32, device=dev)
+        z96 = torch.zeros((N, T, 96), device=dev); z72 = torch.zeros((N, T, 72), device=dev)
+        obj = torch.empty((N, 7), device=dev)
+        ctx = kin_sim.make_ctx(T, data["head_pose"].contiguous(), data["head_vels"].contiguous(), data["obj_head_relative_poses"].contiguous(),
+                               one_hot.contiguous(), z96, z72, cur_t, obj_qpos=obj)
+        qpos, qvel = init_qpos.contiguous().clone(), init_qvel.contiguous().clone()
+        hx = self.init_hidden(N, dev)
+        Q, V, A = [], [], []
+        for t in range(T):
+            cur_t.fill_(t)
+            obj.copy_(data["obj_pose"][:, t, :7])
+            kin_sim.set_state(qpos, qvel)                      # forward kinematics of the kinematic state
+            state = kin_sim.obs_ar(ctx)
+            Q.append(qpos.clone()); V.append(qvel.clone())
+            action, hx = self.get_action(state, hx)
+            A.append(action)
+            if t == T - 1:
+                break
+            nxt = kin_sim.step_kin(action.contiguous())
+            nxt[:, 3:7] = nxt[:, 3:7] / nxt[:, 3:7].norm(dim=1, keepdim=True)   # TrajARNet.step normalises (:323-327)
+            qvel = get_qvel_fd_batch(qpos, nxt, dt).contiguous()
+            qpos = nxt.contiguous()
+        Q, V, A = torch.stack(Q, 1), torch.stack(V, 1), torch.stack(A, 1)
+        V = torch.cat([V[:, 1:], V[:, -2:-1]], 1)              # fix_qvel (:385-388)
+        return Q, V, A
+
+
+class PolicyARContext:
+    """`PolicyAR.init_context` for N episodes at once -> the `ar_context` tensors the env consumes."""
+
+    def __init__(self, net: TrajARNet, kin_sim: kpsim.KpSim, smooth: bool = True):
+        self.net, self.kin_sim, self.smooth = net, kin_sim, smooth
+
+    @torch.no_grad()
+    def init_context(self, data: dict, fix_height: bool = False) -> dict:
+        out = dict(data)
+        init_qpos, init_qvel, ctx_feat = self.net.init_states(data)
+        out["init_qpos"], out["init_qvel"], out["context_feat_rnn"] = init_qpos.contiguous(), init_qvel.contiguous(), ctx_feat
+        ar_qpos, ar_qvel, _ = self.net.rollout(data, self.kin_sim, init_qpos, init_qvel)
+        begin_feet_offset = 0.01
+        N, T = ar_qpos.shape[:2]
+        if self.smooth:
+            if fix_height:
+                fk = self.kin_sim.fk(out["init_qpos"])
+                feet = torch.minimum(fk["wbpos"].view(N, 24, 3)[:, 4, 2], fk["wbpos"].view(N, 24, 3)[:, 8, 2]) - begin_feet_offset
+                out["init_qpos"] = torch.cat([out["init_qpos"][:, :2], (out["init_qpos"][:, 2] - feet)[:, None], out["init_qpos"][:, 3:]], 1).contiguous()
+            ar_qpos = torch.cat([ar_qpos[:, :, :7], gaussian_filter1d_time(ar_qpos[:, :, 7:], 1.0)], 2)
+            if fix_height:
+                fk = self.kin_sim.fk(ar_qpos.reshape(-1, 76).contiguous())
+                wb = fk["wbpos"].view(N, T, 24, 3)
+                feet = torch.minimum(wb[:, 0, 4, 2], wb[:, 0, 8, 2]) - begin_feet_offset   # first frame of each clip (:157-158)
+                ar_qpos = torch.cat([ar_qpos[:, :, :2], ar_qpos[:, :, 2:3] - feet[:, None, None], ar_qpos[:, :, 3:]], 2)
+        fk = self.kin_sim.fk(ar_qpos.reshape(-1, 76).contiguous())
+        out["ar_qpos"], out["ar_qvel"] = ar_qpos, ar_qvel
+        out["ar_wbpos"], out["ar_wbquat"], out["ar_bquat"] = fk["wbpos"].view(N, T, 72), fk["wbquat"].view(N, T, 96), fk["bquat"].view(N, T, 96)
+        return out

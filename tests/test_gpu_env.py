@@ -150,3 +150,29 @@ def test_env_with_step_object():
     assert dg[:, 2].max() == 0
     z = env.sim.get("qpos")[:, 2].cpu().numpy()
     assert z[0] > z[2] + 0.002        # env 0 stands on the raised box, env 2 (no object) on the floor
+
+
+def test_context_rollout_matches_reference_fixture(golden):
+    """Batched PolicyAR.init_context: kinematic roll-out of TrajARNet on the HIP kernels vs the reference's own
+    TrajARNet.forward output (tests/golden/traj_ar_net.npz)."""
+    from kinpoly_amd import sim as kpsim
+    from kinpoly_amd.context import PolicyARContext
+    from tests.test_context_cpu import _data, _net_from_fixture
+    g = golden("traj_ar_net")
+    net = _net_from_fixture(g, torch.float32).cuda()
+    data = _data(g, torch.float32, "cuda")
+    B, T = data["qpos"].shape[:2]
+    kin_sim = kpsim.KpSim(kpsim.KpModel(), B)
+    with torch.no_grad():
+        init_qpos, init_qvel, _ = net.init_states(data)
+    np.testing.assert_allclose(init_qpos.double().cpu().numpy(), g["init_qpos"], atol=2e-5)
+    q, v, a = net.rollout(data, kin_sim, init_qpos, init_qvel)
+    np.testing.assert_allclose(a.double().cpu().numpy(), g["action"], atol=5e-4)
+    np.testing.assert_allclose(q.double().cpu().numpy(), g["ar_qpos"], atol=5e-4)
+    np.testing.assert_allclose(v.double().cpu().numpy(), g["ar_qvel"], atol=2e-2)
+    ctx = PolicyARContext(net, kin_sim, smooth=True).init_context(data)
+    assert ctx["ar_qpos"].shape == (B, T, 76) and ctx["ar_wbpos"].shape == (B, T, 72) and torch.isfinite(ctx["ar_bquat"]).all()
+    from scipy.ndimage import gaussian_filter1d
+    want = gaussian_filter1d(g["ar_qpos"][:, :, 7:], 1, axis=1)
+    np.testing.assert_allclose(ctx["ar_qpos"][:, :, 7:].double().cpu().numpy(), want, atol=5e-4)
+    np.testing.assert_allclose(ctx["ar_qpos"][:, :, :7].double().cpu().numpy(), g["ar_qpos"][:, :, :7], atol=5e-4)

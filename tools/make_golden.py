@@ -319,7 +319,45 @@ def gen_policies():
              mcp_keys=np.array(list(pol.state_dict().keys())), value_keys=np.array(list(val.state_dict().keys())))
 
 
-if __name__ == "__main__":
+def gen_traj_ar_net(hum):
+    """TrajARNet.init_states / forward (kin_poly/models/traj_ar_smpl_net.py:180-201, 346-383): context GRU -> init state,
+    then the full kinematic roll-out of a short clip with seeded weights (weights are regenerated from the seed in the test)."""
+    import kin_poly.models.traj_ar_smpl_net as tn
+    import kin_poly.utils.torch_smpl_humanoid as tsh
+    tsh.load_model_from_path = lambda f: fake_mj_model()
+    cfg = types.SimpleNamespace(model_specs=dict(model_v=1, rnn_hdim=1024, mlp_hsize=[1024, 512, 256], mlp_htype="relu", rnn_type="gru"),
+                                mujoco_model_file="unused.xml", use_of=False, use_head=True, use_action=True, use_vel=False, use_context=False,
+                                add_noise=False, noise_std=0.01, has_z=True, data_dir=os.path.join(REF, "sample_data"))
+    rng = np.random.default_rng(106)
+    B, T = 3, 5
+    qpos = np.stack([[rand_qpos(rng, 0.15) for _ in range(T)] for _ in range(B)])
+    data = dict(qpos=qpos, qvel=rng.normal(size=(B, T, 75)) * 0.1, target=rng.normal(size=(B, T, 80)) * 0.1,
+                head_pose=np.concatenate([rng.normal(size=(B, T, 3)), np.stack([[rand_quat(rng) for _ in range(T)] for _ in range(B)])], 2),
+                head_vels=rng.normal(size=(B, T, 6)) * 0.3, obj_head_relative_poses=rng.normal(size=(B, T, 7)) * 0.3,
+                obj_pose=np.tile(np.array([0.3, 0.2, 0.1, 1.0, 0, 0, 0]), (B, T, 1)), action_one_hot=np.tile(np.array([0, 0, 1.0, 0]), (B, T, 1)))
+    data_t = {k: torch.tensor(v) for k, v in data.items()}
+    net = tn.TrajARNet(cfg, data_sample=data_t, device=torch.device("cpu"), dtype=torch.float64, mode="test", as_policy=True)
+    sd = seeded_state_dict(net, 9)
+    # small output layers keep the roll-out in a sane pose range
+    for k in sd:
+        if k.startswith(("action_fc", "context_fc")):
+            sd[k] = sd[k] * 0.05
+    net.load_state_dict(sd)
+    net.set_schedule_sampling(0.0)
+    with torch.no_grad():
+        d1 = net.init_states({k: v.clone() for k, v in data_t.items()})
+        init_qpos, init_qvel, ctx_feat = d1["init_qpos"].numpy(), d1["init_qvel"].numpy(), d1["context_feat_rnn"].numpy()
+        fp = net.forward({k: v.clone() for k, v in data_t.items()})
+    np.savez(os.path.join(OUT, "traj_ar_net.npz"), seed=9, keys=np.array(list(net.state_dict().keys())),
+             shapes=np.array([list(v.shape) + [0] * (2 - v.dim()) for v in net.state_dict().values()]),
+             **{"in_" + k: v for k, v in data.items()}, init_qpos=init_qpos, init_qvel=init_qvel, context_feat_rnn=ctx_feat,
+             ar_qpos=fp["qpos"].numpy(), ar_qvel=fp["qvel"].numpy(), action=fp["action"].numpy(), state_dim=net.state_dim, context_dim=net.context_dim)
+    from scipy.ndimage import gaussian_filter1d
+    x = rng.normal(size=(12, 69))
+    np.savez(os.path.join(OUT, "smooth.npz"), x=x, y=gaussian_filter1d(x, 1, axis=0))
+
+
+if __name__ == "__main__" and os.environ.get("KP_GOLDEN_ONLY") is None:
     np.savez(os.path.join(OUT, "standing_neutral.npz"), **{k: v for k, v in
              __import__("joblib").load(os.path.join(REF, "sample_data/standing_neutral.pkl")).items() if k in ("qpos", "qvel")})
     hum = make_humanoid()
@@ -329,5 +367,11 @@ if __name__ == "__main__":
     gen_ar_obs_reward(hum)
     gen_gae_zfilter()
     gen_policies()
+    gen_traj_ar_net(hum)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__" and os.environ.get("KP_GOLDEN_ONLY") == "traj":
+    gen_traj_ar_net(make_humanoid())
+    print("traj_ar_net.npz", os.path.getsize(os.path.join(OUT, "traj_ar_net.npz")))
