@@ -1,0 +1,91 @@
+"""Supervised one-step update of the kinematic policy (`step_update: true`, config/statear/kin_poly.yml:65,70):
+PolicyAR.update_supervised_step (kin_poly/models/policy_ar.py:277-287) = policy forward -> kinematic step from the
+recorded sim pose -> TrajARNet.compute_loss_lite against the GT next pose (traj_ar_smpl_net.py:459-497).
+
+Everything here is differentiable torch on the device (autograd through the kinematic step and the forward
+kinematics); the roll-out itself uses the HIP kernels, this runs only in the optimiser step.
+"""
+from __future__ import annotations
+
+import torch
+
+from .context import heading_q, quat_inv, quat_mul
+
+
+def _qmat(q):
+    """quaternion_matrix_batch: rotation matrix of q / |q| -> [..., 3, 3]."""
+    q = q / q.norm(dim=-1, keepdim=True)
+    w, x, y, z = q.unbind(-1)
+    return torch.stack([torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], -1),
+                        torch.stack([2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)], -1),
+                        torch.stack([2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], -1)], -2)
+
+
+def quat_from_expmap(e):
+    """quat_from_expmap_batch (kin_poly/utils/torch_utils.py:239-248)."""
+    angle = e.norm(dim=1)
+    safe = angle.clamp_min(1e-8)
+    axis = torch.where((angle < 1e-8)[:, None], torch.tensor([1.0, 0.0, 0.0], device=e.device, dtype=e.dtype).expand_as(e), e / safe[:, None])
+    return torch.cat([torch.cos(angle / 2)[:, None], axis * torch.sin(angle / 2)[:, None]], 1)
+
+
+def kinematic_step(curr_qpos, action, dt=1.0 / 30.0):
+    """TrajARNet.step (traj_ar_smpl_net.py:292-330), has_z, no pose_delta: -> next_qpos [B,76] (root quat normalised)."""
+    rot = curr_qpos[:, 3:7]
+    linv = (_qmat(heading_q(rot)) @ action[:, 74:77, None])[..., 0]
+    angv = (_qmat(rot) @ action[:, 77:80, None])[..., 0]
+    new_rot = quat_mul(quat_from_expmap(angv * dt), rot)
+    new_rot = new_rot / new_rot.norm(dim=1, keepdim=True)
+    return torch.cat([curr_qpos[:, :2] + linv[:, :2] * dt, action[:, :1], new_rot, action[:, 5:74]], 1)
+
+
+class TorchFK:
+    """Differentiable Humanoid.qpos_fk (kin_poly/utils/torch_smpl_humanoid.py:125-202): world joint positions [B,24,3]."""
+
+    def __init__(self, body_pos, body_parent, device, dtype=torch.float32):
+        self.offsets = torch.as_tensor(body_pos, dtype=dtype, device=device).view(24, 3)
+        self.parents = [int(p) for p in body_parent]
+
+    def wbpos(self, qpos):
+        B = qpos.shape[0]
+        root_q = qpos[:, 3:7] / qpos[:, 3:7].norm(dim=1, keepdim=True)
+        ang = qpos[:, 7:].view(B, 23, 3) * 0.5
+        s, c = torch.sin(ang), torch.cos(ang)
+        z = torch.zeros_like(c[..., 0])
+        qz = torch.stack([c[..., 0], z, z, s[..., 0]], -1); qy = torch.stack([c[..., 1], z, s[..., 1], z], -1); qx = torch.stack([c[..., 2], s[..., 2], z, z], -1)
+        local = quat_mul(quat_mul(qz, qy), qx)                       # 'rzyx'
+        pos, quat = [qpos[:, :3]], [root_q]
+        for i in range(1, 24):
+            p = self.parents[i]
+            pos.append((_qmat(quat[p]) @ self.offsets[i].expand(B, 3)[..., None])[..., 0] + pos[p])
+            quat.append(quat_mul(quat[p], local[:, i - 1]))
+        return torch.stack(pos, 1)
+
+
+def compute_loss_lite(fk: TorchFK, pred_qpos, gt_qpos, w_rp=50.0, w_rr=50.0, w_p=1.0, w_ee=10.0):
+    """TrajARNet.compute_loss_lite with kin_poly.yml weights (model_specs: w_rp 50, w_rr 50, w_p 1, w_ee 10)."""
+    r_pos = (gt_qpos[:, :3] - pred_qpos[:, :3]).pow(2).sum(1)
+    dist = quat_mul(gt_qpos[:, 3:7], quat_inv(pred_qpos[:, 3:7]))
+    iden = torch.tensor([1.0, 0.0, 0.0, 0.0], device=dist.device, dtype=dist.dtype)
+    r_rot = (dist.abs() - iden).pow(2).sum(1)
+    p_rot = (gt_qpos[:, 7:] - pred_qpos[:, 7:]).pow(2).sum(1)
+    ee = (fk.wbpos(gt_qpos) - fk.wbpos(pred_qpos)).reshape(pred_qpos.shape[0], -1).pow(2).sum(1)
+    loss = w_rp * r_pos.mean() + w_rr * r_rot.mean() + w_p * p_rot.mean() + w_ee * ee.mean()
+    return loss, [r_pos.mean(), r_rot.mean(), p_rot.mean(), ee.mean()]
+
+
+def update_supervised_step(policy, optimizer, fk: TorchFK, batch, num_epoch=20, grad_allreduce=None):
+    """batch: RolloutBatch with curr_qpos / gt_target_qpos recorded by VectorSampler(record_qpos=True)."""
+    N, T, _ = batch.states.shape
+    curr, tgt = batch.curr_qpos.reshape(N * T, 76), batch.gt_target_qpos.reshape(N * T, 76)
+    loss_val = None
+    for _ in range(num_epoch):
+        means = policy.unroll(batch.states, batch.episode_start).reshape(N * T, -1)
+        loss, _ = compute_loss_lite(fk, kinematic_step(curr, means), tgt)
+        optimizer.zero_grad()
+        loss.backward()
+        if grad_allreduce is not None:
+            grad_allreduce([p for p in policy.parameters() if p.requires_grad])
+        optimizer.step()
+        loss_val = float(loss.detach())
+    return loss_val

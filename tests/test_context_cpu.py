@@ -49,3 +49,52 @@ def test_qvel_fd_consistent_with_fixture_rollout(golden):
     for t in range(q.shape[1] - 1):
         v = get_qvel_fd_batch(q[:, t], q[:, t + 1], 1 / 30)
         np.testing.assert_allclose(v.numpy(), g["ar_qvel"][:, t], rtol=1e-8, atol=1e-9)
+
+
+def test_kinematic_step_and_loss_lite_match_reference(golden):
+    """differentiable TrajARNet.step + compute_loss_lite (kinpoly_amd/supervised.py) vs the reference's outputs."""
+    from kinpoly_amd.model_compiler import DEFAULT_KPM, read_kpm
+    from kinpoly_amd.supervised import TorchFK, compute_loss_lite, kinematic_step
+    g = golden("step_loss")
+    kpm = read_kpm(DEFAULT_KPM)
+    fk = TorchFK(kpm["body_pos"], kpm["body_parent"], "cpu", torch.float64)
+    cur, act, gt = (torch.tensor(g[k]) for k in ("cur", "act", "gt"))
+    act.requires_grad_(True)
+    nxt = kinematic_step(cur, act)
+    np.testing.assert_allclose(nxt.detach().numpy(), g["next_qpos"], rtol=0, atol=2e-8)   # the reference's batch expmap differs by 7e-9
+    loss, idv = compute_loss_lite(fk, nxt, gt)
+    np.testing.assert_allclose(float(loss), float(g["loss"]), rtol=1e-7)
+    np.testing.assert_allclose([float(x) for x in idv], g["loss_idv"], rtol=1e-6)
+    loss.backward()
+    assert torch.isfinite(act.grad).all() and act.grad.abs().sum() > 0
+    # FK agrees with the pinned numpy restatement
+    fkn = O.qpos_fk(g["cur"][0], kpm["body_pos"].reshape(24, 3), kpm["body_ipos"].reshape(24, 3), kpm["body_parent"])
+    np.testing.assert_allclose(fk.wbpos(cur[:1])[0].numpy(), fkn["wbpos"], atol=1e-12)
+
+
+def test_reference_checkpoint_layout_roundtrip(golden, tmp_path):
+    import os
+    from kinpoly_amd import checkpoint as ck
+    from kinpoly_amd.context import TrajARNet
+    from kinpoly_amd.nets import MLP, Value
+    here = os.path.join(os.path.dirname(__file__), "golden")
+    cp = ck.load_checkpoint(os.path.join(here, "ref_checkpoint_small.p"))       # written by the reference's own classes
+    e = golden("ref_checkpoint_small_expect")
+    assert set(cp) == {"policy_dict", "value_dict", "running_state"}
+    mean, std, clip = ck.running_state_arrays(cp["running_state"])
+    np.testing.assert_allclose(mean, e["mean"]); np.testing.assert_allclose(std, e["std"]); assert clip == 5
+    sd = ck.split_policy_dict(cp["policy_dict"])
+    np.testing.assert_allclose(sd["action_fc.weight"].numpy(), e["w"]); assert "action_log_std" in sd
+    # write our own nets in the reference layout and read them back through the reference-style unpickler
+    net, val = TrajARNet(rnn_hdim=8, mlp_hsize=(8, 8)), Value(MLP(105, (8, 8), "relu"))
+    rs = ck.ZFilter((105,), clip=5.0); rs.rs._n = 3; rs.rs._M[:] = 1.0; rs.rs._S[:] = 8.0
+    ck.save_checkpoint(str(tmp_path / "iter_0001.p"), net, val, rs)
+    raw = open(tmp_path / "iter_0001.p", "rb").read()
+    assert b"uhc.khrylib.utils.zfilter" in raw                                    # class path the reference's CustomUnpickler expects
+    cp2 = ck.load_checkpoint(raw)
+    net2 = TrajARNet(rnn_hdim=8, mlp_hsize=(8, 8))
+    net2.load_state_dict(ck.split_policy_dict(cp2["policy_dict"]))
+    for a, b in zip(net.state_dict().values(), net2.state_dict().values()):
+        assert torch.equal(a, b)
+    assert all(k.startswith("traj_ar_net.") or k == "action_log_std" for k in cp2["policy_dict"])
+    np.testing.assert_allclose(ck.running_state_arrays(cp2["running_state"])[1], 2.0)

@@ -118,6 +118,17 @@ def test_sampler_autoreset_and_ppo_update():
     stats = tr.update(batch)
     assert np.isfinite(stats["value_loss"]) and np.isfinite(stats["surr_loss"])
     assert any((a - b).abs().max() > 0 for a, b in zip(before, [p for p in policy.parameters() if p.requires_grad]))
+    # supervised one-step update (step_update: true): the kinematic one-step loss goes down
+    from kinpoly_amd.supervised import TorchFK, compute_loss_lite, kinematic_step, update_supervised_step
+    fk = TorchFK(KPM["body_pos"], KPM["body_parent"], env.device)
+    opt = torch.optim.Adam([p for p in policy.parameters() if p.requires_grad], lr=5e-4)
+    def cur_loss():
+        with torch.no_grad():
+            m = policy.unroll(batch.states, batch.episode_start).reshape(n * T, -1)
+            return float(compute_loss_lite(fk, kinematic_step(batch.curr_qpos.reshape(n * T, 76), m), batch.gt_target_qpos.reshape(n * T, 76))[0])
+    l0 = cur_loss()
+    update_supervised_step(policy, opt, fk, batch, num_epoch=5)
+    assert cur_loss() < l0
 
 
 def test_env_with_step_object():

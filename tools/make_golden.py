@@ -357,6 +357,44 @@ def gen_traj_ar_net(hum):
     np.savez(os.path.join(OUT, "smooth.npz"), x=x, y=gaussian_filter1d(x, 1, axis=0))
 
 
+def gen_loss_and_checkpoint(hum):
+    """TrajARNet.step + compute_loss_lite (traj_ar_smpl_net.py:292-330, 459-497) on seeded poses, and a small pickle in
+    the reference's checkpoint layout written with the reference's own ZFilter class (agent_ar.py:341-364)."""
+    import pickle
+    import kin_poly.models.traj_ar_smpl_net as tn
+    import kin_poly.utils.torch_smpl_humanoid as tsh
+    tsh.load_model_from_path = lambda f: fake_mj_model()
+    cfg = types.SimpleNamespace(model_specs=dict(model_v=1, rnn_hdim=8, mlp_hsize=[8, 8], mlp_htype="relu", rnn_type="gru", w_rp=50.0, w_rr=50.0, w_p=1.0, w_ee=10.0),
+                                mujoco_model_file="unused.xml", use_of=False, use_head=True, use_action=True, use_vel=False, use_context=False,
+                                add_noise=False, noise_std=0.01, has_z=True, data_dir=os.path.join(REF, "sample_data"))
+    rng = np.random.default_rng(107)
+    B = 6
+    cur = np.stack([rand_qpos(rng, 0.2) for _ in range(B)]); gt = np.stack([rand_qpos(rng, 0.2) for _ in range(B)])
+    act = rng.normal(size=(B, 80)) * 0.3; act[:, 1:5] = np.stack([rand_quat(rng) for _ in range(B)])
+    data_t = dict(qpos=torch.tensor(cur)[:, None], qvel=torch.zeros(B, 1, 75), target=torch.zeros(B, 1, 80), head_pose=torch.zeros(B, 1, 7),
+                  head_vels=torch.zeros(B, 1, 6), obj_head_relative_poses=torch.zeros(B, 1, 7), obj_pose=torch.zeros(B, 1, 7), action_one_hot=torch.zeros(B, 1, 4))
+    data_t["head_pose"][:, :, 3] = 1; data_t["obj_pose"][:, :, 3] = 1
+    net = tn.TrajARNet(cfg, data_sample=data_t, device=torch.device("cpu"), dtype=torch.float64, mode="test", as_policy=True)
+    with torch.no_grad():
+        net.set_sim(torch.tensor(cur))
+        nxt, nqvel = net.step(torch.tensor(act))
+        loss, idv = net.compute_loss_lite(nxt, torch.tensor(gt))
+    np.savez(os.path.join(OUT, "step_loss.npz"), cur=cur, gt=gt, act=act, next_qpos=nxt.numpy(), next_qvel=nqvel.numpy(), loss=loss.item(), loss_idv=np.array(idv))
+    zf = ZFilter((5,), clip=5)
+    for x in rng.normal(size=(20, 5)):
+        zf(x)
+    cp = {"policy_dict": {"traj_ar_net.action_fc.weight": torch.tensor(rng.normal(size=(2, 3))), "action_log_std": torch.ones(1, 2) * -3.2},
+          "value_dict": {"value_head.bias": torch.zeros(1)}, "running_state": zf}
+    with open(os.path.join(OUT, "ref_checkpoint_small.p"), "wb") as f:
+        pickle.dump(cp, f)
+    np.savez(os.path.join(OUT, "ref_checkpoint_small_expect.npz"), mean=zf.rs.mean, std=zf.rs.std, w=cp["policy_dict"]["traj_ar_net.action_fc.weight"].numpy())
+
+
+if __name__ == "__main__" and os.environ.get("KP_GOLDEN_ONLY") == "loss":
+    gen_loss_and_checkpoint(make_humanoid())
+    print("step_loss.npz ok")
+
+
 if __name__ == "__main__" and os.environ.get("KP_GOLDEN_ONLY") is None:
     np.savez(os.path.join(OUT, "standing_neutral.npz"), **{k: v for k, v in
              __import__("joblib").load(os.path.join(REF, "sample_data/standing_neutral.pkl")).items() if k in ("qpos", "qvel")})
@@ -368,6 +406,7 @@ if __name__ == "__main__" and os.environ.get("KP_GOLDEN_ONLY") is None:
     gen_gae_zfilter()
     gen_policies()
     gen_traj_ar_net(hum)
+    gen_loss_and_checkpoint(hum)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
