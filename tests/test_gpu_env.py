@@ -187,3 +187,32 @@ def test_context_rollout_matches_reference_fixture(golden):
     want = gaussian_filter1d(g["ar_qpos"][:, :, 7:], 1, axis=1)
     np.testing.assert_allclose(ctx["ar_qpos"][:, :, 7:].double().cpu().numpy(), want, atol=5e-4)
     np.testing.assert_allclose(ctx["ar_qpos"][:, :, :7].double().cpu().numpy(), g["ar_qpos"][:, :, :7], atol=5e-4)
+
+
+def test_agent_ar_iteration_and_checkpoint(tmp_path):
+    """AgentAR.optimize_policy (sample + PPO + supervised step update + re-initialised contexts) runs two iterations
+    on the batched engine, and its checkpoint round-trips through the reference pickle layout."""
+    from kinpoly_amd import sim as kpsim
+    from kinpoly_amd.agent import AgentAR
+    from kinpoly_amd.env import standing_context
+    n, T = 64, 9
+    fk_sim = kpsim.KpSim(kpsim.KpModel(), n, 0)
+
+    def context_fn(m):
+        ctx = standing_context(m, T, STD["qpos"], STD["qvel"], fk_sim, torch.zeros(m))
+        ctx["obj_pose"] = torch.tensor([0.0, 0, 0, 1, 0, 0, 0], device=ctx["qpos"].device).repeat(m, T, 1)
+        return ctx
+
+    agent = AgentAR(n, context_fn, device=0, horizon=8, num_optim_epoch=2, num_step_update=2, use_init_context=True)
+    infos = [agent.optimize_policy(i) for i in range(2)]
+    for info in infos:
+        assert info["num_steps"] == n * 8 and np.isfinite(info["step_loss"]) and np.isfinite(info["value_loss"])
+    path = str(tmp_path / "iter_0002.p")
+    agent.save_checkpoint(path)
+    before = {k: v.clone() for k, v in agent.policy_net.state_dict().items()}
+    with torch.no_grad():
+        for p in agent.policy_net.parameters():
+            p.add_(1.0)
+    agent.load_checkpoint(path)
+    for k, v in agent.policy_net.state_dict().items():
+        assert torch.equal(v, before[k]), k
