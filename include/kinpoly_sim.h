@@ -62,9 +62,11 @@ int kp_sim_set_state(kp_sim*, const float* qpos, const float* qvel, const uint8_
 int kp_sim_set_target(kp_sim*, const float* target_qpos, const uint8_t* env_mask);
 
 /* object block of set_state: obj_qpos [N,35] = data.qpos[76:111] as reset_model builds it with convert_obj_qpos
- * (humanoid_ar_v1.py:377-381, 479-496: inactive objects parked at [(i+1)*100, 100, 0]).  Objects within 50 m of the
- * origin become collision geometry for the humanoid hulls (chair, box, table, Can, step: boxes / cylinders of the XML,
- * :190-214).  THIS ROUND the objects are static obstacles: their own dynamics (pushable box) is not integrated. */
+ * (humanoid_ar_v1.py:377-381, 479-496: inactive objects parked at [(i+1)*100, 100, 0]), object velocities zero (:382).
+ * Objects within 50 m of the origin (at most two: push = box + table) become free rigid bodies of the env: their
+ * boxes / cylinders (XML :190-214) collide with the humanoid hulls, the floor and each other, and they are integrated
+ * by the same soft-constraint solve as the humanoid.  Model option "dynamic_objects" = 0 freezes them as static obstacles.
+ * Parked objects are not simulated (in the reference they only bounce on the floor 100 m away). */
 int kp_sim_set_objects(kp_sim*, const float* obj_qpos, const uint8_t* env_mask);
 
 /* Humanoid.qpos_fk_batch(qpos) (numpy_smpl_humanoid.py:124-178) on n_rows arbitrary rows, used by
@@ -144,7 +146,8 @@ typedef enum {
     KP_QVEL_D = 13,
     KP_PREV_BQUAT = 14, /* env.prev_bquat                    [N,96] */
     KP_PREV_HPOS = 15,  /* env.prev_hpos                     [N,7]  */
-    KP_OBJ_QPOS = 16    /* get_obj_qpos() = data.qpos[76:111] [N,35] */
+    KP_OBJ_QPOS = 16,   /* get_obj_qpos() = data.qpos[76:111] [N,35]  (simulated poses of the active objects) */
+    KP_OBJ_QVEL = 17    /* get_obj_qvel() = data.qvel[75:105] [N,30] */
 } kp_field;
 int kp_field_dim(int field);
 int kp_sim_get(kp_sim*, int field, float* out);

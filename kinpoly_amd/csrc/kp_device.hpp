@@ -26,6 +26,11 @@ struct DevTables {
     const int8_t *body_parent;
     const uint8_t *body_depth, *body_subtree, *lev_start, *lev_body, *jnt_limited;
     const uint32_t *sched8;   // [64][9] static tree schedule of the 8-lanes-per-body passes (see Lane8)
+    // free objects of the scene (chair, box, table, Can, step): [n_obj][13] mass, com[3], inertia[6], invweight (tran, rot),
+    // armature; body-frame geoms [n_obj_geoms][18] = object, type, size[3], pos[3], mat[9], mass; geom range per object
+    const float *obj_inertial, *obj_geoms;
+    const int *obj_geom_adr;
+    int n_obj;
 };
 
 struct Params {
@@ -46,7 +51,7 @@ struct __attribute__((aligned(16))) EnvLds {
     float xpos[72], xquat[96], xipos[72];
     float cinert[240];                    // body spatial inertia about o, world axes (10 floats / body)
     float cdof[450];                      // motion axis of every dof [ang; lin] about o
-    float sv[144], sa[144], sw[144];      // per-body spatial scratch (velocity / acceleration / wrench)
+    float sv[156], sa[144], sw[144];      // per-body spatial scratch (velocity / acceleration / wrench); sv[144..155]: the two object slots
     float U[450], Dinv[76], uj[76];       // articulated-body pass: U_j = IA s_j, 1/D_j, u_j
     float IAa[25 * 22], pAa[25 * 6];      // articulated inertia / bias force handed to the parent; slot 21 of a record and
                                           // record 24 are kept 0 so that padded / absent operands load a zero without exec masking
@@ -56,7 +61,7 @@ struct __attribute__((aligned(16))) EnvLds {
     float applied[8];
     float con_pos[D_MAXCON * 3], con_dist[D_MAXCON], con_D[D_MAXCON];
     int con_body[D_MAXCON];
-    int con_start[D_NB + 1];
+    int con_start[D_NB + 3];              // contacts are grouped by the entity carrying the vertex: 24 hulls, then the object slots
     float jar3[D_MAXCON * 3], jv3[D_MAXCON * 3];   // contact-frame (normal, t1, t2) residuals J qacc - aref and J search
     float lim_sgn[72], lim_aref[72], lim_D[72], lim_jar[72], lim_jv[72];
     float red[8];
@@ -66,11 +71,24 @@ struct __attribute__((aligned(16))) EnvLds {
 
 // extension used only by the kernel instantiation that simulates object contact (kp_step_kernel<NT, true>)
 constexpr int D_MAXGEOM = 8;            // must equal MAXGEOM in oracle/kp_oracle.c
+constexpr int D_MAXOBJ = 2;             // must equal MAXOBJ in oracle/kp_oracle.c
+constexpr int D_OBJ_CON_PER_GEOM = 4;   // must equal OBJ_CON_PER_GEOM
 struct __attribute__((aligned(16))) EnvLdsObj : EnvLds {
-    float con_n[D_MAXCON * 3];          // contact normal (world), pointing from the object / floor into the hull
+    float con_n[D_MAXCON * 3];          // contact normal (world), pointing from the surface (floor / geom) into the vertex' entity
     float con_iw2[D_MAXCON];            // invweight0 of the second body (0 for the floor)
     float geom[D_MAXGEOM * 17];         // type, size[3], pos[3], mat[9], invweight  (world frame)
-    int ngeom;
+    int ngeom, ngeom_static, nobj;
+    // ---- dynamic free objects (slot k = entity 24 + k): spatial quantities about o like everything else
+    signed char gobj[D_MAXGEOM];        // slot owning world geom g (-1: static)
+    signed char con_b2[D_MAXCON];       // entity carrying the surface: -1 world / static geom, 24 + k
+    float lgeom[D_MAXGEOM * 16];        // body-frame geoms of the dynamic objects, aligned with geom[]
+    float oq[D_MAXOBJ * 7], ov[D_MAXOBJ * 6], oc[D_MAXOBJ * 13];
+    float oR[D_MAXOBJ * 9];
+    float oI[D_MAXOBJ * 10], oIe[D_MAXOBJ * 10];   // spatial inertia (true / with the free-joint armature)
+    float ofb[D_MAXOBJ * 6];            // bias wrench
+    float oqa[D_MAXOBJ * 6];            // joint-space acceleration of the last solve (warm start, integration)
+    float oas[D_MAXOBJ * 6], oa[D_MAXOBJ * 6], omres[D_MAXOBJ * 6], osrch[D_MAXOBJ * 6], oMv[D_MAXOBJ * 6], ogr[D_MAXOBJ * 6], ot[D_MAXOBJ * 6];
+    float Sm[6 * D_MAXOBJ * (6 * D_MAXOBJ + 1)];   // dense object system [n][n + 1] (last column: right-hand side)
 };
 
 // ------------------------------------------------------------------ small math

@@ -20,7 +20,7 @@ struct HostModel {
     int nb = 0, nv = 0, nq = 0, nu = 0, nM = 0, nvert = 0;
     std::vector<int> body_parent, body_depth, body_subtree, dof_body, dof_parent, dof_depth, dof_madr, jnt_limited, vert_adr, obj_geom_adr;
     std::vector<double> body_pos, body_ipos, body_mass, body_inertia, body_rbound, body_invweight0, dof_invweight0,
-        dof_armature, jnt_range, verts, kp, kd, torque_lim, a_scale, opt, body_diffw, obj_geoms, obj_mass;
+        dof_armature, jnt_range, verts, kp, kd, torque_lim, a_scale, opt, body_diffw, obj_geoms, obj_mass, obj_inertial;
     std::string error;
 };
 
@@ -64,6 +64,7 @@ inline bool load_kpm(const char* path, HostModel& m) {
     // free objects (optional): [ngeom, 18] = object id, type, size3, local pos3, local R9, mass; adr [nobj + 1]
     if (!kpm_get(buf, "obj_geoms", &m.obj_geoms, nullptr) || !kpm_get(buf, "obj_geom_adr", nullptr, &m.obj_geom_adr) ||
         !kpm_get(buf, "obj_mass", &m.obj_mass, nullptr)) { m.obj_geoms.clear(); m.obj_geom_adr.clear(); m.obj_mass.clear(); }
+    if (!kpm_get(buf, "obj_inertial", &m.obj_inertial, nullptr)) m.obj_inertial.clear();
 #undef KPF
 #undef KPI
     if (m.opt.size() < 25) { m.error = "opt too short"; return false; }
@@ -75,6 +76,6 @@ inline bool load_kpm(const char* path, HostModel& m) {
 // opt[] indices (kinpoly_amd/model_compiler.py OPT_FIELDS)
 enum { OPT_TIMESTEP = 0, OPT_GX, OPT_GY, OPT_GZ, OPT_SOLREF_TC, OPT_SOLREF_DR, OPT_IMP_D0, OPT_IMP_DW, OPT_IMP_W, OPT_IMP_MID,
        OPT_IMP_POW, OPT_FRIC, OPT_FRIC_SPIN, OPT_FRIC_ROLL, OPT_MARGIN, OPT_IMPRATIO, OPT_MEANINERTIA, OPT_RFC_SCALE, OPT_RFC_LIM,
-       OPT_BR_W, OPT_BR_X, OPT_BR_Y, OPT_BR_Z, OPT_SOLVER_ITER, OPT_SOLVER_TOL };
+       OPT_BR_W, OPT_BR_X, OPT_BR_Y, OPT_BR_Z, OPT_SOLVER_ITER, OPT_SOLVER_TOL, OPT_NV_FULL };
 
 }  // namespace kp

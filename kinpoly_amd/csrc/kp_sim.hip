@@ -23,8 +23,8 @@ int fail(const std::string& m) { g_err = m; return -1; }
 
 struct kp_model {
     kp::HostModel h;
-    int contact = 1, limits = 1, stale = 1, solver_iter = 12, threads = 64;
-    double solver_tol = 1e-6, gravity_z = -9.81;
+    int contact = 1, limits = 1, stale = 1, solver_iter = 12, threads = 64, dynamic_objects = 1;
+    double solver_tol = 1e-8, gravity_z = -9.81;   // solver_tol: mjOption.tolerance of the reference model (kp_model_load)
 };
 
 struct kp_sim {
@@ -41,6 +41,8 @@ struct kp_sim {
     int* diag = nullptr;
     unsigned long long* prof = nullptr;
     float *obj_qpos = nullptr, *geoms = nullptr;      // [N,35], [N,8,17]
+    float *obj_qvel = nullptr, *obj_warm = nullptr;   // [N,30], [N,12]
+    signed char* obj_slot = nullptr;                  // [N,2]
     int* ngeom = nullptr;
     const float* d_obj_geoms = nullptr; const float* d_obj_mass = nullptr; int n_obj_geoms = 0, n_obj = 0;
     bool has_objects = false;
@@ -134,6 +136,11 @@ bool build_tables(kp_sim* s) {
             }
     }
     T.sched8 = upload<uint32_t>(s, sched, &ok);
+    T.obj_inertial = nullptr; T.obj_geoms = nullptr; T.obj_geom_adr = nullptr; T.n_obj = 0;
+    if (!m.obj_geoms.empty() && m.obj_inertial.size() == 13 * m.obj_mass.size()) {
+        T.obj_inertial = upload<float>(s, m.obj_inertial, &ok); T.obj_geoms = upload<float>(s, m.obj_geoms, &ok);
+        T.obj_geom_adr = upload<int>(s, m.obj_geom_adr, &ok); T.n_obj = (int)m.obj_mass.size();
+    }
     // scalar parameters
     auto& P = s->P;
     const auto& o = m.opt;
@@ -144,7 +151,8 @@ bool build_tables(kp_sim* s) {
     P.imp_d0 = (float)clampimp(o[OPT_IMP_D0]); P.imp_dw = (float)dmax; P.imp_w = (float)o[OPT_IMP_W];
     P.imp_mid = (float)clampimp(o[OPT_IMP_MID]); P.imp_pow = (float)std::max(1.0, o[OPT_IMP_POW]);
     P.mu = (float)o[OPT_FRIC]; P.margin = (float)o[OPT_MARGIN];
-    P.scale = (float)(1.0 / (o[OPT_MEANINERTIA] * NV));
+    // mj_solNewton's termination scale: mean inertia and dof count of the WHOLE reference scene (objects included)
+    P.scale = (float)(1.0 / (o[OPT_MEANINERTIA] * (o.size() > OPT_NV_FULL ? o[OPT_NV_FULL] : NV)));
     P.rfc_scale = (float)o[OPT_RFC_SCALE]; P.rfc_lim = (float)o[OPT_RFC_LIM];
     double bn = o[OPT_BR_W] * o[OPT_BR_W] + o[OPT_BR_X] * o[OPT_BR_X] + o[OPT_BR_Y] * o[OPT_BR_Y] + o[OPT_BR_Z] * o[OPT_BR_Z];
     P.br_inv[0] = (float)(o[OPT_BR_W] / bn); P.br_inv[1] = (float)(-o[OPT_BR_X] / bn);
@@ -161,7 +169,9 @@ int launch_step(kp_sim* s, const float* action, int nsub, const uint8_t* mask, b
     A.target_qpos = s->t_qpos; A.action = action; A.env_mask = mask;
     A.xpos = s->xpos; A.xquat = s->xquat; A.xipos = s->xipos; A.diag = s->diag; A.prof = s->prof;
     A.geoms = s->geoms; A.ngeom = s->ngeom;
+    A.obj_slot = s->obj_slot; A.obj_qpos = s->obj_qpos; A.obj_qvel = s->obj_qvel; A.obj_warm = s->obj_warm;
     const bool obj = s->has_objects;
+    if (obj && s->model->threads != 64) return fail("object contact needs threads_per_env = 64");
     size_t lds = obj ? sizeof(kp::EnvLdsObj) : sizeof(kp::EnvLds);
     hipEvent_t e0 = s->ev0, e1 = s->ev1;
     if (time_it && s->ring_on && s->ring_used < 4096) {
@@ -174,10 +184,12 @@ int launch_step(kp_sim* s, const float* action, int nsub, const uint8_t* mask, b
         s->ring_used++;
     }
     if (time_it) HIP_OK(hipEventRecord(e0, s->stream));
-#define KP_LAUNCH(NT_) do { if (obj) hipLaunchKernelGGL((kp::kp_step_kernel<NT_, true>), dim3(s->n), dim3(NT_), lds, s->stream, A); \
-                            else hipLaunchKernelGGL((kp::kp_step_kernel<NT_, false>), dim3(s->n), dim3(NT_), lds, s->stream, A); } while (0)
+#define KP_LAUNCH(NT_) hipLaunchKernelGGL((kp::kp_step_kernel<NT_, false>), dim3(s->n), dim3(NT_), lds, s->stream, A)
     switch (s->model->threads) {
-        case 64: KP_LAUNCH(64); break;
+        case 64:
+            if (obj) hipLaunchKernelGGL((kp::kp_step_kernel<64, true>), dim3(s->n), dim3(64), lds, s->stream, A);
+            else KP_LAUNCH(64);
+            break;
         case 128: KP_LAUNCH(128); break;
         case 256: KP_LAUNCH(256); break;
         default: return fail("threads_per_env must be 64, 128 or 256");
@@ -202,6 +214,7 @@ kp_model* kp_model_load(const char* path) {
     kp_model* m = new kp_model();
     if (!kp::load_kpm(path, m->h)) { fail("kp_model_load: " + m->h.error); delete m; return nullptr; }
     m->gravity_z = m->h.opt[kp::OPT_GZ];
+    m->solver_tol = m->h.opt[kp::OPT_SOLVER_TOL];
     return m;
 }
 void kp_model_free(kp_model* m) { delete m; }
@@ -215,6 +228,7 @@ int kp_model_set_option(kp_model* m, const char* name, double v) {
     else if (k == "stale_kinematics") m->stale = v != 0;
     else if (k == "solver_iter") m->solver_iter = (int)v;
     else if (k == "solver_tol") m->solver_tol = v;
+    else if (k == "dynamic_objects") m->dynamic_objects = v != 0;
     else if (k == "threads_per_env") { if (v != 64 && v != 128 && v != 256) return fail("threads_per_env must be 64, 128 or 256"); m->threads = (int)v; }
     else return fail("kp_model_set_option: unknown option " + k);
     return 0;
@@ -228,9 +242,11 @@ double kp_model_get_option(const kp_model* m, const char* name) {
     if (k == "stale_kinematics") return m->stale;
     if (k == "solver_iter") return m->solver_iter;
     if (k == "solver_tol") return m->solver_tol;
+    if (k == "dynamic_objects") return m->dynamic_objects;
     if (k == "threads_per_env") return m->threads;
     if (k == "timestep") return m->h.opt[kp::OPT_TIMESTEP];
     if (k == "lds_bytes_per_env") return (double)sizeof(kp::EnvLds);
+    if (k == "lds_bytes_per_env_objects") return (double)sizeof(kp::EnvLdsObj);
     return NAN;
 }
 
@@ -252,6 +268,7 @@ kp_sim* kp_sim_create(const kp_model* m, int n_envs, int device_id, void* stream
     s->prev_bquat = dalloc(s, N * 96, &ok); s->prev_hpos = dalloc(s, N * 7, &ok);
     s->diag = (int*)dalloc(s, N * 4, &ok);
     s->obj_qpos = dalloc(s, N * 35, &ok); s->geoms = dalloc(s, N * kp::D_MAXGEOM * 17, &ok); s->ngeom = (int*)dalloc(s, N, &ok);
+    s->obj_qvel = dalloc(s, N * 30, &ok); s->obj_warm = dalloc(s, N * 6 * kp::D_MAXOBJ, &ok); s->obj_slot = (signed char*)dalloc(s, (N * kp::D_MAXOBJ + 3) / 4 + 1, &ok);
     if (!m->h.obj_geoms.empty()) {
         s->d_obj_geoms = upload<float>(s, m->h.obj_geoms, &ok); s->d_obj_mass = upload<float>(s, m->h.obj_mass, &ok);
         s->n_obj_geoms = (int)(m->h.obj_geoms.size() / 18); s->n_obj = (int)m->h.obj_mass.size();
@@ -309,15 +326,28 @@ int kp_sim_set_target(kp_sim* s, const float* tq, const uint8_t* mask) {
     return 0;
 }
 
-// world-frame geoms of the objects that are not parked (thread per env)
+// objects that are not parked (convert_obj_qpos parks the inactive ones 100+ m away): dynamic mode -> they become the env's
+// free bodies (slots in object order, velocities zeroed as reset_model does); static mode -> their world-frame geoms are frozen
 __global__ void k_set_objects(int n, const float* __restrict__ obj_qpos_in, const uint8_t* __restrict__ mask, float* __restrict__ obj_qpos,
                               float* __restrict__ geoms, int* __restrict__ ngeom, const float* __restrict__ og, const float* __restrict__ omass,
-                              int n_og, int n_obj) {
+                              int n_og, int n_obj, int dynamic, signed char* __restrict__ slot, float* __restrict__ obj_qvel, float* __restrict__ obj_warm) {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
     if (mask && !mask[e]) return;
-    int ng = 0;
+    int ng = 0, ns = 0;
     for (int i = 0; i < 35; i++) obj_qpos[(size_t)e * 35 + i] = obj_qpos_in[(size_t)e * 35 + i];
+    for (int i = 0; i < 30; i++) obj_qvel[(size_t)e * 30 + i] = 0.f;
+    for (int i = 0; i < 6 * kp::D_MAXOBJ; i++) obj_warm[(size_t)e * 6 * kp::D_MAXOBJ + i] = 0.f;
+    for (int k = 0; k < kp::D_MAXOBJ; k++) slot[(size_t)e * kp::D_MAXOBJ + k] = -1;
+    if (dynamic) {
+        for (int oi = 0; oi < n_obj && oi < 5 && ns < kp::D_MAXOBJ; oi++) {
+            const float* pose = obj_qpos_in + (size_t)e * 35 + 7 * oi;
+            if (sqrtf(pose[0] * pose[0] + pose[1] * pose[1] + pose[2] * pose[2]) > 50.0f) continue;
+            slot[(size_t)e * kp::D_MAXOBJ + ns++] = (signed char)oi;
+        }
+        ngeom[e] = 0;
+        return;
+    }
     for (int gi = 0; gi < n_og && ng < kp::D_MAXGEOM; gi++) {
         const float* g = og + 18 * gi;
         const int oi = (int)g[0];
@@ -342,9 +372,10 @@ __global__ void k_set_objects(int n, const float* __restrict__ obj_qpos_in, cons
 int kp_sim_set_objects(kp_sim* s, const float* obj_qpos, const uint8_t* mask) {
     if (!s || !obj_qpos) return fail("kp_sim_set_objects: null argument");
     if (!s->d_obj_geoms) return fail("kp_sim_set_objects: the model blob has no object geoms");
+    const int dynamic = s->model->dynamic_objects && s->T.obj_inertial != nullptr;
     HIP_OK(hipSetDevice(s->device));
     hipLaunchKernelGGL(k_set_objects, dim3((s->n + 63) / 64), dim3(64), 0, s->stream, s->n, obj_qpos, mask, s->obj_qpos, s->geoms, s->ngeom,
-                       s->d_obj_geoms, s->d_obj_mass, s->n_obj_geoms, s->n_obj);
+                       s->d_obj_geoms, s->d_obj_mass, s->n_obj_geoms, s->n_obj, dynamic, s->obj_slot, s->obj_qvel, s->obj_warm);
     HIP_OK(hipGetLastError());
     s->has_objects = true;
     return 0;
@@ -396,6 +427,7 @@ int kp_field_dim(int f) {
         case KP_XQUAT: case KP_BQUAT: case KP_TARGET_WBQUAT: case KP_TARGET_BQUAT: case KP_PREV_BQUAT: return 96;
         case KP_HEAD: case KP_PREV_HPOS: return 7;
         case KP_OBJ_QPOS: return 35;
+        case KP_OBJ_QVEL: return 30;
         default: return -1;
     }
 }
@@ -428,6 +460,7 @@ int kp_sim_get(kp_sim* s, int field, float* out) {
         case KP_PREV_BQUAT: src = s->prev_bquat; break;
         case KP_PREV_HPOS: src = s->prev_hpos; break;
         case KP_OBJ_QPOS: src = s->obj_qpos; break;
+        case KP_OBJ_QVEL: src = s->obj_qvel; break;
         case KP_BQUAT:
             hipLaunchKernelGGL(kp::k_bquat, dim3((s->n * 24 + 255) / 256), dim3(256), 0, s->stream, s->n, s->qpos, out);
             HIP_OK(hipGetLastError());

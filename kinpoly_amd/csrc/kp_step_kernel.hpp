@@ -38,8 +38,11 @@ struct StepArgs {
     float *xpos, *xquat, *xipos;
     int* diag;  // [N,4]: ncon (last substep), newton iterations (sum), flags, max ncon
     unsigned long long* prof;  // optional [N,8] shader-clock cycles per phase (kp_sim_phase_cycles)
-    const float* geoms;        // OBJ kernels: [N, D_MAXGEOM, 17] world-frame object geoms
+    const float* geoms;        // OBJ kernels: [N, D_MAXGEOM, 17] world-frame static geoms
     const int* ngeom;          // OBJ kernels: [N]
+    // OBJ kernels, dynamic free objects: slot -> object index of the scene (-1 = empty), free-joint state of all objects
+    const signed char* obj_slot;   // [N, D_MAXOBJ]
+    float *obj_qpos, *obj_qvel, *obj_warm;   // [N, 35], [N, 30], [N, 6 * D_MAXOBJ]
 };
 
 // wave-wide sum without LDS traffic: xor butterflies inside each 16-lane row with DPP (quad_perm, row_half_mirror,
@@ -332,6 +335,28 @@ __device__ __forceinline__ float aba_fwd3(EnvLds& s, const Lane8& L, float* out,
     return a;
 }
 
+// root->leaves pass: joint accelerations from (U, 1/D, u) and the parent's spatial acceleration; leaves them in sv
+__device__ __forceinline__ void aba_forward(EnvLds& s, const Lane8& L, float* out) {
+    const int r = L.r;
+    const bool rowok = r < 6;
+#pragma nounroll
+    for (int lev = 0; lev < D_NLEV; lev++) {
+        const int sh = 5 * lev;
+        const int bq = (int)((L.sb >> sh) & 31ull), par = (int)((L.sp >> sh) & 31ull);
+        const bool active = bq != 31;
+        const int b = active ? bq : 0;
+        float a = (rowok && par != 31) ? s.sv[6 * (par == 31 ? 0 : par) + r] : 0.f;
+        if (lev == 0) {
+            a = aba_fwd3(s, L, out, 0, active, a);
+            a = aba_fwd3(s, L, out, 3, active, a);
+        } else {
+            a = aba_fwd3(s, L, out, b == 0 ? 6 : 6 + 3 * (b - 1), active, a);
+        }
+        if (active && rowok) s.sv[6 * b + r] = a;
+        KP_SYNC();
+    }
+}
+
 template <int NT, bool OBJ>
 __device__ __forceinline__ void aba_solve(EnvLds& s, const Params& P, const Lane8& L, const float* rhs, float* out, bool contact_inertia, int tid) {
     const int r = L.r;
@@ -394,22 +419,45 @@ __device__ __forceinline__ void aba_solve(EnvLds& s, const Params& P, const Lane
         }
         KP_SYNC();
     }
+    aba_forward(s, L, out);
+}
+
+// out = H^-1 (rhs + J_body^T wrench) with the factorisation (U, 1/D) the last aba_solve left in LDS: the bias-force half of the
+// leaves->root pass only (no inertia updates), then the usual root->leaves pass.  rhs / wrench ([24][6], about o) may be null.
+__device__ __forceinline__ void aba_resolve(EnvLds& s, const Lane8& L, const float* rhs, const float* wrench, float* out) {
+    const int r = L.r;
+    const bool rowok = r < 6;
+    const int rc = rowok ? r : 5;
+    const float rmask = rowok ? 1.f : 0.f;
 #pragma nounroll
-    for (int lev = 0; lev < D_NLEV; lev++) {
+    for (int lev = D_NLEV - 1; lev >= 0; lev--) {
         const int sh = 5 * lev;
-        const int bq = (int)((L.sb >> sh) & 31ull), par = (int)((L.sp >> sh) & 31ull);
+        const int bq = (int)((L.sb >> sh) & 31ull), c0 = (int)((L.sc0 >> sh) & 31ull), c1 = (int)((L.sc1 >> sh) & 31ull), c2 = (int)((L.sc2 >> sh) & 31ull);
         const bool active = bq != 31;
         const int b = active ? bq : 0;
-        float a = (rowok && par != 31) ? s.sv[6 * (par == 31 ? 0 : par) + r] : 0.f;
-        if (lev == 0) {
-            a = aba_fwd3(s, L, out, 0, active, a);
-            a = aba_fwd3(s, L, out, 3, active, a);
-        } else {
-            a = aba_fwd3(s, L, out, b == 0 ? 6 : 6 + 3 * (b - 1), active, a);
+        const int pr = 6 * 24;
+        float pA = (s.pAa[rowok ? 6 * c0 + r : pr] + s.pAa[rowok ? 6 * c1 + r : pr]) + s.pAa[rowok ? 6 * c2 + r : pr];
+        if (wrench) pA -= rmask * wrench[6 * b + rc];
+        const int nrounds = lev == 0 ? 2 : 1;
+        for (int rd = 0; rd < nrounds; rd++) {
+            const int d0 = lev == 0 ? (rd == 0 ? 3 : 0) : 6 + 3 * (b == 0 ? 0 : b - 1);
+            float uo[3];
+#pragma unroll
+            for (int j = 2; j >= 0; j--) {
+                const int d = d0 + j;
+                const float u = (rhs ? rhs[d] : 0.f) - sum8(rmask * s.cdof[6 * d + rc] * pA);
+                pA += rmask * s.U[6 * d + rc] * (u * s.Dinv[d]);
+                uo[j] = u;
+            }
+            if (active && r == 0) {
+#pragma unroll
+                for (int j = 0; j < 3; j++) s.uj[d0 + j] = uo[j];
+            }
         }
-        if (active && rowok) s.sv[6 * b + r] = a;
+        if (active && rowok) s.pAa[6 * b + r] = pA;
         KP_SYNC();
     }
+    aba_forward(s, L, out);
 }
 
 // ---------------------------------------------------------------- stable-PD torque + residual force (reference controller)
@@ -527,7 +575,11 @@ __device__ __forceinline__ void collide_plane(EnvLds& s, const DevTables& T, con
                             const V3 w = mulmat(R, v);
                             st3(s.con_pos + 3 * ncon, xb + w - (0.5f * dist) * nrm);
                             s.con_dist[ncon] = dist; s.con_body[ncon] = b;
-                            if (OBJ) { st3(static_cast<EnvLdsObj&>(s).con_n + 3 * ncon, nrm); static_cast<EnvLdsObj&>(s).con_iw2[ncon] = gi < 0 ? 0.f : g[16]; }
+                            if (OBJ) {
+                                EnvLdsObj& so = static_cast<EnvLdsObj&>(s);
+                                st3(so.con_n + 3 * ncon, nrm); so.con_iw2[ncon] = gi < 0 ? 0.f : g[16];
+                                so.con_b2[ncon] = (signed char)((gi < 0 || so.gobj[gi] < 0) ? -1 : D_NB + so.gobj[gi]);
+                            }
                         }
                         ncon++;
                     }
@@ -535,7 +587,63 @@ __device__ __forceinline__ void collide_plane(EnvLds& s, const DevTables& T, con
                 }
             }
         }
-        if (tid == 0) { s.con_start[D_NB] = ncon; s.ncon = ncon; s.nlim = 0; }
+        if (tid == 0) s.con_start[D_NB] = ncon;
+        if constexpr (OBJ) {
+            // dynamic objects in slot order: the 8 vertices of every geom (lane = vertex) against the floor, then against the geoms
+            // of the objects in higher slots; up to 4 deepest per pair (oracle: kpo_collide, second loop)
+            EnvLdsObj& so = static_cast<EnvLdsObj&>(s);
+            int slot_done = 0;
+            for (int ga = so.ngeom_static; ga < ngeom && P.contact; ga++) {
+                const float* g = so.geom + 17 * ga;
+                const int ka = so.gobj[ga];
+                while (slot_done < ka) { slot_done++; if (tid == 0) s.con_start[D_NB + slot_done] = ncon; }
+                const V3 gp = ld3(g + 4);
+                const float gra = g[0] == 0.f ? sqrtf(g[1] * g[1] + g[2] * g[2] + g[3] * g[3]) : sqrtf(g[1] * g[1] + g[2] * g[2]);
+                V3 xw = gp;
+                {
+                    const int v = tid & 7;
+                    V3 l;
+                    if (g[0] == 0.f) l = v3((v & 1) ? g[1] : -g[1], (v & 2) ? g[2] : -g[2], (v & 4) ? g[3] : -g[3]);
+                    else { const int a = v & 3; l = v3(g[1] * (a == 0 ? 1.f : (a == 2 ? -1.f : 0.f)), g[1] * (a == 1 ? 1.f : (a == 3 ? -1.f : 0.f)), (v & 4) ? g[2] : -g[2]); }
+                    xw = gp + mulmat(g + 7, l);
+                }
+                for (int gb = -1; gb < ngeom; gb++) {
+                    const float* h = gb < 0 ? nullptr : so.geom + 17 * gb;
+                    if (gb >= 0 && (so.gobj[gb] < 0 || so.gobj[gb] <= ka)) continue;
+                    if (gb < 0) { if (gp.z - gra > P.margin) continue; }
+                    else {
+                        const V3 dx = gp - ld3(h + 4);
+                        const float grb = h[0] == 0.f ? sqrtf(h[1] * h[1] + h[2] * h[2] + h[3] * h[3]) : sqrtf(h[1] * h[1] + h[2] * h[2]);
+                        if (sqrtf(dot(dx, dx)) - gra - grb > P.margin) continue;
+                    }
+                    float dist = 3.0e38f;
+                    V3 nrm = v3(0.f, 0.f, 1.f);
+                    if (tid < 8) dist = gb < 0 ? xw.z : geom_sdf(h, xw, nrm);
+                    bool cand = dist < P.margin;
+                    for (int r = 0; r < D_OBJ_CON_PER_GEOM; r++) {
+                        float dmin = cand ? dist : 3.0e38f;
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) dmin = fminf(dmin, __shfl_xor(dmin, o, 64));
+                        if (!(dmin < P.margin)) break;
+                        int idx = (cand && dist == dmin) ? tid : 64;
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) idx = min(idx, __shfl_xor(idx, o, 64));
+                        if (ncon < D_MAXCON) {
+                            if (tid == idx) {
+                                st3(s.con_pos + 3 * ncon, xw - (0.5f * dist) * nrm);
+                                s.con_dist[ncon] = dist; s.con_body[ncon] = D_NB + ka;
+                                st3(so.con_n + 3 * ncon, nrm); so.con_iw2[ncon] = gb < 0 ? 0.f : h[16];
+                                so.con_b2[ncon] = (signed char)(gb < 0 ? -1 : D_NB + so.gobj[gb]);
+                            }
+                            ncon++;
+                        }
+                        if (tid == idx) cand = false;
+                    }
+                }
+            }
+            while (slot_done < D_MAXOBJ) { slot_done++; if (tid == 0) s.con_start[D_NB + slot_done] = ncon; }
+        }
+        if (tid == 0) { s.ncon = ncon; s.nlim = 0; }
     }
     KP_SYNC();
 }
@@ -548,11 +656,18 @@ __device__ __forceinline__ void make_constraint(EnvLds& s, const DevTables& T, c
         int b = s.con_body[c];
         float r = s.con_dist[c] - P.margin;
         float imp = impedance(P, r);
-        float dA = (T.body_invw[b] + (OBJ ? static_cast<EnvLdsObj&>(s).con_iw2[c] : 0.f)) * (1.0f + P.mu * P.mu);
+        float iwA = T.body_invw[b < D_NB ? b : 0];
+        if (OBJ && b >= D_NB) iwA = static_cast<EnvLdsObj&>(s).oc[13 * (b - D_NB) + 10];
+        float dA = (iwA + (OBJ ? static_cast<EnvLdsObj&>(s).con_iw2[c] : 0.f)) * (1.0f + P.mu * P.mu);
         float Rn = fmaxf(1e-15f, (1.0f - imp) * dA / imp);
         s.con_D[c] = 1.0f / (2.0f * P.mu * P.mu * Rn);
-        S6 cv = lds6(s.sv + 6 * b);                         // sv still holds cvel from forward_kin_bias
-        V3 vf = frame_comp(contact_frame<OBJ>(s, c), cv.l + cross(cv.a, ld3(s.con_pos + 3 * c) - o));
+        S6 cv = lds6(s.sv + 6 * b);                         // sv still holds cvel from forward_kin_bias (objects: obj_forward)
+        V3 vp = cv.l + cross(cv.a, ld3(s.con_pos + 3 * c) - o);
+        if (OBJ) {
+            const int b2 = static_cast<EnvLdsObj&>(s).con_b2[c];
+            if (b2 >= 0) { const S6 c2 = lds6(s.sv + 6 * b2); vp = vp - (c2.l + cross(c2.a, ld3(s.con_pos + 3 * c) - o)); }
+        }
+        V3 vf = frame_comp(contact_frame<OBJ>(s, c), vp);
         s.jv3[3 * c] = -P.B * vf.x - P.K * imp * r; s.jv3[3 * c + 1] = -P.B * vf.y; s.jv3[3 * c + 2] = -P.B * vf.z;
     }
     for (int j = tid; j < D_NU; j += NT) {
@@ -579,7 +694,12 @@ __device__ __forceinline__ void eval_rows(EnvLds& s, const float* vec, float* ou
     const V3 o = ld3(s.xpos);
     for (int c = tid; c < s.ncon; c += NT) {
         S6 S = lds6(s.sv + 6 * s.con_body[c]);
-        V3 a = frame_comp(contact_frame<OBJ>(s, c), S.l + cross(S.a, ld3(s.con_pos + 3 * c) - o));
+        V3 ap = S.l + cross(S.a, ld3(s.con_pos + 3 * c) - o);
+        if (OBJ) {
+            const int b2 = static_cast<const EnvLdsObj&>(s).con_b2[c];
+            if (b2 >= 0) { const S6 S2 = lds6(s.sv + 6 * b2); ap = ap - (S2.l + cross(S2.a, ld3(s.con_pos + 3 * c) - o)); }
+        }
+        V3 a = frame_comp(contact_frame<OBJ>(s, c), ap);
         if (sub_aref) { a.x -= s.jv3[3 * c]; a.y -= s.jv3[3 * c + 1]; a.z -= s.jv3[3 * c + 2]; }
         out3[3 * c] = a.x; out3[3 * c + 1] = a.y; out3[3 * c + 2] = a.z;
     }
@@ -749,6 +869,381 @@ __device__ __forceinline__ int solve_constraints(EnvLds& s, const Params& P, con
     return it;
 }
 
+// ---------------------------------------------------------------- dynamic free objects (OBJ kernels; one wave per env)
+// An object is one more rigid body whose unknown in the Newton solve is its spatial acceleration about o (a linear
+// re-parametrisation of its six free-joint accelerations, under which Newton steps and the exact line search are invariant).
+// Oracle counterpart: kpo_obj_forward + the object columns of kpo_make_constraint / kpo_solve_constraint.
+
+// 6x6 entry of a 10-float spatial inertia [Ixx Iyy Izz Ixy Ixz Iyz | h | m]
+__device__ __forceinline__ float inert_entry(const float* I, int r, int c) {
+    if (r > c) { const int t = r; r = c; c = t; }
+    if (c < 3) return r == c ? I[r] : I[2 + r + c];
+    if (r >= 3) return r == c ? I[9] : 0.f;
+    const int l = c - 3;
+    if (r == l) return 0.f;
+    return ((l == (r + 2) % 3) ? 1.f : -1.f) * I[6 + (3 - r - l)];
+}
+__device__ __forceinline__ S6 unit6(int j) { return S6{v3(j == 0, j == 1, j == 2), v3(j == 3, j == 4, j == 5)}; }
+
+// D F G F^T a: the active pyramid rows of contact c applied to a point acceleration (world components)
+__device__ __forceinline__ V3 con_DG(const EnvLdsObj& s, const Params& P, int c, V3 a) {
+    const float mu = P.mu, mu2 = mu * mu, Dc = s.con_D[c], jn = s.jar3[3 * c], jt1 = s.jar3[3 * c + 1], jt2 = s.jar3[3 * c + 2];
+    const float a0 = row_val(0, mu, jn, jt1, jt2) < 0.f, a1 = row_val(1, mu, jn, jt1, jt2) < 0.f;
+    const float a2 = row_val(2, mu, jn, jt1, jt2) < 0.f, a3 = row_val(3, mu, jn, jt1, jt2) < 0.f;
+    const float gnn = a0 + a1 + a2 + a3, g11 = mu2 * (a0 + a1), g22 = mu2 * (a2 + a3), gn1 = mu * (a0 - a1), gn2 = mu * (a2 - a3);
+    const Frame fr = contact_frame<true>(s, c);
+    const V3 pf = frame_comp(fr, a);
+    return frame_world(fr, v3(Dc * (gnn * pf.x + gn1 * pf.y + gn2 * pf.z), Dc * (gn1 * pf.x + g11 * pf.y), Dc * (gn2 * pf.x + g22 * pf.z)));
+}
+// K_c acc: the wrench (about o) contact c's active rows put on a body accelerating with acc
+__device__ __forceinline__ S6 con_K(const EnvLdsObj& s, const Params& P, int c, S6 acc, V3 o) {
+    const V3 p = ld3(s.con_pos + 3 * c) - o;
+    const V3 w = con_DG(s, P, c, acc.l + cross(acc.a, p));
+    return S6{cross(p, w), w};
+}
+// contact force (world) of contact c at the current residuals, acting on the entity that carries the vertex
+__device__ __forceinline__ V3 con_force(const EnvLdsObj& s, const Params& P, int c) {
+    const float Dc = s.con_D[c], jn = s.jar3[3 * c], jt1 = s.jar3[3 * c + 1], jt2 = s.jar3[3 * c + 2];
+    float fe[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) { const float x = row_val(e, P.mu, jn, jt1, jt2); fe[e] = x < 0.f ? -Dc * x : 0.f; }
+    return frame_world(contact_frame<true>(s, c), v3(fe[0] + fe[1] + fe[2] + fe[3], P.mu * (fe[0] - fe[1]), P.mu * (fe[2] - fe[3])));
+}
+
+// pose-dependent quantities of the objects (lane = slot), their world geoms (lane = geom); spatial velocity -> sv[24 + k]
+__device__ __forceinline__ void obj_forward(EnvLdsObj& s, const Params& P, int tid) {
+    const V3 o = ld3(s.xpos);
+    if (tid < s.nobj) {
+        const int k = tid;
+        float* q = s.oq + 7 * k;
+        const Q4 qq = qnormalize(Q4{q[3], q[4], q[5], q[6]});
+        q[3] = qq.w; q[4] = qq.x; q[5] = qq.y; q[6] = qq.z;
+        float R[9];
+        q2mat(qq, R);
+#pragma unroll
+        for (int i = 0; i < 9; i++) s.oR[9 * k + i] = R[i];
+        const float* C = s.oc + 13 * k;
+        const float mass = C[0], arm = C[12];
+        const V3 xp = ld3(q), com = xp + mulmat(R, ld3(C + 1));
+        const float I3[9] = {C[4], C[7], C[8], C[7], C[5], C[9], C[8], C[9], C[6]};
+        float Tm[9], W[9];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) Tm[3 * i + j] = R[3 * i] * I3[j] + R[3 * i + 1] * I3[3 + j] + R[3 * i + 2] * I3[6 + j];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) W[3 * i + j] = Tm[3 * i] * R[3 * j] + Tm[3 * i + 1] * R[3 * j + 1] + Tm[3 * i + 2] * R[3 * j + 2];
+        const V3 rr = com - o, ra = xp - o;
+        const float r2 = dot(rr, rr), a2 = dot(ra, ra);
+        float* ci = s.oI + 10 * k;
+        ci[0] = W[0] + mass * (r2 - rr.x * rr.x); ci[1] = W[4] + mass * (r2 - rr.y * rr.y); ci[2] = W[8] + mass * (r2 - rr.z * rr.z);
+        ci[3] = W[1] - mass * rr.x * rr.y; ci[4] = W[2] - mass * rr.x * rr.z; ci[5] = W[5] - mass * rr.y * rr.z;
+        ci[6] = mass * rr.x; ci[7] = mass * rr.y; ci[8] = mass * rr.z; ci[9] = mass;
+        // the free joint's armature (diagonal in joint coordinates) = a point mass at the body origin + an isotropic rotor
+        float* ce = s.oIe + 10 * k;
+        ce[0] = ci[0] + arm * (a2 - ra.x * ra.x) + arm; ce[1] = ci[1] + arm * (a2 - ra.y * ra.y) + arm; ce[2] = ci[2] + arm * (a2 - ra.z * ra.z) + arm;
+        ce[3] = ci[3] - arm * ra.x * ra.y; ce[4] = ci[4] - arm * ra.x * ra.z; ce[5] = ci[5] - arm * ra.y * ra.z;
+        ce[6] = ci[6] + arm * ra.x; ce[7] = ci[7] + arm * ra.y; ce[8] = ci[8] + arm * ra.z; ce[9] = ci[9] + arm;
+        const V3 vl = ld3(s.ov + 6 * k), ww = mulmat(R, ld3(s.ov + 6 * k + 3));
+        const S6 cv = S6{ww, vl - cross(ww, ra)};
+        const S6 ca = S6{v3(0.f, 0.f, 0.f), v3(-P.gx, -P.gy, -P.gz) + cross(vl, ww)};
+        sts6(s.ofb + 6 * k, inert_mul(ci, ca) + cross_force(cv, inert_mul(ci, cv)));
+        sts6(s.sv + 6 * (D_NB + k), cv);
+        // warm start: joint-space acceleration of the previous solve -> spatial acceleration in this pose
+        const V3 al_q = ld3(s.oqa + 6 * k), aa = mulmat(R, ld3(s.oqa + 6 * k + 3));
+        sts6(s.oa + 6 * k, S6{aa, al_q - cross(aa, ra)});
+    }
+    KP_SYNC();
+    if (tid >= s.ngeom_static && tid < s.ngeom) {
+        const int k = s.gobj[tid];
+        const float* l = s.lgeom + 16 * tid;
+        const float* R = s.oR + 9 * k;
+        float* g = s.geom + 17 * tid;
+        g[0] = l[0]; g[1] = l[1]; g[2] = l[2]; g[3] = l[3];
+        st3(g + 4, ld3(s.oq + 7 * k) + mulmat(R, ld3(l + 4)));
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) g[7 + 3 * i + j] = R[3 * i] * l[7 + j] + R[3 * i + 1] * l[10 + j] + R[3 * i + 2] * l[13 + j];
+        g[16] = s.oc[13 * k + 10];
+    }
+    KP_SYNC();
+}
+
+// Gaussian elimination of the n x n SPD system in s.Sm (row stride 13, right-hand side in column n); solution -> column n
+__device__ __forceinline__ void dense_solve(EnvLdsObj& s, int n, int tid) {
+    constexpr int ST = 6 * D_MAXOBJ + 1;
+    for (int j = 0; j < n; j++) {
+        if (tid > j && tid < n) {
+            const float l = s.Sm[tid * ST + j] / s.Sm[j * ST + j];
+            for (int c = j + 1; c <= n; c++) s.Sm[tid * ST + c] -= l * s.Sm[j * ST + c];
+        }
+        KP_SYNC();
+    }
+    for (int j = n - 1; j >= 0; j--) {
+        if (tid == j) s.Sm[j * ST + n] /= s.Sm[j * ST + j];
+        KP_SYNC();
+        if (tid < j) s.Sm[tid * ST + n] -= s.Sm[tid * ST + j] * s.Sm[j * ST + n];
+        KP_SYNC();
+    }
+}
+
+// object rows of the Newton system: Sm = blockdiag(I_eff) + sum of the active contact matrices K_c over the contacts that touch an
+// object (own block +K_c, object-object block -K_c); column n = rhs
+__device__ __forceinline__ void obj_hessian(EnvLdsObj& s, const Params& P, const float* rhs, float sign, int tid) {
+    constexpr int ST = 6 * D_MAXOBJ + 1;
+    const int n = 6 * s.nobj;
+    if (tid < n) {
+        const int k = tid / 6, r = tid - 6 * k;
+        float* row = s.Sm + ST * tid;
+        for (int c = 0; c < n; c++) row[c] = (c / 6 == k) ? inert_entry(s.oIe + 10 * k, r, c - 6 * k) : 0.f;
+        row[n] = sign * rhs[tid];
+        const V3 o = ld3(s.xpos);
+        const S6 er = unit6(r);
+        for (int c = 0; c < s.ncon; c++) {
+            const int A = s.con_body[c], B = s.con_b2[c];
+            if (A != D_NB + k && B != D_NB + k) continue;
+            const S6 Kr = con_K(s, P, c, er, o);
+            const float kr[6] = {Kr.a.x, Kr.a.y, Kr.a.z, Kr.l.x, Kr.l.y, Kr.l.z};
+            const int other = (A == D_NB + k) ? B : A;
+#pragma unroll
+            for (int i = 0; i < 6; i++) row[6 * k + i] += kr[i];
+            if (other >= D_NB) {
+#pragma unroll
+                for (int i = 0; i < 6; i++) row[6 * (other - D_NB) + i] -= kr[i];
+            }
+        }
+    }
+    KP_SYNC();
+}
+
+// out[6k..] = sum over the hull contacts whose surface belongs to object k of K_c sv[hull]   (= -H_oh y for the y behind sv)
+__device__ __forceinline__ void obj_coupling_u(EnvLdsObj& s, const Params& P, float* out, int tid) {
+    if (tid < s.nobj) {
+        const V3 o = ld3(s.xpos);
+        S6 acc = S6{v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f)};
+        for (int c = 0; c < s.con_start[D_NB]; c++)
+            if (s.con_b2[c] == D_NB + tid) acc = acc + con_K(s, P, c, lds6(s.sv + 6 * s.con_body[c]), o);
+        sts6(out + 6 * tid, acc);
+    }
+    KP_SYNC();
+}
+// sw[b] = sign * sum over hull b's contacts with an object surface (slot ksel, or any if ksel < 0) of K_c acc[slot]
+__device__ __forceinline__ void hull_coupling_wrench(EnvLdsObj& s, const Params& P, int ksel, const float* acc, float sign, int tid) {
+    if (tid < D_NB) {
+        const V3 o = ld3(s.xpos);
+        S6 W = S6{v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f)};
+        for (int c = s.con_start[tid]; c < s.con_start[tid + 1]; c++) {
+            const int B = s.con_b2[c];
+            if (B >= D_NB && (ksel < 0 || B == D_NB + ksel)) W = W + con_K(s, P, c, lds6(acc + 6 * (B - D_NB)), o);
+        }
+        sts6(s.sw + 6 * tid, sign * W);
+    }
+    KP_SYNC();
+}
+// 0.5 mres_o . (a_o - a_smooth_o) summed over the objects (every lane gets the value)
+__device__ __forceinline__ float obj_gauss(const EnvLdsObj& s) {
+    float c = 0.f;
+    for (int i = 0; i < 6 * s.nobj; i++) c += 0.5f * s.omres[i] * (s.oa[i] - s.oas[i]);
+    return c;
+}
+
+// spatial -> joint-space acceleration of the objects, then the same semi-implicit Euler step as the humanoid root
+__device__ __forceinline__ void obj_integrate(EnvLdsObj& s, const Params& P, int tid) {
+    if (tid < s.nobj) {
+        const int k = tid;
+        const float* R = s.oR + 9 * k;
+        const S6 a = lds6(s.oa + 6 * k);
+        const V3 ra = ld3(s.oq + 7 * k) - ld3(s.xpos);
+        const V3 ql = a.l + cross(a.a, ra);
+        const V3 qa = v3(R[0] * a.a.x + R[3] * a.a.y + R[6] * a.a.z, R[1] * a.a.x + R[4] * a.a.y + R[7] * a.a.z, R[2] * a.a.x + R[5] * a.a.y + R[8] * a.a.z);
+        sts6(s.oqa + 6 * k, S6{ql, qa});
+        float* v = s.ov + 6 * k;
+        float* q = s.oq + 7 * k;
+        v[0] += P.h * ql.x; v[1] += P.h * ql.y; v[2] += P.h * ql.z; v[3] += P.h * qa.x; v[4] += P.h * qa.y; v[5] += P.h * qa.z;
+        q[0] += P.h * v[0]; q[1] += P.h * v[1]; q[2] += P.h * v[2];
+        const V3 w = ld3(v + 3);
+        const float n = sqrtf(dot(w, w));
+        Q4 qr = Q4{1.f, 0.f, 0.f, 0.f};
+        if (n >= 1e-15f) { float sn, cs; sincosf(0.5f * P.h * n, &sn, &cs); const float kk = sn / n; qr = Q4{cs, w.x * kk, w.y * kk, w.z * kk}; }
+        const Q4 qn = qmul(qnormalize(Q4{q[3], q[4], q[5], q[6]}), qr);
+        q[3] = qn.w; q[4] = qn.x; q[5] = qn.y; q[6] = qn.z;
+    }
+}
+
+// the constraint solve with free objects in the scene: same Newton iteration as solve_constraints on the joint unknowns
+// (q_humanoid, a_object...).  The Newton system is solved exactly by block elimination: the articulated-body pass factorises
+// the humanoid block, 6 n_obj + 1 bias-only passes form the Schur complement on the objects when a hull touches one.
+template <int NT>
+__device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params& P, const Lane8& L8, int depth, int tid) {
+    constexpr int ST = 6 * D_MAXOBJ + 1;
+    const int nobj = s.nobj, no6 = 6 * nobj;
+    // smooth acceleration of the objects: I_eff a = -bias wrench
+    if (no6 > 0) {
+        {
+            const int n = no6;
+            if (tid < n) {
+                const int k = tid / 6, r = tid - 6 * k;
+                float* row = s.Sm + ST * tid;
+                for (int c = 0; c < n; c++) row[c] = (c / 6 == k) ? inert_entry(s.oIe + 10 * k, r, c - 6 * k) : 0.f;
+                row[n] = -s.ofb[tid];
+            }
+            KP_SYNC();
+        }
+        dense_solve(s, no6, tid);
+        if (tid < no6) s.oas[tid] = s.Sm[ST * tid + no6];
+        KP_SYNC();
+    }
+    if (s.ncon == 0 && s.nlim == 0) {
+        for (int i = tid; i < D_NV; i += NT) s.qacc[i] = s.qacc_s[i];
+        if (tid < no6) s.oa[tid] = s.oas[tid];
+        KP_SYNC();
+        return 0;
+    }
+    // candidate A: the smooth accelerations (Gauss term 0)
+    if (tid < no6) s.sv[6 * D_NB + tid] = s.oas[tid];
+    KP_SYNC();
+    eval_rows<NT, true>(s, s.qacc_s, s.jar3, s.lim_jar, true, tid);
+    float cost = primal_cost<NT>(s, P, nullptr, nullptr, s.jar3, s.lim_jar, tid);
+    // candidate B: warm start
+    {
+        float* wj3 = s.U;
+        float* wlim = s.x;
+        spatial_accumulate<NT>(s, s.qacc, depth, tid);
+        if (tid < no6) s.sv[6 * D_NB + tid] = s.oa[tid];
+        KP_SYNC();
+        eval_rows<NT, true>(s, s.qacc, wj3, wlim, true, tid);
+        wrench_project<NT, true>(s, P, s.qacc, s.Mv, true, false, tid);
+        for (int i = tid; i < D_NV; i += NT) s.mres[i] = s.Mv[i] - s.smooth[i];
+        if (tid < nobj) sts6(s.omres + 6 * tid, inert_mul(s.oIe + 10 * tid, lds6(s.oa + 6 * tid) + (-1.0f) * lds6(s.oas + 6 * tid)));
+        KP_SYNC();
+        const float cw = primal_cost<NT>(s, P, s.qacc, s.mres, wj3, wlim, tid) + obj_gauss(s);
+        if (cw < cost) {
+            cost = cw;
+            for (int k = tid; k < 3 * s.ncon; k += NT) s.jar3[k] = wj3[k];
+            for (int j = tid; j < D_NU; j += NT) s.lim_jar[j] = wlim[j];
+        } else {
+            for (int i = tid; i < D_NV; i += NT) { s.qacc[i] = s.qacc_s[i]; s.mres[i] = 0.f; }
+            if (tid < no6) { s.oa[tid] = s.oas[tid]; s.omres[tid] = 0.f; }
+        }
+        KP_SYNC();
+    }
+    int it = 0;
+    for (; it < P.max_iter; it++) {
+        // gradient: humanoid dofs (mres - J^T f) and object wrenches
+        wrench_project<NT, true>(s, P, nullptr, s.grad, false, true, tid);
+        if (tid < nobj) {
+            const V3 o = ld3(s.xpos);
+            S6 g = lds6(s.omres + 6 * tid);
+            for (int c = 0; c < s.ncon; c++) {
+                const int A = s.con_body[c], B = s.con_b2[c];
+                if (A != D_NB + tid && B != D_NB + tid) continue;
+                const V3 F = con_force(s, P, c), p = ld3(s.con_pos + 3 * c) - o;
+                const float sg = (A == D_NB + tid) ? -1.f : 1.f;
+                g = g + sg * S6{cross(p, F), F};
+            }
+            sts6(s.ogr + 6 * tid, g);
+        }
+        KP_SYNC();
+        float g2 = 0.f;
+        for (int i = tid; i < D_NV; i += NT) {
+            const float g = s.mres[i] + s.grad[i];
+            s.grad[i] = g; g2 += g * g;
+            s.x[i] = -g;
+            s.extra[i] = (i >= 6 && s.lim_jar[i - 6] < 0.f) ? s.lim_D[i - 6] : 0.f;
+        }
+        if (tid < nobj) {   // gradient in joint coordinates: [g_l ; R^T (g_a + r x g_l)], r = o - body origin
+            const S6 g = lds6(s.ogr + 6 * tid);
+            const V3 t = g.a + cross(ld3(s.xpos) - ld3(s.oq + 7 * tid), g.l);
+            g2 += dot(g.l, g.l) + dot(t, t);
+        }
+        g2 = block_sum<NT>(s, g2, tid);
+        KP_SYNC();
+        if (P.scale * sqrtf(g2) < P.tol) break;
+        // search direction
+        bool couple = false;
+        for (int c = tid; c < s.con_start[D_NB]; c += NT) {
+            if (s.con_b2[c] < D_NB) continue;
+            const float jn = s.jar3[3 * c], jt1 = s.jar3[3 * c + 1], jt2 = s.jar3[3 * c + 2];
+#pragma unroll
+            for (int e = 0; e < 4; e++) couple |= row_val(e, P.mu, jn, jt1, jt2) < 0.f;
+        }
+        couple = __ballot(couple) != 0ull;
+        if (no6 > 0) obj_hessian(s, P, s.ogr, -1.0f, tid);
+        if (!couple) {
+            aba_solve<NT, true>(s, P, L8, s.x, s.search, true, tid);
+            if (no6 > 0) { dense_solve(s, no6, tid); if (tid < no6) s.osrch[tid] = s.Sm[ST * tid + no6]; KP_SYNC(); }
+        } else {
+            aba_solve<NT, true>(s, P, L8, s.x, s.search, true, tid);          // factorisation + y0 = H_hh^-1 (-g_h)
+            obj_coupling_u(s, P, s.ot, tid);                                    // -H_oh y0
+            if (tid < no6) s.Sm[ST * tid + no6] += s.ot[tid];
+            for (int kj = 0; kj < no6; kj++) {
+                if (tid < no6) s.oMv[tid] = tid == kj ? 1.f : 0.f;
+                KP_SYNC();
+                hull_coupling_wrench(s, P, kj / 6, s.oMv, -1.0f, tid);         // H_ho e_kj as body wrenches
+                aba_resolve(s, L8, nullptr, s.sw, s.Mv);                        // z = H_hh^-1 H_ho e_kj (sv = its spatial accelerations)
+                obj_coupling_u(s, P, s.ot, tid);                                // -H_oh z
+                if (tid < no6) s.Sm[ST * tid + kj] += s.ot[tid];
+                KP_SYNC();
+            }
+            dense_solve(s, no6, tid);
+            if (tid < no6) s.osrch[tid] = s.Sm[ST * tid + no6];
+            KP_SYNC();
+            hull_coupling_wrench(s, P, -1, s.osrch, 1.0f, tid);                 // -H_ho da
+            aba_resolve(s, L8, s.x, s.sw, s.search);
+        }
+        if (tid < no6) s.sv[6 * D_NB + tid] = s.osrch[tid];
+        KP_SYNC();
+        eval_rows<NT, true>(s, s.search, s.jv3, s.lim_jv, false, tid);
+        wrench_project<NT, true>(s, P, s.search, s.Mv, true, false, tid);
+        if (tid < nobj) sts6(s.oMv + 6 * tid, inert_mul(s.oIe + 10 * tid, lds6(s.osrch + 6 * tid)));
+        KP_SYNC();
+        float g0 = 0.f, h0 = 0.f;
+        for (int i = tid; i < D_NV; i += NT) { g0 += s.search[i] * s.mres[i]; h0 += s.search[i] * s.Mv[i]; }
+        if (tid < no6) { g0 += s.osrch[tid] * s.omres[tid]; h0 += s.osrch[tid] * s.oMv[tid]; }
+        g0 = block_sum<NT>(s, g0, tid); h0 = block_sum<NT>(s, h0, tid);
+        float alpha = 0.f, lo = 0.f, hi = 3.0e38f;
+        for (int ls = 0; ls < 20; ls++) {
+            float d1 = 0.f, d2 = 0.f;
+            for (int k = tid; k < s.ncon; k += NT) {
+                const float Dc = s.con_D[k];
+                const float vn = s.jv3[3 * k], vt1 = s.jv3[3 * k + 1], vt2 = s.jv3[3 * k + 2];
+                const float jn = s.jar3[3 * k] + alpha * vn, jt1 = s.jar3[3 * k + 1] + alpha * vt1, jt2 = s.jar3[3 * k + 2] + alpha * vt2;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float x = row_val(e, P.mu, jn, jt1, jt2);
+                    if (x < 0.f) { const float jv = row_val(e, P.mu, vn, vt1, vt2); d1 += Dc * x * jv; d2 += Dc * jv * jv; }
+                }
+            }
+            for (int j = tid; j < D_NU; j += NT) {
+                if (s.lim_sgn[j] != 0.f) { const float jv = s.lim_jv[j], x = s.lim_jar[j] + alpha * jv; if (x < 0.f) { d1 += s.lim_D[j] * x * jv; d2 += s.lim_D[j] * jv * jv; } }
+            }
+            d1 = block_sum<NT>(s, d1, tid); d2 = block_sum<NT>(s, d2, tid);
+            const float dphi = g0 + alpha * h0 + d1, ddphi = h0 + d2;
+            if (!(ddphi > 0.f)) break;
+            if (dphi < 0.f) lo = alpha; else hi = alpha;
+            float an = alpha - dphi / ddphi;
+            if (!(an > lo && an < hi)) an = hi < 1.0e38f ? 0.5f * (lo + hi) : 2.0f * alpha + 1.0f;
+            const float step = an - alpha;
+            alpha = an;
+            if (fabsf(step) <= 1e-6f * fabsf(alpha)) break;
+        }
+        if (!(alpha > 0.f)) break;
+        for (int i = tid; i < D_NV; i += NT) { s.qacc[i] += alpha * s.search[i]; s.mres[i] += alpha * s.Mv[i]; }
+        if (tid < no6) { s.oa[tid] += alpha * s.osrch[tid]; s.omres[tid] += alpha * s.oMv[tid]; }
+        for (int k = tid; k < 3 * s.ncon; k += NT) s.jar3[k] += alpha * s.jv3[k];
+        for (int j = tid; j < D_NU; j += NT) if (s.lim_sgn[j] != 0.f) s.lim_jar[j] += alpha * s.lim_jv[j];
+        KP_SYNC();
+        const float newcost = primal_cost<NT>(s, P, s.qacc, s.mres, s.jar3, s.lim_jar, tid) + obj_gauss(s);
+        const float improvement = P.scale * (cost - newcost);
+        cost = newcost;
+        if (improvement < P.tol) { it++; break; }
+    }
+    return it;
+}
+
 // ---------------------------------------------------------------- the kernel
 template <int NT, bool OBJ>
 __global__ __launch_bounds__(NT, (NT == 64 ? 2 : 1)) void kp_step_kernel(StepArgs A) {
@@ -777,8 +1272,24 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 2 : 1)) void kp_step_kernel(StepArg
     if (tid < 6) s.pAa[6 * 24 + tid] = 0.f;
     if (tid == 0) { s.ncon = 0; s.nlim = 0; s.flag = 0; }
     if constexpr (OBJ) {
+        static_assert(NT == 64, "the object kernel runs one wavefront per environment");
         for (int i = tid; i < D_MAXGEOM * 17; i += NT) s.geom[i] = A.geoms[(size_t)env * D_MAXGEOM * 17 + i];
-        if (tid == 0) s.ngeom = A.ngeom[env];
+        const int ngs = A.ngeom[env];
+        int nobj = 0, ng = ngs;
+        if (tid < D_MAXGEOM) s.gobj[tid] = -1;
+        for (int k = 0; k < D_MAXOBJ; k++) {
+            const int oi = A.obj_slot ? A.obj_slot[(size_t)env * D_MAXOBJ + k] : -1;
+            if (oi < 0 || oi >= T.n_obj) break;
+            nobj = k + 1;
+            if (tid < 7) s.oq[7 * k + tid] = A.obj_qpos[(size_t)env * 35 + 7 * oi + tid];
+            if (tid < 6) { s.ov[6 * k + tid] = A.obj_qvel[(size_t)env * 30 + 6 * oi + tid]; s.oqa[6 * k + tid] = A.obj_warm[(size_t)env * 6 * D_MAXOBJ + 6 * k + tid]; }
+            if (tid < 13) s.oc[13 * k + tid] = T.obj_inertial[13 * oi + tid];
+            for (int gi = T.obj_geom_adr[oi]; gi < T.obj_geom_adr[oi + 1] && ng < D_MAXGEOM; gi++, ng++) {
+                if (tid < 16) s.lgeom[16 * ng + tid] = T.obj_geoms[18 * gi + 1 + tid];
+                if (tid == 0) s.gobj[ng] = (signed char)k;
+            }
+        }
+        if (tid == 0) { s.ngeom_static = ngs; s.ngeom = ng; s.nobj = nobj; }
     }
     KP_SYNC();
     forward_kin_bias<NT>(s, T, P, depth, bpos, tid);
@@ -809,6 +1320,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 2 : 1)) void kp_step_kernel(StepArg
 #pragma unroll
         for (int n = 0; n < (D_NV + NT - 1) / NT; n++) { int i = tid + n * NT; if (i < D_NV) qd_save_v[n] = s.qvel[i]; }
         forward_kin_bias<NT>(s, T, P, depth, bpos, tid);
+        if constexpr (OBJ) obj_forward(s, P, tid);
         KP_T(1)
         collide_plane<NT, OBJ>(s, T, P, tid);
         KP_T(2)
@@ -822,10 +1334,12 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 2 : 1)) void kp_step_kernel(StepArg
         KP_SYNC();
         aba_solve<NT, OBJ>(s, P, L8, s.smooth, s.qacc_s, false, tid);   // qacc_smooth = M^-1 qfrc_smooth; sv = its spatial accel
         KP_T(4)
-        niter_total += solve_constraints<NT, OBJ>(s, P, L8, depth, tid);
+        if constexpr (OBJ) niter_total += solve_constraints_obj<NT>(s, P, L8, depth, tid);
+        else niter_total += solve_constraints<NT, OBJ>(s, P, L8, depth, tid);
         KP_T(5)
         maxcon = max(maxcon, s.ncon);
         // ---- semi-implicit Euler (mj_Euler, no damping)
+        if constexpr (OBJ) obj_integrate(s, P, tid);       // reads xpos[0] (o) of this substep's forward pass
         for (int i = tid; i < D_NV; i += NT) s.qvel[i] += P.h * s.qacc[i];
         KP_SYNC();
         for (int j = tid; j < D_NU; j += NT) s.qpos[7 + j] += P.h * s.qvel[6 + j];
@@ -862,6 +1376,15 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 2 : 1)) void kp_step_kernel(StepArg
     for (int n = 0; n < (D_NV + NT - 1) / NT; n++) { int i = tid + n * NT; if (i < D_NV) A.qvel_d[(size_t)env * D_NV + i] = qd_save_v[n]; }
     for (int i = tid; i < 72; i += NT) { A.xpos[(size_t)env * 72 + i] = s.xpos[i]; A.xipos[(size_t)env * 72 + i] = s.xipos[i]; }
     for (int i = tid; i < 96; i += NT) A.xquat[(size_t)env * 96 + i] = s.xquat[i];
+    if constexpr (OBJ) {
+        if (A.n_substeps > 0) {
+            for (int k = 0; k < s.nobj; k++) {
+                const int oi = A.obj_slot[(size_t)env * D_MAXOBJ + k];
+                if (tid < 7) { const float v = s.oq[7 * k + tid]; bad |= !(fabsf(v) < 1e10f); A.obj_qpos[(size_t)env * 35 + 7 * oi + tid] = v; }
+                if (tid < 6) { A.obj_qvel[(size_t)env * 30 + 6 * oi + tid] = s.ov[6 * k + tid]; A.obj_warm[(size_t)env * 6 * D_MAXOBJ + 6 * k + tid] = s.oqa[6 * k + tid]; }
+            }
+        }
+    }
     if (bad) atomicOr(&s.flag, 1);
     KP_SYNC();
     if (tid == 0 && A.diag && A.n_substeps > 0) { int* dg = A.diag + 4 * (size_t)env; dg[0] = s.ncon; dg[1] = niter_total; dg[2] = s.flag; dg[3] = maxcon; }

@@ -36,7 +36,7 @@ import xml.etree.ElementTree as ET
 import numpy as np
 
 KPM_MAGIC = 0x314D504B  # 'KPM1'
-KPM_VERSION = 4
+KPM_VERSION = 5
 
 # MuJoCo 2.1.0 defaults that the reference never overrides [MJ-ext]
 MJ_DEFAULTS = dict(
@@ -295,7 +295,7 @@ def compile_model(xml_path: str, uhc_yml: str | None = None) -> dict:
     dof_invw = dinv.copy()
     dof_invw[0:3] = dinv[0:3].mean()
     dof_invw[3:6] = dinv[3:6].mean()
-    meaninertia = float(np.diag(M0).mean())
+    # (meaninertia: see the free-object section below -- it spans all dofs of the scene)
 
     # ---- floor
     fl = px["floor"]
@@ -324,7 +324,9 @@ def compile_model(xml_path: str, uhc_yml: str | None = None) -> dict:
         base_rot = cfg.get("data_specs", {}).get("base_rot", base_rot)
     diffw = np.ones(nb)
 
-    # ---- free objects (recorded; dynamics of objects is a later-round row)
+    # ---- free objects: collision geoms (body frame) + inertial properties from the geoms' explicit `mass=`
+    # (inertiafromgeom) [MJ-ext].  obj_inertial[o] = mass, com[3], inertia about com in body axes (xx yy zz xy xz yz),
+    # invweight0 (translational, rotational), free-joint armature (the <default><joint armature> applies to them).
     obj_geoms = []
     for oi, ob in enumerate(px["objects"]):
         for g in ob["geoms"]:
@@ -339,6 +341,35 @@ def compile_model(xml_path: str, uhc_yml: str | None = None) -> dict:
     for g in obj_geoms:
         obj_geom_adr[int(g[0]) + 1:] += 1
         obj_mass[int(g[0])] += g[17]
+    obj_arm = float(px["joint_default"].get("armature", 0.0))
+    obj_inertial = np.zeros((nobj, 13))
+    obj_trace = 0.0
+    for oi in range(nobj):
+        gs = [g for g in obj_geoms if int(g[0]) == oi]
+        mo = sum(g[17] for g in gs)
+        com = sum(g[17] * g[5:8] for g in gs) / mo
+        Io = np.zeros((3, 3))
+        for g in gs:
+            mg, sz, Rg = g[17], g[2:5], g[8:17].reshape(3, 3)
+            if int(g[1]) == 0:      # box, half sizes
+                Il = np.diag([mg / 3.0 * (sz[1] ** 2 + sz[2] ** 2), mg / 3.0 * (sz[0] ** 2 + sz[2] ** 2), mg / 3.0 * (sz[0] ** 2 + sz[1] ** 2)])
+            else:                   # cylinder along local z: radius, half height
+                ixx = mg * (3.0 * sz[0] ** 2 + (2.0 * sz[1]) ** 2) / 12.0
+                Il = np.diag([ixx, ixx, 0.5 * mg * sz[0] ** 2])
+            dd = g[5:8] - com
+            Io += Rg @ Il @ Rg.T + mg * (dd @ dd * np.eye(3) - np.outer(dd, dd))
+        # generalized mass matrix of the free joint at the identity pose: dofs = [lin (world); ang (body axes, about the body origin)]
+        rx = np.array([[0, -com[2], com[1]], [com[2], 0, -com[0]], [-com[1], com[0], 0]])
+        Jv = np.hstack([np.eye(3), -rx]); Jw = np.hstack([np.zeros((3, 3)), np.eye(3)])
+        Mo = mo * Jv.T @ Jv + Jw.T @ Io @ Jw + obj_arm * np.eye(6)
+        A = np.vstack([Jv, Jw]) @ np.linalg.inv(Mo) @ np.vstack([Jv, Jw]).T
+        obj_inertial[oi] = [mo, *com, Io[0, 0], Io[1, 1], Io[2, 2], Io[0, 1], Io[0, 2], Io[1, 2],
+                            np.trace(A[:3, :3]) / 3.0, np.trace(A[3:, 3:]) / 3.0, obj_arm]
+        obj_trace += float(np.trace(Mo))
+    # mjModel.stat.meaninertia is the mean diagonal of qM at qpos0 over ALL dofs of the scene, objects included, and the
+    # solver's termination scale is 1 / (meaninertia * nv) with the scene's nv [MJ-ext]: both are kept as the reference has them.
+    nv_full = nv + 6 * nobj
+    meaninertia = float((np.trace(M0) + obj_trace) / nv_full)
 
     model = dict(
         dims=np.array([nb, nv, nv + 1, nu, nM, len(verts), len(px["objects"]), len(obj_geoms), condim], np.int32),
@@ -355,8 +386,8 @@ def compile_model(xml_path: str, uhc_yml: str | None = None) -> dict:
         opt=np.array([px["timestep"], *MJ_DEFAULTS["gravity"], *MJ_DEFAULTS["solref"], *MJ_DEFAULTS["solimp"],
                       *fric, geom_margin, MJ_DEFAULTS["impratio"], meaninertia,
                       rfc_scale, rfc_lim, *base_rot,
-                      MJ_DEFAULTS["solver_iterations"], MJ_DEFAULTS["solver_tolerance"]], float),
-        obj_geoms=obj_geoms, obj_geom_adr=obj_geom_adr, obj_mass=obj_mass,
+                      MJ_DEFAULTS["solver_iterations"], MJ_DEFAULTS["solver_tolerance"], nv_full], float),
+        obj_geoms=obj_geoms, obj_geom_adr=obj_geom_adr, obj_mass=obj_mass, obj_inertial=obj_inertial,
         M0=M0,
     )
     model["_names"] = [b["name"] for b in bodies]
@@ -367,7 +398,7 @@ def compile_model(xml_path: str, uhc_yml: str | None = None) -> dict:
 OPT_FIELDS = ["timestep", "gx", "gy", "gz", "solref_tc", "solref_dr", "solimp_d0", "solimp_dw", "solimp_w",
               "solimp_mid", "solimp_pow", "fric_slide", "fric_spin", "fric_roll", "margin", "impratio",
               "meaninertia", "rfc_scale", "rfc_lim", "base_rot_w", "base_rot_x", "base_rot_y", "base_rot_z",
-              "solver_iter", "solver_tol"]
+              "solver_iter", "solver_tol", "nv_full"]
 
 
 def write_kpm(model: dict, path: str):

@@ -20,7 +20,7 @@ DEFAULT_KPM = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets",
 STEP_KPM = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets", "smpl_humanoid_step.kpm")
 
 FIELDS = dict(qpos=0, qvel=1, xpos=2, xquat=3, xipos=4, bquat=5, head=6, target_qpos=7, target_wbpos=8,
-              target_wbquat=9, target_bquat=10, target_com=11, qpos_d=12, qvel_d=13, prev_bquat=14, prev_hpos=15, obj_qpos=16)
+              target_wbquat=9, target_bquat=10, target_com=11, qpos_d=12, qvel_d=13, prev_bquat=14, prev_hpos=15, obj_qpos=16, obj_qvel=17)
 
 _lib = None
 

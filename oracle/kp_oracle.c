@@ -36,6 +36,9 @@
 #define MAXEFC (MAXCON * 4 + 2 * 69)
 #define CON_PER_GEOM 3
 #define MAXGEOM 8
+#define MAXOBJ 2                        /* dynamic free objects per env (push: box + table) */
+#define NVT_MAX (NV_MAX + 6 * MAXOBJ)   /* dofs of the humanoid + the active objects */
+#define OBJ_CON_PER_GEOM 4
 #define MJ_MINVAL 1e-15
 #define MJ_MINIMP 0.0001
 #define MJ_MAXIMP 0.9999
@@ -54,6 +57,7 @@ typedef struct {
     double kp[69], kd[69], torque_lim[69], a_scale[69];
     double timestep, gravity[3], solref[2], solimp[5], friction[3], margin, impratio, meaninertia;
     double rfc_scale, rfc_lim, base_rot[4];
+    int nv_full;   /* dofs of the whole reference scene (humanoid + all objects): solver termination scale */
     int solver_iter;
     double solver_tol;
     /* switches (tests) */
@@ -61,10 +65,19 @@ typedef struct {
 } kpo_model;
 
 /* static collision geometry of the active objects (chair / box / table / Can / step), world frame */
-typedef struct { int type; double size[3], pos[3], mat[9], invw, rbound; } kpo_geom;
+typedef struct { int type; double size[3], pos[3], mat[9], invw, rbound; int obj; /* owning dynamic object slot, -1 = static */ } kpo_geom;
+/* a dynamic free object: inertial constants, body-frame geoms, free-joint state (qpos = pos + quat, qvel = world linear +
+ * body-frame angular velocity, as MuJoCo's free joint) and the quantities of the last forward pass */
+typedef struct {
+    double mass, ipos[3], inertia[6], invw[2], arm;
+    int ngeom; kpo_geom lgeom[MAXGEOM];
+    double qpos[7], qvel[6];
+    double xmat[9], xipos[3], Iw[9], M[36], bias[6];
+} kpo_obj;
 
 typedef struct {
-    int ngeom; kpo_geom geom[MAXGEOM];   /* survives kpo_reset */
+    int ngeom, ngeom_static; kpo_geom geom[MAXGEOM];   /* world-frame geoms: static ones first, then those of the dynamic objects */
+    int nobj; kpo_obj obj[MAXOBJ];                      /* both survive kpo_reset */
     double qpos[NQ_MAX], qvel[NV_MAX];
     double ctrl[69], qfrc_applied[NV_MAX];
     /* derived (state of the last forward pass) */
@@ -75,15 +88,15 @@ typedef struct {
     double cdof[NV_MAX][6], cdof_dot[NV_MAX][6];
     double cvel[NB_MAX][6], cacc[NB_MAX][6], cfrc[NB_MAX][6];
     double qM[NM_MAX], qLD[NM_MAX], qLDiagInv[NV_MAX];
-    double qfrc_bias[NV_MAX], qfrc_smooth[NV_MAX], qacc_smooth[NV_MAX], qacc[NV_MAX];
-    double qacc_warmstart[NV_MAX], qfrc_constraint[NV_MAX];
+    double qfrc_bias[NV_MAX], qfrc_smooth[NVT_MAX], qacc_smooth[NVT_MAX], qacc[NVT_MAX];   /* [humanoid 75 | 6 per object] */
+    double qacc_warmstart[NVT_MAX], qfrc_constraint[NVT_MAX];
     /* contacts */
     int ncon;
-    int con_body[MAXCON];
+    int con_body[MAXCON], con_b2[MAXCON];   /* entity carrying the vertex (0..23 hull, 24+k object k) / the surface (-1 world, 24+k) */
     double con_pos[MAXCON][3], con_dist[MAXCON], con_frame[MAXCON][9], con_invw2[MAXCON];
     /* constraint rows */
     int nefc;
-    double efc_J[MAXEFC][NV_MAX], efc_aref[MAXEFC], efc_D[MAXEFC], efc_force[MAXEFC];
+    double efc_J[MAXEFC][NVT_MAX], efc_aref[MAXEFC], efc_D[MAXEFC], efc_force[MAXEFC];
     int solver_niter;
 } kpo_data;
 
@@ -188,11 +201,11 @@ kpo_model *kpo_model_load(const char *path) {
     { uint64_t c; const void *p = kpm_find(buf, "verts", &c, 0); memcpy(m->verts, p, 8 * 3 * m->nvert); }
     LOADF(m->kp, "kp", m->nu); LOADF(m->kd, "kd", m->nu); LOADF(m->torque_lim, "torque_lim", m->nu);
     LOADF(m->a_scale, "a_scale", m->nu);
-    double opt[25]; LOADF(opt, "opt", 25);
+    double opt[26]; LOADF(opt, "opt", 26);
     m->timestep = opt[0]; memcpy(m->gravity, opt + 1, 24); memcpy(m->solref, opt + 4, 16);
     memcpy(m->solimp, opt + 6, 40); memcpy(m->friction, opt + 11, 24); m->margin = opt[14];
     m->impratio = opt[15]; m->meaninertia = opt[16]; m->rfc_scale = opt[17]; m->rfc_lim = opt[18];
-    memcpy(m->base_rot, opt + 19, 32); m->solver_iter = (int)opt[23]; m->solver_tol = opt[24];
+    memcpy(m->base_rot, opt + 19, 32); m->solver_iter = (int)opt[23]; m->solver_tol = opt[24]; m->nv_full = (int)opt[25];
     m->enable_contact = 1; m->enable_limits = 1;
     free(buf);
     return m;
@@ -342,6 +355,82 @@ static void kpo_vel_bias(const kpo_model *m, kpo_data *d) {
     for (int i = 0; i < m->nv; i++) { double s = 0; for (int c = 0; c < 6; c++) s += d->cdof[i][c] * d->cfrc[m->dof_body[i]][c]; d->qfrc_bias[i] = s; }
 }
 
+/* ------------------------------------------------------------------ dynamic free objects
+ * The same mj_kinematics / mj_crb / mj_rne arithmetic as above, written out for a single free body [MJ-ext].  Dofs of
+ * object k sit at nv + 6k: 3 world-frame translations of the body origin, then 3 rotations about the body axes. */
+static int kpo_nvt(const kpo_model *m, const kpo_data *d) { return m->nv + 6 * d->nobj; }
+static void kpo_obj_forward(const kpo_model *m, kpo_data *d) {
+    d->ngeom = d->ngeom_static;
+    for (int k = 0; k < d->nobj; k++) {
+        kpo_obj *o = &d->obj[k];
+        quat_normalize(o->qpos + 3);
+        quat2mat(o->xmat, o->qpos + 3);
+        const double *R = o->xmat;
+        double r[3]; mat_mulvec(r, R, o->ipos);                       /* com - body origin, world axes */
+        for (int a = 0; a < 3; a++) o->xipos[a] = o->qpos[a] + r[a];
+        const double *Ib = o->inertia;
+        double I3[9] = {Ib[0], Ib[3], Ib[4], Ib[3], Ib[1], Ib[5], Ib[4], Ib[5], Ib[2]}, T[9];
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double v = 0; for (int c = 0; c < 3; c++) v += R[3 * i + c] * I3[3 * c + j]; T[3 * i + j] = v; }
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double v = 0; for (int c = 0; c < 3; c++) v += T[3 * i + c] * R[3 * j + c]; o->Iw[3 * i + j] = v; }
+        for (int gi = 0; gi < o->ngeom && d->ngeom < MAXGEOM; gi++) {
+            const kpo_geom *l = &o->lgeom[gi]; kpo_geom *g = &d->geom[d->ngeom++];
+            *g = *l; g->obj = k; g->invw = o->invw[0];
+            double pw[3]; mat_mulvec(pw, R, l->pos);
+            for (int a = 0; a < 3; a++) g->pos[a] = o->qpos[a] + pw[a];
+            for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double v = 0; for (int c = 0; c < 3; c++) v += R[3 * i + c] * l->mat[3 * c + j]; g->mat[3 * i + j] = v; }
+        }
+        /* velocity Jacobians of (com velocity, angular velocity) w.r.t. the 6 dofs */
+        double Jv[3][6], Jw[3][6];
+        memset(Jv, 0, sizeof(Jv)); memset(Jw, 0, sizeof(Jw));
+        for (int j = 0; j < 3; j++) {
+            Jv[j][j] = 1;
+            double ax[3] = {R[j], R[3 + j], R[6 + j]}, axr[3]; v3_cross(axr, ax, r);
+            for (int a = 0; a < 3; a++) { Jv[a][3 + j] = axr[a]; Jw[a][3 + j] = ax[a]; }
+        }
+        for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) {
+            double v = 0;
+            for (int a = 0; a < 3; a++) v += o->mass * Jv[a][i] * Jv[a][j];
+            for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) v += Jw[a][i] * o->Iw[3 * a + b] * Jw[b][j];
+            o->M[6 * i + j] = v + (i == j ? o->arm : 0.0);
+        }
+        double w[3]; mat_mulvec(w, R, o->qvel + 3);                    /* world angular velocity */
+        double wr[3], wwr[3], Iw_w[3], gyro[3];
+        v3_cross(wr, w, r); v3_cross(wwr, w, wr); mat_mulvec(Iw_w, o->Iw, w); v3_cross(gyro, w, Iw_w);
+        double fl[3] = {o->mass * (wwr[0] - m->gravity[0]), o->mass * (wwr[1] - m->gravity[1]), o->mass * (wwr[2] - m->gravity[2])};
+        for (int i = 0; i < 6; i++) { double v = 0; for (int a = 0; a < 3; a++) v += Jv[a][i] * fl[a] + Jw[a][i] * gyro[a]; o->bias[i] = v; }
+    }
+}
+/* translational Jacobian (times sign) of world point p moving with entity ent (0..23 hull body, 24+k object k) */
+static void kpo_point_jac(const kpo_model *m, const kpo_data *d, int ent, const double *p, double sign, double Jp[3][NVT_MAX]) {
+    if (ent < 0) return;
+    if (ent < NB_MAX) {
+        double r[3] = {p[0] - d->subtree_com[0], p[1] - d->subtree_com[1], p[2] - d->subtree_com[2]};
+        int last = ent == 0 ? 5 : 6 + 3 * (ent - 1) + 2;
+        for (int i = last; i >= 0; i = m->dof_parent[i]) {
+            double wxr[3]; v3_cross(wxr, d->cdof[i], r);
+            for (int k = 0; k < 3; k++) Jp[k][i] += sign * (d->cdof[i][3 + k] + wxr[k]);
+        }
+    } else {
+        const kpo_obj *o = &d->obj[ent - NB_MAX];
+        int base = m->nv + 6 * (ent - NB_MAX);
+        double r[3] = {p[0] - o->qpos[0], p[1] - o->qpos[1], p[2] - o->qpos[2]};
+        for (int j = 0; j < 3; j++) {
+            Jp[j][base + j] += sign;
+            double ax[3] = {o->xmat[j], o->xmat[3 + j], o->xmat[6 + j]}, axr[3]; v3_cross(axr, ax, r);
+            for (int k = 0; k < 3; k++) Jp[k][base + 3 + j] += sign * axr[k];
+        }
+    }
+}
+/* the 8 collision vertices of an object geom (body frame of the geom): box corners (bit 0/1/2 = +x/+y/+z), cylinder
+ * rim points at 0/90/180/270 degrees on the bottom then the top cap.  Engine rule, see kpo_collide. */
+static void kpo_geom_vertex(const kpo_geom *g, int v, double *xw) {
+    double l[3];
+    if (g->type == 0) { l[0] = (v & 1) ? g->size[0] : -g->size[0]; l[1] = (v & 2) ? g->size[1] : -g->size[1]; l[2] = (v & 4) ? g->size[2] : -g->size[2]; }
+    else { static const double cs[4][2] = {{1, 0}, {0, 1}, {-1, 0}, {0, -1}}; l[0] = g->size[0] * cs[v & 3][0]; l[1] = g->size[0] * cs[v & 3][1]; l[2] = (v & 4) ? g->size[1] : -g->size[1]; }
+    mat_mulvec(xw, g->mat, l);
+    for (int a = 0; a < 3; a++) xw[a] += g->pos[a];
+}
+
 /* hull-vs-plane narrow phase.  Engine rule (documented in DESIGN.md): per hull, the up-to-3
  * deepest vertices with dist < margin, ties broken by vertex index; contact point is the midpoint
  * between the vertex and its projection; frame = MuJoCo mju_makeFrame of the plane normal. [MJ-ext] */
@@ -413,8 +502,47 @@ static void kpo_collide(const kpo_model *m, kpo_data *d) {
             for (int k = 0; k < nbest && d->ncon < MAXCON; k++) {
                 int c = d->ncon++;
                 double w[3]; mat_mulvec(w, d->xmat[b], m->verts + 3 * best[k]);
-                d->con_body[c] = b; d->con_dist[c] = bd[k]; d->con_invw2[c] = g ? g->invw : 0.0;
+                d->con_body[c] = b; d->con_b2[c] = (g && g->obj >= 0) ? NB_MAX + g->obj : -1;
+                d->con_dist[c] = bd[k]; d->con_invw2[c] = g ? g->invw : 0.0;
                 for (int a = 0; a < 3; a++) d->con_pos[c][a] = d->xpos[b][a] + w[a] - 0.5 * bd[k] * bn[k][a];
+                memcpy(d->con_frame[c], bn[k], 24);
+                kpo_make_frame(d->con_frame[c]);
+            }
+        }
+    }
+    /* dynamic objects, in slot order: every geom's 8 vertices against the floor, then against the geoms of the objects
+     * in higher slots (push: the box's corners on the table); up to 4 deepest vertices per pair.  Engine rule: MuJoCo's
+     * plane-box / plane-cylinder / box-box routines are not restated. */
+    for (int gi = d->ngeom_static; gi < d->ngeom; gi++) {
+        const kpo_geom *ga = &d->geom[gi];
+        for (int gj = -1; gj < d->ngeom; gj++) {
+            const kpo_geom *gb = gj < 0 ? NULL : &d->geom[gj];
+            if (gb && (gb->obj < 0 || gb->obj <= ga->obj)) continue;
+            if (!gb) { if (ga->pos[2] - ga->rbound > m->margin) continue; }
+            else {
+                double dx[3] = {ga->pos[0] - gb->pos[0], ga->pos[1] - gb->pos[1], ga->pos[2] - gb->pos[2]};
+                if (sqrt(v3_dot(dx, dx)) - ga->rbound - gb->rbound > m->margin) continue;
+            }
+            int best[OBJ_CON_PER_GEOM]; double bd[OBJ_CON_PER_GEOM], bn[OBJ_CON_PER_GEOM][3]; int nbest = 0;
+            for (int v = 0; v < 8; v++) {
+                double xw[3], nrm[3] = {0, 0, 1}, dist;
+                kpo_geom_vertex(ga, v, xw);
+                dist = gb ? kpo_geom_sdf(gb, xw, nrm) : xw[2];
+                if (dist >= m->margin) continue;
+                int pos = nbest;
+                while (pos > 0 && dist < bd[pos - 1]) pos--;
+                if (pos >= OBJ_CON_PER_GEOM) continue;
+                int last = nbest < OBJ_CON_PER_GEOM ? nbest : OBJ_CON_PER_GEOM - 1;
+                for (int k = last; k > pos; k--) { best[k] = best[k - 1]; bd[k] = bd[k - 1]; memcpy(bn[k], bn[k - 1], 24); }
+                best[pos] = v; bd[pos] = dist; memcpy(bn[pos], nrm, 24);
+                if (nbest < OBJ_CON_PER_GEOM) nbest++;
+            }
+            for (int k = 0; k < nbest && d->ncon < MAXCON; k++) {
+                int c = d->ncon++;
+                double xw[3]; kpo_geom_vertex(ga, best[k], xw);
+                d->con_body[c] = NB_MAX + ga->obj; d->con_b2[c] = gb ? NB_MAX + gb->obj : -1;
+                d->con_dist[c] = bd[k]; d->con_invw2[c] = gb ? gb->invw : 0.0;
+                for (int a = 0; a < 3; a++) d->con_pos[c][a] = xw[a] - 0.5 * bd[k] * bn[k][a];
                 memcpy(d->con_frame[c], bn[k], 24);
                 kpo_make_frame(d->con_frame[c]);
             }
@@ -438,7 +566,10 @@ static double kpo_impedance(const kpo_model *m, double pos) {
 
 /* mj_makeConstraint + mj_makeImpedance: joint limits then pyramidal contacts  [MJ-ext] */
 static void kpo_make_constraint(const kpo_model *m, kpo_data *d) {
-    int ne = 0, nv = m->nv;
+    int ne = 0, nv = kpo_nvt(m, d);
+    double qvel[NVT_MAX];
+    memcpy(qvel, d->qvel, sizeof(double) * m->nv);
+    for (int k = 0; k < d->nobj; k++) memcpy(qvel + m->nv + 6 * k, d->obj[k].qvel, 48);
     double tc = fmax(m->solref[0], 2 * m->timestep), dr = m->solref[1], dmax = fmin(MJ_MAXIMP, fmax(MJ_MINIMP, m->solimp[1]));
     double K = 1.0 / (dmax * dmax * tc * tc * dr * dr), B = 2.0 / (dmax * tc);
     if (m->enable_limits) {
@@ -460,17 +591,13 @@ static void kpo_make_constraint(const kpo_model *m, kpo_data *d) {
     }
     for (int c = 0; c < d->ncon; c++) {
         int b = d->con_body[c];
-        /* translational Jacobian of the contact point on body b (world geom has none) */
-        double Jp[3][NV_MAX]; memset(Jp, 0, sizeof(Jp));
-        double r[3] = {d->con_pos[c][0] - d->subtree_com[0], d->con_pos[c][1] - d->subtree_com[1], d->con_pos[c][2] - d->subtree_com[2]};
-        int last = 6 + 3 * (b - 1) + 2; if (b == 0) last = 5;
-        for (int i = last; i >= 0; i = m->dof_parent[i]) {
-            double wxr[3]; v3_cross(wxr, d->cdof[i], r);
-            for (int k = 0; k < 3; k++) Jp[k][i] = d->cdof[i][3 + k] + wxr[k];
-        }
+        /* translational Jacobian of the contact point: entity carrying the vertex minus entity carrying the surface */
+        double Jp[3][NVT_MAX]; memset(Jp, 0, sizeof(Jp));
+        kpo_point_jac(m, d, b, d->con_pos[c], 1.0, Jp);
+        kpo_point_jac(m, d, d->con_b2[c], d->con_pos[c], -1.0, Jp);
         const double *fr = d->con_frame[c];
         double mu = m->friction[0]; /* impratio 1 */
-        double tran = m->body_invweight0[b][0] + d->con_invw2[c];
+        double tran = (b < NB_MAX ? m->body_invweight0[b][0] : d->obj[b - NB_MAX].invw[0]) + d->con_invw2[c];
         double imp = kpo_impedance(m, d->con_dist[c] - m->margin);
         double dA = tran + mu * mu * tran;
         double Rn = fmax(MJ_MINVAL, (1 - imp) * dA / imp);
@@ -482,7 +609,7 @@ static void kpo_make_constraint(const kpo_model *m, kpo_data *d) {
                 double jn = fr[0] * Jp[0][i] + fr[1] * Jp[1][i] + fr[2] * Jp[2][i];
                 double jt = fr[3 * t] * Jp[0][i] + fr[3 * t + 1] * Jp[1][i] + fr[3 * t + 2] * Jp[2][i];
                 d->efc_J[ne][i] = jn + sgn * mu * jt;
-                vel += d->efc_J[ne][i] * d->qvel[i];
+                vel += d->efc_J[ne][i] * qvel[i];
             }
             d->efc_D[ne] = 1.0 / Rpy;
             d->efc_aref[ne] = -B * vel - K * imp * (d->con_dist[c] - m->margin);
@@ -509,9 +636,16 @@ static void chol_solve(const double *L, int n, double *x) {
 }
 
 /* primal cost at qacc: returns cost; fills jar-derived force and gradient */
+static void kpo_mulM_full(const kpo_model *m, const kpo_data *d, const double *v, double *r) {
+    kpo_mulM(m, d->qM, v, r);
+    for (int k = 0; k < d->nobj; k++) for (int i = 0; i < 6; i++) {
+        double s = 0; for (int j = 0; j < 6; j++) s += d->obj[k].M[6 * i + j] * v[m->nv + 6 * k + j];
+        r[m->nv + 6 * k + i] = s;
+    }
+}
 static double kpo_cost(const kpo_model *m, kpo_data *d, const double *qacc, double *grad, double *jar_out) {
-    int nv = m->nv;
-    double Ma[NV_MAX]; kpo_mulM(m, d->qM, qacc, Ma);
+    int nv = kpo_nvt(m, d);
+    double Ma[NVT_MAX]; kpo_mulM_full(m, d, qacc, Ma);
     double cost = 0;
     for (int i = 0; i < nv; i++) cost += 0.5 * (Ma[i] - d->qfrc_smooth[i]) * (qacc[i] - d->qacc_smooth[i]);
     for (int i = 0; i < nv; i++) d->qfrc_constraint[i] = 0;
@@ -528,16 +662,18 @@ static double kpo_cost(const kpo_model *m, kpo_data *d, const double *qacc, doub
 
 /* Newton solver on the primal problem (mj_solNewton) with an exact 1-D line search.  [MJ-ext] */
 static void kpo_solve_constraint(const kpo_model *m, kpo_data *d) {
-    int nv = m->nv, ne = d->nefc;
+    int nv = kpo_nvt(m, d), ne = d->nefc;
     d->solver_niter = 0;
     if (ne == 0) { memcpy(d->qacc, d->qacc_smooth, sizeof(double) * nv); memset(d->qfrc_constraint, 0, sizeof(double) * nv); return; }
-    double H[NV_MAX * NV_MAX], Mfull[NV_MAX * NV_MAX];
-    double qacc[NV_MAX], grad[NV_MAX], jar[MAXEFC], search[NV_MAX], jv[MAXEFC], Mv[NV_MAX];
+    static double H[NVT_MAX * NVT_MAX], Mfull[NVT_MAX * NVT_MAX];
+    double qacc[NVT_MAX], grad[NVT_MAX], jar[MAXEFC], search[NVT_MAX], jv[MAXEFC], Mv[NVT_MAX];
     /* warmstart choice */
     double cw = kpo_cost(m, d, d->qacc_warmstart, NULL, NULL), cs = kpo_cost(m, d, d->qacc_smooth, NULL, NULL);
     memcpy(qacc, cw < cs ? d->qacc_warmstart : d->qacc_smooth, sizeof(double) * nv);
-    kpo_fullM(m, d, Mfull);
-    double scale = 1.0 / (m->meaninertia * (nv > 1 ? nv : 1));
+    memset(Mfull, 0, sizeof(double) * nv * nv);
+    for (int i = 0; i < m->nv; i++) { int adr = m->dof_madr[i]; for (int j = i; j >= 0; j = m->dof_parent[j], adr++) Mfull[i * nv + j] = Mfull[j * nv + i] = d->qM[adr]; }
+    for (int k = 0; k < d->nobj; k++) for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) Mfull[(m->nv + 6 * k + i) * nv + m->nv + 6 * k + j] = d->obj[k].M[6 * i + j];
+    double scale = 1.0 / (m->meaninertia * (m->nv_full > 1 ? m->nv_full : 1));   /* scene-wide constants of the reference model */
     double cost = kpo_cost(m, d, qacc, grad, jar);
     for (int it = 0; it < m->solver_iter; it++) {
         memcpy(H, Mfull, sizeof(double) * nv * nv);
@@ -550,7 +686,7 @@ static void kpo_solve_constraint(const kpo_model *m, kpo_data *d) {
         for (int i = 0; i < nv; i++) search[i] = -grad[i];
         chol_solve(H, nv, search);
         /* exact line search: phi(a) = cost(qacc + a*search), piecewise quadratic convex */
-        kpo_mulM(m, d->qM, search, Mv);
+        kpo_mulM_full(m, d, search, Mv);
         for (int e = 0; e < ne; e++) { double s = 0; for (int i = 0; i < nv; i++) s += d->efc_J[e][i] * search[i]; jv[e] = s; }
         double g0 = 0, h0 = 0; /* Gauss part: derivative at alpha: g0 + alpha*h0 */
         for (int i = 0; i < nv; i++) { g0 += search[i] * (grad[i] + d->qfrc_constraint[i]); h0 += search[i] * Mv[i]; }
@@ -581,11 +717,18 @@ void kpo_forward(const kpo_model *m, kpo_data *d) {
     kpo_kinematics(m, d);
     kpo_crb(m, d);
     kpo_factor_sparse(m, d->qM, d->qLD, d->qLDiagInv);
+    kpo_obj_forward(m, d);
     kpo_collide(m, d);
     kpo_vel_bias(m, d);
     for (int i = 0; i < nv; i++) d->qfrc_smooth[i] = -d->qfrc_bias[i] + d->qfrc_applied[i] + (i >= 6 ? d->ctrl[i - 6] : 0.0);
     memcpy(d->qacc_smooth, d->qfrc_smooth, sizeof(double) * nv);
     kpo_solve_sparse(m, d->qLD, d->qLDiagInv, d->qacc_smooth);
+    for (int k = 0; k < d->nobj; k++) {
+        double L[36], x[6]; memcpy(L, d->obj[k].M, sizeof(L));
+        for (int i = 0; i < 6; i++) { x[i] = -d->obj[k].bias[i]; d->qfrc_smooth[nv + 6 * k + i] = x[i]; }
+        chol_factor(L, 6); chol_solve(L, 6, x);
+        memcpy(d->qacc_smooth + nv + 6 * k, x, 48);
+    }
     kpo_make_constraint(m, d);
     kpo_solve_constraint(m, d);
 }
@@ -594,7 +737,15 @@ void kpo_forward(const kpo_model *m, kpo_data *d) {
 void kpo_step(const kpo_model *m, kpo_data *d) {
     double h = m->timestep;
     kpo_forward(m, d);
-    memcpy(d->qacc_warmstart, d->qacc, sizeof(double) * m->nv);
+    memcpy(d->qacc_warmstart, d->qacc, sizeof(double) * kpo_nvt(m, d));
+    for (int k = 0; k < d->nobj; k++) {
+        kpo_obj *o = &d->obj[k];
+        for (int i = 0; i < 6; i++) o->qvel[i] += h * d->qacc[m->nv + 6 * k + i];
+        for (int i = 0; i < 3; i++) o->qpos[i] += h * o->qvel[i];
+        double *ow = o->qvel + 3, on = sqrt(v3_dot(ow, ow)), oq[4] = {1, 0, 0, 0}, onew[4];
+        if (on >= MJ_MINVAL) { double ang = h * on, sn = sin(0.5 * ang) / on; oq[0] = cos(0.5 * ang); oq[1] = ow[0] * sn; oq[2] = ow[1] * sn; oq[3] = ow[2] * sn; }
+        quat_normalize(o->qpos + 3); quat_mul(onew, o->qpos + 3, oq); memcpy(o->qpos + 3, onew, 32);
+    }
     for (int i = 0; i < m->nv; i++) d->qvel[i] += h * d->qacc[i];
     for (int k = 0; k < 3; k++) d->qpos[k] += h * d->qvel[k];
     double *w = d->qvel + 3, n = sqrt(v3_dot(w, w));
@@ -607,9 +758,11 @@ void kpo_step(const kpo_model *m, kpo_data *d) {
 
 /* set_state + sim.forward()  (mujoco_env.py:97-103); sim.reset() zeroes ctrl / qfrc_applied / warmstart */
 void kpo_reset(const kpo_model *m, kpo_data *d, const double *qpos, const double *qvel) {
-    int ng = d->ngeom; kpo_geom gsave[MAXGEOM]; memcpy(gsave, d->geom, sizeof(gsave));
+    int ng = d->ngeom_static, no = d->nobj; kpo_geom gsave[MAXGEOM]; memcpy(gsave, d->geom, sizeof(gsave));
+    static kpo_obj osave[MAXOBJ]; memcpy(osave, d->obj, sizeof(osave));
     memset(d, 0, sizeof(*d));
-    d->ngeom = ng; memcpy(d->geom, gsave, sizeof(gsave));
+    d->ngeom = d->ngeom_static = ng; memcpy(d->geom, gsave, sizeof(gsave));
+    d->nobj = no; memcpy(d->obj, osave, sizeof(osave));
     memcpy(d->qpos, qpos, sizeof(double) * m->nq); memcpy(d->qvel, qvel, sizeof(double) * m->nv);
     kpo_forward(m, d);
 }
@@ -668,13 +821,35 @@ void kpo_do_simulation(const kpo_model *m, kpo_data *d, const double *action, co
 
 /* n x 17 doubles: type (0 box, 1 cylinder), size[3], pos[3], mat[9] (world), invweight of the owning object */
 void kpo_set_geoms(kpo_data *d, int n, const double *p) {
-    d->ngeom = n > MAXGEOM ? MAXGEOM : n;
+    d->ngeom = d->ngeom_static = n > MAXGEOM ? MAXGEOM : n;
     for (int i = 0; i < d->ngeom; i++, p += 17) {
-        kpo_geom *g = &d->geom[i];
+        kpo_geom *g = &d->geom[i]; g->obj = -1;
         g->type = (int)p[0]; memcpy(g->size, p + 1, 24); memcpy(g->pos, p + 4, 24); memcpy(g->mat, p + 7, 72); g->invw = p[16];
         g->rbound = g->type == 0 ? sqrt(v3_dot(g->size, g->size)) : sqrt(g->size[0] * g->size[0] + g->size[1] * g->size[1]);
     }
 }
+
+/* dynamic objects: inertial[13] = mass, com[3], inertia[6], invweight (tran, rot), armature; geoms [ng][16] body frame =
+ * type, size[3], pos[3], mat[9]; state qpos[7], qvel[6].  kpo_set_objects(d, 0, ..) removes them. */
+void kpo_set_object(kpo_data *d, int k, const double *inertial, int ng, const double *geoms, const double *qpos7, const double *qvel6) {
+    if (k < 0 || k >= MAXOBJ) return;
+    kpo_obj *o = &d->obj[k];
+    memset(o, 0, sizeof(*o));
+    o->mass = inertial[0]; memcpy(o->ipos, inertial + 1, 24); memcpy(o->inertia, inertial + 4, 48); o->invw[0] = inertial[10]; o->invw[1] = inertial[11]; o->arm = inertial[12];
+    o->ngeom = ng > MAXGEOM ? MAXGEOM : ng;
+    for (int i = 0; i < o->ngeom; i++, geoms += 16) {
+        kpo_geom *g = &o->lgeom[i];
+        g->type = (int)geoms[0]; memcpy(g->size, geoms + 1, 24); memcpy(g->pos, geoms + 4, 24); memcpy(g->mat, geoms + 7, 72);
+        g->rbound = g->type == 0 ? sqrt(v3_dot(g->size, g->size)) : sqrt(g->size[0] * g->size[0] + g->size[1] * g->size[1]);
+    }
+    memcpy(o->qpos, qpos7, 56); memcpy(o->qvel, qvel6, 48);
+    if (k + 1 > d->nobj) d->nobj = k + 1;
+}
+void kpo_clear_objects(kpo_data *d) { d->nobj = 0; d->ngeom = d->ngeom_static; }
+void kpo_get_object(const kpo_data *d, int k, double *qpos7, double *qvel6) { memcpy(qpos7, d->obj[k].qpos, 56); memcpy(qvel6, d->obj[k].qvel, 48); }
+void kpo_get_object_dyn(const kpo_data *d, int k, double *M36, double *bias6) { memcpy(M36, d->obj[k].M, 288); memcpy(bias6, d->obj[k].bias, 48); }
+void kpo_get_qacc_full(const kpo_data *d, double *out) { memcpy(out, d->qacc, sizeof(double) * NVT_MAX); }
+void kpo_get_contact_pairs(const kpo_data *d, int *b1, int *b2) { for (int c = 0; c < d->ncon; c++) { b1[c] = d->con_body[c]; b2[c] = d->con_b2[c]; } }
 
 /* ------------------------------------------------------------------ accessors for ctypes */
 #define GETTER(name, field, n) void kpo_get_##name(const kpo_data *d, double *out) { memcpy(out, d->field, sizeof(double) * (n)); }
@@ -684,6 +859,7 @@ GETTER(subtree_com, subtree_com, 3) GETTER(ctrl, ctrl, 69) GETTER(qfrc_applied, 
 GETTER(cvel, cvel, 144)
 void kpo_get_efc(const kpo_data *d, double *force, double *D, double *aref) { memcpy(force, d->efc_force, 8 * d->nefc); memcpy(D, d->efc_D, 8 * d->nefc); memcpy(aref, d->efc_aref, 8 * d->nefc); }
 void kpo_get_efc_J(const kpo_data *d, double *J) { for (int e = 0; e < d->nefc; e++) memcpy(J + (size_t)e * NV_MAX, d->efc_J[e], 8 * NV_MAX); }
+void kpo_get_efc_J_full(const kpo_data *d, double *J) { for (int e = 0; e < d->nefc; e++) memcpy(J + (size_t)e * NVT_MAX, d->efc_J[e], 8 * NVT_MAX); }
 int kpo_get_ncon(const kpo_data *d) { return d->ncon; }
 int kpo_get_nefc(const kpo_data *d) { return d->nefc; }
 int kpo_get_niter(const kpo_data *d) { return d->solver_niter; }

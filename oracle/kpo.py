@@ -51,6 +51,13 @@ def lib():
         L.kpo_solveM.argtypes = [P, P, D]
         L.kpo_get_contacts.argtypes = [P, I, D, D]
         L.kpo_set_geoms.argtypes = [P, C.c_int, D]
+        L.kpo_set_object.argtypes = [P, C.c_int, D, C.c_int, D, D, D]
+        L.kpo_clear_objects.argtypes = [P]
+        L.kpo_get_object.argtypes = [P, C.c_int, D, D]
+        L.kpo_get_object_dyn.argtypes = [P, C.c_int, D, D]
+        L.kpo_get_qacc_full.argtypes = [P, D]
+        L.kpo_get_efc_J_full.argtypes = [P, D]
+        L.kpo_get_contact_pairs.argtypes = [P, I, I]
         L.kpo_get_efc.argtypes = [P, D, D, D]
         L.kpo_get_efc_J.argtypes = [P, D]
         L.kpo_rollout_batch.argtypes = [P, C.c_int, D, D, D, D, C.c_int, C.c_int]
@@ -106,6 +113,35 @@ class OracleSim:
         """packed [n,17]: type, size3, pos3, R9 (world), invweight (see object_geoms())."""
         g = np.ascontiguousarray(packed, np.float64).reshape(-1, 17)
         self.L.kpo_set_geoms(self.d, g.shape[0], _dp(g))
+
+    def set_object(self, slot, kpm: dict, obj_index, qpos7, qvel6=None):
+        """Make object `obj_index` of the compiled model (chair, box, table, Can, step) the dynamic free body in `slot` (0/1)."""
+        inert = np.ascontiguousarray(kpm["obj_inertial"].reshape(-1, 13)[obj_index], np.float64)
+        og = kpm["obj_geoms"].reshape(-1, 18)
+        g = np.ascontiguousarray(og[og[:, 0].astype(int) == obj_index][:, 1:17], np.float64)
+        q = np.ascontiguousarray(qpos7, np.float64); v = np.zeros(6) if qvel6 is None else np.ascontiguousarray(qvel6, np.float64)
+        self.L.kpo_set_object(self.d, slot, _dp(inert), g.shape[0], _dp(g), _dp(q), _dp(v))
+
+    def clear_objects(self):
+        self.L.kpo_clear_objects(self.d)
+
+    def get_object(self, slot):
+        q, v = np.zeros(7), np.zeros(6); self.L.kpo_get_object(self.d, slot, _dp(q), _dp(v)); return q, v
+
+    def object_dyn(self, slot):
+        M, b = np.zeros((6, 6)), np.zeros(6); self.L.kpo_get_object_dyn(self.d, slot, _dp(M), _dp(b)); return M, b
+
+    def qacc_full(self):
+        out = np.zeros(NV + 12); self.L.kpo_get_qacc_full(self.d, _dp(out)); return out
+
+    def efc_J_full(self):
+        n = self.nefc; J = np.zeros((max(n, 1), NV + 12)); self.L.kpo_get_efc_J_full(self.d, _dp(J)); return J[:n]
+
+    def contact_pairs(self):
+        n = self.L.kpo_get_ncon(self.d)
+        b1 = np.zeros(64, np.int32); b2 = np.zeros(64, np.int32)
+        self.L.kpo_get_contact_pairs(self.d, b1.ctypes.data_as(C.POINTER(C.c_int)), b2.ctypes.data_as(C.POINTER(C.c_int)))
+        return b1[:n], b2[:n]
 
     def forward(self):
         self.L.kpo_forward(self.m, self.d)

@@ -288,6 +288,7 @@ def test_object_contact_matches_oracle(kp):
     action = rng.normal(size=(n, 75)) * 0.1
     blk = _obj_block(n, [c[0] for c in cases])
     model = kp.KpModel(STEP_KPM)
+    model.set_option("dynamic_objects", 0)          # this test: objects frozen as static obstacles
     sim = kp.KpSim(model, n)
     sim.set_objects(dev(blk))
     sim.set_state(dev(qpos), dev(qvel)); sim.set_target(dev(qpos))
@@ -316,3 +317,67 @@ def test_object_contact_matches_oracle(kp):
     # the object cases really produced object contacts (more than the floor alone) or changed the motion
     floor_only = got[-1]
     assert np.abs(got[0] - floor_only).max() > 0.05 and np.abs(got[2] - floor_only).max() > 1e-3
+
+
+def test_dynamic_objects_match_oracle(kp):
+    """Free-body dynamics of the active objects (object-floor, box-on-table, hull-object contacts coupled through the
+    Newton solve) against the oracle: humanoid and object trajectories after 3 control steps."""
+    from kinpoly_amd.model_compiler import STEP_KPM
+    kpm = read_kpm(STEP_KPM)
+    x0, y0 = STD["qpos"][0], STD["qpos"][1]
+    fk = O.qpos_fk(STD["qpos"], BODY_POS, BODY_IPOS, PARENT)
+    verts, vadr = kpm["verts"].reshape(-1, 3), kpm["vert_adr"]
+    tip = max((fk["wbpos"][b] + verts[vadr[b]:vadr[b + 1]] @ O.quaternion_matrix3(fk["wbquat"][b]).T)[:, 0].max() for b in (4, 8))
+    tilt = np.array([np.cos(0.3), np.sin(0.3) * 0.6, np.sin(0.3) * 0.8, 0.0])
+    cases = [
+        ({1: [x0 + 1.5, y0, 0.30, *tilt]}, 0.0),                                  # tilted box dropped next to the humanoid: impact + tumble
+        ({1: [x0 + 1.2, y0, 0.921, 1, 0, 0, 0], 2: [x0 + 1.2, y0, 0.7905, 1, 0, 0, 0]}, 0.0),  # push scene: box resting on the table
+        ({4: [x0, y0, 0.3705, 1, 0, 0, 0]}, 0.341),                               # standing on the (40 kg) step (top at 0.3405)
+        ({3: [x0 + 0.36, y0 + 0.05, 0.69, 1, 0, 0, 0]}, 0.0),                     # Can against the legs
+        ({1: [tip + 0.15 - 0.004, y0, 0.2205, 1, 0, 0, 0]}, 0.0),                 # 1 kg box on the floor, 4 mm into the toe tips
+        ({0: [tip + 0.209 - 0.004, y0, 0.3805, 1, 0, 0, 0]}, 0.0),                # chair (100 t) at the toe tips
+    ]
+    n = len(cases)
+    rng = np.random.default_rng(22)
+    qpos = np.tile(STD["qpos"], (n, 1)); qvel = rng.normal(size=(n, 75)) * 0.1
+    for e, (_, lift) in enumerate(cases):
+        qpos[e, 2] += lift
+    action = rng.normal(size=(n, 75)) * 0.1
+    blk = _obj_block(n, [c[0] for c in cases])
+    model = kp.KpModel(STEP_KPM)
+    assert model.get_option("dynamic_objects") == 1
+    sim = kp.KpSim(model, n)
+    sim.set_objects(dev(blk))
+    sim.set_state(dev(qpos), dev(qvel)); sim.set_target(dev(qpos))
+    a = dev(action)
+    nstep = 3
+    for _ in range(nstep):
+        sim.step_ctrl(a, 15)
+    got = sim.get("qpos").double().cpu().numpy()
+    gobj = sim.get("obj_qpos").double().cpu().numpy(); gobjv = sim.get("obj_qvel").double().cpu().numpy()
+    dg = sim.diag()
+    assert dg[:, 2].max() == 0
+    errs, oerrs, moved = [], [], []
+    for e in range(n):
+        o = OracleSim(kpm=STEP_KPM)
+        for slot, oi in enumerate(sorted(cases[e][0])):
+            o.set_object(slot, kpm, oi, cases[e][0][oi])
+        o.reset(qpos[e], qvel[e])
+        for _ in range(nstep):
+            o.do_simulation(action[e], qpos[e], 15)
+        errs.append(np.abs(o.get("qpos") - got[e]).max())
+        oe, mv = 0.0, 0.0
+        for slot, oi in enumerate(sorted(cases[e][0])):
+            oq, ov = o.get_object(slot)
+            oe = max(oe, np.abs(oq - gobj[e, 7 * oi: 7 * oi + 7]).max(), 0.1 * np.abs(ov - gobjv[e, 6 * oi: 6 * oi + 6]).max())
+            mv = max(mv, np.abs(oq - np.asarray(cases[e][0][oi], float)).max())
+        oerrs.append(oe); moved.append(mv)
+        # parked objects are untouched
+        for oi in range(5):
+            if oi not in cases[e][0]:
+                np.testing.assert_allclose(gobj[e, 7 * oi: 7 * oi + 7], blk[e, 7 * oi: 7 * oi + 7], atol=1e-4)
+    print("dynamic objects |dqpos| humanoid:", ["%.2e" % x for x in errs], "object:", ["%.2e" % x for x in oerrs], "object moved:", ["%.3f" % x for x in moved],
+          "newton iters", dg[:, 1].tolist(), "ncon", dg[:, 0].tolist())
+    assert max(errs) < 1e-3 and np.median(errs) < 2e-4
+    assert max(oerrs) < 1e-3 and np.median(oerrs) < 2e-4
+    assert moved[0] > 0.02 and moved[4] > 1e-4          # the dropped box fell; the light box was pushed by the toes
