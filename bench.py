@@ -169,7 +169,7 @@ def main():
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "note": "latency/VALU-bound tree recursion with state resident in LDS: compulsory HBM traffic is tiny by construction (DESIGN.md)"},
             "kernel_share_of_step": kern_s / (elapsed / args.steps),
-            "contacts_mean": float(diag[:, 0].mean()), "newton_iters_per_substep": float(diag[:, 1].mean() / 15.0), "bad_envs": int((diag[:, 2] != 0).sum()),
+            "contacts_mean": float(diag[:, 0].mean()), "newton_iters_per_substep": float(diag[:, 1].mean() / 15.0), "hessian_factorisations_per_substep": float((diag[:, 3] >> 8).mean() / 15.0), "bad_envs": int((diag[:, 2] != 0).sum()),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(std)

@@ -153,7 +153,7 @@ int kp_field_dim(int field);
 int kp_sim_get(kp_sim*, int field, float* out);
 
 /* per-env diagnostics of the last kp_sim_step_ctrl: int32 [N,4] = {contacts in last substep,
- * Newton iterations (sum over substeps), flags (1 = non-finite state), max contacts}.  HOST pointer;
+ * Newton iterations (sum over substeps), flags (1 = non-finite state), max contacts | Hessian factorisations << 8}.  HOST pointer;
  * synchronises the stream. */
 int kp_sim_diag(kp_sim*, int32_t* out_host);
 

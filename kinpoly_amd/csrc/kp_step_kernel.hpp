@@ -777,10 +777,25 @@ __device__ __forceinline__ void spatial_accumulate(EnvLds& s, const float* vec, 
     }
 }
 
+// records the active pyramid rows of every contact; returns 1 on the lanes that saw a change since the last call
+template <int NT>
+__device__ __forceinline__ float active_set_changed(EnvLds& s, const Params& P, int tid) {
+    float changed = 0.f;
+    for (int c = tid; c < s.ncon; c += NT) {
+        const float jn = s.jar3[3 * c], jt1 = s.jar3[3 * c + 1], jt2 = s.jar3[3 * c + 2];
+        unsigned m = 0;
+#pragma unroll
+        for (int e = 0; e < 4; e++) m |= (row_val(e, P.mu, jn, jt1, jt2) < 0.f ? 1u : 0u) << e;
+        if (m != s.con_act[c]) changed = 1.f;
+        s.con_act[c] = (unsigned char)m;
+    }
+    return changed;
+}
+
 // constraint solve: Newton on the primal problem (mj_solNewton) with an exact line search.  Returns iterations.
 // On entry sv holds the spatial accelerations of qacc_s (left by the smooth aba_solve), jv3 holds aref.
 template <int NT, bool OBJ>
-__device__ __forceinline__ int solve_constraints(EnvLds& s, const Params& P, const Lane8& L8, int depth, int tid) {
+__device__ __forceinline__ int solve_constraints(EnvLds& s, const Params& P, const Lane8& L8, int depth, int tid, int& nfact) {
     if (s.ncon == 0 && s.nlim == 0) {
         for (int i = tid; i < D_NV; i += NT) s.qacc[i] = s.qacc_s[i];
         KP_SYNC();
@@ -812,18 +827,24 @@ __device__ __forceinline__ int solve_constraints(EnvLds& s, const Params& P, con
     for (; it < P.max_iter; it++) {
         // gradient = mres - J^T f
         wrench_project<NT, OBJ>(s, P, nullptr, s.grad, false, true, tid);
-        float g2 = 0.f;
+        float g2 = 0.f, changed = 0.f;
         for (int i = tid; i < D_NV; i += NT) {
             float g = s.mres[i] + s.grad[i];
             s.grad[i] = g; g2 += g * g;
             s.x[i] = -g;
-            s.extra[i] = (i >= 6 && s.lim_jar[i - 6] < 0.f) ? s.lim_D[i - 6] : 0.f;
+            const float ex = (i >= 6 && s.lim_jar[i - 6] < 0.f) ? s.lim_D[i - 6] : 0.f;
+            if (ex != s.extra[i]) changed = 1.f;
+            s.extra[i] = ex;
         }
+        changed += active_set_changed<NT>(s, P, tid);
         g2 = block_sum<NT>(s, g2, tid);
+        changed = block_sum<NT>(s, changed, tid);
         KP_SYNC();
         if (P.scale * sqrtf(g2) < P.tol) break;
-        // search = -H^-1 grad,  H = M + J^T D_active J : articulated-body pass with contact inertia
-        aba_solve<NT, OBJ>(s, P, L8, s.x, s.search, true, tid);
+        // search = -H^-1 grad,  H = M + J^T D_active J : articulated-body pass with contact inertia; while the active set
+        // stands the factorisation of the previous iteration is reused (mj_solNewton updates its Cholesky factor the same way)
+        if (it == 0 || changed > 0.f) { aba_solve<NT, OBJ>(s, P, L8, s.x, s.search, true, tid); nfact++; }
+        else aba_resolve(s, L8, s.x, nullptr, s.search);
         eval_rows<NT, OBJ>(s, s.search, s.jv3, s.lim_jv, false, tid);           // aref (in jv3) is folded into jar3 by now
         wrench_project<NT, OBJ>(s, P, s.search, s.Mv, true, false, tid);
         // exact line search on phi(alpha)
@@ -979,7 +1000,22 @@ __device__ __forceinline__ void dense_solve(EnvLdsObj& s, int n, int tid) {
         if (tid > j && tid < n) {
             const float l = s.Sm[tid * ST + j] / s.Sm[j * ST + j];
             for (int c = j + 1; c <= n; c++) s.Sm[tid * ST + c] -= l * s.Sm[j * ST + c];
+            s.Sm[tid * ST + j] = l;                         // keep the multiplier for dense_resolve
         }
+        KP_SYNC();
+    }
+    for (int j = n - 1; j >= 0; j--) {
+        if (tid == j) s.Sm[j * ST + n] /= s.Sm[j * ST + j];
+        KP_SYNC();
+        if (tid < j) s.Sm[tid * ST + n] -= s.Sm[tid * ST + j] * s.Sm[j * ST + n];
+        KP_SYNC();
+    }
+}
+// a new right-hand side (column n) through the factors dense_solve left in place
+__device__ __forceinline__ void dense_resolve(EnvLdsObj& s, int n, int tid) {
+    constexpr int ST = 6 * D_MAXOBJ + 1;
+    for (int j = 0; j < n; j++) {
+        if (tid > j && tid < n) s.Sm[tid * ST + n] -= s.Sm[tid * ST + j] * s.Sm[j * ST + n];
         KP_SYNC();
     }
     for (int j = n - 1; j >= 0; j--) {
@@ -1077,7 +1113,7 @@ __device__ __forceinline__ void obj_integrate(EnvLdsObj& s, const Params& P, int
 // (q_humanoid, a_object...).  The Newton system is solved exactly by block elimination: the articulated-body pass factorises
 // the humanoid block, 6 n_obj + 1 bias-only passes form the Schur complement on the objects when a hull touches one.
 template <int NT>
-__device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params& P, const Lane8& L8, int depth, int tid) {
+__device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params& P, const Lane8& L8, int depth, int tid, int& nfact) {
     constexpr int ST = 6 * D_MAXOBJ + 1;
     const int nobj = s.nobj, no6 = 6 * nobj;
     // smooth acceleration of the objects: I_eff a = -bias wrench
@@ -1147,22 +1183,28 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
             sts6(s.ogr + 6 * tid, g);
         }
         KP_SYNC();
-        float g2 = 0.f;
+        float g2 = 0.f, changed = 0.f;
         for (int i = tid; i < D_NV; i += NT) {
             const float g = s.mres[i] + s.grad[i];
             s.grad[i] = g; g2 += g * g;
             s.x[i] = -g;
-            s.extra[i] = (i >= 6 && s.lim_jar[i - 6] < 0.f) ? s.lim_D[i - 6] : 0.f;
+            const float ex = (i >= 6 && s.lim_jar[i - 6] < 0.f) ? s.lim_D[i - 6] : 0.f;
+            if (ex != s.extra[i]) changed = 1.f;
+            s.extra[i] = ex;
         }
+        changed += active_set_changed<NT>(s, P, tid);
         if (tid < nobj) {   // gradient in joint coordinates: [g_l ; R^T (g_a + r x g_l)], r = o - body origin
             const S6 g = lds6(s.ogr + 6 * tid);
             const V3 t = g.a + cross(ld3(s.xpos) - ld3(s.oq + 7 * tid), g.l);
             g2 += dot(g.l, g.l) + dot(t, t);
         }
         g2 = block_sum<NT>(s, g2, tid);
+        changed = block_sum<NT>(s, changed, tid);
         KP_SYNC();
         if (P.scale * sqrtf(g2) < P.tol) break;
         // search direction
+        const bool refactor = it == 0 || changed > 0.f;
+        nfact += refactor;
         bool couple = false;
         for (int c = tid; c < s.con_start[D_NB]; c += NT) {
             if (s.con_b2[c] < D_NB) continue;
@@ -1171,11 +1213,24 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
             for (int e = 0; e < 4; e++) couple |= row_val(e, P.mu, jn, jt1, jt2) < 0.f;
         }
         couple = __ballot(couple) != 0ull;
-        if (no6 > 0) obj_hessian(s, P, s.ogr, -1.0f, tid);
-        if (!couple) {
+        if (!refactor) {
+            // same active set as the previous iteration: the articulated-body factors and the eliminated object system stand
+            aba_resolve(s, L8, s.x, nullptr, s.search);
+            if (no6 > 0) {
+                if (tid < no6) s.Sm[ST * tid + no6] = -s.ogr[tid];
+                KP_SYNC();
+                if (couple) { obj_coupling_u(s, P, s.ot, tid); if (tid < no6) s.Sm[ST * tid + no6] += s.ot[tid]; KP_SYNC(); }
+                dense_resolve(s, no6, tid);
+                if (tid < no6) s.osrch[tid] = s.Sm[ST * tid + no6];
+                KP_SYNC();
+                if (couple) { hull_coupling_wrench(s, P, -1, s.osrch, 1.0f, tid); aba_resolve(s, L8, s.x, s.sw, s.search); }
+            }
+        } else if (!couple) {
+            if (no6 > 0) obj_hessian(s, P, s.ogr, -1.0f, tid);
             aba_solve<NT, true>(s, P, L8, s.x, s.search, true, tid);
             if (no6 > 0) { dense_solve(s, no6, tid); if (tid < no6) s.osrch[tid] = s.Sm[ST * tid + no6]; KP_SYNC(); }
         } else {
+            obj_hessian(s, P, s.ogr, -1.0f, tid);
             aba_solve<NT, true>(s, P, L8, s.x, s.search, true, tid);          // factorisation + y0 = H_hh^-1 (-g_h)
             obj_coupling_u(s, P, s.ot, tid);                                    // -H_oh y0
             if (tid < no6) s.Sm[ST * tid + no6] += s.ot[tid];
@@ -1264,8 +1319,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 2 : 1)) void kp_step_kernel(StepArg
         s.qvel[i] = A.qvel_d[(size_t)env * D_NV + i]; s.act[i] = A.action ? A.action[(size_t)env * D_NV + i] : 0.f;
         s.arm[i] = T.dof_armature[i]; s.dbody[i] = T.dof_body[i]; s.extra[i] = 0.f; s.qacc[i] = A.warm[(size_t)env * D_NV + i];
     }
-    if (tid < D_NB) { s.bpar[tid] = (unsigned char)(T.body_parent[tid] < 0 ? 0 : T.body_parent[tid]); s.bsub[tid] = T.body_subtree[tid]; s.levb[tid] = T.lev_body[tid]; }
-    if (tid < D_NLEV + 2) s.levs[tid] = T.lev_start[tid];
+    if (tid < D_NB) { s.bpar[tid] = (unsigned char)(T.body_parent[tid] < 0 ? 0 : T.body_parent[tid]); s.bsub[tid] = T.body_subtree[tid]; }
     if (tid < 8) s.applied[tid] = 0.f;
     if (tid < 25) s.IAa[22 * tid + 21] = 0.f;
     if (tid < 22) s.IAa[22 * 24 + tid] = 0.f;
@@ -1304,7 +1358,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 2 : 1)) void kp_step_kernel(StepArg
         for (int i = tid; i < D_NV; i += NT) s.qvel[i] = A.qvel[(size_t)env * D_NV + i];
         KP_SYNC();
     }
-    int niter_total = 0, maxcon = 0;
+    int niter_total = 0, maxcon = 0, nfact_total = 0;
     unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
     const bool prof = A.prof != nullptr;
 #define KP_T(i) if (prof) { t1 = __builtin_readcyclecounter(); pc[i] += t1 - t0; t0 = t1; }
@@ -1334,8 +1388,8 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 2 : 1)) void kp_step_kernel(StepArg
         KP_SYNC();
         aba_solve<NT, OBJ>(s, P, L8, s.smooth, s.qacc_s, false, tid);   // qacc_smooth = M^-1 qfrc_smooth; sv = its spatial accel
         KP_T(4)
-        if constexpr (OBJ) niter_total += solve_constraints_obj<NT>(s, P, L8, depth, tid);
-        else niter_total += solve_constraints<NT, OBJ>(s, P, L8, depth, tid);
+        if constexpr (OBJ) niter_total += solve_constraints_obj<NT>(s, P, L8, depth, tid, nfact_total);
+        else niter_total += solve_constraints<NT, OBJ>(s, P, L8, depth, tid, nfact_total);
         KP_T(5)
         maxcon = max(maxcon, s.ncon);
         // ---- semi-implicit Euler (mj_Euler, no damping)
@@ -1387,7 +1441,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 2 : 1)) void kp_step_kernel(StepArg
     }
     if (bad) atomicOr(&s.flag, 1);
     KP_SYNC();
-    if (tid == 0 && A.diag && A.n_substeps > 0) { int* dg = A.diag + 4 * (size_t)env; dg[0] = s.ncon; dg[1] = niter_total; dg[2] = s.flag; dg[3] = maxcon; }
+    if (tid == 0 && A.diag && A.n_substeps > 0) { int* dg = A.diag + 4 * (size_t)env; dg[0] = s.ncon; dg[1] = niter_total; dg[2] = s.flag; dg[3] = maxcon | (nfact_total << 8); }
 }
 
 }  // namespace kp

@@ -116,6 +116,12 @@ class BatchedHumanoidAREnv:
         c = self.ctx
         if "obj_pose" in c and bool((c["action_one_hot"].sum(1) > 0).any()):
             self.obj_qpos, self.obj7 = convert_obj_qpos(c["action_one_hot"], c["obj_pose"][:, 0])
+            # get_obj_qpos(action_one_hot) reads the SIMULATED pose of the action's (first) object every step (:466-477)
+            a_idx = c["action_one_hot"].argmax(1)
+            self._obj_has = c["action_one_hot"].sum(1) > 0
+            start = torch.tensor(ACTION_INDEX_MAP, device=self.device)[a_idx]
+            self._obj_cols = start[:, None] + torch.arange(7, device=self.device)[None]
+            self._obj35 = torch.empty((self.n, 35), dtype=torch.float32, device=self.device)
         else:
             self.obj_qpos = self.obj7 = None
         self._ctx_struct = self.sim.make_ctx(T, c["head_pose"], c["head_vels"], c["obj_head_relative_poses"], c["action_one_hot"],
@@ -130,6 +136,9 @@ class BatchedHumanoidAREnv:
             self.cur_t.masked_fill_(env_mask.to(self.device, torch.bool), 0)
         if self.obj_qpos is not None:
             self.sim.set_objects(self.obj_qpos, m8)
+            fresh = torch.gather(self.obj_qpos, 1, self._obj_cols)
+            keep = ~self._obj_has if env_mask is None else ~(self._obj_has & env_mask.to(self.device, torch.bool))
+            self.obj7.copy_(torch.where(keep[:, None], self.obj7, fresh))
         self.sim.set_state(self.ctx["init_qpos"], self.ctx["init_qvel"], m8)
         self.sim.set_target(self.ctx["init_qpos"], m8)
         return self.sim.obs_ar(self._ctx_struct, self._obs)
@@ -145,6 +154,9 @@ class BatchedHumanoidAREnv:
         with torch.no_grad():
             cc_action = self.cc_policy.select_action(cc_obs, mean_action, self.gen).contiguous()
         sim.step_ctrl(cc_action, self.frame_skip)
+        if self.obj7 is not None:
+            sim.get("obj_qpos", self._obj35)
+            self.obj7.copy_(torch.where(self._obj_has[:, None], torch.gather(self._obj35, 1, self._obj_cols), self.obj7))
         self.cur_t += 1
         reward, info6, fail, diffs = sim.term_reward(self._ctx_struct, self.reward_cfg, self._reward, self._info, self._fail, self._diffs)
         end = (self.cur_t >= self.env_episode_len) | (self.cur_t >= self.ctx_len)

@@ -849,6 +849,7 @@ void kpo_clear_objects(kpo_data *d) { d->nobj = 0; d->ngeom = d->ngeom_static; }
 void kpo_get_object(const kpo_data *d, int k, double *qpos7, double *qvel6) { memcpy(qpos7, d->obj[k].qpos, 56); memcpy(qvel6, d->obj[k].qvel, 48); }
 void kpo_get_object_dyn(const kpo_data *d, int k, double *M36, double *bias6) { memcpy(M36, d->obj[k].M, 288); memcpy(bias6, d->obj[k].bias, 48); }
 void kpo_get_qacc_full(const kpo_data *d, double *out) { memcpy(out, d->qacc, sizeof(double) * NVT_MAX); }
+void kpo_get_qacc_smooth_full(const kpo_data *d, double *out) { memcpy(out, d->qacc_smooth, sizeof(double) * NVT_MAX); }
 void kpo_get_contact_pairs(const kpo_data *d, int *b1, int *b2) { for (int c = 0; c < d->ncon; c++) { b1[c] = d->con_body[c]; b2[c] = d->con_b2[c]; } }
 
 /* ------------------------------------------------------------------ accessors for ctypes */

@@ -56,6 +56,7 @@ def lib():
         L.kpo_get_object.argtypes = [P, C.c_int, D, D]
         L.kpo_get_object_dyn.argtypes = [P, C.c_int, D, D]
         L.kpo_get_qacc_full.argtypes = [P, D]
+        L.kpo_get_qacc_smooth_full.argtypes = [P, D]
         L.kpo_get_efc_J_full.argtypes = [P, D]
         L.kpo_get_contact_pairs.argtypes = [P, I, I]
         L.kpo_get_efc.argtypes = [P, D, D, D]
@@ -133,6 +134,9 @@ class OracleSim:
 
     def qacc_full(self):
         out = np.zeros(NV + 12); self.L.kpo_get_qacc_full(self.d, _dp(out)); return out
+
+    def qacc_smooth_full(self):
+        out = np.zeros(NV + 12); self.L.kpo_get_qacc_smooth_full(self.d, _dp(out)); return out
 
     def efc_J_full(self):
         n = self.nefc; J = np.zeros((max(n, 1), NV + 12)); self.L.kpo_get_efc_J_full(self.d, _dp(J)); return J[:n]

@@ -132,16 +132,18 @@ def test_sampler_autoreset_and_ppo_update():
 
 
 def test_env_with_step_object():
-    """action_one_hot = 'step': the step box becomes collision geometry and enters the AR observation."""
+    """action_one_hot = 'step': the 40 kg step box is a free body of the env -- the humanoid stands on it, its simulated
+    pose enters the AR observation every step (get_obj_qpos reads data.qpos)."""
     from kinpoly_amd.env import BatchedHumanoidAREnv, standing_context
     n, T = 4, 6
     env = BatchedHumanoidAREnv(n, 0, mode="test", seed=0)
     ctx = standing_context(n, T, STD["qpos"], STD["qvel"], env.sim)
     one_hot = torch.zeros((n, 4), device=env.device); one_hot[:2, 3] = 1.0          # envs 0, 1: "step"
-    pose = torch.tensor([STD["qpos"][0], STD["qpos"][1], 0.23 - 0.21, 1.0, 0, 0, 0], device=env.device).repeat(n, 1)  # box top 1 cm under the floor level
-    pose[0, 2] = 0.23 - 0.195                                                     # env 0: box top 5 mm above the floor => feet rest on it
+    pose = torch.tensor([STD["qpos"][0], STD["qpos"][1], 0.3705, 1.0, 0, 0, 0], device=env.device).repeat(n, 1)  # box resting on the floor, top at 0.3405
+    pose[1, 0] += 1.0                                                             # env 1: the box stands 1 m ahead, untouched
     ctx["action_one_hot"] = one_hot
     ctx["obj_pose"] = pose.unsqueeze(1).repeat(1, T, 1).contiguous()
+    ctx["init_qpos"][0, 2] += 0.341; ctx["qpos"][0, :, 2] += 0.341                 # env 0 starts on top of the box
     env.load_context(ctx)
     obs = env.reset().double().cpu().numpy()
     rd = {k: env.sim.get(k).double().cpu().numpy() for k in ("qpos", "xpos", "xquat", "obj_qpos")}
@@ -156,11 +158,19 @@ def test_env_with_step_object():
     for i in range(n):
         cur = q0[i].double().cpu().numpy(); cur[3:7] = O.de_heading(cur[3:7]); a[i, :74] = torch.tensor(cur[2:], dtype=torch.float32)
     for _ in range(3):
-        env.step(a)
+        obs_t, _, _, _ = env.step(a)
     dg = env.sim.diag()
     assert dg[:, 2].max() == 0
-    z = env.sim.get("qpos")[:, 2].cpu().numpy()
-    assert z[0] > z[2] + 0.002        # env 0 stands on the raised box, env 2 (no object) on the floor
+    rd = {k: env.sim.get(k).double().cpu().numpy() for k in ("qpos", "xpos", "xquat", "obj_qpos")}
+    z = rd["qpos"][:, 2]
+    assert abs(z[0] - z[2] - 0.341) < 0.01        # env 0 still stands on the box, env 2 (no object) on the floor
+    assert np.abs(rd["obj_qpos"][:2, 28:35] - pose[:2].cpu().numpy()).max() < 5e-3      # the boxes rest (settle by < 5 mm)
+    assert np.abs(rd["obj_qpos"][0, 28:35] - pose[0].cpu().numpy()).max() > 1e-6         # ... but they are simulated, not frozen
+    # the observation of step t uses the simulated object pose of step t
+    for i in range(2):
+        want = O.obs_ar(rd["qpos"][i], rd["xpos"][i].reshape(24, 3), rd["xquat"][i].reshape(24, 4), c["head_pose"][i, 3], c["head_vels"][i, 3],
+                        c["obj_head_relative_poses"][i, 3], c["action_one_hot"][i], rd["obj_qpos"][i, 28:35])
+        np.testing.assert_allclose(obs_t[i].double().cpu().numpy(), want, atol=5e-5)
 
 
 def test_context_rollout_matches_reference_fixture(golden):

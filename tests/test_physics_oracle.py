@@ -151,3 +151,94 @@ def test_standing_is_held_by_contacts():
         o.do_simulation(np.zeros(75), STD["qpos"], 15)
     assert o.get("qpos")[2] > 0.85 and np.isfinite(o.get("qvel")).all()
     assert o.get("xpos").reshape(24, 3)[:, 2].min() > -0.05
+
+
+# ------------------------------------------------------------------ dynamic free objects (chair / box / table / Can / step)
+def _no_armature(kpm):
+    k = dict(kpm); oi = kpm["obj_inertial"].reshape(-1, 13).copy(); oi[:, 12] = 0.0; k["obj_inertial"] = oi.reshape(-1)
+    return k
+
+
+def test_object_torque_free_motion_conserves_momenta():
+    """A spinning, translating box in zero gravity: linear momentum of its COM and angular momentum about it are
+    conserved by the free-body equations (bias forces of kpo_obj_forward), up to the O(h) integrator drift."""
+    kpm = _no_armature(KPM)
+    o = OracleSim(contact=False, gravity=0.0)
+    quat = np.array([0.8, 0.2, -0.4, 0.4]); quat /= np.linalg.norm(quat)
+    o.set_object(0, kpm, 0, [0.3, -0.2, 2.0, *quat], [0.4, -0.3, 0.2, 1.5, -0.7, 0.9])     # the chair: COM offset + non-spherical inertia
+    q = STD["qpos"].copy(); q[0] += 30
+    o.reset(q, np.zeros(75))
+    inert = kpm["obj_inertial"].reshape(-1, 13)[0]
+    m, c = inert[0], inert[1:4]
+    Ib = np.array([[inert[4], inert[7], inert[8]], [inert[7], inert[5], inert[9]], [inert[8], inert[9], inert[6]]])
+    P, L, E = [], [], []
+    for _ in range(300):
+        oq, ov = o.get_object(0)
+        R = O.quaternion_matrix3(oq[3:7]); w = R @ ov[3:]
+        vc = ov[:3] + np.cross(w, R @ c)
+        P.append(m * vc); L.append(R @ Ib @ R.T @ w); E.append(0.5 * m * vc @ vc + 0.5 * w @ (R @ Ib @ R.T) @ w)
+        o.step()
+    P, L, E = np.array(P), np.array(L), np.array(E)
+    assert np.abs(P - P[0]).max() < 2e-3 * np.linalg.norm(P[0])
+    assert np.abs(L - L[0]).max() < 2e-2 * np.linalg.norm(L[0]) and abs(E[-1] - E[0]) < 2e-2 * E[0]
+    # halving the step halves the drift: it is integrator error, not a wrong bias term
+    assert np.abs(L[150] - L[0]).max() < 0.6 * np.abs(L[-1] - L[0]).max() + 1e-9
+
+
+def test_object_mass_matrix_and_free_fall():
+    kpm = _no_armature(KPM)
+    o = OracleSim(contact=False)
+    quat = np.array([0.5, -0.5, 0.3, 0.6]); quat /= np.linalg.norm(quat)
+    o.set_object(0, kpm, 3, [0.0, 0.0, 3.0, *quat], [0.1, 0.2, 0.0, 0.3, 0.5, -0.4])
+    q = STD["qpos"].copy(); q[0] += 30
+    o.reset(q, np.zeros(75))
+    M, bias = o.object_dyn(0)
+    assert np.allclose(M, M.T) and np.linalg.eigvalsh(M).min() > 0
+    oq, ov = o.get_object(0)
+    qa = o.qacc_full()[75:81]
+    R = O.quaternion_matrix3(oq[3:7]); c = R @ kpm["obj_inertial"].reshape(-1, 13)[3, 1:4]
+    w = R @ ov[3:]; alpha = R @ qa[3:]
+    a_com = qa[:3] + np.cross(alpha, c) + np.cross(w, np.cross(w, c))
+    np.testing.assert_allclose(a_com, [0, 0, -9.81], atol=1e-9)
+
+
+def test_objects_rest_and_carry_load():
+    """Push scene at rest: the floor carries table + box, the table carries the box; standing on the step: the floor under
+    the step carries humanoid + step.  Also the KKT conditions of the coupled solve (all dofs)."""
+    from kinpoly_amd.model_compiler import STEP_KPM
+    kpm = read_kpm(STEP_KPM)
+    inert = kpm["obj_inertial"].reshape(-1, 13)
+    o = OracleSim(kpm=STEP_KPM)
+    o.set_object(0, kpm, 1, [0, 0, 0.921, 1, 0, 0, 0]); o.set_object(1, kpm, 2, [0, 0, 0.7905, 1, 0, 0, 0])
+    q = STD["qpos"].copy(); q[0] += 30
+    o.reset(q, np.zeros(75))
+    for _ in range(450):
+        o.step()
+    o.forward()
+    f, D, aref, _ = o.efc(); J = o.efc_J_full(); b1, b2 = o.contact_pairs()
+    rows = np.repeat(np.arange(len(b1)), 4)
+    lim = o.nefc - 4 * len(b1)
+    fz_floor_table = sum((J[lim + r, 75 + 6 + 2] * f[lim + r]) for r in range(4 * len(b1)) if b1[rows[r]] == 25 and b2[rows[r]] == -1)
+    fz_table_box = sum((J[lim + r, 75 + 2] * f[lim + r]) for r in range(4 * len(b1)) if b1[rows[r]] == 24 and b2[rows[r]] == 25)
+    assert abs(fz_floor_table - (inert[1, 0] + inert[2, 0]) * 9.81) < 0.01 * inert[2, 0] * 9.81
+    assert abs(fz_table_box - inert[1, 0] * 9.81) < 0.02 * inert[1, 0] * 9.81
+    bq, bv = o.get_object(0)
+    assert abs(bq[2] - 0.921) < 2e-3 and np.abs(bv).max() < 1e-3
+    # KKT of the coupled system: M (qacc - qacc_smooth) = J^T f on humanoid and object dofs
+    M = np.zeros((87, 87)); M[:75, :75] = o.fullM(); M[75:81, 75:81] = o.object_dyn(0)[0]; M[81:87, 81:87] = o.object_dyn(1)[0]
+    res = M @ (o.qacc_full() - o.qacc_smooth_full()) - J.T @ f
+    assert np.abs(res).max() < 1e-4 * np.abs(J.T @ f).max()
+
+    o = OracleSim(kpm=STEP_KPM)
+    o.set_object(0, kpm, 4, [STD["qpos"][0], STD["qpos"][1], 0.3705, 1, 0, 0, 0])
+    q = STD["qpos"].copy(); q[2] += 0.341
+    o.reset(q, STD["qvel"])
+    for _ in range(20):
+        o.do_simulation(np.zeros(75), q, 15)
+    o.forward()
+    f, D, aref, _ = o.efc(); J = o.efc_J_full(); b1, b2 = o.contact_pairs()
+    assert ((b1 < 24) & (b2 == 24)).sum() >= 6 and ((b1 == 24) & (b2 == -1)).sum() == 4     # feet on the step, step on the floor
+    rows = np.repeat(np.arange(len(b1)), 4); lim = o.nefc - 4 * len(b1)
+    fz = sum((J[lim + r, 75 + 2] * f[lim + r]) for r in range(4 * len(b1)) if b1[rows[r]] == 24 and b2[rows[r]] == -1)
+    total = (MASS.sum() + inert[4, 0]) * 9.81
+    assert abs(fz - total) < 0.1 * total and o.get("qpos")[2] > q[2] - 0.05

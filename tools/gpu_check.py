@@ -54,7 +54,7 @@ def compare(name, n, nsub, contact, lift, action_scale, steps=1, threads=64, sta
         errv.append(np.abs(o.get("qvel") - gv[e]).max())
         errx.append(np.abs(o.get("xpos") - gx[e]).max())
     print(f"[{name}] n={n} nsub={nsub}x{steps} thr={threads}: max|dqpos|={max(errq):.3e} median={np.median(errq):.3e}  "
-          f"max|dqvel|={max(errv):.3e}  max|dxpos|={max(errx):.3e}  ncon(max)={dg[:, 3].max()} iters(mean)={dg[:, 1].mean():.1f} flags={dg[:, 2].max()}",
+          f"max|dqvel|={max(errv):.3e}  max|dxpos|={max(errx):.3e}  ncon(max)={(dg[:, 3] & 255).max()} iters(mean)={dg[:, 1].mean():.1f} flags={dg[:, 2].max()}",
           flush=True)
 
 
@@ -74,7 +74,7 @@ def timing(n, threads, contact, lift, steps=5):
         ts.append(sim.last_step_seconds())
     dg = sim.diag()
     print(f"[timing] n={n} thr={threads} contact={contact} lift={lift}: {np.mean(ts)*1e3:.3f} ms/control-step "
-          f"({n/np.mean(ts):.0f} env-steps/s physics only) ncon(mean)={dg[:,0].mean():.1f} iters/substep={dg[:,1].mean()/15:.2f}", flush=True)
+          f"({n/np.mean(ts):.0f} env-steps/s physics only) ncon(mean)={dg[:,0].mean():.1f} iters/substep={dg[:,1].mean()/15:.2f} factorisations/substep={(dg[:,3] >> 8).mean()/15:.2f}", flush=True)
 
 
 if __name__ == "__main__":
