@@ -121,6 +121,14 @@ def _allreduce_grads(params, group=None):
         g.copy_(flat[off:off + g.numel()].view_as(g)); off += g.numel()
 
 
+def ppo_surrogate(log_probs, fixed_log_probs, advantages, clip_epsilon=0.2, ind=None):
+    """AgentPPO.ppo_loss (uhc/khrylib/rl/agents/agent_ppo.py:58-65): clipped surrogate over the rows `ind` (the `exps` mask)."""
+    if ind is not None:
+        log_probs, fixed_log_probs, advantages = log_probs[ind], fixed_log_probs[ind], advantages[ind]
+    ratio = torch.exp(log_probs - fixed_log_probs)
+    return -torch.min(ratio * advantages, torch.clamp(ratio, 1.0 - clip_epsilon, 1.0 + clip_epsilon) * advantages).mean()
+
+
 class PPOTrainer:
     """AgentPPO.update_policy / ppo_loss / update_value (agent_ar.py:756-772, 852-870; agent_ppo.py:53-56)."""
 
@@ -146,8 +154,7 @@ class PPOTrainer:
             self.opt_v.zero_grad(); vloss.backward(); _allreduce_grads(list(self.value.parameters()), self.group); self.opt_v.step()
             means = self.policy.unroll(batch.states, batch.episode_start)
             log_probs = self.policy.log_prob(means.reshape(N * T, -1), batch.actions.reshape(N * T, -1))
-            ratio = torch.exp(log_probs - fixed_log_probs)
-            surr = -torch.min(ratio * adv, torch.clamp(ratio, 1.0 - self.clip_epsilon, 1.0 + self.clip_epsilon) * adv).mean()
+            surr = ppo_surrogate(log_probs, fixed_log_probs, adv, self.clip_epsilon)
             self.opt_p.zero_grad(); surr.backward()
             params = [p for p in self.policy.parameters() if p.requires_grad]
             _allreduce_grads(params, self.group)

@@ -88,3 +88,21 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hpp", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not pat.search(src), f"{f} references the oracle"
+
+
+def test_ppo_surrogate_and_log_prob_match_reference(golden):
+    """KinPolicy.log_prob (DiagGaussian) + rollout.ppo_surrogate against AgentPPO.ppo_loss run in the reference (fixture)."""
+    import torch
+    from kinpoly_amd.nets import KinPolicy
+    from kinpoly_amd.rollout import ppo_surrogate
+    g = golden("ppo_loss")
+    pol = KinPolicy(log_std=float(g["log_std"])).double()
+    pol.action_log_std.data.fill_(float(g["log_std"]))      # the fp32-constructed parameter carries -3.2 rounded to float
+    t = lambda k: torch.tensor(g[k], dtype=torch.float64)  # noqa: E731
+    fixed = pol.log_prob(t("mean_old"), t("actions"))
+    new = pol.log_prob(t("mean_new"), t("actions"))
+    np.testing.assert_allclose(fixed.detach().numpy(), g["fixed_log_probs"], rtol=1e-12, atol=1e-9)
+    np.testing.assert_allclose(new.detach().numpy(), g["new_log_probs"], rtol=1e-12, atol=1e-9)
+    ind = torch.tensor(g["exps"]).nonzero(as_tuple=False).squeeze(1)
+    loss = ppo_surrogate(new, fixed, t("adv"), float(g["clip_epsilon"]), ind)
+    assert abs(float(loss) - float(g["loss"])) < 1e-10

@@ -390,6 +390,42 @@ def gen_loss_and_checkpoint(hum):
     np.savez(os.path.join(OUT, "ref_checkpoint_small_expect.npz"), mean=zf.rs.mean, std=zf.rs.std, w=cp["policy_dict"]["traj_ar_net.action_fc.weight"].numpy())
 
 
+def gen_ppo_loss():
+    """AgentPPO.ppo_loss (uhc/khrylib/rl/agents/agent_ppo.py:58-65) with DiagGaussian log-probabilities
+    (uhc/khrylib/rl/core/distributions.py:6-23) on seeded means / actions / advantages, exps mask included."""
+    from uhc.khrylib.rl.agents.agent_ppo import AgentPPO
+    from uhc.khrylib.rl.core.distributions import DiagGaussian
+    rng = np.random.default_rng(31)
+    B, A = 96, 80
+    log_std = -3.2
+    mean_old = rng.normal(size=(B, A)) * 0.3
+    mean_new = mean_old + rng.normal(size=(B, A)) * 0.5 * np.exp(log_std)
+    actions = mean_old + rng.normal(size=(B, A)) * np.exp(log_std)
+    adv = rng.normal(size=(B, 1))
+    exps = (rng.uniform(size=B) < 0.8).astype(np.float64)
+
+    class Pol:                                   # policy_net.get_log_prob(x, a) = forward(x).log_prob(a)  (policy.py)
+        def __init__(self, mean):
+            self.mean = torch.tensor(mean)
+
+        def get_log_prob(self, x, a):
+            idx = x.long().view(-1)
+            return DiagGaussian(self.mean[idx], torch.full((idx.numel(), A), float(np.exp(log_std)))).log_prob(a)
+
+    states = torch.arange(B, dtype=torch.float64).view(B, 1)        # "states" index the stored means
+    fixed = Pol(mean_old).get_log_prob(states, torch.tensor(actions))
+    stub = types.SimpleNamespace(policy_net=Pol(mean_new), trans_policy=lambda x: x, clip_epsilon=0.2)
+    ind = torch.tensor(exps).nonzero(as_tuple=False).squeeze(1)
+    loss = AgentPPO.ppo_loss(stub, states, torch.tensor(actions), torch.tensor(adv), fixed, ind)
+    np.savez(os.path.join(OUT, "ppo_loss.npz"), mean_old=mean_old, mean_new=mean_new, actions=actions, adv=adv, exps=exps, log_std=log_std,
+             fixed_log_probs=fixed.numpy(), new_log_probs=Pol(mean_new).get_log_prob(states, torch.tensor(actions)).numpy(), loss=float(loss), clip_epsilon=0.2)
+
+
+if __name__ == "__main__" and os.environ.get("KP_GOLDEN_ONLY") == "ppo":
+    gen_ppo_loss()
+    print("ppo_loss.npz ok")
+
+
 if __name__ == "__main__" and os.environ.get("KP_GOLDEN_ONLY") == "loss":
     gen_loss_and_checkpoint(make_humanoid())
     print("step_loss.npz ok")
@@ -407,6 +443,7 @@ if __name__ == "__main__" and os.environ.get("KP_GOLDEN_ONLY") is None:
     gen_policies()
     gen_traj_ar_net(hum)
     gen_loss_and_checkpoint(hum)
+    gen_ppo_loss()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
