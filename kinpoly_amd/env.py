@@ -43,8 +43,9 @@ class RunningState:
 class BatchedHumanoidAREnv:
     def __init__(self, n_envs, device=0, kpm_path=None, cc_policy: PolicyMCP | None = None,
                  cc_running_state: RunningState | None = None, mode="train", wild=False, joint_controller=False,
-                 env_episode_len=100000, body_diff_thresh=10.0, body_diff_gt_thresh=12.0, model_options=None, seed=0):
+                 env_episode_len=100000, body_diff_thresh=10.0, body_diff_gt_thresh=12.0, model_options=None, seed=0, ar_mode=False):
         self.n = int(n_envs)
+        self.ar_mode = bool(ar_mode)
         if kpm_path is None:  # agent_ar.py:165-169: mocap training uses ..._all_step.xml, --wild uses ..._all.xml
             kpm_path = kpsim.DEFAULT_KPM if wild else kpsim.STEP_KPM
         self.model = kpsim.KpModel(kpm_path, **(model_options or {}))
@@ -91,8 +92,9 @@ class BatchedHumanoidAREnv:
         new = {k: ctx[k].to(self.device, torch.float32) for k in CTX_KEYS}
         if new["action_one_hot"].dim() == 3:
             new["action_one_hot"] = new["action_one_hot"][:, 0]
-        if "obj_pose" in ctx:
-            new["obj_pose"] = ctx["obj_pose"].to(self.device, torch.float32)
+        for k in ("obj_pose", "ar_qpos", "ar_qvel"):
+            if k in ctx:
+                new[k] = ctx[k].to(self.device, torch.float32)
         if self.ctx is None or env_mask is None or self.ctx["qpos"].shape[1] != T:
             if env_mask is not None and self.ctx is not None:
                 raise ValueError("masked load_context needs the same clip length T")
@@ -139,15 +141,29 @@ class BatchedHumanoidAREnv:
             fresh = torch.gather(self.obj_qpos, 1, self._obj_cols)
             keep = ~self._obj_has if env_mask is None else ~(self._obj_has & env_mask.to(self.device, torch.bool))
             self.obj7.copy_(torch.where(keep[:, None], self.obj7, fresh))
-        self.sim.set_state(self.ctx["init_qpos"], self.ctx["init_qvel"], m8)
-        self.sim.set_target(self.ctx["init_qpos"], m8)
+        if self.ar_mode:                          # reset_model (:339-341): start from the kinematic roll-out's first frame
+            q0, v0 = self.ctx["ar_qpos"][:, 0].contiguous(), self.ctx["ar_qvel"][:, 0].contiguous()
+        else:
+            q0, v0 = self.ctx["init_qpos"], self.ctx["init_qvel"]
+        self.sim.set_state(q0, v0, m8)
+        self.sim.set_target(q0, m8)
         return self.sim.obs_ar(self._ctx_struct, self._obs)
+
+    def _ar_frame(self, key):
+        """ar_context[key][cur_t + 1] per env."""
+        t = (self.cur_t.long() + 1).clamp_(max=self.ctx[key].shape[1] - 1)
+        return self.ctx[key][torch.arange(self.n, device=self.device), t].contiguous()
+
+    def ar_fail_safe(self, env_mask: torch.Tensor | None = None):
+        """HumanoidAREnv.ar_fail_safe (:327-331): put the humanoid back on the kinematic roll-out (objects keep their state)."""
+        m8 = None if env_mask is None else env_mask.to(self.device, torch.uint8).contiguous()
+        self.sim.set_state(self._ar_frame("ar_qpos"), self._ar_frame("ar_qvel"), m8)
 
     def step(self, a: torch.Tensor):
         sim = self.sim
         sim.step_begin()
         sim.step_kin(a, self._next_qpos)
-        sim.set_target(self._next_qpos)
+        sim.set_target(self._ar_frame("ar_qpos") if self.ar_mode else self._next_qpos)     # ar_mode: the UHC tracks the kinematic roll-out (:263-264)
         rs = self.cc_running_state
         cc_obs = sim.obs_cc(self._cc_obs, rs.mean, rs.std, rs.clip)
         mean_action = self.mode == "test" or (self.mode == "train" and self.joint_controller)
@@ -263,7 +279,7 @@ class HumanoidAREnv:
         self.b = BatchedHumanoidAREnv(1, device, cc_policy=pol, cc_running_state=rs, mode=mode, wild=wild,
                                       joint_controller=bool(getattr(cfg, "joint_controller", False)),
                                       env_episode_len=int(getattr(cc_cfg, "env_episode_len", 100000)),
-                                      body_diff_thresh=ps.get("body_diff_thresh", 10), body_diff_gt_thresh=ps.get("body_diff_gt_thresh", 12))
+                                      body_diff_thresh=ps.get("body_diff_thresh", 10), body_diff_gt_thresh=ps.get("body_diff_gt_thresh", 12), ar_mode=ar_mode)
         self.kin_cfg, self.cc_cfg, self.ar_mode = cfg, cc_cfg, ar_mode
         self.cc_policy, self.cc_running_state = self.b.cc_policy, self.b.cc_running_state
         self.dt, self.end_reward = self.b.dt, 0.0
@@ -287,8 +303,8 @@ class HumanoidAREnv:
         self.ar_context = {k: (v[0].detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)[0]) for k, v in data_dict.items()}
         self.ar_context["len"] = self.ar_context["qpos"].shape[0] - 1
         ctx = {k: torch.as_tensor(np.asarray(self.ar_context[k]), dtype=torch.float32)[None] for k in
-               ("qpos", "head_pose", "head_vels", "obj_head_relative_poses", "action_one_hot")}
-        key_q, key_v = ("ar_qpos", "ar_qvel") if self.ar_mode else ("init_qpos", "init_qvel")
+               ("qpos", "head_pose", "head_vels", "obj_head_relative_poses", "action_one_hot", "obj_pose", "ar_qpos", "ar_qvel") if k in self.ar_context}
+        key_q, key_v = ("ar_qpos", "ar_qvel") if (self.ar_mode and "init_qpos" not in self.ar_context) else ("init_qpos", "init_qvel")
         iq, iv = self.ar_context[key_q], self.ar_context[key_v]
         ctx["init_qpos"] = torch.as_tensor(iq[0] if iq.ndim == 2 else iq, dtype=torch.float32)[None]
         ctx["init_qvel"] = torch.as_tensor(iv[0] if iv.ndim == 2 else iv, dtype=torch.float32)[None]
@@ -319,7 +335,20 @@ class HumanoidAREnv:
     def get_body_com(self): return self._g("xipos")
 
     def get_obj_qpos(self, action_one_hot=None):
-        return np.array([0, 0, 0, 1, 0, 0, 0.0]) if action_one_hot is not None else np.zeros(35)
+        """humanoid_ar_v1.py:466-477: the whole object block, or the pose of the action's (first) object."""
+        full = self._g("obj_qpos") if self.b.obj_qpos is not None else convert_obj_qpos(torch.zeros((1, 4)), torch.zeros((1, 7)))[0][0].double().numpy()
+        if action_one_hot is None:
+            return full
+        if np.sum(action_one_hot) == 0:
+            return np.array([0, 0, 0, 1, 0, 0, 0.0])
+        a = int(np.nonzero(action_one_hot)[0][0])
+        return full[ACTION_INDEX_MAP[a]:ACTION_INDEX_MAP[a] + ACTION_LEN[a]][:7]
+
+    def get_obj_qvel(self):
+        return self._g("obj_qvel") if self.b.obj_qpos is not None else np.zeros(30)
+
+    def ar_fail_safe(self):
+        self.b.ar_fail_safe()
 
     @property
     def target(self):

@@ -94,6 +94,34 @@ def test_single_env_facade_numpy_surface():
     assert info["cc_action"].shape == (75,) and info["cc_state"].shape == (784,) and 0 < info["percent"] <= 1
     assert env.get_humanoid_qpos().shape == (76,) and env.get_head().shape == (7,) and env.get_body_quat().shape == (96,)
     assert env.target["wbpos"].shape == (72,) and env.cur_t == 1 and abs(env.dt - 1 / 30) < 1e-6
+    assert env.get_obj_qpos().shape == (35,) and env.get_obj_qvel().shape == (30,)
+    np.testing.assert_allclose(env.get_obj_qpos(np.zeros(4)), [0, 0, 0, 1, 0, 0, 0])
+
+
+def test_ar_mode_and_fail_safe():
+    """ar_mode (eval_ar_policy.py --ar_mode): reset from ar_qpos[0], the UHC tracks ar_qpos[t + 1] instead of the policy's
+    step_ar output; ar_fail_safe puts the humanoid back on the kinematic roll-out (humanoid_ar_v1.py:263-264, 327-331, 339-341)."""
+    from kinpoly_amd.env import HumanoidAREnv, standing_context
+    import types
+    cfg = types.SimpleNamespace(policy_specs={"body_diff_thresh": 10, "body_diff_gt_thresh": 12}, joint_controller=False)
+    env = HumanoidAREnv(cfg, types.SimpleNamespace(env_episode_len=100000), None, mode="test", ar_mode=True)
+    T = 8
+    ctx = standing_context(1, T, STD["qpos"], STD["qvel"], env.b.sim)
+    ar_qpos = ctx["qpos"].clone(); ar_qpos[0, :, 7 + 3 * 15 + 1] += torch.linspace(0, 0.4, T, device=ar_qpos.device)   # the roll-out raises an arm
+    ar_qvel = torch.zeros((1, T, 75), device=ar_qpos.device)
+    d = {k: v.cpu() for k, v in ctx.items()} | {"action_one_hot": ctx["action_one_hot"].cpu()[:, None].repeat(1, T, 1), "ar_qpos": ar_qpos.cpu(), "ar_qvel": ar_qvel.cpu()}
+    del d["init_qpos"], d["init_qvel"]
+    env.load_context(d)
+    env.reset()
+    np.testing.assert_allclose(env.get_humanoid_qpos(), ar_qpos[0, 0].cpu().numpy(), atol=1e-6)
+    junk = np.zeros(80)                                            # the kinematic action is ignored for the target in ar_mode
+    env.step(junk)
+    np.testing.assert_allclose(env.target["qpos"], ar_qpos[0, 1].cpu().numpy(), atol=1e-6)
+    env.step(junk)
+    np.testing.assert_allclose(env.target["qpos"], ar_qpos[0, 2].cpu().numpy(), atol=1e-6)
+    env.ar_fail_safe()
+    np.testing.assert_allclose(env.get_humanoid_qpos(), ar_qpos[0, 3].cpu().numpy(), atol=1e-6)
+    np.testing.assert_allclose(env.get_humanoid_qvel(), 0.0, atol=1e-7)
 
 
 def test_sampler_autoreset_and_ppo_update():
