@@ -97,7 +97,7 @@ def cpu_baseline(std, seconds_budget=15.0):
             x = {k: sim.get(k) for k in ("qpos", "qvel", "xpos", "xquat", "xipos")}
             xp, xq = x["xpos"].reshape(24, 3), x["xquat"].reshape(24, 4)
             O.dynamic_supervision_v1(np.concatenate([xp[13], xq[13]]), prev_hpos, O.get_body_quat(x["qpos"]), prev_bquat, xp, tgt, head, gt_bquat, gt_bquat, 1 / 30, O.REWARD_WEIGHTS)
-            fail = O.calc_body_diff(xp, tgt["wbpos"]) > 10 or O.calc_body_diff(xp, fk0["wbpos"]) > 12
+            fail = O.calc_body_diff(xp, tgt["wbpos"], kpm["body_diffw"]) > 10 or O.calc_body_diff(xp, fk0["wbpos"], kpm["body_diffw"]) > 12
             obs = O.obs_ar(x["qpos"], xp, xq, head, hv, obj_rel, one_hot, None)
             n_steps += 1
             if fail or time.perf_counter() - t0 > seconds_budget:

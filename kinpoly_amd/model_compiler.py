@@ -323,6 +323,10 @@ def compile_model(xml_path: str, uhc_yml: str | None = None) -> dict:
         rfc_lim = float(cfg.get("residual_force_lim", 100.0))
         base_rot = cfg.get("data_specs", {}).get("base_rot", base_rot)
     diffw = np.ones(nb)
+    if uhc_yml is not None and "body_params" in cfg:          # jpos_diffw = [1] + body_params weights (copycat_config.py:139-143)
+        bp = cfg["body_params"]
+        assert [r[0] for r in bp] == [b["name"] for b in bodies[1:]], "uhc.yml body order differs from the XML body order"
+        diffw = np.concatenate([[1.0], np.array([r[1] for r in bp], float)])
 
     # ---- free objects: collision geoms (body frame) + inertial properties from the geoms' explicit `mass=`
     # (inertiafromgeom) [MJ-ext].  obj_inertial[o] = mass, com[3], inertia about com in body axes (xx yy zz xy xz yz),

@@ -20,6 +20,7 @@ from oracle.kpo import OracleSim  # noqa: E402
 
 KPM = read_kpm(DEFAULT_KPM)
 BODY_POS, BODY_IPOS, PARENT = KPM["body_pos"].reshape(24, 3), KPM["body_ipos"].reshape(24, 3), KPM["body_parent"]
+DIFFW = KPM["body_diffw"]
 STD = np.load(os.path.join(os.path.dirname(__file__), "golden", "standing_neutral.npz"))
 
 
@@ -234,7 +235,7 @@ def test_obs_ar_and_reward_match_pinned_oracle(kp, golden):
                                           c["gt_bquat"][i, t], c["gt_bquat"][i, t - 1], 1.0 / 30.0, O.REWARD_WEIGHTS)
         np.testing.assert_allclose(info[i], inf, atol=2e-4, rtol=2e-3)
         assert abs(rew[i] - r) < 2e-4
-        bd = O.calc_body_diff(xpos, tgt["wbpos"]); bgd = O.calc_body_diff(xpos, c["gt_wbpos"][i, t].reshape(24, 3))
+        bd = O.calc_body_diff(xpos, tgt["wbpos"], DIFFW); bgd = O.calc_body_diff(xpos, c["gt_wbpos"][i, t].reshape(24, 3), DIFFW)
         np.testing.assert_allclose(diffs[i], [bd, bgd], rtol=1e-5, atol=1e-4)
         assert bool(fail[i]) == bool(bd > 10 or bgd > 12)
 

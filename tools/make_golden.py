@@ -172,7 +172,7 @@ def make_env(cls):
                                env_term_body='body', env_episode_len=100000)
     env.cc_cfg = cc
     env.body_qposaddr = {n: (7 + 3 * (i - 1), 10 + 3 * (i - 1)) for i, n in enumerate(NAMES) if i > 0}
-    env.jpos_diffw = np.ones((24, 1))
+    env.jpos_diffw = KPM["body_diffw"].reshape(24, 1).copy()      # cc_cfg.jpos_diffw[:, None] (uhc.yml body_params: toes / hands 0)
     return env
 
 
