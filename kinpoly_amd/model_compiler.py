@@ -322,11 +322,15 @@ def compile_model(xml_path: str, uhc_yml: str | None = None) -> dict:
         rfc_scale = float(cfg.get("residual_force_scale", 200.0))
         rfc_lim = float(cfg.get("residual_force_lim", 100.0))
         base_rot = cfg.get("data_specs", {}).get("base_rot", base_rot)
+    # env.jpos_diffw (calc_body_diff) defaults to ones in both envs: no config carries reward_weights['jpos_diffw']
+    # (uhc/envs/humanoid_im.py:28, kin_poly/envs/humanoid_ar_v1.py:59).  uhc.yml body_params (toes / hands 0) only weigh the pose
+    # term of the UHC reward, cfg.b_diffw (copycat_config.py:139-143, uhc/core/reward_function.py:31).
     diffw = np.ones(nb)
-    if uhc_yml is not None and "body_params" in cfg:          # jpos_diffw = [1] + body_params weights (copycat_config.py:139-143)
+    uhc_b_diffw = np.ones(nb)
+    if uhc_yml is not None and "body_params" in cfg:
         bp = cfg["body_params"]
         assert [r[0] for r in bp] == [b["name"] for b in bodies[1:]], "uhc.yml body order differs from the XML body order"
-        diffw = np.concatenate([[1.0], np.array([r[1] for r in bp], float)])
+        uhc_b_diffw = np.concatenate([[1.0], np.array([r[1] for r in bp], float)])
 
     # ---- free objects: collision geoms (body frame) + inertial properties from the geoms' explicit `mass=`
     # (inertiafromgeom) [MJ-ext].  obj_inertial[o] = mass, com[3], inertia about com in body axes (xx yy zz xy xz yz),
@@ -381,7 +385,7 @@ def compile_model(xml_path: str, uhc_yml: str | None = None) -> dict:
         body_pos=body_pos, body_ipos=ipos, body_mass=mass,
         body_inertia=np.stack([inertia[:, 0, 0], inertia[:, 1, 1], inertia[:, 2, 2],
                                inertia[:, 0, 1], inertia[:, 0, 2], inertia[:, 1, 2]], axis=1),
-        body_gpos0=gpos, body_rbound=rbound, body_diffw=diffw,
+        body_gpos0=gpos, body_rbound=rbound, body_diffw=diffw, uhc_b_diffw=uhc_b_diffw,
         body_invweight0=body_invw, dof_invweight0=dof_invw,
         dof_body=dof_body, dof_parent=dof_parent, dof_depth=dof_depth, dof_madr=dof_madr,
         dof_armature=np.array(arm), jnt_range=np.array(jrange), jnt_limited=np.array(jlimited, np.int32),

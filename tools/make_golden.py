@@ -172,7 +172,7 @@ def make_env(cls):
                                env_term_body='body', env_episode_len=100000)
     env.cc_cfg = cc
     env.body_qposaddr = {n: (7 + 3 * (i - 1), 10 + 3 * (i - 1)) for i, n in enumerate(NAMES) if i > 0}
-    env.jpos_diffw = KPM["body_diffw"].reshape(24, 1).copy()      # cc_cfg.jpos_diffw[:, None] (uhc.yml body_params: toes / hands 0)
+    env.jpos_diffw = np.ones((24, 1))      # reward_weights.get("jpos_diffw", ones): no config sets it (humanoid_im.py:28, humanoid_ar_v1.py:59)
     return env
 
 
@@ -421,6 +421,72 @@ def gen_ppo_loss():
              fixed_log_probs=fixed.numpy(), new_log_probs=Pol(mean_new).get_log_prob(states, torch.tensor(actions)).numpy(), loss=float(loss), clip_epsilon=0.2)
 
 
+def gen_uhc_expert_reward():
+    """UHC training env (uhc/envs/humanoid_im.py HumanoidEnv) pieces: get_expert (uhc/utils/tools.py:20-85) over a seeded clip,
+    world_rfc_implicit_reward (uhc/core/reward_function.py:4-53), calc_body_diff (mean form, humanoid_im.py:719-726), the
+    784-d observation against expert frame t + 1.  sim.forward() is played by this repo's oracle (MuJoCo-side inputs)."""
+    from uhc.utils.tools import get_expert
+    from uhc.core.reward_function import world_rfc_implicit_reward
+    rng = np.random.default_rng(41)
+    env = make_env(him.HumanoidEnv)
+    env.frame_skip = 15                              # dt = model.opt.timestep * frame_skip (a property)
+    env.cur_t, env.start_ind = 0, 0
+    o = OracleSim()
+
+    class Sim:
+        def get_state(self): return None
+        def set_state(self, st): pass
+        def forward(self_inner):
+            o.reset(env.data.qpos[:76].copy(), np.zeros(75))
+            d = env.data
+            d.body_xpos = np.vstack([np.zeros((1, 3)), o.get("xpos").reshape(NB, 3)])
+            d.body_xquat = np.vstack([[[1, 0, 0, 0]], o.get("xquat").reshape(NB, 4)])
+            d.xipos = np.vstack([np.zeros((1, 3)), o.get("xipos").reshape(NB, 3)])
+            d.subtree_com = np.vstack([o.get("subtree_com")[None], np.zeros((24, 3))])
+    env.sim = Sim()
+    d = FakeData(); d.qpos = np.zeros(76); d.qvel = np.zeros(75)
+    d.get_body_xipos = lambda name: d.xipos[(["world"] + NAMES).index(name)]
+    env.data = d
+    T = 12
+    clip = np.stack([rand_qpos(rng, 0.15) for _ in range(T)])
+    base = rand_qpos(rng, 0.3)
+    for t in range(T):                               # a smooth-ish clip around one pose, with a joint crossing +-pi
+        clip[t, :3] = base[:3] + 0.02 * t * np.array([1.0, 0.5, 0.1])
+        clip[t, 7:] = base[7:] + 0.1 * np.sin(0.5 * t + np.arange(69))
+    clip[:, 7 + 20] = np.linspace(3.0, 3.4, T)       # crosses pi: exercises the 2 pi unwrap of get_qvel_fd_new
+    expert = get_expert(clip.copy(), {"cyclic": False, "seq_name": "synthetic"}, env)
+    out = {"clip": clip}
+    for k in ("qvel", "rlinv", "rlinv_local", "rangv", "rq_rmh", "com", "body_com", "head_pose", "ee_pos", "ee_wpos", "bquat", "bangvel", "wbpos", "wbquat"):
+        out["e_" + k] = np.asarray(expert[k])
+    out["e_height_lb"], out["e_head_height_lb"] = expert["height_lb"], expert["head_height_lb"]
+    # reward / termination / observation at a simulated state a few frames into the clip
+    env.expert = expert
+    env.cfg = types.SimpleNamespace(reward_weights=dict(w_p=0.3, w_v=0.1, w_e=0.45, w_c=0.1, w_vf=0.05, k_p=2.0, k_v=0.005, k_e=5.0, k_c=100.0, k_vf=1.0),
+                                    b_diffw=KPM["uhc_b_diffw"][1:].copy())    # uhc.yml body_params (toes / hands 0)
+    rec = {k: [] for k in ("r_t", "r_qpos", "r_qvel", "r_prev_bquat", "r_action", "r_reward", "r_info", "r_body_diff", "r_obs", "r_xpos", "r_xquat", "r_xipos", "r_com")}
+    for t in (1, 4, 9):
+        q = clip[t] + np.concatenate([rng.normal(size=3) * 0.02, np.zeros(4), rng.normal(size=69) * 0.05]); q[3:7] /= np.linalg.norm(q[3:7])
+        v = rng.normal(size=75) * 0.3
+        env.data.qpos = q.copy(); env.data.qvel = v.copy()
+        env.sim.forward()
+        env.cur_t = t
+        env.prev_bquat = out["e_bquat"][t - 1] + 0.0
+        action = rng.normal(size=75) * 0.3
+        r, info = world_rfc_implicit_reward(env, None, action, None)
+        rec["r_t"].append(t); rec["r_qpos"].append(q); rec["r_qvel"].append(v); rec["r_prev_bquat"].append(env.prev_bquat.copy()); rec["r_action"].append(action)
+        rec["r_reward"].append(r); rec["r_info"].append(info); rec["r_body_diff"].append(env.calc_body_diff())
+        rec["r_obs"].append(env.get_full_obs_v1())
+        rec["r_xpos"].append(env.data.body_xpos[1:25].copy()); rec["r_xquat"].append(env.data.body_xquat[1:25].copy()); rec["r_xipos"].append(env.data.xipos[1:25].copy())
+        rec["r_com"].append(env.data.subtree_com[0].copy())
+    out.update({k: np.stack(v) for k, v in rec.items()})
+    np.savez(os.path.join(OUT, "uhc_expert_reward.npz"), **out)
+
+
+if __name__ == "__main__" and os.environ.get("KP_GOLDEN_ONLY") == "uhc":
+    gen_uhc_expert_reward()
+    print("uhc_expert_reward.npz ok")
+
+
 if __name__ == "__main__" and os.environ.get("KP_GOLDEN_ONLY") == "ppo":
     gen_ppo_loss()
     print("ppo_loss.npz ok")
@@ -444,6 +510,7 @@ if __name__ == "__main__" and os.environ.get("KP_GOLDEN_ONLY") is None:
     gen_traj_ar_net(hum)
     gen_loss_and_checkpoint(hum)
     gen_ppo_loss()
+    gen_uhc_expert_reward()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
