@@ -98,3 +98,43 @@ def test_reference_checkpoint_layout_roundtrip(golden, tmp_path):
         assert torch.equal(a, b)
     assert all(k.startswith("traj_ar_net.") or k == "action_log_std" for k in cp2["policy_dict"])
     np.testing.assert_allclose(ck.running_state_arrays(cp2["running_state"])[1], 2.0)
+
+
+def test_uhc_torch_features_and_reward_match_reference(golden):
+    """The batched torch pieces of the UHC env (finite-difference velocities, body angular velocities, world_rfc_implicit
+    reward) in fp64 on the CPU against the reference-generated fixture."""
+    from kinpoly_amd.uhc_env import get_angvel_fd_t, get_qvel_fd_new_t, world_rfc_implicit_reward_t
+    from kinpoly_amd.model_compiler import DEFAULT_KPM, read_kpm
+    g = golden("uhc_expert_reward")
+    t = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)  # noqa: E731
+    clip = t(g["clip"])
+    qvel = get_qvel_fd_new_t(clip[:-1], clip[1:], 1 / 30).clamp(-10, 10)
+    np.testing.assert_allclose(qvel.numpy(), g["e_qvel"][1:], rtol=1e-8, atol=1e-8)
+    bav = get_angvel_fd_t(t(g["e_bquat"][:-1]), t(g["e_bquat"][1:]), 1 / 30)
+    np.testing.assert_allclose(bav.numpy(), g["e_bangvel"][1:], rtol=1e-8, atol=1e-8)
+    kpm = read_kpm(DEFAULT_KPM)
+    from oracle import np_oracle as O
+    idx = [int(x) for x in g["r_t"]]
+    bq = np.stack([O.get_body_quat(q) for q in g["r_qpos"]])
+    r, info = world_rfc_implicit_reward_t(t(g["r_xpos"]).reshape(3, 72), t(bq), t(g["r_prev_bquat"]), t(g["r_com"]), t(g["r_action"]),
+                                          t(g["e_bquat"][idx]), t(g["e_bangvel"][idx]), t(g["e_ee_wpos"][idx]), t(g["e_com"][idx]), t(kpm["uhc_b_diffw"]))
+    np.testing.assert_allclose(r.numpy(), g["r_reward"], rtol=1e-7)
+    np.testing.assert_allclose(info.numpy(), g["r_info"], rtol=1e-7)
+
+
+def test_running_state_online_equals_sequential_pushes(golden):
+    """RunningStateOnline.update on whole batches == ZFilter/RunningStat.push row by row (fixture from the reference's ZFilter)."""
+    from kinpoly_amd.uhc_env import RunningStateOnline
+    g = golden("gae_zfilter")
+    # the 50 pushed rows are regenerated with the fixture generator's draw order (tools/make_golden.py gen_gae_zfilter, seed 104)
+    rng = np.random.default_rng(104)
+    B = 257
+    rng.uniform(0, 1, size=(B, 1)); rng.normal(size=(B, 1)); rng.choice(B, 9, replace=False)
+    xs = rng.normal(size=(50, 784)) * rng.uniform(0.1, 3, size=784) + rng.normal(size=784)
+    rs = RunningStateOnline(784, 5.0, "cpu")
+    for chunk in torch.split(torch.tensor(xs), 7):
+        rs.update(chunk)
+    np.testing.assert_allclose(rs._mean64.numpy(), g["zf_mean"], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(torch.sqrt(rs._m2 / (rs.count - 1)).numpy(), g["zf_std"], rtol=1e-10)
+    y = rs(torch.tensor(g["zf_x"], dtype=torch.float32)[None], update=False)[0]
+    np.testing.assert_allclose(y.numpy(), g["zf_y"], rtol=1e-4, atol=1e-5)
