@@ -254,3 +254,34 @@ def test_agent_ar_iteration_and_checkpoint(tmp_path):
     agent.load_checkpoint(path)
     for k, v in agent.policy_net.state_dict().items():
         assert torch.equal(v, before[k]), k
+
+
+def test_batched_evaluation_and_coverage_files(tmp_path):
+    """run_seq / test_coverage (eval_ar_policy.py:178-262) batched: per-sequence records with the reference's keys, early
+    termination handled per env, fail-safe continuation, coverage pickles readable with joblib."""
+    import joblib
+    from kinpoly_amd.context import TrajARNet
+    from kinpoly_amd.env import BatchedHumanoidAREnv, standing_context
+    from kinpoly_amd.evaluate import run_sequences, write_coverage
+    n, T = 6, 10
+    torch.manual_seed(3)
+    env = BatchedHumanoidAREnv(n, 0, mode="test", seed=3)
+    ctx = standing_context(n, T, STD["qpos"], STD["qvel"], env.sim)
+    ctx["ar_qpos"] = ctx["qpos"].clone(); ctx["ar_qvel"] = torch.zeros((n, T, 75), device=env.device)
+    env.load_context(ctx)
+    env.reward_cfg.body_diff_thresh = 0.8              # a random-init policy drifts: some sequences terminate early
+    net = TrajARNet().to(env.device)
+    keys = [f"sit-{i:02d}" for i in range(n)]
+    res = run_sequences(env, net, keys, fail_safe=False)
+    assert set(res) == set(keys)
+    for k, r in res.items():
+        L = len(r["pred"])
+        assert 1 <= L <= T - 1 and len(r["target"]) == L and len(r["obj_pose"]) == L and r["pred"][0].shape == (76,) and r["obj_pose"][0].shape == (35,)
+        assert 0 < r["percent"] <= 1 and abs(r["percent"] - L / (T - 1)) < 1e-6 and r["fail_safe"] is False
+    assert min(len(r["pred"]) for r in res.values()) < T - 1, "expected at least one early termination in this set-up"
+    res_fs = run_sequences(env, net, keys, fail_safe=True)
+    assert all(len(r["pred"]) == T - 1 and r["percent"] == 1.0 for r in res_fs.values()) and any(r["fail_safe"] for r in res_fs.values())
+    cov = write_coverage(res_fs, str(tmp_path), 750, "features_test")
+    full = joblib.load(str(tmp_path / "0750_features_test_coverage_full.pkl")); brief = joblib.load(str(tmp_path / "0750_features_test_coverage.pkl"))
+    assert set(full) == set(keys) and set(brief[keys[0]]) == {"percent", "values", "fail_safe"}
+    assert cov == sum(1 for r in res_fs.values() if not r["fail_safe"])
