@@ -1,0 +1,58 @@
+#!/usr/bin/env python
+"""Counterpart of the reference's scripts/eval_ar_policy.py --mode stats on the batched engine: every sequence of the test
+set is one environment; writes `<iter>_<data_file>_coverage(.|_full).pkl` in the reference's format.
+
+The reference's test sets are not part of its repository; without `--data` this evaluates synthetic standing sequences.
+
+    python scripts/eval_ar_policy.py --num_seq 256 [--ckpt results/.../iter_0750.p] [--fail_safe] [--ar_mode]
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--num_seq", type=int, default=256)
+    ap.add_argument("--clip_len", type=int, default=100)
+    ap.add_argument("--ckpt", type=str, default="")
+    ap.add_argument("--iter", type=int, default=0)
+    ap.add_argument("--fail_safe", action="store_true")
+    ap.add_argument("--ar_mode", action="store_true")
+    ap.add_argument("--wild", action="store_true")
+    ap.add_argument("--result_dir", type=str, default="results/eval")
+    ap.add_argument("--data_file", type=str, default="synthetic_standing")
+    args = ap.parse_args()
+    from kinpoly_amd import checkpoint as ck
+    from kinpoly_amd import sim as kpsim
+    from kinpoly_amd.context import PolicyARContext, TrajARNet
+    from kinpoly_amd.env import BatchedHumanoidAREnv, standing_context
+    from kinpoly_amd.evaluate import run_sequences, write_coverage
+    std = np.load(os.path.join(ROOT, "tests", "golden", "standing_neutral.npz"))
+    n, T = args.num_seq, args.clip_len
+    torch.manual_seed(0)
+    env = BatchedHumanoidAREnv(n, 0, mode="test", wild=args.wild, ar_mode=args.ar_mode, seed=0)
+    net = TrajARNet().to(env.device)
+    if args.ckpt:
+        cp = ck.load_checkpoint(args.ckpt)
+        net.load_state_dict(ck.split_policy_dict(cp["policy_dict"]), strict=False)
+    g = torch.Generator().manual_seed(0)
+    ctx = standing_context(n, T, std["qpos"], std["qvel"], env.sim, (torch.rand(n, generator=g) * 2 - 1) * np.pi)
+    ctx["obj_pose"] = torch.tensor([0.0, 0, 0, 1, 0, 0, 0], device=env.device).repeat(n, T, 1)
+    ctx = PolicyARContext(net, kpsim.KpSim(env.model, n, 0), smooth=True).init_context(ctx)
+    env.load_context(ctx)
+    keys = [f"standing-{i:05d}" for i in range(n)]
+    res = run_sequences(env, net, keys, fail_safe=args.fail_safe)
+    cov = write_coverage(res, args.result_dir, args.iter, args.data_file)
+    pct = np.array([r["percent"] for r in res.values()])
+    print(f"Coverage of {cov} out of {n} | mean percent {pct.mean():.3f} | fail-safe used in {sum(r['fail_safe'] for r in res.values())}")
+
+
+if __name__ == "__main__":
+    main()
