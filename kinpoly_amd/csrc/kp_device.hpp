@@ -90,6 +90,8 @@ struct __attribute__((aligned(16))) EnvLdsObj : EnvLds {
     float oqa[D_MAXOBJ * 6];            // joint-space acceleration of the last solve (warm start, integration)
     float oas[D_MAXOBJ * 6], oa[D_MAXOBJ * 6], omres[D_MAXOBJ * 6], osrch[D_MAXOBJ * 6], oMv[D_MAXOBJ * 6], ogr[D_MAXOBJ * 6], ot[D_MAXOBJ * 6];
     float Sm[6 * D_MAXOBJ * (6 * D_MAXOBJ + 1)];   // dense object system [n][n + 1] (last column: right-hand side)
+    float cM[D_MAXCON * 6];             // per contact: D F G F^T of the active pyramid rows (world, xx yy zz xy xz yz)
+    float red[4 * 21];                  // row partials of the wave-wide vector sums (lane = contact)
 };
 
 // ------------------------------------------------------------------ small math

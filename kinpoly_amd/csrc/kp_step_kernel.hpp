@@ -58,6 +58,18 @@ __device__ __forceinline__ float wave_sum(float v) {
     return (r0 + r1) + (r2 + r3);
 }
 
+// wave-wide minimum, same exchange pattern (every lane gets the result)
+__device__ __forceinline__ float wave_min(float v) {
+    v = fminf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)));
+    v = fminf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)));
+    v = fminf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true)));
+    v = fminf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true)));
+    const int vi = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 48));
+    return fminf(fminf(r0, r1), fminf(r2, r3));
+}
+
 template <int NT>
 __device__ __forceinline__ float block_sum(EnvLds& s, float v, int tid) {
     v = wave_sum(v);
@@ -528,52 +540,60 @@ __device__ __forceinline__ float geom_sdf(const float* g, V3 x, V3& nw) {
     return dist;
 }
 
+__device__ __forceinline__ float geom_rbound(const float* g) { return g[0] == 0.f ? sqrtf(g[1] * g[1] + g[2] * g[2] + g[3] * g[3]) : sqrtf(g[1] * g[1] + g[2] * g[2]); }
+
+// Narrow phase (first wavefront).  Broad phase in parallel: lane = hull body (then lane = object geom) tests all its targets
+// (bit 0 = floor, bit j = geom j - 1) at once; the serial part only visits the pairs that passed, in the oracle's order
+// (body-major, floor first), so contact indices, con_start[] grouping and tie-breaks are unchanged.
 template <int NT, bool OBJ>
 __device__ __forceinline__ void collide_plane(EnvLds& s, const DevTables& T, const Params& P, int tid) {
     if (tid < 64) {
-        const int bb = tid < D_NB ? tid : 0;
-        bool near = (tid < D_NB) && !(s.xpos[3 * bb + 2] - T.body_rbound[bb] > P.margin);
-        unsigned long long mask = __ballot(near);
-        int ncon = 0;
+        int ncon = 0, next_b = 0;
         const int ngeom = OBJ ? static_cast<EnvLdsObj&>(s).ngeom : 0;
-        for (int b = 0; b < D_NB; b++) {
-            if (tid == 0) s.con_start[b] = ncon;
-            if (!P.contact) continue;
+        unsigned mybits = 0;
+        if (tid < D_NB && P.contact) {
+            const V3 xb = ld3(s.xpos + 3 * tid);
+            const float rb = T.body_rbound[tid];
+            if (!(xb.z - rb > P.margin)) mybits = 1u;
+            if constexpr (OBJ) {
+                for (int gi = 0; gi < ngeom; gi++) {
+                    const float* g = static_cast<EnvLdsObj&>(s).geom + 17 * gi;
+                    const V3 dx = xb - ld3(g + 4);
+                    if (sqrtf(dot(dx, dx)) - rb - geom_rbound(g) > P.margin) continue;
+                    V3 ntmp;                                   // the signed distance is 1-Lipschitz: no vertex of the hull can be closer
+                    if (geom_sdf(g, xb, ntmp) - rb > P.margin) continue;
+                    mybits |= 2u << gi;
+                }
+            }
+        }
+        unsigned long long bodies = __ballot(mybits != 0u);
+        while (bodies) {
+            const int b = __ffsll((long long)bodies) - 1;
+            bodies &= bodies - 1ull;
+            unsigned bits = (unsigned)__builtin_amdgcn_readlane((int)mybits, b);
+            if (tid == 0) for (int bb = next_b; bb <= b; bb++) s.con_start[bb] = ncon;
+            next_b = b + 1;
             const int vadr = T.vert_adr[b], nvb = T.vert_adr[b + 1] - vadr;
-            const float rb = T.body_rbound[b];
             const V3 xb = ld3(s.xpos + 3 * b);
             float R[9];
-            bool have_R = false;
+            q2mat(Q4{s.xquat[4 * b], s.xquat[4 * b + 1], s.xquat[4 * b + 2], s.xquat[4 * b + 3]}, R);
             V3 v = v3(0.f, 0.f, 0.f), xw = v3(0.f, 0.f, 0.f);
-            for (int gi = -1; gi < ngeom; gi++) {
+            if (tid < nvb) { v = ld3(T.verts + 3 * (vadr + tid)); xw = xb + mulmat(R, v); }
+            while (bits) {
+                const int gi = __ffs((int)bits) - 2;           // -1 = floor
+                bits &= bits - 1u;
                 const float* g = gi < 0 ? nullptr : static_cast<EnvLdsObj&>(s).geom + 17 * gi;
-                if (gi < 0) { if (!((mask >> b) & 1ull)) continue; }
-                else {
-                    const V3 dx = xb - ld3(g + 4);
-                    const float gr = g[0] == 0.f ? sqrtf(g[1] * g[1] + g[2] * g[2] + g[3] * g[3]) : sqrtf(g[1] * g[1] + g[2] * g[2]);
-                    if (sqrtf(dot(dx, dx)) - rb - gr > P.margin) continue;
-                }
-                if (!have_R) {
-                    q2mat(Q4{s.xquat[4 * b], s.xquat[4 * b + 1], s.xquat[4 * b + 2], s.xquat[4 * b + 3]}, R);
-                    if (tid < nvb) { v = ld3(T.verts + 3 * (vadr + tid)); xw = xb + mulmat(R, v); }
-                    have_R = true;
-                }
                 float dist = 3.0e38f;
                 V3 nrm = v3(0.f, 0.f, 1.f);
-                if (tid < nvb) dist = gi < 0 ? xb.z + (R[6] * v.x + R[7] * v.y + R[8] * v.z) : geom_sdf(g, xw, nrm);
+                if (tid < nvb) dist = gi < 0 ? xw.z : geom_sdf(g, xw, nrm);
                 bool cand = dist < P.margin;
                 for (int r = 0; r < D_CON_PER_GEOM; r++) {
-                    float dmin = cand ? dist : 3.0e38f;
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) dmin = fminf(dmin, __shfl_xor(dmin, o, 64));
-                    if (!(dmin < P.margin)) break;
-                    int idx = (cand && dist == dmin) ? tid : 64;
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) idx = min(idx, __shfl_xor(idx, o, 64));
+                    if (__ballot(cand) == 0ull) break;
+                    const float dmin = wave_min(cand ? dist : 3.0e38f);
+                    const int idx = __ffsll((long long)__ballot(cand && dist == dmin)) - 1;      // deepest vertex, lowest index on ties
                     if (ncon < D_MAXCON) {
                         if (tid == idx) {
-                            const V3 w = mulmat(R, v);
-                            st3(s.con_pos + 3 * ncon, xb + w - (0.5f * dist) * nrm);
+                            st3(s.con_pos + 3 * ncon, xw - (0.5f * dist) * nrm);
                             s.con_dist[ncon] = dist; s.con_body[ncon] = b;
                             if (OBJ) {
                                 EnvLdsObj& so = static_cast<EnvLdsObj&>(s);
@@ -587,47 +607,55 @@ __device__ __forceinline__ void collide_plane(EnvLds& s, const DevTables& T, con
                 }
             }
         }
-        if (tid == 0) s.con_start[D_NB] = ncon;
+        if (tid == 0) for (int bb = next_b; bb <= D_NB; bb++) s.con_start[bb] = ncon;
         if constexpr (OBJ) {
             // dynamic objects in slot order: the 8 vertices of every geom (lane = vertex) against the floor, then against the geoms
             // of the objects in higher slots; up to 4 deepest per pair (oracle: kpo_collide, second loop)
             EnvLdsObj& so = static_cast<EnvLdsObj&>(s);
             int slot_done = 0;
-            for (int ga = so.ngeom_static; ga < ngeom && P.contact; ga++) {
+            unsigned gbits = 0;
+            if (tid >= so.ngeom_static && tid < ngeom && P.contact) {
+                const float* g = so.geom + 17 * tid;
+                const V3 gp = ld3(g + 4);
+                const float gra = geom_rbound(g);
+                const int ka = so.gobj[tid];
+                if (!(gp.z - gra > P.margin)) gbits = 1u;
+                for (int gb = 0; gb < ngeom; gb++) {
+                    const float* h = so.geom + 17 * gb;
+                    if (so.gobj[gb] < 0 || so.gobj[gb] <= ka) continue;
+                    const V3 dx = gp - ld3(h + 4);
+                    if (sqrtf(dot(dx, dx)) - gra - geom_rbound(h) > P.margin) continue;
+                    gbits |= 2u << gb;
+                }
+            }
+            unsigned long long geoms = __ballot(gbits != 0u);
+            while (geoms) {
+                const int ga = __ffsll((long long)geoms) - 1;
+                geoms &= geoms - 1ull;
+                unsigned bits = (unsigned)__builtin_amdgcn_readlane((int)gbits, ga);
                 const float* g = so.geom + 17 * ga;
                 const int ka = so.gobj[ga];
                 while (slot_done < ka) { slot_done++; if (tid == 0) s.con_start[D_NB + slot_done] = ncon; }
-                const V3 gp = ld3(g + 4);
-                const float gra = g[0] == 0.f ? sqrtf(g[1] * g[1] + g[2] * g[2] + g[3] * g[3]) : sqrtf(g[1] * g[1] + g[2] * g[2]);
-                V3 xw = gp;
+                V3 xw;
                 {
                     const int v = tid & 7;
                     V3 l;
                     if (g[0] == 0.f) l = v3((v & 1) ? g[1] : -g[1], (v & 2) ? g[2] : -g[2], (v & 4) ? g[3] : -g[3]);
                     else { const int a = v & 3; l = v3(g[1] * (a == 0 ? 1.f : (a == 2 ? -1.f : 0.f)), g[1] * (a == 1 ? 1.f : (a == 3 ? -1.f : 0.f)), (v & 4) ? g[2] : -g[2]); }
-                    xw = gp + mulmat(g + 7, l);
+                    xw = ld3(g + 4) + mulmat(g + 7, l);
                 }
-                for (int gb = -1; gb < ngeom; gb++) {
+                while (bits) {
+                    const int gb = __ffs((int)bits) - 2;
+                    bits &= bits - 1u;
                     const float* h = gb < 0 ? nullptr : so.geom + 17 * gb;
-                    if (gb >= 0 && (so.gobj[gb] < 0 || so.gobj[gb] <= ka)) continue;
-                    if (gb < 0) { if (gp.z - gra > P.margin) continue; }
-                    else {
-                        const V3 dx = gp - ld3(h + 4);
-                        const float grb = h[0] == 0.f ? sqrtf(h[1] * h[1] + h[2] * h[2] + h[3] * h[3]) : sqrtf(h[1] * h[1] + h[2] * h[2]);
-                        if (sqrtf(dot(dx, dx)) - gra - grb > P.margin) continue;
-                    }
                     float dist = 3.0e38f;
                     V3 nrm = v3(0.f, 0.f, 1.f);
                     if (tid < 8) dist = gb < 0 ? xw.z : geom_sdf(h, xw, nrm);
                     bool cand = dist < P.margin;
                     for (int r = 0; r < D_OBJ_CON_PER_GEOM; r++) {
-                        float dmin = cand ? dist : 3.0e38f;
-#pragma unroll
-                        for (int o = 32; o > 0; o >>= 1) dmin = fminf(dmin, __shfl_xor(dmin, o, 64));
-                        if (!(dmin < P.margin)) break;
-                        int idx = (cand && dist == dmin) ? tid : 64;
-#pragma unroll
-                        for (int o = 32; o > 0; o >>= 1) idx = min(idx, __shfl_xor(idx, o, 64));
+                        if (__ballot(cand) == 0ull) break;
+                        const float dmin = wave_min(cand ? dist : 3.0e38f);
+                        const int idx = __ffsll((long long)__ballot(cand && dist == dmin)) - 1;
                         if (ncon < D_MAXCON) {
                             if (tid == idx) {
                                 st3(s.con_pos + 3 * ncon, xw - (0.5f * dist) * nrm);
@@ -993,77 +1021,158 @@ __device__ __forceinline__ void obj_forward(EnvLdsObj& s, const Params& P, int t
     KP_SYNC();
 }
 
-// Gaussian elimination of the n x n SPD system in s.Sm (row stride 13, right-hand side in column n); solution -> column n
-__device__ __forceinline__ void dense_solve(EnvLdsObj& s, int n, int tid) {
-    constexpr int ST = 6 * D_MAXOBJ + 1;
-    for (int j = 0; j < n; j++) {
-        if (tid > j && tid < n) {
-            const float l = s.Sm[tid * ST + j] / s.Sm[j * ST + j];
-            for (int c = j + 1; c <= n; c++) s.Sm[tid * ST + c] -= l * s.Sm[j * ST + c];
-            s.Sm[tid * ST + j] = l;                         // keep the multiplier for dense_resolve
+// The <= 12 x 12 SPD object system, one row per lane, held in registers (row stride 13 in s.Sm, right-hand side in column n).
+// Gaussian elimination with the pivot row broadcast by v_readlane; rows >= n are identity padding.  refactor = false reuses the
+// multipliers / upper triangle a previous call stored back to s.Sm and only pushes a new right-hand side through them.
+__device__ __forceinline__ void dense_solve(EnvLdsObj& s, int n, int tid, bool refactor) {
+    constexpr int ST = 6 * D_MAXOBJ + 1, NN = 6 * D_MAXOBJ;
+    float a[NN + 1];
+    const bool rowok = tid < n;
+#pragma unroll
+    for (int c = 0; c < NN; c++) a[c] = (rowok && c < n) ? s.Sm[tid * ST + c] : (c == tid ? 1.f : 0.f);
+    a[NN] = rowok ? s.Sm[tid * ST + n] : 0.f;
+#pragma unroll
+    for (int j = 0; j < NN; j++) {
+        const float pinv = 1.0f / __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a[j]), j));
+        const bool lower = tid > j;
+        const float l = refactor ? (lower ? a[j] * pinv : 0.f) : (lower ? a[j] : 0.f);
+        if (refactor) {
+#pragma unroll
+            for (int c = j + 1; c < NN; c++) a[c] -= l * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a[c]), j));
+            if (lower) a[j] = l;
         }
-        KP_SYNC();
+        a[NN] -= l * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a[NN]), j));
     }
-    for (int j = n - 1; j >= 0; j--) {
-        if (tid == j) s.Sm[j * ST + n] /= s.Sm[j * ST + j];
-        KP_SYNC();
-        if (tid < j) s.Sm[tid * ST + n] -= s.Sm[tid * ST + j] * s.Sm[j * ST + n];
-        KP_SYNC();
+#pragma unroll
+    for (int j = NN - 1; j >= 0; j--) {
+        const float xj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a[NN] / a[j]), j));
+        if (tid == j) a[NN] = xj;
+        if (tid < j) a[NN] -= a[j] * xj;
     }
-}
-// a new right-hand side (column n) through the factors dense_solve left in place
-__device__ __forceinline__ void dense_resolve(EnvLdsObj& s, int n, int tid) {
-    constexpr int ST = 6 * D_MAXOBJ + 1;
-    for (int j = 0; j < n; j++) {
-        if (tid > j && tid < n) s.Sm[tid * ST + n] -= s.Sm[tid * ST + j] * s.Sm[j * ST + n];
-        KP_SYNC();
+    if (rowok) {
+        if (refactor) {
+#pragma unroll
+            for (int c = 0; c < NN; c++) if (c < n) s.Sm[tid * ST + c] = a[c];
+        }
+        s.Sm[tid * ST + n] = a[NN];
     }
-    for (int j = n - 1; j >= 0; j--) {
-        if (tid == j) s.Sm[j * ST + n] /= s.Sm[j * ST + j];
-        KP_SYNC();
-        if (tid < j) s.Sm[tid * ST + n] -= s.Sm[tid * ST + j] * s.Sm[j * ST + n];
-        KP_SYNC();
-    }
+    KP_SYNC();
 }
 
-// object rows of the Newton system: Sm = blockdiag(I_eff) + sum of the active contact matrices K_c over the contacts that touch an
-// object (own block +K_c, object-object block -K_c); column n = rhs
+// per contact (lane = contact): the active-row matrix D F G F^T and the contact force at the current residuals
+template <int NT>
+__device__ __forceinline__ void con_prepare(EnvLdsObj& s, const Params& P, int tid) {
+    for (int c = tid; c < s.ncon; c += NT) {
+        const V3 mx = con_DG(s, P, c, v3(1.f, 0.f, 0.f)), my = con_DG(s, P, c, v3(0.f, 1.f, 0.f)), mz = con_DG(s, P, c, v3(0.f, 0.f, 1.f));
+        float* m = s.cM + 6 * c;
+        m[0] = mx.x; m[1] = my.y; m[2] = mz.z; m[3] = mx.y; m[4] = mx.z; m[5] = my.z;
+        st3(s.sa + 3 * c, con_force(s, P, c));     // contact forces live in sa/sw (192 of 288 floats) until the next wrench_project
+    }
+    KP_SYNC();
+}
+// K_c acc from the prepared matrix
+__device__ __forceinline__ S6 con_Kp(const EnvLdsObj& s, int c, S6 acc, V3 o) {
+    const V3 p = ld3(s.con_pos + 3 * c) - o;
+    const V3 a = acc.l + cross(acc.a, p);
+    const float* m = s.cM + 6 * c;
+    const V3 w = v3(m[0] * a.x + m[3] * a.y + m[4] * a.z, m[3] * a.x + m[1] * a.y + m[5] * a.z, m[4] * a.x + m[5] * a.y + m[2] * a.z);
+    return S6{cross(p, w), w};
+}
+__device__ __forceinline__ S6 wave_sum6(S6 v) {
+    return S6{v3(wave_sum(v.a.x), wave_sum(v.a.y), wave_sum(v.a.z)), v3(wave_sum(v.l.x), wave_sum(v.l.y), wave_sum(v.l.z))};
+}
+
+// sum of V per-lane values over the 64 lanes (lane = contact): four DPP exchanges inside each 16-lane row, the four row sums meet
+// in LDS.  Deterministic order.  The V results are handed to `store(v, sum)` on lane v.
+__device__ __forceinline__ float row_sum16(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+    return v;
+}
+template <int V>
+__device__ __forceinline__ float lanes_sum(EnvLdsObj& s, const float* vals, int tid) {
+    static_assert(V <= 21, "red[] holds 4 x 21 partials");
+#pragma unroll
+    for (int v = 0; v < V; v++) {
+        const float r = row_sum16(vals[v]);
+        if ((tid & 15) == 0) s.red[(tid >> 4) * 21 + v] = r;
+    }
+    KP_SYNC();
+    const float out = tid < V ? (s.red[tid] + s.red[21 + tid]) + (s.red[42 + tid] + s.red[63 + tid]) : 0.f;
+    KP_SYNC();
+    return out;                                                     // lane v < V holds sum v
+}
+// symmetric 6 x 6 index (r <= c) -> 0..20, row-major upper triangle
+__device__ __forceinline__ constexpr int sym6(int r, int c) { return r <= c ? (r * (13 - r)) / 2 + (c - r) : (c * (13 - c)) / 2 + (r - c); }
+
+// object rows of the Newton system: Sm = blockdiag(I_eff) + sum of the active contact matrices K_c = P M_c P^T over the contacts that
+// touch an object (own block +K_c, object-object block -K_c); column n = sign * rhs.  Lane = contact: every lane forms the 21 unique
+// entries of its K_c = [[X M X^T, X M], [M X^T, M]] (X = [p]x), then one wave-wide vector sum per block.
 __device__ __forceinline__ void obj_hessian(EnvLdsObj& s, const Params& P, const float* rhs, float sign, int tid) {
     constexpr int ST = 6 * D_MAXOBJ + 1;
-    const int n = 6 * s.nobj;
-    if (tid < n) {
-        const int k = tid / 6, r = tid - 6 * k;
-        float* row = s.Sm + ST * tid;
-        for (int c = 0; c < n; c++) row[c] = (c / 6 == k) ? inert_entry(s.oIe + 10 * k, r, c - 6 * k) : 0.f;
-        row[n] = sign * rhs[tid];
-        const V3 o = ld3(s.xpos);
-        const S6 er = unit6(r);
-        for (int c = 0; c < s.ncon; c++) {
-            const int A = s.con_body[c], B = s.con_b2[c];
-            if (A != D_NB + k && B != D_NB + k) continue;
-            const S6 Kr = con_K(s, P, c, er, o);
-            const float kr[6] = {Kr.a.x, Kr.a.y, Kr.a.z, Kr.l.x, Kr.l.y, Kr.l.z};
-            const int other = (A == D_NB + k) ? B : A;
+    const int nobj = s.nobj, n = 6 * nobj;
+    const V3 o = ld3(s.xpos);
+    const bool have = tid < s.ncon;
+    const int c = have ? tid : 0;
+    const int A = have ? s.con_body[c] : -1, B = have ? (int)s.con_b2[c] : -1;
+    float K[21];
+    {
+        const V3 p = ld3(s.con_pos + 3 * c) - o;
+        const float* m = s.cM + 6 * c;
+        const V3 m0 = v3(m[0], m[3], m[4]), m1 = v3(m[3], m[1], m[5]), m2 = v3(m[4], m[5], m[2]);     // columns (= rows) of M
+        const V3 b0 = cross(p, m0), b1 = cross(p, m1), b2 = cross(p, m2);                               // B = X M, column j = p x M[:, j]
+        // rows of B: B_i = (b0[i], b1[i], b2[i]); A = X M X^T, row i = p x B_i
+        const V3 a0 = cross(p, v3(b0.x, b1.x, b2.x)), a1 = cross(p, v3(b0.y, b1.y, b2.y)), a2 = cross(p, v3(b0.z, b1.z, b2.z));
+        K[sym6(0, 0)] = a0.x; K[sym6(0, 1)] = a0.y; K[sym6(0, 2)] = a0.z; K[sym6(1, 1)] = a1.y; K[sym6(1, 2)] = a1.z; K[sym6(2, 2)] = a2.z;
+        K[sym6(0, 3)] = b0.x; K[sym6(0, 4)] = b1.x; K[sym6(0, 5)] = b2.x;
+        K[sym6(1, 3)] = b0.y; K[sym6(1, 4)] = b1.y; K[sym6(1, 5)] = b2.y;
+        K[sym6(2, 3)] = b0.z; K[sym6(2, 4)] = b1.z; K[sym6(2, 5)] = b2.z;
+        K[sym6(3, 3)] = m[0]; K[sym6(3, 4)] = m[3]; K[sym6(3, 5)] = m[4]; K[sym6(4, 4)] = m[1]; K[sym6(4, 5)] = m[5]; K[sym6(5, 5)] = m[2];
+    }
+    // lane v < 21 owns unique entry v: its (r, cc)
+    int er = 0, ec = tid;
 #pragma unroll
-            for (int i = 0; i < 6; i++) row[6 * k + i] += kr[i];
-            if (other >= D_NB) {
+    for (int r = 0; r < 5; r++) if (ec >= 6 - er && er == r) { ec -= 6 - er; er++; }
+    ec += er;
+    for (int blk = 0; blk < (nobj == 2 ? 3 : 1); blk++) {           // blocks (0,0), (1,1), (0,1)
+        const int k = blk == 1 ? 1 : 0;
+        float w;
+        if (blk < 2) w = (have && (A == D_NB + k || B == D_NB + k)) ? 1.f : 0.f;
+        else w = (have && A >= D_NB && B >= D_NB) ? -1.f : 0.f;
+        float vals[21];
 #pragma unroll
-                for (int i = 0; i < 6; i++) row[6 * (other - D_NB) + i] -= kr[i];
+        for (int v = 0; v < 21; v++) vals[v] = w * K[v];
+        const float sum = lanes_sum<21>(s, vals, tid);
+        if (tid < 21) {
+            if (blk < 2) {
+                const float v = sum + inert_entry(s.oIe + 10 * k, er, ec);
+                s.Sm[(6 * k + er) * ST + 6 * k + ec] = v; s.Sm[(6 * k + ec) * ST + 6 * k + er] = v;
+            } else {                                                 // K symmetric: block (0,1) = -K, block (1,0) = -K^T = -K
+                s.Sm[er * ST + 6 + ec] = sum; s.Sm[ec * ST + 6 + er] = sum; s.Sm[(6 + ec) * ST + er] = sum; s.Sm[(6 + er) * ST + ec] = sum;
             }
         }
     }
+    if (tid < n) s.Sm[tid * ST + n] = sign * rhs[tid];
     KP_SYNC();
 }
 
 // out[6k..] = sum over the hull contacts whose surface belongs to object k of K_c sv[hull]   (= -H_oh y for the y behind sv)
 __device__ __forceinline__ void obj_coupling_u(EnvLdsObj& s, const Params& P, float* out, int tid) {
-    if (tid < s.nobj) {
-        const V3 o = ld3(s.xpos);
-        S6 acc = S6{v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f)};
-        for (int c = 0; c < s.con_start[D_NB]; c++)
-            if (s.con_b2[c] == D_NB + tid) acc = acc + con_K(s, P, c, lds6(s.sv + 6 * s.con_body[c]), o);
-        sts6(out + 6 * tid, acc);
+    const V3 o = ld3(s.xpos);
+    const bool have = tid < s.con_start[D_NB];
+    const int c = have ? tid : 0;
+    const int B = have ? (int)s.con_b2[c] : -1;
+    const S6 w = con_Kp(s, c, lds6(s.sv + 6 * s.con_body[c]), o);
+    float vals[12];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const float f = B == D_NB + k ? 1.f : 0.f;
+        vals[6 * k] = f * w.a.x; vals[6 * k + 1] = f * w.a.y; vals[6 * k + 2] = f * w.a.z; vals[6 * k + 3] = f * w.l.x; vals[6 * k + 4] = f * w.l.y; vals[6 * k + 5] = f * w.l.z;
     }
+    const float sum = lanes_sum<12>(s, vals, tid);
+    if (tid < 6 * s.nobj) out[tid] = sum;
     KP_SYNC();
 }
 // sw[b] = sign * sum over hull b's contacts with an object surface (slot ksel, or any if ksel < 0) of K_c acc[slot]
@@ -1073,10 +1182,28 @@ __device__ __forceinline__ void hull_coupling_wrench(EnvLdsObj& s, const Params&
         S6 W = S6{v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f)};
         for (int c = s.con_start[tid]; c < s.con_start[tid + 1]; c++) {
             const int B = s.con_b2[c];
-            if (B >= D_NB && (ksel < 0 || B == D_NB + ksel)) W = W + con_K(s, P, c, lds6(acc + 6 * (B - D_NB)), o);
+            if (B >= D_NB && (ksel < 0 || B == D_NB + ksel)) W = W + con_Kp(s, c, lds6(acc + 6 * (B - D_NB)), o);
         }
         sts6(s.sw + 6 * tid, sign * W);
     }
+    KP_SYNC();
+}
+// object part of the gradient: g_k = mres_k - sum_{vertex side = k} [p x F; F] + sum_{surface side = k} [p x F; F]
+__device__ __forceinline__ void obj_gradient(EnvLdsObj& s, int tid) {
+    const V3 o = ld3(s.xpos);
+    const bool have = tid < s.ncon;
+    const int c = have ? tid : 0;
+    const int A = have ? s.con_body[c] : -1, B = have ? (int)s.con_b2[c] : -1;
+    const V3 F = ld3(s.sa + 3 * c), p = ld3(s.con_pos + 3 * c) - o;
+    const V3 t = cross(p, F);
+    float vals[12];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const float f = A == D_NB + k ? -1.f : (B == D_NB + k ? 1.f : 0.f);
+        vals[6 * k] = f * t.x; vals[6 * k + 1] = f * t.y; vals[6 * k + 2] = f * t.z; vals[6 * k + 3] = f * F.x; vals[6 * k + 4] = f * F.y; vals[6 * k + 5] = f * F.z;
+    }
+    const float sum = lanes_sum<12>(s, vals, tid);
+    if (tid < 6 * s.nobj) s.ogr[tid] = s.omres[tid] + sum;
     KP_SYNC();
 }
 // 0.5 mres_o . (a_o - a_smooth_o) summed over the objects (every lane gets the value)
@@ -1128,7 +1255,7 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
             }
             KP_SYNC();
         }
-        dense_solve(s, no6, tid);
+        dense_solve(s, no6, tid, true);
         if (tid < no6) s.oas[tid] = s.Sm[ST * tid + no6];
         KP_SYNC();
     }
@@ -1170,19 +1297,7 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
     for (; it < P.max_iter; it++) {
         // gradient: humanoid dofs (mres - J^T f) and object wrenches
         wrench_project<NT, true>(s, P, nullptr, s.grad, false, true, tid);
-        if (tid < nobj) {
-            const V3 o = ld3(s.xpos);
-            S6 g = lds6(s.omres + 6 * tid);
-            for (int c = 0; c < s.ncon; c++) {
-                const int A = s.con_body[c], B = s.con_b2[c];
-                if (A != D_NB + tid && B != D_NB + tid) continue;
-                const V3 F = con_force(s, P, c), p = ld3(s.con_pos + 3 * c) - o;
-                const float sg = (A == D_NB + tid) ? -1.f : 1.f;
-                g = g + sg * S6{cross(p, F), F};
-            }
-            sts6(s.ogr + 6 * tid, g);
-        }
-        KP_SYNC();
+        if (nobj > 0) { con_prepare<NT>(s, P, tid); obj_gradient(s, tid); }
         float g2 = 0.f, changed = 0.f;
         for (int i = tid; i < D_NV; i += NT) {
             const float g = s.mres[i] + s.grad[i];
@@ -1213,41 +1328,47 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
             for (int e = 0; e < 4; e++) couple |= row_val(e, P.mu, jn, jt1, jt2) < 0.f;
         }
         couple = __ballot(couple) != 0ull;
-        if (!refactor) {
-            // same active set as the previous iteration: the articulated-body factors and the eliminated object system stand
-            aba_resolve(s, L8, s.x, nullptr, s.search);
-            if (no6 > 0) {
-                if (tid < no6) s.Sm[ST * tid + no6] = -s.ogr[tid];
-                KP_SYNC();
-                if (couple) { obj_coupling_u(s, P, s.ot, tid); if (tid < no6) s.Sm[ST * tid + no6] += s.ot[tid]; KP_SYNC(); }
-                dense_resolve(s, no6, tid);
-                if (tid < no6) s.osrch[tid] = s.Sm[ST * tid + no6];
-                KP_SYNC();
-                if (couple) { hull_coupling_wrench(s, P, -1, s.osrch, 1.0f, tid); aba_resolve(s, L8, s.x, s.sw, s.search); }
-            }
-        } else if (!couple) {
+        // H = [[H_hh, H_ho], [H_oh, H_oo]] by block elimination.  refactor: one articulated-body factorisation of H_hh (+ the object
+        // rows); the passes below only push right-hand sides through it (pass -1: y0 when the factors are reused, passes 0..n-1:
+        // the Schur-complement columns when a hull touches an object, pass n: the back-substitution)
+        if (refactor) {
             if (no6 > 0) obj_hessian(s, P, s.ogr, -1.0f, tid);
-            aba_solve<NT, true>(s, P, L8, s.x, s.search, true, tid);
-            if (no6 > 0) { dense_solve(s, no6, tid); if (tid < no6) s.osrch[tid] = s.Sm[ST * tid + no6]; KP_SYNC(); }
-        } else {
-            obj_hessian(s, P, s.ogr, -1.0f, tid);
-            aba_solve<NT, true>(s, P, L8, s.x, s.search, true, tid);          // factorisation + y0 = H_hh^-1 (-g_h)
-            obj_coupling_u(s, P, s.ot, tid);                                    // -H_oh y0
-            if (tid < no6) s.Sm[ST * tid + no6] += s.ot[tid];
-            for (int kj = 0; kj < no6; kj++) {
-                if (tid < no6) s.oMv[tid] = tid == kj ? 1.f : 0.f;
-                KP_SYNC();
-                hull_coupling_wrench(s, P, kj / 6, s.oMv, -1.0f, tid);         // H_ho e_kj as body wrenches
-                aba_resolve(s, L8, nullptr, s.sw, s.Mv);                        // z = H_hh^-1 H_ho e_kj (sv = its spatial accelerations)
+            aba_solve<NT, true>(s, P, L8, s.x, s.search, true, tid);          // y0 = H_hh^-1 (-g_h); sv = its spatial accelerations
+            if (couple) { obj_coupling_u(s, P, s.ot, tid); if (tid < no6) s.Sm[ST * tid + no6] += s.ot[tid]; KP_SYNC(); }     // rhs_o -= H_oh y0
+        }
+        if (!(refactor && no6 == 0)) {
+            int kj = refactor ? (couple ? 0 : no6) : -1;
+            while (true) {
+                const float* rhsp = nullptr; const float* wr = nullptr; float* outp = s.Mv;
+                if (kj == -1) { rhsp = s.x; outp = s.search; }
+                else if (kj < no6) {
+                    if (tid < no6) s.oMv[tid] = tid == kj ? 1.f : 0.f;
+                    KP_SYNC();
+                    hull_coupling_wrench(s, P, kj / 6, s.oMv, -1.0f, tid);      // H_ho e_kj as body wrenches
+                    wr = s.sw;
+                } else {
+                    dense_solve(s, no6, tid, refactor);
+                    if (tid < no6) s.osrch[tid] = s.Sm[ST * tid + no6];
+                    KP_SYNC();
+                    if (!couple) break;
+                    hull_coupling_wrench(s, P, -1, s.osrch, 1.0f, tid);         // -H_ho da
+                    rhsp = s.x; wr = s.sw; outp = s.search;
+                }
+                aba_resolve(s, L8, rhsp, wr, outp);
+                if (kj == no6) break;
+                if (kj == -1) {
+                    if (no6 == 0) break;
+                    if (tid < no6) s.Sm[ST * tid + no6] = -s.ogr[tid];
+                    KP_SYNC();
+                    if (couple) { obj_coupling_u(s, P, s.ot, tid); if (tid < no6) s.Sm[ST * tid + no6] += s.ot[tid]; KP_SYNC(); }
+                    kj = no6;
+                    continue;
+                }
                 obj_coupling_u(s, P, s.ot, tid);                                // -H_oh z
                 if (tid < no6) s.Sm[ST * tid + kj] += s.ot[tid];
                 KP_SYNC();
+                kj++;
             }
-            dense_solve(s, no6, tid);
-            if (tid < no6) s.osrch[tid] = s.Sm[ST * tid + no6];
-            KP_SYNC();
-            hull_coupling_wrench(s, P, -1, s.osrch, 1.0f, tid);                 // -H_ho da
-            aba_resolve(s, L8, s.x, s.sw, s.search);
         }
         if (tid < no6) s.sv[6 * D_NB + tid] = s.osrch[tid];
         KP_SYNC();
