@@ -1320,14 +1320,17 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
         // search direction
         const bool refactor = it == 0 || changed > 0.f;
         nfact += refactor;
-        bool couple = false;
+        int cslot = -1;                                   // object slot this lane's hull contact presses on with an active row
         for (int c = tid; c < s.con_start[D_NB]; c += NT) {
             if (s.con_b2[c] < D_NB) continue;
             const float jn = s.jar3[3 * c], jt1 = s.jar3[3 * c + 1], jt2 = s.jar3[3 * c + 2];
+            bool act = false;
 #pragma unroll
-            for (int e = 0; e < 4; e++) couple |= row_val(e, P.mu, jn, jt1, jt2) < 0.f;
+            for (int e = 0; e < 4; e++) act |= row_val(e, P.mu, jn, jt1, jt2) < 0.f;
+            if (act) cslot = s.con_b2[c] - D_NB;
         }
-        couple = __ballot(couple) != 0ull;
+        const unsigned cmask = (__ballot(cslot == 0) != 0ull ? 1u : 0u) | (__ballot(cslot == 1) != 0ull ? 2u : 0u);
+        const bool couple = cmask != 0u;
         // H = [[H_hh, H_ho], [H_oh, H_oo]] by block elimination.  refactor: one articulated-body factorisation of H_hh (+ the object
         // rows); the passes below only push right-hand sides through it (pass -1: y0 when the factors are reused, passes 0..n-1:
         // the Schur-complement columns when a hull touches an object, pass n: the back-substitution)
@@ -1342,6 +1345,7 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
                 const float* rhsp = nullptr; const float* wr = nullptr; float* outp = s.Mv;
                 if (kj == -1) { rhsp = s.x; outp = s.search; }
                 else if (kj < no6) {
+                    if (!((cmask >> (kj / 6)) & 1u)) { kj += 6; continue; }     // no hull presses on this object: H_ho e = 0, column done
                     if (tid < no6) s.oMv[tid] = tid == kj ? 1.f : 0.f;
                     KP_SYNC();
                     hull_coupling_wrench(s, P, kj / 6, s.oMv, -1.0f, tid);      // H_ho e_kj as body wrenches

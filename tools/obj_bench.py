@@ -27,6 +27,9 @@ def block(active):
 
 for name, active, lift in (("standing on the step box", {4: [x0, y0, 0.3705, 1, 0, 0, 0]}, 0.341),
                            ("push scene (box on table, 0.45 m ahead)", {1: [x0 + 0.75, y0, 0.921, 1, 0, 0, 0], 2: [x0 + 0.75, y0, 0.7905, 1, 0, 0, 0]}, 0.0),
+                           ("push scene 2 m away (box on table, far from the humanoid)", {1: [x0 + 2.5, y0, 0.921, 1, 0, 0, 0], 2: [x0 + 2.5, y0, 0.7905, 1, 0, 0, 0]}, 0.0),
+                           ("table alone 2 m away (1 object, 16 floor contacts)", {2: [x0 + 2.0, y0, 0.7905, 1, 0, 0, 0]}, 0.0),
+                           ("box + step on the floor 2 m away (2 objects, 8 floor contacts)", {1: [x0 + 2.0, y0 + 1.0, 0.2205, 1, 0, 0, 0], 4: [x0 + 2.0, y0, 0.3705, 1, 0, 0, 0]}, 0.0),
                            ("step box 2 m away (dynamic, untouched)", {4: [x0 + 2.0, y0, 0.3705, 1, 0, 0, 0]}, 0.0),
                            ("step box 2 m away, dynamic_objects=0 (static obstacle)", {4: [x0 + 2.0, y0, 0.3705, 1, 0, 0, 0]}, -1.0),
                            ("no object (floor-only kernel)", {}, 0.0)):
