@@ -184,10 +184,12 @@ int launch_step(kp_sim* s, const float* action, int nsub, const uint8_t* mask, b
         s->ring_used++;
     }
     if (time_it) HIP_OK(hipEventRecord(e0, s->stream));
-#define KP_LAUNCH(NT_) hipLaunchKernelGGL((kp::kp_step_kernel<NT_, false>), dim3(s->n), dim3(NT_), lds, s->stream, A)
+#define KP_LAUNCH(NT_) do { if (nsub > 0) hipLaunchKernelGGL((kp::kp_step_kernel<NT_, false>), dim3(s->n), dim3(NT_), lds, s->stream, A); \
+                            else hipLaunchKernelGGL((kp::kp_forward_kernel<NT_, false>), dim3(s->n), dim3(NT_), lds, s->stream, A); } while (0)
     switch (s->model->threads) {
         case 64:
-            if (obj) hipLaunchKernelGGL((kp::kp_step_kernel<64, true>), dim3(s->n), dim3(64), lds, s->stream, A);
+            if (obj && nsub > 0) hipLaunchKernelGGL((kp::kp_step_kernel<64, true>), dim3(s->n), dim3(64), lds, s->stream, A);
+            else if (obj) hipLaunchKernelGGL((kp::kp_forward_kernel<64, true>), dim3(s->n), dim3(64), lds, s->stream, A);
             else KP_LAUNCH(64);
             break;
         case 128: KP_LAUNCH(128); break;

@@ -1425,8 +1425,11 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
 }
 
 // ---------------------------------------------------------------- the kernel
-template <int NT, bool OBJ>
-__global__ __launch_bounds__(NT, (NT == 64 ? 2 : 1)) void kp_step_kernel(StepArgs A) {
+// FWD = true compiles the forward-only launch (sim.forward(): derived quantities at a new state, no substeps) as its own
+// small kernel, so that the control-step kernel's launches are the only ones under its name in a profile.
+template <int NT, bool OBJ, bool FWD>
+__device__ __forceinline__ void step_body(StepArgs A) {
+    if (FWD) A.n_substeps = 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     typename std::conditional<OBJ, EnvLdsObj, EnvLds>::type& s = *reinterpret_cast<typename std::conditional<OBJ, EnvLdsObj, EnvLds>::type*>(smem_raw);
     const int env = blockIdx.x, tid = threadIdx.x;
@@ -1568,5 +1571,10 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 2 : 1)) void kp_step_kernel(StepArg
     KP_SYNC();
     if (tid == 0 && A.diag && A.n_substeps > 0) { int* dg = A.diag + 4 * (size_t)env; dg[0] = s.ncon; dg[1] = niter_total; dg[2] = s.flag; dg[3] = maxcon | (nfact_total << 8); }
 }
+
+template <int NT, bool OBJ>
+__global__ __launch_bounds__(NT, (NT == 64 ? 2 : 1)) void kp_step_kernel(StepArgs A) { step_body<NT, OBJ, false>(A); }
+template <int NT, bool OBJ>
+__global__ __launch_bounds__(NT, (NT == 64 ? 2 : 1)) void kp_forward_kernel(StepArgs A) { step_body<NT, OBJ, true>(A); }
 
 }  // namespace kp
