@@ -78,44 +78,60 @@ __global__ void k_step_kin(int n, const float* __restrict__ qpos, const float* _
     for (int j = 0; j < D_NU; j++) o[7 + j] = a[5 + j];
 }
 
-// ---------------------------------------------------------------- target FK: one thread per env (24-body chain in registers/scratch)
+// ---------------------------------------------------------------- target FK: one wavefront per row, lane = body, level-synchronous chain in LDS
+// (256-thread blocks = 4 rows).  Row loads and stores are coalesced; the 9-level parent chain goes through LDS.
 struct TargetBufs { float *qpos, *wbpos, *wbquat, *bquat, *com; };
-__global__ void k_target_fk(int n, const float* __restrict__ tq, const uint8_t* __restrict__ mask, TargetBufs B,
-                            const float* __restrict__ body_pos, const float* __restrict__ body_ipos, const int8_t* __restrict__ parent) {
-    int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
-    if (mask && !mask[e]) return;
-    const float* q = tq + (size_t)e * D_NQ;
-    float* oq = B.qpos + (size_t)e * D_NQ;
-    float wq[D_NB][4], wp[D_NB][3];
-    Q4 rq = Q4{q[3], q[4], q[5], q[6]};
-    float rn = sqrtf(rq.w * rq.w + rq.x * rq.x + rq.y * rq.y + rq.z * rq.z);
-    rq = Q4{rq.w / rn, rq.x / rn, rq.y / rn, rq.z / rn};  // fix_quat: root_rotations /= norm (no zero guard in the reference)
-    if (B.qpos) {
-        for (int i = 0; i < D_NQ; i++) oq[i] = q[i];
-        oq[3] = rq.w; oq[4] = rq.x; oq[5] = rq.y; oq[6] = rq.z;
+__global__ __launch_bounds__(256) void k_target_fk(int n, const float* __restrict__ tq, const uint8_t* __restrict__ mask, TargetBufs B,
+                                                    const float* __restrict__ body_pos, const float* __restrict__ body_ipos, const int8_t* __restrict__ parent,
+                                                    const uint8_t* __restrict__ depth) {
+    __shared__ float sq[4][80], swq[4][D_NB * 4], swp[4][D_NB * 3];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int e = blockIdx.x * 4 + w;
+    const bool live = e < n && !(mask && !mask[e]);
+    if (live) {
+        const float* q = tq + (size_t)e * D_NQ;
+        for (int i = lane; i < D_NQ; i += 64) sq[w][i] = q[i];
     }
-    for (int b = 0; b < D_NB; b++) {
-        Q4 wqb; V3 pos;
-        float dummy[4];
-        float* obq = B.bquat ? B.bquat + (size_t)e * 96 + 4 * b : dummy;
+    __syncthreads();
+    const int b = lane;
+    Q4 wqb = Q4{1.f, 0.f, 0.f, 0.f}, lq = wqb, bq = wqb;
+    V3 pos = v3(0.f, 0.f, 0.f);
+    int dep = 99, p = 0;
+    if (live && b < D_NB) {
+        dep = depth[b]; p = parent[b] < 0 ? 0 : parent[b];
+        const float* q = sq[w];
         if (b == 0) {
-            wqb = rq; pos = v3(q[0], q[1], q[2]);
-            obq[0] = rq.w; obq[1] = rq.x; obq[2] = rq.y; obq[3] = rq.z;
+            Q4 rq = Q4{q[3], q[4], q[5], q[6]};
+            const float rn = sqrtf(rq.w * rq.w + rq.x * rq.x + rq.y * rq.y + rq.z * rq.z);
+            rq = Q4{rq.w / rn, rq.x / rn, rq.y / rn, rq.z / rn};  // fix_quat: root_rotations /= norm (no zero guard in the reference)
+            wqb = rq; bq = rq; pos = v3(q[0], q[1], q[2]);
         } else {
-            int p = parent[b];
             const float* ang = q + 7 + 3 * (b - 1);
-            Q4 pq = Q4{wq[p][0], wq[p][1], wq[p][2], wq[p][3]};
-            pos = q_mul_vec(pq, ld3(body_pos + 3 * b)) + v3(wp[p][0], wp[p][1], wp[p][2]);
-            wqb = qmul(pq, q_euler_rzyx(ang[0], ang[1], ang[2]));
-            Q4 bq = q_euler_sxyz(ang[0], ang[1], ang[2]);
-            obq[0] = bq.w; obq[1] = bq.x; obq[2] = bq.y; obq[3] = bq.z;
+            lq = q_euler_rzyx(ang[0], ang[1], ang[2]);
+            bq = q_euler_sxyz(ang[0], ang[1], ang[2]);
         }
-        wq[b][0] = wqb.w; wq[b][1] = wqb.x; wq[b][2] = wqb.y; wq[b][3] = wqb.z;
-        wp[b][0] = pos.x; wp[b][1] = pos.y; wp[b][2] = pos.z;
+    }
+    for (int lev = 0; lev < D_NLEV; lev++) {
+        if (dep == lev) {
+            if (b > 0) {
+                const Q4 pq = Q4{swq[w][4 * p], swq[w][4 * p + 1], swq[w][4 * p + 2], swq[w][4 * p + 3]};
+                pos = q_mul_vec(pq, ld3(body_pos + 3 * b)) + ld3(swp[w] + 3 * p);
+                wqb = qmul(pq, lq);
+            }
+            swq[w][4 * b] = wqb.w; swq[w][4 * b + 1] = wqb.x; swq[w][4 * b + 2] = wqb.y; swq[w][4 * b + 3] = wqb.z;
+            st3(swp[w] + 3 * b, pos);
+        }
+        __syncthreads();
+    }
+    if (live && b < D_NB) {
+        if (B.bquat) { float* o = B.bquat + (size_t)e * 96 + 4 * b; o[0] = bq.w; o[1] = bq.x; o[2] = bq.y; o[3] = bq.z; }
         if (B.wbpos) st3(B.wbpos + (size_t)e * 72 + 3 * b, pos);
-        if (B.wbquat) { float* owq = B.wbquat + (size_t)e * 96 + 4 * b; owq[0] = wqb.w; owq[1] = wqb.x; owq[2] = wqb.y; owq[3] = wqb.z; }
+        if (B.wbquat) { float* o = B.wbquat + (size_t)e * 96 + 4 * b; o[0] = wqb.w; o[1] = wqb.x; o[2] = wqb.y; o[3] = wqb.z; }
         if (B.com) st3(B.com + (size_t)e * 72 + 3 * b, q_mul_vec(wqb, ld3(body_ipos + 3 * b)) + pos);
+    }
+    if (live && B.qpos) {
+        float* oq = B.qpos + (size_t)e * D_NQ;
+        for (int i = lane; i < D_NQ; i += 64) oq[i] = (i >= 3 && i < 7) ? swq[w][i - 3] : sq[w][i];     // root quaternion normalised
     }
 }
 

@@ -323,7 +323,7 @@ int kp_sim_set_target(kp_sim* s, const float* tq, const uint8_t* mask) {
     if (!s || !tq) return fail("kp_sim_set_target: null argument");
     HIP_OK(hipSetDevice(s->device));
     kp::TargetBufs B{s->t_qpos, s->t_wbpos, s->t_wbquat, s->t_bquat, s->t_com};
-    hipLaunchKernelGGL(kp::k_target_fk, dim3((s->n + 63) / 64), dim3(64), 0, s->stream, s->n, tq, mask, B, s->T.body_pos, s->T.body_ipos, s->T.body_parent);
+    hipLaunchKernelGGL(kp::k_target_fk, dim3((s->n + 3) / 4), dim3(256), 0, s->stream, s->n, tq, mask, B, s->T.body_pos, s->T.body_ipos, s->T.body_parent, s->T.body_depth);
     HIP_OK(hipGetLastError());
     return 0;
 }
@@ -387,8 +387,8 @@ int kp_sim_fk(kp_sim* s, int n_rows, const float* qpos, float* qpos_out, float* 
     if (!s || !qpos || n_rows <= 0) return fail("kp_sim_fk: bad arguments");
     HIP_OK(hipSetDevice(s->device));
     kp::TargetBufs B{qpos_out, wbpos, wbquat, bquat, com};
-    hipLaunchKernelGGL(kp::k_target_fk, dim3((n_rows + 63) / 64), dim3(64), 0, s->stream, n_rows, qpos, (const uint8_t*)nullptr, B,
-                       s->T.body_pos, s->T.body_ipos, s->T.body_parent);
+    hipLaunchKernelGGL(kp::k_target_fk, dim3((n_rows + 3) / 4), dim3(256), 0, s->stream, n_rows, qpos, (const uint8_t*)nullptr, B,
+                       s->T.body_pos, s->T.body_ipos, s->T.body_parent, s->T.body_depth);
     HIP_OK(hipGetLastError());
     return 0;
 }
