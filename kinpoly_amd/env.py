@@ -87,7 +87,9 @@ class BatchedHumanoidAREnv:
 
     def load_context(self, ctx: dict, env_mask: torch.Tensor | None = None):
         """ctx tensors are [N, T, .] (action_one_hot [N, T, 4] or [N, 4]; init_qpos/init_qvel [N, .]).
-        With env_mask (bool [N]) only those envs' rows are replaced (T must match)."""
+        With env_mask (bool [N]) only those envs' rows are replaced (T must match).
+        Ragged episodes: pad every clip to the longest T (repeat the last frame) and pass ctx["len"] = frames per env [N];
+        an env's episode then ends at its own len - 1 (`ar_context['len']`, humanoid_ar_v1.py:312)."""
         T = ctx["qpos"].shape[1]
         new = {k: ctx[k].to(self.device, torch.float32) for k in CTX_KEYS}
         if new["action_one_hot"].dim() == 3:
@@ -114,7 +116,17 @@ class BatchedHumanoidAREnv:
                 gt = self.sim.fk(rows)
                 self.ctx["gt_bquat"][idx] = gt["bquat"].view(-1, T, 96)
                 self.ctx["gt_wbpos"][idx] = gt["wbpos"].view(-1, T, 72)
-        self.ctx_len = T - 1
+        lens = ctx.get("len")
+        if lens is None:
+            new_len = torch.full((self.n,), T - 1, dtype=torch.int32, device=self.device)
+        else:
+            new_len = torch.as_tensor(lens, device=self.device).to(torch.int32) - 1
+            if int(new_len.max()) > T - 1 or int(new_len.min()) < 1:
+                raise ValueError("ctx['len'] must lie in [2, T]")
+        if self.ctx_len is None or env_mask is None or self.ctx_len.shape[0] != self.n:
+            self.ctx_len = new_len
+        else:
+            self.ctx_len = torch.where(env_mask.to(self.device, torch.bool), new_len, self.ctx_len)
         c = self.ctx
         if "obj_pose" in c and bool((c["action_one_hot"].sum(1) > 0).any()):
             self.obj_qpos, self.obj7 = convert_obj_qpos(c["action_one_hot"], c["obj_pose"][:, 0])

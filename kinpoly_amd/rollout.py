@@ -64,7 +64,7 @@ class VectorSampler:
             action = action.contiguous()
             if self.record_qpos:
                 Q[:, t] = env.sim.get("qpos")
-                G[:, t] = env.ctx["qpos"][ar, (env.cur_t.long() + 1).clamp(max=env.ctx_len)]
+                G[:, t] = env.ctx["qpos"][ar, torch.minimum(env.cur_t.long() + 1, env.ctx_len.long())]
             _, _, done, info = env.step(action)
             A[:, t] = action
             R[:, t] = info["custom_reward"]

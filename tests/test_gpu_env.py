@@ -285,3 +285,32 @@ def test_batched_evaluation_and_coverage_files(tmp_path):
     full = joblib.load(str(tmp_path / "0750_features_test_coverage_full.pkl")); brief = joblib.load(str(tmp_path / "0750_features_test_coverage.pkl"))
     assert set(full) == set(keys) and set(brief[keys[0]]) == {"percent", "values", "fail_safe"}
     assert cov == sum(1 for r in res_fs.values() if not r["fail_safe"])
+
+
+def test_ragged_episode_lengths():
+    """Clips of different length in one batch: padded to the longest, ctx['len'] gives each env its own end
+    (`end = cur_t + start_ind >= ar_context['len']`, humanoid_ar_v1.py:312) and `percent`."""
+    from kinpoly_amd.env import BatchedHumanoidAREnv, standing_context
+    n, T = 4, 10
+    env = BatchedHumanoidAREnv(n, 0, mode="test", seed=0)
+    ctx = standing_context(n, T, STD["qpos"], STD["qvel"], env.sim)
+    lens = [10, 6, 4, 10]
+    ctx["len"] = torch.tensor(lens)
+    env.load_context(ctx)
+    env.reward_cfg.body_diff_thresh = 1e9                      # no early termination: only the clip ends count
+    env.reset()
+    a = torch.zeros((n, 80), device=env.device)
+    q0 = env.sim.get("qpos")
+    for i in range(n):
+        cur = q0[i].double().cpu().numpy(); cur[3:7] = O.de_heading(cur[3:7]); a[i, :74] = torch.tensor(cur[2:], dtype=torch.float32)
+    ended_at = [None] * n
+    for t in range(1, T):
+        _, _, done, info = env.step(a)
+        for i in range(n):
+            if bool(info["end"][i]) and ended_at[i] is None:
+                ended_at[i] = t
+                assert abs(float(info["percent"][i]) - 1.0) < 1e-6
+        assert not bool(info["fail"].any())
+    assert ended_at == [L - 1 for L in lens]
+    with pytest.raises(ValueError):
+        bad = dict(ctx); bad["len"] = torch.tensor([11, 6, 4, 10]); env.load_context(bad)
