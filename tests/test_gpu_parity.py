@@ -78,6 +78,20 @@ def test_abi_loads_and_errors(kp):
         m.set_option("no_such_option", 1)
     with pytest.raises(kp.KinPolyNativeError):
         kp.KpModel("/nonexistent.kpm")
+    # error behaviour of the C ABI: negative return + kp_last_error text, never an exception / crash across the boundary
+    import ctypes as C
+    sim = kp.KpSim(m, 4)
+    assert L.kp_sim_set_state(sim.h, None, None, None) == -1 and b"null" in L.kp_last_error()
+    assert L.kp_sim_get(sim.h, 999, C.c_void_p(sim.get("qpos").data_ptr())) == -1 and b"unknown field" in L.kp_last_error()
+    assert L.kp_sim_step_ctrl(None, None, 15, None) != 0
+    assert not L.kp_sim_create(m.h, 0, 0, None) and b"bad arguments" in L.kp_last_error()
+    assert L.kp_model_set_option(m.h, b"threads_per_env", C.c_double(96.0)) == -1
+    m2 = kp.KpModel(kp.STEP_KPM, threads_per_env=128)
+    s2 = kp.KpSim(m2, 2)
+    blk = np.zeros((2, 35), np.float32); blk[:, 28:35] = [0, 0, 0.37, 1, 0, 0, 0]
+    s2.set_objects(dev(blk))
+    with pytest.raises(kp.KinPolyNativeError):                      # the object kernel is one wavefront per env
+        s2.set_state(dev(np.tile(STD["qpos"], (2, 1))), dev(np.zeros((2, 75))))
 
 
 @pytest.mark.parametrize("threads", [64, 128, 256])
