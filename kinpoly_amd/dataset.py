@@ -1,0 +1,214 @@
+"""The data formats either side of the rollout path: the per-take feature file the reference trains from
+(`<data_dir>/features/<data_file>.p`, a joblib dict  take -> {qpos, qvel, head_pose, head_vels, obj_pose,
+obj_head_relative_poses, action_one_hot, wbpos, wbquat, bquat, of_files, ...}, written by
+kin_poly/data_process/process_smpl.py:140-235) and the sampler that serves clips from it
+(kin_poly/data_loaders/statear_smpl_dataset.py), here batched: N episodes per call instead of one.
+
+    build_take_features   process_smpl.post_process_expert on top of the batched get_expert (one FK launch per take)
+    StateARDataset        preprocess_data (derived `target` trajectory), sample_seq x N -> [N, fr_num, .] tensors,
+                          adaptive take sampling (freq_dict / ewma), get_seq_by_ind / iter_seq, padded ragged batches
+    synthetic_takes       SURVEY.md section 8(d) config 4 stand-in for the absent MoCap set, in the same schema
+"""
+from __future__ import annotations
+
+import math
+import os
+
+import numpy as np
+import torch
+
+from .context import heading_q, quat_inv, quat_mul, quat_rotate_t
+
+ACTIONS = ("sit", "push", "avoid", "step")             # cfg.all_actions order = action_one_hot columns
+TRAIN_KEYS = ("wbpos", "wbquat", "bquat")
+
+
+# ------------------------------------------------------------------ feature construction (torch, any device, any float dtype)
+def _fd_vel(cur7, nxt7, dt):
+    """get_head_vel / get_root_vel body (process_smpl.py:30-55, statear_smpl_dataset.py:186-214): linear velocity in the
+    heading frame, angular velocity (axis * angle / dt, angle wrapped once) in the root frame; [T-1, 6]."""
+    v = quat_rotate_t(heading_q(cur7[:, 3:7]), (nxt7[:, :3] - cur7[:, :3]) / dt)
+    qrel = quat_mul(nxt7[:, 3:7], quat_inv(cur7[:, 3:7]))
+    w = qrel[:, 0]
+    small = (1 - w.abs()) < 1e-8
+    s = torch.sqrt((1 - w * w).clamp_min(1e-30))
+    angle = torch.where(small, torch.zeros_like(w), 2 * torch.acos(w.clamp(-1.0, 1.0)))
+    axis = torch.where(small[:, None], torch.tensor([1.0, 0.0, 0.0], device=w.device, dtype=w.dtype).expand_as(qrel[:, 1:]), qrel[:, 1:] / s[:, None])
+    angle = torch.where(angle > math.pi, angle - 2 * math.pi, angle)
+    rv = quat_rotate_t(cur7[:, 3:7], axis * angle[:, None] / dt)
+    return torch.cat([v, rv], 1)
+
+
+def get_head_vel(pose7, dt=1.0 / 30.0):
+    v = _fd_vel(pose7[:-1], pose7[1:], dt)
+    return torch.cat([v, v[-1:]], 0)
+
+
+def get_obj_relative_pose(obj_poses, ref_poses, num_objs=1):
+    """process_smpl.py:110-135: object position in the reference's heading frame + heading^-1 (x) object quaternion."""
+    qh = heading_q(ref_poses[:, 3:7])
+    out = []
+    for o in range(num_objs):
+        out.append(quat_rotate_t(qh, obj_poses[:, 7 * o:7 * o + 3] - ref_poses[:, :3]))
+        out.append(quat_mul(quat_inv(qh), obj_poses[:, 7 * o + 3:7 * o + 7]))
+    return torch.cat(out, 1)
+
+
+def get_traj_de_heading(qpos):
+    """statear_smpl_dataset.py:153-181 with cfg.has_z: qpos[2:] with the root quaternion de-headed."""
+    t = qpos[:, 2:].clone()
+    t[:, 1:5] = quat_mul(quat_inv(heading_q(qpos[:, 3:7])), qpos[:, 3:7])
+    return t
+
+
+def build_take_features(sim, qpos, obj_pose=None, action: str | None = None, body_mass=None, dt=1.0 / 30.0) -> dict:
+    """One take of the feature file from its qpos clip [T, 76] (+ object poses [T, 7k]): get_expert features, then
+    post_process_expert (process_smpl.py:137-152, 217-226).  Returns numpy float64 arrays like the reference's file."""
+    from .uhc_env import get_expert_batch
+    q = torch.as_tensor(np.asarray(qpos), dtype=torch.float32)
+    T = q.shape[0]
+    mass = body_mass if body_mass is not None else torch.ones(24)
+    ex = get_expert_batch(sim, q[None], torch.as_tensor(mass, dtype=torch.float32, device=sim.device), dt)
+    out = {k: ex[k][0].double().cpu().numpy() for k in ("qpos", "qvel", "wbpos", "wbquat", "bquat", "head_pose", "body_com", "com", "ee_pos", "ee_wpos", "bangvel", "rq_rmh")}
+    out["qpos"] = np.asarray(qpos, np.float64)
+    if obj_pose is None:
+        obj = np.tile(np.array([0.0, 0, 0, 1, 0, 0, 0]), (T, 1)); one_hot = np.zeros((T, 4))
+    else:
+        obj = np.asarray(obj_pose, np.float64); one_hot = np.zeros((T, 4)); one_hot[:, ACTIONS.index(action)] = 1.0
+    nobj = obj.shape[1] // 7
+    hp, ob = torch.as_tensor(out["head_pose"]), torch.as_tensor(obj)
+    out.update(obj_pose=obj, action_one_hot=one_hot, action=action or "none", head_vels=get_head_vel(hp, dt).numpy(),
+               obj_head_relative_poses=get_obj_relative_pose(ob, hp, nobj).numpy(),
+               obj_root_relative_poses=get_obj_relative_pose(ob, torch.as_tensor(out["qpos"][:, :7]), nobj).numpy(),
+               of_files=[f"{i:05d}.npy" for i in range(T)], len=T)
+    return out
+
+
+def write_features(path, takes: dict):
+    import joblib
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    joblib.dump(takes, path)
+
+
+# ------------------------------------------------------------------ the dataset
+class StateARDataset:
+    KEYS = ("qvel", "target", "qpos", "head_vels", "head_pose", "action_one_hot", "obj_head_relative_poses", "obj_pose")
+
+    def __init__(self, features, takes=None, data_mode="train", fr_num=100, wild=False, dt=1.0 / 30.0, seed=0, device="cpu"):
+        if isinstance(features, (str, os.PathLike)):
+            import joblib
+            features = joblib.load(features)
+        self.rng = np.random.RandomState(seed)
+        self.data_mode, self.fr_num, self.dt, self.wild, self.device = data_mode, int(fr_num), dt, wild, torch.device(device)
+        self.takes, self.data = [], {k: [] for k in self.KEYS + (TRAIN_KEYS if data_mode == "train" and not wild else ())}
+        for take in (takes if takes is not None else sorted(features)):
+            e = features[take]
+            q = torch.as_tensor(np.asarray(e["qpos"]), dtype=torch.float64)
+            if data_mode == "train" and q.shape[0] < self.fr_num and not wild:
+                continue                                        # :100-102
+            assert len(e["of_files"]) == q.shape[0]
+            target = torch.cat([get_traj_de_heading(q), torch.cat([_fd_vel(q[:-1, :7], q[1:, :7], dt)] + [_fd_vel(q[-2:-1, :7], q[-1:, :7], dt)], 0)], 1)
+            row = dict(qvel=e["qvel"], target=target, qpos=q, head_vels=e["head_vels"], head_pose=e["head_pose"], action_one_hot=e["action_one_hot"],
+                       obj_head_relative_poses=np.asarray(e["obj_head_relative_poses"])[:, :7], obj_pose=e["obj_pose"])
+            for k in self.data:
+                v = row[k] if k in row else e[k]
+                v = torch.as_tensor(np.asarray(v) if not torch.is_tensor(v) else v, dtype=torch.float32)
+                if k == "obj_pose" and v.shape[1] < 14:       # one width for every take (push carries two objects): zero-padded, the env
+                    v = torch.cat([v, torch.zeros((v.shape[0], 14 - v.shape[1]))], 1)      # reads only the action's slice (convert_obj_qpos)
+                self.data[k].append(v)
+            self.takes.append(take)
+        self.freq_indices = np.array([i for i, q in enumerate(self.data["qpos"]) for _ in range(int(np.ceil(q.shape[0] / self.fr_num)))])
+        self.all_indices = list(range(len(self.takes)))
+        self.traj_dim = self.data["target"][0].shape[1] if self.takes else 0
+        self.counter = 0
+
+    def get_len(self):
+        return len(self.takes)
+
+    def get_seq_len(self, ind):
+        return self.data["qpos"][ind].shape[0]
+
+    def get_seq_key(self, ind):
+        return self.takes[ind]
+
+    def _slice(self, ind, start, end):
+        return {k: v[ind][start:end] for k, v in self.data.items()}
+
+    def take_probs(self, freq_dict, sampling_temp=0.5):
+        """:281-286: exp(-ewma(success history) / T), normalised; takes without history get ewma 0."""
+        def ewma(x, alpha=0.05):
+            avg = x[0]
+            for v in x[1:]:
+                avg = alpha * v + (1 - alpha) * avg
+            return avg
+        p = np.exp(-np.array([ewma((np.array(freq_dict[k])[:, 0] == 1).astype(float)) if len(freq_dict[k]) > 0 else 0.0 for k in freq_dict]) / sampling_temp)
+        return p / p.sum()
+
+    def sample_batch(self, n, freq_dict=None, use_freq=True, full_sample=False, sampling_temp=0.5, sampling_freq=0.9):
+        """n independent `sample_seq` draws (:264-327) -> dict of [n, fr_num, .] tensors (+ 'take_ind', 'fr_start')."""
+        inds, starts = np.zeros(n, np.int64), np.zeros(n, np.int64)
+        probs = None if freq_dict is None else self.take_probs(freq_dict, sampling_temp)
+        for i in range(n):
+            if use_freq and freq_dict is None:
+                inds[i] = self.rng.choice(self.freq_indices)
+            elif use_freq:
+                inds[i] = self.rng.choice(self.all_indices, p=probs) if self.rng.binomial(1, sampling_freq) else self.rng.choice(self.all_indices)
+                starts[i] = 0 if full_sample else self.rng.randint(0, max(self.get_seq_len(inds[i]) - self.fr_num, 1))
+            else:
+                inds[i] = self.rng.choice(self.all_indices)
+        return self.batch(inds, starts, None if full_sample else self.fr_num)
+
+    def batch(self, inds, starts=None, length=None):
+        """Rows (take, start) as one padded batch; `len` holds each row's valid frame count (ragged when length is None)."""
+        inds = np.asarray(inds); starts = np.zeros(len(inds), np.int64) if starts is None else np.asarray(starts)
+        lens = [min(length, self.get_seq_len(i) - s) if length else self.get_seq_len(i) - s for i, s in zip(inds, starts)]
+        T = max(lens)
+        out = {}
+        for k, v in self.data.items():
+            rows = []
+            for i, s, L in zip(inds, starts, lens):
+                r = v[i][s:s + L]
+                rows.append(r if L == T else torch.cat([r, r[-1:].expand(T - L, -1)], 0))       # pad with the last frame
+            out[k] = torch.stack(rows, 0).to(self.device)
+        out["len"] = torch.tensor(lens, dtype=torch.int32, device=self.device)
+        out["take_ind"], out["fr_start"] = torch.as_tensor(inds), torch.as_tensor(starts)
+        return out
+
+    def get_seq_by_ind(self, ind, full_sample=False):
+        return self.batch([ind], [0], None if full_sample else self.fr_num)
+
+    def iter_seq(self):
+        ind = self.counter % len(self.takes)
+        self.counter += 1
+        self.curr_key = self.takes[ind]
+        return self.batch([ind], [0], None)
+
+    def set_seq_counter(self, idx):
+        self.counter = idx
+
+
+# ------------------------------------------------------------------ synthetic stand-in for the absent MoCap set
+def synthetic_takes(sim, std_qpos, n_per_action=2, T_range=(110, 160), body_mass=None, seed=0):
+    """standing -> seeded smooth joint-space sinusoids (amplitude <= 0.3 rad, <= 1 Hz), four action
+    classes with their object(s) at constant poses in front of / behind the humanoid, yaw U(-pi, pi)."""
+    rng = np.random.default_rng(seed)
+    std_qpos = np.asarray(std_qpos, np.float64)
+    obj_local = {"sit": [[0.0, -0.6, 0.3805]], "push": [[0.0, 0.8, 0.921], [0.0, 0.8, 0.7905]], "avoid": [[0.0, 1.0, 0.69]], "step": [[0.0, 0.8, 0.3705]]}
+    takes = {}
+    for a in ACTIONS:
+        for j in range(n_per_action):
+            T = int(rng.integers(*T_range))
+            yaw = rng.uniform(-np.pi, np.pi)
+            qz = np.array([np.cos(yaw / 2), 0, 0, np.sin(yaw / 2)])
+            q = np.tile(std_qpos, (T, 1))
+            w, x, y, z = std_qpos[3:7]
+            q[:, 3:7] = [qz[0] * w - qz[3] * z, qz[0] * x - qz[3] * y, qz[0] * y + qz[3] * x, qz[0] * z + qz[3] * w]     # qz (x) q_root
+            amp, fr, ph = rng.uniform(0, 0.3, 69), rng.uniform(0.1, 1.0, 69), rng.uniform(0, 2 * np.pi, 69)
+            tt = np.arange(T)[:, None] / 30.0
+            q[:, 7:] += amp * (np.sin(2 * np.pi * fr * tt + ph) - np.sin(ph)) * np.minimum(tt / 0.5, 1.0)
+            c, s_ = np.cos(yaw), np.sin(yaw)
+            obj = []
+            for lx, ly, lz in obj_local[a]:
+                obj += [std_qpos[0] + c * lx - s_ * ly, std_qpos[1] + s_ * lx + c * ly, lz, *qz]
+            takes[f"{a}-synthetic-{j:02d}"] = build_take_features(sim, q, np.tile(np.array(obj), (T, 1)), a, body_mass)
+    return takes

@@ -5,7 +5,8 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 scripts/train_ar_policy.py
 
 The reference's MoCap dataset and trained UHC weights are not part of its repository (downlaod_data.sh), so this
-driver runs the synthetic standing-clip configuration of SURVEY.md section 8(d) (config 3) with seeded random-init networks.
+driver builds synthetic takes in the reference's feature-file schema (all four action classes with their objects, SURVEY.md
+section 8(d) config 4) unless --data points at a real feature file, and trains seeded random-init networks on them.
 """
 import argparse
 import json
@@ -29,6 +30,7 @@ def main():
     ap.add_argument("--num_optim_epoch", type=int, default=10)
     ap.add_argument("--num_step_update", type=int, default=20)
     ap.add_argument("--save", type=str, default="")
+    ap.add_argument("--data", type=str, default="", help="feature file in the reference's schema (<data_dir>/features/<data_file>.p)")
     args = ap.parse_args()
     world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
@@ -36,20 +38,24 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     from kinpoly_amd.agent import AgentAR
-    from kinpoly_amd.env import standing_context
     std = np.load(os.path.join(ROOT, "tests", "golden", "standing_neutral.npz"))
-    holder = {}
+    from kinpoly_amd import dataset as D
+    from kinpoly_amd import sim as kpsim
+    from kinpoly_amd.model_compiler import read_kpm
+    # the agent's kinematic twin sim doubles as the FK engine of the feature construction
+    fk_sim = kpsim.KpSim(kpsim.KpModel(kpsim.STEP_KPM), args.num_envs, local)
+    if args.data:
+        ds = D.StateARDataset(args.data, fr_num=args.clip_len, seed=4 + rank, device=fk_sim.device)
+    else:       # the reference's MoCap features are not in its repository: same schema, synthetic takes
+        takes = D.synthetic_takes(fk_sim, std["qpos"], n_per_action=4, T_range=(args.clip_len + 10, args.clip_len + 60),
+                                  body_mass=read_kpm(kpsim.STEP_KPM)["body_mass"], seed=4 + rank)
+        ds = D.StateARDataset(takes, fr_num=args.clip_len, seed=4 + rank, device=fk_sim.device)
+    if rank == 0:
+        print(f"dataset: {ds.get_len()} takes, {len(ds.freq_indices)} windows of {args.clip_len} frames", flush=True)
 
     def context_fn(n):
-        g = torch.Generator().manual_seed(4 + rank + 1000 * holder.get("calls", 0)); holder["calls"] = holder.get("calls", 0) + 1
-        headings = (torch.rand(n, generator=g) * 2 - 1) * np.pi
-        ctx = standing_context(n, args.clip_len, std["qpos"], std["qvel"], holder["agent_sim"], headings)
-        ctx["obj_pose"] = torch.tensor([0.0, 0, 0, 1, 0, 0, 0], device=ctx["qpos"].device).repeat(n, args.clip_len, 1)
-        return ctx
+        return ds.sample_batch(n)          # n x sample_seq (statear_smpl_dataset.py:264-327)
 
-    # the context builder needs a sim for FK before the agent exists: use a throw-away one
-    from kinpoly_amd import sim as kpsim
-    holder["agent_sim"] = kpsim.KpSim(kpsim.KpModel(), args.num_envs, local)
     agent = AgentAR(args.num_envs, context_fn, device=local, horizon=args.horizon, num_optim_epoch=args.num_optim_epoch,
                     num_step_update=args.num_step_update)
     for it in range(args.iters):

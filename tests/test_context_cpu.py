@@ -138,3 +138,38 @@ def test_running_state_online_equals_sequential_pushes(golden):
     np.testing.assert_allclose(torch.sqrt(rs._m2 / (rs.count - 1)).numpy(), g["zf_std"], rtol=1e-10)
     y = rs(torch.tensor(g["zf_x"], dtype=torch.float32)[None], update=False)[0]
     np.testing.assert_allclose(y.numpy(), g["zf_y"], rtol=1e-4, atol=1e-5)
+
+
+def test_dataset_features_and_sampling(golden):
+    """kinpoly_amd.dataset: feature construction vs the reference fixture (fp64 torch on the CPU), then the sampler's
+    contract: fixed-length windows inside their take, adaptive take probabilities, ragged full-sequence batches."""
+    from kinpoly_amd import dataset as D
+    g = golden("dataset_features")
+    t = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)  # noqa: E731
+    np.testing.assert_allclose(D.get_head_vel(t(g["head_pose"])).numpy(), g["head_vels"], rtol=1e-8, atol=1e-8)
+    np.testing.assert_allclose(D.get_obj_relative_pose(t(g["obj_pose"]), t(g["head_pose"]), 2).numpy(), g["obj_head_relative_poses"], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(D.get_traj_de_heading(t(g["clip"])).numpy(), g["traj_pos"], rtol=1e-9, atol=1e-10)
+    rng = np.random.default_rng(0)
+    feats = {}
+    for i, T in enumerate((14, 30, 9, 22)):
+        clip = np.tile(g["clip"][:1], (T, 1)); clip[:, :3] += 0.01 * np.arange(T)[:, None]
+        feats[f"sit-{i}"] = dict(qpos=clip, qvel=rng.normal(size=(T, 75)), head_pose=np.tile(g["head_pose"][:1], (T, 1)), head_vels=rng.normal(size=(T, 6)),
+                                 action_one_hot=np.tile([1.0, 0, 0, 0], (T, 1)), obj_head_relative_poses=rng.normal(size=(T, 14)), obj_pose=rng.normal(size=(T, 14)),
+                                 wbpos=rng.normal(size=(T, 72)), wbquat=rng.normal(size=(T, 96)), bquat=rng.normal(size=(T, 96)), of_files=["x"] * T)
+    ds = D.StateARDataset(feats, fr_num=10, seed=3)
+    assert ds.takes == ["sit-0", "sit-1", "sit-3"] and ds.get_len() == 3        # the 9-frame take is shorter than fr_num: dropped in train mode
+    assert sorted(set(ds.freq_indices.tolist())) == [0, 1, 2] and len(ds.freq_indices) == 2 + 3 + 3
+    np.testing.assert_allclose(ds.data["target"][0][:, :74].numpy(), D.get_traj_de_heading(t(feats["sit-0"]["qpos"])).numpy(), atol=1e-6)
+    freq = {k: [[1, 0]] * 8 if k == "sit-1" else [[0, 5]] * 8 for k in ds.takes}
+    p = ds.take_probs(freq)
+    assert p[1] < p[0] and abs(p.sum() - 1) < 1e-12                                # often-succeeding takes are sampled less
+    b = ds.sample_batch(64, freq_dict=freq)
+    assert b["qpos"].shape == (64, 10, 76) and b["target"].shape == (64, 10, 80) and b["obj_head_relative_poses"].shape == (64, 10, 7)
+    for r in range(64):
+        i, s0 = int(b["take_ind"][r]), int(b["fr_start"][r])
+        assert 0 <= s0 <= ds.get_seq_len(i) - 10 and torch.equal(b["qpos"][r], ds.data["qpos"][i][s0:s0 + 10])
+    full = ds.batch([0, 1, 2])
+    assert full["qpos"].shape == (3, 30, 76) and full["len"].tolist() == [14, 30, 22]
+    assert torch.equal(full["qpos"][0, 13], full["qpos"][0, 29])                   # padded with the last frame
+    one = ds.iter_seq(); two = ds.iter_seq()
+    assert one["qpos"].shape[1] == 14 and two["qpos"].shape[1] == 30 and ds.curr_key == "sit-1"

@@ -314,3 +314,41 @@ def test_ragged_episode_lengths():
     assert ended_at == [L - 1 for L in lens]
     with pytest.raises(ValueError):
         bad = dict(ctx); bad["len"] = torch.tensor([11, 6, 4, 10]); env.load_context(bad)
+
+
+def test_dataset_to_rollout_pipeline_with_objects(tmp_path):
+    """The whole caller chain on the reference's feature-file schema: synthetic takes of all four action classes (with their
+    objects) -> joblib feature file -> StateARDataset.sample_batch -> batched init_context -> env with free objects -> steps."""
+    from kinpoly_amd import dataset as D
+    from kinpoly_amd import sim as kpsim
+    from kinpoly_amd.context import PolicyARContext, TrajARNet
+    from kinpoly_amd.env import BatchedHumanoidAREnv
+    n, fr = 16, 12
+    torch.manual_seed(1)
+    env = BatchedHumanoidAREnv(n, 0, mode="train", seed=1)
+    takes = D.synthetic_takes(env.sim, STD["qpos"], n_per_action=1, T_range=(20, 30), body_mass=KPM["body_mass"], seed=2)
+    assert sorted(t.split("-")[0] for t in takes) == ["avoid", "push", "sit", "step"]
+    path = str(tmp_path / "features" / "synthetic.p")
+    D.write_features(path, takes)
+    ds = D.StateARDataset(path, fr_num=fr, seed=5, device=env.device)
+    batch = ds.sample_batch(n)
+    assert batch["qpos"].shape == (n, fr, 76) and batch["obj_pose"].shape == (n, fr, 14) and set(batch["action_one_hot"].sum(2).unique().tolist()) == {1.0}
+    net = TrajARNet().to(env.device)
+    ctx = PolicyARContext(net, kpsim.KpSim(env.model, n, 0), smooth=True).init_context(batch)
+    ctx["init_qpos"] = batch["qpos"][:, 0].contiguous(); ctx["init_qvel"] = batch["qvel"][:, 0].contiguous()      # start on the clip (random-init net)
+    env.load_context(ctx)
+    obs = env.reset()
+    assert torch.isfinite(obs).all()
+    objq0 = env.sim.get("obj_qpos").clone()
+    a_idx = batch["action_one_hot"][:, 0].argmax(1).cpu().numpy()
+    for e in range(n):                                             # the action's object(s) sit at their clip pose, the others are parked
+        st = (0, 7, 21, 28)[a_idx[e]]
+        np.testing.assert_allclose(objq0[e, st:st + 7].cpu().numpy(), batch["obj_pose"][e, 0, :7].cpu().numpy(), atol=1e-5)
+    hx = net.init_hidden(n, env.device)
+    for _ in range(4):
+        action, hx = net.select_action(obs, hx, True, env.gen)
+        obs, _, done, info = env.step(action.contiguous())
+        assert torch.isfinite(obs).all() and torch.isfinite(info["custom_reward"]).all()
+    assert int(env.sim.diag()[:, 2].max()) == 0
+    moved = (env.sim.get("obj_qpos") - objq0).abs().max(1).values
+    assert float(moved.max()) < 0.05                               # objects resting on the floor / table stay put (mm-level settling)

@@ -30,7 +30,8 @@ class Pkg(MagicMock):
 for m in ['cv2', 'OpenGL', 'OpenGL.GL', 'gym', 'gym.envs', 'gym.envs.mujoco', 'gym.envs.mujoco.mujoco_env', 'gym.utils',
           'gym.spaces', 'glfw', 'torchvision', 'torchvision.models', 'torchvision.transforms', 'skimage', 'skimage.util',
           'skimage.util.shape', 'mujoco_py', 'mujoco_py.builder', 'mujoco_py.generated', 'mujoco_py.generated.const',
-          'mujoco_py.utils', 'mujoco_py.functions', 'wandb', 'lxml', 'lxml.etree', 'ipdb', 'torchgeometry', 'smplx', 'imageio']:
+          'mujoco_py.utils', 'mujoco_py.functions', 'wandb', 'lxml', 'lxml.etree', 'ipdb', 'torchgeometry', 'smplx', 'imageio',
+          'kin_poly.envs.humanoid_v2', 'kin_poly.data_loaders.statereg_dataset', 'kin_poly.utils.torch_humanoid']:   # modules the reference imports but does not ship
     sys.modules[m] = Pkg()
 sys.path.insert(0, REF)
 sys.path.insert(0, REPO)
@@ -482,6 +483,45 @@ def gen_uhc_expert_reward():
     np.savez(os.path.join(OUT, "uhc_expert_reward.npz"), **out)
 
 
+def gen_dataset_features(hum):
+    """Data formats either side of the path: per-take feature construction (kin_poly/data_process/process_smpl.py:30-135:
+    get_head_vel, get_obj_relative_pose) and the dataset's derived trajectory (statear_smpl_dataset.py:153-214:
+    get_traj_de_heading with has_z, get_root_vel), plus the adaptive take-sampling probabilities (:281-290, ewma)."""
+    import kin_poly.data_process.process_smpl as ps
+    import kin_poly.data_loaders.statear_smpl_dataset as dsm
+    from kin_poly.utils.math_utils import ewma
+    rng = np.random.default_rng(51)
+    T = 14
+    base = rand_qpos(rng, 0.2)
+    clip = np.tile(base, (T, 1))
+    for t in range(T):
+        clip[t, :3] = base[:3] + 0.03 * t * np.array([1.0, -0.4, 0.05])
+        ang = 0.25 * t
+        clip[t, 3:7] = quaternion_multiply(np.array([np.cos(ang / 2), 0, 0, np.sin(ang / 2)]), base[3:7])      # turning about z: heading changes
+        clip[t, 7:] = base[7:] + 0.1 * np.sin(0.4 * t + np.arange(69))
+    head_pose = np.stack([np.concatenate([r["wbpos"].reshape(24, 3)[13], r["wbquat"].reshape(24, 4)[13]]) for r in (hum.qpos_fk(q.copy()) for q in clip)])
+    obj_pose = np.tile(np.concatenate([[0.6, 0.2, 0.4], rand_quat(rng), [1.0, -0.3, 0.7], rand_quat(rng)]), (T, 1))
+    obj_pose[:, 0] += 0.01 * np.arange(T)
+    out = {"clip": clip, "head_pose": head_pose, "obj_pose": obj_pose,
+           "head_vels": ps.get_head_vel(head_pose), "obj_head_relative_poses": ps.get_obj_relative_pose(obj_pose, head_pose, num_objs=2),
+           "obj_root_relative_poses": ps.get_obj_relative_pose(obj_pose, clip[:, :7], num_objs=2)}
+    ds = dsm.StateARDataset.__new__(dsm.StateARDataset)
+    ds.cfg = types.SimpleNamespace(has_z=True); ds.dt = 1 / 30; ds.base_rot = [0.7071, 0.7071, 0.0, 0.0]
+    out["traj_pos"] = ds.get_traj_de_heading(clip.copy()); out["traj_root_vel"] = ds.get_root_vel(clip.copy())
+    # adaptive sampling probabilities over takes
+    freq = {f"take{i}": [[int(rng.uniform() < 0.6), int(rng.integers(0, 50))] for _ in range(int(rng.integers(0, 12)))] for i in range(9)}
+    temp = 0.5
+    probs = np.exp(-np.array([ewma(np.array(freq[k])[:, 0] == 1) if len(freq[k]) > 0 else 0 for k in freq.keys()]) / temp)
+    out["freq_success"] = np.array([np.array([r[0] for r in freq[k]] + [-1] * (12 - len(freq[k]))) for k in freq])   # -1 padded
+    out["freq_probs"] = probs / probs.sum(); out["sampling_temp"] = temp
+    np.savez(os.path.join(OUT, "dataset_features.npz"), **out)
+
+
+if __name__ == "__main__" and os.environ.get("KP_GOLDEN_ONLY") == "data":
+    gen_dataset_features(make_humanoid())
+    print("dataset_features.npz ok")
+
+
 if __name__ == "__main__" and os.environ.get("KP_GOLDEN_ONLY") == "uhc":
     gen_uhc_expert_reward()
     print("uhc_expert_reward.npz ok")
@@ -511,6 +551,7 @@ if __name__ == "__main__" and os.environ.get("KP_GOLDEN_ONLY") is None:
     gen_loss_and_checkpoint(hum)
     gen_ppo_loss()
     gen_uhc_expert_reward()
+    gen_dataset_features(hum)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
