@@ -162,6 +162,16 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        # what actually bounds the kernel: VALU issue.  Instruction count per launch from the committed PMC pass, live launch time
+        valu = None
+        pv = os.path.join(ROOT, "profiles", "r01_v4", "pmc_SQ_INSTS_VALU+SQ_ACTIVE_INST_VALU+SQ_IFETCH.json")
+        if os.path.exists(pmc) and os.path.exists(pv):
+            d = json.load(open(pv))
+            k = [x for x in d if "kp_step_kernel" in x]
+            if k:
+                insts = d[k[0]]["SQ_INSTS_VALU"]["median"]           # wave-level VALU instructions per launch (4096 envs, tools/pmc_step.py)
+                valu = {"valu_insts_per_launch": insts, "cycles_per_wave64_op": 4, "simds": 1024, "shader_clock_ghz": 2.38,
+                        "valu_busy_frac": insts * 4 / (1024 * kern_s * 2.38e9), "source": "instruction count: profiles/r01_v4 PMC pass on the standing-contact workload (tools/pmc_step.py); clock: profiles/r01_v4/clock_probe.log"}
         out = {
             "metric": "env-steps/sec (whole node) at 4096 envs/GPU, 69-DoF SMPL", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -173,7 +183,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "kp_step_kernel", "launch_ms": kern_s * 1e3, "launches_timed": n_launch,
                          "algorithmic_bytes_per_launch": algo_bytes,
-                         "note": "latency/VALU-bound tree recursion with state resident in LDS: compulsory HBM traffic is tiny by construction (DESIGN.md)"},
+                         "note": "latency/VALU-bound tree recursion with state resident in LDS: compulsory HBM traffic is tiny by construction (DESIGN.md)",
+                         "valu": valu},
             "kernel_share_of_step": kern_s / (elapsed / args.steps),
             "contacts_mean": float(diag[:, 0].mean()), "newton_iters_per_substep": float(diag[:, 1].mean() / 15.0), "hessian_factorisations_per_substep": float((diag[:, 3] >> 8).mean() / 15.0), "bad_envs": int((diag[:, 2] != 0).sum()),
         }
