@@ -65,7 +65,7 @@ struct __attribute__((aligned(16))) EnvLds {
     float jar3[D_MAXCON * 3], jv3[D_MAXCON * 3];   // contact-frame (normal, t1, t2) residuals J qacc - aref and J search
     float lim_sgn[72], lim_aref[72], lim_D[72], lim_jar[72], lim_jv[72];
     float red[8];
-    unsigned char bpar[D_NB], bsub[D_NB], dbody[76];
+    unsigned char bpar[D_NB], bsub[D_NB], bdep[D_NB], dbody[76];
     unsigned char con_act[D_MAXCON];      // active pyramid rows (4 bits) of every contact at the last factorisation
     int ncon, nlim, flag;
 };

@@ -370,7 +370,9 @@ __device__ __forceinline__ void aba_forward(EnvLds& s, const Lane8& L, float* ou
 }
 
 template <int NT, bool OBJ>
-__device__ __forceinline__ void aba_solve(EnvLds& s, const Params& P, const Lane8& L, const float* rhs, float* out, bool contact_inertia, int tid) {
+// lev_clean: tree levels >= lev_clean carry no active contact row and no active joint limit, so their articulated inertias, U and
+// 1/D are the ones the smooth solve (same M, no extra armature) left in LDS this substep: only the bias-force half runs there.
+__device__ __forceinline__ void aba_solve(EnvLds& s, const Params& P, const Lane8& L, const float* rhs, float* out, bool contact_inertia, int tid, int lev_clean = D_NLEV) {
     const int r = L.r;
     const bool rowok = r < 6;
 #pragma nounroll
@@ -379,6 +381,27 @@ __device__ __forceinline__ void aba_solve(EnvLds& s, const Params& P, const Lane
         const int bq = (int)((L.sb >> sh) & 31ull), c0 = (int)((L.sc0 >> sh) & 31ull), c1 = (int)((L.sc1 >> sh) & 31ull), c2 = (int)((L.sc2 >> sh) & 31ull);
         const bool active = bq != 31;
         const int b = active ? bq : 0;
+        if (lev >= lev_clean) {                                    // lev_clean >= 1: the root level is never clean
+            const float rmask = rowok ? 1.f : 0.f;
+            const int rc = rowok ? r : 5, pr = 6 * 24;
+            float pA = (s.pAa[rowok ? 6 * c0 + r : pr] + s.pAa[rowok ? 6 * c1 + r : pr]) + s.pAa[rowok ? 6 * c2 + r : pr];
+            const int d0 = 6 + 3 * (b == 0 ? 0 : b - 1);
+            float uo[3];
+#pragma unroll
+            for (int j = 2; j >= 0; j--) {
+                const int d = d0 + j;
+                const float u = rhs[d] - sum8(rmask * s.cdof[6 * d + rc] * pA);
+                pA += rmask * s.U[6 * d + rc] * (u * s.Dinv[d]);
+                uo[j] = u;
+            }
+            if (active && r == 0) {
+#pragma unroll
+                for (int j = 0; j < 3; j++) s.uj[d0 + j] = uo[j];
+            }
+            if (active && rowok) s.pAa[6 * b + r] = pA;
+            KP_SYNC();
+            continue;
+        }
         // ---- one LDS round: body inertia row + children rows (the per-dof operands are fetched by aba_elim3 in the same round)
         float IAx[8];
         float pA;
@@ -820,6 +843,34 @@ __device__ __forceinline__ float active_set_changed(EnvLds& s, const Params& P, 
     return changed;
 }
 
+// first tree level below every active constraint: 1 + the deepest level holding a body with an active contact row or a dof with
+// an active joint limit (jar < 0); the root level always counts as dirty
+template <int NT>
+__device__ __forceinline__ int first_clean_level(EnvLds& s, const Params& P, int tid) {
+    float deep = 0.f;
+    for (int c = tid; c < s.ncon; c += NT) {
+        const int b = s.con_body[c];
+        if (b >= D_NB) continue;                                 // object-side contacts do not touch the humanoid tree
+        const float jn = s.jar3[3 * c], jt1 = s.jar3[3 * c + 1], jt2 = s.jar3[3 * c + 2];
+        bool act = false;
+#pragma unroll
+        for (int e = 0; e < 4; e++) act |= row_val(e, P.mu, jn, jt1, jt2) < 0.f;
+        if (act) deep = fmaxf(deep, (float)s.bdep[b]);
+    }
+    for (int j = tid; j < D_NU; j += NT) if (s.lim_jar[j] < 0.f && s.lim_D[j] != 0.f) deep = fmaxf(deep, (float)s.bdep[s.dbody[6 + j]]);
+    float m = -wave_min(-deep);
+    if (NT > 64) {
+        KP_SYNC();
+        if ((tid & 63) == 0) s.red[tid >> 6] = m;
+        KP_SYNC();
+        m = s.red[0];
+#pragma unroll
+        for (int w = 1; w < NT / 64; w++) m = fmaxf(m, s.red[w]);
+        KP_SYNC();
+    }
+    return (int)m + 1;
+}
+
 // constraint solve: Newton on the primal problem (mj_solNewton) with an exact line search.  Returns iterations.
 // On entry sv holds the spatial accelerations of qacc_s (left by the smooth aba_solve), jv3 holds aref.
 template <int NT, bool OBJ>
@@ -834,8 +885,8 @@ __device__ __forceinline__ int solve_constraints(EnvLds& s, const Params& P, con
     float cost = primal_cost<NT>(s, P, nullptr, nullptr, s.jar3, s.lim_jar, tid);
     // candidate B: warm start = s.qacc (qacc of the previous substep / control step), mj_fwdConstraint's rule
     {
-        float* wj3 = s.U;      // scratch: U / x are rewritten by the next aba_solve
-        float* wlim = s.x;
+        float* wj3 = s.jv3;    // in place over aref (each lane reads its aref, writes its residual; aref is not needed afterwards);
+        float* wlim = s.x;     // U must stay as the smooth solve left it (aba_solve's clean levels)
         spatial_accumulate<NT>(s, s.qacc, depth, tid);
         eval_rows<NT, OBJ>(s, s.qacc, wj3, wlim, true, tid);
         wrench_project<NT, OBJ>(s, P, s.qacc, s.Mv, true, false, tid);
@@ -851,7 +902,7 @@ __device__ __forceinline__ int solve_constraints(EnvLds& s, const Params& P, con
         }
         KP_SYNC();
     }
-    int it = 0;
+    int it = 0, lev_hist = 1;
     for (; it < P.max_iter; it++) {
         // gradient = mres - J^T f
         wrench_project<NT, OBJ>(s, P, nullptr, s.grad, false, true, tid);
@@ -871,7 +922,12 @@ __device__ __forceinline__ int solve_constraints(EnvLds& s, const Params& P, con
         if (P.scale * sqrtf(g2) < P.tol) break;
         // search = -H^-1 grad,  H = M + J^T D_active J : articulated-body pass with contact inertia; while the active set
         // stands the factorisation of the previous iteration is reused (mj_solNewton updates its Cholesky factor the same way)
-        if (it == 0 || changed > 0.f) { aba_solve<NT, OBJ>(s, P, L8, s.x, s.search, true, tid); nfact++; }
+        if (it == 0 || changed > 0.f) {
+            // levels an earlier factorisation of this substep rewrote no longer hold the smooth solve's factors: the clean range only shrinks
+            lev_hist = max(lev_hist, first_clean_level<NT>(s, P, tid));
+            aba_solve<NT, OBJ>(s, P, L8, s.x, s.search, true, tid, lev_hist);
+            nfact++;
+        }
         else aba_resolve(s, L8, s.x, nullptr, s.search);
         eval_rows<NT, OBJ>(s, s.search, s.jv3, s.lim_jv, false, tid);           // aref (in jv3) is folded into jar3 by now
         wrench_project<NT, OBJ>(s, P, s.search, s.Mv, true, false, tid);
@@ -1272,7 +1328,7 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
     float cost = primal_cost<NT>(s, P, nullptr, nullptr, s.jar3, s.lim_jar, tid);
     // candidate B: warm start
     {
-        float* wj3 = s.U;
+        float* wj3 = s.jv3;    // in place over aref; U stays as the smooth solve left it (aba_solve's clean levels)
         float* wlim = s.x;
         spatial_accumulate<NT>(s, s.qacc, depth, tid);
         if (tid < no6) s.sv[6 * D_NB + tid] = s.oa[tid];
@@ -1293,7 +1349,7 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
         }
         KP_SYNC();
     }
-    int it = 0;
+    int it = 0, lev_hist = 1;
     for (; it < P.max_iter; it++) {
         // gradient: humanoid dofs (mres - J^T f) and object wrenches
         wrench_project<NT, true>(s, P, nullptr, s.grad, false, true, tid);
@@ -1336,7 +1392,8 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
         // the Schur-complement columns when a hull touches an object, pass n: the back-substitution)
         if (refactor) {
             if (no6 > 0) obj_hessian(s, P, s.ogr, -1.0f, tid);
-            aba_solve<NT, true>(s, P, L8, s.x, s.search, true, tid);          // y0 = H_hh^-1 (-g_h); sv = its spatial accelerations
+            lev_hist = max(lev_hist, first_clean_level<NT>(s, P, tid));   // the clean range only shrinks within a substep
+            aba_solve<NT, true>(s, P, L8, s.x, s.search, true, tid, lev_hist);     // y0 = H_hh^-1 (-g_h); sv = its spatial accelerations
             if (couple) { obj_coupling_u(s, P, s.ot, tid); if (tid < no6) s.Sm[ST * tid + no6] += s.ot[tid]; KP_SYNC(); }     // rhs_o -= H_oh y0
         }
         if (!(refactor && no6 == 0)) {
@@ -1447,7 +1504,7 @@ __device__ __forceinline__ void step_body(StepArgs A) {
         s.qvel[i] = A.qvel_d[(size_t)env * D_NV + i]; s.act[i] = A.action ? A.action[(size_t)env * D_NV + i] : 0.f;
         s.arm[i] = T.dof_armature[i]; s.dbody[i] = T.dof_body[i]; s.extra[i] = 0.f; s.qacc[i] = A.warm[(size_t)env * D_NV + i];
     }
-    if (tid < D_NB) { s.bpar[tid] = (unsigned char)(T.body_parent[tid] < 0 ? 0 : T.body_parent[tid]); s.bsub[tid] = T.body_subtree[tid]; }
+    if (tid < D_NB) { s.bpar[tid] = (unsigned char)(T.body_parent[tid] < 0 ? 0 : T.body_parent[tid]); s.bsub[tid] = T.body_subtree[tid]; s.bdep[tid] = T.body_depth[tid]; }
     if (tid < 8) s.applied[tid] = 0.f;
     if (tid < 25) s.IAa[22 * tid + 21] = 0.f;
     if (tid < 22) s.IAa[22 * 24 + tid] = 0.f;
