@@ -122,8 +122,19 @@ __device__ __forceinline__ V3 frame_world(const Frame& f, V3 c) { return c.x * f
 //      sums and projection on the dofs (backward half of mj_rne) -> qfrc_bias.
 template <int NT>
 __device__ __forceinline__ void forward_kin_bias(EnvLds& s, const DevTables& T, const Params& P, int depth, V3 bpos, int tid) {
-    float* sc = s.U;
+    float* sc = s.U;              // scratch (free outside the ABA passes): [0, 138) half-angle sin/cos, [144, 384) per-body joint frames
+    float* jf = s.U + 144;        // per body: local rotation qz (x) qy (x) qx (4), second axis R(qz) e_y (3), third axis R(qz qy) e_x (3)
     for (int i = tid; i < D_NU; i += NT) { float sn, cs; sincosf(0.5f * s.qpos[7 + i], &sn, &cs); sc[2 * i] = sn; sc[2 * i + 1] = cs; }
+    KP_SYNC();
+    if (tid >= 1 && tid < D_NB) {         // body-parallel: everything of the three hinges that does not depend on the parent
+        const int j0 = 3 * (tid - 1);
+        const Q4 qz = Q4{sc[2 * j0 + 1], 0.f, 0.f, sc[2 * j0]}, qy = Q4{sc[2 * j0 + 3], 0.f, sc[2 * j0 + 2], 0.f}, qx = Q4{sc[2 * j0 + 5], sc[2 * j0 + 4], 0.f, 0.f};
+        const Q4 qzy = qmul(qz, qy);
+        const Q4 ql = qmul(qzy, qx);
+        const V3 a1 = qrot(qz, v3(0.f, 1.f, 0.f)), a2 = qrot(qzy, v3(1.f, 0.f, 0.f));
+        float* f = jf + 10 * tid;
+        f[0] = ql.w; f[1] = ql.x; f[2] = ql.y; f[3] = ql.z; st3(f + 4, a1); st3(f + 7, a2);
+    }
     KP_SYNC();
     for (int lev = 0; lev < D_NLEV; lev++) {
         if (depth == lev) {
@@ -155,23 +166,23 @@ __device__ __forceinline__ void forward_kin_bias(EnvLds& s, const DevTables& T, 
                 q = Q4{s.xquat[4 * p], s.xquat[4 * p + 1], s.xquat[4 * p + 2], s.xquat[4 * p + 3]};
                 const V3 ppos = ld3(s.xpos + 3 * p);
                 cv = lds6(s.sv + 6 * p); ca = lds6(s.sa + 6 * p);
-                const float qd0 = s.qvel[d0], qd1 = s.qvel[d0 + 1], qd2 = s.qvel[d0 + 2];
-                const float sn0 = sc[2 * (d0 - 6)], cs0 = sc[2 * (d0 - 6) + 1], sn1 = sc[2 * (d0 - 5)], cs1 = sc[2 * (d0 - 5) + 1];
-                const float sn2 = sc[2 * (d0 - 4)], cs2 = sc[2 * (d0 - 4) + 1];
-                pos = ppos + qrot(q, bpos);
+                const float qds[3] = {s.qvel[d0], s.qvel[d0 + 1], s.qvel[d0 + 2]};
+                const float* f = jf + 10 * b;
+                const Q4 ql = Q4{f[0], f[1], f[2], f[3]};
+                const V3 a1 = ld3(f + 4), a2 = ld3(f + 7);
+                float R[9];
+                q2mat(q, R);                                       // parent rotation: the three hinge axes are R e_z, R a1, R a2
+                pos = ppos + mulmat(R, bpos);
                 const V3 r = o - pos;
-                const float qds[3] = {qd0, qd1, qd2}, sns[3] = {sn0, sn1, sn2}, css[3] = {cs0, cs1, cs2};
+                const V3 axes[3] = {v3(R[2], R[5], R[8]), mulmat(R, a1), mulmat(R, a2)};
 #pragma unroll
                 for (int j = 0; j < 3; j++) {
-                    const V3 e = j == 0 ? v3(0.f, 0.f, 1.f) : (j == 1 ? v3(0.f, 1.f, 0.f) : v3(1.f, 0.f, 0.f));
-                    const V3 axis = qrot(q, e);
-                    const S6 cd = S6{axis, cross(axis, r)};
+                    const S6 cd = S6{axes[j], cross(axes[j], r)};
                     sts6(s.cdof + 6 * (d0 + j), cd);
                     const S6 cdd = cross_motion(cv, cd);
                     cv = cv + qds[j] * cd; ca = ca + qds[j] * cdd;
-                    q = qmul(q, Q4{css[j], e.x * sns[j], e.y * sns[j], e.z * sns[j]});
                 }
-                q = qnormalize(q);
+                q = qnormalize(qmul(q, ql));
             }
             st3(s.xpos + 3 * b, pos);
             s.xquat[4 * b] = q.w; s.xquat[4 * b + 1] = q.x; s.xquat[4 * b + 2] = q.y; s.xquat[4 * b + 3] = q.z;
