@@ -128,6 +128,10 @@ int kp_gae(int n_envs, int T, const float* rewards, const float* masks, const fl
  * state (qpos_d/qvel_d) the stale derived quantities belong to; runs the forward pass on the latter. */
 int kp_sim_set_full_state(kp_sim*, const float* qpos, const float* qvel, const float* qpos_d, const float* qvel_d, const uint8_t* env_mask);
 
+/* object block of MjSimState save / restore: overwrite data.qpos[76:111] / data.qvel[75:105] of the simulated objects
+ * (read them back with KP_OBJ_QPOS / KP_OBJ_QVEL).  Which objects are simulated stays as kp_sim_set_objects decided. */
+int kp_sim_set_obj_state(kp_sim*, const float* obj_qpos, const float* obj_qvel, const uint8_t* env_mask);
+
 /* read-outs of the mujoco-py data fields the env uses (humanoid_im.py:342-416, humanoid_ar_v1.py:460-512) */
 typedef enum {
     KP_QPOS = 0,        /* data.qpos[:76]                    [N,76]  */

@@ -532,6 +532,17 @@ int kp_sim_set_full_state(kp_sim* s, const float* qpos, const float* qvel, const
     return launch_step(s, nullptr, 0, mask, false);
 }
 
+int kp_sim_set_obj_state(kp_sim* s, const float* obj_qpos, const float* obj_qvel, const uint8_t* mask) {
+    if (!s || !obj_qpos || !obj_qvel) return fail("kp_sim_set_obj_state: null argument");
+    if (!s->has_objects) return fail("kp_sim_set_obj_state: call kp_sim_set_objects first (it decides which objects are simulated)");
+    HIP_OK(hipSetDevice(s->device));
+    int n = s->n;
+    hipLaunchKernelGGL(k_copy_rows, dim3((n * 35 + 255) / 256), dim3(256), 0, s->stream, n, 35, obj_qpos, s->obj_qpos, (float*)nullptr, mask);
+    hipLaunchKernelGGL(k_copy_rows, dim3((n * 30 + 255) / 256), dim3(256), 0, s->stream, n, 30, obj_qvel, s->obj_qvel, (float*)nullptr, mask);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
 int kp_sim_diag(kp_sim* s, int32_t* out_host) {
     if (!s || !out_host) return fail("kp_sim_diag: null argument");
     HIP_OK(hipSetDevice(s->device));

@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "kp_sim_n_envs", "kp_sim_set_state", "kp_sim_set_target", "kp_sim_step_ctrl", "kp_sim_step_kin", "kp_sim_obs_cc",
     "kp_field_dim", "kp_sim_get", "kp_sim_diag", "kp_sim_last_step_seconds", "kp_last_error", "kp_version",
     "kp_sim_step_begin", "kp_sim_obs_ar", "kp_sim_term_reward", "kp_gae", "kp_sim_set_full_state", "kp_sim_fk",
-    "kp_sim_timing_reset", "kp_sim_timing_mean_seconds", "kp_sim_phase_cycles", "kp_sim_set_objects",
+    "kp_sim_timing_reset", "kp_sim_timing_mean_seconds", "kp_sim_phase_cycles", "kp_sim_set_objects", "kp_sim_set_obj_state",
 ]
 
 
@@ -91,6 +91,7 @@ def load_library(path: str | None = None):
     L.kp_sim_timing_mean_seconds.argtypes = [P, C.POINTER(C.c_int)]; L.kp_sim_timing_mean_seconds.restype = C.c_double
     L.kp_sim_phase_cycles.argtypes = [P, C.POINTER(C.c_double)]; L.kp_sim_phase_cycles.restype = C.c_int
     L.kp_sim_set_objects.argtypes = [P, F, U8]; L.kp_sim_set_objects.restype = C.c_int
+    L.kp_sim_set_obj_state.argtypes = [P, F, F, U8]; L.kp_sim_set_obj_state.restype = C.c_int
     L.kp_sim_fk.argtypes = [P, C.c_int, F, F, F, F, F, F]; L.kp_sim_fk.restype = C.c_int
     L.kp_last_error.restype = C.c_char_p
     L.kp_version.restype = C.c_char_p
@@ -171,6 +172,9 @@ class KpSim:
 
     def set_objects(self, obj_qpos, env_mask=None):
         _check(self.L.kp_sim_set_objects(self.h, _ptr(obj_qpos, self.n, 35), _mask_ptr(env_mask, self.n)), "kp_sim_set_objects")
+
+    def set_obj_state(self, obj_qpos, obj_qvel, env_mask=None):
+        _check(self.L.kp_sim_set_obj_state(self.h, _ptr(obj_qpos, self.n, 35), _ptr(obj_qvel, self.n, 30), _mask_ptr(env_mask, self.n)), "kp_sim_set_obj_state")
 
     def set_target(self, target_qpos, env_mask=None):
         _check(self.L.kp_sim_set_target(self.h, _ptr(target_qpos, self.n, NQ), _mask_ptr(env_mask, self.n)), "kp_sim_set_target")

@@ -424,3 +424,33 @@ def test_dynamic_objects_match_oracle(kp):
     assert max(errs) < 1e-3 and np.median(errs) < 2e-4
     assert max(oerrs) < 1e-3 and np.median(oerrs) < 2e-4
     assert moved[0] > 0.02 and moved[4] > 1e-4          # the dropped box fell; the light box was pushed by the toes
+
+
+def test_save_restore_with_objects(kp):
+    """MjSimState-style save / restore including the object block: replaying from a restored state follows the same trajectory
+    (up to the solver warm start, which mujoco-py does not restore either)."""
+    from kinpoly_amd.model_compiler import STEP_KPM
+    n = 4
+    x0, y0 = STD["qpos"][0], STD["qpos"][1]
+    blk = _obj_block(n, [{4: [x0, y0, 0.3705, 1, 0, 0, 0]}] * n)
+    qpos = np.tile(STD["qpos"], (n, 1)); qpos[:, 2] += 0.341
+    rng = np.random.default_rng(5)
+    qvel = rng.normal(size=(n, 75)) * 0.1
+    sim = kp.KpSim(kp.KpModel(STEP_KPM), n)
+    sim.set_objects(dev(blk)); sim.set_state(dev(qpos), dev(qvel)); sim.set_target(dev(qpos))
+    a = dev(rng.normal(size=(n, 75)) * 0.1)
+    for _ in range(2):
+        sim.step_ctrl(a, 15)
+    saved = {k: sim.get(k).clone() for k in ("qpos", "qvel", "qpos_d", "qvel_d", "obj_qpos", "obj_qvel")}
+    for _ in range(2):
+        sim.step_ctrl(a, 15)
+    ref = {k: sim.get(k).clone() for k in ("qpos", "obj_qpos")}
+    sim.set_obj_state(saved["obj_qpos"], saved["obj_qvel"])
+    sim.set_full_state(saved["qpos"], saved["qvel"], saved["qpos_d"], saved["qvel_d"])
+    for _ in range(2):
+        sim.step_ctrl(a, 15)
+    assert (sim.get("qpos") - ref["qpos"]).abs().max().item() < 2e-5
+    assert (sim.get("obj_qpos") - ref["obj_qpos"]).abs().max().item() < 2e-5
+    s2 = kp.KpSim(kp.KpModel(STEP_KPM), n)
+    with pytest.raises(kp.KinPolyNativeError):
+        s2.set_obj_state(saved["obj_qpos"], saved["obj_qvel"])
