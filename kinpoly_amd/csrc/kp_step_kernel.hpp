@@ -772,12 +772,12 @@ __device__ __forceinline__ void eval_rows(EnvLds& s, const float* vec, float* ou
     KP_SYNC();
 }
 
-// out = M vec (with_inertia; sv must hold the spatial accelerations of vec) - J^T f(jar) (with_forces)
+// out = M (va - vb) (with_inertia; acc6 [24][6] must hold the body spatial accelerations of va - vb) - J^T f(jar) (with_forces)
 template <int NT, bool OBJ>
-__device__ __forceinline__ void wrench_project(EnvLds& s, const Params& P, const float* vec, float* out, bool with_inertia, bool with_forces, int tid) {
+__device__ __forceinline__ void wrench_project(EnvLds& s, const Params& P, const float* acc6, const float* va, const float* vb, float* out, bool with_inertia, bool with_forces, int tid) {
     if (tid < D_NB) {
         const int b = tid;
-        S6 W = with_inertia ? inert_mul(s.cinert + 10 * b, lds6(s.sv + 6 * b)) : S6{v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f)};
+        S6 W = with_inertia ? inert_mul(s.cinert + 10 * b, lds6(acc6 + 6 * b)) : S6{v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f)};
         if (with_forces) {
             const V3 o = ld3(s.xpos);
             for (int c = s.con_start[b]; c < s.con_start[b + 1]; c++) {
@@ -803,18 +803,28 @@ __device__ __forceinline__ void wrench_project(EnvLds& s, const Params& P, const
     KP_SYNC();
     for (int d = tid; d < D_NV; d += NT) {
         float v = dot6(lds6(s.cdof + 6 * d), lds6(s.sa + 6 * s.dbody[d]));
-        if (with_inertia) v += s.arm[d] * vec[d];
+        if (with_inertia) v += s.arm[d] * (va[d] - (vb ? vb[d] : 0.f));
         if (with_forces && d >= 6) { float jr = s.lim_jar[d - 6]; if (jr < 0.f) v -= s.lim_sgn[d - 6] * (-s.lim_D[d - 6] * jr); }
         out[d] = v;
     }
     KP_SYNC();
 }
 
-// primal cost at the current (qacc, mres, jar):  0.5 mres.(qacc - qacc_s) + sum 0.5 D jar_-^2
+// 0.5 a^T I_b b summed over the bodies + 0.5 arm x y over the dofs: lane partial of  0.5 x^T M y  for the generalized vectors x, y
+// whose body spatial accelerations are acca / accb (xa - xb and ya - yb give the dof vectors; xb / yb may be null)
 template <int NT>
-__device__ __forceinline__ float primal_cost(EnvLds& s, const Params& P, const float* qacc, const float* mres, const float* jar3, const float* lim_jar, int tid) {
+__device__ __forceinline__ float quad_form_M(const EnvLds& s, const float* acca, const float* accb, const float* xa, const float* xb, const float* ya, const float* yb, int tid) {
     float c = 0.f;
-    if (mres) for (int i = tid; i < D_NV; i += NT) c += 0.5f * mres[i] * (qacc[i] - s.qacc_s[i]);
+    if (tid < D_NB) c += 0.5f * dot6(lds6(acca + 6 * tid), inert_mul(s.cinert + 10 * tid, lds6(accb + 6 * tid)));
+    for (int i = tid; i < D_NV; i += NT) c += 0.5f * s.arm[i] * (xa[i] - (xb ? xb[i] : 0.f)) * (ya[i] - (yb ? yb[i] : 0.f));
+    return c;
+}
+
+// primal cost at the current iterate:  0.5 (qacc - qacc_s)^T M (qacc - qacc_s) + sum 0.5 D jar_-^2.  sacc = body spatial
+// accelerations of qacc - qacc_s (null: qacc = qacc_s, Gauss term 0)
+template <int NT>
+__device__ __forceinline__ float primal_cost(EnvLds& s, const Params& P, const float* sacc, const float* jar3, const float* lim_jar, int tid) {
+    float c = sacc ? quad_form_M<NT>(s, sacc, sacc, s.qacc, s.qacc_s, s.qacc, s.qacc_s, tid) : 0.f;
     for (int k = tid; k < s.ncon; k += NT) {
         const float Dc = s.con_D[k], jn = jar3[3 * k], jt1 = jar3[3 * k + 1], jt2 = jar3[3 * k + 2];
 #pragma unroll
@@ -893,34 +903,39 @@ __device__ __forceinline__ int solve_constraints(EnvLds& s, const Params& P, con
     }
     // candidate A: qacc_smooth (M qacc_s = qfrc_smooth => Gauss term 0); sv holds its spatial accelerations
     eval_rows<NT, OBJ>(s, s.qacc_s, s.jar3, s.lim_jar, true, tid);
-    float cost = primal_cost<NT>(s, P, nullptr, nullptr, s.jar3, s.lim_jar, tid);
+    float cost = primal_cost<NT>(s, P, nullptr, s.jar3, s.lim_jar, tid);
+    // The Gauss part of the problem is carried in body form: sacc[b] = spatial acceleration of body b induced by qacc - qacc_s, so
+    // M (qacc - qacc_s) never has to be projected on the dofs on its own (it rides along with the gradient's projection).
+    float* sacc = s.Mv;        // [24][6] over Mv + mres (152 floats)
     // candidate B: warm start = s.qacc (qacc of the previous substep / control step), mj_fwdConstraint's rule
     {
         float* wj3 = s.jv3;    // in place over aref (each lane reads its aref, writes its residual; aref is not needed afterwards);
         float* wlim = s.x;     // U must stay as the smooth solve left it (aba_solve's clean levels)
+        for (int i = tid; i < D_NB * 6; i += NT) sacc[i] = s.sv[i];            // accelerations of qacc_s
+        KP_SYNC();
         spatial_accumulate<NT>(s, s.qacc, depth, tid);
         eval_rows<NT, OBJ>(s, s.qacc, wj3, wlim, true, tid);
-        wrench_project<NT, OBJ>(s, P, s.qacc, s.Mv, true, false, tid);
-        for (int i = tid; i < D_NV; i += NT) s.mres[i] = s.Mv[i] - s.smooth[i];
+        for (int i = tid; i < D_NB * 6; i += NT) sacc[i] = s.sv[i] - sacc[i];
         KP_SYNC();
-        float cw = primal_cost<NT>(s, P, s.qacc, s.mres, wj3, wlim, tid);
+        float cw = primal_cost<NT>(s, P, sacc, wj3, wlim, tid);
         if (cw < cost) {
             cost = cw;
             for (int k = tid; k < 3 * s.ncon; k += NT) s.jar3[k] = wj3[k];
             for (int j = tid; j < D_NU; j += NT) s.lim_jar[j] = wlim[j];
         } else {
-            for (int i = tid; i < D_NV; i += NT) { s.qacc[i] = s.qacc_s[i]; s.mres[i] = 0.f; }
+            for (int i = tid; i < D_NV; i += NT) s.qacc[i] = s.qacc_s[i];
+            for (int i = tid; i < D_NB * 6; i += NT) sacc[i] = 0.f;
         }
         KP_SYNC();
     }
     int it = 0, lev_hist = 1;
     for (; it < P.max_iter; it++) {
-        // gradient = mres - J^T f
-        wrench_project<NT, OBJ>(s, P, nullptr, s.grad, false, true, tid);
+        // gradient = M (qacc - qacc_s) - J^T f: one projection of the body wrenches I_b sacc_b - contact forces
+        wrench_project<NT, OBJ>(s, P, sacc, s.qacc, s.qacc_s, s.grad, true, true, tid);
         float g2 = 0.f, changed = 0.f;
         for (int i = tid; i < D_NV; i += NT) {
-            float g = s.mres[i] + s.grad[i];
-            s.grad[i] = g; g2 += g * g;
+            float g = s.grad[i];
+            g2 += g * g;
             s.x[i] = -g;
             const float ex = (i >= 6 && s.lim_jar[i - 6] < 0.f) ? s.lim_D[i - 6] : 0.f;
             if (ex != s.extra[i]) changed = 1.f;
@@ -941,10 +956,9 @@ __device__ __forceinline__ int solve_constraints(EnvLds& s, const Params& P, con
         }
         else aba_resolve(s, L8, s.x, nullptr, s.search);
         eval_rows<NT, OBJ>(s, s.search, s.jv3, s.lim_jv, false, tid);           // aref (in jv3) is folded into jar3 by now
-        wrench_project<NT, OBJ>(s, P, s.search, s.Mv, true, false, tid);
-        // exact line search on phi(alpha)
-        float g0 = 0.f, h0 = 0.f;
-        for (int i = tid; i < D_NV; i += NT) { g0 += s.search[i] * s.mres[i]; h0 += s.search[i] * s.Mv[i]; }
+        // exact line search on phi(alpha): g0 = search^T M (qacc - qacc_s), h0 = search^T M search, both in body form (sv = search's accelerations)
+        float g0 = 2.0f * quad_form_M<NT>(s, s.sv, sacc, s.search, nullptr, s.qacc, s.qacc_s, tid);
+        float h0 = 2.0f * quad_form_M<NT>(s, s.sv, s.sv, s.search, nullptr, s.search, nullptr, tid);
         g0 = block_sum<NT>(s, g0, tid); h0 = block_sum<NT>(s, h0, tid);
         float alpha = 0.f, lo = 0.f, hi = 3.0e38f;
         for (int ls = 0; ls < 20; ls++) {
@@ -973,11 +987,12 @@ __device__ __forceinline__ int solve_constraints(EnvLds& s, const Params& P, con
             if (fabsf(step) <= 1e-6f * fabsf(alpha)) break;
         }
         if (!(alpha > 0.f)) break;
-        for (int i = tid; i < D_NV; i += NT) { s.qacc[i] += alpha * s.search[i]; s.mres[i] += alpha * s.Mv[i]; }
+        for (int i = tid; i < D_NV; i += NT) s.qacc[i] += alpha * s.search[i];
+        for (int i = tid; i < D_NB * 6; i += NT) sacc[i] += alpha * s.sv[i];
         for (int k = tid; k < 3 * s.ncon; k += NT) s.jar3[k] += alpha * s.jv3[k];
         for (int j = tid; j < D_NU; j += NT) if (s.lim_sgn[j] != 0.f) s.lim_jar[j] += alpha * s.lim_jv[j];
         KP_SYNC();
-        float newcost = primal_cost<NT>(s, P, s.qacc, s.mres, s.jar3, s.lim_jar, tid);
+        float newcost = primal_cost<NT>(s, P, sacc, s.jar3, s.lim_jar, tid);
         float improvement = P.scale * (cost - newcost);
         cost = newcost;
         if (improvement < P.tol) { it++; break; }
@@ -1336,26 +1351,29 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
     if (tid < no6) s.sv[6 * D_NB + tid] = s.oas[tid];
     KP_SYNC();
     eval_rows<NT, true>(s, s.qacc_s, s.jar3, s.lim_jar, true, tid);
-    float cost = primal_cost<NT>(s, P, nullptr, nullptr, s.jar3, s.lim_jar, tid);
+    float cost = primal_cost<NT>(s, P, nullptr, s.jar3, s.lim_jar, tid);
+    float* sacc = s.Mv;        // body spatial accelerations of qacc - qacc_s ([24][6] over Mv + mres), see solve_constraints
     // candidate B: warm start
     {
         float* wj3 = s.jv3;    // in place over aref; U stays as the smooth solve left it (aba_solve's clean levels)
         float* wlim = s.x;
+        for (int i = tid; i < D_NB * 6; i += NT) sacc[i] = s.sv[i];
+        KP_SYNC();
         spatial_accumulate<NT>(s, s.qacc, depth, tid);
         if (tid < no6) s.sv[6 * D_NB + tid] = s.oa[tid];
         KP_SYNC();
         eval_rows<NT, true>(s, s.qacc, wj3, wlim, true, tid);
-        wrench_project<NT, true>(s, P, s.qacc, s.Mv, true, false, tid);
-        for (int i = tid; i < D_NV; i += NT) s.mres[i] = s.Mv[i] - s.smooth[i];
+        for (int i = tid; i < D_NB * 6; i += NT) sacc[i] = s.sv[i] - sacc[i];
         if (tid < nobj) sts6(s.omres + 6 * tid, inert_mul(s.oIe + 10 * tid, lds6(s.oa + 6 * tid) + (-1.0f) * lds6(s.oas + 6 * tid)));
         KP_SYNC();
-        const float cw = primal_cost<NT>(s, P, s.qacc, s.mres, wj3, wlim, tid) + obj_gauss(s);
+        const float cw = primal_cost<NT>(s, P, sacc, wj3, wlim, tid) + obj_gauss(s);
         if (cw < cost) {
             cost = cw;
             for (int k = tid; k < 3 * s.ncon; k += NT) s.jar3[k] = wj3[k];
             for (int j = tid; j < D_NU; j += NT) s.lim_jar[j] = wlim[j];
         } else {
-            for (int i = tid; i < D_NV; i += NT) { s.qacc[i] = s.qacc_s[i]; s.mres[i] = 0.f; }
+            for (int i = tid; i < D_NV; i += NT) s.qacc[i] = s.qacc_s[i];
+            for (int i = tid; i < D_NB * 6; i += NT) sacc[i] = 0.f;
             if (tid < no6) { s.oa[tid] = s.oas[tid]; s.omres[tid] = 0.f; }
         }
         KP_SYNC();
@@ -1363,12 +1381,12 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
     int it = 0, lev_hist = 1;
     for (; it < P.max_iter; it++) {
         // gradient: humanoid dofs (mres - J^T f) and object wrenches
-        wrench_project<NT, true>(s, P, nullptr, s.grad, false, true, tid);
+        wrench_project<NT, true>(s, P, sacc, s.qacc, s.qacc_s, s.grad, true, true, tid);
         if (nobj > 0) { con_prepare<NT>(s, P, tid); obj_gradient(s, tid); }
         float g2 = 0.f, changed = 0.f;
         for (int i = tid; i < D_NV; i += NT) {
-            const float g = s.mres[i] + s.grad[i];
-            s.grad[i] = g; g2 += g * g;
+            const float g = s.grad[i];
+            g2 += g * g;
             s.x[i] = -g;
             const float ex = (i >= 6 && s.lim_jar[i - 6] < 0.f) ? s.lim_D[i - 6] : 0.f;
             if (ex != s.extra[i]) changed = 1.f;
@@ -1410,7 +1428,7 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
         if (!(refactor && no6 == 0)) {
             int kj = refactor ? (couple ? 0 : no6) : -1;
             while (true) {
-                const float* rhsp = nullptr; const float* wr = nullptr; float* outp = s.Mv;
+                const float* rhsp = nullptr; const float* wr = nullptr; float* outp = s.grad;     // scratch: -grad already sits in s.x
                 if (kj == -1) { rhsp = s.x; outp = s.search; }
                 else if (kj < no6) {
                     if (!((cmask >> (kj / 6)) & 1u)) { kj += 6; continue; }     // no hull presses on this object: H_ho e = 0, column done
@@ -1445,11 +1463,10 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
         if (tid < no6) s.sv[6 * D_NB + tid] = s.osrch[tid];
         KP_SYNC();
         eval_rows<NT, true>(s, s.search, s.jv3, s.lim_jv, false, tid);
-        wrench_project<NT, true>(s, P, s.search, s.Mv, true, false, tid);
         if (tid < nobj) sts6(s.oMv + 6 * tid, inert_mul(s.oIe + 10 * tid, lds6(s.osrch + 6 * tid)));
         KP_SYNC();
-        float g0 = 0.f, h0 = 0.f;
-        for (int i = tid; i < D_NV; i += NT) { g0 += s.search[i] * s.mres[i]; h0 += s.search[i] * s.Mv[i]; }
+        float g0 = 2.0f * quad_form_M<NT>(s, s.sv, sacc, s.search, nullptr, s.qacc, s.qacc_s, tid);
+        float h0 = 2.0f * quad_form_M<NT>(s, s.sv, s.sv, s.search, nullptr, s.search, nullptr, tid);
         if (tid < no6) { g0 += s.osrch[tid] * s.omres[tid]; h0 += s.osrch[tid] * s.oMv[tid]; }
         g0 = block_sum<NT>(s, g0, tid); h0 = block_sum<NT>(s, h0, tid);
         float alpha = 0.f, lo = 0.f, hi = 3.0e38f;
@@ -1479,12 +1496,13 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
             if (fabsf(step) <= 1e-6f * fabsf(alpha)) break;
         }
         if (!(alpha > 0.f)) break;
-        for (int i = tid; i < D_NV; i += NT) { s.qacc[i] += alpha * s.search[i]; s.mres[i] += alpha * s.Mv[i]; }
+        for (int i = tid; i < D_NV; i += NT) s.qacc[i] += alpha * s.search[i];
+        for (int i = tid; i < D_NB * 6; i += NT) sacc[i] += alpha * s.sv[i];
         if (tid < no6) { s.oa[tid] += alpha * s.osrch[tid]; s.omres[tid] += alpha * s.oMv[tid]; }
         for (int k = tid; k < 3 * s.ncon; k += NT) s.jar3[k] += alpha * s.jv3[k];
         for (int j = tid; j < D_NU; j += NT) if (s.lim_sgn[j] != 0.f) s.lim_jar[j] += alpha * s.lim_jv[j];
         KP_SYNC();
-        const float newcost = primal_cost<NT>(s, P, s.qacc, s.mres, s.jar3, s.lim_jar, tid) + obj_gauss(s);
+        const float newcost = primal_cost<NT>(s, P, sacc, s.jar3, s.lim_jar, tid) + obj_gauss(s);
         const float improvement = P.scale * (cost - newcost);
         cost = newcost;
         if (improvement < P.tol) { it++; break; }
