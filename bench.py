@@ -164,14 +164,14 @@ def main():
             traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
         # what actually bounds the kernel: VALU issue.  Instruction count per launch from the committed PMC pass, live launch time
         valu = None
-        pv = os.path.join(ROOT, "profiles", "r01_v5", "pmc_SQ_INSTS_VALU+SQ_INSTS_SALU+SQ_INSTS_LDS.json")
+        pv = os.path.join(ROOT, "profiles", "r01_v6", "pmc_SQ_INSTS_VALU+SQ_INSTS_SALU+SQ_INSTS_LDS.json")
         if os.path.exists(pmc) and os.path.exists(pv):
             d = json.load(open(pv))
             k = [x for x in d if "kp_step_kernel" in x]
             if k:
                 insts = d[k[0]]["SQ_INSTS_VALU"]["median"]           # wave-level VALU instructions per launch (4096 envs, tools/pmc_step.py)
                 valu = {"valu_insts_per_launch": insts, "cycles_per_wave64_op": 4, "simds": 1024, "shader_clock_ghz": 2.38,
-                        "valu_busy_frac": insts * 4 / (1024 * kern_s * 2.38e9), "source": "instruction count: profiles/r01_v5 PMC pass on the standing-contact workload (tools/pmc_step.py); clock: profiles/r01_v4/clock_probe.log"}
+                        "valu_busy_frac": insts * 4 / (1024 * kern_s * 2.38e9), "source": "instruction count: profiles/r01_v6 PMC pass on the standing-contact workload (tools/pmc_step.py); clock: profiles/r01_v4/clock_probe.log"}
         out = {
             "metric": "env-steps/sec (whole node) at 4096 envs/GPU, 69-DoF SMPL", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
