@@ -454,3 +454,46 @@ def test_save_restore_with_objects(kp):
     s2 = kp.KpSim(kp.KpModel(STEP_KPM), n)
     with pytest.raises(kp.KinPolyNativeError):
         s2.set_obj_state(saved["obj_qpos"], saved["obj_qvel"])
+
+
+def test_lying_many_contacts_and_joint_limits(kp):
+    """Hard cases of the constraint solve against the oracle: the humanoid lying on the floor in random orientations (30+
+    simultaneous contacts, the 64-contact cap in reach) with joints wound past their +-180 degree limits (active limit rows)."""
+    n = 12
+    rng = np.random.default_rng(31)
+    qpos = np.tile(STD["qpos"], (n, 1)); qvel = rng.normal(size=(n, 75)) * 0.05
+    for e in range(n):
+        ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+        ang = rng.uniform(1.2, 1.9)                                   # tipped over by 70-110 degrees about a random axis
+        tip = np.concatenate([[np.cos(ang / 2)], np.sin(ang / 2) * ax])
+        qpos[e, 3:7] = O.quaternion_multiply(tip, STD["qpos"][3:7])
+        qpos[e, 2] = 0.16 + 0.04 * rng.uniform()
+        qpos[e, 7:] += rng.normal(size=69) * 0.15
+    for e in range(n):                                                # three joints per env just past +-180 degrees
+        jj = rng.choice(69, 3, replace=False)
+        qpos[e, 7 + jj] = rng.choice([-1.0, 1.0], 3) * (np.pi + rng.uniform(0.02, 0.15, 3))
+    action = rng.normal(size=(n, 75)) * 0.2
+    sim = kp.KpSim(kp.KpModel(), n)
+    sim.set_state(dev(qpos), dev(qvel)); sim.set_target(dev(qpos))
+    a = dev(action)
+    nstep = 4
+    maxc = np.zeros(n, int)
+    for _ in range(nstep):
+        sim.step_ctrl(a, 15)
+        dg = sim.diag()
+        assert dg[:, 2].max() == 0
+        maxc = np.maximum(maxc, dg[:, 3] & 255)
+    got = sim.get("qpos").double().cpu().numpy()
+    errs, ncs, nlims = [], [], []
+    for e in range(n):
+        o = OracleSim()
+        o.reset(qpos[e], qvel[e])
+        nl = 0
+        for _ in range(nstep):
+            o.do_simulation(action[e], qpos[e], 15)
+            nl = max(nl, o.nefc - 4 * len(o.contacts()[0]))
+        errs.append(np.abs(o.get("qpos") - got[e]).max()); ncs.append((int(maxc[e]), len(o.contacts()[0]))); nlims.append(nl)
+    print("lying |dqpos|:", ["%.1e" % x for x in errs], "max contacts (hip) / last (oracle):", ncs, "limit rows:", nlims)
+    assert max(c[0] for c in ncs) >= 30 and max(nlims) >= 1
+    # equally deep vertices on flat hull faces can swap between fp32 and fp64 (different 3-vertex set): bounded, not bit-level
+    assert max(errs) < 1e-3 and np.median(errs) < 5e-5
