@@ -1,5 +1,5 @@
 // kp_step_kernel.hpp -- the fused control-step kernel: n_substeps x { stable-PD torque, residual
-// force, mj_step-equivalent forward dynamics with hull-plane soft contact, semi-implicit Euler }.
+// force, mj_step-equivalent forward dynamics with soft contact (hulls, floor, free objects), semi-implicit Euler }.
 //
 // Replaces HOT LOOP C of the reference: HumanoidEnv.do_simulation (uhc/envs/humanoid_im.py:506-533)
 //   compute_torque / compute_desired_accel   uhc/envs/humanoid_im.py:418-480
@@ -16,7 +16,9 @@
 //     The joint-space mass matrix is never formed or factorised (the reference materialises a dense
 //     105x105 M and a Cholesky factor per substep);
 //   * J v is read off the spatial accelerations the ABA forward pass leaves behind, J^T f and M v are a
-//     body-wrench subtree sum projected on the dofs.
+//     body-wrench subtree sum projected on the dofs; the solver's Gauss term lives in body form (spatial
+//     accelerations), so one projection per Newton iteration suffices;
+//   * Newton factorisations reuse the smooth solve's factors on the tree levels no active constraint reaches.
 #pragma once
 #include <type_traits>
 
@@ -114,8 +116,9 @@ __device__ __forceinline__ V3 frame_comp(const Frame& f, V3 v) { return v3(dot(f
 __device__ __forceinline__ V3 frame_world(const Frame& f, V3 c) { return c.x * f.n + c.y * f.t1 + c.z * f.t2; }
 
 // ---------------------------------------------------------------- kinematics + velocities + bias
-// Three phases so that the level-serial chain stays short:
-//   0. half-angle sin/cos of all 69 hinge angles, one lane per hinge (scratch: s.U, free outside the ABA passes);
+// Phases, so that the level-serial chain stays short:
+//   0. half-angle sin/cos of all 69 hinge angles, one lane per hinge (scratch: s.U, free outside the ABA passes), then per
+//      body (parallel) the local rotation qz qy qx and the second / third hinge axis in the parent frame;
 //   K. level-synchronous chain (lane = body): world pose, motion axes cdof, spatial velocity cvel and the
 //      velocity-product acceleration cacc (mj_kinematics + mj_comVel + the forward half of mj_rne);
 //   B. body-parallel (24 lanes at once): COM, world inertia about o, body wrench I a + v x* I v; then subtree
@@ -544,7 +547,7 @@ __device__ __forceinline__ void spd_torque_rfc(EnvLds& s, const DevTables& T, co
     KP_SYNC();
 }
 
-// ---------------------------------------------------------------- hull-vs-plane collision (wave 0; lane = hull vertex)
+// ---------------------------------------------------------------- collision (wave 0)
 // signed distance + outward normal (world) of a static box (type 0) / z-axis cylinder (type 1) at world point x
 __device__ __forceinline__ float geom_sdf(const float* g, V3 x, V3& nw) {
     const float* R = g + 7;
@@ -1165,7 +1168,7 @@ __device__ __forceinline__ S6 wave_sum6(S6 v) {
 }
 
 // sum of V per-lane values over the 64 lanes (lane = contact): four DPP exchanges inside each 16-lane row, the four row sums meet
-// in LDS.  Deterministic order.  The V results are handed to `store(v, sum)` on lane v.
+// in LDS.  Deterministic order.  Lane v < V returns sum v.
 __device__ __forceinline__ float row_sum16(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
