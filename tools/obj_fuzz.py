@@ -1,0 +1,77 @@
+"""Randomised parity sweep of the free-object path: N scenes (random action class, objects dropped / tilted / overlapping
+the humanoid's reach), HIP kernel vs the fp64 oracle after a few control steps.  Prints the error distribution."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from kinpoly_amd.model_compiler import read_kpm  # noqa: E402
+from kinpoly_amd.sim import STEP_KPM, KpModel, KpSim  # noqa: E402
+from oracle.kpo import OracleSim  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+nstep = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+seed = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+kpm = read_kpm(STEP_KPM)
+std = np.load(os.path.join(ROOT, "tests/golden/standing_neutral.npz"))
+rng = np.random.default_rng(seed)
+x0, y0 = std["qpos"][0], std["qpos"][1]
+nominal = {0: [[0.0, -0.45, 0.3805]], 1: [[0.0, 0.55, 0.921], [0.0, 0.55, 0.7905]], 2: [[0.0, 0.45, 0.69]], 3: [[0.0, 0.0, 0.3705]]}   # per action: objects (local x, y, z)
+obj_of_action = {0: [0], 1: [1, 2], 2: [3], 3: [4]}
+
+
+def rquat(scale):
+    ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+    a = rng.normal() * scale
+    return np.concatenate([[np.cos(a / 2)], np.sin(a / 2) * ax])
+
+
+blk = np.zeros((n, 35))
+for i in range(5):
+    blk[:, 7 * i: 7 * i + 3] = [(i + 1) * 100, 100, 0]
+qpos = np.tile(std["qpos"], (n, 1)); qvel = rng.normal(size=(n, 75)) * 0.2
+scenes = []
+for e in range(n):
+    a = int(rng.integers(0, 4))
+    objs = {}
+    shift = rng.normal(size=2) * 0.15
+    lift = rng.uniform(0, 0.25) if rng.uniform() < 0.5 else 0.0
+    tilt = rquat(0.25 if rng.uniform() < 0.5 else 0.0)
+    for oi, (lx, ly, lz) in zip(obj_of_action[a], nominal[a]):
+        objs[oi] = [x0 + lx + shift[0], y0 + ly + shift[1], lz + lift + 0.0005, *tilt]
+        blk[e, 7 * oi: 7 * oi + 7] = objs[oi]
+    if a == 3:
+        qpos[e, 2] += 0.341 + lift + 0.02
+    qpos[e, 7:] += rng.normal(size=69) * 0.1
+    scenes.append(objs)
+action = rng.normal(size=(n, 75)) * 0.2
+dev = lambda x: torch.tensor(x, dtype=torch.float32, device="cuda")  # noqa: E731
+sim = KpSim(KpModel(STEP_KPM), n)
+sim.set_objects(dev(blk)); sim.set_state(dev(qpos), dev(qvel)); sim.set_target(dev(qpos))
+a_t = dev(action)
+maxc = np.zeros(n, int); its = np.zeros(n, int)
+for _ in range(nstep):
+    sim.step_ctrl(a_t, 15)
+    dg = sim.diag(); maxc = np.maximum(maxc, dg[:, 3] & 255); its += dg[:, 1]
+    assert dg[:, 2].max() == 0, "non-finite state"
+got = sim.get("qpos").double().cpu().numpy(); gobj = sim.get("obj_qpos").double().cpu().numpy()
+eh, eo = [], []
+for e in range(n):
+    o = OracleSim(kpm=STEP_KPM)
+    for slot, oi in enumerate(sorted(scenes[e])):
+        o.set_object(slot, kpm, oi, scenes[e][oi])
+    o.reset(qpos[e], qvel[e])
+    for _ in range(nstep):
+        o.do_simulation(action[e], qpos[e], 15)
+    eh.append(np.abs(o.get("qpos") - got[e]).max())
+    eo.append(max(np.abs(o.get_object(slot)[0] - gobj[e, 7 * oi: 7 * oi + 7]).max() for slot, oi in enumerate(sorted(scenes[e]))))
+eh, eo = np.array(eh), np.array(eo)
+print(f"{n} scenes x {nstep} control steps (seed {seed}): humanoid |dqpos| median {np.median(eh):.2e} p90 {np.quantile(eh, .9):.2e} max {eh.max():.2e}; "
+      f"objects median {np.median(eo):.2e} p90 {np.quantile(eo, .9):.2e} max {eo.max():.2e}; contacts max {maxc.max()} mean {maxc.mean():.1f}; "
+      f"newton it/substep {its.mean() / 15 / nstep:.2f}; scenes above 1e-4: {int(((eh > 1e-4) | (eo > 1e-4)).sum())}")
+worst = np.argsort(-np.maximum(eh, eo))[:5]
+for e in worst:
+    print(f"  scene {e}: objects {sorted(scenes[e])} err humanoid {eh[e]:.2e} object {eo[e]:.2e} contacts {maxc[e]}")
