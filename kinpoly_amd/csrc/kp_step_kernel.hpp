@@ -258,9 +258,11 @@ struct Lane8 {
     float cisgn[8];
     int idx21[8];    // index into the 21-float symmetric storage
     unsigned long long sb, sp, sc0, sc1, sc2;  // 5 bits per level: body, parent, children (31 = none) of this lane's slot
+    unsigned multi;  // bit lev set: some body of that level has more than one child (wave-uniform; only levels 0 and 3 of the SMPL tree)
     __device__ __forceinline__ void init(int tid, const uint32_t* __restrict__ sched8) {
         slot = tid >> 3; r = tid & 7;
         sb = sp = sc0 = sc1 = sc2 = 0ull;
+        unsigned mm = 0;
 #pragma unroll
         for (int l = 0; l < D_NLEV; l++) {
             const unsigned w = tid < 64 ? sched8[tid * D_NLEV + l] : 0u;
@@ -271,7 +273,9 @@ struct Lane8 {
             sc0 |= (unsigned long long)((act && k0 != 31u) ? k0 : 24u) << (5 * l);
             sc1 |= (unsigned long long)((act && k1 != 31u) ? k1 : 24u) << (5 * l);
             sc2 |= (unsigned long long)((act && k2 != 31u) ? k2 : 24u) << (5 * l);
+            if (__ballot(act && k1 != 31u) != 0ull) mm |= 1u << l;
         }
+        multi = mm;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const int kx = k < 4 ? k : 11 - k;
@@ -398,7 +402,8 @@ __device__ __forceinline__ void aba_solve(EnvLds& s, const Params& P, const Lane
         if (lev >= lev_clean) {                                    // lev_clean >= 1: the root level is never clean
             const float rmask = rowok ? 1.f : 0.f;
             const int rc = rowok ? r : 5, pr = 6 * 24;
-            float pA = (s.pAa[rowok ? 6 * c0 + r : pr] + s.pAa[rowok ? 6 * c1 + r : pr]) + s.pAa[rowok ? 6 * c2 + r : pr];
+            float pA = s.pAa[rowok ? 6 * c0 + r : pr];
+            if ((L.multi >> lev) & 1u) pA += s.pAa[rowok ? 6 * c1 + r : pr] + s.pAa[rowok ? 6 * c2 + r : pr];
             const int d0 = 6 + 3 * (b == 0 ? 0 : b - 1);
             float uo[3];
 #pragma unroll
@@ -421,11 +426,17 @@ __device__ __forceinline__ void aba_solve(EnvLds& s, const Params& P, const Lane
         float pA;
         {
             const float* ci = s.cinert + 10 * b;
-            const float* r0 = s.IAa + 22 * c0; const float* r1 = s.IAa + 22 * c1; const float* r2 = s.IAa + 22 * c2;
-#pragma unroll
-            for (int k = 0; k < 8; k++) IAx[k] = (L.cisgn[k] * ci[L.ciidx[k]] + r0[L.idx21[k]]) + (r1[L.idx21[k]] + r2[L.idx21[k]]);
+            const float* r0 = s.IAa + 22 * c0;
             const int pr = rowok ? r : 6 * 24;                 // padding rows read the zero record
-            pA = (s.pAa[rowok ? 6 * c0 + r : pr] + s.pAa[rowok ? 6 * c1 + r : pr]) + s.pAa[rowok ? 6 * c2 + r : pr];
+#pragma unroll
+            for (int k = 0; k < 8; k++) IAx[k] = L.cisgn[k] * ci[L.ciidx[k]] + r0[L.idx21[k]];
+            pA = s.pAa[rowok ? 6 * c0 + r : pr];
+            if ((L.multi >> lev) & 1u) {                       // second / third child: only the levels where some body branches
+                const float* r1 = s.IAa + 22 * c1; const float* r2 = s.IAa + 22 * c2;
+#pragma unroll
+                for (int k = 0; k < 8; k++) IAx[k] += r1[L.idx21[k]] + r2[L.idx21[k]];
+                pA += s.pAa[rowok ? 6 * c1 + r : pr] + s.pAa[rowok ? 6 * c2 + r : pr];
+            }
         }
         if (contact_inertia && active && s.con_start[b + 1] > s.con_start[b]) {
             const V3 o = ld3(s.xpos);
@@ -485,7 +496,8 @@ __device__ __forceinline__ void aba_resolve(EnvLds& s, const Lane8& L, const flo
         const bool active = bq != 31;
         const int b = active ? bq : 0;
         const int pr = 6 * 24;
-        float pA = (s.pAa[rowok ? 6 * c0 + r : pr] + s.pAa[rowok ? 6 * c1 + r : pr]) + s.pAa[rowok ? 6 * c2 + r : pr];
+        float pA = s.pAa[rowok ? 6 * c0 + r : pr];
+        if ((L.multi >> lev) & 1u) pA += s.pAa[rowok ? 6 * c1 + r : pr] + s.pAa[rowok ? 6 * c2 + r : pr];
         if (wrench) pA -= rmask * wrench[6 * b + rc];
         const int nrounds = lev == 0 ? 2 : 1;
         for (int rd = 0; rd < nrounds; rd++) {
