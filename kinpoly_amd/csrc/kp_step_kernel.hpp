@@ -307,8 +307,7 @@ __device__ __forceinline__ void aba_elim3(EnvLds& s, const Lane8& L, const float
 #pragma unroll
     for (int j = 0; j < 3; j++) {
         const int d = d0 + j;
-#pragma unroll
-        for (int k = 0; k < 8; k++) sxa[j][k] = s.cdof[6 * d + min(L.col[k], 5)];   // padding needs no mask: its IA entries and U are exact zeros
+        gather8(rowok ? s.cdof[6 * d + r] : 0.f, sxa[j]);    // lane r fetches its own component, the 8-lane all-gather lands in XOR order
         dsc[j] = s.arm[d] + s.extra[d];
         rh[j] = rhs[d];
     }
