@@ -56,9 +56,9 @@ struct __attribute__((aligned(16))) EnvLds {
     float IAa[25 * 22], pAa[25 * 6];      // articulated inertia / bias force handed to the parent; slot 21 of a record and
                                           // record 24 are kept 0 so that padded / absent operands load a zero without exec masking
     float arm[76];                        // dof armature
-    float bias[76], smooth[76], qacc_s[76], qacc[76], grad[76], search[76], Mv[76], mres[76], x[76], extra[76];
-    float ctrl[72];
-    float applied[8];
+    float fb[144];                        // bias wrench of every body (gyroscopic + Coriolis + gravity), about o: enters the ABA passes as pA
+    float qacc_s[76], qacc[76], grad[76], search[76], Mv[76], mres[76], x[76], extra[76];
+    float applied_pad[2], applied[6], ctrl[72];   // applied ++ ctrl is qfrc_applied + qfrc_actuator as one 76-vector
     float con_pos[D_MAXCON * 3], con_dist[D_MAXCON], con_D[D_MAXCON];
     int con_body[D_MAXCON];
     int con_start[D_NB + 3];              // contacts are grouped by the entity carrying the vertex: 24 hulls, then the object slots

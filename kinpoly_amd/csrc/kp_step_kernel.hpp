@@ -121,8 +121,8 @@ __device__ __forceinline__ V3 frame_world(const Frame& f, V3 c) { return c.x * f
 //      body (parallel) the local rotation qz qy qx and the second / third hinge axis in the parent frame;
 //   K. level-synchronous chain (lane = body): world pose, motion axes cdof, spatial velocity cvel and the
 //      velocity-product acceleration cacc (mj_kinematics + mj_comVel + the forward half of mj_rne);
-//   B. body-parallel (24 lanes at once): COM, world inertia about o, body wrench I a + v x* I v; then subtree
-//      sums and projection on the dofs (backward half of mj_rne) -> qfrc_bias.
+//   B. body-parallel (24 lanes at once): COM, world inertia about o, body wrench fb = I a + v x* I v.  qfrc_bias itself
+//      (backward half of mj_rne: subtree sums + projection on the dofs) is never formed: the solves take fb as bias force.
 template <int NT>
 __device__ __forceinline__ void forward_kin_bias(EnvLds& s, const DevTables& T, const Params& P, int depth, V3 bpos, int tid) {
     float* sc = s.U;              // scratch (free outside the ABA passes): [0, 138) half-angle sin/cos, [144, 384) per-body joint frames
@@ -219,18 +219,8 @@ __device__ __forceinline__ void forward_kin_bias(EnvLds& s, const DevTables& T, 
         ci[3] = W[1] - mass * rr.x * rr.y; ci[4] = W[2] - mass * rr.x * rr.z; ci[5] = W[5] - mass * rr.y * rr.z;
         ci[6] = mass * rr.x; ci[7] = mass * rr.y; ci[8] = mass * rr.z; ci[9] = mass;
         const S6 f = inert_mul(ci, ca) + cross_force(cv, inert_mul(ci, cv));
-        sts6(s.sw + 6 * b, f);
-    }
-    KP_SYNC();
-    // subtree sums of the body wrenches -> sa (cacc no longer needed), then project on the dofs
-    for (int it = tid; it < D_NB * 6; it += NT) {
-        int b = it / 6, c = it - 6 * b, n = s.bsub[b];
-        float acc = 0.f;
-        for (int k = b; k < b + n; k++) acc += s.sw[6 * k + c];
-        s.sa[it] = acc;
-    }
-    KP_SYNC();
-    for (int d = tid; d < D_NV; d += NT) s.bias[d] = dot6(lds6(s.cdof + 6 * d), lds6(s.sa + 6 * s.dbody[d]));
+        sts6(s.fb + 6 * b, f);         // stays a body wrench: the articulated-body passes fold it into their bias force,
+    }                                  // which is the backward half of mj_rne (subtree sums + projection) done for free
     KP_SYNC();
 }
 
@@ -389,7 +379,7 @@ __device__ __forceinline__ void aba_forward(EnvLds& s, const Lane8& L, float* ou
 template <int NT, bool OBJ>
 // lev_clean: tree levels >= lev_clean carry no active contact row and no active joint limit, so their articulated inertias, U and
 // 1/D are the ones the smooth solve (same M, no extra armature) left in LDS this substep: only the bias-force half runs there.
-__device__ __forceinline__ void aba_solve(EnvLds& s, const Params& P, const Lane8& L, const float* rhs, float* out, bool contact_inertia, int tid, int lev_clean = D_NLEV) {
+__device__ __forceinline__ void aba_solve(EnvLds& s, const Params& P, const Lane8& L, const float* rhs, float* out, bool contact_inertia, int tid, int lev_clean = D_NLEV, const float* bwrench = nullptr) {
     const int r = L.r;
     const bool rowok = r < 6;
 #pragma nounroll
@@ -436,6 +426,7 @@ __device__ __forceinline__ void aba_solve(EnvLds& s, const Params& P, const Lane
                 for (int k = 0; k < 8; k++) IAx[k] += r1[L.idx21[k]] + r2[L.idx21[k]];
                 pA += s.pAa[rowok ? 6 * c1 + r : pr] + s.pAa[rowok ? 6 * c2 + r : pr];
             }
+            if (bwrench) pA += (rowok ? 1.f : 0.f) * bwrench[6 * b + (rowok ? r : 5)];
         }
         if (contact_inertia && active && s.con_start[b + 1] > s.con_start[b]) {
             const V3 o = ld3(s.xpos);
@@ -536,10 +527,10 @@ __device__ __forceinline__ void spd_torque_rfc(EnvLds& s, const DevTables& T, co
         }
         s.extra[i] = kd * P.h;                      // (M + K_d dt): K_d dt is extra joint armature
         s.search[i] = ep;
-        s.x[i] = -s.bias[i] - kp * ep - kd * s.qvel[i];
+        s.x[i] = -kp * ep - kd * s.qvel[i];
     }
     KP_SYNC();
-    aba_solve<NT, OBJ>(s, P, L8, s.x, s.x, false, tid);
+    aba_solve<NT, OBJ>(s, P, L8, s.x, s.x, false, tid, D_NLEV, s.fb);
     for (int j = tid; j < D_NU; j += NT) {
         int i = j + 6;
         float tq = -T.kp[j] * s.search[i] - T.kd[j] * (s.qvel[i] + s.x[i] * P.h);
@@ -1548,7 +1539,7 @@ __device__ __forceinline__ void step_body(StepArgs A) {
         s.arm[i] = T.dof_armature[i]; s.dbody[i] = T.dof_body[i]; s.extra[i] = 0.f; s.qacc[i] = A.warm[(size_t)env * D_NV + i];
     }
     if (tid < D_NB) { s.bpar[tid] = (unsigned char)(T.body_parent[tid] < 0 ? 0 : T.body_parent[tid]); s.bsub[tid] = T.body_subtree[tid]; s.bdep[tid] = T.body_depth[tid]; }
-    if (tid < 8) s.applied[tid] = 0.f;
+    if (tid < 6) s.applied[tid] = 0.f;
     if (tid < 25) s.IAa[22 * tid + 21] = 0.f;
     if (tid < 22) s.IAa[22 * 24 + tid] = 0.f;
     if (tid < 6) s.pAa[6 * 24 + tid] = 0.f;
@@ -1609,12 +1600,9 @@ __device__ __forceinline__ void step_body(StepArgs A) {
         make_constraint<NT, OBJ>(s, T, P, tid);                 // needs sv = cvel: before any aba_solve
         KP_T(3)
         if (!P.stale) spd_torque_rfc<NT, OBJ>(s, T, P, L8, depth, tid);
-        for (int i = tid; i < D_NV; i += NT) {
-            float f = -s.bias[i] + (i < 6 ? s.applied[i] : s.ctrl[i - 6]);
-            s.smooth[i] = f; s.extra[i] = 0.f;
-        }
+        for (int i = tid; i < D_NV; i += NT) s.extra[i] = 0.f;
         KP_SYNC();
-        aba_solve<NT, OBJ>(s, P, L8, s.smooth, s.qacc_s, false, tid);   // qacc_smooth = M^-1 qfrc_smooth; sv = its spatial accel
+        aba_solve<NT, OBJ>(s, P, L8, s.applied, s.qacc_s, false, tid, D_NLEV, s.fb);   // qacc_smooth = M^-1 qfrc_smooth; sv = its spatial accel
         KP_T(4)
         if constexpr (OBJ) niter_total += solve_constraints_obj<NT>(s, P, L8, depth, tid, nfact_total);
         else niter_total += solve_constraints<NT, OBJ>(s, P, L8, depth, tid, nfact_total);
