@@ -50,12 +50,15 @@ def build_engine(device_index, seed, threads):
 def rollout_steps(sampler, k):
     """k batched env-steps without keeping the experience (identical work to VectorSampler.sample's loop body)."""
     env, pol = sampler.env, sampler.policy
+    n_done = torch.zeros((), dtype=torch.int64, device=env.device)
     with torch.no_grad():
         for _ in range(k):
             action, sampler.hx = pol.select_action(sampler.obs, sampler.hx, False, env.gen)
             _, _, done, info = env.step(action.contiguous())
+            n_done += done.sum()
             sampler.obs = env.reset(done).clone()
             sampler.hx = sampler.hx * (~done).float().unsqueeze(1)
+    return n_done
 
 
 def cpu_baseline(std, seconds_budget=15.0):
@@ -144,7 +147,7 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
-    rollout_steps(sampler, args.steps)
+    n_done = rollout_steps(sampler, args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -162,16 +165,10 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-        # what actually bounds the kernel: VALU issue.  Instruction count per launch from the committed PMC pass, live launch time
+        # what actually bounds the kernel: VALU issue.  Counts and kernel duration both from the committed PMC pass (tools/pmc_step.py workload)
         valu = None
-        pv = os.path.join(ROOT, "profiles", "r01_v6", "pmc_SQ_INSTS_VALU+SQ_INSTS_SALU+SQ_INSTS_LDS.json")
-        if os.path.exists(pmc) and os.path.exists(pv):
-            d = json.load(open(pv))
-            k = [x for x in d if "kp_step_kernel" in x]
-            if k:
-                insts = d[k[0]]["SQ_INSTS_VALU"]["median"]           # wave-level VALU instructions per launch (4096 envs, tools/pmc_step.py)
-                valu = {"valu_insts_per_launch": insts, "cycles_per_wave64_op": 4, "simds": 1024, "shader_clock_ghz": 2.38,
-                        "valu_busy_frac": insts * 4 / (1024 * kern_s * 2.38e9), "source": "instruction count: profiles/r01_v6 PMC pass on the standing-contact workload (tools/pmc_step.py); clock: profiles/r01_v4/clock_probe.log"}
+        if os.path.exists(pmc):
+            valu = json.load(open(pmc)).get("issue")
         out = {
             "metric": "env-steps/sec (whole node) at 4096 envs/GPU, 69-DoF SMPL", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -187,6 +184,9 @@ def main():
                          "valu": valu},
             "kernel_share_of_step": kern_s / (elapsed / args.steps),
             "contacts_mean": float(diag[:, 0].mean()), "newton_iters_per_substep": float(diag[:, 1].mean() / 15.0), "hessian_factorisations_per_substep": float((diag[:, 3] >> 8).mean() / 15.0), "bad_envs": int((diag[:, 2] != 0).sum()),
+            # random-init networks put the kinematic target far from the humanoid, so (as in the reference with untrained weights) the
+            # body-diff termination (humanoid_ar_v1.py:303-309) fires on almost every step: each timed step includes the device-side reset
+            "episodes_ended_per_step_frac": float(n_done.item()) / (ENVS_PER_GPU * args.steps),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(std)

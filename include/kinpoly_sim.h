@@ -161,6 +161,11 @@ int kp_sim_get(kp_sim*, int field, float* out);
  * synchronises the stream. */
 int kp_sim_diag(kp_sim*, int32_t* out_host);
 
+/* shader-clock cycles >> 10 every env took inside the last kp_sim_step_ctrl launch, uint32 [N], HOST pointer; synchronises.
+ * With model option "lpt_order" = 1 (default 0) the next launch starts the envs longest-first from these (workgroup order
+ * only: results do not depend on it; measured gain is within noise because an env's cost correlates only 0.6 step to step). */
+int kp_sim_launch_cost(kp_sim*, uint32_t* out_host);
+
 /* seconds the last kp_sim_step_ctrl launch took, measured with HIP events on the sim's stream
  * (synchronises); -1 if none recorded. */
 double kp_sim_last_step_seconds(kp_sim*);

@@ -23,7 +23,7 @@ int fail(const std::string& m) { g_err = m; return -1; }
 
 struct kp_model {
     kp::HostModel h;
-    int contact = 1, limits = 1, stale = 1, solver_iter = 12, threads = 64, dynamic_objects = 1;
+    int contact = 1, limits = 1, stale = 1, solver_iter = 12, threads = 64, dynamic_objects = 1, lpt_order = 0;
     double solver_tol = 1e-8, gravity_z = -9.81;   // solver_tol: mjOption.tolerance of the reference model (kp_model_load)
 };
 
@@ -39,6 +39,7 @@ struct kp_sim {
     float *prev_bquat = nullptr, *prev_hpos = nullptr, *diffw = nullptr;
     float *t_qpos = nullptr, *t_wbpos = nullptr, *t_wbquat = nullptr, *t_bquat = nullptr, *t_com = nullptr;
     int* diag = nullptr;
+    int* order = nullptr; unsigned* cost = nullptr;   // launch order of the control-step kernel (k_lpt_order)
     unsigned long long* prof = nullptr;
     float *obj_qpos = nullptr, *geoms = nullptr;      // [N,35], [N,8,17]
     float *obj_qvel = nullptr, *obj_warm = nullptr;   // [N,30], [N,12]
@@ -170,6 +171,11 @@ int launch_step(kp_sim* s, const float* action, int nsub, const uint8_t* mask, b
     A.xpos = s->xpos; A.xquat = s->xquat; A.xipos = s->xipos; A.diag = s->diag; A.prof = s->prof;
     A.geoms = s->geoms; A.ngeom = s->ngeom;
     A.obj_slot = s->obj_slot; A.obj_qpos = s->obj_qpos; A.obj_qvel = s->obj_qvel; A.obj_warm = s->obj_warm;
+    A.order = nullptr; A.cost = s->cost;
+    if (nsub > 0 && s->model->lpt_order) {      // longest env first: order the workgroups by the cycles of the previous control step
+        hipLaunchKernelGGL(kp::k_lpt_order, dim3(1), dim3(1024), 0, s->stream, s->n, s->cost, s->order);
+        A.order = s->order;
+    }
     const bool obj = s->has_objects;
     if (obj && s->model->threads != 64) return fail("object contact needs threads_per_env = 64");
     size_t lds = obj ? sizeof(kp::EnvLdsObj) : sizeof(kp::EnvLds);
@@ -231,6 +237,7 @@ int kp_model_set_option(kp_model* m, const char* name, double v) {
     else if (k == "solver_iter") m->solver_iter = (int)v;
     else if (k == "solver_tol") m->solver_tol = v;
     else if (k == "dynamic_objects") m->dynamic_objects = v != 0;
+    else if (k == "lpt_order") m->lpt_order = v != 0;
     else if (k == "threads_per_env") { if (v != 64 && v != 128 && v != 256) return fail("threads_per_env must be 64, 128 or 256"); m->threads = (int)v; }
     else return fail("kp_model_set_option: unknown option " + k);
     return 0;
@@ -245,6 +252,7 @@ double kp_model_get_option(const kp_model* m, const char* name) {
     if (k == "solver_iter") return m->solver_iter;
     if (k == "solver_tol") return m->solver_tol;
     if (k == "dynamic_objects") return m->dynamic_objects;
+    if (k == "lpt_order") return m->lpt_order;
     if (k == "threads_per_env") return m->threads;
     if (k == "timestep") return m->h.opt[kp::OPT_TIMESTEP];
     if (k == "lds_bytes_per_env") return (double)sizeof(kp::EnvLds);
@@ -269,6 +277,7 @@ kp_sim* kp_sim_create(const kp_model* m, int n_envs, int device_id, void* stream
     s->scratch = dalloc(s, N * 96, &ok);
     s->prev_bquat = dalloc(s, N * 96, &ok); s->prev_hpos = dalloc(s, N * 7, &ok);
     s->diag = (int*)dalloc(s, N * 4, &ok);
+    s->order = (int*)dalloc(s, N, &ok); s->cost = (unsigned*)dalloc(s, N, &ok);
     s->obj_qpos = dalloc(s, N * 35, &ok); s->geoms = dalloc(s, N * kp::D_MAXGEOM * 17, &ok); s->ngeom = (int*)dalloc(s, N, &ok);
     s->obj_qvel = dalloc(s, N * 30, &ok); s->obj_warm = dalloc(s, N * 6 * kp::D_MAXOBJ, &ok); s->obj_slot = (signed char*)dalloc(s, (N * kp::D_MAXOBJ + 3) / 4 + 1, &ok);
     if (!m->h.obj_geoms.empty()) {
@@ -548,6 +557,14 @@ int kp_sim_diag(kp_sim* s, int32_t* out_host) {
     HIP_OK(hipSetDevice(s->device));
     HIP_OK(hipStreamSynchronize(s->stream));
     HIP_OK(hipMemcpy(out_host, s->diag, sizeof(int) * 4 * (size_t)s->n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int kp_sim_launch_cost(kp_sim* s, uint32_t* out_host) {
+    if (!s || !out_host) return fail("kp_sim_launch_cost: null argument");
+    HIP_OK(hipSetDevice(s->device));
+    HIP_OK(hipStreamSynchronize(s->stream));
+    HIP_OK(hipMemcpy(out_host, s->cost, sizeof(unsigned) * (size_t)s->n, hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -45,6 +45,10 @@ struct StepArgs {
     // OBJ kernels, dynamic free objects: slot -> object index of the scene (-1 = empty), free-joint state of all objects
     const signed char* obj_slot;   // [N, D_MAXOBJ]
     float *obj_qpos, *obj_qvel, *obj_warm;   // [N, 35], [N, 30], [N, 6 * D_MAXOBJ]
+    // launch order (longest-processing-time first): workgroup i simulates env order[i]; cost[env] = shader-clock cycles >> 10 this
+    // launch spent on env.  Both optional.  The result of an env does not depend on the workgroup that computes it.
+    const int* order;
+    unsigned* cost;
 };
 
 // wave-wide sum without LDS traffic: xor butterflies inside each 16-lane row with DPP (quad_perm, row_half_mirror,
@@ -1523,9 +1527,11 @@ __device__ __forceinline__ void step_body(StepArgs A) {
     if (FWD) A.n_substeps = 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     typename std::conditional<OBJ, EnvLdsObj, EnvLds>::type& s = *reinterpret_cast<typename std::conditional<OBJ, EnvLdsObj, EnvLds>::type*>(smem_raw);
-    const int env = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
+    const int env = A.order && !FWD ? A.order[blockIdx.x] : (int)blockIdx.x;
     if (env >= A.n_envs) return;
     if (A.env_mask && !A.env_mask[env]) return;
+    const unsigned long long t_launch = __builtin_readcyclecounter();
     const DevTables& T = A.T;
     const Params& P = A.P;
     const int depth = tid < D_NB ? T.body_depth[tid] : -1;
@@ -1658,6 +1664,28 @@ __device__ __forceinline__ void step_body(StepArgs A) {
     if (bad) atomicOr(&s.flag, 1);
     KP_SYNC();
     if (tid == 0 && A.diag && A.n_substeps > 0) { int* dg = A.diag + 4 * (size_t)env; dg[0] = s.ncon; dg[1] = niter_total; dg[2] = s.flag; dg[3] = maxcon | (nfact_total << 8); }
+    if (tid == 0 && A.cost && A.n_substeps > 0) A.cost[env] = (unsigned)((__builtin_readcyclecounter() - t_launch) >> 10);
+}
+
+// Launch order for the next control step: envs sorted by the cycles they took in the last one, longest first (counting sort on
+// 256 bins scaled to the maximum, one workgroup).  With N envs on 8 x 256 wave slots the launch otherwise ends on whichever
+// long env (many contacts, many Newton iterations) happened to start in the second round.
+__global__ __launch_bounds__(1024) void k_lpt_order(int n, const unsigned* __restrict__ cost, int* __restrict__ order) {
+    __shared__ unsigned hist[256], base[256], cmax;
+    const int tid = threadIdx.x;
+    if (tid < 256) hist[tid] = 0;
+    if (tid == 0) cmax = 1;
+    __syncthreads();
+    unsigned m = 0;
+    for (int i = tid; i < n; i += 1024) m = max(m, cost[i]);
+    atomicMax(&cmax, m);
+    __syncthreads();
+    const float sc = 255.f / (float)cmax;
+    for (int i = tid; i < n; i += 1024) atomicAdd(&hist[255 - (int)((float)cost[i] * sc)], 1u);
+    __syncthreads();
+    if (tid == 0) { unsigned a = 0; for (int b = 0; b < 256; b++) { base[b] = a; a += hist[b]; } }
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) order[atomicAdd(&base[255 - (int)((float)cost[i] * sc)], 1u)] = i;
 }
 
 template <int NT, bool OBJ>

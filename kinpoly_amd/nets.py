@@ -32,8 +32,10 @@ class MLP(nn.Module):
             last = nh
 
     def forward(self, x):
+        fused = self.activation is torch.relu and x.is_cuda and x.dim() == 2 and not torch.is_grad_enabled()
         for affine in self.affine_layers:
-            x = self.activation(affine(x))
+            # rollout path: bias + relu in the GEMM epilogue (hipBLASLt) instead of a separate pass over the activations
+            x = torch._addmm_activation(affine.bias, x, affine.weight.t()) if fused else self.activation(affine(x))
         return x
 
 
@@ -86,7 +88,7 @@ class PolicyMCP(nn.Module):
         else:
             w1, b1, w2, b2, w3, b3 = self._fuse()
             K = self.num_primitive
-            h = torch.relu(torch.addmm(b1, x, w1.t()))                   # [N, K*h1]
+            h = torch._addmm_activation(b1, x, w1.t())                   # [N, K*h1], relu in the GEMM epilogue
             h = h.view(x.shape[0], K, -1).transpose(0, 1)                # [K, N, h1]
             h = torch.relu(torch.baddbmm(b2.unsqueeze(1), h, w2))        # [K, N, h2]
             x_all = torch.baddbmm(b3.unsqueeze(1), h, w3).transpose(0, 1)  # [N, K, A]

@@ -31,6 +31,7 @@ ABI_SYMBOLS = [
     "kp_field_dim", "kp_sim_get", "kp_sim_diag", "kp_sim_last_step_seconds", "kp_last_error", "kp_version",
     "kp_sim_step_begin", "kp_sim_obs_ar", "kp_sim_term_reward", "kp_gae", "kp_sim_set_full_state", "kp_sim_fk",
     "kp_sim_timing_reset", "kp_sim_timing_mean_seconds", "kp_sim_phase_cycles", "kp_sim_set_objects", "kp_sim_set_obj_state",
+    "kp_sim_launch_cost",
 ]
 
 
@@ -90,6 +91,7 @@ def load_library(path: str | None = None):
     L.kp_sim_timing_reset.argtypes = [P]; L.kp_sim_timing_reset.restype = C.c_int
     L.kp_sim_timing_mean_seconds.argtypes = [P, C.POINTER(C.c_int)]; L.kp_sim_timing_mean_seconds.restype = C.c_double
     L.kp_sim_phase_cycles.argtypes = [P, C.POINTER(C.c_double)]; L.kp_sim_phase_cycles.restype = C.c_int
+    L.kp_sim_launch_cost.argtypes = [P, C.c_void_p]; L.kp_sim_launch_cost.restype = C.c_int
     L.kp_sim_set_objects.argtypes = [P, F, U8]; L.kp_sim_set_objects.restype = C.c_int
     L.kp_sim_set_obj_state.argtypes = [P, F, F, U8]; L.kp_sim_set_obj_state.restype = C.c_int
     L.kp_sim_fk.argtypes = [P, C.c_int, F, F, F, F, F, F]; L.kp_sim_fk.restype = C.c_int
@@ -263,6 +265,13 @@ class KpSim:
         out = (C.c_double * 8)()
         _check(self.L.kp_sim_phase_cycles(self.h, out), "kp_sim_phase_cycles")
         return dict(zip(("spd", "kin_bias", "collide", "constraint", "smooth", "contact", "integrate", "total"), list(out)))
+
+    def launch_cost(self):
+        """shader-clock cycles every env took in the last control-step launch (numpy uint64 [N])."""
+        import numpy as np
+        out = np.zeros(self.n, np.uint32)
+        _check(self.L.kp_sim_launch_cost(self.h, out.ctypes.data_as(C.c_void_p)), "kp_sim_launch_cost")
+        return out.astype(np.uint64) << 10
 
     def last_step_seconds(self) -> float:
         return self.L.kp_sim_last_step_seconds(self.h)

@@ -179,6 +179,25 @@ def test_contact_invariants_4096(kp):
     assert q[:, 2].min() > 0.6                                  # PD-held standing poses have not collapsed after 1/3 s
 
 
+def test_launch_order_does_not_change_results(kp):
+    """Model option lpt_order (workgroup i simulates env order[i], longest env of the previous launch first) is a schedule,
+    not arithmetic: states are bit-identical with it on and off; kp_sim_launch_cost reports non-zero cycles for every env."""
+    n = 1000                                                    # not a multiple of anything in the launch geometry
+    qpos, qvel = make_states(n, 21, lift=0.0, vel=0.5, noise=0.2)
+    act = np.random.default_rng(22).normal(size=(n, 75)) * 0.2
+    res = []
+    for lpt in (0, 1):
+        sim = kp.KpSim(kp.KpModel(lpt_order=lpt), n)
+        sim.set_state(dev(qpos), dev(qvel)); sim.set_target(dev(np.tile(STD["qpos"], (n, 1))))
+        a = dev(act)
+        for _ in range(4):
+            sim.step_ctrl(a, 15)
+        cost = sim.launch_cost()
+        assert cost.shape == (n,) and cost.min() > 100_000 and cost.max() < 100_000_000
+        res.append((sim.get("qpos").cpu().numpy(), sim.get("qvel").cpu().numpy(), sim.diag()))
+    assert (res[0][0] == res[1][0]).all() and (res[0][1] == res[1][1]).all() and (res[0][2] == res[1][2]).all()
+
+
 def test_target_fk_matches_golden(kp, golden):
     g = golden("fk")
     n = len(g["qpos_in"])
