@@ -9,7 +9,7 @@ per GPU: kinematic policy (GRU+MLP) -> step_ar -> target
 termination + reward -> AR obs (105) -> device-side auto-reset.  Inputs are synthetic and resident in HBM
 before the timed region (standing clip contexts, seeded random-init networks).
 
-Prints ONE JSON line on rank 0 (see the task contract) with `roofline` (dominant kernel kp_step_kernel,
+Prints ONE JSON line on rank 0 (see the task contract) with `roofline` (dominant kernel kp_step_queue_kernel = kp_step_kernel scheduled as jobs,
 live HIP-event launch durations) and, at N = 1, `cpu_baseline` (the fp64 oracle port on 1 host core).
 """
 import argparse
@@ -37,7 +37,7 @@ def build_engine(device_index, seed, threads):
     from kinpoly_amd.rollout import VectorSampler
     torch.manual_seed(seed)
     std = np.load(os.path.join(ROOT, "tests", "golden", "standing_neutral.npz"))
-    env = BatchedHumanoidAREnv(ENVS_PER_GPU, device_index, mode="train", seed=seed, model_options={"threads_per_env": threads})
+    env = BatchedHumanoidAREnv(ENVS_PER_GPU, device_index, mode="train", seed=seed, model_options={"threads_per_env": threads, **({"substeps_per_job": int(os.environ["KP_SUBSTEPS_PER_JOB"])} if "KP_SUBSTEPS_PER_JOB" in os.environ else {})})
     policy = KinPolicy().to(env.device).float()
     g = torch.Generator().manual_seed(seed)
     headings = (torch.rand(ENVS_PER_GPU, generator=g) * 2 - 1) * np.pi
@@ -156,6 +156,7 @@ def main():
         elapsed = float(t.item())
     kern_s, n_launch = env.sim.timing_mean_seconds()
     diag = env.sim.diag()
+    cost = env.sim.launch_cost().astype(np.float64)
 
     if rank == 0:
         value = ENVS_PER_GPU * world * args.steps / elapsed
@@ -178,7 +179,7 @@ def main():
                                    "random-init seeded networks", "envs_per_gpu": ENVS_PER_GPU, "substeps": 15, "clip_len": CLIP_LEN,
                        "threads_per_env": args.threads_per_env, "parallelism": f"env-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "kp_step_kernel", "launch_ms": kern_s * 1e3, "launches_timed": n_launch,
+                         "traffic": traffic, "kernel": "kp_step_queue_kernel" if int(env.model.get_option("substeps_per_job")) > 0 else "kp_step_kernel", "launch_ms": kern_s * 1e3, "launches_timed": n_launch,
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "note": "latency/VALU-bound tree recursion with state resident in LDS: compulsory HBM traffic is tiny by construction (DESIGN.md)",
                          "valu": valu},
@@ -187,6 +188,10 @@ def main():
             # random-init networks put the kinematic target far from the humanoid, so (as in the reference with untrained weights) the
             # body-diff termination (humanoid_ar_v1.py:303-309) fires on almost every step: each timed step includes the device-side reset
             "episodes_ended_per_step_frac": float(n_done.item()) / (ENVS_PER_GPU * args.steps),
+            # per-env shader-clock cycles of the last launch (kp_sim_launch_cost): what the launch would take if its waves were perfectly
+            # packed on the 2048 resident slots vs its longest env
+            "launch_balance": {"substeps_per_job": int(env.model.get_option("substeps_per_job")), "sum_env_cycles_over_2048_slots_ms": float(cost.sum() / 2048 / 2.38e6),
+                               "longest_env_ms": float(cost.max() / 2.38e6), "median_env_ms": float(np.median(cost) / 2.38e6)},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(std)

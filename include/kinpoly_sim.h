@@ -43,7 +43,11 @@ kp_model* kp_model_load(const char* kpm_path);
 void kp_model_free(kp_model*);
 /* options: "contact" (0/1), "limits" (0/1), "gravity_z", "stale_kinematics" (0/1, default 1: SPD and
  * read-outs see the one-substep-stale derived quantities mujoco-py exposes), "solver_iter",
- * "solver_tol", "threads_per_env" (64/128/256). */
+ * "solver_tol", "threads_per_env" (64/128/256), "dynamic_objects" (0/1);
+ * scheduling only (results do not depend on them): "substeps_per_job" (default 3; 0 = one workgroup per env and control step):
+ * with more envs than resident wavefront slots a control step is cut into jobs of that many substeps which resident waves pull from
+ * a FIFO, so that the launch does not end on the tail of its longest envs; "queue_slots" (0 = CUs x 8, x 6 with objects);
+ * "lpt_order" (0/1, default 0: longest-env-first workgroup order for the plain launch). */
 int kp_model_set_option(kp_model*, const char* name, double value);
 double kp_model_get_option(const kp_model*, const char* name);
 
@@ -158,7 +162,7 @@ int kp_sim_get(kp_sim*, int field, float* out);
 
 /* per-env diagnostics of the last kp_sim_step_ctrl: int32 [N,4] = {contacts in last substep,
  * Newton iterations (sum over substeps), flags (1 = non-finite state), max contacts | Hessian factorisations << 8}.  HOST pointer;
- * synchronises the stream. */
+ * synchronises the stream.  Fails if the job queue of the last launch stalled (never observed; see kp_step_queue_kernel). */
 int kp_sim_diag(kp_sim*, int32_t* out_host);
 
 /* shader-clock cycles >> 10 every env took inside the last kp_sim_step_ctrl launch, uint32 [N], HOST pointer; synchronises.

@@ -23,7 +23,7 @@ int fail(const std::string& m) { g_err = m; return -1; }
 
 struct kp_model {
     kp::HostModel h;
-    int contact = 1, limits = 1, stale = 1, solver_iter = 12, threads = 64, dynamic_objects = 1, lpt_order = 0;
+    int contact = 1, limits = 1, stale = 1, solver_iter = 12, threads = 64, dynamic_objects = 1, lpt_order = 0, substeps_per_job = 3, queue_slots = 0;
     double solver_tol = 1e-8, gravity_z = -9.81;   // solver_tol: mjOption.tolerance of the reference model (kp_model_load)
 };
 
@@ -40,6 +40,8 @@ struct kp_sim {
     float *t_qpos = nullptr, *t_wbpos = nullptr, *t_wbquat = nullptr, *t_bquat = nullptr, *t_com = nullptr;
     int* diag = nullptr;
     int* order = nullptr; unsigned* cost = nullptr;   // launch order of the control-step kernel (k_lpt_order)
+    unsigned *jobq = nullptr, *jobctr = nullptr;      // job FIFO of kp_step_queue_kernel
+    int jobq_cap = 0, wave_slots = 2048;
     unsigned long long* prof = nullptr;
     float *obj_qpos = nullptr, *geoms = nullptr;      // [N,35], [N,8,17]
     float *obj_qvel = nullptr, *obj_warm = nullptr;   // [N,30], [N,12]
@@ -180,6 +182,10 @@ int launch_step(kp_sim* s, const float* action, int nsub, const uint8_t* mask, b
     if (obj && s->model->threads != 64) return fail("object contact needs threads_per_env = 64");
     size_t lds = obj ? sizeof(kp::EnvLdsObj) : sizeof(kp::EnvLds);
     hipEvent_t e0 = s->ev0, e1 = s->ev1;
+    if (time_it) {      // a launch that is being captured into a hipGraph carries no timing events (they could not be read back)
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s->stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) time_it = false;
+    }
     if (time_it && s->ring_on && s->ring_used < 4096) {
         if ((int)s->ring.size() < 2 * (s->ring_used + 1)) {
             hipEvent_t a, b;
@@ -192,6 +198,20 @@ int launch_step(kp_sim* s, const float* action, int nsub, const uint8_t* mask, b
     if (time_it) HIP_OK(hipEventRecord(e0, s->stream));
 #define KP_LAUNCH(NT_) do { if (nsub > 0) hipLaunchKernelGGL((kp::kp_step_kernel<NT_, false>), dim3(s->n), dim3(NT_), lds, s->stream, A); \
                             else hipLaunchKernelGGL((kp::kp_forward_kernel<NT_, false>), dim3(s->n), dim3(NT_), lds, s->stream, A); } while (0)
+    // more envs than resident wave slots: schedule the control step as jobs of substeps_per_job substeps pulled from a FIFO by one
+    // resident wave per slot (kp_step_queue_kernel) instead of one workgroup per env, which ends on a long tail
+    const int spj = s->model->substeps_per_job;
+    const int slots = s->model->queue_slots > 0 ? s->model->queue_slots : (obj ? s->wave_slots / 8 * 6 : s->wave_slots);
+    const int parts = spj > 0 ? (nsub + spj - 1) / spj : 1;
+    const bool queue = nsub > 0 && spj > 0 && parts > 1 && parts <= 16 && s->model->threads == 64 && s->n > slots && !s->prof && !A.order;
+    A.jobq = s->jobq; A.jobctr = s->jobctr; A.n_parts = queue ? parts : 1; A.sub_per_part = queue ? spj : nsub;
+    if (queue) {
+        const unsigned total = (unsigned)s->n * (unsigned)parts;
+        hipLaunchKernelGGL(kp::k_queue_init, dim3((total + 255) / 256), dim3(256), 0, s->stream, s->n, total, s->jobq, s->jobctr);
+        if (time_it) HIP_OK(hipEventRecord(e0, s->stream));
+        if (obj) hipLaunchKernelGGL((kp::kp_step_queue_kernel<true>), dim3(slots), dim3(64), lds, s->stream, A);
+        else hipLaunchKernelGGL((kp::kp_step_queue_kernel<false>), dim3(slots), dim3(64), lds, s->stream, A);
+    } else
     switch (s->model->threads) {
         case 64:
             if (obj && nsub > 0) hipLaunchKernelGGL((kp::kp_step_kernel<64, true>), dim3(s->n), dim3(64), lds, s->stream, A);
@@ -238,6 +258,8 @@ int kp_model_set_option(kp_model* m, const char* name, double v) {
     else if (k == "solver_tol") m->solver_tol = v;
     else if (k == "dynamic_objects") m->dynamic_objects = v != 0;
     else if (k == "lpt_order") m->lpt_order = v != 0;
+    else if (k == "queue_slots") { if (v < 0) return fail("queue_slots must be >= 0 (0 = resident wave slots of the device)"); m->queue_slots = (int)v; }
+    else if (k == "substeps_per_job") { if (v < 0 || v > 255) return fail("substeps_per_job must be 0 (whole control step per workgroup) .. 255"); m->substeps_per_job = (int)v; }
     else if (k == "threads_per_env") { if (v != 64 && v != 128 && v != 256) return fail("threads_per_env must be 64, 128 or 256"); m->threads = (int)v; }
     else return fail("kp_model_set_option: unknown option " + k);
     return 0;
@@ -253,6 +275,8 @@ double kp_model_get_option(const kp_model* m, const char* name) {
     if (k == "solver_tol") return m->solver_tol;
     if (k == "dynamic_objects") return m->dynamic_objects;
     if (k == "lpt_order") return m->lpt_order;
+    if (k == "substeps_per_job") return m->substeps_per_job;
+    if (k == "queue_slots") return m->queue_slots;
     if (k == "threads_per_env") return m->threads;
     if (k == "timestep") return m->h.opt[kp::OPT_TIMESTEP];
     if (k == "lds_bytes_per_env") return (double)sizeof(kp::EnvLds);
@@ -278,6 +302,11 @@ kp_sim* kp_sim_create(const kp_model* m, int n_envs, int device_id, void* stream
     s->prev_bquat = dalloc(s, N * 96, &ok); s->prev_hpos = dalloc(s, N * 7, &ok);
     s->diag = (int*)dalloc(s, N * 4, &ok);
     s->order = (int*)dalloc(s, N, &ok); s->cost = (unsigned*)dalloc(s, N, &ok);
+    s->jobq_cap = (int)N * 16; s->jobq = (unsigned*)dalloc(s, (size_t)s->jobq_cap, &ok); s->jobctr = (unsigned*)dalloc(s, 4, &ok);
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, s->device) == hipSuccess && prop.multiProcessorCount > 0) s->wave_slots = prop.multiProcessorCount * 8;
+    }
     s->obj_qpos = dalloc(s, N * 35, &ok); s->geoms = dalloc(s, N * kp::D_MAXGEOM * 17, &ok); s->ngeom = (int*)dalloc(s, N, &ok);
     s->obj_qvel = dalloc(s, N * 30, &ok); s->obj_warm = dalloc(s, N * 6 * kp::D_MAXOBJ, &ok); s->obj_slot = (signed char*)dalloc(s, (N * kp::D_MAXOBJ + 3) / 4 + 1, &ok);
     if (!m->h.obj_geoms.empty()) {
@@ -557,6 +586,9 @@ int kp_sim_diag(kp_sim* s, int32_t* out_host) {
     HIP_OK(hipSetDevice(s->device));
     HIP_OK(hipStreamSynchronize(s->stream));
     HIP_OK(hipMemcpy(out_host, s->diag, sizeof(int) * 4 * (size_t)s->n, hipMemcpyDeviceToHost));
+    unsigned ctr[4] = {0, 0, 0, 0};
+    HIP_OK(hipMemcpy(ctr, s->jobctr, sizeof(ctr), hipMemcpyDeviceToHost));
+    if (ctr[2]) return fail("kp_step_queue_kernel: a wavefront gave up waiting for a job to be published (job queue stalled); states are incomplete");
     return 0;
 }
 

@@ -49,6 +49,11 @@ struct StepArgs {
     // launch spent on env.  Both optional.  The result of an env does not depend on the workgroup that computes it.
     const int* order;
     unsigned* cost;
+    // job-queue launch (kp_step_queue_kernel): a control step of an env = n_parts jobs of sub_per_part substeps handed from wave to
+    // wave through HBM.  jobq [n_envs * n_parts] entries (env | part << 24, 0xFFFFFFFF = not yet published), jobctr = {head, tail, stalled}
+    unsigned* jobq;
+    unsigned* jobctr;
+    int n_parts, sub_per_part;
 };
 
 // wave-wide sum without LDS traffic: xor butterflies inside each 16-lane row with DPP (quad_perm, row_half_mirror,
@@ -523,8 +528,11 @@ __device__ __forceinline__ void spd_torque_rfc(EnvLds& s, const DevTables& T, co
         if (i >= 6) {
             int j = i - 6;
             float q = s.qpos[i + 1], base = s.tq[i + 1];
-            while (base - q > 3.14159265358979f) base -= 6.28318530717959f;
-            while (base - q < -3.14159265358979f) base += 6.28318530717959f;
+            // the reference's 2 pi unwrap loops (humanoid_im.py:447-452) in closed form: no trip count that depends on the data, so a
+            // non-finite or absurd target cannot spin the wavefront (it yields a non-finite state, which diag flags)
+            const float dq = base - q;
+            if (dq > 3.14159265358979f) base -= 6.28318530717959f * ceilf((dq - 3.14159265358979f) * 0.159154943091895f);
+            else if (dq < -3.14159265358979f) base += 6.28318530717959f * ceilf((-dq - 3.14159265358979f) * 0.159154943091895f);
             float target = base + s.act[j] * T.ascale[j];
             kp = T.kp[j]; kd = T.kd[j];
             ep = q + s.qvel[i] * P.h - target;
@@ -1522,13 +1530,26 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
 // ---------------------------------------------------------------- the kernel
 // FWD = true compiles the forward-only launch (sim.forward(): derived quantities at a new state, no substeps) as its own
 // small kernel, so that the control-step kernel's launches are the only ones under its name in a profile.
-template <int NT, bool OBJ, bool FWD>
-__device__ __forceinline__ void step_body(StepArgs A) {
+// Global accesses to state that one job of kp_step_queue_kernel writes and a later job (another wave, maybe another XCD with its own
+// L2) reads.  Relaxed agent-scope atomics are plain loads / stores with the sc1 bit: they go through to the memory side instead of
+// living in an XCD's L2, so the hand-over needs no L2 write-back / invalidate fence.  Outside the queue kernel: ordinary accesses.
+template <bool Q, typename V> __device__ __forceinline__ V gld(const V* p) {
+    if constexpr (Q) return __hip_atomic_load(const_cast<V*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
+template <bool Q, typename V> __device__ __forceinline__ void gst(V* p, V v) {
+    if constexpr (Q) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
+template <int NT, bool OBJ, bool FWD, bool Q = false>
+__device__ __forceinline__ void step_body(StepArgs A, const int env_in, const int part) {
     if (FWD) A.n_substeps = 0;
+    else if (part >= 0) A.n_substeps = min(A.sub_per_part, A.n_substeps - part * A.sub_per_part);   // this job's share of the control step
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     typename std::conditional<OBJ, EnvLdsObj, EnvLds>::type& s = *reinterpret_cast<typename std::conditional<OBJ, EnvLdsObj, EnvLds>::type*>(smem_raw);
     const int tid = threadIdx.x;
-    const int env = A.order && !FWD ? A.order[blockIdx.x] : (int)blockIdx.x;
+    const int env = env_in;
     if (env >= A.n_envs) return;
     if (A.env_mask && !A.env_mask[env]) return;
     const unsigned long long t_launch = __builtin_readcyclecounter();
@@ -1539,10 +1560,10 @@ __device__ __forceinline__ void step_body(StepArgs A) {
     const V3 bpos = tid < D_NB ? ld3(T.body_pos + 3 * tid) : v3(0.f, 0.f, 0.f);
 
     // ---- load: derived state first (the state the last forward pass ran on), then the real state
-    for (int i = tid; i < D_NQ; i += NT) { s.qpos[i] = A.qpos_d[(size_t)env * D_NQ + i]; s.tq[i] = A.target_qpos ? A.target_qpos[(size_t)env * D_NQ + i] : 0.f; }
+    for (int i = tid; i < D_NQ; i += NT) { s.qpos[i] = gld<Q>(A.qpos_d + (size_t)env * D_NQ + i); s.tq[i] = A.target_qpos ? A.target_qpos[(size_t)env * D_NQ + i] : 0.f; }
     for (int i = tid; i < D_NV; i += NT) {
-        s.qvel[i] = A.qvel_d[(size_t)env * D_NV + i]; s.act[i] = A.action ? A.action[(size_t)env * D_NV + i] : 0.f;
-        s.arm[i] = T.dof_armature[i]; s.dbody[i] = T.dof_body[i]; s.extra[i] = 0.f; s.qacc[i] = A.warm[(size_t)env * D_NV + i];
+        s.qvel[i] = gld<Q>(A.qvel_d + (size_t)env * D_NV + i); s.act[i] = A.action ? A.action[(size_t)env * D_NV + i] : 0.f;
+        s.arm[i] = T.dof_armature[i]; s.dbody[i] = T.dof_body[i]; s.extra[i] = 0.f; s.qacc[i] = gld<Q>(A.warm + (size_t)env * D_NV + i);
     }
     if (tid < D_NB) { s.bpar[tid] = (unsigned char)(T.body_parent[tid] < 0 ? 0 : T.body_parent[tid]); s.bsub[tid] = T.body_subtree[tid]; s.bdep[tid] = T.body_depth[tid]; }
     if (tid < 6) s.applied[tid] = 0.f;
@@ -1560,8 +1581,8 @@ __device__ __forceinline__ void step_body(StepArgs A) {
             const int oi = A.obj_slot ? A.obj_slot[(size_t)env * D_MAXOBJ + k] : -1;
             if (oi < 0 || oi >= T.n_obj) break;
             nobj = k + 1;
-            if (tid < 7) s.oq[7 * k + tid] = A.obj_qpos[(size_t)env * 35 + 7 * oi + tid];
-            if (tid < 6) { s.ov[6 * k + tid] = A.obj_qvel[(size_t)env * 30 + 6 * oi + tid]; s.oqa[6 * k + tid] = A.obj_warm[(size_t)env * 6 * D_MAXOBJ + 6 * k + tid]; }
+            if (tid < 7) s.oq[7 * k + tid] = gld<Q>(A.obj_qpos + (size_t)env * 35 + 7 * oi + tid);
+            if (tid < 6) { s.ov[6 * k + tid] = gld<Q>(A.obj_qvel + (size_t)env * 30 + 6 * oi + tid); s.oqa[6 * k + tid] = gld<Q>(A.obj_warm + (size_t)env * 6 * D_MAXOBJ + 6 * k + tid); }
             if (tid < 13) s.oc[13 * k + tid] = T.obj_inertial[13 * oi + tid];
             for (int gi = T.obj_geom_adr[oi]; gi < T.obj_geom_adr[oi + 1] && ng < D_MAXGEOM; gi++, ng++) {
                 if (tid < 16) s.lgeom[16 * ng + tid] = T.obj_geoms[18 * gi + 1 + tid];
@@ -1579,8 +1600,8 @@ __device__ __forceinline__ void step_body(StepArgs A) {
     for (int n = 0; n < (D_NV + NT - 1) / NT; n++) { int i = tid + n * NT; qd_save_v[n] = i < D_NV ? s.qvel[i] : 0.f; }
     KP_SYNC();
     if (A.n_substeps > 0) {
-        for (int i = tid; i < D_NQ; i += NT) s.qpos[i] = A.qpos[(size_t)env * D_NQ + i];
-        for (int i = tid; i < D_NV; i += NT) s.qvel[i] = A.qvel[(size_t)env * D_NV + i];
+        for (int i = tid; i < D_NQ; i += NT) s.qpos[i] = gld<Q>(A.qpos + (size_t)env * D_NQ + i);
+        for (int i = tid; i < D_NV; i += NT) s.qvel[i] = gld<Q>(A.qvel + (size_t)env * D_NV + i);
         KP_SYNC();
     }
     int niter_total = 0, maxcon = 0, nfact_total = 0;
@@ -1644,27 +1665,38 @@ __device__ __forceinline__ void step_body(StepArgs A) {
     }
     // ---- store
     bool bad = false;
-    for (int i = tid; i < D_NQ; i += NT) { float v = s.qpos[i]; bad |= !(fabsf(v) < 1e10f); if (A.n_substeps > 0) A.qpos[(size_t)env * D_NQ + i] = v; }
-    for (int i = tid; i < D_NV; i += NT) { float v = s.qvel[i]; bad |= !(fabsf(v) < 1e10f); if (A.n_substeps > 0) { A.qvel[(size_t)env * D_NV + i] = v; A.warm[(size_t)env * D_NV + i] = s.qacc[i]; } }
+    for (int i = tid; i < D_NQ; i += NT) { float v = s.qpos[i]; bad |= !(fabsf(v) < 1e10f); if (A.n_substeps > 0) gst<Q>(A.qpos + (size_t)env * D_NQ + i, v); }
+    for (int i = tid; i < D_NV; i += NT) { float v = s.qvel[i]; bad |= !(fabsf(v) < 1e10f); if (A.n_substeps > 0) { gst<Q>(A.qvel + (size_t)env * D_NV + i, v); gst<Q>(A.warm + (size_t)env * D_NV + i, s.qacc[i]); } }
 #pragma unroll
-    for (int n = 0; n < (D_NQ + NT - 1) / NT; n++) { int i = tid + n * NT; if (i < D_NQ) A.qpos_d[(size_t)env * D_NQ + i] = qd_save_q[n]; }
+    for (int n = 0; n < (D_NQ + NT - 1) / NT; n++) { int i = tid + n * NT; if (i < D_NQ) gst<Q>(A.qpos_d + (size_t)env * D_NQ + i, qd_save_q[n]); }
 #pragma unroll
-    for (int n = 0; n < (D_NV + NT - 1) / NT; n++) { int i = tid + n * NT; if (i < D_NV) A.qvel_d[(size_t)env * D_NV + i] = qd_save_v[n]; }
-    for (int i = tid; i < 72; i += NT) { A.xpos[(size_t)env * 72 + i] = s.xpos[i]; A.xipos[(size_t)env * 72 + i] = s.xipos[i]; }
-    for (int i = tid; i < 96; i += NT) A.xquat[(size_t)env * 96 + i] = s.xquat[i];
+    for (int n = 0; n < (D_NV + NT - 1) / NT; n++) { int i = tid + n * NT; if (i < D_NV) gst<Q>(A.qvel_d + (size_t)env * D_NV + i, qd_save_v[n]); }
+    if (!Q || part == A.n_parts - 1) {      // read-outs: the last job of the control step only (earlier jobs' copies could land later from another L2)
+        for (int i = tid; i < 72; i += NT) { A.xpos[(size_t)env * 72 + i] = s.xpos[i]; A.xipos[(size_t)env * 72 + i] = s.xipos[i]; }
+        for (int i = tid; i < 96; i += NT) A.xquat[(size_t)env * 96 + i] = s.xquat[i];
+    }
     if constexpr (OBJ) {
         if (A.n_substeps > 0) {
             for (int k = 0; k < s.nobj; k++) {
                 const int oi = A.obj_slot[(size_t)env * D_MAXOBJ + k];
-                if (tid < 7) { const float v = s.oq[7 * k + tid]; bad |= !(fabsf(v) < 1e10f); A.obj_qpos[(size_t)env * 35 + 7 * oi + tid] = v; }
-                if (tid < 6) { A.obj_qvel[(size_t)env * 30 + 6 * oi + tid] = s.ov[6 * k + tid]; A.obj_warm[(size_t)env * 6 * D_MAXOBJ + 6 * k + tid] = s.oqa[6 * k + tid]; }
+                if (tid < 7) { const float v = s.oq[7 * k + tid]; bad |= !(fabsf(v) < 1e10f); gst<Q>(A.obj_qpos + (size_t)env * 35 + 7 * oi + tid, v); }
+                if (tid < 6) { gst<Q>(A.obj_qvel + (size_t)env * 30 + 6 * oi + tid, s.ov[6 * k + tid]); gst<Q>(A.obj_warm + (size_t)env * 6 * D_MAXOBJ + 6 * k + tid, s.oqa[6 * k + tid]); }
             }
         }
     }
     if (bad) atomicOr(&s.flag, 1);
     KP_SYNC();
-    if (tid == 0 && A.diag && A.n_substeps > 0) { int* dg = A.diag + 4 * (size_t)env; dg[0] = s.ncon; dg[1] = niter_total; dg[2] = s.flag; dg[3] = maxcon | (nfact_total << 8); }
-    if (tid == 0 && A.cost && A.n_substeps > 0) A.cost[env] = (unsigned)((__builtin_readcyclecounter() - t_launch) >> 10);
+    if (tid == 0 && A.diag && A.n_substeps > 0) {
+        int* dg = A.diag + 4 * (size_t)env;
+        if (part > 0) {      // later job of the same control step: accumulate
+            const int d3 = gld<Q>(dg + 3);
+            niter_total += gld<Q>(dg + 1); s.flag |= gld<Q>(dg + 2);
+            maxcon = max(maxcon, d3 & 255); nfact_total += d3 >> 8;
+        }
+        gst<Q>(dg + 0, s.ncon); gst<Q>(dg + 1, niter_total); gst<Q>(dg + 2, s.flag); gst<Q>(dg + 3, maxcon | (nfact_total << 8));
+    }
+    if (tid == 0 && A.cost && A.n_substeps > 0)
+        gst<Q>(A.cost + env, (part > 0 ? gld<Q>(A.cost + env) : 0u) + (unsigned)((__builtin_readcyclecounter() - t_launch) >> 10));
 }
 
 // Launch order for the next control step: envs sorted by the cycles they took in the last one, longest first (counting sort on
@@ -1689,8 +1721,49 @@ __global__ __launch_bounds__(1024) void k_lpt_order(int n, const unsigned* __res
 }
 
 template <int NT, bool OBJ>
-__global__ __launch_bounds__(NT, (NT == 64 ? 2 : 1)) void kp_step_kernel(StepArgs A) { step_body<NT, OBJ, false>(A); }
+__global__ __launch_bounds__(NT, (NT == 64 ? 2 : 1)) void kp_step_kernel(StepArgs A) {
+    step_body<NT, OBJ, false>(A, A.order ? A.order[blockIdx.x] : (int)blockIdx.x, -1);
+}
 template <int NT, bool OBJ>
-__global__ __launch_bounds__(NT, (NT == 64 ? 2 : 1)) void kp_forward_kernel(StepArgs A) { step_body<NT, OBJ, true>(A); }
+__global__ __launch_bounds__(NT, (NT == 64 ? 2 : 1)) void kp_forward_kernel(StepArgs A) { step_body<NT, OBJ, true>(A, (int)blockIdx.x, -1); }
+
+// Same control step, scheduled in finer grains.  4096 envs on 8 x 256 wave slots are two rounds of whole-control-step jobs whose
+// lengths spread 2.9 M .. 5.4 M cycles, so a third of a kp_step_kernel launch is its tail (tools/launch_balance.py).  Here one
+// resident wavefront per slot pulls jobs (env, part) from a FIFO in HBM: a job is sub_per_part substeps of one env, and finishing it
+// publishes the env's next part at the tail.  An env therefore migrates between waves (its state already round-trips through HBM at
+// job boundaries exactly as it does between launches), the makespan becomes sum / slots + about one job, and the arithmetic is
+// that of kp_step_kernel bit for bit.  Progress: indices are claimed in order, so a wave that waits for entry idx waits for a publish by
+// a wave that is running a job; if nothing is running every entry below n_envs * n_parts has been published.  A bounded spin turns
+// any violation of that argument into an error flag (jobctr[2]) instead of a hung queue.
+template <bool OBJ>
+__global__ __launch_bounds__(64, 2) void kp_step_queue_kernel(StepArgs A) {
+    const unsigned total = (unsigned)A.n_envs * (unsigned)A.n_parts;
+    for (;;) {
+        unsigned idx = 0;
+        if (threadIdx.x == 0) idx = atomicAdd(&A.jobctr[0], 1u);
+        idx = (unsigned)__builtin_amdgcn_readfirstlane((int)idx);
+        if (idx >= total) return;
+        unsigned e, spins = 0;
+        while ((e = __hip_atomic_load(&A.jobq[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0xFFFFFFFFu) {
+            __builtin_amdgcn_s_sleep(32);
+            if (++spins > (1u << 21)) { if (threadIdx.x == 0) atomicExch(&A.jobctr[2], 1u); return; }
+        }
+        asm volatile("" ::: "memory");                        // the job's (sc1) state loads stay behind the load that saw the entry
+        e = (unsigned)__builtin_amdgcn_readfirstlane((int)e);
+        const int env = (int)(e & 0xFFFFFFu), part = (int)(e >> 24);
+        step_body<64, OBJ, false, true>(A, env, part);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // every lane's write-through state store has been acknowledged ...
+        if (part + 1 < A.n_parts && threadIdx.x == 0) {                // ... before the env's next job becomes visible
+            const unsigned pos = atomicAdd(&A.jobctr[1], 1u);
+            __hip_atomic_store(&A.jobq[pos], (unsigned)env | ((unsigned)(part + 1) << 24), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+__global__ void k_queue_init(int n_envs, unsigned total, unsigned* __restrict__ jobq, unsigned* __restrict__ jobctr) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) jobq[i] = i < (unsigned)n_envs ? i : 0xFFFFFFFFu;
+    if (i == 0) { jobctr[0] = 0u; jobctr[1] = (unsigned)n_envs; }
+}
 
 }  // namespace kp

@@ -198,6 +198,89 @@ def test_launch_order_does_not_change_results(kp):
     assert (res[0][0] == res[1][0]).all() and (res[0][1] == res[1][1]).all() and (res[0][2] == res[1][2]).all()
 
 
+def _run_sched(kp, model, n, qpos, qvel, act, blk=None, steps=3, split=None):
+    sim = kp.KpSim(model, n)
+    if blk is not None:
+        sim.set_objects(dev(blk))
+    sim.set_state(dev(qpos), dev(qvel)); sim.set_target(dev(np.tile(STD["qpos"], (n, 1))))
+    a = dev(act)
+    for _ in range(steps):
+        for ns in (split or [15]):
+            sim.step_ctrl(a, ns)
+    out = [sim.get(k).cpu().numpy() for k in ("qpos", "qvel", "xpos", "xquat", "qpos_d")]
+    if blk is not None:
+        out += [sim.get("obj_qpos").cpu().numpy(), sim.get("obj_qvel").cpu().numpy()]
+    return out, sim.diag()
+
+
+@pytest.mark.timeout(300, method="thread")
+def test_job_queue_schedule_is_bit_identical(kp):
+    """kp_step_queue_kernel (a control step = jobs of `substeps_per_job` substeps pulled from a FIFO by resident waves, the env's
+    state handed from wave to wave through HBM) against kp_step_kernel (one workgroup per env): same bits in every state and
+    diagnostic, (i) forced onto 48 / 7 slots so that every env migrates and the queue runs many rounds deep, with 5-, 4- (ragged
+    last job) and 1-substep jobs, (ii) at the device's real slot count with 4096 envs, (iii) with free objects; and a control
+    step launched as 5 + 5 + 5 substeps equals one launch of 15 (the hand-over the jobs rely on)."""
+    n = 300
+    qpos, qvel = make_states(n, 41, lift=0.0, vel=0.5, noise=0.2)
+    act = np.random.default_rng(42).normal(size=(n, 75)) * 0.2
+    ref, dref = _run_sched(kp, kp.KpModel(substeps_per_job=0), n, qpos, qvel, act)
+    for spj, slots in ((5, 48), (4, 7), (1, 48)):
+        got, dg = _run_sched(kp, kp.KpModel(substeps_per_job=spj, queue_slots=slots), n, qpos, qvel, act)
+        for a_, b_ in zip(ref, got):
+            assert (a_ == b_).all(), f"substeps_per_job={spj} slots={slots}"
+        assert (dref == dg).all()
+    split, dsp = _run_sched(kp, kp.KpModel(substeps_per_job=0), n, qpos, qvel, act, split=[5, 5, 5])
+    for a_, b_ in zip(ref[:5], split):
+        assert (a_ == b_).all(), "5+5+5 substeps must equal one launch of 15"
+    # real slot count
+    n = 4096
+    qpos, qvel = make_states(n, 43, lift=0.0, vel=0.5, noise=0.2)
+    act = np.random.default_rng(44).normal(size=(n, 75)) * 0.2
+    ref, dref = _run_sched(kp, kp.KpModel(substeps_per_job=0), n, qpos, qvel, act, steps=2)
+    got, dg = _run_sched(kp, kp.KpModel(substeps_per_job=5), n, qpos, qvel, act, steps=2)
+    for a_, b_ in zip(ref, got):
+        assert (a_ == b_).all()
+    assert (dref == dg).all() and dg[:, 2].max() == 0
+    # objects (6 envs/CU kernel): push scene and standing on the step box, replicated
+    from kinpoly_amd.model_compiler import STEP_KPM
+    n = 200
+    x0, y0 = STD["qpos"][0], STD["qpos"][1]
+    cases = [{1: [x0 + 1.2, y0, 0.921, 1, 0, 0, 0], 2: [x0 + 1.2, y0, 0.7905, 1, 0, 0, 0]}, {4: [x0, y0, 0.3705, 1, 0, 0, 0]}]
+    qpos, qvel = make_states(n, 45, lift=0.0, vel=0.2, noise=0.05)
+    qpos[1::2, 2] += 0.341
+    act = np.random.default_rng(46).normal(size=(n, 75)) * 0.1
+    blk = _obj_block(n, [cases[e % 2] for e in range(n)])
+    ref, dref = _run_sched(kp, kp.KpModel(STEP_KPM, substeps_per_job=0), n, qpos, qvel, act, blk=blk)
+    got, dg = _run_sched(kp, kp.KpModel(STEP_KPM, substeps_per_job=5, queue_slots=24), n, qpos, qvel, act, blk=blk)
+    for a_, b_ in zip(ref, got):
+        assert (a_ == b_).all()
+    assert (dref == dg).all()
+
+
+@pytest.mark.timeout(180, method="thread")
+def test_absurd_targets_do_not_spin_the_kernel(kp):
+    """The stable-PD target is unwrapped by multiples of 2 pi towards the joint angle (humanoid_im.py:447-452, a data-dependent
+    loop in the reference).  Non-finite or absurd targets (a diverged kinematic policy) must neither hang the launch nor touch
+    the other environments."""
+    n = 8
+    qpos, qvel = make_states(n, 31, lift=0.0, vel=0.2, noise=0.05)
+    act = np.random.default_rng(32).normal(size=(n, 75)) * 0.1
+    clean = np.tile(STD["qpos"], (n, 1))
+    bad = clean.copy()
+    bad[0, 17] = np.inf; bad[1, 30] = 1e30; bad[2, 44] = np.nan; bad[3, 9] = -np.inf; bad[3, 60] = -3e38
+    outs = []
+    for tgt in (clean, bad):
+        sim = kp.KpSim(kp.KpModel(), n)
+        sim.set_state(dev(qpos), dev(qvel)); sim.set_target(dev(tgt))
+        for _ in range(2):
+            sim.step_ctrl(dev(act), 15)
+        outs.append((sim.get("qpos").cpu().numpy(), sim.diag()))
+    assert (outs[0][0][4:] == outs[1][0][4:]).all()
+    assert np.isfinite(outs[0][0]).all() and outs[0][1][:, 2].max() == 0
+    bad_rows = ~np.isfinite(outs[1][0]).all(1)
+    assert (outs[1][1][bad_rows, 2] != 0).all()                # whatever went non-finite is flagged
+
+
 def test_target_fk_matches_golden(kp, golden):
     g = golden("fk")
     n = len(g["qpos_in"])

@@ -43,13 +43,34 @@ for S in [int(x) for x in os.environ.get('KP_PIPE_S', '1,2,4').split(',')]:
             sm.start()
             parts.append(sm)
     torch.cuda.synchronize()
+    use_graph = os.environ.get("KP_PIPE_GRAPH", "0") == "1"
+    graphs = []
+    if use_graph:          # one hipGraph per sub-batch: the whole env-step (policies, C-ABI launches, reset) replayed with one host call
+        with torch.no_grad():
+            for st, sm in zip(streams, parts):
+                with torch.cuda.stream(st):
+                    for _ in range(3):
+                        one_step(sm)
+                    sm.static_obs, sm.static_hx = sm.obs.clone(), sm.hx.clone()
+                st.synchronize()
+                g = torch.cuda.CUDAGraph()
+                g.register_generator_state(sm.env.gen)
+                with torch.cuda.graph(g, stream=st):
+                    sm.obs, sm.hx = sm.static_obs, sm.static_hx
+                    one_step(sm)
+                    sm.static_obs.copy_(sm.obs); sm.static_hx.copy_(sm.hx)
+                graphs.append(g)
+        torch.cuda.synchronize()
 
     def run(k):
         with torch.no_grad():
             for _ in range(k):
-                for st, sm in zip(streams, parts):
+                for j, (st, sm) in enumerate(zip(streams, parts)):
                     with torch.cuda.stream(st):
-                        one_step(sm)
+                        if use_graph:
+                            graphs[j].replay()
+                        else:
+                            one_step(sm)
     run(5)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -58,4 +79,4 @@ for S in [int(x) for x in os.environ.get('KP_PIPE_S', '1,2,4').split(',')]:
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print(f"   host enqueue time {t_enq / 30 * 1e3:.3f} ms per 4096-env step")
-    print(f"S={S}: {dt / 30 * 1e3:.3f} ms per 4096-env step -> {N * 30 / dt:.0f} env-steps/s", flush=True)
+    print(f"S={S} graph={int(use_graph)}: {dt / 30 * 1e3:.3f} ms per 4096-env step -> {N * 30 / dt:.0f} env-steps/s", flush=True)
