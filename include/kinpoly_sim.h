@@ -45,8 +45,9 @@ void kp_model_free(kp_model*);
  * read-outs see the one-substep-stale derived quantities mujoco-py exposes), "solver_iter",
  * "solver_tol", "threads_per_env" (64/128/256), "dynamic_objects" (0/1);
  * scheduling only (results do not depend on them): "substeps_per_job" (default 3; 0 = one workgroup per env and control step):
- * with more envs than resident wavefront slots a control step is cut into jobs of that many substeps which resident waves pull from
- * a FIFO, so that the launch does not end on the tail of its longest envs; "queue_slots" (0 = CUs x 8, x 6 with objects);
+ * with more envs than resident wavefront slots a control step is cut into jobs of that many substeps (the last job; with "job_taper"
+ * = 1, the default, each earlier job is two substeps longer: 15 = 7 + 5 + 3) which resident waves pull from a FIFO, so that the
+ * launch does not end on the tail of its longest envs; "queue_slots" (0 = CUs x 8, x 6 with objects);
  * "lpt_order" (0/1, default 0: longest-env-first workgroup order for the plain launch). */
 int kp_model_set_option(kp_model*, const char* name, double value);
 double kp_model_get_option(const kp_model*, const char* name);

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -23,7 +24,7 @@ int fail(const std::string& m) { g_err = m; return -1; }
 
 struct kp_model {
     kp::HostModel h;
-    int contact = 1, limits = 1, stale = 1, solver_iter = 12, threads = 64, dynamic_objects = 1, lpt_order = 0, substeps_per_job = 3, queue_slots = 0;
+    int contact = 1, limits = 1, stale = 1, solver_iter = 12, threads = 64, dynamic_objects = 1, lpt_order = 0, substeps_per_job = 3, queue_slots = 0, job_taper = 1;
     double solver_tol = 1e-8, gravity_z = -9.81;   // solver_tol: mjOption.tolerance of the reference model (kp_model_load)
 };
 
@@ -202,9 +203,28 @@ int launch_step(kp_sim* s, const float* action, int nsub, const uint8_t* mask, b
     // resident wave per slot (kp_step_queue_kernel) instead of one workgroup per env, which ends on a long tail
     const int spj = s->model->substeps_per_job;
     const int slots = s->model->queue_slots > 0 ? s->model->queue_slots : (obj ? s->wave_slots / 8 * 6 : s->wave_slots);
-    const int parts = spj > 0 ? (nsub + spj - 1) / spj : 1;
-    const bool queue = nsub > 0 && spj > 0 && parts > 1 && parts <= 16 && s->model->threads == 64 && s->n > slots && !s->prof && !A.order;
-    A.jobq = s->jobq; A.jobctr = s->jobctr; A.n_parts = queue ? parts : 1; A.sub_per_part = queue ? spj : nsub;
+    // job sizes: `spj` substeps for the last job, two more for each job before it ("job_taper", 15 = 7 + 5 + 3; the FIFO runs all envs'
+    // first jobs, then all second jobs ...: long jobs first keep the hand-overs few, short jobs last keep the end of the launch short)
+    int sizes[16], parts = 0;
+    if (spj > 0 && nsub > 0) {
+        int rem = nsub, size = spj;
+        while (rem > 0 && parts < 16) {
+            int take = parts == 15 ? rem : std::min(rem, size);
+            if (rem - take > 0 && rem - take < spj) take = rem;
+            sizes[parts++] = take; rem -= take;
+            if (s->model->job_taper) size += 2;
+        }
+        std::reverse(sizes, sizes + parts);
+        if (const char* e = std::getenv("KP_JOB_SCHEDULE")) {      // experiments: explicit comma-separated job sizes
+            int tmp[16], np = 0, sum = 0;
+            for (const char* c = e; *c && np < 16;) { tmp[np] = std::atoi(c); sum += tmp[np++]; while (*c && *c != ',') c++; if (*c) c++; }
+            if (sum == nsub) { parts = np; std::copy(tmp, tmp + np, sizes); }
+        }
+    }
+    const bool queue = nsub > 0 && parts > 1 && s->model->threads == 64 && s->n > slots && !s->prof && !A.order;
+    A.jobq = s->jobq; A.jobctr = s->jobctr; A.n_parts = queue ? parts : 1;
+    A.part_sub_lo = A.part_sub_hi = 0;
+    for (int k = 0; queue && k < parts; k++) (k < 8 ? A.part_sub_lo : A.part_sub_hi) |= (unsigned long long)(sizes[k] & 255) << (8 * (k & 7));
     if (queue) {
         const unsigned total = (unsigned)s->n * (unsigned)parts;
         hipLaunchKernelGGL(kp::k_queue_init, dim3((total + 255) / 256), dim3(256), 0, s->stream, s->n, total, s->jobq, s->jobctr);
@@ -258,6 +278,7 @@ int kp_model_set_option(kp_model* m, const char* name, double v) {
     else if (k == "solver_tol") m->solver_tol = v;
     else if (k == "dynamic_objects") m->dynamic_objects = v != 0;
     else if (k == "lpt_order") m->lpt_order = v != 0;
+    else if (k == "job_taper") m->job_taper = v != 0;
     else if (k == "queue_slots") { if (v < 0) return fail("queue_slots must be >= 0 (0 = resident wave slots of the device)"); m->queue_slots = (int)v; }
     else if (k == "substeps_per_job") { if (v < 0 || v > 255) return fail("substeps_per_job must be 0 (whole control step per workgroup) .. 255"); m->substeps_per_job = (int)v; }
     else if (k == "threads_per_env") { if (v != 64 && v != 128 && v != 256) return fail("threads_per_env must be 64, 128 or 256"); m->threads = (int)v; }
@@ -277,6 +298,7 @@ double kp_model_get_option(const kp_model* m, const char* name) {
     if (k == "lpt_order") return m->lpt_order;
     if (k == "substeps_per_job") return m->substeps_per_job;
     if (k == "queue_slots") return m->queue_slots;
+    if (k == "job_taper") return m->job_taper;
     if (k == "threads_per_env") return m->threads;
     if (k == "timestep") return m->h.opt[kp::OPT_TIMESTEP];
     if (k == "lds_bytes_per_env") return (double)sizeof(kp::EnvLds);

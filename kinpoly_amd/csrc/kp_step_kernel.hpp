@@ -49,11 +49,12 @@ struct StepArgs {
     // launch spent on env.  Both optional.  The result of an env does not depend on the workgroup that computes it.
     const int* order;
     unsigned* cost;
-    // job-queue launch (kp_step_queue_kernel): a control step of an env = n_parts jobs of sub_per_part substeps handed from wave to
+    // job-queue launch (kp_step_queue_kernel): a control step of an env = n_parts jobs of part_sub[] substeps handed from wave to
     // wave through HBM.  jobq [n_envs * n_parts] entries (env | part << 24, 0xFFFFFFFF = not yet published), jobctr = {head, tail, stalled}
     unsigned* jobq;
     unsigned* jobctr;
-    int n_parts, sub_per_part;
+    int n_parts;
+    unsigned long long part_sub_lo, part_sub_hi;   // substeps of job 0 .. 15, one byte each (sum = n_substeps); packed so that no lookup indexes the kernel argument
 };
 
 // wave-wide sum without LDS traffic: xor butterflies inside each 16-lane row with DPP (quad_perm, row_half_mirror,
@@ -1545,7 +1546,7 @@ template <bool Q, typename V> __device__ __forceinline__ void gst(V* p, V v) {
 template <int NT, bool OBJ, bool FWD, bool Q = false>
 __device__ __forceinline__ void step_body(StepArgs A, const int env_in, const int part) {
     if (FWD) A.n_substeps = 0;
-    else if (part >= 0) A.n_substeps = min(A.sub_per_part, A.n_substeps - part * A.sub_per_part);   // this job's share of the control step
+    else if (part >= 0) A.n_substeps = (int)(((part < 8 ? A.part_sub_lo >> (8 * part) : A.part_sub_hi >> (8 * (part - 8)))) & 255ull);   // this job's share of the control step
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     typename std::conditional<OBJ, EnvLdsObj, EnvLds>::type& s = *reinterpret_cast<typename std::conditional<OBJ, EnvLdsObj, EnvLds>::type*>(smem_raw);
     const int tid = threadIdx.x;
@@ -1729,7 +1730,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 2 : 1)) void kp_forward_kernel(Step
 
 // Same control step, scheduled in finer grains.  4096 envs on 8 x 256 wave slots are two rounds of whole-control-step jobs whose
 // lengths spread 2.9 M .. 5.4 M cycles, so a third of a kp_step_kernel launch is its tail (tools/launch_balance.py).  Here one
-// resident wavefront per slot pulls jobs (env, part) from a FIFO in HBM: a job is sub_per_part substeps of one env, and finishing it
+// resident wavefront per slot pulls jobs (env, part) from a FIFO in HBM: a job is a few substeps of one env, and finishing it
 // publishes the env's next part at the tail.  An env therefore migrates between waves (its state already round-trips through HBM at
 // job boundaries exactly as it does between launches), the makespan becomes sum / slots + about one job, and the arithmetic is
 // that of kp_step_kernel bit for bit.  Progress: indices are claimed in order, so a wave that waits for entry idx waits for a publish by

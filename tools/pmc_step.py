@@ -19,7 +19,9 @@ sim = KpSim(KpModel(), n)
 q = torch.tensor(qpos, dtype=torch.float32, device="cuda"); v = torch.tensor(qvel, dtype=torch.float32, device="cuda")
 sim.set_state(q, v); sim.set_target(q.clone())
 a = torch.tensor(rng.normal(size=(n, 75)) * 0.2, dtype=torch.float32, device="cuda")
+ms = []
 for _ in range(10):
     sim.step_ctrl(a, 15)
+    ms.append(sim.last_step_seconds() * 1e3)
 torch.cuda.synchronize()
-print("ms/launch", sim.last_step_seconds() * 1e3)
+print("ms/launch last", ms[-1], "median", float(np.median(ms[2:])))
