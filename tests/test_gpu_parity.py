@@ -198,15 +198,16 @@ def test_launch_order_does_not_change_results(kp):
     assert (res[0][0] == res[1][0]).all() and (res[0][1] == res[1][1]).all() and (res[0][2] == res[1][2]).all()
 
 
-def _run_sched(kp, model, n, qpos, qvel, act, blk=None, steps=3, split=None):
+def _run_sched(kp, model, n, qpos, qvel, act, blk=None, steps=3, split=None, mask=None):
     sim = kp.KpSim(model, n)
+    m8 = None if mask is None else torch.tensor(mask, dtype=torch.uint8, device="cuda")
     if blk is not None:
         sim.set_objects(dev(blk))
     sim.set_state(dev(qpos), dev(qvel)); sim.set_target(dev(np.tile(STD["qpos"], (n, 1))))
     a = dev(act)
     for _ in range(steps):
         for ns in (split or [15]):
-            sim.step_ctrl(a, ns)
+            sim.step_ctrl(a, ns, m8)
     out = [sim.get(k).cpu().numpy() for k in ("qpos", "qvel", "xpos", "xquat", "qpos_d")]
     if blk is not None:
         out += [sim.get("obj_qpos").cpu().numpy(), sim.get("obj_qvel").cpu().numpy()]
@@ -229,6 +230,12 @@ def test_job_queue_schedule_is_bit_identical(kp):
         for a_, b_ in zip(ref, got):
             assert (a_ == b_).all(), f"substeps_per_job={spj} slots={slots}"
         assert (dref == dg).all()
+    mask = (np.arange(n) % 3 != 1).astype(np.uint8)             # masked envs still pass through the queue (their jobs are empty)
+    refm, drefm = _run_sched(kp, kp.KpModel(substeps_per_job=0), n, qpos, qvel, act, mask=mask)
+    gotm, dgm = _run_sched(kp, kp.KpModel(substeps_per_job=3, queue_slots=16), n, qpos, qvel, act, mask=mask)
+    for a_, b_ in zip(refm, gotm):
+        assert (a_ == b_).all()
+    assert (drefm == dgm).all() and (refm[0][mask == 0] == np.float32(qpos)[mask == 0]).all()
     split, dsp = _run_sched(kp, kp.KpModel(substeps_per_job=0), n, qpos, qvel, act, split=[5, 5, 5])
     for a_, b_ in zip(ref[:5], split):
         assert (a_ == b_).all(), "5+5+5 substeps must equal one launch of 15"
