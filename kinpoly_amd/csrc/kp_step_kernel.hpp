@@ -149,54 +149,53 @@ __device__ __forceinline__ void forward_kin_bias(EnvLds& s, const DevTables& T, 
         f[0] = ql.w; f[1] = ql.x; f[2] = ql.y; f[3] = ql.z; st3(f + 4, a1); st3(f + 7, a2);
     }
     KP_SYNC();
-    for (int lev = 0; lev < D_NLEV; lev++) {
+    if (tid == 0) {                       // root (level 0): free joint
+        const Q4 q = qnormalize(Q4{s.qpos[3], s.qpos[4], s.qpos[5], s.qpos[6]});
+        s.qpos[3] = q.w; s.qpos[4] = q.x; s.qpos[5] = q.y; s.qpos[6] = q.z;
+        const V3 pos = ld3(s.qpos);
+        float R[9]; q2mat(q, R);
+        const V3 vl = ld3(s.qvel), wb = ld3(s.qvel + 3);
+        const V3 ww = mulmat(R, wb);
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            float* c = s.cdof + 6 * k;
+            c[0] = c[1] = c[2] = 0.f; c[3] = k == 0; c[4] = k == 1; c[5] = k == 2;
+            float* r = s.cdof + 6 * (3 + k);
+            r[0] = R[k]; r[1] = R[3 + k]; r[2] = R[6 + k]; r[3] = r[4] = r[5] = 0.f;
+        }
+        st3(s.xpos, pos);
+        s.xquat[0] = q.w; s.xquat[1] = q.x; s.xquat[2] = q.y; s.xquat[3] = q.z;
+        sts6(s.sv, S6{ww, vl}); sts6(s.sa, S6{v3(0.f, 0.f, 0.f), v3(-P.gx, -P.gy, -P.gz) + cross(vl, ww)});
+    }
+    KP_SYNC();
+#pragma nounroll
+    for (int lev = 1; lev < D_NLEV; lev++) {
         if (depth == lev) {
             const int b = tid;
-            S6 cv, ca;
-            V3 pos;
-            Q4 q;
-            if (b == 0) {
-                q = qnormalize(Q4{s.qpos[3], s.qpos[4], s.qpos[5], s.qpos[6]});
-                s.qpos[3] = q.w; s.qpos[4] = q.x; s.qpos[5] = q.y; s.qpos[6] = q.z;
-                pos = ld3(s.qpos);
-                float R[9]; q2mat(q, R);
-                V3 vl = ld3(s.qvel), wb = ld3(s.qvel + 3);
-                V3 ww = mulmat(R, wb);
+            const int p = s.bpar[b];
+            const int d0 = 6 + 3 * (b - 1);
+            // one LDS round: parent pose / velocity / acceleration, own joint state
+            const V3 o = ld3(s.xpos);
+            Q4 q = Q4{s.xquat[4 * p], s.xquat[4 * p + 1], s.xquat[4 * p + 2], s.xquat[4 * p + 3]};
+            const V3 ppos = ld3(s.xpos + 3 * p);
+            S6 cv = lds6(s.sv + 6 * p), ca = lds6(s.sa + 6 * p);
+            const float qds[3] = {s.qvel[d0], s.qvel[d0 + 1], s.qvel[d0 + 2]};
+            const float* f = jf + 10 * b;
+            const Q4 ql = Q4{f[0], f[1], f[2], f[3]};
+            const V3 a1 = ld3(f + 4), a2 = ld3(f + 7);
+            float R[9];
+            q2mat(q, R);                                       // parent rotation: the three hinge axes are R e_z, R a1, R a2
+            const V3 pos = ppos + mulmat(R, bpos);
+            const V3 r = o - pos;
+            const V3 axes[3] = {v3(R[2], R[5], R[8]), mulmat(R, a1), mulmat(R, a2)};
 #pragma unroll
-                for (int k = 0; k < 3; k++) {
-                    float* c = s.cdof + 6 * k;
-                    c[0] = c[1] = c[2] = 0.f; c[3] = k == 0; c[4] = k == 1; c[5] = k == 2;
-                    float* r = s.cdof + 6 * (3 + k);
-                    r[0] = R[k]; r[1] = R[3 + k]; r[2] = R[6 + k]; r[3] = r[4] = r[5] = 0.f;
-                }
-                cv = S6{ww, vl};
-                ca = S6{v3(0.f, 0.f, 0.f), v3(-P.gx, -P.gy, -P.gz) + cross(vl, ww)};
-            } else {
-                const int p = s.bpar[b];
-                const int d0 = 6 + 3 * (b - 1);
-                // one LDS round: parent pose / velocity / acceleration, own joint state
-                const V3 o = ld3(s.xpos);
-                q = Q4{s.xquat[4 * p], s.xquat[4 * p + 1], s.xquat[4 * p + 2], s.xquat[4 * p + 3]};
-                const V3 ppos = ld3(s.xpos + 3 * p);
-                cv = lds6(s.sv + 6 * p); ca = lds6(s.sa + 6 * p);
-                const float qds[3] = {s.qvel[d0], s.qvel[d0 + 1], s.qvel[d0 + 2]};
-                const float* f = jf + 10 * b;
-                const Q4 ql = Q4{f[0], f[1], f[2], f[3]};
-                const V3 a1 = ld3(f + 4), a2 = ld3(f + 7);
-                float R[9];
-                q2mat(q, R);                                       // parent rotation: the three hinge axes are R e_z, R a1, R a2
-                pos = ppos + mulmat(R, bpos);
-                const V3 r = o - pos;
-                const V3 axes[3] = {v3(R[2], R[5], R[8]), mulmat(R, a1), mulmat(R, a2)};
-#pragma unroll
-                for (int j = 0; j < 3; j++) {
-                    const S6 cd = S6{axes[j], cross(axes[j], r)};
-                    sts6(s.cdof + 6 * (d0 + j), cd);
-                    const S6 cdd = cross_motion(cv, cd);
-                    cv = cv + qds[j] * cd; ca = ca + qds[j] * cdd;
-                }
-                q = qnormalize(qmul(q, ql));
+            for (int j = 0; j < 3; j++) {
+                const S6 cd = S6{axes[j], cross(axes[j], r)};
+                sts6(s.cdof + 6 * (d0 + j), cd);
+                const S6 cdd = cross_motion(cv, cd);
+                cv = cv + qds[j] * cd; ca = ca + qds[j] * cdd;
             }
+            q = qnormalize(qmul(q, ql));
             st3(s.xpos + 3 * b, pos);
             s.xquat[4 * b] = q.w; s.xquat[4 * b + 1] = q.x; s.xquat[4 * b + 2] = q.y; s.xquat[4 * b + 3] = q.z;
             sts6(s.sv + 6 * b, cv); sts6(s.sa + 6 * b, ca);
