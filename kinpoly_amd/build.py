@@ -37,7 +37,8 @@ def needs_build() -> bool:
 def build_native(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+    extra = os.environ.get("KP_HIPCC_FLAGS", "").split()
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", *extra,
            *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB]
     if verbose:
         print(" ".join(cmd))
