@@ -352,3 +352,65 @@ def test_dataset_to_rollout_pipeline_with_objects(tmp_path):
     assert int(env.sim.diag()[:, 2].max()) == 0
     moved = (env.sim.get("obj_qpos") - objq0).abs().max(1).values
     assert float(moved.max()) < 0.05                               # objects resting on the floor / table stay put (mm-level settling)
+
+
+@pytest.mark.timeout(240, method="thread")
+def test_env_step_captures_into_a_hip_graph():
+    """Every entry point of the C ABI only enqueues on the sim's stream, so a whole rollout step (kinematic policy, env.step
+    through the library's kernels, masked reset) captures into one hipGraph; replaying it three times gives the same bits
+    as three eager steps (test mode: mean actions, no random numbers).  n = 2304 > the wave slots, i.e. the job-queue launch."""
+    from kinpoly_amd.nets import KinPolicy
+    n = 2304
+
+    def one_step(env, pol, st):
+        a, st["hx"] = pol.select_action(st["obs"], st["hx"], True)
+        a = a * 0.0 + st["a0"]                                  # keep the untrained policy's output near the current pose
+        obs, _, done, _ = env.step(a.contiguous())
+        st["obs"] = env.reset(done).clone()
+        st["hx"] = st["hx"] * (~done).float().unsqueeze(1)
+
+    def initial(env, ctx):
+        obs0 = env.reset().clone()
+        q0 = ctx["init_qpos"]
+        a0 = torch.zeros((n, 80), device=env.device)
+        a0[:, :74] = torch.cat([q0[:, 2:3], obs0[:, 1:5], q0[:, 7:]], 1)    # obs_ar[0:74] = qpos[2:] with the root de-headed
+        return obs0, a0
+
+    outs = []
+    for use_graph in (False, True):
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side), torch.no_grad():
+            env, ctx = _mk_env(n, T=12, mode="test", seed=5)
+            torch.manual_seed(7)
+            pol = KinPolicy().to(env.device).float()
+            obs0, a0 = initial(env, ctx)
+            st = {"obs": obs0, "hx": pol.init_hidden(n, env.device), "a0": a0}
+            if not use_graph:
+                for _ in range(3):
+                    one_step(env, pol, st)
+            else:
+                side.synchronize()
+                g = torch.cuda.CUDAGraph()
+                s_obs, s_hx = st["obs"].clone(), st["hx"].clone()
+                st["obs"], st["hx"] = s_obs, s_hx
+                # warm the lazily built pieces (fused PolicyMCP weights, hipBLASLt workspaces) outside the capture, then restore
+                saved = {k: env.sim.get(k).clone() for k in ("qpos", "qvel", "qpos_d", "qvel_d")}
+                cur_t = env.cur_t.clone()
+                one_step(env, pol, st)
+                env.sim.set_full_state(saved["qpos"], saved["qvel"], saved["qpos_d"], saved["qvel_d"]); env.cur_t.copy_(cur_t)
+                obs0b, _ = initial(env, ctx)
+                s_obs.copy_(obs0b); s_hx.zero_(); st["obs"], st["hx"] = s_obs, s_hx
+                side.synchronize()
+                with torch.cuda.graph(g, stream=side):
+                    st["obs"], st["hx"] = s_obs, s_hx
+                    one_step(env, pol, st)
+                    s_obs.copy_(st["obs"]); s_hx.copy_(st["hx"])
+                # the capture itself executed nothing: state is still the initial one
+                for _ in range(3):
+                    g.replay()
+                st["obs"], st["hx"] = s_obs, s_hx
+            side.synchronize()
+            outs.append((st["obs"].cpu().numpy(), env.sim.get("qpos").cpu().numpy(), env.sim.get("qvel").cpu().numpy(), env.cur_t.cpu().numpy()))
+    for a_, b_ in zip(*outs):
+        assert (a_ == b_).all()
+    assert np.isfinite(outs[0][1]).all() and outs[0][3].max() == 3
