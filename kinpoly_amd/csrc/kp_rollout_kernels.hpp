@@ -80,52 +80,59 @@ __device__ __forceinline__ V3 rot_from_quat(Q4 q) {  // rotation_from_quaternion
 
 struct RewardW { float w_hp, w_hq, w_p, w_jp, w_act_p, w_act_v, k_hp, k_hq, k_p, k_jp, k_act_p, k_act_v, dt, thresh, gt_thresh; int use_gt; };
 
-// inputs are AFTER do_simulation and cur_t += 1: qpos fresh, xpos/xquat stale (as the reference reads them)
-__global__ void k_term_reward(int n, CtxDev C, RewardW W, const float* __restrict__ qpos, const float* __restrict__ xpos,
+// inputs are AFTER do_simulation and cur_t += 1: qpos fresh, xpos/xquat stale (as the reference reads them).
+// 32 lanes per env (lane = body, 24 active), 8 envs per 256-thread block; the per-body terms are summed by an xor butterfly.
+__global__ __launch_bounds__(256) void k_term_reward(int n, CtxDev C, RewardW W, const float* __restrict__ qpos, const float* __restrict__ xpos,
                               const float* __restrict__ xquat, const float* __restrict__ t_wbpos, const float* __restrict__ t_bquat,
                               const float* __restrict__ prev_bquat, const float* __restrict__ prev_hpos, const float* __restrict__ diffw,
                               float* __restrict__ reward, float* __restrict__ info, uint8_t* __restrict__ fail, float* __restrict__ diffs) {
-    int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
+    const int b = threadIdx.x & 31, e_raw = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const bool valid = e_raw < n;
+    const int e = valid ? e_raw : 0;
     int t = C.cur_t[e];
     t = t < 1 ? 1 : (t >= C.T ? C.T - 1 : t);
     const float* q = qpos + (size_t)e * D_NQ;
     const float* xp = xpos + (size_t)e * 72;
-    const float* xq = xquat + (size_t)e * 96;
-    const float* hp = C.head_pose + ((size_t)e * C.T + t) * 7;
     const float* gtb = C.gt_bquat + ((size_t)e * C.T + t) * 96;
     const float* gtp = C.gt_bquat + ((size_t)e * C.T + t - 1) * 96;
     const float* gtw = C.gt_wbpos + ((size_t)e * C.T + t) * 72;
-    // head terms
-    V3 hd = ld3(xp + 39) - ld3(hp);
-    float hp_r = expf(-W.k_hp * dot(hd, hd));
-    Q4 hq = qmul(Q4{xq[52], xq[53], xq[54], xq[55]}, q_inverse(Q4{hp[3], hp[4], hp[5], hp[6]}));
-    float hqd = quat_norm_v2(hq);
-    float hq_r = expf(-W.k_hq * hqd * hqd);
     float pq = 0.f, pp = 0.f, pg = 0.f, vel2 = 0.f, bd = 0.f, bgd = 0.f;
-    for (int b = 0; b < D_NB; b++) {
-        Q4 cb = b == 0 ? Q4{q[3], q[4], q[5], q[6]} : q_euler_sxyz(q[7 + 3 * (b - 1)], q[8 + 3 * (b - 1)], q[9 + 3 * (b - 1)]);
+    if (b < D_NB) {
+        const Q4 cb = b == 0 ? Q4{q[3], q[4], q[5], q[6]} : q_euler_sxyz(q[7 + 3 * (b - 1)], q[8 + 3 * (b - 1)], q[9 + 3 * (b - 1)]);
         const float* tb = t_bquat + (size_t)e * 96 + 4 * b;
-        pq += quat_norm_v2(qmul(cb, q_inverse(Q4{tb[0], tb[1], tb[2], tb[3]})));
-        V3 dpos = ld3(xp + 3 * b) - ld3(t_wbpos + (size_t)e * 72 + 3 * b);
-        float dn = sqrtf(dot(dpos, dpos));
-        pp += dn;
-        float wgt = diffw ? diffw[b] : 1.0f;
-        bd += wgt * dn;
-        V3 dg = ld3(xp + 3 * b) - ld3(gtw + 3 * b);
-        bgd += wgt * sqrtf(dot(dg, dg));
-        Q4 g = Q4{gtb[4 * b], gtb[4 * b + 1], gtb[4 * b + 2], gtb[4 * b + 3]};
-        Q4 gpv = Q4{gtp[4 * b], gtp[4 * b + 1], gtp[4 * b + 2], gtp[4 * b + 3]};
-        pg += quat_norm_v2(qmul(g, q_inverse(cb)));
+        pq = quat_norm_v2(qmul(cb, q_inverse(Q4{tb[0], tb[1], tb[2], tb[3]})));
+        const V3 x = ld3(xp + 3 * b);
+        const V3 dpos = x - ld3(t_wbpos + (size_t)e * 72 + 3 * b);
+        pp = sqrtf(dot(dpos, dpos));
+        const float wgt = diffw ? diffw[b] : 1.0f;
+        bd = wgt * pp;
+        const V3 dg = x - ld3(gtw + 3 * b);
+        bgd = wgt * sqrtf(dot(dg, dg));
+        const Q4 g = Q4{gtb[4 * b], gtb[4 * b + 1], gtb[4 * b + 2], gtb[4 * b + 3]};
+        const Q4 gpv = Q4{gtp[4 * b], gtp[4 * b + 1], gtp[4 * b + 2], gtp[4 * b + 3]};
+        pg = quat_norm_v2(qmul(g, q_inverse(cb)));
         const float* pb = prev_bquat + (size_t)e * 96 + 4 * b;
-        V3 cv = (1.0f / W.dt) * rot_from_quat(qmul(cb, q_inverse(Q4{pb[0], pb[1], pb[2], pb[3]})));
-        V3 gv = (1.0f / W.dt) * rot_from_quat(qmul(g, q_inverse(gpv)));
-        V3 dv = cv - gv;
-        vel2 += dot(dv, dv);
+        const V3 cv = (1.0f / W.dt) * rot_from_quat(qmul(cb, q_inverse(Q4{pb[0], pb[1], pb[2], pb[3]})));
+        const V3 gv = (1.0f / W.dt) * rot_from_quat(qmul(g, q_inverse(gpv)));
+        const V3 dv = cv - gv;
+        vel2 = dot(dv, dv);
     }
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) {
+        pq += __shfl_xor(pq, m, 32); pp += __shfl_xor(pp, m, 32); pg += __shfl_xor(pg, m, 32);
+        vel2 += __shfl_xor(vel2, m, 32); bd += __shfl_xor(bd, m, 32); bgd += __shfl_xor(bgd, m, 32);
+    }
+    if (b != 0 || !valid) return;
+    const float* xq = xquat + (size_t)e * 96;
+    const float* hp = C.head_pose + ((size_t)e * C.T + t) * 7;
+    const V3 hd = ld3(xp + 39) - ld3(hp);
+    const float hp_r = expf(-W.k_hp * dot(hd, hd));
+    const Q4 hq = qmul(Q4{xq[52], xq[53], xq[54], xq[55]}, q_inverse(Q4{hp[3], hp[4], hp[5], hp[6]}));
+    const float hqd = quat_norm_v2(hq);
+    const float hq_r = expf(-W.k_hq * hqd * hqd);
     pq *= (1.0f / 24.0f); pp *= (1.0f / 24.0f); pg *= (1.0f / 24.0f);
-    float p_r = expf(-W.k_p * pq * pq), jp_r = expf(-W.k_jp * pp * pp);
-    float gt_r = expf(-W.k_act_p * pg), av_r = expf(-W.k_act_v * vel2);
+    const float p_r = expf(-W.k_p * pq * pq), jp_r = expf(-W.k_jp * pp * pp);
+    const float gt_r = expf(-W.k_act_p * pg), av_r = expf(-W.k_act_v * vel2);
     reward[e] = W.w_hp * hp_r + W.w_hq * hq_r + W.w_p * p_r + W.w_jp * jp_r + W.w_act_p * gt_r + W.w_act_v * av_r;
     float* inf = info + (size_t)e * 6;
     inf[0] = hp_r; inf[1] = hq_r; inf[2] = p_r; inf[3] = jp_r; inf[4] = gt_r; inf[5] = av_r;

@@ -567,7 +567,7 @@ int kp_sim_term_reward(kp_sim* s, const kp_ctx* c, const kp_reward_cfg* w, float
     HIP_OK(hipSetDevice(s->device));
     kp::RewardW W{w->w_hp, w->w_hq, w->w_p, w->w_jp, w->w_act_p, w->w_act_v, w->k_hp, w->k_hq, w->k_p, w->k_jp, w->k_act_p, w->k_act_v,
                   w->dt, w->body_diff_thresh, w->body_diff_gt_thresh, w->use_gt_term};
-    hipLaunchKernelGGL(kp::k_term_reward, dim3((s->n + 63) / 64), dim3(64), 0, s->stream, s->n, to_dev(c), W, s->qpos, s->xpos, s->xquat,
+    hipLaunchKernelGGL(kp::k_term_reward, dim3((s->n + 7) / 8), dim3(256), 0, s->stream, s->n, to_dev(c), W, s->qpos, s->xpos, s->xquat,
                        s->t_wbpos, s->t_bquat, s->prev_bquat, s->prev_hpos, s->diffw, reward, info, failp, diffs);
     HIP_OK(hipGetLastError());
     return 0;
