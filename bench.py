@@ -33,8 +33,9 @@ HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 def build_engine(device_index, seed, threads):
     from kinpoly_amd.env import BatchedHumanoidAREnv, standing_context
-    from kinpoly_amd.nets import KinPolicy
+    from kinpoly_amd.nets import KinPolicy, enable_tuned_gemms
     from kinpoly_amd.rollout import VectorSampler
+    build_engine.tuned = enable_tuned_gemms()
     torch.manual_seed(seed)
     std = np.load(os.path.join(ROOT, "tests", "golden", "standing_neutral.npz"))
     env = BatchedHumanoidAREnv(ENVS_PER_GPU, device_index, mode="train", seed=seed, model_options={"threads_per_env": threads, **({"substeps_per_job": int(os.environ["KP_SUBSTEPS_PER_JOB"])} if "KP_SUBSTEPS_PER_JOB" in os.environ else {})})
@@ -177,7 +178,8 @@ def main():
             "config": {"workload": "BASELINE configs[2] rollout: kin_poly.yml dynamics-regulated env-step (kin GRU policy, step_ar, target FK, "
                                    "UHC obs+ZFilter+PolicyMCP, 15 substeps SPD+RFC+contact, term/reward, AR obs, auto-reset), standing MoCap clip, "
                                    "random-init seeded networks", "envs_per_gpu": ENVS_PER_GPU, "substeps": 15, "clip_len": CLIP_LEN,
-                       "threads_per_env": args.threads_per_env, "parallelism": f"env-sharded x{world}"},
+                       "threads_per_env": args.threads_per_env, "parallelism": f"env-sharded x{world}",
+                       "gemm_selection": "kinpoly_amd/assets/tunableop_gfx950.csv (rocBLAS / hipBLASLt solution per shape, fp32)" if getattr(build_engine, "tuned", False) else "library default"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "kp_step_queue_kernel" if int(env.model.get_option("substeps_per_job")) > 0 else "kp_step_kernel", "launch_ms": kern_s * 1e3, "launches_timed": n_launch,
                          "algorithmic_bytes_per_launch": algo_bytes,

@@ -20,6 +20,29 @@ import torch
 import torch.nn as nn
 
 
+TUNED_GEMMS = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "assets", "tunableop_gfx950.csv")
+
+
+def enable_tuned_gemms(path: str = TUNED_GEMMS) -> bool:
+    """Use the rocBLAS / hipBLASLt solutions recorded for the rollout's GEMM shapes (4096 envs: GRU gates, the two policy MLPs,
+    PolicyMCP's batched primitives) by torch's TunableOp on MI355X (`tools/tune_gemms.py` writes the file).  Selection only:
+    no tuning happens at run time, shapes that are not in the file (or a file recorded with other library versions) fall back
+    to the default heuristics.  Returns whether the file was taken."""
+    import os
+    if not (torch.cuda.is_available() and os.path.exists(path) and hasattr(torch.cuda, "tunable")):
+        return False
+    try:
+        torch.cuda.tunable.enable(True)
+        torch.cuda.tunable.tuning_enable(False)
+        torch.cuda.tunable.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), "kp_tunableop_unused.csv"))   # never write next to the asset
+        if hasattr(torch.cuda.tunable, "write_file_on_exit"):
+            torch.cuda.tunable.write_file_on_exit(False)
+        return bool(torch.cuda.tunable.read_file(path))
+    except Exception:
+        torch.cuda.tunable.enable(False)
+        return False
+
+
 class MLP(nn.Module):
     def __init__(self, input_dim, hidden_dims=(128, 128), activation="tanh"):
         super().__init__()
