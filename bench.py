@@ -48,13 +48,25 @@ def build_engine(device_index, seed, threads):
     return env, policy, sampler, std
 
 
-def rollout_steps(sampler, k):
+def tracking_action(env):
+    """The kinematic action a converged policy emits on the standing clip: next pose = the clip's pose (step_ar's encoding:
+    root height, de-headed root quaternion, 69 joint angles, zero root velocities).  Used by --workload tracked only."""
+    q0 = env.ctx["init_qpos"]
+    obs0 = env.reset().clone()                                   # obs_ar[0:74] = qpos[2:] with the root quaternion de-headed
+    a = torch.zeros((env.n, 80), device=env.device)
+    a[:, :74] = torch.cat([q0[:, 2:3], obs0[:, 1:5], q0[:, 7:]], 1)
+    return a
+
+
+def rollout_steps(sampler, k, a_track=None):
     """k batched env-steps without keeping the experience (identical work to VectorSampler.sample's loop body)."""
     env, pol = sampler.env, sampler.policy
     n_done = torch.zeros((), dtype=torch.int64, device=env.device)
     with torch.no_grad():
         for _ in range(k):
             action, sampler.hx = pol.select_action(sampler.obs, sampler.hx, False, env.gen)
+            if a_track is not None:                              # the policy's GEMMs ran; a trained policy's output stands in for theirs
+                action = action * 0.0 + a_track + 0.04 * torch.randn(action.shape, device=action.device, generator=env.gen)
             _, _, done, info = env.step(action.contiguous())
             n_done += done.sum()
             sampler.obs = env.reset(done).clone()
@@ -118,6 +130,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--threads-per-env", type=int, default=int(os.environ.get("KP_THREADS_PER_ENV", "64")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=("random_init", "tracked"), default="random_init",
+                    help="random_init (default, BASELINE configs[2]): seeded random-init networks; tracked: same step, but the kinematic "
+                         "policy's output is replaced by the clip's own pose + exploration noise, i.e. episodes that last (secondary figure)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -138,7 +153,11 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     env, policy, sampler, std = build_engine(local_rank, 4 + rank, args.threads_per_env)
-    rollout_steps(sampler, args.warmup)
+    a_track = None
+    if args.workload == "tracked":
+        a_track = tracking_action(env)
+        sampler.start()
+    rollout_steps(sampler, args.warmup, a_track)
     env.sim.timing_reset()
 
     def barrier():
@@ -148,7 +167,7 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
-    n_done = rollout_steps(sampler, args.steps)
+    n_done = rollout_steps(sampler, args.steps, a_track)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -177,7 +196,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[2] rollout: kin_poly.yml dynamics-regulated env-step (kin GRU policy, step_ar, target FK, "
                                    "UHC obs+ZFilter+PolicyMCP, 15 substeps SPD+RFC+contact, term/reward, AR obs, auto-reset), standing MoCap clip, "
-                                   "random-init seeded networks", "envs_per_gpu": ENVS_PER_GPU, "substeps": 15, "clip_len": CLIP_LEN,
+                                   "random-init seeded networks" + ("; SECONDARY workload 'tracked': kinematic policy output replaced by the clip pose + N(0, 0.04) noise" if args.workload == "tracked" else ""), "envs_per_gpu": ENVS_PER_GPU, "substeps": 15, "clip_len": CLIP_LEN,
                        "threads_per_env": args.threads_per_env, "parallelism": f"env-sharded x{world}",
                        "gemm_selection": "kinpoly_amd/assets/tunableop_gfx950.csv (rocBLAS / hipBLASLt solution per shape, fp32)" if getattr(build_engine, "tuned", False) else "library default"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
