@@ -171,6 +171,11 @@ int kp_sim_diag(kp_sim*, int32_t* out_host);
  * only: results do not depend on it; measured gain is within noise because an env's cost correlates only 0.6 step to step). */
 int kp_sim_launch_cost(kp_sim*, uint32_t* out_host);
 
+/* the job sizes kp_sim_step_ctrl uses for a control step of n_substeps when it schedules through the job queue (host arithmetic, no
+ * device): sizes16[0 .. return value) sum to n_substeps, the last is substeps_per_job (or absorbs a smaller remainder), earlier
+ * ones grow by 2 with taper.  Returns the number of jobs (<= 16) or a negative error. */
+int kp_job_schedule(int n_substeps, int substeps_per_job, int taper, int* sizes16);
+
 /* seconds the last kp_sim_step_ctrl launch took, measured with HIP events on the sim's stream
  * (synchronises); -1 if none recorded. */
 double kp_sim_last_step_seconds(kp_sim*);

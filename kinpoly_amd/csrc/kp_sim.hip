@@ -166,6 +166,22 @@ bool build_tables(kp_sim* s) {
     return ok;
 }
 
+// Job sizes of kp_step_queue_kernel for a control step of nsub substeps: `spj` substeps for the last job and (taper) two more for each job
+// before it -- the FIFO runs all envs' first jobs, then all second jobs ...: long jobs first keep the hand-overs few, short jobs
+// last keep the end of the launch short -- what is left over becomes the first job (or joins it if shorter than spj); at most 16 jobs.
+// 15 = 7 + 5 + 3.
+int job_schedule(int nsub, int spj, int taper, int* sizes) {
+    int parts = 0, rem = nsub, size = spj;
+    while (rem > 0 && parts < 16) {
+        int take = parts == 15 ? rem : std::min(rem, size);
+        if (rem - take > 0 && rem - take < spj) take = rem;
+        sizes[parts++] = take; rem -= take;
+        if (taper) size += 2;
+    }
+    std::reverse(sizes, sizes + parts);
+    return parts;
+}
+
 int launch_step(kp_sim* s, const float* action, int nsub, const uint8_t* mask, bool time_it) {
     kp::StepArgs A;
     A.T = s->T; A.P = s->P; A.n_envs = s->n; A.n_substeps = nsub;
@@ -203,18 +219,9 @@ int launch_step(kp_sim* s, const float* action, int nsub, const uint8_t* mask, b
     // resident wave per slot (kp_step_queue_kernel) instead of one workgroup per env, which ends on a long tail
     const int spj = s->model->substeps_per_job;
     const int slots = s->model->queue_slots > 0 ? s->model->queue_slots : (obj ? s->wave_slots / 8 * 6 : s->wave_slots);
-    // job sizes: `spj` substeps for the last job, two more for each job before it ("job_taper", 15 = 7 + 5 + 3; the FIFO runs all envs'
-    // first jobs, then all second jobs ...: long jobs first keep the hand-overs few, short jobs last keep the end of the launch short)
     int sizes[16], parts = 0;
     if (spj > 0 && nsub > 0) {
-        int rem = nsub, size = spj;
-        while (rem > 0 && parts < 16) {
-            int take = parts == 15 ? rem : std::min(rem, size);
-            if (rem - take > 0 && rem - take < spj) take = rem;
-            sizes[parts++] = take; rem -= take;
-            if (s->model->job_taper) size += 2;
-        }
-        std::reverse(sizes, sizes + parts);
+        parts = job_schedule(nsub, spj, s->model->job_taper, sizes);
         if (const char* e = std::getenv("KP_JOB_SCHEDULE")) {      // experiments: explicit comma-separated job sizes
             int tmp[16], np = 0, sum = 0;
             for (const char* c = e; *c && np < 16;) { tmp[np] = std::atoi(c); sum += tmp[np++]; while (*c && *c != ',') c++; if (*c) c++; }
@@ -612,6 +619,11 @@ int kp_sim_diag(kp_sim* s, int32_t* out_host) {
     HIP_OK(hipMemcpy(ctr, s->jobctr, sizeof(ctr), hipMemcpyDeviceToHost));
     if (ctr[2]) return fail("kp_step_queue_kernel: a wavefront gave up waiting for a job to be published (job queue stalled); states are incomplete");
     return 0;
+}
+
+int kp_job_schedule(int n_substeps, int substeps_per_job, int taper, int* sizes16) {
+    if (!sizes16 || n_substeps <= 0 || substeps_per_job <= 0 || n_substeps > 255) return fail("kp_job_schedule: need sizes16, 0 < n_substeps <= 255, substeps_per_job > 0");
+    return job_schedule(n_substeps, substeps_per_job, taper, sizes16);
 }
 
 int kp_sim_launch_cost(kp_sim* s, uint32_t* out_host) {

@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "kp_field_dim", "kp_sim_get", "kp_sim_diag", "kp_sim_last_step_seconds", "kp_last_error", "kp_version",
     "kp_sim_step_begin", "kp_sim_obs_ar", "kp_sim_term_reward", "kp_gae", "kp_sim_set_full_state", "kp_sim_fk",
     "kp_sim_timing_reset", "kp_sim_timing_mean_seconds", "kp_sim_phase_cycles", "kp_sim_set_objects", "kp_sim_set_obj_state",
-    "kp_sim_launch_cost",
+    "kp_sim_launch_cost", "kp_job_schedule",
 ]
 
 
@@ -91,6 +91,7 @@ def load_library(path: str | None = None):
     L.kp_sim_timing_reset.argtypes = [P]; L.kp_sim_timing_reset.restype = C.c_int
     L.kp_sim_timing_mean_seconds.argtypes = [P, C.POINTER(C.c_int)]; L.kp_sim_timing_mean_seconds.restype = C.c_double
     L.kp_sim_phase_cycles.argtypes = [P, C.POINTER(C.c_double)]; L.kp_sim_phase_cycles.restype = C.c_int
+    L.kp_job_schedule.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]; L.kp_job_schedule.restype = C.c_int
     L.kp_sim_launch_cost.argtypes = [P, C.c_void_p]; L.kp_sim_launch_cost.restype = C.c_int
     L.kp_sim_set_objects.argtypes = [P, F, U8]; L.kp_sim_set_objects.restype = C.c_int
     L.kp_sim_set_obj_state.argtypes = [P, F, F, U8]; L.kp_sim_set_obj_state.restype = C.c_int
@@ -275,6 +276,16 @@ class KpSim:
 
     def last_step_seconds(self) -> float:
         return self.L.kp_sim_last_step_seconds(self.h)
+
+
+def job_schedule(n_substeps: int, substeps_per_job: int = 3, taper: bool = True) -> list:
+    """Job sizes of the queue-scheduled control step (kp_job_schedule; host arithmetic only)."""
+    L = load_library()
+    out = (C.c_int * 16)()
+    n = L.kp_job_schedule(int(n_substeps), int(substeps_per_job), int(bool(taper)), out)
+    if n < 0:
+        raise KinPolyNativeError(f"kp_job_schedule: {L.kp_last_error().decode()}")
+    return list(out[:n])
 
 
 def gae(rewards: torch.Tensor, masks: torch.Tensor, values: torch.Tensor, gamma: float, tau: float):

@@ -106,3 +106,22 @@ def test_ppo_surrogate_and_log_prob_match_reference(golden):
     ind = torch.tensor(g["exps"]).nonzero(as_tuple=False).squeeze(1)
     loss = ppo_surrogate(new, fixed, t("adv"), float(g["clip_epsilon"]), ind)
     assert abs(float(loss) - float(g["loss"])) < 1e-10
+
+
+def test_job_schedule_host_logic():
+    """kp_job_schedule (host arithmetic of the queue-scheduled control step): sizes sum to the control step, at most 16 jobs, the
+    last job is substeps_per_job long unless the whole step is shorter, tapered sizes never grow towards the end."""
+    from kinpoly_amd import sim as kpsim
+    assert kpsim.job_schedule(15, 3, True) == [7, 5, 3]
+    assert kpsim.job_schedule(15, 3, False) == [3, 3, 3, 3, 3]
+    assert kpsim.job_schedule(15, 16, True) == [15]
+    for nsub in (1, 2, 7, 15, 16, 30, 100, 255):
+        for spj in (1, 2, 3, 5, 8):
+            for taper in (False, True):
+                sz = kpsim.job_schedule(nsub, spj, taper)
+                assert sum(sz) == nsub and 1 <= len(sz) <= 16 and min(sz) >= 1
+                assert sz[-1] == spj or len(sz) == 1 or len(sz) == 16
+                if taper and len(sz) > 2:
+                    assert all(a >= b for a, b in zip(sz[1:], sz[2:]))
+    with pytest.raises(kpsim.KinPolyNativeError):
+        kpsim.job_schedule(0, 3, True)
