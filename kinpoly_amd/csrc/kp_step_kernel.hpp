@@ -364,11 +364,11 @@ __device__ __forceinline__ float aba_fwd3(EnvLds& s, const Lane8& L, float* out,
 }
 
 // root->leaves pass: joint accelerations from (U, 1/D, u) and the parent's spatial acceleration; leaves them in sv
-__device__ __forceinline__ void aba_forward(EnvLds& s, const Lane8& L, float* out) {
+__device__ __forceinline__ void aba_forward(EnvLds& s, const Lane8& L, float* out, int lev_max = D_NLEV - 1) {
     const int r = L.r;
     const bool rowok = r < 6;
 #pragma nounroll
-    for (int lev = 0; lev < D_NLEV; lev++) {
+    for (int lev = 0; lev <= lev_max; lev++) {
         const int sh = 5 * lev;
         const int bq = (int)((L.sb >> sh) & 31ull), par = (int)((L.sp >> sh) & 31ull);
         const bool active = bq != 31;
@@ -483,13 +483,19 @@ __device__ __forceinline__ void aba_solve(EnvLds& s, const Params& P, const Lane
 
 // out = H^-1 (rhs + J_body^T wrench) with the factorisation (U, 1/D) the last aba_solve left in LDS: the bias-force half of the
 // leaves->root pass only (no inertia updates), then the usual root->leaves pass.  rhs / wrench ([24][6], about o) may be null.
-__device__ __forceinline__ void aba_resolve(EnvLds& s, const Lane8& L, const float* rhs, const float* wrench, float* out) {
+// lev_max < D_NLEV - 1: the caller knows that rhs and wrench vanish on every body below tree level lev_max and only needs the
+// accelerations (sv) / out entries down to that level: the deeper levels would carry exact zeros up and are skipped in both halves.
+__device__ __forceinline__ void aba_resolve(EnvLds& s, const Lane8& L, const float* rhs, const float* wrench, float* out, int lev_max = D_NLEV - 1) {
     const int r = L.r;
     const bool rowok = r < 6;
     const int rc = rowok ? r : 5;
     const float rmask = rowok ? 1.f : 0.f;
+    if (lev_max < D_NLEV - 1) {            // the skipped children hand up zero bias forces
+        for (int i = threadIdx.x; i < 24 * 6; i += 64) s.pAa[i] = 0.f;
+        KP_SYNC();
+    }
 #pragma nounroll
-    for (int lev = D_NLEV - 1; lev >= 0; lev--) {
+    for (int lev = lev_max; lev >= 0; lev--) {
         const int sh = 5 * lev;
         const int bq = (int)((L.sb >> sh) & 31ull), c0 = (int)((L.sc0 >> sh) & 31ull), c1 = (int)((L.sc1 >> sh) & 31ull), c2 = (int)((L.sc2 >> sh) & 31ull);
         const bool active = bq != 31;
@@ -517,7 +523,7 @@ __device__ __forceinline__ void aba_resolve(EnvLds& s, const Lane8& L, const flo
         if (active && rowok) s.pAa[6 * b + r] = pA;
         KP_SYNC();
     }
-    aba_forward(s, L, out);
+    aba_forward(s, L, out, lev_max);
 }
 
 // ---------------------------------------------------------------- stable-PD torque + residual force (reference controller)
@@ -1423,8 +1429,10 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
         const bool refactor = it == 0 || changed > 0.f;
         nfact += refactor;
         int cslot = -1;                                   // object slot this lane's hull contact presses on with an active row
+        float cdep = 0.f;                                 // deepest tree level of a hull that touches an object
         for (int c = tid; c < s.con_start[D_NB]; c += NT) {
             if (s.con_b2[c] < D_NB) continue;
+            cdep = fmaxf(cdep, (float)s.bdep[s.con_body[c]]);
             const float jn = s.jar3[3 * c], jt1 = s.jar3[3 * c + 1], jt2 = s.jar3[3 * c + 2];
             bool act = false;
 #pragma unroll
@@ -1433,6 +1441,7 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
         }
         const unsigned cmask = (__ballot(cslot == 0) != 0ull ? 1u : 0u) | (__ballot(cslot == 1) != 0ull ? 2u : 0u);
         const bool couple = cmask != 0u;
+        const int lev_cpl = (int)(-wave_min(-cdep));     // Schur-complement columns only load, and are only read at, bodies down to here
         // H = [[H_hh, H_ho], [H_oh, H_oo]] by block elimination.  refactor: one articulated-body factorisation of H_hh (+ the object
         // rows); the passes below only push right-hand sides through it (pass -1: y0 when the factors are reused, passes 0..n-1:
         // the Schur-complement columns when a hull touches an object, pass n: the back-substitution)
@@ -1461,7 +1470,7 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
                     hull_coupling_wrench(s, P, -1, s.osrch, 1.0f, tid);         // -H_ho da
                     rhsp = s.x; wr = s.sw; outp = s.search;
                 }
-                aba_resolve(s, L8, rhsp, wr, outp);
+                aba_resolve(s, L8, rhsp, wr, outp, (kj >= 0 && kj < no6) ? lev_cpl : D_NLEV - 1);
                 if (kj == no6) break;
                 if (kj == -1) {
                     if (no6 == 0) break;
