@@ -41,7 +41,7 @@ for e in range(n):
     lift = rng.uniform(0, 0.25) if rng.uniform() < 0.5 else 0.0
     tilt = rquat(0.25 if rng.uniform() < 0.5 else 0.0)
     for oi, (lx, ly, lz) in zip(obj_of_action[a], nominal[a]):
-        objs[oi] = [x0 + lx + shift[0], y0 + ly + shift[1], lz + lift + 0.0005, *tilt]
+        objs[oi] = [x0 + lx + shift[0], y0 + ly + shift[1], lz + lift + 0.0003, *tilt]   # 0.3 mm: clear of the knife edge dist == margin (the table rests 0.5 mm above its nominal height)
         blk[e, 7 * oi: 7 * oi + 7] = objs[oi]
     if a == 3:
         qpos[e, 2] += 0.341 + lift + 0.02
