@@ -79,6 +79,11 @@ int kp_sim_set_objects(kp_sim*, const float* obj_qpos, const uint8_t* env_mask);
  * normalised), wbpos [n_rows,72], wbquat [n_rows,96], bquat [n_rows,96], body_com [n_rows,72]; outputs may be NULL. */
 int kp_sim_fk(kp_sim*, int n_rows, const float* qpos, float* qpos_out, float* wbpos, float* wbquat, float* bquat, float* body_com);
 
+/* backward of qpos -> wbpos of the same rows (the autograd path through Humanoid.qpos_fk that TrajARNet.compute_loss_lite's
+ * end-effector term takes, traj_ar_smpl_net.py:459-497, torch_smpl_humanoid.py:125-202): grad_qpos [n_rows,76] =
+ * (d wbpos / d qpos)^T grad_wbpos [n_rows,72]; wbpos / wbquat are the outputs of the kp_sim_fk call on those rows. */
+int kp_sim_fk_backward(kp_sim*, int n_rows, const float* qpos, const float* wbpos, const float* wbquat, const float* grad_wbpos, float* grad_qpos);
+
 /* HumanoidEnv.do_simulation(cc_action, n_substeps)   (humanoid_im.py:506-533): per substep stable-PD
  * torque (compute_torque :433-480), clip, rfc_implicit (:497-504), sim.step() (:527).  cc_action [N,75]. */
 int kp_sim_step_ctrl(kp_sim*, const float* cc_action, int n_substeps, const uint8_t* env_mask);

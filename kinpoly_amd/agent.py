@@ -44,7 +44,7 @@ class AgentAR:
         self.trainer = PPOTrainer(self.policy_net, self.value_net, gamma, tau, clip_epsilon, policy_lr, value_lr, num_optim_epoch)
         self.opt_sup = torch.optim.Adam([p for p in self.policy_net.parameters() if p.requires_grad], lr=supervised_lr)
         kpm = read_kpm(kpsim.DEFAULT_KPM)
-        self.fk = TorchFK(kpm["body_pos"], kpm["body_parent"], self.device)
+        self.fk = TorchFK(kpm["body_pos"], kpm["body_parent"], self.device, sim=self.kin_sim)   # HIP forward / backward kernels for the loss FK
         self.sampler = VectorSampler(self.env, self.policy_net, record_qpos=True)
         self.epoch = 0
         self._new_episodes()

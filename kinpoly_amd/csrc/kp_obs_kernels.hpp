@@ -135,6 +135,55 @@ __global__ __launch_bounds__(256) void k_target_fk(int n, const float* __restric
     }
 }
 
+// ---------------------------------------------------------------- backward of qpos -> wbpos (the end-effector term of compute_loss_lite)
+// grad_qpos = (d wbpos / d qpos)^T grad_wbpos for the rows of a k_target_fk call (its wbpos / wbquat outputs are the saved forward state).
+// A hinge of body b turns the strict descendants of b about pos_b, so with F_b = sum g_j and M_b = sum (pos_j - pos_b) x g_j over
+// them: d/d theta_k = a_k . M_b (a_k = world axis of the hinge: R_p e_z, R_p Rz e_y, R_p Rz Ry e_x for the 'rzyx' order);
+// root translation = sum of all g_j; root rotation, parametrised by the raw quaternion q (normalised inside the forward pass):
+// torque tau = M_0 about pos_0 -> gradient (0, 2 tau) (x) u / |q| with u = q / |q|.  One wave per row, lane = body.
+__global__ __launch_bounds__(256) void k_fk_wbpos_grad(int n, const float* __restrict__ qpos, const float* __restrict__ wbpos, const float* __restrict__ wbquat,
+                                                        const float* __restrict__ gw, float* __restrict__ gq, const int8_t* __restrict__ parent,
+                                                        const uint8_t* __restrict__ subtree) {
+    __shared__ float sp[4][D_NB * 3], sg[4][D_NB * 3];
+    const int w = threadIdx.x >> 6, b = threadIdx.x & 63;
+    const int e = blockIdx.x * 4 + w;
+    const bool live = e < n;
+    if (live && b < D_NB) {
+        st3(sp[w] + 3 * b, ld3(wbpos + (size_t)e * 72 + 3 * b));
+        st3(sg[w] + 3 * b, ld3(gw + (size_t)e * 72 + 3 * b));
+    }
+    __syncthreads();
+    if (!live || b >= D_NB) return;
+    const V3 pb = ld3(sp[w] + 3 * b);
+    V3 F = v3(0.f, 0.f, 0.f), M = v3(0.f, 0.f, 0.f);
+    const int nb = subtree[b];
+    for (int j = b + 1; j < b + nb; j++) {
+        const V3 g = ld3(sg[w] + 3 * j);
+        F = F + g; M = M + cross(ld3(sp[w] + 3 * j) - pb, g);
+    }
+    const float* q = qpos + (size_t)e * D_NQ;
+    float* o = gq + (size_t)e * D_NQ;
+    if (b == 0) {
+        st3(o, F + ld3(sg[w]));
+        const float qn = sqrtf(q[3] * q[3] + q[4] * q[4] + q[5] * q[5] + q[6] * q[6]);
+        const float* uq = wbquat + (size_t)e * 96;
+        const Q4 G = qmul(Q4{0.f, 2.f * M.x, 2.f * M.y, 2.f * M.z}, Q4{uq[0], uq[1], uq[2], uq[3]});
+        o[3] = G.w / qn; o[4] = G.x / qn; o[5] = G.y / qn; o[6] = G.z / qn;
+    } else {
+        const int p = parent[b];
+        const float* pq = wbquat + (size_t)e * 96 + 4 * p;
+        float R[9];
+        q_matrix(Q4{pq[0], pq[1], pq[2], pq[3]}, R);
+        const float tz = q[7 + 3 * (b - 1)], ty = q[8 + 3 * (b - 1)];
+        float sz, cz, sy, cy;
+        sincosf(tz, &sz, &cz); sincosf(ty, &sy, &cy);
+        const V3 az = mulmat(R, v3(0.f, 0.f, 1.f));
+        const V3 ay = mulmat(R, v3(-sz, cz, 0.f));                  // Rz e_y
+        const V3 ax = mulmat(R, v3(cz * cy, sz * cy, -sy));         // Rz Ry e_x
+        o[7 + 3 * (b - 1)] = dot(az, M); o[8 + 3 * (b - 1)] = dot(ay, M); o[9 + 3 * (b - 1)] = dot(ax, M);
+    }
+}
+
 // ---------------------------------------------------------------- get_body_quat: thread per (env, body)
 __global__ void k_bquat(int n, const float* __restrict__ qpos, float* __restrict__ out) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;

@@ -460,6 +460,15 @@ int kp_sim_fk(kp_sim* s, int n_rows, const float* qpos, float* qpos_out, float* 
     return 0;
 }
 
+int kp_sim_fk_backward(kp_sim* s, int n_rows, const float* qpos, const float* wbpos, const float* wbquat, const float* grad_wbpos, float* grad_qpos) {
+    if (!s || !qpos || !wbpos || !wbquat || !grad_wbpos || !grad_qpos || n_rows <= 0) return fail("kp_sim_fk_backward: bad arguments");
+    HIP_OK(hipSetDevice(s->device));
+    hipLaunchKernelGGL(kp::k_fk_wbpos_grad, dim3((n_rows + 3) / 4), dim3(256), 0, s->stream, n_rows, qpos, wbpos, wbquat, grad_wbpos, grad_qpos,
+                       s->T.body_parent, s->T.body_subtree);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
 int kp_sim_step_ctrl(kp_sim* s, const float* action, int nsub, const uint8_t* mask) {
     if (!s || !action || nsub <= 0) return fail("kp_sim_step_ctrl: bad arguments");
     HIP_OK(hipSetDevice(s->device));

