@@ -21,7 +21,7 @@ from . import sim as kpsim
 from .context import PolicyARContext, TrajARNet
 from .env import BatchedHumanoidAREnv
 from .model_compiler import read_kpm
-from .nets import MLP, Value
+from .nets import MLP, Value, enable_tuned_gemms
 from .rollout import PPOTrainer, VectorSampler, _allreduce_grads
 from .supervised import TorchFK, update_supervised_step
 
@@ -31,6 +31,7 @@ class AgentAR:
                  policy_lr=1e-5, value_lr=3e-4, supervised_lr=5e-4, num_optim_epoch=10, num_step_update=20, gamma=0.95, tau=0.95,
                  clip_epsilon=0.2, rl_update=True, step_update=True, model_options=None):
         rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+        enable_tuned_gemms()          # library GEMM solution per shape (rollout and update shapes at 4096 envs); selection only
         torch.manual_seed(seed + rank)
         self.env = BatchedHumanoidAREnv(n_envs, device, mode="train", wild=wild, seed=seed + rank, model_options=model_options)
         self.device = self.env.device
