@@ -228,7 +228,7 @@ int launch_step(kp_sim* s, const float* action, int nsub, const uint8_t* mask, b
             if (sum == nsub) { parts = np; std::copy(tmp, tmp + np, sizes); }
         }
     }
-    const bool queue = nsub > 0 && parts > 1 && s->model->threads == 64 && s->n > slots && !s->prof && !A.order;
+    const bool queue = nsub > 0 && parts > 1 && s->model->threads == 64 && s->n > slots && s->n <= 0xFFFFFF && !s->prof && !A.order;   // env ids take 24 bits of a queue entry
     A.jobq = s->jobq; A.jobctr = s->jobctr; A.n_parts = queue ? parts : 1;
     A.part_sub_lo = A.part_sub_hi = 0;
     for (int k = 0; queue && k < parts; k++) (k < 8 ? A.part_sub_lo : A.part_sub_hi) |= (unsigned long long)(sizes[k] & 255) << (8 * (k & 7));
