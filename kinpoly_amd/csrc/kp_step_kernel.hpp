@@ -18,7 +18,11 @@
 //   * J v is read off the spatial accelerations the ABA forward pass leaves behind, J^T f and M v are a
 //     body-wrench subtree sum projected on the dofs; the solver's Gauss term lives in body form (spatial
 //     accelerations), so one projection per Newton iteration suffices;
-//   * Newton factorisations reuse the smooth solve's factors on the tree levels no active constraint reaches.
+//   * Newton factorisations reuse the smooth solve's factors on the tree levels no active constraint reaches;
+//   * the RNE bias forces are never projected on the dofs: they stay body wrenches and enter the passes as articulated bias force.
+// Launch forms: kp_step_kernel (one workgroup = one wavefront per env and control step), kp_forward_kernel (sim.forward() only) and
+// kp_step_queue_kernel (the same step_body run by resident wavefronts that pull (env, few substeps) jobs from a FIFO in HBM, used
+// when there are more envs than wavefront slots; bit-identical results).
 #pragma once
 #include <type_traits>
 
