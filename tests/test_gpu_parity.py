@@ -607,3 +607,38 @@ def test_lying_many_contacts_and_joint_limits(kp):
     assert max(c[0] for c in ncs) >= 30 and max(nlims) >= 1
     # equally deep vertices on flat hull faces can swap between fp32 and fp64 (different 3-vertex set): bounded, not bit-level
     assert max(errs) < 1e-3 and np.median(errs) < 5e-5
+
+
+def test_c_abi_from_plain_cpp(kp):
+    """examples/c_abi_demo (C++, no Python, no torch: kp_model_load .. kp_sim_step_ctrl .. kp_sim_get through the shared library)
+    gives the same state as the ctypes binding on the same seeded inputs."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "c_abi_demo")
+    assert os.path.exists(exe), "examples/c_abi_demo is built by __graft_entry__.build()"
+    n, steps = 256, 3
+    out = subprocess.run([exe, DEFAULT_KPM, os.path.join(root, "tests", "golden", "standing_neutral_qpos.f32"), str(n), str(steps)],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    m = re.search(r"qpos checksum ([-0-9.]+), lowest root height ([-0-9.]+), contacts/env ([0-9.]+), non-finite (\d+)", out.stdout)
+    assert m, out.stdout
+    # the same inputs through the Python binding: the demo's LCG, in numpy
+    q0 = np.fromfile(os.path.join(root, "tests", "golden", "standing_neutral_qpos.f32"), np.float32)
+    qpos = np.tile(q0, (n, 1)).astype(np.float32)
+    rng = np.uint32(12345)
+    with np.errstate(over="ignore"):
+        for e in range(n):
+            for i in range(76):
+                rng = np.uint32(rng * np.uint32(1664525) + np.uint32(1013904223))
+                u = np.float32(np.float32(rng >> np.uint32(8)) * np.float32(1.0 / 16777216.0) - np.float32(0.5))
+                if i >= 7:
+                    qpos[e, i] = np.float32(q0[i] + np.float32(0.05) * u)
+    sim = kp.KpSim(kp.KpModel(), n)
+    q = torch.tensor(qpos, device="cuda")
+    sim.set_state(q, torch.zeros((n, 75), device="cuda")); sim.set_target(q.clone())
+    a = torch.zeros((n, 75), device="cuda")
+    for _ in range(steps):
+        sim.step_ctrl(a, 15)
+    got = sim.get("qpos").double().cpu().numpy()
+    assert abs(float(m.group(1)) - got.sum()) < 2e-2 and abs(float(m.group(2)) - got[:, 2].min()) < 1e-4 and int(m.group(4)) == 0
