@@ -244,6 +244,22 @@ def main():
             "launch_balance": {"substeps_per_job": int(env.model.get_option("substeps_per_job")), "sum_env_cycles_over_2048_slots_ms": float(cost.sum() / 2048 / 2.38e6),
                                "longest_env_ms": float(cost.max() / 2.38e6), "median_env_ms": float(np.median(cost) / 2.38e6)},
         }
+        if world == 1 and args.workload == "random_init":
+            # secondary figure (not the metric): the same step with episodes that last -- see --workload tracked
+            try:
+                a_tr = tracking_action(env)
+                sampler.start()
+                rollout_steps(sampler, 20, a_tr)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                nd = rollout_steps(sampler, 60, a_tr)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t1
+                out["secondary_tracked_workload"] = {"value": ENVS_PER_GPU * 60 / dt, "unit": "env-steps/s", "ms_per_step": dt / 60 * 1e3, "steps": 60, "warmup": 20,
+                                                     "episodes_ended_per_step_frac": float(nd.item()) / (ENVS_PER_GPU * 60),
+                                                     "note": "kinematic policy output replaced by the clip pose + N(0, e^-3.2) noise (its GEMMs still run): what a pretrained policy emits"}
+            except Exception as ex:
+                out["secondary_tracked_workload"] = {"error": type(ex).__name__}
         if world == 1 and not args.no_cpu_baseline:
             workers = min(35, os.cpu_count() or 1)
             try:
