@@ -3,8 +3,12 @@
 (kin_poly/models/traj_ar_smpl_net.py:157-201, 346-383).
 
 Per episode the reference (i) runs a context GRU over the whole clip and predicts the initial pose / velocity,
-(ii) rolls the kinematic policy over the whole clip (T GRU steps + T forward-kinematics calls), (iii) smooths the
-rolled-out joint angles with a Gaussian (sigma = 1 frame) and re-runs FK.  Here all N environments' clips go
+(ii) rolls the kinematic policy over the whole clip (T GRU steps + T forward-kinematics calls), (iii) "smooths" the
+roll-out and re-runs FK.  NOTE on (iii): with `cfg.smooth` the reference executes
+`ar_qpos[:, 7:] = gaussian_filter1d(ar_qpos[:, 7:], 1, axis=0)` on a `[1, T, 76]` tensor (policy_ar.py:150-152): the slice takes
+FRAMES 7.. (not joint columns) and the filter runs along the length-1 batch axis, which leaves every value unchanged
+(fixture `smooth_effective.npz`, generated with the reference's statement).  The default here reproduces that effective
+behaviour (ar_qpos untouched); `smooth_time_axis=True` is the documented deviation that really smooths the joint angles in time.  Here all N environments' clips go
 through these three stages together: the GRUs are [N, .] GEMMs, and the kinematic roll-out reuses the HIP
 kernels of the rollout path (`step_kin`, forward kinematics, `obs_ar`) on a second, physics-free `KpSim`.
 
@@ -149,8 +153,10 @@ class TrajARNet(KinPolicy):
 class PolicyARContext:
     """`PolicyAR.init_context` for N episodes at once -> the `ar_context` tensors the env consumes."""
 
-    def __init__(self, net: TrajARNet, kin_sim: kpsim.KpSim, smooth: bool = True):
-        self.net, self.kin_sim, self.smooth = net, kin_sim, smooth
+    def __init__(self, net: TrajARNet, kin_sim: kpsim.KpSim, smooth: bool = True, smooth_time_axis: bool = False):
+        # smooth = cfg.smooth (kin_poly.yml:19): selects the branch of init_context (fix_height + FK of ar_qpos);
+        # smooth_time_axis: deviation from the reference, see the module docstring
+        self.net, self.kin_sim, self.smooth, self.smooth_time_axis = net, kin_sim, smooth, smooth_time_axis
 
     @torch.no_grad()
     def init_context(self, data: dict, fix_height: bool = False) -> dict:
@@ -165,7 +171,8 @@ class PolicyARContext:
                 fk = self.kin_sim.fk(out["init_qpos"])
                 feet = torch.minimum(fk["wbpos"].view(N, 24, 3)[:, 4, 2], fk["wbpos"].view(N, 24, 3)[:, 8, 2]) - begin_feet_offset
                 out["init_qpos"] = torch.cat([out["init_qpos"][:, :2], (out["init_qpos"][:, 2] - feet)[:, None], out["init_qpos"][:, 3:]], 1).contiguous()
-            ar_qpos = torch.cat([ar_qpos[:, :, :7], gaussian_filter1d_time(ar_qpos[:, :, 7:], 1.0)], 2)
+            if self.smooth_time_axis:      # NOT what the reference computes (its filter call is a no-op, module docstring)
+                ar_qpos = torch.cat([ar_qpos[:, :, :7], gaussian_filter1d_time(ar_qpos[:, :, 7:], 1.0)], 2)
             if fix_height:
                 fk = self.kin_sim.fk(ar_qpos.reshape(-1, 76).contiguous())
                 wb = fk["wbpos"].view(N, T, 24, 3)

@@ -41,6 +41,17 @@ def test_gaussian_smoothing_matches_scipy(golden):
     np.testing.assert_allclose(y, g["y"], rtol=1e-12, atol=1e-13)
 
 
+def test_reference_smoothing_statement_is_a_noop(golden):
+    """PolicyAR.init_context's `ar_qpos[:, 7:] = gaussian_filter1d(ar_qpos[:, 7:], 1, axis=0)` on its [1, T, 76] tensor
+    (policy_ar.py:150-152) filters a length-1 axis: the fixture holds that statement's input and output."""
+    g = golden("smooth_effective")
+    assert g["x"].shape[0] == 1 and g["x"].shape[2] == 76
+    np.testing.assert_allclose(g["y"], g["x"], rtol=0, atol=1e-15)
+    import inspect
+    from kinpoly_amd.context import PolicyARContext
+    assert inspect.signature(PolicyARContext.__init__).parameters["smooth_time_axis"].default is False
+
+
 def test_qvel_fd_consistent_with_fixture_rollout(golden):
     """ar_qvel of the reference roll-out is get_qvel_fd_batch of consecutive ar_qpos (after fix_qvel)."""
     from kinpoly_amd.context import get_qvel_fd_batch

@@ -356,6 +356,11 @@ def gen_traj_ar_net(hum):
     from scipy.ndimage import gaussian_filter1d
     x = rng.normal(size=(12, 69))
     np.savez(os.path.join(OUT, "smooth.npz"), x=x, y=gaussian_filter1d(x, 1, axis=0))
+    # the statement PolicyAR.init_context really executes (policy_ar.py:150-152) on its [1, T, 76] roll-out tensor
+    ar_qpos = torch.tensor(rng.normal(size=(1, 20, 76)))
+    x_eff = ar_qpos.numpy().copy()
+    ar_qpos[:, 7:] = torch.from_numpy(gaussian_filter1d(ar_qpos[:, 7:].cpu(), 1, axis=0))
+    np.savez(os.path.join(OUT, "smooth_effective.npz"), x=x_eff, y=ar_qpos.numpy())
 
 
 def gen_loss_and_checkpoint(hum):
