@@ -42,8 +42,8 @@ typedef struct kp_sim kp_sim;
 kp_model* kp_model_load(const char* kpm_path);
 void kp_model_free(kp_model*);
 /* options: "contact" (0/1), "limits" (0/1), "gravity_z", "stale_kinematics" (0/1, default 1: SPD and
- * read-outs see the one-substep-stale derived quantities mujoco-py exposes), "solver_iter",
- * "solver_tol", "threads_per_env" (64/128/256), "dynamic_objects" (0/1);
+ * read-outs see the one-substep-stale derived quantities mujoco-py exposes), "solver_iter" (default: the blob's
+ * mjOption.iterations = 100; cap hits are counted in kp_sim_diag), "solver_tol", "threads_per_env" (64/128/256), "dynamic_objects" (0/1);
  * scheduling only (results do not depend on them): "substeps_per_job" (default 3; 0 = one workgroup per env and control step):
  * with more envs than resident wavefront slots a control step is cut into jobs of that many substeps (the last job; with "job_taper"
  * = 1, the default, each earlier job is two substeps longer: 15 = 7 + 5 + 3) which resident waves pull from a FIFO, so that the
@@ -57,6 +57,20 @@ double kp_model_get_option(const kp_model*, const char* name);
 kp_sim* kp_sim_create(const kp_model*, int n_envs, int device_id, void* hip_stream);
 void kp_sim_destroy(kp_sim*);
 int kp_sim_n_envs(const kp_sim*);
+
+/* Rebind the HIP stream all later calls enqueue on (kp_sim_create's stream otherwise).  The caller orders the two streams
+ * (e.g. an event) if work is still in flight on the old one. */
+int kp_sim_set_stream(kp_sim*, void* hip_stream);
+
+/* Device pointer to uint32[4] the control-step launches maintain: [2] != 0 means a kp_step_queue_kernel launch stalled (a wave gave
+ * up waiting for a job; sticky until the next kp_sim_diag reports it) -- a rollout loop can fold it into its own device-side
+ * checks without a host sync.  [0], [1] are the queue's head / tail counters of the last launch. */
+const uint32_t* kp_sim_status_device(kp_sim*);
+
+/* mjf.mj_fullM(model, M, data.qM) and data.qfrc_bias as compute_desired_accel reads them (uhc/envs/humanoid_im.py:422-426):
+ * M [N,75,75] (dense, symmetric, armature on the diagonal), bias [N,75]; either may be NULL.  The simulator never forms them
+ * on the hot path (matrix-free solves); this read-out is for callers of the reference surface.  Same data as KP_M / KP_BIAS. */
+int kp_sim_mass_matrix(kp_sim*, float* M, float* bias);
 
 /* sim.reset() + set_state(qpos, qvel) + sim.forward()   (mujoco_env.py:86-103) for the masked envs.
  * qpos [N,76], qvel [N,75]. */
@@ -161,13 +175,18 @@ typedef enum {
     KP_PREV_BQUAT = 14, /* env.prev_bquat                    [N,96] */
     KP_PREV_HPOS = 15,  /* env.prev_hpos                     [N,7]  */
     KP_OBJ_QPOS = 16,   /* get_obj_qpos() = data.qpos[76:111] [N,35]  (simulated poses of the active objects) */
-    KP_OBJ_QVEL = 17    /* get_obj_qvel() = data.qvel[75:105] [N,30] */
+    KP_OBJ_QVEL = 17,   /* get_obj_qvel() = data.qvel[75:105] [N,30] */
+    KP_M = 18,          /* mj_fullM(model, M, data.qM)[:75,:75]   [N,75*75] row-major, armature included (humanoid_im.py:422-425);
+                           of the state the derived quantities belong to (KP_QPOS_D), like mujoco-py's data.qM between steps */
+    KP_BIAS = 19        /* data.qfrc_bias[:75]               [N,75]  (humanoid_im.py:426), same state */
 } kp_field;
 int kp_field_dim(int field);
 int kp_sim_get(kp_sim*, int field, float* out);
 
 /* per-env diagnostics of the last kp_sim_step_ctrl: int32 [N,4] = {contacts in last substep,
- * Newton iterations (sum over substeps), flags (1 = non-finite state), max contacts | Hessian factorisations << 8}.  HOST pointer;
+ * Newton iterations (sum over substeps), flags (bit 0 = non-finite state) | number of substeps whose Newton solve stopped at the
+ * iteration cap ("solver_iter", default mjOption.iterations = 100) instead of a termination test << 8,
+ * max contacts | Hessian factorisations << 8}.  HOST pointer;
  * synchronises the stream.  Fails if the job queue of the last launch stalled (never observed; see kp_step_queue_kernel). */
 int kp_sim_diag(kp_sim*, int32_t* out_host);
 

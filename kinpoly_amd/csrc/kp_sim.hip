@@ -24,8 +24,8 @@ int fail(const std::string& m) { g_err = m; return -1; }
 
 struct kp_model {
     kp::HostModel h;
-    int contact = 1, limits = 1, stale = 1, solver_iter = 12, threads = 64, dynamic_objects = 1, lpt_order = 0, substeps_per_job = 3, queue_slots = 0, job_taper = 1;
-    double solver_tol = 1e-8, gravity_z = -9.81;   // solver_tol: mjOption.tolerance of the reference model (kp_model_load)
+    int contact = 1, limits = 1, stale = 1, solver_iter = 100, threads = 64, dynamic_objects = 1, lpt_order = 0, substeps_per_job = 3, queue_slots = 0, job_taper = 1;
+    double solver_tol = 1e-8, gravity_z = -9.81;   // solver_iter / solver_tol: mjOption.iterations / tolerance of the reference model (kp_model_load)
 };
 
 struct kp_sim {
@@ -234,8 +234,7 @@ int launch_step(kp_sim* s, const float* action, int nsub, const uint8_t* mask, b
     for (int k = 0; queue && k < parts; k++) (k < 8 ? A.part_sub_lo : A.part_sub_hi) |= (unsigned long long)(sizes[k] & 255) << (8 * (k & 7));
     if (queue) {
         const unsigned total = (unsigned)s->n * (unsigned)parts;
-        hipLaunchKernelGGL(kp::k_queue_init, dim3((total + 255) / 256), dim3(256), 0, s->stream, s->n, total, s->jobq, s->jobctr);
-        if (time_it) HIP_OK(hipEventRecord(e0, s->stream));
+        hipLaunchKernelGGL(kp::k_queue_init, dim3((total + 255) / 256), dim3(256), 0, s->stream, s->n, total, s->jobq, s->jobctr);   // inside the timed bracket
         if (obj) hipLaunchKernelGGL((kp::kp_step_queue_kernel<true>), dim3(slots), dim3(64), lds, s->stream, A);
         else hipLaunchKernelGGL((kp::kp_step_queue_kernel<false>), dim3(slots), dim3(64), lds, s->stream, A);
     } else
@@ -270,6 +269,8 @@ kp_model* kp_model_load(const char* path) {
     if (!kp::load_kpm(path, m->h)) { fail("kp_model_load: " + m->h.error); delete m; return nullptr; }
     m->gravity_z = m->h.opt[kp::OPT_GZ];
     m->solver_tol = m->h.opt[kp::OPT_SOLVER_TOL];
+    m->solver_iter = (int)m->h.opt[kp::OPT_SOLVER_ITER];      // 100: MuJoCo's default, which the reference never overrides
+    if (m->solver_iter < 1) m->solver_iter = 100;
     return m;
 }
 void kp_model_free(kp_model* m) { delete m; }
@@ -362,6 +363,25 @@ void kp_sim_destroy(kp_sim* s) {
     delete s;
 }
 int kp_sim_n_envs(const kp_sim* s) { return s ? s->n : -1; }
+
+int kp_sim_set_stream(kp_sim* s, void* stream) {
+    if (!s) return fail("kp_sim_set_stream: null argument");
+    s->stream = (hipStream_t)stream;
+    return 0;
+}
+
+const uint32_t* kp_sim_status_device(kp_sim* s) { return s ? s->jobctr : nullptr; }
+
+int kp_sim_mass_matrix(kp_sim* s, float* M, float* bias) {
+    if (!s || (!M && !bias)) return fail("kp_sim_mass_matrix: null argument");
+    HIP_OK(hipSetDevice(s->device));
+    kp::StepArgs A{};
+    A.T = s->T; A.P = s->P; A.n_envs = s->n; A.n_substeps = 0;
+    A.qpos_d = s->qpos_d; A.qvel_d = s->qvel_d;
+    hipLaunchKernelGGL(kp::kp_mass_kernel, dim3(s->n), dim3(64), sizeof(kp::EnvLds), s->stream, A, M, bias);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
 
 // masked row copy kernel (set_state writes only the masked envs)
 __global__ void k_copy_rows(int n, int dim, const float* __restrict__ src, float* __restrict__ dst, float* __restrict__ dst2,
@@ -506,6 +526,8 @@ int kp_field_dim(int f) {
         case KP_HEAD: case KP_PREV_HPOS: return 7;
         case KP_OBJ_QPOS: return 35;
         case KP_OBJ_QVEL: return 30;
+        case KP_M: return 75 * 75;
+        case KP_BIAS: return 75;
         default: return -1;
     }
 }
@@ -543,6 +565,8 @@ int kp_sim_get(kp_sim* s, int field, float* out) {
             hipLaunchKernelGGL(kp::k_bquat, dim3((s->n * 24 + 255) / 256), dim3(256), 0, s->stream, s->n, s->qpos, out);
             HIP_OK(hipGetLastError());
             return 0;
+        case KP_M: return kp_sim_mass_matrix(s, out, nullptr);
+        case KP_BIAS: return kp_sim_mass_matrix(s, nullptr, out);
         case KP_HEAD:
             hipLaunchKernelGGL(k_head, dim3((s->n + 255) / 256), dim3(256), 0, s->stream, s->n, s->xpos, s->xquat, out);
             HIP_OK(hipGetLastError());
@@ -626,7 +650,10 @@ int kp_sim_diag(kp_sim* s, int32_t* out_host) {
     HIP_OK(hipMemcpy(out_host, s->diag, sizeof(int) * 4 * (size_t)s->n, hipMemcpyDeviceToHost));
     unsigned ctr[4] = {0, 0, 0, 0};
     HIP_OK(hipMemcpy(ctr, s->jobctr, sizeof(ctr), hipMemcpyDeviceToHost));
-    if (ctr[2]) return fail("kp_step_queue_kernel: a wavefront gave up waiting for a job to be published (job queue stalled); states are incomplete");
+    if (ctr[2]) {
+        hipMemset(s->jobctr + 2, 0, sizeof(unsigned));     // reported once
+        return fail("kp_step_queue_kernel: a wavefront gave up waiting for a job to be published (job queue stalled); states are incomplete");
+    }
     return 0;
 }
 

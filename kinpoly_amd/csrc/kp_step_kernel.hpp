@@ -42,7 +42,7 @@ struct StepArgs {
     const uint8_t* env_mask;  // optional: envs with mask==0 are skipped
     // outputs: kinematics of the last forward pass (x_14 in stale mode)
     float *xpos, *xquat, *xipos;
-    int* diag;  // [N,4]: ncon (last substep), newton iterations (sum), flags, max ncon
+    int* diag;  // [N,4]: ncon (last substep), newton iterations (sum), flags | substeps whose Newton solve ended at the iteration cap << 8, max ncon | factorisations << 8
     unsigned long long* prof;  // optional [N,8] shader-clock cycles per phase (kp_sim_phase_cycles)
     const float* geoms;        // OBJ kernels: [N, D_MAXGEOM, 17] world-frame static geoms
     const int* ngeom;          // OBJ kernels: [N]
@@ -922,7 +922,7 @@ __device__ __forceinline__ int first_clean_level(EnvLds& s, const Params& P, int
 // constraint solve: Newton on the primal problem (mj_solNewton) with an exact line search.  Returns iterations.
 // On entry sv holds the spatial accelerations of qacc_s (left by the smooth aba_solve), jv3 holds aref.
 template <int NT, bool OBJ>
-__device__ __forceinline__ int solve_constraints(EnvLds& s, const Params& P, const Lane8& L8, int depth, int tid, int& nfact) {
+__device__ __forceinline__ int solve_constraints(EnvLds& s, const Params& P, const Lane8& L8, int depth, int tid, int& nfact, int& ncap) {
     if (s.ncon == 0 && s.nlim == 0) {
         for (int i = tid; i < D_NV; i += NT) s.qacc[i] = s.qacc_s[i];
         KP_SYNC();
@@ -956,6 +956,7 @@ __device__ __forceinline__ int solve_constraints(EnvLds& s, const Params& P, con
         KP_SYNC();
     }
     int it = 0, lev_hist = 1;
+    bool done = false;          // left the loop through one of mj_solNewton's termination tests (not the iteration cap)
     for (; it < P.max_iter; it++) {
         // gradient = M (qacc - qacc_s) - J^T f: one projection of the body wrenches I_b sacc_b - contact forces
         wrench_project<NT, OBJ>(s, P, sacc, s.qacc, s.qacc_s, s.grad, true, true, tid);
@@ -972,7 +973,7 @@ __device__ __forceinline__ int solve_constraints(EnvLds& s, const Params& P, con
         g2 = block_sum<NT>(s, g2, tid);
         changed = block_sum<NT>(s, changed, tid);
         KP_SYNC();
-        if (P.scale * sqrtf(g2) < P.tol) break;
+        if (P.scale * sqrtf(g2) < P.tol) { done = true; break; }
         // search = -H^-1 grad,  H = M + J^T D_active J : articulated-body pass with contact inertia; while the active set
         // stands the factorisation of the previous iteration is reused (mj_solNewton updates its Cholesky factor the same way)
         if (it == 0 || changed > 0.f) {
@@ -1013,7 +1014,7 @@ __device__ __forceinline__ int solve_constraints(EnvLds& s, const Params& P, con
             alpha = an;
             if (fabsf(step) <= 1e-6f * fabsf(alpha)) break;
         }
-        if (!(alpha > 0.f)) break;
+        if (!(alpha > 0.f)) { done = true; break; }
         for (int i = tid; i < D_NV; i += NT) s.qacc[i] += alpha * s.search[i];
         for (int i = tid; i < D_NB * 6; i += NT) sacc[i] += alpha * s.sv[i];
         for (int k = tid; k < 3 * s.ncon; k += NT) s.jar3[k] += alpha * s.jv3[k];
@@ -1022,8 +1023,9 @@ __device__ __forceinline__ int solve_constraints(EnvLds& s, const Params& P, con
         float newcost = primal_cost<NT>(s, P, sacc, s.jar3, s.lim_jar, tid);
         float improvement = P.scale * (cost - newcost);
         cost = newcost;
-        if (improvement < P.tol) { it++; break; }
+        if (improvement < P.tol) { it++; done = true; break; }
     }
+    if (!done) ncap++;          // the solver stopped at opt.iterations: counted per env in diag (flags >> 8)
     return it;
 }
 
@@ -1349,7 +1351,7 @@ __device__ __forceinline__ void obj_integrate(EnvLdsObj& s, const Params& P, int
 // (q_humanoid, a_object...).  The Newton system is solved exactly by block elimination: the articulated-body pass factorises
 // the humanoid block, 6 n_obj + 1 bias-only passes form the Schur complement on the objects when a hull touches one.
 template <int NT>
-__device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params& P, const Lane8& L8, int depth, int tid, int& nfact) {
+__device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params& P, const Lane8& L8, int depth, int tid, int& nfact, int& ncap) {
     constexpr int ST = 6 * D_MAXOBJ + 1;
     const int nobj = s.nobj, no6 = 6 * nobj;
     // smooth acceleration of the objects: I_eff a = -bias wrench
@@ -1406,6 +1408,7 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
         KP_SYNC();
     }
     int it = 0, lev_hist = 1;
+    bool done = false;          // left the loop through one of mj_solNewton's termination tests (not the iteration cap)
     for (; it < P.max_iter; it++) {
         // gradient: humanoid dofs (mres - J^T f) and object wrenches
         wrench_project<NT, true>(s, P, sacc, s.qacc, s.qacc_s, s.grad, true, true, tid);
@@ -1428,7 +1431,7 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
         g2 = block_sum<NT>(s, g2, tid);
         changed = block_sum<NT>(s, changed, tid);
         KP_SYNC();
-        if (P.scale * sqrtf(g2) < P.tol) break;
+        if (P.scale * sqrtf(g2) < P.tol) { done = true; break; }
         // search direction
         const bool refactor = it == 0 || changed > 0.f;
         nfact += refactor;
@@ -1525,7 +1528,7 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
             alpha = an;
             if (fabsf(step) <= 1e-6f * fabsf(alpha)) break;
         }
-        if (!(alpha > 0.f)) break;
+        if (!(alpha > 0.f)) { done = true; break; }
         for (int i = tid; i < D_NV; i += NT) s.qacc[i] += alpha * s.search[i];
         for (int i = tid; i < D_NB * 6; i += NT) sacc[i] += alpha * s.sv[i];
         if (tid < no6) { s.oa[tid] += alpha * s.osrch[tid]; s.omres[tid] += alpha * s.oMv[tid]; }
@@ -1535,8 +1538,9 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
         const float newcost = primal_cost<NT>(s, P, sacc, s.jar3, s.lim_jar, tid) + obj_gauss(s);
         const float improvement = P.scale * (cost - newcost);
         cost = newcost;
-        if (improvement < P.tol) { it++; break; }
+        if (improvement < P.tol) { it++; done = true; break; }
     }
+    if (!done) ncap++;          // the solver stopped at opt.iterations: counted per env in diag (flags >> 8)
     return it;
 }
 
@@ -1617,7 +1621,7 @@ __device__ __forceinline__ void step_body(StepArgs A, const int env_in, const in
         for (int i = tid; i < D_NV; i += NT) s.qvel[i] = gld<Q>(A.qvel + (size_t)env * D_NV + i);
         KP_SYNC();
     }
-    int niter_total = 0, maxcon = 0, nfact_total = 0;
+    int niter_total = 0, maxcon = 0, nfact_total = 0, ncap_total = 0;
     unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
     const bool prof = A.prof != nullptr;
 #define KP_T(i) if (prof) { t1 = __builtin_readcyclecounter(); pc[i] += t1 - t0; t0 = t1; }
@@ -1644,8 +1648,8 @@ __device__ __forceinline__ void step_body(StepArgs A, const int env_in, const in
         KP_SYNC();
         aba_solve<NT, OBJ>(s, P, L8, s.applied, s.qacc_s, false, tid, D_NLEV, s.fb);   // qacc_smooth = M^-1 qfrc_smooth; sv = its spatial accel
         KP_T(4)
-        if constexpr (OBJ) niter_total += solve_constraints_obj<NT>(s, P, L8, depth, tid, nfact_total);
-        else niter_total += solve_constraints<NT, OBJ>(s, P, L8, depth, tid, nfact_total);
+        if constexpr (OBJ) niter_total += solve_constraints_obj<NT>(s, P, L8, depth, tid, nfact_total, ncap_total);
+        else niter_total += solve_constraints<NT, OBJ>(s, P, L8, depth, tid, nfact_total, ncap_total);
         KP_T(5)
         maxcon = max(maxcon, s.ncon);
         // ---- semi-implicit Euler (mj_Euler, no damping)
@@ -1702,14 +1706,56 @@ __device__ __forceinline__ void step_body(StepArgs A, const int env_in, const in
     if (tid == 0 && A.diag && A.n_substeps > 0) {
         int* dg = A.diag + 4 * (size_t)env;
         if (part > 0) {      // later job of the same control step: accumulate
-            const int d3 = gld<Q>(dg + 3);
-            niter_total += gld<Q>(dg + 1); s.flag |= gld<Q>(dg + 2);
+            const int d3 = gld<Q>(dg + 3), d2 = gld<Q>(dg + 2);
+            niter_total += gld<Q>(dg + 1); s.flag |= d2 & 255; ncap_total += d2 >> 8;
             maxcon = max(maxcon, d3 & 255); nfact_total += d3 >> 8;
         }
-        gst<Q>(dg + 0, s.ncon); gst<Q>(dg + 1, niter_total); gst<Q>(dg + 2, s.flag); gst<Q>(dg + 3, maxcon | (nfact_total << 8));
+        gst<Q>(dg + 0, s.ncon); gst<Q>(dg + 1, niter_total); gst<Q>(dg + 2, (s.flag & 255) | (ncap_total << 8)); gst<Q>(dg + 3, maxcon | (nfact_total << 8));
     }
     if (tid == 0 && A.cost && A.n_substeps > 0)
         gst<Q>(A.cost + env, (part > 0 ? gld<Q>(A.cost + env) : 0u) + (unsigned)((__builtin_readcyclecounter() - t_launch) >> 10));
+}
+
+// mj_fullM(model, M, data.qM)[:75, :75] and data.qfrc_bias[:75] as the reference's compute_desired_accel reads them
+// (uhc/envs/humanoid_im.py:422-426): the dense joint-space inertia matrix (armature included) and the bias force of the state the
+// derived quantities belong to (qpos_d / qvel_d: what mujoco-py's data holds between sim.step() calls).  The simulator itself
+// never forms either (every solve is an articulated-body pass); this read-out builds column j of M as the projection of the body
+// wrenches I_b a_b(e_j) summed over subtrees (a composite-rigid-body product M e_j), and qfrc_bias as the same projection of the
+// RNE body wrenches.  Off the hot path: 76 projections per env.
+__global__ __launch_bounds__(64) void kp_mass_kernel(StepArgs A, float* __restrict__ Mout, float* __restrict__ bias_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    EnvLds& s = *reinterpret_cast<EnvLds*>(smem_raw);
+    constexpr int NT = 64;
+    const int tid = threadIdx.x, env = blockIdx.x;
+    if (env >= A.n_envs) return;
+    const DevTables& T = A.T;
+    const Params& P = A.P;
+    const int depth = tid < D_NB ? T.body_depth[tid] : -1;
+    const V3 bpos = tid < D_NB ? ld3(T.body_pos + 3 * tid) : v3(0.f, 0.f, 0.f);
+    for (int i = tid; i < D_NQ; i += NT) s.qpos[i] = A.qpos_d[(size_t)env * D_NQ + i];
+    for (int i = tid; i < D_NV; i += NT) { s.qvel[i] = A.qvel_d[(size_t)env * D_NV + i]; s.arm[i] = T.dof_armature[i]; s.dbody[i] = T.dof_body[i]; }
+    if (tid < D_NB) { s.bpar[tid] = (unsigned char)(T.body_parent[tid] < 0 ? 0 : T.body_parent[tid]); s.bsub[tid] = T.body_subtree[tid]; s.bdep[tid] = T.body_depth[tid]; }
+    KP_SYNC();
+    forward_kin_bias<NT>(s, T, P, depth, bpos, tid);
+    // qfrc_bias: subtree sums of the RNE body wrenches projected on the motion axes (backward half of mj_rne)
+    for (int it = tid; it < D_NB * 6; it += NT) {
+        const int b = it / 6, c = it - 6 * b, n = s.bsub[b];
+        float acc = 0.f;
+        for (int k = b; k < b + n; k++) acc += s.fb[6 * k + c];
+        s.sa[it] = acc;
+    }
+    KP_SYNC();
+    if (bias_out) for (int d = tid; d < D_NV; d += NT) bias_out[(size_t)env * D_NV + d] = dot6(lds6(s.cdof + 6 * d), lds6(s.sa + 6 * s.dbody[d]));
+    KP_SYNC();
+    if (!Mout) return;
+    for (int j = 0; j < D_NV; j++) {
+        for (int i = tid; i < D_NV; i += NT) s.x[i] = i == j ? 1.f : 0.f;
+        KP_SYNC();
+        spatial_accumulate<NT>(s, s.x, depth, tid);
+        wrench_project<NT, false>(s, P, s.sv, s.x, nullptr, s.grad, true, false, tid);
+        for (int d = tid; d < D_NV; d += NT) Mout[((size_t)env * D_NV + d) * D_NV + j] = s.grad[d];
+        KP_SYNC();
+    }
 }
 
 // Launch order for the next control step: envs sorted by the cycles they took in the last one, longest first (counting sort on

@@ -1,7 +1,8 @@
 """ctypes binding of libkinpoly_sim.so (include/kinpoly_sim.h) for torch device tensors.
 
-This is the thin host layer: tensors in, tensors out, every call enqueued on torch's current
-HIP stream.  There is NO CPU fallback: if the extension or a HIP device is missing, construction
+This is the thin host layer: tensors in, tensors out.  A `KpSim` enqueues on the torch stream that was current when it
+was created; `KpSim.use_current_stream()` rebinds it (kp_sim_set_stream) when the caller moves to another stream -- the library
+never guesses.  There is NO CPU fallback: if the extension or a HIP device is missing, construction
 fails loudly.
 """
 from __future__ import annotations
@@ -20,7 +21,8 @@ DEFAULT_KPM = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets",
 STEP_KPM = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets", "smpl_humanoid_step.kpm")
 
 FIELDS = dict(qpos=0, qvel=1, xpos=2, xquat=3, xipos=4, bquat=5, head=6, target_qpos=7, target_wbpos=8,
-              target_wbquat=9, target_bquat=10, target_com=11, qpos_d=12, qvel_d=13, prev_bquat=14, prev_hpos=15, obj_qpos=16, obj_qvel=17)
+              target_wbquat=9, target_bquat=10, target_com=11, qpos_d=12, qvel_d=13, prev_bquat=14, prev_hpos=15, obj_qpos=16, obj_qvel=17,
+              M=18, bias=19)
 
 _lib = None
 
@@ -31,7 +33,7 @@ ABI_SYMBOLS = [
     "kp_field_dim", "kp_sim_get", "kp_sim_diag", "kp_sim_last_step_seconds", "kp_last_error", "kp_version",
     "kp_sim_step_begin", "kp_sim_obs_ar", "kp_sim_term_reward", "kp_gae", "kp_sim_set_full_state", "kp_sim_fk",
     "kp_sim_timing_reset", "kp_sim_timing_mean_seconds", "kp_sim_phase_cycles", "kp_sim_set_objects", "kp_sim_set_obj_state",
-    "kp_sim_launch_cost", "kp_job_schedule", "kp_sim_fk_backward",
+    "kp_sim_launch_cost", "kp_job_schedule", "kp_sim_fk_backward", "kp_sim_set_stream", "kp_sim_status_device", "kp_sim_mass_matrix",
 ]
 
 
@@ -97,6 +99,9 @@ def load_library(path: str | None = None):
     L.kp_sim_set_obj_state.argtypes = [P, F, F, U8]; L.kp_sim_set_obj_state.restype = C.c_int
     L.kp_sim_fk.argtypes = [P, C.c_int, F, F, F, F, F, F]; L.kp_sim_fk.restype = C.c_int
     L.kp_sim_fk_backward.argtypes = [P, C.c_int, F, F, F, F, F]; L.kp_sim_fk_backward.restype = C.c_int
+    L.kp_sim_set_stream.argtypes = [P, C.c_void_p]; L.kp_sim_set_stream.restype = C.c_int
+    L.kp_sim_status_device.argtypes = [P]; L.kp_sim_status_device.restype = C.c_void_p
+    L.kp_sim_mass_matrix.argtypes = [P, F, F]; L.kp_sim_mass_matrix.restype = C.c_int
     L.kp_last_error.restype = C.c_char_p
     L.kp_version.restype = C.c_char_p
     _lib = L
@@ -161,6 +166,29 @@ class KpSim:
             self.h = self.L.kp_sim_create(model.h, self.n, self.device.index, C.c_void_p(stream))
         if not self.h:
             raise KinPolyNativeError(f"kp_sim_create: {self.L.kp_last_error().decode()}")
+        self._stream = stream
+
+    def use_current_stream(self):
+        """Enqueue all later calls on torch's current stream of this device (the caller orders the old and the new stream)."""
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        if stream != self._stream:
+            _check(self.L.kp_sim_set_stream(self.h, C.c_void_p(stream)), "kp_sim_set_stream")
+            self._stream = stream
+
+    def status_tensor(self) -> torch.Tensor:
+        """int32 [4] device view of the launch status words (kp_sim_status_device): [2] != 0 = a queue launch stalled."""
+        if getattr(self, "_status", None) is None:
+            ptr = self.L.kp_sim_status_device(self.h)
+            iface = {"shape": (4,), "typestr": "<i4", "data": (int(ptr), False), "version": 3, "strides": None}
+            holder = type("_KpStatus", (), {"__cuda_array_interface__": iface})()
+            self._status = torch.as_tensor(holder, device=self.device)
+        return self._status
+
+    def mass_matrix(self):
+        """(M [N,75,75], qfrc_bias [N,75]) of the state the derived quantities belong to (mj_fullM / data.qfrc_bias)."""
+        M = torch.empty((self.n, 75, 75), dtype=torch.float32, device=self.device); b = self._new(75)
+        _check(self.L.kp_sim_mass_matrix(self.h, C.c_void_p(M.data_ptr()), C.c_void_p(b.data_ptr())), "kp_sim_mass_matrix")
+        return M, b
 
     def __del__(self):
         try:

@@ -1,0 +1,187 @@
+"""GPU tests added in round 2 (run with -m gpu on an MI355X), all through the C ABI of libkinpoly_sim.so:
+
+  * PolicyMCP / Value: the fused fp32 device path against the REFERENCE's own forward (tests/golden/policies.npz was written by
+    uhc/core/policy_mcp.py and uhc/khrylib/rl/core/critic.py with seeded weights that the test regenerates);
+  * KP_M / KP_BIAS read-outs (mj_fullM / data.qfrc_bias, uhc/envs/humanoid_im.py:422-426) against the fp64 oracle;
+  * the Newton solver's iteration cap: default = the model's mjOption.iterations (100), cap hits counted in kp_sim_diag.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from oracle import np_oracle as O  # noqa: E402
+from oracle.kpo import OracleSim  # noqa: E402
+
+STD = np.load(os.path.join(os.path.dirname(__file__), "golden", "standing_neutral.npz"))
+
+
+@pytest.fixture(scope="module")
+def kp():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no HIP device is visible")
+    from kinpoly_amd import sim as kpsim
+    return kpsim
+
+
+def dev(a):
+    return torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device="cuda")
+
+
+def _mcp_shapes():
+    shapes = {}
+    for k in range(8):
+        shapes[f"nets.{k}.0.affine_layers.0.weight"] = (512, 784); shapes[f"nets.{k}.0.affine_layers.0.bias"] = (512,)
+        shapes[f"nets.{k}.0.affine_layers.1.weight"] = (256, 512); shapes[f"nets.{k}.0.affine_layers.1.bias"] = (256,)
+        shapes[f"nets.{k}.1.weight"] = (75, 256); shapes[f"nets.{k}.1.bias"] = (75,)
+    dims = [784, 300, 200, 8]
+    for i in range(3):
+        shapes[f"composer.0.affine_layers.{i}.weight"] = (dims[i + 1], dims[i]); shapes[f"composer.0.affine_layers.{i}.bias"] = (dims[i + 1],)
+    shapes["action_log_std"] = (1, 75)
+    return shapes
+
+
+def test_policy_mcp_fused_path_matches_reference_forward(kp, golden):
+    """nets.PolicyMCP (3 batched GEMMs, fp32, MFMA) loaded with the fixture's seeded weights vs the output the
+    reference's PolicyMCP.forward produced for them (uhc/core/policy_mcp.py:30-38)."""
+    from kinpoly_amd.nets import PolicyMCP
+    g = golden("policies")
+    shapes = _mcp_shapes()
+    sd = O.seeded_state_dict([(str(k), shapes[str(k)]) for k in g["mcp_keys"]], int(g["mcp_seed"]))
+    pol = PolicyMCP()
+    missing = pol.load_state_dict({k: torch.tensor(v, dtype=torch.float32) for k, v in sd.items()}, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    pol = pol.cuda().float()
+    x = dev(g["x"])
+    with torch.no_grad():
+        fused = pol.action_mean(x)                       # rollout path: fused GEMMs (no grad)
+        w = pol.composer(x)
+    np.testing.assert_allclose(w.double().cpu().numpy(), g["mcp_weights"], atol=2e-5)
+    np.testing.assert_allclose(fused.double().cpu().numpy(), g["mcp_mean"], atol=2e-4, rtol=1e-4)
+    # the training path (plain modules, autograd on) computes the same thing
+    for p in pol.parameters():
+        p.requires_grad_(True)
+    plain = pol.action_mean(x)
+    assert plain.requires_grad
+    np.testing.assert_allclose(plain.detach().double().cpu().numpy(), g["mcp_mean"], atol=2e-4, rtol=1e-4)
+    # select_action(mean_action=True) is what the env calls in test mode
+    with torch.no_grad():
+        np.testing.assert_allclose(pol.select_action(x, True).double().cpu().numpy(), g["mcp_mean"], atol=2e-4, rtol=1e-4)
+
+
+def test_value_net_matches_reference_forward(kp, golden):
+    from kinpoly_amd.nets import MLP, Value
+    g = golden("policies")
+    vshapes = {"net.affine_layers.0.weight": (512, 105), "net.affine_layers.0.bias": (512,), "net.affine_layers.1.weight": (256, 512),
+               "net.affine_layers.1.bias": (256,), "value_head.weight": (1, 256), "value_head.bias": (1,)}
+    vsd = O.seeded_state_dict([(str(k), vshapes[str(k)]) for k in g["value_keys"]], int(g["value_seed"]))
+    val = Value(MLP(105, (512, 256), "relu"))
+    val.load_state_dict({k: torch.tensor(v, dtype=torch.float32) for k, v in vsd.items()}, strict=True)
+    val = val.cuda()
+    with torch.no_grad():
+        got = val(dev(g["s"]))
+    np.testing.assert_allclose(got.double().cpu().numpy(), g["value"], atol=2e-4, rtol=1e-4)
+
+
+def test_mass_matrix_and_bias_readouts_match_oracle(kp):
+    """KP_M / KP_BIAS = mj_fullM(model, M, data.qM)[:75,:75] / data.qfrc_bias[:75] (humanoid_im.py:422-426) of the state the
+    derived quantities belong to: after set_state that is the state itself, after a control step it is x_14 (qpos_d)."""
+    n = 8
+    rng = np.random.default_rng(5)
+    qpos = np.tile(STD["qpos"], (n, 1)); qpos[:, 2] += 0.3
+    qpos[:, 7:] += rng.normal(size=(n, 69)) * 0.4
+    q = rng.normal(size=(n, 4)); qpos[:, 3:7] = q / np.linalg.norm(q, axis=1, keepdims=True)
+    qvel = rng.normal(size=(n, 75)) * 1.5
+    sim = kp.KpSim(kp.KpModel(), n)
+    sim.set_state(dev(qpos), dev(qvel))
+    M, b = sim.mass_matrix()
+    M, b = M.double().cpu().numpy(), b.double().cpu().numpy()
+    q32, v32 = dev(qpos).double().cpu().numpy(), dev(qvel).double().cpu().numpy()
+    o = OracleSim()
+    for e in range(n):
+        o.reset(q32[e], v32[e])
+        Mo, bo = o.fullM(), o.get("qfrc_bias")
+        np.testing.assert_allclose(M[e], Mo, atol=2e-5 * np.abs(Mo).max())
+        np.testing.assert_allclose(M[e], M[e].T, atol=1e-5 * np.abs(Mo).max())
+        np.testing.assert_allclose(b[e], bo, atol=3e-5 * max(1.0, np.abs(bo).max()))
+    # the generic getter returns the same data, flattened
+    np.testing.assert_array_equal(sim.get("M").view(n, 75, 75).double().cpu().numpy(), M)
+    np.testing.assert_array_equal(sim.get("bias").double().cpu().numpy(), b)
+    # after a control step the read-outs belong to x_14 (stale derived quantities, like mujoco-py's data.qM)
+    act = dev(rng.normal(size=(n, 75)) * 0.2)
+    sim.set_target(dev(qpos))
+    sim.step_ctrl(act, 15)
+    M2 = sim.get("M").view(n, 75, 75).double().cpu().numpy()
+    qd, vd = sim.get("qpos_d").double().cpu().numpy(), sim.get("qvel_d").double().cpu().numpy()
+    for e in range(2):
+        o.reset(qd[e], vd[e])
+        np.testing.assert_allclose(M2[e], o.fullM(), atol=2e-5 * np.abs(M2[e]).max())
+
+
+def _buried_states(n, seed):
+    rng = np.random.default_rng(seed)
+    qpos = np.tile(STD["qpos"], (n, 1)); qvel = rng.normal(size=(n, 75)) * 0.5
+    for e in range(n):
+        if e % 2:
+            q = rng.normal(size=4); qpos[e, 3:7] = q / np.linalg.norm(q)
+        qpos[e, 2] = rng.uniform(-0.1, 0.35); qpos[e, 7:] += rng.normal(size=69) * 0.3
+    return qpos, qvel, rng.normal(size=(n, 75)) * 0.3
+
+
+def test_newton_iteration_cap_is_the_models_and_cap_hits_are_counted(kp):
+    """the product used to cap Newton at 12 iterations silently.  Now the default is the blob's
+    mjOption.iterations (100, what the oracle and MuJoCo run with), diag counts the substeps that ended at the cap, and on
+    half-buried starts (dozens of deep contacts, the worst case seen in training) no env hits it and HIP == oracle."""
+    model = kp.KpModel()
+    assert model.get_option("solver_iter") == 100
+    n = 32
+    qpos, qvel, act = _buried_states(n, 11)
+    sim = kp.KpSim(model, n)
+    sim.set_state(dev(qpos), dev(qvel)); sim.set_target(dev(np.tile(STD["qpos"], (n, 1))))
+    a = dev(act)
+    sim.step_ctrl(a, 15)
+    dg = sim.diag()
+    assert int((dg[:, 2] >> 8).max()) == 0, "a Newton solve ended at the 100-iteration cap"
+    assert int((dg[:, 2] & 1).max()) == 0
+    assert int(dg[:, 3].max() & 255) >= 20          # the scene family really is contact-heavy
+    got = sim.get("qpos").double().cpu().numpy()
+    q32, v32, a32 = dev(qpos).double().cpu().numpy(), dev(qvel).double().cpu().numpy(), a.double().cpu().numpy()
+    o = OracleSim()
+    for e in range(8):
+        o.reset(q32[e], v32[e]); o.do_simulation(a32[e], STD["qpos"], 15)
+        assert np.abs(o.get("qpos") - got[e]).max() < 1e-4
+    # a deliberately small cap is reported, not hidden
+    m2 = kp.KpModel(solver_iter=2)
+    s2 = kp.KpSim(m2, n)
+    s2.set_state(dev(qpos), dev(qvel)); s2.set_target(dev(np.tile(STD["qpos"], (n, 1))))
+    s2.step_ctrl(a, 15)
+    d2 = s2.diag()
+    assert int((d2[:, 2] >> 8).sum()) > 0 and int((d2[:, 2] >> 8).max()) <= 15
+    assert (d2[:, 1] <= 2 * 15).all()
+
+
+def test_sim_follows_an_explicit_stream_rebind(kp):
+    """KpSim enqueues on the stream it was created on; use_current_stream() rebinds it (kp_sim_set_stream)."""
+    n = 4
+    sim = kp.KpSim(kp.KpModel(), n)
+    q, v = dev(np.tile(STD["qpos"], (n, 1))), dev(np.tile(STD["qvel"], (n, 1)))
+    sim.set_state(q, v); sim.set_target(q)
+    a = torch.zeros((n, 75), device="cuda")
+    sim.step_ctrl(a, 15)
+    want = sim.get("qpos").clone()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        sim.use_current_stream()
+        sim.set_state(q, v); sim.set_target(q)
+        sim.step_ctrl(a, 15)
+        got = sim.get("qpos")
+    side.synchronize()
+    sim.use_current_stream()
+    assert torch.equal(got, want)
+    st = sim.status_tensor()
+    assert st.shape == (4,) and int(st[2]) == 0
