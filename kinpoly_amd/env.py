@@ -275,6 +275,43 @@ def standing_context(n, T, std_qpos, std_qvel, sim: kpsim.KpSim, headings: torch
             "init_qvel": torch.tensor(std_qvel, dtype=torch.float32, device=dev).repeat(n, 1).contiguous()}
 
 
+SMPL_BODY_NAMES = ("Pelvis", "L_Hip", "L_Knee", "L_Ankle", "L_Toe", "R_Hip", "R_Knee", "R_Ankle", "R_Toe", "Torso", "Spine", "Chest", "Neck", "Head",
+                   "L_Thorax", "L_Shoulder", "L_Elbow", "L_Wrist", "L_Hand", "R_Thorax", "R_Shoulder", "R_Elbow", "R_Wrist", "R_Hand")   # XML body order
+
+
+class Box:
+    """The two attributes-and-a-method of gym.spaces.Box the reference's callers touch (humanoid_ar_v1.py:106-112;
+    agent_ar.py:146 reads action_space.shape[0]); gym itself is not a dependency of this engine."""
+
+    def __init__(self, low, high, dtype=np.float32):
+        self.low, self.high, self.dtype = np.asarray(low, dtype), np.asarray(high, dtype), dtype
+        self.shape = self.low.shape
+
+    def sample(self, rng=None):
+        rng = rng or np.random
+        lo, hi = np.where(np.isfinite(self.low), self.low, -1.0), np.where(np.isfinite(self.high), self.high, 1.0)
+        return rng.uniform(lo, hi).astype(self.dtype)
+
+    def contains(self, x):
+        x = np.asarray(x)
+        return x.shape == self.shape and bool(np.all(x >= self.low) and np.all(x <= self.high))
+
+
+class _ModelView:
+    """Read-only stand-in for the mujoco-py `env.model` attributes callers of the env read:
+    nq / nv / nu, opt.timestep, body_names, actuator_names (one motor per hinge, XML order), actuator_ctrlrange."""
+
+    def __init__(self, kp_model, has_objects=True):
+        import types
+        self.nu = 69
+        self.nq, self.nv = (76 + 35, 75 + 30) if has_objects else (76, 75)
+        self.opt = types.SimpleNamespace(timestep=kp_model.get_option("timestep"))
+        self.body_names = ("world",) + SMPL_BODY_NAMES
+        self._body_name2id = {n: i for i, n in enumerate(self.body_names)}
+        self.actuator_names = tuple(f"{b}_{a}" for b in SMPL_BODY_NAMES[1:] for a in "zyx")
+        self.actuator_ctrlrange = np.tile(np.array([[-1.0, 1.0]]), (self.nu, 1))
+
+
 class HumanoidAREnv:
     """Single-environment facade with the reference constructor and numpy float64 I/O
     (kin_poly/envs/humanoid_ar_v1.py:28).  `cfg` / `cc_cfg` are duck-typed: only `policy_specs` thresholds,
@@ -292,16 +329,39 @@ class HumanoidAREnv:
                                       joint_controller=bool(getattr(cfg, "joint_controller", False)),
                                       env_episode_len=int(getattr(cc_cfg, "env_episode_len", 100000)),
                                       body_diff_thresh=ps.get("body_diff_thresh", 10), body_diff_gt_thresh=ps.get("body_diff_gt_thresh", 12), ar_mode=ar_mode)
-        self.kin_cfg, self.cc_cfg, self.ar_mode = cfg, cc_cfg, ar_mode
+        self.kin_cfg, self.cc_cfg, self.ar_mode, self.wild, self.mode = cfg, cc_cfg, ar_mode, wild, mode
         self.cc_policy, self.cc_running_state = self.b.cc_policy, self.b.cc_running_state
         self.dt, self.end_reward = self.b.dt, 0.0
         self.prev_bquat = self.prev_hpos = self.prev_qpos = self.prev_qvel = None
+        # constants / spaces of the reference constructor (humanoid_ar_v1.py:36-39, 50-59, 90-112; humanoid_im.py:30-49)
+        self.model = _ModelView(self.b.model)
+        self.frame_skip, self.sim_iter, self.start_ind = 15, 15, 0
+        self.qpos_lim, self.qvel_lim, self.body_lim = 76, 75, 25
+        self.num_obj, self.action_index_map, self.action_len = 5, list(ACTION_INDEX_MAP), list(ACTION_LEN)
+        self.action_names = ["sit", "push", "avoid", "step"]
+        self.ndof, self.vf_dim, self.cc_action_dim = 69, 6, 75
+        self.action_dim, self.obs_dim = 75, kpsim.AR_OBS_DIM      # set_spaces() (:106-112): the Box is 75-d although step() takes the 80-d kinematic action
+        self.action_space = Box(-np.ones(self.action_dim), np.ones(self.action_dim))
+        self.observation_space = Box(-np.inf * np.ones(self.obs_dim), np.inf * np.ones(self.obs_dim))
+        self.body_diff_thresh, self.body_diff_gt_thresh = ps.get("body_diff_thresh", 10), ps.get("body_diff_gt_thresh", 12)
+        self.jpos_diffw = np.ones((24, 1))
+        self.gt_targets = self.ar_context = None
+        self.np_random = np.random.RandomState(0)                 # MujocoEnv.__init__ seeds at construction (mujoco_env.py:57)
         if init_context is not None:
             self.load_context(init_context)
 
-    def seed(self, seed):
+    def seed(self, seed=None):
         self.np_random = np.random.RandomState(seed)
-        return self.b.seed(seed)
+        return self.b.seed(0 if seed is None else seed)
+
+    def render(self, mode="human"):
+        """No viewer in this engine (the reference's mujoco-py viewer is out of scope): a no-op so that
+        callers which render unconditionally keep working."""
+        return None
+
+    @property
+    def bquat(self):
+        return self.get_body_quat()
 
     def set_mode(self, mode):
         self.b.set_mode(mode)
@@ -321,6 +381,12 @@ class HumanoidAREnv:
         ctx["init_qpos"] = torch.as_tensor(iq[0] if iq.ndim == 2 else iq, dtype=torch.float32)[None]
         ctx["init_qvel"] = torch.as_tensor(iv[0] if iv.ndim == 2 else iv, dtype=torch.float32)[None]
         self.b.load_context(ctx)
+        # gt_targets = smpl_humanoid.qpos_fk_batch(ar_context['qpos'])   (:87)
+        T = self.ar_context["qpos"].shape[0]
+        fk = self.b.sim.fk(self.b.ctx["qpos"][0].contiguous())
+        self.gt_targets = {"qpos": fk["qpos"].double().cpu().numpy(), "wbpos": fk["wbpos"].view(T, 24, 3).double().cpu().numpy(),
+                           "wbquat": fk["wbquat"].view(T, 24, 4).double().cpu().numpy(), "bquat": fk["bquat"].view(T, 96).double().cpu().numpy(),
+                           "body_com": fk["body_com"].view(T, 24, 3).double().cpu().numpy()}
 
     def reset(self):
         return self.b.reset()[0].double().cpu().numpy()

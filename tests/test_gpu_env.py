@@ -96,6 +96,51 @@ def test_single_env_facade_numpy_surface():
     assert env.target["wbpos"].shape == (72,) and env.cur_t == 1 and abs(env.dt - 1 / 30) < 1e-6
     assert env.get_obj_qpos().shape == (35,) and env.get_obj_qvel().shape == (30,)
     np.testing.assert_allclose(env.get_obj_qpos(np.zeros(4)), [0, 0, 0, 1, 0, 0, 0])
+    # the rest of the reference surface (humanoid_ar_v1.py:28-112)
+    assert env.action_space.shape == (75,) and env.observation_space.shape == (105,) and env.action_space.contains(env.action_space.sample(env.np_random))
+    assert env.start_ind == 0 and env.render() is None and env.num_obj == 5 and env.action_names == ["sit", "push", "avoid", "step"]
+    assert len(env.model.actuator_names) == 69 and env.model.actuator_names[0] == "L_Hip_z" and env.model.actuator_names[-1] == "R_Hand_x"
+    assert env.model._body_name2id["Head"] == 14 and env.model.nu == 69
+    gt = env.gt_targets
+    assert gt["wbpos"].shape == (10, 24, 3) and gt["wbquat"].shape == (10, 24, 4) and gt["bquat"].shape == (10, 96)
+    want = O.qpos_fk(STD["qpos"], BP, BI, PAR)
+    np.testing.assert_allclose(gt["wbpos"][3], want["wbpos"], atol=2e-5)
+    assert isinstance(env.np_random.uniform(), float) and env.bquat.shape == (96,)
+
+
+def test_wild_mode_env_runs_without_gt_termination(golden):
+    """BASELINE configs[4] (`--wild`, eval_ar_policy.py:265-395): wild=True builds the env on ..._mesh_all.xml (no step box), mode
+    'test' = mean actions, and the GT-based termination of humanoid_ar_v1.py:303-306 is off: an env whose GT clip is far from
+    the simulated pose keeps running where the train-mode env fails, while the target-based test (:307-309) still applies."""
+    from kinpoly_amd.env import BatchedHumanoidAREnv, standing_context
+    n, T = 16, 12
+    torch.manual_seed(0)
+    envs = {}
+    for name, kw in (("wild", dict(mode="test", wild=True)), ("train", dict(mode="train", wild=False))):
+        env = BatchedHumanoidAREnv(n, 0, seed=0, **kw)
+        ctx = standing_context(n, T, STD["qpos"], STD["qvel"], env.sim)
+        # GT clip displaced by 1 m: sum_j |xpos_j - gt_j| = 24 m > body_diff_gt_thresh = 12
+        far = ctx["qpos"].clone(); far[:, :, 0] += 1.0
+        ctx["qpos"] = far
+        env.load_context(ctx)
+        envs[name] = env
+    assert envs["wild"].model.get_option("timestep") == envs["train"].model.get_option("timestep")
+    assert envs["wild"].reward_cfg.use_gt_term == 0 and envs["train"].reward_cfg.use_gt_term == 1
+    acts = {}
+    for name, env in envs.items():
+        obs = env.reset().clone()
+        cur = env.sim.get("qpos")
+        a = torch.zeros((n, 80), device=env.device)
+        a[:, :74] = torch.cat([cur[:, 2:3], obs[:, 1:5], cur[:, 7:]], 1)      # track the current pose (step_ar encoding)
+        obs2, _, done, info = env.step(a)
+        acts[name] = (done.clone(), info["fail"].clone(), info["cc_action"].clone(), info["body_diff"].clone())
+        assert torch.isfinite(obs2).all()
+    assert not bool(acts["wild"][1].any()), "wild mode must not terminate on the GT clip"
+    assert bool(acts["train"][1].all()), "train mode terminates when the GT clip is > body_diff_gt_thresh away"
+    assert float(acts["train"][3][:, 1].min()) > 12.0
+    # test mode = mean UHC actions: deterministic, identical across the batch rows that share a state
+    assert torch.allclose(acts["wild"][2][0], acts["wild"][2][1], atol=1e-6)
+    assert int(envs["wild"].sim.diag()[:, 2].max()) == 0
 
 
 def test_ar_mode_and_fail_safe():
