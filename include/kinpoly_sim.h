@@ -67,6 +67,13 @@ int kp_sim_set_stream(kp_sim*, void* hip_stream);
  * checks without a host sync.  [0], [1] are the queue's head / tail counters of the last launch. */
 const uint32_t* kp_sim_status_device(kp_sim*);
 
+/* Test / debugging read-out of data.contact: the contact set of the LAST collision pass of the last kp_sim_step_ctrl launch
+ * (i.e. of the state before its final substep).  The first call arms the recording (costs a few KB of stores per env and launch
+ * afterwards), later calls copy float32 [N, 1 + 64 * 9] to the HOST pointer: [0] = number of contacts, then per contact
+ * {entity carrying the first geom's counterpart (0..23 hull body, 24 + k object slot), other entity (-1 world), dist, pos[3],
+ * normal[3] (pointing into the first entity)}.  Synchronises. */
+int kp_sim_contacts(kp_sim*, float* out_host);
+
 /* mjf.mj_fullM(model, M, data.qM) and data.qfrc_bias as compute_desired_accel reads them (uhc/envs/humanoid_im.py:422-426):
  * M [N,75,75] (dense, symmetric, armature on the diagonal), bias [N,75]; either may be NULL.  The simulator never forms them
  * on the hot path (matrix-free solves); this read-out is for callers of the reference surface.  Same data as KP_M / KP_BIAS. */

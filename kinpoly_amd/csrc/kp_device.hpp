@@ -13,7 +13,7 @@ namespace kp {
 
 constexpr int D_NB = 24, D_NV = 75, D_NQ = 76, D_NU = 69;
 constexpr int D_MAXCON = 64;          // must equal MAXCON in oracle/kp_oracle.c
-constexpr int D_CON_PER_GEOM = 3;     // must equal CON_PER_GEOM in oracle/kp_oracle.c
+constexpr int D_CON_PER_GEOM = 4;     // mjc_PlaneConvex: support vertex + up to 3 hull-graph neighbours (CON_PER_GEOM in oracle/kp_oracle.c)
 constexpr int D_NLEV = 9;             // body tree depth levels (Pelvis .. Hand)
 
 struct DevTables {
@@ -22,6 +22,8 @@ struct DevTables {
     const float *kp, *kd, *tlim, *ascale;
     const float *verts;
     const uint16_t *vert_adr;
+    const uint16_t *vert_nbr_adr;   // hull graph: neighbours (hull-local ids) of global vertex v are vert_nbr[vert_nbr_adr[v] .. vert_nbr_adr[v + 1])
+    const uint8_t *vert_nbr;
     const uint8_t *dof_body;
     const int8_t *body_parent;
     const uint8_t *body_depth, *body_subtree, *lev_start, *lev_body, *jnt_limited;

@@ -18,7 +18,7 @@ constexpr int NB = 24, NV = 75, NQ = 76, NU = 69, NM = 1221, MAXDEPTH = 30;
 
 struct HostModel {
     int nb = 0, nv = 0, nq = 0, nu = 0, nM = 0, nvert = 0;
-    std::vector<int> body_parent, body_depth, body_subtree, dof_body, dof_parent, dof_depth, dof_madr, jnt_limited, vert_adr, obj_geom_adr;
+    std::vector<int> body_parent, body_depth, body_subtree, dof_body, dof_parent, dof_depth, dof_madr, jnt_limited, vert_adr, obj_geom_adr, vert_nbr_adr, vert_nbr;
     std::vector<double> body_pos, body_ipos, body_mass, body_inertia, body_rbound, body_invweight0, dof_invweight0,
         dof_armature, jnt_range, verts, kp, kd, torque_lim, a_scale, opt, body_diffw, obj_geoms, obj_mass, obj_inertial;
     std::string error;
@@ -57,6 +57,8 @@ inline bool load_kpm(const char* path, HostModel& m) {
     KPI(body_parent, "body_parent") KPI(body_depth, "body_depth") KPI(body_subtree, "body_subtree")
     KPI(dof_body, "dof_body") KPI(dof_parent, "dof_parent") KPI(dof_depth, "dof_depth") KPI(dof_madr, "dof_madr")
     KPI(jnt_limited, "jnt_limited") KPI(vert_adr, "vert_adr")
+    if (!kpm_get(buf, "vert_nbr_adr", nullptr, &m.vert_nbr_adr) || !kpm_get(buf, "vert_nbr", nullptr, &m.vert_nbr) || (int)m.vert_nbr_adr.size() != m.nvert + 1) {
+        m.error = "blob has no hull graph (vert_nbr_adr / vert_nbr): recompile the model with kinpoly_amd/model_compiler.py (KPM version 6)"; return false; }
     KPF(body_pos, "body_pos") KPF(body_ipos, "body_ipos") KPF(body_mass, "body_mass") KPF(body_inertia, "body_inertia")
     KPF(body_rbound, "body_rbound") KPF(body_invweight0, "body_invweight0") KPF(dof_invweight0, "dof_invweight0")
     KPF(dof_armature, "dof_armature") KPF(jnt_range, "jnt_range") KPF(verts, "verts")

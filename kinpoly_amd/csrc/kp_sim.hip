@@ -44,6 +44,7 @@ struct kp_sim {
     unsigned *jobq = nullptr, *jobctr = nullptr;      // job FIFO of kp_step_queue_kernel
     int jobq_cap = 0, wave_slots = 2048;
     unsigned long long* prof = nullptr;
+    float* dbg_contacts = nullptr;
     float *obj_qpos = nullptr, *geoms = nullptr;      // [N,35], [N,8,17]
     float *obj_qvel = nullptr, *obj_warm = nullptr;   // [N,30], [N,12]
     signed char* obj_slot = nullptr;                  // [N,2]
@@ -98,6 +99,7 @@ bool build_tables(kp_sim* s) {
     s->diffw = const_cast<float*>(upload<float>(s, m.body_diffw, &ok));
     T.verts = upload<float>(s, m.verts, &ok);
     T.vert_adr = upload<uint16_t>(s, m.vert_adr, &ok);
+    T.vert_nbr_adr = upload<uint16_t>(s, m.vert_nbr_adr, &ok); T.vert_nbr = upload<uint8_t>(s, m.vert_nbr, &ok);
     T.dof_body = upload<uint8_t>(s, m.dof_body, &ok);
     T.body_parent = upload<int8_t>(s, m.body_parent, &ok); T.body_depth = upload<uint8_t>(s, m.body_depth, &ok);
     T.body_subtree = upload<uint8_t>(s, m.body_subtree, &ok); T.jnt_limited = upload<uint8_t>(s, m.jnt_limited, &ok);
@@ -188,7 +190,7 @@ int launch_step(kp_sim* s, const float* action, int nsub, const uint8_t* mask, b
     A.qpos = s->qpos; A.qvel = s->qvel; A.qpos_d = s->qpos_d; A.qvel_d = s->qvel_d; A.warm = s->warm;
     A.target_qpos = s->t_qpos; A.action = action; A.env_mask = mask;
     A.xpos = s->xpos; A.xquat = s->xquat; A.xipos = s->xipos; A.diag = s->diag; A.prof = s->prof;
-    A.geoms = s->geoms; A.ngeom = s->ngeom;
+    A.geoms = s->geoms; A.ngeom = s->ngeom; A.dbg_contacts = s->dbg_contacts;
     A.obj_slot = s->obj_slot; A.obj_qpos = s->obj_qpos; A.obj_qvel = s->obj_qvel; A.obj_warm = s->obj_warm;
     A.order = nullptr; A.cost = s->cost;
     if (nsub > 0 && s->model->lpt_order) {      // longest env first: order the workgroups by the cycles of the previous control step
@@ -371,6 +373,23 @@ int kp_sim_set_stream(kp_sim* s, void* stream) {
 }
 
 const uint32_t* kp_sim_status_device(kp_sim* s) { return s ? s->jobctr : nullptr; }
+
+int kp_sim_contacts(kp_sim* s, float* out_host) {
+    if (!s) return fail("kp_sim_contacts: null argument");
+    HIP_OK(hipSetDevice(s->device));
+    const size_t count = (size_t)s->n * (1 + kp::D_MAXCON * 9);
+    if (!s->dbg_contacts) {           // first call arms the recording: later kp_sim_step_ctrl launches store their last contact set
+        bool ok = true;
+        s->dbg_contacts = dalloc(s, count, &ok);
+        if (!ok) return fail("kp_sim_contacts: allocation failed");
+        if (out_host) std::memset(out_host, 0, sizeof(float) * count);
+        return 0;
+    }
+    if (!out_host) return 0;
+    HIP_OK(hipStreamSynchronize(s->stream));
+    HIP_OK(hipMemcpy(out_host, s->dbg_contacts, sizeof(float) * count, hipMemcpyDeviceToHost));
+    return 0;
+}
 
 int kp_sim_mass_matrix(kp_sim* s, float* M, float* bias) {
     if (!s || (!M && !bias)) return fail("kp_sim_mass_matrix: null argument");

@@ -27,6 +27,7 @@
 #include <type_traits>
 
 #include "kp_device.hpp"
+#include "kp_collide.hpp"
 
 namespace kp {
 
@@ -44,6 +45,7 @@ struct StepArgs {
     float *xpos, *xquat, *xipos;
     int* diag;  // [N,4]: ncon (last substep), newton iterations (sum), flags | substeps whose Newton solve ended at the iteration cap << 8, max ncon | factorisations << 8
     unsigned long long* prof;  // optional [N,8] shader-clock cycles per phase (kp_sim_phase_cycles)
+    float* dbg_contacts;       // optional [N, 1 + 64 * 9]: contacts of the last substep's collision pass (kp_sim_contacts; tests)
     const float* geoms;        // OBJ kernels: [N, D_MAXGEOM, 17] world-frame static geoms
     const int* ngeom;          // OBJ kernels: [N]
     // OBJ kernels, dynamic free objects: slot -> object index of the scene (-1 = empty), free-joint state of all objects
@@ -85,6 +87,8 @@ __device__ __forceinline__ float wave_min(float v) {
     const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 48));
     return fminf(fminf(r0, r1), fminf(r2, r3));
 }
+
+__device__ __forceinline__ float wave_max_f(float v) { return -wave_min(-v); }
 
 template <int NT>
 __device__ __forceinline__ float block_sum(EnvLds& s, float v, int tid) {
@@ -571,43 +575,26 @@ __device__ __forceinline__ void spd_torque_rfc(EnvLds& s, const DevTables& T, co
     KP_SYNC();
 }
 
-// ---------------------------------------------------------------- collision (wave 0)
-// signed distance + outward normal (world) of a static box (type 0) / z-axis cylinder (type 1) at world point x
-__device__ __forceinline__ float geom_sdf(const float* g, V3 x, V3& nw) {
-    const float* R = g + 7;
-    const V3 r = x - ld3(g + 4);
-    const V3 l = v3(R[0] * r.x + R[3] * r.y + R[6] * r.z, R[1] * r.x + R[4] * r.y + R[7] * r.z, R[2] * r.x + R[5] * r.y + R[8] * r.z);
-    V3 nl; float dist;
-    if (g[0] == 0.f) {
-        const V3 q = v3(fabsf(l.x) - g[1], fabsf(l.y) - g[2], fabsf(l.z) - g[3]);
-        const V3 o = v3(fmaxf(q.x, 0.f), fmaxf(q.y, 0.f), fmaxf(q.z, 0.f));
-        const float len = sqrtf(dot(o, o)), mx = fmaxf(q.x, fmaxf(q.y, q.z));
-        dist = len + fminf(mx, 0.f);
-        const V3 sg = v3(l.x < 0.f ? -1.f : 1.f, l.y < 0.f ? -1.f : 1.f, l.z < 0.f ? -1.f : 1.f);
-        if (len > 0.f) nl = v3(o.x / len * sg.x, o.y / len * sg.y, o.z / len * sg.z);
-        else if (q.x >= q.y && q.x >= q.z) nl = v3(sg.x, 0.f, 0.f);           // first maximal axis, like the oracle's argmax
-        else if (q.y >= q.z) nl = v3(0.f, sg.y, 0.f);
-        else nl = v3(0.f, 0.f, sg.z);
-    } else {
-        const float rr = sqrtf(l.x * l.x + l.y * l.y), ux = rr > 1e-12f ? l.x / rr : 1.f, uy = rr > 1e-12f ? l.y / rr : 0.f;
-        const float qr = rr - g[1], qz = fabsf(l.z) - g[2], sz = l.z < 0.f ? -1.f : 1.f;
-        const float orr = fmaxf(qr, 0.f), oz = fmaxf(qz, 0.f), len = sqrtf(orr * orr + oz * oz), mx = fmaxf(qr, qz);
-        dist = len + fminf(mx, 0.f);
-        if (len > 0.f) nl = v3(orr * ux / len, orr * uy / len, oz * sz / len);
-        else if (qr > qz) nl = v3(ux, uy, 0.f);
-        else nl = v3(0.f, 0.f, sz);
-    }
-    nw = mulmat(R, nl);
-    return dist;
-}
-
+// ---------------------------------------------------------------- collision (first wavefront)
 __device__ __forceinline__ float geom_rbound(const float* g) { return g[0] == 0.f ? sqrtf(g[1] * g[1] + g[2] * g[2] + g[3] * g[3]) : sqrtf(g[1] * g[1] + g[2] * g[2]); }
 
-// Narrow phase (first wavefront).  Broad phase in parallel: lane = hull body (then lane = object geom) tests all its targets
-// (bit 0 = floor, bit j = geom j - 1) at once; the serial part only visits the pairs that passed, in the oracle's order
-// (body-major, floor first), so contact indices, con_start[] grouping and tie-breaks are unchanged.
+// one lane appends a contact: vertex-side entity A (0..23 hull, 24 + k object slot), surface-side entity B (-1 world / static geom),
+// normal pointing from B's geom into A's
+template <bool OBJ>
+__device__ __forceinline__ void put_contact(EnvLds& s, int c, V3 pos, float dist, V3 nrm, int A, int B, float iw2) {
+    st3(s.con_pos + 3 * c, pos);
+    s.con_dist[c] = dist; s.con_body[c] = A;
+    if constexpr (OBJ) {
+        EnvLdsObj& so = static_cast<EnvLdsObj&>(s);
+        st3(so.con_n + 3 * c, nrm); so.con_iw2[c] = iw2; so.con_b2[c] = (signed char)B;
+    }
+}
+
+// mj_collision of the scene.  Mid phase in parallel: lane = hull body (then lane = object geom) tests all its targets (bit 0 = floor,
+// bit j = geom j - 1) with bounding spheres; the serial part visits only the pairs that passed, in the oracle's order (entity-major,
+// floor first), so contact indices and the con_start[] grouping are the oracle's.  Narrow phases: kp_collide.hpp.
 template <int NT, bool OBJ>
-__device__ __forceinline__ void collide_plane(EnvLds& s, const DevTables& T, const Params& P, int tid) {
+__device__ __forceinline__ void collide(EnvLds& s, const DevTables& T, const Params& P, int tid) {
     if (tid < 64) {
         int ncon = 0, next_b = 0;
         const int ngeom = OBJ ? static_cast<EnvLdsObj&>(s).ngeom : 0;
@@ -621,8 +608,6 @@ __device__ __forceinline__ void collide_plane(EnvLds& s, const DevTables& T, con
                     const float* g = static_cast<EnvLdsObj&>(s).geom + 17 * gi;
                     const V3 dx = xb - ld3(g + 4);
                     if (sqrtf(dot(dx, dx)) - rb - geom_rbound(g) > P.margin) continue;
-                    V3 ntmp;                                   // the signed distance is 1-Lipschitz: no vertex of the hull can be closer
-                    if (geom_sdf(g, xb, ntmp) - rb > P.margin) continue;
                     mybits |= 2u << gi;
                 }
             }
@@ -638,41 +623,48 @@ __device__ __forceinline__ void collide_plane(EnvLds& s, const DevTables& T, con
             const V3 xb = ld3(s.xpos + 3 * b);
             float R[9];
             q2mat(Q4{s.xquat[4 * b], s.xquat[4 * b + 1], s.xquat[4 * b + 2], s.xquat[4 * b + 3]}, R);
-            V3 v = v3(0.f, 0.f, 0.f), xw = v3(0.f, 0.f, 0.f);
+            V3 v = v3(0.f, 0.f, 0.f), xw = v3(0.f, 0.f, 3.0e38f);
             if (tid < nvb) { v = ld3(T.verts + 3 * (vadr + tid)); xw = xb + mulmat(R, v); }
             while (bits) {
                 const int gi = __ffs((int)bits) - 2;           // -1 = floor
                 bits &= bits - 1u;
-                const float* g = gi < 0 ? nullptr : static_cast<EnvLdsObj&>(s).geom + 17 * gi;
-                float dist = 3.0e38f;
-                V3 nrm = v3(0.f, 0.f, 1.f);
-                if (tid < nvb) dist = gi < 0 ? xw.z : geom_sdf(g, xw, nrm);
-                bool cand = dist < P.margin;
-                for (int r = 0; r < D_CON_PER_GEOM; r++) {
-                    if (__ballot(cand) == 0ull) break;
-                    const float dmin = wave_min(cand ? dist : 3.0e38f);
-                    const int idx = __ffsll((long long)__ballot(cand && dist == dmin)) - 1;      // deepest vertex, lowest index on ties
-                    if (ncon < D_MAXCON) {
-                        if (tid == idx) {
-                            st3(s.con_pos + 3 * ncon, xw - (0.5f * dist) * nrm);
-                            s.con_dist[ncon] = dist; s.con_body[ncon] = b;
-                            if (OBJ) {
-                                EnvLdsObj& so = static_cast<EnvLdsObj&>(s);
-                                st3(so.con_n + 3 * ncon, nrm); so.con_iw2[ncon] = gi < 0 ? 0.f : g[16];
-                                so.con_b2[ncon] = (signed char)((gi < 0 || so.gobj[gi] < 0) ? -1 : D_NB + so.gobj[gi]);
-                            }
+                if (gi < 0) {
+                    // mjc_PlaneConvex: the support vertex of -normal (deepest, first on ties), then up to three of its hull-graph
+                    // neighbours, in graph order, that are within the margin
+                    const float dmin = wave_min(xw.z);
+                    if (dmin > P.margin) continue;
+                    const int idx = __builtin_amdgcn_readfirstlane(__ffsll((long long)__ballot(xw.z == dmin)) - 1);
+                    const int n0 = T.vert_nbr_adr[vadr + idx], n1 = T.vert_nbr_adr[vadr + idx + 1];
+                    int cnt = 0;
+                    for (int k = -1; k < n1 - n0 && cnt < D_CON_PER_GEOM; k++) {
+                        const int j = k < 0 ? idx : (int)T.vert_nbr[n0 + k];
+                        const float zj = bcast_lane(xw.z, j);
+                        if (k >= 0 && zj > P.margin) continue;
+                        if (ncon < D_MAXCON) {
+                            if (tid == j) put_contact<OBJ>(s, ncon, v3(xw.x, xw.y, xw.z - 0.5f * xw.z), xw.z, v3(0.f, 0.f, 1.f), b, -1, 0.f);
+                            ncon++;
                         }
+                        cnt++;
+                    }
+                } else if constexpr (OBJ) {
+                    // mjc_Convex (libccd MPR): geom 1 = the box / cylinder, geom 2 = the hull; one contact, normal into the hull
+                    EnvLdsObj& so = static_cast<EnvLdsObj&>(s);
+                    const float* g = so.geom + 17 * gi;
+                    const GeomSupport ga(g);
+                    const HullSupport hb(xb, R, ld3(s.xipos + 3 * b), v, tid < nvb);
+                    Contact c;
+                    if (convex_pair(ga, hb, P.margin, c) && ncon < D_MAXCON) {
+                        if (tid == 0) put_contact<OBJ>(s, ncon, c.pos, c.dist, c.n, b, so.gobj[gi] < 0 ? -1 : D_NB + so.gobj[gi], g[16]);
                         ncon++;
                     }
-                    if (tid == idx) cand = false;
                 }
             }
         }
         if (tid == 0) for (int bb = next_b; bb <= D_NB; bb++) s.con_start[bb] = ncon;
         if constexpr (OBJ) {
-            // dynamic objects in slot order: the 8 vertices of every geom (lane = vertex) against the floor, then against the geoms
-            // of the objects in higher slots; up to 4 deepest per pair (oracle: kpo_collide, second loop)
+            // dynamic objects in slot order: every geom against the floor, then against the geoms of the objects in higher slots
             EnvLdsObj& so = static_cast<EnvLdsObj&>(s);
+            float* rec = s.U + 96;                             // contact records of one pair; s.U is free outside the ABA passes
             int slot_done = 0;
             unsigned gbits = 0;
             if (tid >= so.ngeom_static && tid < ngeom && P.contact) {
@@ -697,37 +689,41 @@ __device__ __forceinline__ void collide_plane(EnvLds& s, const DevTables& T, con
                 const float* g = so.geom + 17 * ga;
                 const int ka = so.gobj[ga];
                 while (slot_done < ka) { slot_done++; if (tid == 0) s.con_start[D_NB + slot_done] = ncon; }
-                V3 xw;
-                {
-                    const int v = tid & 7;
-                    V3 l;
-                    if (g[0] == 0.f) l = v3((v & 1) ? g[1] : -g[1], (v & 2) ? g[2] : -g[2], (v & 4) ? g[3] : -g[3]);
-                    else { const int a = v & 3; l = v3(g[1] * (a == 0 ? 1.f : (a == 2 ? -1.f : 0.f)), g[1] * (a == 1 ? 1.f : (a == 3 ? -1.f : 0.f)), (v & 4) ? g[2] : -g[2]); }
-                    xw = ld3(g + 4) + mulmat(g + 7, l);
-                }
                 while (bits) {
                     const int gb = __ffs((int)bits) - 2;
                     bits &= bits - 1u;
                     const float* h = gb < 0 ? nullptr : so.geom + 17 * gb;
-                    float dist = 3.0e38f;
-                    V3 nrm = v3(0.f, 0.f, 1.f);
-                    if (tid < 8) dist = gb < 0 ? xw.z : geom_sdf(h, xw, nrm);
-                    bool cand = dist < P.margin;
-                    for (int r = 0; r < D_OBJ_CON_PER_GEOM; r++) {
-                        if (__ballot(cand) == 0ull) break;
-                        const float dmin = wave_min(cand ? dist : 3.0e38f);
-                        const int idx = __ffsll((long long)__ballot(cand && dist == dmin)) - 1;
-                        if (ncon < D_MAXCON) {
-                            if (tid == idx) {
-                                st3(s.con_pos + 3 * ncon, xw - (0.5f * dist) * nrm);
-                                s.con_dist[ncon] = dist; s.con_body[ncon] = D_NB + ka;
-                                st3(so.con_n + 3 * ncon, nrm); so.con_iw2[ncon] = gb < 0 ? 0.f : h[16];
-                                so.con_b2[ncon] = (signed char)(gb < 0 ? -1 : D_NB + so.gobj[gb]);
-                            }
-                            ncon++;
+                    int n = 0, entB = -1; float iw2 = 0.f, sgn = 1.f;
+                    if (gb < 0) {
+                        if (g[0] == 0.f) {
+                            // mjc_PlaneBox: lane = corner (bit 0 / 1 / 2 = +x / +y / +z); corners that point up or lie beyond the margin
+                            // are skipped, the first four of the rest (in index order) make contacts
+                            const int i = tid & 7;
+                            const V3 corner = mulmat(g + 7, v3((i & 1) ? g[1] : -g[1], (i & 2) ? g[2] : -g[2], (i & 4) ? g[3] : -g[3]));
+                            const float dist = g[6], ldist = corner.z;
+                            const bool ok = tid < 8 && !(dist + ldist > P.margin || ldist > 0.f);
+                            const unsigned long long m = __ballot(ok);
+                            const int rank = __popcll(m & ((1ull << tid) - 1ull));
+                            n = min(__popcll(m), 4);
+                            if (ok && rank < 4) put_rec(rec, rank, dist + ldist, corner + ld3(g + 4) - (0.5f * (dist + ldist)) * v3(0.f, 0.f, 1.f), v3(0.f, 0.f, 1.f));
+                        } else n = plane_cylinder(g, P.margin, rec, tid == 0);
+                    } else {
+                        // geom 1 = the lower geom type (cylinder < box), then the lower geom id (ga); the stored normal runs from gb into ga
+                        const bool a_first = !(g[0] == 0.f && h[0] != 0.f);
+                        entB = D_NB + so.gobj[gb]; iw2 = h[16]; sgn = a_first ? -1.f : 1.f;
+                        if (g[0] == 0.f && h[0] == 0.f) {
+                            if (tid == 0) n = box_box(g, h, P.margin, rec, s.U);
+                            n = __builtin_amdgcn_readfirstlane(n);
+                        } else {
+                            const GeomSupport s1(a_first ? g : h), s2(a_first ? h : g);
+                            Contact c;
+                            n = convex_pair(s1, s2, P.margin, c);
+                            if (n && tid == 0) put_rec(rec, 0, c.dist, c.pos, c.n);
                         }
-                        if (tid == idx) cand = false;
                     }
+                    n = min(n, D_MAXCON - ncon);
+                    if (tid < n) put_contact<OBJ>(s, ncon + tid, ld3(rec + 7 * tid + 1), rec[7 * tid], sgn * ld3(rec + 7 * tid + 4), D_NB + ka, entB, iw2);
+                    ncon += n;
                 }
             }
             while (slot_done < D_MAXOBJ) { slot_done++; if (tid == 0) s.con_start[D_NB + slot_done] = ncon; }
@@ -1639,7 +1635,7 @@ __device__ __forceinline__ void step_body(StepArgs A, const int env_in, const in
         forward_kin_bias<NT>(s, T, P, depth, bpos, tid);
         if constexpr (OBJ) obj_forward(s, P, tid);
         KP_T(1)
-        collide_plane<NT, OBJ>(s, T, P, tid);
+        collide<NT, OBJ>(s, T, P, tid);
         KP_T(2)
         make_constraint<NT, OBJ>(s, T, P, tid);                 // needs sv = cvel: before any aba_solve
         KP_T(3)
@@ -1699,6 +1695,16 @@ __device__ __forceinline__ void step_body(StepArgs A, const int env_in, const in
                 if (tid < 7) { const float v = s.oq[7 * k + tid]; bad |= !(fabsf(v) < 1e10f); gst<Q>(A.obj_qpos + (size_t)env * 35 + 7 * oi + tid, v); }
                 if (tid < 6) { gst<Q>(A.obj_qvel + (size_t)env * 30 + 6 * oi + tid, s.ov[6 * k + tid]); gst<Q>(A.obj_warm + (size_t)env * 6 * D_MAXOBJ + 6 * k + tid, s.oqa[6 * k + tid]); }
             }
+        }
+    }
+    if (A.dbg_contacts && A.n_substeps > 0) {      // test hook: the contact set of the last collision pass
+        float* o = A.dbg_contacts + (size_t)env * (1 + D_MAXCON * 9);
+        if (tid == 0) o[0] = (float)s.ncon;
+        for (int c = tid; c < s.ncon; c += NT) {
+            float* r = o + 1 + 9 * c;
+            r[0] = (float)s.con_body[c]; r[2] = s.con_dist[c]; r[3] = s.con_pos[3 * c]; r[4] = s.con_pos[3 * c + 1]; r[5] = s.con_pos[3 * c + 2];
+            if constexpr (OBJ) { const EnvLdsObj& so = static_cast<const EnvLdsObj&>(s); r[1] = (float)so.con_b2[c]; r[6] = so.con_n[3 * c]; r[7] = so.con_n[3 * c + 1]; r[8] = so.con_n[3 * c + 2]; }
+            else { r[1] = -1.f; r[6] = 0.f; r[7] = 0.f; r[8] = 1.f; }
         }
     }
     if (bad) atomicOr(&s.flag, 1);

@@ -11,7 +11,8 @@ convex hulls under ``geom/``, and emits every constant the HIP simulator needs:
 * kinematic tree (parents, local offsets), per-body mass / COM / inertia from the
   mesh at density 1000 kg/m^3 (exact polyhedral integration),
 * dof tables in MuJoCo's ``qM`` sparse layout (dof_parent, dof_madr, armature),
-* hull vertices per body (for hull-vs-plane collision) and bounding radii,
+* hull vertices per body, the vertex adjacency graph of each convex hull (qhull, as MuJoCo's mesh compiler builds
+  `mesh_graph` for its plane-mesh / support-function code) and bounding radii,
 * stable-PD gains / torque limits / RFC parameters from ``config/uhc/uhc.yml:81-156``,
 * constraint-model constants evaluated at ``qpos0`` (body/dof ``invweight0``,
   ``meaninertia``) the soft-contact model needs,
@@ -36,7 +37,7 @@ import xml.etree.ElementTree as ET
 import numpy as np
 
 KPM_MAGIC = 0x314D504B  # 'KPM1'
-KPM_VERSION = 5
+KPM_VERSION = 6
 
 # MuJoCo 2.1.0 defaults that the reference never overrides [MJ-ext]
 MJ_DEFAULTS = dict(
@@ -90,6 +91,27 @@ def polyhedron_mass_props(tris: np.ndarray, density: float):
     C -= V * np.outer(com_rel, com_rel)
     inertia = (np.trace(C) * np.eye(3) - C) * density
     return V * density, ref + com_rel, inertia
+
+
+def hull_graph(v: np.ndarray):
+    """Vertex adjacency of the convex hull of `v` [n,3] (every row must be a hull vertex), as ordered neighbour lists.
+
+    MuJoCo's mesh compiler runs qhull ("qhull Qt": triangulated facets) on the mesh vertices and stores, per hull vertex, the
+    list of vertices it shares a facet edge with (`mesh_graph`; user_mesh.cc MakeGraph) [MJ-ext]: facets are visited in qhull's
+    order, and each facet appends, for each of its three vertices, the other two if not yet listed.  scipy.spatial.ConvexHull
+    drives the same qhull with the same option, so the lists -- and their order, which decides WHICH neighbours make contacts
+    when more than three qualify -- are rebuilt the same way here.  (What cannot be reproduced: MuJoCo's own vertex numbering
+    of the un-welded STL triangles, which only permutes ties.)"""
+    from scipy.spatial import ConvexHull
+    h = ConvexHull(v, qhull_options="Qt")
+    assert len(h.vertices) == len(v), "mesh has vertices inside its convex hull"
+    lists = [[] for _ in range(len(v))]
+    for tri in h.simplices:
+        for a in range(3):
+            for c in range(3):
+                if c != a and int(tri[c]) not in lists[int(tri[a])]:
+                    lists[int(tri[a])].append(int(tri[c]))
+    return lists
 
 
 # --------------------------------------------------------------------------- XML parsing
@@ -220,6 +242,7 @@ def compile_model(xml_path: str, uhc_yml: str | None = None) -> dict:
     ipos = np.zeros((nb, 3))
     inertia = np.zeros((nb, 3, 3))
     verts_all, vert_adr, rbound = [], [0], np.zeros(nb)
+    nbr_adr, nbr = [0], []
     for i, b in enumerate(bodies):
         assert len(b["geoms"]) == 1 and b["geoms"][0]["type"] == "mesh"
         tris = read_binary_stl(px["meshes"][b["geoms"][0]["mesh"]])
@@ -229,6 +252,14 @@ def compile_model(xml_path: str, uhc_yml: str | None = None) -> dict:
         verts_all.append(v)
         vert_adr.append(vert_adr[-1] + len(v))
         rbound[i] = np.linalg.norm(v, axis=1).max()
+        lists = hull_graph(v)
+        # mjc_PlaneConvex skips a neighbour closer than 1e-3 * rbound to the first contact [MJ-ext]: distinct vertices of these
+        # hulls are >= 2.4 mm apart, so that filter can never fire and the kernels do not carry it
+        from scipy.spatial.distance import pdist
+        assert pdist(v).min() > 2e-3 * rbound[i], "hull vertices closer than the plane-mesh duplicate filter"
+        for lst in lists:
+            nbr.extend(lst)
+            nbr_adr.append(len(nbr))
     verts = np.concatenate(verts_all)
 
     # ---- dofs: free root (3 trans world axes + 3 rot body axes) then 3 hinges (z,y,x) per body
@@ -390,6 +421,7 @@ def compile_model(xml_path: str, uhc_yml: str | None = None) -> dict:
         dof_body=dof_body, dof_parent=dof_parent, dof_depth=dof_depth, dof_madr=dof_madr,
         dof_armature=np.array(arm), jnt_range=np.array(jrange), jnt_limited=np.array(jlimited, np.int32),
         vert_adr=np.array(vert_adr, np.int32), verts=verts,
+        vert_nbr_adr=np.array(nbr_adr, np.int32), vert_nbr=np.array(nbr, np.int32),   # hull graph: neighbours of vertex v (hull-local ids)
         kp=kp, kd=kd, torque_lim=tlim, a_scale=a_scale,
         opt=np.array([px["timestep"], *MJ_DEFAULTS["gravity"], *MJ_DEFAULTS["solref"], *MJ_DEFAULTS["solimp"],
                       *fric, geom_margin, MJ_DEFAULTS["impratio"], meaninertia,

@@ -34,6 +34,7 @@ ABI_SYMBOLS = [
     "kp_sim_step_begin", "kp_sim_obs_ar", "kp_sim_term_reward", "kp_gae", "kp_sim_set_full_state", "kp_sim_fk",
     "kp_sim_timing_reset", "kp_sim_timing_mean_seconds", "kp_sim_phase_cycles", "kp_sim_set_objects", "kp_sim_set_obj_state",
     "kp_sim_launch_cost", "kp_job_schedule", "kp_sim_fk_backward", "kp_sim_set_stream", "kp_sim_status_device", "kp_sim_mass_matrix",
+    "kp_sim_contacts",
 ]
 
 
@@ -102,6 +103,7 @@ def load_library(path: str | None = None):
     L.kp_sim_set_stream.argtypes = [P, C.c_void_p]; L.kp_sim_set_stream.restype = C.c_int
     L.kp_sim_status_device.argtypes = [P]; L.kp_sim_status_device.restype = C.c_void_p
     L.kp_sim_mass_matrix.argtypes = [P, F, F]; L.kp_sim_mass_matrix.restype = C.c_int
+    L.kp_sim_contacts.argtypes = [P, C.c_void_p]; L.kp_sim_contacts.restype = C.c_int
     L.kp_last_error.restype = C.c_char_p
     L.kp_version.restype = C.c_char_p
     _lib = L
@@ -183,6 +185,20 @@ class KpSim:
             holder = type("_KpStatus", (), {"__cuda_array_interface__": iface})()
             self._status = torch.as_tensor(holder, device=self.device)
         return self._status
+
+    def record_contacts(self):
+        """Arm the contact read-out (kp_sim_contacts): later step_ctrl launches keep the contact set of their last collision pass."""
+        _check(self.L.kp_sim_contacts(self.h, None), "kp_sim_contacts")
+
+    def contacts(self):
+        """List over envs of dict(body, b2, dist [n], pos [n,3], normal [n,3]) of the last collision pass (after record_contacts())."""
+        buf = np.zeros((self.n, 1 + 64 * 9), np.float32)
+        _check(self.L.kp_sim_contacts(self.h, buf.ctypes.data_as(C.c_void_p)), "kp_sim_contacts")
+        out = []
+        for e in range(self.n):
+            n = int(buf[e, 0]); r = buf[e, 1:1 + 9 * n].reshape(n, 9).astype(np.float64)
+            out.append(dict(body=r[:, 0].astype(int), b2=r[:, 1].astype(int), dist=r[:, 2], pos=r[:, 3:6], normal=r[:, 6:9]))
+        return out
 
     def mass_matrix(self):
         """(M [N,75,75], qfrc_bias [N,75]) of the state the derived quantities belong to (mj_fullM / data.qfrc_bias)."""

@@ -34,7 +34,7 @@
 #define NM_MAX 1221
 #define MAXCON 64
 #define MAXEFC (MAXCON * 4 + 2 * 69)
-#define CON_PER_GEOM 3
+#define CON_PER_GEOM 4                  /* mjc_PlaneConvex: support vertex + up to 3 of its hull-graph neighbours */
 #define MAXGEOM 8
 #define MAXOBJ 2                        /* dynamic free objects per env (push: box + table) */
 #define NVT_MAX (NV_MAX + 6 * MAXOBJ)   /* dofs of the humanoid + the active objects */
@@ -54,12 +54,15 @@ typedef struct {
     int jnt_limited[69];
     int vert_adr[NB_MAX + 1];
     double *verts; /* [nvert][3] body frame */
+    int *vert_nbr_adr, *vert_nbr;   /* hull graph: neighbours (hull-local vertex ids) of vertex v are vert_nbr[vert_nbr_adr[v] .. vert_nbr_adr[v + 1]) */
     double kp[69], kd[69], torque_lim[69], a_scale[69];
     double timestep, gravity[3], solref[2], solimp[5], friction[3], margin, impratio, meaninertia;
     double rfc_scale, rfc_lim, base_rot[4];
     int nv_full;   /* dofs of the whole reference scene (humanoid + all objects): solver termination scale */
     int solver_iter;
     double solver_tol;
+    int ls_iterations; double ls_tolerance;   /* mjOption.ls_iterations = 50, ls_tolerance = 0.01 (MuJoCo 2.1.0 defaults) */
+    int ls_exact;                              /* 1: exact minimiser along the search direction instead of PrimalSearch (tests) */
     /* switches (tests) */
     int enable_contact, enable_limits;
 } kpo_model;
@@ -199,6 +202,9 @@ kpo_model *kpo_model_load(const char *path) {
     LOADI(m->vert_adr, "vert_adr", m->nb + 1);
     m->verts = malloc(sizeof(double) * 3 * m->nvert);
     { uint64_t c; const void *p = kpm_find(buf, "verts", &c, 0); memcpy(m->verts, p, 8 * 3 * m->nvert); }
+    { uint64_t c, c2; const void *p = kpm_find(buf, "vert_nbr_adr", &c, 1), *q = kpm_find(buf, "vert_nbr", &c2, 1);
+      if (!p || !q || c != (uint64_t)m->nvert + 1) { fprintf(stderr, "kpo: blob has no hull graph (recompile the model, KPM version 6)\n"); free(buf); free(m->verts); free(m); return NULL; }
+      m->vert_nbr_adr = malloc(4 * c); memcpy(m->vert_nbr_adr, p, 4 * c); m->vert_nbr = malloc(4 * (c2 ? c2 : 1)); memcpy(m->vert_nbr, q, 4 * c2); }
     LOADF(m->kp, "kp", m->nu); LOADF(m->kd, "kd", m->nu); LOADF(m->torque_lim, "torque_lim", m->nu);
     LOADF(m->a_scale, "a_scale", m->nu);
     double opt[26]; LOADF(opt, "opt", 26);
@@ -207,12 +213,14 @@ kpo_model *kpo_model_load(const char *path) {
     m->impratio = opt[15]; m->meaninertia = opt[16]; m->rfc_scale = opt[17]; m->rfc_lim = opt[18];
     memcpy(m->base_rot, opt + 19, 32); m->solver_iter = (int)opt[23]; m->solver_tol = opt[24]; m->nv_full = (int)opt[25];
     m->enable_contact = 1; m->enable_limits = 1;
+    m->ls_iterations = 50; m->ls_tolerance = 0.01; m->ls_exact = 0;
     free(buf);
     return m;
 }
-void kpo_model_free(kpo_model *m) { if (m) { free(m->verts); free(m); } }
+void kpo_model_free(kpo_model *m) { if (m) { free(m->verts); free(m->vert_nbr_adr); free(m->vert_nbr); free(m); } }
 void kpo_model_set_flags(kpo_model *m, int contact, int limits) { m->enable_contact = contact; m->enable_limits = limits; }
 void kpo_model_set_gravity(kpo_model *m, double gz) { m->gravity[2] = gz; }
+void kpo_model_set_ls_exact(kpo_model *m, int exact) { m->ls_exact = exact; }
 kpo_data *kpo_data_new(void) { return calloc(1, sizeof(kpo_data)); }
 void kpo_data_free(kpo_data *d) { free(d); }
 size_t kpo_data_sizeof(void) { return sizeof(kpo_data); }
@@ -421,45 +429,8 @@ static void kpo_point_jac(const kpo_model *m, const kpo_data *d, int ent, const 
         }
     }
 }
-/* the 8 collision vertices of an object geom (body frame of the geom): box corners (bit 0/1/2 = +x/+y/+z), cylinder
- * rim points at 0/90/180/270 degrees on the bottom then the top cap.  Engine rule, see kpo_collide. */
-static void kpo_geom_vertex(const kpo_geom *g, int v, double *xw) {
-    double l[3];
-    if (g->type == 0) { l[0] = (v & 1) ? g->size[0] : -g->size[0]; l[1] = (v & 2) ? g->size[1] : -g->size[1]; l[2] = (v & 4) ? g->size[2] : -g->size[2]; }
-    else { static const double cs[4][2] = {{1, 0}, {0, 1}, {-1, 0}, {0, -1}}; l[0] = g->size[0] * cs[v & 3][0]; l[1] = g->size[0] * cs[v & 3][1]; l[2] = (v & 4) ? g->size[1] : -g->size[1]; }
-    mat_mulvec(xw, g->mat, l);
-    for (int a = 0; a < 3; a++) xw[a] += g->pos[a];
-}
+#include "kp_collide.h"
 
-/* hull-vs-plane narrow phase.  Engine rule (documented in DESIGN.md): per hull, the up-to-3
- * deepest vertices with dist < margin, ties broken by vertex index; contact point is the midpoint
- * between the vertex and its projection; frame = MuJoCo mju_makeFrame of the plane normal. [MJ-ext] */
-/* signed distance + outward normal (world) of a static box / cylinder geom at world point x.
- * Engine rule for hull-vs-primitive contacts: the reference leaves these to MuJoCo's general convex
- * narrow phase (libccd), which cannot be restated verifiably; here every hull VERTEX is tested against the
- * primitive's exact signed-distance field and the <= 3 deepest vertices with dist < margin make contacts. */
-static double kpo_geom_sdf(const kpo_geom *g, const double *x, double *nw) {
-    double r[3] = {x[0] - g->pos[0], x[1] - g->pos[1], x[2] - g->pos[2]}, l[3], nl[3], dist;
-    for (int k = 0; k < 3; k++) l[k] = g->mat[k] * r[0] + g->mat[3 + k] * r[1] + g->mat[6 + k] * r[2];   /* R^T r */
-    if (g->type == 0) {
-        double q[3], o[3], len2 = 0, mx = -1e300; int am = 0;
-        for (int k = 0; k < 3; k++) { q[k] = fabs(l[k]) - g->size[k]; o[k] = q[k] > 0 ? q[k] : 0; len2 += o[k] * o[k]; if (q[k] > mx) { mx = q[k]; am = k; } }
-        double len = sqrt(len2);
-        dist = len + (mx < 0 ? mx : 0);
-        if (len > 0) for (int k = 0; k < 3; k++) nl[k] = o[k] / len * (l[k] < 0 ? -1.0 : 1.0);
-        else { nl[0] = nl[1] = nl[2] = 0; nl[am] = l[am] < 0 ? -1.0 : 1.0; }
-    } else {
-        double rr = sqrt(l[0] * l[0] + l[1] * l[1]), ux = rr > 1e-12 ? l[0] / rr : 1.0, uy = rr > 1e-12 ? l[1] / rr : 0.0;
-        double qr = rr - g->size[0], qz = fabs(l[2]) - g->size[1], sz = l[2] < 0 ? -1.0 : 1.0;
-        double orr = qr > 0 ? qr : 0, oz = qz > 0 ? qz : 0, len = sqrt(orr * orr + oz * oz), mx = qr > qz ? qr : qz;
-        dist = len + (mx < 0 ? mx : 0);
-        if (len > 0) { nl[0] = orr * ux / len; nl[1] = orr * uy / len; nl[2] = oz * sz / len; }
-        else if (qr > qz) { nl[0] = ux; nl[1] = uy; nl[2] = 0; }
-        else { nl[0] = nl[1] = 0; nl[2] = sz; }
-    }
-    mat_mulvec(nw, g->mat, nl);
-    return dist;
-}
 /* mju_makeFrame: x-axis given, y from (0,1,0) or (0,0,1) made orthogonal, z = x cross y  [MJ-ext] */
 static void kpo_make_frame(double *fr) {
     double *x = fr, *y = fr + 3, *z = fr + 6;
@@ -471,80 +442,72 @@ static void kpo_make_frame(double *fr) {
     v3_cross(z, x, y);
 }
 
-/* narrow phase.  Engine rule (documented in DESIGN.md): per (hull, plane|primitive) pair, the up-to-3
- * deepest hull vertices with dist < margin, ties broken by vertex index; contact point is the midpoint
- * between the vertex and its projection; contacts are emitted body by body: floor first, then geoms. [MJ-ext] */
+static void kpo_shape_of_geom(const kpo_geom *g, kpc_shape *s) {
+    s->type = g->type; memcpy(s->size, g->size, 24); memcpy(s->pos, g->pos, 24); memcpy(s->mat, g->mat, 72); memcpy(s->center, g->pos, 24);
+    s->verts = NULL; s->nvert = 0;
+}
+static void kpo_shape_of_hull(const kpo_model *m, const kpo_data *d, int b, kpc_shape *s) {
+    s->type = 2; s->size[0] = s->size[1] = s->size[2] = 0; memcpy(s->pos, d->xpos[b], 24); memcpy(s->mat, d->xmat[b], 72);
+    memcpy(s->center, d->xipos[b], 24);              /* MuJoCo centres a mesh geom on the mesh's COM: geom_xpos == xipos for these one-geom bodies */
+    s->verts = m->verts + 3 * m->vert_adr[b]; s->nvert = m->vert_adr[b + 1] - m->vert_adr[b];
+}
+/* append the contacts of one geom pair.  ent_a / ent_b: entities of the solver (0..23 hull body, 24+k object, -1 world); the
+ * stored normal points from ent_b's geom into ent_a's (flip = the MuJoCo normal, geom 1 -> geom 2, runs the other way) */
+static void kpo_emit(kpo_data *d, const kpc_contact *c, int n, int ent_a, int ent_b, double invw_b, int flip) {
+    for (int i = 0; i < n && d->ncon < MAXCON; i++) {
+        int k = d->ncon++;
+        d->con_body[k] = ent_a; d->con_b2[k] = ent_b; d->con_dist[k] = c[i].dist; d->con_invw2[k] = invw_b;
+        memcpy(d->con_pos[k], c[i].pos, 24);
+        for (int a = 0; a < 3; a++) d->con_frame[k][a] = flip ? -c[i].normal[a] : c[i].normal[a];
+        kpo_make_frame(d->con_frame[k]);
+    }
+}
+/* MuJoCo orders a pair by geom type (cylinder 5 < box 6 < mesh 7) and, for equal types, by geom id  [MJ-ext] */
+static int kpo_type_rank(int type) { return type == 1 ? 5 : (type == 0 ? 6 : 7); }
+
+/* mj_collision for the scene: contacts are emitted entity by entity (24 hulls in body order: floor first, then the object geoms;
+ * then the dynamic objects' geoms: floor first, then the geoms of objects in higher slots), mid-phase = bounding spheres. */
 static void kpo_collide(const kpo_model *m, kpo_data *d) {
     d->ncon = 0;
     if (!m->enable_contact) return;
+    kpc_contact con[KPC_MAXPAIR];
     for (int b = 0; b < m->nb; b++) {
+        kpc_shape hull; kpo_shape_of_hull(m, d, b, &hull);
         for (int gi = -1; gi < d->ngeom; gi++) {
             const kpo_geom *g = gi < 0 ? NULL : &d->geom[gi];
-            if (!g) { if (d->xpos[b][2] - m->body_rbound[b] > m->margin) continue; }
-            else {
+            if (!g) {
+                if (d->xpos[b][2] - m->body_rbound[b] > m->margin) continue;
+                int n = kpo_plane_mesh(&hull, m->vert_nbr_adr + m->vert_adr[b], m->vert_nbr, m->margin, m->body_rbound[b], con);
+                kpo_emit(d, con, n, b, -1, 0.0, 0);
+            } else {
                 double dx[3] = {d->xpos[b][0] - g->pos[0], d->xpos[b][1] - g->pos[1], d->xpos[b][2] - g->pos[2]};
                 if (sqrt(v3_dot(dx, dx)) - m->body_rbound[b] - g->rbound > m->margin) continue;
-            }
-            int best[CON_PER_GEOM]; double bd[CON_PER_GEOM], bn[CON_PER_GEOM][3]; int nbest = 0;
-            for (int v = m->vert_adr[b]; v < m->vert_adr[b + 1]; v++) {
-                double w[3], nrm[3] = {0, 0, 1}, dist; mat_mulvec(w, d->xmat[b], m->verts + 3 * v);
-                double xw[3] = {d->xpos[b][0] + w[0], d->xpos[b][1] + w[1], d->xpos[b][2] + w[2]};
-                dist = g ? kpo_geom_sdf(g, xw, nrm) : xw[2];
-                if (dist >= m->margin) continue;
-                int pos = nbest;
-                while (pos > 0 && dist < bd[pos - 1]) pos--;
-                if (pos >= CON_PER_GEOM) continue;
-                int last = nbest < CON_PER_GEOM ? nbest : CON_PER_GEOM - 1;
-                for (int k = last; k > pos; k--) { best[k] = best[k - 1]; bd[k] = bd[k - 1]; memcpy(bn[k], bn[k - 1], 24); }
-                best[pos] = v; bd[pos] = dist; memcpy(bn[pos], nrm, 24);
-                if (nbest < CON_PER_GEOM) nbest++;
-            }
-            for (int k = 0; k < nbest && d->ncon < MAXCON; k++) {
-                int c = d->ncon++;
-                double w[3]; mat_mulvec(w, d->xmat[b], m->verts + 3 * best[k]);
-                d->con_body[c] = b; d->con_b2[c] = (g && g->obj >= 0) ? NB_MAX + g->obj : -1;
-                d->con_dist[c] = bd[k]; d->con_invw2[c] = g ? g->invw : 0.0;
-                for (int a = 0; a < 3; a++) d->con_pos[c][a] = d->xpos[b][a] + w[a] - 0.5 * bd[k] * bn[k][a];
-                memcpy(d->con_frame[c], bn[k], 24);
-                kpo_make_frame(d->con_frame[c]);
+                kpc_shape gs; kpo_shape_of_geom(g, &gs);
+                int n = kpo_convex(&gs, &hull, m->margin, con);           /* g1 = box / cylinder, g2 = mesh: normal into the hull */
+                if (getenv("KPO_MPR_TRACE")) fprintf(stderr, "mpr hull %d geom %d (type %d): n %d discover %d refine %d penetr %d dist %.6f\n", b, gi, g->type, n, kpc_stat_discover, kpc_stat_refine, kpc_stat_penetr, n ? con[0].dist : 0.0);
+                kpo_emit(d, con, n, b, g->obj >= 0 ? NB_MAX + g->obj : -1, g->invw, 0);
             }
         }
     }
-    /* dynamic objects, in slot order: every geom's 8 vertices against the floor, then against the geoms of the objects
-     * in higher slots (push: the box's corners on the table); up to 4 deepest vertices per pair.  Engine rule: MuJoCo's
-     * plane-box / plane-cylinder / box-box routines are not restated. */
     for (int gi = d->ngeom_static; gi < d->ngeom; gi++) {
         const kpo_geom *ga = &d->geom[gi];
+        kpc_shape sa; kpo_shape_of_geom(ga, &sa);
         for (int gj = -1; gj < d->ngeom; gj++) {
             const kpo_geom *gb = gj < 0 ? NULL : &d->geom[gj];
             if (gb && (gb->obj < 0 || gb->obj <= ga->obj)) continue;
-            if (!gb) { if (ga->pos[2] - ga->rbound > m->margin) continue; }
-            else {
+            if (!gb) {
+                if (ga->pos[2] - ga->rbound > m->margin) continue;
+                int n = ga->type == 0 ? kpo_plane_box(&sa, m->margin, con) : kpo_plane_cylinder(&sa, m->margin, con);
+                kpo_emit(d, con, n, NB_MAX + ga->obj, -1, 0.0, 0);
+            } else {
                 double dx[3] = {ga->pos[0] - gb->pos[0], ga->pos[1] - gb->pos[1], ga->pos[2] - gb->pos[2]};
                 if (sqrt(v3_dot(dx, dx)) - ga->rbound - gb->rbound > m->margin) continue;
-            }
-            int best[OBJ_CON_PER_GEOM]; double bd[OBJ_CON_PER_GEOM], bn[OBJ_CON_PER_GEOM][3]; int nbest = 0;
-            for (int v = 0; v < 8; v++) {
-                double xw[3], nrm[3] = {0, 0, 1}, dist;
-                kpo_geom_vertex(ga, v, xw);
-                dist = gb ? kpo_geom_sdf(gb, xw, nrm) : xw[2];
-                if (dist >= m->margin) continue;
-                int pos = nbest;
-                while (pos > 0 && dist < bd[pos - 1]) pos--;
-                if (pos >= OBJ_CON_PER_GEOM) continue;
-                int last = nbest < OBJ_CON_PER_GEOM ? nbest : OBJ_CON_PER_GEOM - 1;
-                for (int k = last; k > pos; k--) { best[k] = best[k - 1]; bd[k] = bd[k - 1]; memcpy(bn[k], bn[k - 1], 24); }
-                best[pos] = v; bd[pos] = dist; memcpy(bn[pos], nrm, 24);
-                if (nbest < OBJ_CON_PER_GEOM) nbest++;
-            }
-            for (int k = 0; k < nbest && d->ncon < MAXCON; k++) {
-                int c = d->ncon++;
-                double xw[3]; kpo_geom_vertex(ga, best[k], xw);
-                d->con_body[c] = NB_MAX + ga->obj; d->con_b2[c] = gb ? NB_MAX + gb->obj : -1;
-                d->con_dist[c] = bd[k]; d->con_invw2[c] = gb ? gb->invw : 0.0;
-                for (int a = 0; a < 3; a++) d->con_pos[c][a] = xw[a] - 0.5 * bd[k] * bn[k][a];
-                memcpy(d->con_frame[c], bn[k], 24);
-                kpo_make_frame(d->con_frame[c]);
+                kpc_shape sb; kpo_shape_of_geom(gb, &sb);
+                /* geom 1 = lower type rank, then lower geom id (ga comes first in the scene: lower object index) */
+                int a_first = kpo_type_rank(ga->type) <= kpo_type_rank(gb->type);
+                const kpc_shape *g1 = a_first ? &sa : &sb, *g2 = a_first ? &sb : &sa;
+                int n = (ga->type == 0 && gb->type == 0) ? kpo_box_box(g1, g2, m->margin, con) : kpo_convex(g1, g2, m->margin, con);
+                kpo_emit(d, con, n, NB_MAX + ga->obj, NB_MAX + gb->obj, gb->invw, a_first);   /* stored normal: from gb into ga */
             }
         }
     }
@@ -660,7 +623,65 @@ static double kpo_cost(const kpo_model *m, kpo_data *d, const double *qacc, doub
     return cost;
 }
 
-/* Newton solver on the primal problem (mj_solNewton) with an exact 1-D line search.  [MJ-ext] */
+/* PrimalSearch of engine_solver.c  [MJ-ext]: the line search mj_solNewton runs (mjOption.ls_iterations = 50, ls_tolerance = 0.01).
+ * One Newton step on phi' from alpha = 0; further Newton steps while the derivative keeps its sign; once the minimum is
+ * bracketed, midpoint + the Newton points of both bracket ends are the candidates of every round.  It returns as soon as a point
+ * has |phi'| < gtol = tolerance * ls_tolerance * |search| * meaninertia * nv.  (The exact minimiser, phi' = 0, satisfies the same
+ * test; the two differ by at most gtol / phi'' in alpha.) */
+typedef struct { int ne; double g0, h0; const double *jar, *jv, *D; int evals; } kpo_ls_ctx;
+typedef struct { double alpha, cost, deriv[2]; } kpo_ls_pnt;
+static void kpo_ls_eval(kpo_ls_ctx *c, kpo_ls_pnt *p) {            /* PrimalEval: cost relative to alpha = 0 and its two derivatives */
+    double a = p->alpha, cost = a * c->g0 + 0.5 * a * a * c->h0, d1 = c->g0 + a * c->h0, d2 = c->h0;
+    for (int e = 0; e < c->ne; e++) {
+        double x0 = c->jar[e], x = x0 + a * c->jv[e];
+        if (x < 0) { cost += 0.5 * c->D[e] * x * x; d1 += c->D[e] * x * c->jv[e]; d2 += c->D[e] * c->jv[e] * c->jv[e]; }
+        if (x0 < 0) cost -= 0.5 * c->D[e] * x0 * x0;
+    }
+    p->cost = cost; p->deriv[0] = d1; p->deriv[1] = d2; c->evals++;
+}
+static int kpo_ls_update_bracket(kpo_ls_ctx *c, kpo_ls_pnt *p, const kpo_ls_pnt cand[3], kpo_ls_pnt *pnext) {
+    int flag = 0;
+    for (int i = 0; i < 3; i++) {
+        if (p->deriv[0] < 0 && cand[i].deriv[0] < 0 && p->deriv[0] < cand[i].deriv[0]) { *p = cand[i]; flag = 1; }
+        else if (p->deriv[0] > 0 && cand[i].deriv[0] > 0 && p->deriv[0] > cand[i].deriv[0]) { *p = cand[i]; flag = 2; }
+    }
+    if (flag) { pnext->alpha = p->alpha - p->deriv[0] / p->deriv[1]; kpo_ls_eval(c, pnext); }
+    return flag;
+}
+static double kpo_primal_search(kpo_ls_ctx *c, double snorm, double gtol_per_snorm, int ls_iterations) {
+    kpo_ls_pnt p0, p1, p2, pmid, p1next, p2next;
+    if (snorm < MJ_MINVAL) return 0;
+    double gtol = gtol_per_snorm * snorm;
+    p0.alpha = 0; kpo_ls_eval(c, &p0);
+    if (!(p0.deriv[1] > 0)) return 0;
+    p1.alpha = p0.alpha - p0.deriv[0] / p0.deriv[1]; kpo_ls_eval(c, &p1);
+    if (p0.cost < p1.cost) p1 = p0;
+    if (fabs(p1.deriv[0]) < gtol) return p1.alpha;
+    int dir = p1.deriv[0] < 0 ? 1 : -1, p2update = 0;
+    p2 = p1;
+    while (p1.deriv[0] * dir <= -gtol && c->evals < ls_iterations) {
+        p2 = p1; p2update = 1;
+        p1.alpha -= p1.deriv[0] / p1.deriv[1]; kpo_ls_eval(c, &p1);
+        if (fabs(p1.deriv[0]) < gtol) return p1.alpha;
+    }
+    if (c->evals >= ls_iterations || !p2update) return p1.alpha;
+    p2next = p1;
+    p1next.alpha = p1.alpha - p1.deriv[0] / p1.deriv[1]; kpo_ls_eval(c, &p1next);
+    while (c->evals < ls_iterations) {
+        pmid.alpha = 0.5 * (p1.alpha + p2.alpha); kpo_ls_eval(c, &pmid);
+        kpo_ls_pnt cand[3] = {p1next, p2next, pmid};
+        int best = -1; double bc = 0;
+        for (int i = 0; i < 3; i++) if (fabs(cand[i].deriv[0]) < gtol && (best < 0 || cand[i].cost < bc)) { bc = cand[i].cost; best = i; }
+        if (best >= 0) return cand[best].alpha;
+        int b1 = kpo_ls_update_bracket(c, &p1, cand, &p1next), b2 = kpo_ls_update_bracket(c, &p2, cand, &p2next);
+        if (!b1 && !b2) return pmid.cost < p0.cost ? pmid.alpha : 0;
+    }
+    if (p1.cost <= p2.cost && p1.cost < p0.cost) return p1.alpha;
+    if (p2.cost <= p1.cost && p2.cost < p0.cost) return p2.alpha;
+    return 0;
+}
+
+/* Newton solver on the primal problem (mj_solNewton: mj_solPrimal with flg_Newton).  [MJ-ext] */
 static void kpo_solve_constraint(const kpo_model *m, kpo_data *d) {
     int nv = kpo_nvt(m, d), ne = d->nefc;
     d->solver_niter = 0;
@@ -685,19 +706,25 @@ static void kpo_solve_constraint(const kpo_model *m, kpo_data *d) {
         if (chol_factor(H, nv)) break;
         for (int i = 0; i < nv; i++) search[i] = -grad[i];
         chol_solve(H, nv, search);
-        /* exact line search: phi(a) = cost(qacc + a*search), piecewise quadratic convex */
+        /* line search on phi(a) = cost(qacc + a * search), a convex piecewise quadratic */
         kpo_mulM_full(m, d, search, Mv);
         for (int e = 0; e < ne; e++) { double s = 0; for (int i = 0; i < nv; i++) s += d->efc_J[e][i] * search[i]; jv[e] = s; }
         double g0 = 0, h0 = 0; /* Gauss part: derivative at alpha: g0 + alpha*h0 */
         for (int i = 0; i < nv; i++) { g0 += search[i] * (grad[i] + d->qfrc_constraint[i]); h0 += search[i] * Mv[i]; }
         double alpha = 0;
-        for (int ls = 0; ls < 50; ls++) {
-            double dphi = g0 + alpha * h0, ddphi = h0;
-            for (int e = 0; e < ne; e++) { double x = jar[e] + alpha * jv[e]; if (x < 0) { dphi += d->efc_D[e] * x * jv[e]; ddphi += d->efc_D[e] * jv[e] * jv[e]; } }
-            if (ddphi <= 0) break;
-            double step = -dphi / ddphi;
-            alpha += step;
-            if (fabs(step) < 1e-14 * (1 + fabs(alpha))) break;
+        if (m->ls_exact) {          /* exact minimiser (what the HIP kernel computes): Newton on phi' to machine precision */
+            for (int ls = 0; ls < 50; ls++) {
+                double dphi = g0 + alpha * h0, ddphi = h0;
+                for (int e = 0; e < ne; e++) { double x = jar[e] + alpha * jv[e]; if (x < 0) { dphi += d->efc_D[e] * x * jv[e]; ddphi += d->efc_D[e] * jv[e] * jv[e]; } }
+                if (ddphi <= 0) break;
+                double step = -dphi / ddphi;
+                alpha += step;
+                if (fabs(step) < 1e-14 * (1 + fabs(alpha))) break;
+            }
+        } else {
+            kpo_ls_ctx ctx = {ne, g0, h0, jar, jv, d->efc_D, 0};
+            double sn = 0; for (int i = 0; i < nv; i++) sn += search[i] * search[i];
+            alpha = kpo_primal_search(&ctx, sqrt(sn), m->solver_tol * m->ls_tolerance / scale, m->ls_iterations);
         }
         if (alpha == 0) break;
         for (int i = 0; i < nv; i++) qacc[i] += alpha * search[i];
@@ -867,6 +894,7 @@ int kpo_get_niter(const kpo_data *d) { return d->solver_niter; }
 void kpo_get_contacts(const kpo_data *d, int *body, double *pos, double *dist) {
     for (int c = 0; c < d->ncon; c++) { body[c] = d->con_body[c]; memcpy(pos + 3 * c, d->con_pos[c], 24); dist[c] = d->con_dist[c]; }
 }
+void kpo_get_contact_normals(const kpo_data *d, double *n) { for (int c = 0; c < d->ncon; c++) memcpy(n + 3 * c, d->con_frame[c], 24); }
 void kpo_set_qpos_qvel(kpo_data *d, const double *qpos, const double *qvel) { memcpy(d->qpos, qpos, 8 * NQ_MAX); memcpy(d->qvel, qvel, 8 * NV_MAX); }
 void kpo_set_ctrl(kpo_data *d, const double *ctrl, const double *applied6) { memcpy(d->ctrl, ctrl, 8 * 69); if (applied6) memcpy(d->qfrc_applied, applied6, 48); }
 void kpo_solveM(const kpo_model *m, const kpo_data *d, double *x) { kpo_solve_sparse(m, d->qLD, d->qLDiagInv, x); }
@@ -880,4 +908,28 @@ void kpo_rollout_batch(const kpo_model *m, int n, double *qpos, double *qvel, co
         memcpy(qpos + (size_t)e * NQ_MAX, d->qpos, 8 * NQ_MAX); memcpy(qvel + (size_t)e * NV_MAX, d->qvel, 8 * NV_MAX);
     }
     kpo_data_free(d);
+}
+
+/* ------------------------------------------------------------------ narrow-phase test hooks (tests/test_collide_oracle.py)
+ * shape record: [type, size3 (hull: the MPR centre), pos3, mat9] = 16 doubles; hull vertices / graph passed separately.
+ * kind: 0 kpo_convex(a, b)  1 kpo_plane_box(a)  2 kpo_plane_cylinder(a)  3 kpo_box_box(a, b)  4 kpo_plane_mesh(b).
+ * out [n][7] = dist, pos3, normal3 (geom 1 -> geom 2).  Returns the number of contacts. */
+static void kpo_shape_from_record(const double *r, const double *verts, int nvert, kpc_shape *s) {
+    s->type = (int)r[0]; memcpy(s->size, r + 1, 24); memcpy(s->pos, r + 4, 24); memcpy(s->mat, r + 7, 72);
+    if (s->type == 2) { memcpy(s->center, r + 1, 24); s->verts = verts; s->nvert = nvert; }
+    else { memcpy(s->center, s->pos, 24); s->verts = NULL; s->nvert = 0; }
+}
+int kpo_narrowphase(int kind, const double *a, const double *verts_a, int nvert_a, const double *b, const double *verts_b, int nvert_b,
+                    const int *nbr_adr, const int *nbr, double margin, double rbound, double *out) {
+    kpc_shape sa, sb; kpc_contact con[KPC_MAXPAIR];
+    int n = 0;
+    if (a) kpo_shape_from_record(a, verts_a, nvert_a, &sa);
+    if (b) kpo_shape_from_record(b, verts_b, nvert_b, &sb);
+    if (kind == 0) n = kpo_convex(&sa, &sb, margin, con);
+    else if (kind == 1) n = kpo_plane_box(&sa, margin, con);
+    else if (kind == 2) n = kpo_plane_cylinder(&sa, margin, con);
+    else if (kind == 3) n = kpo_box_box(&sa, &sb, margin, con);
+    else if (kind == 4) n = kpo_plane_mesh(&sb, nbr_adr, nbr, margin, rbound, con);
+    for (int i = 0; i < n; i++) { out[7 * i] = con[i].dist; memcpy(out + 7 * i + 1, con[i].pos, 24); memcpy(out + 7 * i + 4, con[i].normal, 24); }
+    return n;
 }

@@ -37,6 +37,7 @@ def lib():
         L.kpo_model_free.argtypes = [P]
         L.kpo_model_set_flags.argtypes = [P, C.c_int, C.c_int]
         L.kpo_model_set_gravity.argtypes = [P, C.c_double]
+        L.kpo_model_set_ls_exact.argtypes = [P, C.c_int]
         L.kpo_data_new.restype = P
         L.kpo_data_free.argtypes = [P]
         for f in ("kpo_forward", "kpo_step"):
@@ -50,6 +51,7 @@ def lib():
         L.kpo_set_ctrl.argtypes = [P, D, D]
         L.kpo_solveM.argtypes = [P, P, D]
         L.kpo_get_contacts.argtypes = [P, I, D, D]
+        L.kpo_get_contact_normals.argtypes = [P, D]
         L.kpo_set_geoms.argtypes = [P, C.c_int, D]
         L.kpo_set_object.argtypes = [P, C.c_int, D, C.c_int, D, D, D]
         L.kpo_clear_objects.argtypes = [P]
@@ -62,6 +64,7 @@ def lib():
         L.kpo_get_efc.argtypes = [P, D, D, D]
         L.kpo_get_efc_J.argtypes = [P, D]
         L.kpo_rollout_batch.argtypes = [P, C.c_int, D, D, D, D, C.c_int, C.c_int]
+        L.kpo_narrowphase.argtypes = [C.c_int, D, D, C.c_int, D, D, C.c_int, I, I, C.c_double, C.c_double, D]; L.kpo_narrowphase.restype = C.c_int
         for g in ("ncon", "nefc", "niter"):
             getattr(L, "kpo_get_" + g).argtypes = [P]; getattr(L, "kpo_get_" + g).restype = C.c_int
         for f in _FIELDS:
@@ -81,7 +84,7 @@ _FIELDS = dict(qpos=NQ, qvel=NV, xpos=72, xquat=96, xipos=72, qM=NM, qfrc_bias=N
 class OracleSim:
     """One scalar fp64 environment."""
 
-    def __init__(self, kpm: str = DEFAULT_KPM, contact=True, limits=True, gravity=None):
+    def __init__(self, kpm: str = DEFAULT_KPM, contact=True, limits=True, gravity=None, ls_exact=False):
         L = lib()
         self.L = L
         self.m = L.kpo_model_load(kpm.encode())
@@ -89,6 +92,7 @@ class OracleSim:
         L.kpo_model_set_flags(self.m, int(contact), int(limits))
         if gravity is not None:
             L.kpo_model_set_gravity(self.m, float(gravity))
+        L.kpo_model_set_ls_exact(self.m, int(ls_exact))     # default: MuJoCo's PrimalSearch; True: the exact minimiser (as the HIP kernel)
         self.d = L.kpo_data_new()
 
     def __del__(self):
@@ -181,6 +185,13 @@ class OracleSim:
         self.L.kpo_get_contacts(self.d, body.ctypes.data_as(C.POINTER(C.c_int)), _dp(pos), _dp(dist))
         return body[:n], pos[:n], dist[:n]
 
+    def contacts_full(self):
+        """dict(body, b2, dist, pos, normal) of the last collision pass (same layout as KpSim.contacts())."""
+        body, pos, dist = self.contacts()
+        b1, b2 = self.contact_pairs()
+        nrm = np.zeros((64, 3)); self.L.kpo_get_contact_normals(self.d, _dp(nrm))
+        return dict(body=body.astype(int), b2=b2.astype(int), dist=dist, pos=pos, normal=nrm[:len(body)])
+
     def efc(self):
         n = self.nefc
         f, D, a, J = np.zeros(max(n, 1)), np.zeros(max(n, 1)), np.zeros(max(n, 1)), np.zeros((max(n, 1), NV))
@@ -223,3 +234,31 @@ def object_geoms(kpm: dict, obj_qpos35, max_dist=50.0):
         pos = pose[:3] + R @ og[gi, 5:8]
         out.append(np.concatenate([[og[gi, 1]], og[gi, 2:5], pos, Rg.reshape(-1), [1.0 / mass[oi]]]))
     return np.array(out).reshape(-1, 17)
+
+
+def shape_record(kind, size=(0, 0, 0), pos=(0, 0, 0), mat=None, center=None):
+    """[type, size3 | hull centre, pos3, mat9] for narrowphase(): kind in ('box', 'cylinder', 'hull')."""
+    t = {"box": 0, "cylinder": 1, "hull": 2}[kind]
+    m = np.eye(3) if mat is None else np.asarray(mat, float)
+    s = np.asarray(center if t == 2 else size, float)
+    return np.concatenate([[t], np.resize(s, 3) if len(s) == 3 else np.concatenate([s, np.zeros(3 - len(s))]), np.asarray(pos, float), m.reshape(-1)])
+
+
+def narrowphase(kind, a=None, b=None, verts_a=None, verts_b=None, graph=None, margin=0.001, rbound=1.0):
+    """One geom pair through the oracle's restatement of the MuJoCo narrow phase (kp_collide.h):
+    kind = 'convex' (a, b) | 'plane_box' (a) | 'plane_cylinder' (a) | 'box_box' (a, b) | 'plane_mesh' (b + graph = neighbour lists).
+    Returns [n, 7] rows (dist, pos3, normal3 from geom 1 to geom 2)."""
+    L = lib()
+    k = {"convex": 0, "plane_box": 1, "plane_cylinder": 2, "box_box": 3, "plane_mesh": 4}[kind]
+    ip = lambda x: x.ctypes.data_as(C.POINTER(C.c_int))  # noqa: E731
+    va = None if verts_a is None else np.ascontiguousarray(verts_a, np.float64)
+    vb = None if verts_b is None else np.ascontiguousarray(verts_b, np.float64)
+    adr = nbr = None
+    if graph is not None:
+        adr = np.zeros(len(graph) + 1, np.int32); adr[1:] = np.cumsum([len(g) for g in graph]); nbr = np.array([j for g in graph for j in g] or [0], np.int32)
+    out = np.zeros((8, 7))
+    ar = None if a is None else np.ascontiguousarray(a, np.float64); br = None if b is None else np.ascontiguousarray(b, np.float64)
+    n = L.kpo_narrowphase(k, None if ar is None else _dp(ar), None if va is None else _dp(va), 0 if va is None else len(va),
+                          None if br is None else _dp(br), None if vb is None else _dp(vb), 0 if vb is None else len(vb),
+                          None if adr is None else ip(adr), None if nbr is None else ip(nbr), float(margin), float(rbound), _dp(out))
+    return out[:n].copy()

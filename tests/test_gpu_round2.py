@@ -185,3 +185,90 @@ def test_sim_follows_an_explicit_stream_rebind(kp):
     assert torch.equal(got, want)
     st = sim.status_tensor()
     assert st.shape == (4,) and int(st[2]) == 0
+
+
+def _object_scenes(n, seed):
+    """Randomised scenes of all four action classes (tools/obj_fuzz.py generator): objects dropped, tilted and shifted into the humanoid."""
+    from kinpoly_amd.model_compiler import STEP_KPM, read_kpm
+    kpm = read_kpm(STEP_KPM)
+    rng = np.random.default_rng(seed)
+    x0, y0 = STD["qpos"][0], STD["qpos"][1]
+    nominal = {0: [[0.0, -0.45, 0.3805]], 1: [[0.0, 0.55, 0.921], [0.0, 0.55, 0.7905]], 2: [[0.0, 0.45, 0.69]], 3: [[0.0, 0.0, 0.3705]]}
+    obj_of_action = {0: [0], 1: [1, 2], 2: [3], 3: [4]}
+    blk = np.zeros((n, 35))
+    for i in range(5):
+        blk[:, 7 * i: 7 * i + 3] = [(i + 1) * 100, 100, 0]
+    qpos = np.tile(STD["qpos"], (n, 1)); qvel = rng.normal(size=(n, 75)) * 0.2
+    scenes = []
+    for e in range(n):
+        a = e % 4
+        shift = rng.normal(size=2) * 0.15
+        lift = rng.uniform(0, 0.25) if rng.uniform() < 0.5 else 0.0
+        ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+        ang = rng.normal() * (0.25 if rng.uniform() < 0.5 else 0.0)
+        tilt = np.concatenate([[np.cos(ang / 2)], np.sin(ang / 2) * ax])
+        objs = {}
+        for oi, (lx, ly, lz) in zip(obj_of_action[a], nominal[a]):
+            objs[oi] = [x0 + lx + shift[0], y0 + ly + shift[1], lz + lift + 0.0003, *tilt]
+            blk[e, 7 * oi: 7 * oi + 7] = objs[oi]
+        if a == 3:
+            qpos[e, 2] += 0.341 + lift + 0.02
+        qpos[e, 7:] += rng.normal(size=69) * 0.1
+        scenes.append(objs)
+    return kpm, blk, qpos, qvel, scenes
+
+
+def test_contact_sets_match_oracle_contact_by_contact(kp):
+    """Narrow-phase parity below the trajectory level: for one state, the contact list the kernel builds (mjc_PlaneConvex walk of the
+    hull graph, mjc_PlaneBox / mjc_PlaneCylinder, libccd MPR for hull - box / cylinder, box - box clipping) equals the oracle's
+    (oracle/kp_collide.h) contact by contact: same entity pairs in the same order, dist / position / normal to fp32 accuracy."""
+    from kinpoly_amd.model_compiler import STEP_KPM
+    n = 48
+    kpm, blk, qpos, qvel, scenes = _object_scenes(n, 5)
+    sim = kp.KpSim(kp.KpModel(STEP_KPM), n)
+    sim.record_contacts()
+    sim.set_objects(dev(blk)); sim.set_state(dev(qpos), dev(qvel)); sim.set_target(dev(qpos))
+    sim.step_ctrl(dev(np.zeros((n, 75))), 1)
+    hip = sim.contacts()
+    q32, v32, b32 = dev(qpos).double().cpu().numpy(), dev(qvel).double().cpu().numpy(), dev(blk).double().cpu().numpy()
+    kinds = set()
+    n_contacts = 0
+    for e in range(n):
+        o = OracleSim(kpm=STEP_KPM)
+        for slot, oi in enumerate(sorted(scenes[e])):
+            o.set_object(slot, kpm, oi, b32[e, 7 * oi:7 * oi + 7])
+        o.reset(q32[e], v32[e])
+        c, h = o.contacts_full(), hip[e]
+        assert list(c["body"]) == list(h["body"]) and list(c["b2"]) == list(h["b2"]), f"scene {e}: entity lists differ"
+        if len(c["body"]) == 0:
+            continue
+        n_contacts += len(c["body"])
+        np.testing.assert_allclose(h["dist"], c["dist"], atol=2e-5, err_msg=f"scene {e}")
+        np.testing.assert_allclose(h["pos"], c["pos"], atol=2e-5, err_msg=f"scene {e}")
+        np.testing.assert_allclose(h["normal"], c["normal"], atol=2e-4, err_msg=f"scene {e}")
+        for a, b in zip(c["body"], c["b2"]):
+            kinds.add(("hull" if a < 24 else "obj", "floor" if b < 0 else "obj"))
+    assert kinds == {("hull", "floor"), ("hull", "obj"), ("obj", "floor"), ("obj", "obj")} and n_contacts > 300
+
+
+def test_floor_contacts_follow_the_hull_graph_rule(kp):
+    """mjc_PlaneConvex on the device: per hull the deepest vertex plus at most three of its hull-graph neighbours -- never more than
+    four contacts per hull, and the same set as the oracle on feet-flat, lying and half-buried states."""
+    n = 24
+    qpos, qvel, act = _buried_states(n, 3)
+    qpos[:8] = STD["qpos"]; qpos[:8, 2] -= np.linspace(0.0, 0.03, 8)          # feet pressed flat into the floor
+    sim = kp.KpSim(kp.KpModel(), n)
+    sim.record_contacts()
+    sim.set_state(dev(qpos), dev(qvel)); sim.set_target(dev(np.tile(STD["qpos"], (n, 1))))
+    sim.step_ctrl(dev(act), 1)
+    hip = sim.contacts()
+    q32, v32 = dev(qpos).double().cpu().numpy(), dev(qvel).double().cpu().numpy()
+    o = OracleSim()
+    for e in range(n):
+        o.reset(q32[e], v32[e])
+        c, h = o.contacts_full(), hip[e]
+        assert list(c["body"]) == list(h["body"])
+        assert len(h["body"]) == 0 or np.bincount(h["body"]).max() <= 4
+        np.testing.assert_allclose(h["dist"], c["dist"], atol=2e-6)
+        np.testing.assert_allclose(h["pos"], c["pos"], atol=2e-6)
+    assert max(len(h["body"]) for h in hip) >= 16
