@@ -75,7 +75,6 @@ struct __attribute__((aligned(16))) EnvLds {
 // extension used only by the kernel instantiation that simulates object contact (kp_step_kernel<NT, true>)
 constexpr int D_MAXGEOM = 8;            // must equal MAXGEOM in oracle/kp_oracle.c
 constexpr int D_MAXOBJ = 2;             // must equal MAXOBJ in oracle/kp_oracle.c
-constexpr int D_OBJ_CON_PER_GEOM = 4;   // must equal OBJ_CON_PER_GEOM
 struct __attribute__((aligned(16))) EnvLdsObj : EnvLds {
     float con_n[D_MAXCON * 3];          // contact normal (world), pointing from the surface (floor / geom) into the vertex' entity
     float con_iw2[D_MAXCON];            // invweight0 of the second body (0 for the floor)

@@ -38,7 +38,6 @@
 #define MAXGEOM 8
 #define MAXOBJ 2                        /* dynamic free objects per env (push: box + table) */
 #define NVT_MAX (NV_MAX + 6 * MAXOBJ)   /* dofs of the humanoid + the active objects */
-#define OBJ_CON_PER_GEOM 4
 #define MJ_MINVAL 1e-15
 #define MJ_MINIMP 0.0001
 #define MJ_MAXIMP 0.9999
