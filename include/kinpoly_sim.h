@@ -117,8 +117,10 @@ int kp_sim_step_kin(kp_sim*, const float* kin_action, float* next_qpos);
 int kp_sim_obs_cc(kp_sim*, float* out, const float* zf_mean, const float* zf_std, float clip);
 
 /* per-episode context rows the env reads each step (ar_context, humanoid_ar_v1.py:84-88).
- * Arrays are [N, T, dim] device pointers; cur_t is int32 [N] (env.cur_t).  obj_qpos [N,7] may be NULL
- * (then get_obj_qpos() == [0,0,0,1,0,0,0], :465-466). */
+ * Arrays are [R, T, dim] device pointers (action_one_hot [R, 4]), R >= N context rows; env e reads row `row[e]` (int32 [N], or
+ * NULL: row e, R = N).  The indirection lets a sampler keep the NEXT episodes' contexts resident next to the current ones and
+ * switch an env to its new clip on `done` without copying (agent_ar.py:519-537 draws a new clip per episode).  cur_t is
+ * int32 [N] (env.cur_t).  obj_qpos [N,7] (per env, not per row) may be NULL (then get_obj_qpos() == [0,0,0,1,0,0,0], :465-466). */
 typedef struct {
     int T;
     const float* head_pose;               /* [N,T,7]  ar_context['head_pose'] */
@@ -129,6 +131,7 @@ typedef struct {
     const float* gt_wbpos;                /* [N,T,72] gt_targets['wbpos'] */
     const float* obj_qpos;                /* [N,7] or NULL */
     const int32_t* cur_t;                 /* [N] */
+    const int32_t* row;                   /* [N] context row of every env, or NULL */
 } kp_ctx;
 
 /* records prev_bquat / prev_hpos at the top of HumanoidAREnv.step (humanoid_ar_v1.py:246-249) */
@@ -154,6 +157,11 @@ int kp_sim_term_reward(kp_sim*, const kp_ctx* ctx, const kp_reward_cfg* cfg, flo
  * [N,T] layout (each env's T rows contiguous, time increasing).  All pointers device, float32. */
 int kp_gae(int n_envs, int T, const float* rewards, const float* masks, const float* values, float gamma, float tau,
            float* advantages, float* returns, void* hip_stream);
+/* same with a bootstrap: last_values [N] = V(state after env e's last row), used where that row's mask is 1 (an episode the fixed
+ * horizon of the lock-step sampler cut; the reference's workers always finish their episodes, so its recursion starts from 0).
+ * last_values may be NULL (= kp_gae). */
+int kp_gae_bootstrap(int n_envs, int T, const float* rewards, const float* masks, const float* values, const float* last_values,
+                     float gamma, float tau, float* advantages, float* returns, void* hip_stream);
 
 /* restore a complete simulator state (what MjSimState + the derived arrays would hold): qpos/qvel and the
  * state (qpos_d/qvel_d) the stale derived quantities belong to; runs the forward pass on the latter. */

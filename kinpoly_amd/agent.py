@@ -1,13 +1,16 @@
 """`AgentAR` on the batched engine: the per-iteration driver of kin_poly/core/agent_ar.py
-(`optimize_policy` :271-297 = sample :651-680 + update_params :682-752), one process per GPU.
+(`optimize_policy` :271-297 = per_epoch_update + sample :651-680 + update_params :682-752), one process per GPU.
 
-    sample         VectorSampler over N envs (device SoA, auto-reset through the batched init_context)
-    rl_update      GAE (k_gae) + global advantage normalisation (RCCL all-gather) + PPO epochs (:756-772)
-    step_update    supervised one-step update x num_step_update (:277-287 of policy_ar.py)
-    checkpoints    reference pickle layout (kinpoly_amd/checkpoint.py)
+    per_epoch_update  LambdaLR schedules of the policy / value optimisers (:215-225, 268-269)
+    sample            VectorSampler over N envs: device SoA, every episode on a freshly drawn clip (EpisodeSource: batched
+                      sample_seq + init_context ahead of the rollout, freq_dict feedback, :518-606)
+    rl_update         GAE (k_gae) + global advantage normalisation (RCCL all-gather) + PPO epochs (:756-772); with
+                      joint_controller also update_controller on the UHC policy (:774-794)
+    step_update       supervised one-step update x num_step_update (policy_ar.py:277-287) + its own LambdaLR (`step_lr`, :88-89)
+    checkpoints       reference pickle layout (kinpoly_amd/checkpoint.py)
 
-Dataset files of the reference are not in its repository, so episodes come from a `context_fn(n) -> dict` callable
-(kinpoly_amd.env.standing_context for the synthetic configs of SURVEY.md section 8(d)).
+Episodes come from a `StateARDataset` (the reference's feature-file sampler, kinpoly_amd/dataset.py) or, for the synthetic
+single-clip configs of SURVEY.md section 8(d), from a `context_fn(n) -> dict` callable.
 """
 from __future__ import annotations
 
@@ -22,49 +25,54 @@ from .context import PolicyARContext, TrajARNet
 from .env import BatchedHumanoidAREnv
 from .model_compiler import read_kpm
 from .nets import MLP, Value, enable_tuned_gemms
-from .rollout import PPOTrainer, VectorSampler, _allreduce_grads
+from .rollout import EpisodeSource, PPOTrainer, VectorSampler, _allreduce_grads, lambda_lr
 from .supervised import TorchFK, update_supervised_step
 
 
 class AgentAR:
-    def __init__(self, n_envs, context_fn, device=0, horizon=99, seed=4, wild=False, use_init_context=True,
+    def __init__(self, n_envs, context_fn=None, device=0, horizon=99, seed=4, wild=False, use_init_context=True,
                  policy_lr=1e-5, value_lr=3e-4, supervised_lr=5e-4, num_optim_epoch=10, num_step_update=20, gamma=0.95, tau=0.95,
-                 clip_epsilon=0.2, rl_update=True, step_update=True, model_options=None):
+                 clip_epsilon=0.2, rl_update=True, step_update=True, model_options=None, dataset=None, sampling_temp=0.3, sampling_freq=0.5,
+                 pool_depth=2, num_epoch_fix=100, num_epoch=10000, joint_controller=False):
         rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
         enable_tuned_gemms()          # library GEMM solution per shape (rollout and update shapes at 4096 envs); selection only
         torch.manual_seed(seed + rank)
-        self.env = BatchedHumanoidAREnv(n_envs, device, mode="train", wild=wild, seed=seed + rank, model_options=model_options)
+        self.env = BatchedHumanoidAREnv(n_envs, device, mode="train", wild=wild, seed=seed + rank, model_options=model_options,
+                                        joint_controller=joint_controller)
         self.device = self.env.device
         self.policy_net = TrajARNet().to(self.device)
         self.value_net = Value(MLP(105, (512, 256), "relu")).to(self.device)
         self._sync_params()
         self.kin_sim = kpsim.KpSim(self.env.model, n_envs, self.device.index)      # physics-free twin for the kinematic roll-out
         self.ctx_builder = PolicyARContext(self.policy_net, self.kin_sim, smooth=True)
-        self.context_fn, self.use_init_context = context_fn, use_init_context
+        # sampling_temp / sampling_freq: kin_poly.yml:67-68; freq_dict lives in the source (agent_ar.py:228-234)
+        self.source = EpisodeSource(dataset=dataset, context_fn=context_fn if dataset is None else None,
+                                    ctx_builder=self.ctx_builder if use_init_context else None,
+                                    sampling_temp=sampling_temp, sampling_freq=sampling_freq, fix_height=False)
         self.horizon, self.rl_update, self.step_update, self.num_step_update = horizon, rl_update, step_update, num_step_update
-        self.trainer = PPOTrainer(self.policy_net, self.value_net, gamma, tau, clip_epsilon, policy_lr, value_lr, num_optim_epoch)
+        self.trainer = PPOTrainer(self.policy_net, self.value_net, gamma, tau, clip_epsilon, policy_lr, value_lr, num_optim_epoch,
+                                  num_epoch_fix=num_epoch_fix, num_epoch=num_epoch, cc_policy=self.env.cc_policy if joint_controller else None)
         self.opt_sup = torch.optim.Adam([p for p in self.policy_net.parameters() if p.requires_grad], lr=supervised_lr)
+        self.sched_sup = lambda_lr(self.opt_sup, num_epoch_fix, num_epoch)          # PolicyAR.setup_optimizers / step_lr (policy_ar.py:45-62, 88-89)
         kpm = read_kpm(kpsim.DEFAULT_KPM)
         self.fk = TorchFK(kpm["body_pos"], kpm["body_parent"], self.device, sim=self.kin_sim)   # HIP forward / backward kernels for the loss FK
-        self.sampler = VectorSampler(self.env, self.policy_net, record_qpos=True)
+        self.sampler = VectorSampler(self.env, self.policy_net, record_qpos=True, source=self.source, pool_depth=pool_depth,
+                                     record_full=joint_controller)
         self.epoch = 0
-        self._new_episodes()
+        self.sampler.start()
+
+    @property
+    def freq_dict(self):
+        return self.source.freq_dict
 
     def _sync_params(self):
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             for p in list(self.policy_net.parameters()) + list(self.value_net.parameters()):
                 dist.broadcast(p.data, 0)
 
-    def _new_episodes(self):
-        """sample_seq + init_context + load_context + reset for every env (agent_ar.py:519-537)."""
-        data = self.context_fn(self.env.n)
-        if self.use_init_context:
-            data = self.ctx_builder.init_context(data, fix_height=False)
-        self.env.load_context(data)
-        self.sampler.start()
-
     def optimize_policy(self, i_iter=None):
         t0 = time.time()
+        self.trainer.per_epoch_update()
         batch = self.sampler.sample(self.horizon)
         torch.cuda.synchronize(self.device)
         t1 = time.time()
@@ -73,13 +81,14 @@ class AgentAR:
             info.update(self.trainer.update(batch))
         if self.step_update:
             info["step_loss"] = update_supervised_step(self.policy_net, self.opt_sup, self.fk, batch, self.num_step_update, _allreduce_grads)
+        self.sched_sup.step()
         torch.cuda.synchronize(self.device)
         t2 = time.time()
-        self._new_episodes()
         self.epoch += 1
         n = batch.rewards.numel()
         info.update(T_sample=t1 - t0, T_update=t2 - t1, T_total=time.time() - t0, num_steps=n, avg_reward=float(batch.rewards.mean()),
-                    fail_rate=float(batch.fails.float().mean()), env_steps_per_s=n / (t1 - t0))
+                    fail_rate=float(batch.fails.float().mean()), env_steps_per_s=n / (t1 - t0), episodes=len(batch.episodes.get("percent", ())),
+                    pool_exhausted=self.sampler.pool_exhausted, policy_lr=self.trainer.opt_p.param_groups[0]["lr"])
         return info
 
     def save_checkpoint(self, path):

@@ -14,6 +14,8 @@ struct CtxDev {  // mirrors kp_ctx in include/kinpoly_sim.h
     int T;
     const float *head_pose, *head_vels, *obj_rel, *action_one_hot, *gt_bquat, *gt_wbpos, *obj_qpos;
     const int* cur_t;
+    const int* row;      // optional: env e reads context row row[e] of the [R, T, .] arrays (null: row e)
+    __device__ __forceinline__ size_t r(int e) const { return row ? (size_t)row[e] : (size_t)e; }
 };
 
 __device__ __forceinline__ V3 tv_heading(V3 v, Q4 q) { return q_tmul_vec(q_heading(q), v); }  // transform_vec(v, q, 'heading')
@@ -34,10 +36,10 @@ __global__ void k_obs_ar(int n, CtxDev C, const float* __restrict__ qpos, const 
     V3 hpos = ld3(xpos + (size_t)e * 72 + 3 * hb);
     const float* hq4 = xquat + (size_t)e * 96 + 4 * hb;
     Q4 hrot = Q4{hq4[0], hq4[1], hq4[2], hq4[3]};
-    const float* hp = C.head_pose + ((size_t)e * C.T + t) * 7;
-    const float* hv = C.head_vels + ((size_t)e * C.T + t) * 6;
-    const float* orl = C.obj_rel + ((size_t)e * C.T + t) * 7;
-    const float* oh = C.action_one_hot + (size_t)e * 4;
+    const float* hp = C.head_pose + (C.r(e) * C.T + t) * 7;
+    const float* hv = C.head_vels + (C.r(e) * C.T + t) * 6;
+    const float* orl = C.obj_rel + (C.r(e) * C.T + t) * 7;
+    const float* oh = C.action_one_hot + C.r(e) * 4;
     st3(o + 74, tv_heading(ld3(hp) - hpos, hrot));
     Q4 dr = qmul(q_inverse(Q4{hp[3], hp[4], hp[5], hp[6]}), hrot);
     o[77] = dr.w; o[78] = dr.x; o[79] = dr.y; o[80] = dr.z;
@@ -93,9 +95,9 @@ __global__ __launch_bounds__(256) void k_term_reward(int n, CtxDev C, RewardW W,
     t = t < 1 ? 1 : (t >= C.T ? C.T - 1 : t);
     const float* q = qpos + (size_t)e * D_NQ;
     const float* xp = xpos + (size_t)e * 72;
-    const float* gtb = C.gt_bquat + ((size_t)e * C.T + t) * 96;
-    const float* gtp = C.gt_bquat + ((size_t)e * C.T + t - 1) * 96;
-    const float* gtw = C.gt_wbpos + ((size_t)e * C.T + t) * 72;
+    const float* gtb = C.gt_bquat + (C.r(e) * C.T + t) * 96;
+    const float* gtp = C.gt_bquat + (C.r(e) * C.T + t - 1) * 96;
+    const float* gtw = C.gt_wbpos + (C.r(e) * C.T + t) * 72;
     float pq = 0.f, pp = 0.f, pg = 0.f, vel2 = 0.f, bd = 0.f, bgd = 0.f;
     if (b < D_NB) {
         const Q4 cb = b == 0 ? Q4{q[3], q[4], q[5], q[6]} : q_euler_sxyz(q[7 + 3 * (b - 1)], q[8 + 3 * (b - 1)], q[9 + 3 * (b - 1)]);
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(256) void k_term_reward(int n, CtxDev C, RewardW W,
     }
     if (b != 0 || !valid) return;
     const float* xq = xquat + (size_t)e * 96;
-    const float* hp = C.head_pose + ((size_t)e * C.T + t) * 7;
+    const float* hp = C.head_pose + (C.r(e) * C.T + t) * 7;
     const V3 hd = ld3(xp + 39) - ld3(hp);
     const float hp_r = expf(-W.k_hp * dot(hd, hd));
     const Q4 hq = qmul(Q4{xq[52], xq[53], xq[54], xq[55]}, q_inverse(Q4{hp[3], hp[4], hp[5], hp[6]}));
@@ -141,11 +143,13 @@ __global__ __launch_bounds__(256) void k_term_reward(int n, CtxDev C, RewardW W,
 }
 
 // reverse scan per env over an env-major [N, T] layout (time contiguous per env), masks cut episodes
+// last_values (optional, [n]): V(s_T) of the state after each env's last row -- the bootstrap of an episode the horizon cut (the row's
+// mask is 1 there); null = 0, the reference's flat-batch recursion whose last row always ends an episode
 __global__ void k_gae(int n, int T, const float* __restrict__ rewards, const float* __restrict__ masks, const float* __restrict__ values,
-                      float gamma, float tau, float* __restrict__ adv, float* __restrict__ ret) {
+                      const float* __restrict__ last_values, float gamma, float tau, float* __restrict__ adv, float* __restrict__ ret) {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
-    float prev_v = 0.f, prev_a = 0.f;
+    float prev_v = last_values ? last_values[e] : 0.f, prev_a = 0.f;
     for (int t = T - 1; t >= 0; t--) {
         size_t i = (size_t)e * T + t;
         float m = masks[i], v = values[i];

@@ -599,7 +599,7 @@ int kp_sim_get(kp_sim* s, int field, float* out) {
 static kp::CtxDev to_dev(const kp_ctx* c) {
     kp::CtxDev d;
     d.T = c->T; d.head_pose = c->head_pose; d.head_vels = c->head_vels; d.obj_rel = c->obj_head_relative_poses;
-    d.action_one_hot = c->action_one_hot; d.gt_bquat = c->gt_bquat; d.gt_wbpos = c->gt_wbpos; d.obj_qpos = c->obj_qpos; d.cur_t = c->cur_t;
+    d.action_one_hot = c->action_one_hot; d.gt_bquat = c->gt_bquat; d.gt_wbpos = c->gt_wbpos; d.obj_qpos = c->obj_qpos; d.cur_t = c->cur_t; d.row = c->row;
     return d;
 }
 
@@ -632,11 +632,15 @@ int kp_sim_term_reward(kp_sim* s, const kp_ctx* c, const kp_reward_cfg* w, float
     return 0;
 }
 
-int kp_gae(int n, int T, const float* rewards, const float* masks, const float* values, float gamma, float tau, float* adv, float* ret, void* stream) {
+int kp_gae_bootstrap(int n, int T, const float* rewards, const float* masks, const float* values, const float* last_values, float gamma, float tau,
+                     float* adv, float* ret, void* stream) {
     if (n <= 0 || T <= 0 || !rewards || !masks || !values || !adv || !ret) return fail("kp_gae: bad arguments");
-    hipLaunchKernelGGL(kp::k_gae, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, n, T, rewards, masks, values, gamma, tau, adv, ret);
+    hipLaunchKernelGGL(kp::k_gae, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, n, T, rewards, masks, values, last_values, gamma, tau, adv, ret);
     HIP_OK(hipGetLastError());
     return 0;
+}
+int kp_gae(int n, int T, const float* rewards, const float* masks, const float* values, float gamma, float tau, float* adv, float* ret, void* stream) {
+    return kp_gae_bootstrap(n, T, rewards, masks, values, nullptr, gamma, tau, adv, ret, stream);
 }
 
 int kp_sim_set_full_state(kp_sim* s, const float* qpos, const float* qvel, const float* qpos_d, const float* qvel_d, const uint8_t* mask) {

@@ -64,7 +64,9 @@ class BatchedHumanoidAREnv:
         self.gen.manual_seed(seed)
         self.cur_t = torch.zeros(self.n, dtype=torch.int32, device=self.device)
         self.ctx = None
-        self.ctx_len = None
+        self.row = None           # int32 [N]: context row every env reads (load_context / set_rows)
+        self.row_len = None       # int32 [R]: ar_context['len'] of every row
+        self.row_meta = None      # [R, 2]: take index, first frame of every row (v_meta of the reference's memory rows)
         self.obj_qpos = None      # [N,35] = data.qpos[76:111] (convert_obj_qpos)
         self.obj7 = None          # [N,7]  = get_obj_qpos(action_one_hot)
         self._ctx_struct = None
@@ -85,26 +87,35 @@ class BatchedHumanoidAREnv:
         self.mode = mode
         self.reward_cfg.use_gt_term = int(mode == "train" and not self.wild)
 
-    def load_context(self, ctx: dict, env_mask: torch.Tensor | None = None):
-        """ctx tensors are [N, T, .] (action_one_hot [N, T, 4] or [N, 4]; init_qpos/init_qvel [N, .]).
-        With env_mask (bool [N]) only those envs' rows are replaced (T must match).
-        Ragged episodes: pad every clip to the longest T (repeat the last frame) and pass ctx["len"] = frames per env [N];
-        an env's episode then ends at its own len - 1 (`ar_context['len']`, humanoid_ar_v1.py:312)."""
-        T = ctx["qpos"].shape[1]
+    def load_context(self, ctx: dict, env_mask: torch.Tensor | None = None, row: torch.Tensor | None = None, keep_state: bool = False):
+        """ctx tensors are [R, T, .] (action_one_hot [R, T, 4] or [R, 4]; init_qpos/init_qvel [R, .]) with R = n_envs context rows,
+        or -- for a sampler that keeps the next episodes' clips resident -- R = k * n_envs rows with `row` (int32 [N]) naming the
+        row every env starts on (default: env e on row e); `set_rows` later switches finished envs to other rows without copying.
+        With env_mask (bool [N], R = N only) just those envs' rows are replaced (T must match).
+        Ragged episodes: pad every clip to the longest T (repeat the last frame) and pass ctx["len"] = frames per row [R];
+        an env's episode then ends at its own len - 1 (`ar_context['len']`, humanoid_ar_v1.py:312).
+        keep_state: the envs are in the middle of episodes whose clips are among the new rows (a sampler re-laying its row table):
+        per-env episode state (cur_t, the simulated object pose) is left alone."""
+        R, T = ctx["qpos"].shape[:2]
+        if R % self.n != 0:
+            raise ValueError(f"context rows ({R}) must be a multiple of n_envs ({self.n})")
+        if env_mask is not None and (R != self.n or row is not None):
+            raise ValueError("masked load_context works on one row per env")
         new = {k: ctx[k].to(self.device, torch.float32) for k in CTX_KEYS}
         if new["action_one_hot"].dim() == 3:
             new["action_one_hot"] = new["action_one_hot"][:, 0]
         for k in ("obj_pose", "ar_qpos", "ar_qvel"):
             if k in ctx:
                 new[k] = ctx[k].to(self.device, torch.float32)
-        if self.ctx is None or env_mask is None or self.ctx["qpos"].shape[1] != T:
+        fresh = self.ctx is None or env_mask is None or self.ctx["qpos"].shape[:2] != (R, T)
+        if fresh:
             if env_mask is not None and self.ctx is not None:
                 raise ValueError("masked load_context needs the same clip length T")
             self.ctx = {k: v.contiguous().clone() for k, v in new.items()}
             rows = self.ctx["qpos"].reshape(-1, 76).contiguous()
             gt = self.sim.fk(rows)
-            self.ctx["gt_bquat"] = gt["bquat"].view(self.n, T, 96).contiguous()
-            self.ctx["gt_wbpos"] = gt["wbpos"].view(self.n, T, 72).contiguous()
+            self.ctx["gt_bquat"] = gt["bquat"].view(R, T, 96).contiguous()
+            self.ctx["gt_wbpos"] = gt["wbpos"].view(R, T, 72).contiguous()
         else:
             m = env_mask.to(self.device, torch.bool)
             idx = m.nonzero(as_tuple=True)[0]
@@ -112,51 +123,84 @@ class BatchedHumanoidAREnv:
                 for k, v in new.items():
                     self.ctx[k][idx] = v[idx]
                 rows = self.ctx["qpos"][idx].reshape(-1, 76).contiguous()
-                # qpos_fk_batch works on any row count; pad through a temp sim-independent call
                 gt = self.sim.fk(rows)
                 self.ctx["gt_bquat"][idx] = gt["bquat"].view(-1, T, 96)
                 self.ctx["gt_wbpos"][idx] = gt["wbpos"].view(-1, T, 72)
         lens = ctx.get("len")
         if lens is None:
-            new_len = torch.full((self.n,), T - 1, dtype=torch.int32, device=self.device)
+            new_len = torch.full((R,), T - 1, dtype=torch.int32, device=self.device)
         else:
             new_len = torch.as_tensor(lens, device=self.device).to(torch.int32) - 1
             if int(new_len.max()) > T - 1 or int(new_len.min()) < 1:
                 raise ValueError("ctx['len'] must lie in [2, T]")
-        if self.ctx_len is None or env_mask is None or self.ctx_len.shape[0] != self.n:
-            self.ctx_len = new_len
+        if fresh or self.row_len is None:
+            self.row_len = new_len
         else:
-            self.ctx_len = torch.where(env_mask.to(self.device, torch.bool), new_len, self.ctx_len)
+            self.row_len = torch.where(env_mask.to(self.device, torch.bool), new_len, self.row_len)
+        # per-row episode meta (v_meta of push_memory, agent_ar.py:627-631): take index, first frame; optional
+        self.row_meta = torch.stack([torch.as_tensor(ctx[k]).to(self.device, torch.float32) if k in ctx else torch.zeros(R, device=self.device)
+                                     for k in ("take_ind", "fr_start")], 1) if fresh or self.row_meta is None else self.row_meta
+        if fresh:
+            self.row = (torch.arange(self.n, device=self.device, dtype=torch.int32) if row is None else row.to(self.device, torch.int32).contiguous().clone())
         c = self.ctx
         if "obj_pose" in c and bool((c["action_one_hot"].sum(1) > 0).any()):
-            self.obj_qpos, self.obj7 = convert_obj_qpos(c["action_one_hot"], c["obj_pose"][:, 0])
-            # get_obj_qpos(action_one_hot) reads the SIMULATED pose of the action's (first) object every step (:466-477)
+            # data.qpos[76:111] of every row as reset_model builds it (convert_obj_qpos) + which 7 columns get_obj_qpos(action_one_hot) reads
+            self._row_obj_qpos, self._row_obj7 = convert_obj_qpos(c["action_one_hot"], c["obj_pose"][:, 0])
             a_idx = c["action_one_hot"].argmax(1)
-            self._obj_has = c["action_one_hot"].sum(1) > 0
+            self._row_obj_has = c["action_one_hot"].sum(1) > 0
             start = torch.tensor(ACTION_INDEX_MAP, device=self.device)[a_idx]
-            self._obj_cols = start[:, None] + torch.arange(7, device=self.device)[None]
-            self._obj35 = torch.empty((self.n, 35), dtype=torch.float32, device=self.device)
+            self._row_obj_cols = start[:, None] + torch.arange(7, device=self.device)[None]
+            r = self.row.long()
+            if not (keep_state and self.obj7 is not None):
+                self.obj_qpos, self.obj7 = self._row_obj_qpos[r].contiguous(), self._row_obj7[r].contiguous()
+                self._obj_has, self._obj_cols = self._row_obj_has[r].contiguous(), self._row_obj_cols[r].contiguous()
+                self._obj35 = torch.empty((self.n, 35), dtype=torch.float32, device=self.device)
         else:
             self.obj_qpos = self.obj7 = None
         self._ctx_struct = self.sim.make_ctx(T, c["head_pose"], c["head_vels"], c["obj_head_relative_poses"], c["action_one_hot"],
-                                             c["gt_bquat"], c["gt_wbpos"], self.cur_t, obj_qpos=self.obj7)
+                                             c["gt_bquat"], c["gt_wbpos"], self.cur_t, obj_qpos=self.obj7, row=self.row)
+
+    @property
+    def ctx_len(self):
+        """ar_context['len'] of every env's current clip (int32 [N])."""
+        return self.row_len[self.row.long()]
+
+    def set_rows(self, new_row: torch.Tensor, env_mask: torch.Tensor | None = None):
+        """Put the masked envs on other context rows (device op, no copy): the new episode's clip of agent_ar.py:519-535.
+        Follow with reset(env_mask)."""
+        nr = new_row.to(self.device, torch.int32)
+        if env_mask is None:
+            self.row.copy_(nr)
+        else:
+            self.row.copy_(torch.where(env_mask.to(self.device, torch.bool), nr, self.row))
+
+    def ctx_rows(self, key):
+        """ctx[key] gathered to the envs' current rows: [N, ...]."""
+        return self.ctx[key][self.row.long()]
 
     def reset(self, env_mask: torch.Tensor | None = None):
         """sim.reset(); cur_t = 0; reset_model(): state <- ar_context init_qpos/init_qvel, target = FK(init) (:334-387)."""
         m8 = None if env_mask is None else env_mask.to(self.device, torch.uint8).contiguous()
+        mb = None if env_mask is None else env_mask.to(self.device, torch.bool)
         if env_mask is None:
             self.cur_t.zero_()
         else:
-            self.cur_t.masked_fill_(env_mask.to(self.device, torch.bool), 0)
+            self.cur_t.masked_fill_(mb, 0)
+        r = self.row.long()
         if self.obj_qpos is not None:
+            if mb is None:
+                self.obj_qpos.copy_(self._row_obj_qpos[r]); self._obj_has.copy_(self._row_obj_has[r]); self._obj_cols.copy_(self._row_obj_cols[r])
+            else:
+                self.obj_qpos.copy_(torch.where(mb[:, None], self._row_obj_qpos[r], self.obj_qpos))
+                self._obj_has.copy_(torch.where(mb, self._row_obj_has[r], self._obj_has))
+                self._obj_cols.copy_(torch.where(mb[:, None], self._row_obj_cols[r], self._obj_cols))
             self.sim.set_objects(self.obj_qpos, m8)
-            fresh = torch.gather(self.obj_qpos, 1, self._obj_cols)
-            keep = ~self._obj_has if env_mask is None else ~(self._obj_has & env_mask.to(self.device, torch.bool))
-            self.obj7.copy_(torch.where(keep[:, None], self.obj7, fresh))
+            fresh = torch.where(self._obj_has[:, None], torch.gather(self.obj_qpos, 1, self._obj_cols), self._row_obj7[r])
+            self.obj7.copy_(fresh if mb is None else torch.where(mb[:, None], fresh, self.obj7))
         if self.ar_mode:                          # reset_model (:339-341): start from the kinematic roll-out's first frame
-            q0, v0 = self.ctx["ar_qpos"][:, 0].contiguous(), self.ctx["ar_qvel"][:, 0].contiguous()
+            q0, v0 = self.ctx["ar_qpos"][r, 0].contiguous(), self.ctx["ar_qvel"][r, 0].contiguous()
         else:
-            q0, v0 = self.ctx["init_qpos"], self.ctx["init_qvel"]
+            q0, v0 = self.ctx["init_qpos"][r].contiguous(), self.ctx["init_qvel"][r].contiguous()
         self.sim.set_state(q0, v0, m8)
         self.sim.set_target(q0, m8)
         return self.sim.obs_ar(self._ctx_struct, self._obs)
@@ -164,7 +208,7 @@ class BatchedHumanoidAREnv:
     def _ar_frame(self, key):
         """ar_context[key][cur_t + 1] per env."""
         t = (self.cur_t.long() + 1).clamp_(max=self.ctx[key].shape[1] - 1)
-        return self.ctx[key][torch.arange(self.n, device=self.device), t].contiguous()
+        return self.ctx[key][self.row.long(), t].contiguous()
 
     def ar_fail_safe(self, env_mask: torch.Tensor | None = None):
         """HumanoidAREnv.ar_fail_safe (:327-331): put the humanoid back on the kinematic roll-out (objects keep their state)."""
@@ -187,10 +231,11 @@ class BatchedHumanoidAREnv:
             self.obj7.copy_(torch.where(self._obj_has[:, None], torch.gather(self._obj35, 1, self._obj_cols), self.obj7))
         self.cur_t += 1
         reward, info6, fail, diffs = sim.term_reward(self._ctx_struct, self.reward_cfg, self._reward, self._info, self._fail, self._diffs)
-        end = (self.cur_t >= self.env_episode_len) | (self.cur_t >= self.ctx_len)
+        clen = self.ctx_len
+        end = (self.cur_t >= self.env_episode_len) | (self.cur_t >= clen)
         done = fail.bool() | end
         obs = sim.obs_ar(self._ctx_struct, self._obs)
-        info = {"fail": fail.bool(), "end": end, "percent": self.cur_t.float() / self.ctx_len, "cc_action": cc_action, "cc_state": cc_obs,
+        info = {"fail": fail.bool(), "end": end, "percent": self.cur_t.float() / clen, "cc_action": cc_action, "cc_state": cc_obs,
                 "custom_reward": reward, "custom_info": info6, "body_diff": diffs}
         return obs, torch.ones(self.n, device=self.device), done, info
 

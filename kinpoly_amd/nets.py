@@ -169,12 +169,13 @@ class KinPolicy(nn.Module):
         var = torch.exp(2 * log_std)
         return (-(action - mean) ** 2 / (2 * var) - 0.5 * math.log(2 * math.pi) - log_std).sum(1, keepdim=True)
 
-    def unroll(self, states, episode_start):
+    def unroll(self, states, episode_start, hx0=None):
         """Training-time forward over an env-major rollout [N, T, state_dim]: re-runs the GRU through time,
         zeroing the hidden state where `episode_start[n, t]` (what initialize_rnn + the padded [T_max,
-        n_episodes] re-pack do in the reference, policy_ar.py:104-122,216-234).  Returns means [N, T, A]."""
+        n_episodes] re-pack do in the reference, policy_ar.py:104-122,216-234).  hx0 [N, H]: hidden state the behaviour
+        policy held before row 0 (episodes that continue from the previous sample() call; default zeros).  Returns means [N, T, A]."""
         N, T, _ = states.shape
-        hx = self.init_hidden(N, states.device)
+        hx = self.init_hidden(N, states.device) if hx0 is None else hx0.to(states.dtype)
         outs = []
         for t in range(T):
             hx = hx * (~episode_start[:, t]).to(hx.dtype).unsqueeze(1)

@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "kp_sim_step_begin", "kp_sim_obs_ar", "kp_sim_term_reward", "kp_gae", "kp_sim_set_full_state", "kp_sim_fk",
     "kp_sim_timing_reset", "kp_sim_timing_mean_seconds", "kp_sim_phase_cycles", "kp_sim_set_objects", "kp_sim_set_obj_state",
     "kp_sim_launch_cost", "kp_job_schedule", "kp_sim_fk_backward", "kp_sim_set_stream", "kp_sim_status_device", "kp_sim_mass_matrix",
-    "kp_sim_contacts",
+    "kp_sim_contacts", "kp_gae_bootstrap",
 ]
 
 
@@ -42,7 +42,7 @@ class KpCtx(C.Structure):
     """mirror of kp_ctx (include/kinpoly_sim.h)"""
     _fields_ = [("T", C.c_int), ("head_pose", C.c_void_p), ("head_vels", C.c_void_p), ("obj_head_relative_poses", C.c_void_p),
                 ("action_one_hot", C.c_void_p), ("gt_bquat", C.c_void_p), ("gt_wbpos", C.c_void_p), ("obj_qpos", C.c_void_p),
-                ("cur_t", C.c_void_p)]
+                ("cur_t", C.c_void_p), ("row", C.c_void_p)]
 
 
 class KpRewardCfg(C.Structure):
@@ -90,6 +90,7 @@ def load_library(path: str | None = None):
     L.kp_sim_obs_ar.argtypes = [P, C.POINTER(KpCtx), F]; L.kp_sim_obs_ar.restype = C.c_int
     L.kp_sim_term_reward.argtypes = [P, C.POINTER(KpCtx), C.POINTER(KpRewardCfg), F, F, U8, F]; L.kp_sim_term_reward.restype = C.c_int
     L.kp_gae.argtypes = [C.c_int, C.c_int, F, F, F, C.c_float, C.c_float, F, F, C.c_void_p]; L.kp_gae.restype = C.c_int
+    L.kp_gae_bootstrap.argtypes = [C.c_int, C.c_int, F, F, F, F, C.c_float, C.c_float, F, F, C.c_void_p]; L.kp_gae_bootstrap.restype = C.c_int
     L.kp_sim_set_full_state.argtypes = [P, F, F, F, F, U8]; L.kp_sim_set_full_state.restype = C.c_int
     L.kp_sim_timing_reset.argtypes = [P]; L.kp_sim_timing_reset.restype = C.c_int
     L.kp_sim_timing_mean_seconds.argtypes = [P, C.POINTER(C.c_int)]; L.kp_sim_timing_mean_seconds.restype = C.c_double
@@ -277,17 +278,20 @@ class KpSim:
     def step_begin(self):
         _check(self.L.kp_sim_step_begin(self.h), "kp_sim_step_begin")
 
-    def make_ctx(self, T, head_pose, head_vels, obj_rel, action_one_hot, gt_bquat, gt_wbpos, cur_t, obj_qpos=None) -> "KpCtx":
+    def make_ctx(self, T, head_pose, head_vels, obj_rel, action_one_hot, gt_bquat, gt_wbpos, cur_t, obj_qpos=None, row=None) -> "KpCtx":
         n = self.n
-        for t, shp in ((head_pose, (n, T, 7)), (head_vels, (n, T, 6)), (obj_rel, (n, T, 7)), (action_one_hot, (n, 4)),
-                       (gt_bquat, (n, T, 96)), (gt_wbpos, (n, T, 72))):
+        R = head_pose.shape[0] if row is not None else n        # context rows (>= n_envs with the row indirection)
+        if row is not None and (row.dtype != torch.int32 or tuple(row.shape) != (n,) or not row.is_cuda):
+            raise ValueError("row must be an int32 device tensor [n_envs]")
+        for t, shp in ((head_pose, (R, T, 7)), (head_vels, (R, T, 6)), (obj_rel, (R, T, 7)), (action_one_hot, (R, 4)),
+                       (gt_bquat, (R, T, 96)), (gt_wbpos, (R, T, 72))):
             if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous() or tuple(t.shape) != shp:
                 raise ValueError(f"context tensor must be contiguous float32 on device with shape {shp}, got {tuple(t.shape)}")
         if cur_t.dtype != torch.int32 or tuple(cur_t.shape) != (n,) or not cur_t.is_cuda:
             raise ValueError("cur_t must be an int32 device tensor [n_envs]")
         ctx = KpCtx(int(T), head_pose.data_ptr(), head_vels.data_ptr(), obj_rel.data_ptr(), action_one_hot.data_ptr(), gt_bquat.data_ptr(),
-                    gt_wbpos.data_ptr(), None if obj_qpos is None else obj_qpos.data_ptr(), cur_t.data_ptr())
-        ctx._keep = (head_pose, head_vels, obj_rel, action_one_hot, gt_bquat, gt_wbpos, obj_qpos, cur_t)
+                    gt_wbpos.data_ptr(), None if obj_qpos is None else obj_qpos.data_ptr(), cur_t.data_ptr(), None if row is None else row.data_ptr())
+        ctx._keep = (head_pose, head_vels, obj_rel, action_one_hot, gt_bquat, gt_wbpos, obj_qpos, cur_t, row)
         return ctx
 
     def obs_ar(self, ctx: "KpCtx", out=None):
@@ -343,8 +347,9 @@ def job_schedule(n_substeps: int, substeps_per_job: int = 3, taper: bool = True)
     return list(out[:n])
 
 
-def gae(rewards: torch.Tensor, masks: torch.Tensor, values: torch.Tensor, gamma: float, tau: float):
-    """estimate_advantages before normalisation on env-major [N, T] float32 device tensors (k_gae)."""
+def gae(rewards: torch.Tensor, masks: torch.Tensor, values: torch.Tensor, gamma: float, tau: float, last_values: torch.Tensor | None = None):
+    """estimate_advantages before normalisation on env-major [N, T] float32 device tensors (k_gae); last_values [N] bootstraps
+    episodes the horizon cut (kp_gae_bootstrap)."""
     L = load_library()
     n, T = rewards.shape
     for t in (rewards, masks, values):
@@ -352,6 +357,9 @@ def gae(rewards: torch.Tensor, masks: torch.Tensor, values: torch.Tensor, gamma:
             raise ValueError("gae: expected contiguous float32 device tensors [N, T]")
     adv = torch.empty_like(rewards); ret = torch.empty_like(rewards)
     stream = torch.cuda.current_stream(rewards.device).cuda_stream
-    _check(L.kp_gae(n, T, C.c_void_p(rewards.data_ptr()), C.c_void_p(masks.data_ptr()), C.c_void_p(values.data_ptr()), float(gamma), float(tau),
-                    C.c_void_p(adv.data_ptr()), C.c_void_p(ret.data_ptr()), C.c_void_p(stream)), "kp_gae")
+    if last_values is not None and (not last_values.is_cuda or last_values.dtype != torch.float32 or not last_values.is_contiguous() or tuple(last_values.shape) != (n,)):
+        raise ValueError("gae: last_values must be a contiguous float32 device tensor [N]")
+    _check(L.kp_gae_bootstrap(n, T, C.c_void_p(rewards.data_ptr()), C.c_void_p(masks.data_ptr()), C.c_void_p(values.data_ptr()),
+                              None if last_values is None else C.c_void_p(last_values.data_ptr()), float(gamma), float(tau),
+                              C.c_void_p(adv.data_ptr()), C.c_void_p(ret.data_ptr()), C.c_void_p(stream)), "kp_gae_bootstrap")
     return adv, ret

@@ -126,7 +126,7 @@ def update_supervised_step(policy, optimizer, fk: TorchFK, batch, num_epoch=20, 
     with torch.no_grad():
         tgt_wbpos = fk.wbpos(tgt)              # the GT side of the end-effector term does not change between epochs
     for _ in range(num_epoch):
-        means = policy.unroll(batch.states, batch.episode_start).reshape(N * T, -1)
+        means = policy.unroll(batch.states, batch.episode_start, batch.hx0).reshape(N * T, -1)
         loss, _ = compute_loss_lite(fk, kinematic_step(curr, means), tgt, gt_wbpos=tgt_wbpos)
         optimizer.zero_grad()
         loss.backward()

@@ -53,11 +53,10 @@ def main():
     if rank == 0:
         print(f"dataset: {ds.get_len()} takes, {len(ds.freq_indices)} windows of {args.clip_len} frames", flush=True)
 
-    def context_fn(n):
-        return ds.sample_batch(n)          # n x sample_seq (statear_smpl_dataset.py:264-327)
-
-    agent = AgentAR(args.num_envs, context_fn, device=local, horizon=args.horizon, num_optim_epoch=args.num_optim_epoch,
-                    num_step_update=args.num_step_update)
+    # every episode draws its clip through data_loader.sample_seq(freq_dict, sampling_temp, sampling_freq) (agent_ar.py:519-523): the
+    # agent keeps the freq_dict and feeds each finished episode's [percent, fr_start] back (random window starts, adaptive takes)
+    agent = AgentAR(args.num_envs, dataset=ds, device=local, horizon=args.horizon, num_optim_epoch=args.num_optim_epoch,
+                    num_step_update=args.num_step_update, sampling_temp=0.3, sampling_freq=0.5)
     for it in range(args.iters):
         info = agent.optimize_policy(it)
         if rank == 0:

@@ -184,3 +184,27 @@ def test_dataset_features_and_sampling(golden):
     assert torch.equal(full["qpos"][0, 13], full["qpos"][0, 29])                   # padded with the last frame
     one = ds.iter_seq(); two = ds.iter_seq()
     assert one["qpos"].shape[1] == 14 and two["qpos"].shape[1] == 30 and ds.curr_key == "sit-1"
+
+
+def test_unroll_matches_reference_padded_rnn_forward(golden):
+    """KinPolicy.unroll over an env-major batch with mid-batch episode starts vs the reference's own train-mode forward
+    (PolicyAR.initialize_rnn + forward: scatter into the padded [T_max, n_episodes] layout, GRU from zeros per episode, gather back;
+    policy_ar.py:104-122, 216-240), which wrote tests/golden/unroll.npz with the seeded TrajARNet of traj_ar_net.npz."""
+    g, gt = golden("unroll"), golden("traj_ar_net")
+    net = _net_from_fixture(gt)
+    states, masks = torch.tensor(g["states"]), g["masks"]
+    assert int(g["num_episode"]) == 4 and int(g["max_episode_len"]) == 6
+    N, T = 2, 7                                                    # the flat batch is the concatenation of two workers' rows
+    starts = np.concatenate([[True], masks[:-1] == 0]).reshape(N, T)
+    starts[:, 0] = True
+    assert masks.reshape(N, T)[:, -1].max() == 0                   # the reference's workers always finish their last episode
+    with torch.no_grad():
+        means = net.unroll(states.view(N, T, -1), torch.tensor(starts))
+    np.testing.assert_allclose(means.reshape(N * T, -1).numpy(), g["action_mean"], rtol=1e-9, atol=1e-11)
+    # a carried-in hidden state is used on rows that do not start an episode, ignored on rows that do
+    hx0 = torch.randn(N, net.rnn_hdim, dtype=torch.float64)
+    with torch.no_grad():
+        m2 = net.unroll(states.view(N, T, -1), torch.tensor(starts), hx0)
+        st2 = starts.copy(); st2[1, 0] = False
+        m3 = net.unroll(states.view(N, T, -1), torch.tensor(st2), hx0)
+    assert torch.equal(m2, means) and torch.equal(m3[0], means[0]) and not torch.allclose(m3[1, :1], means[1, :1])

@@ -1,0 +1,156 @@
+"""GPU tests of the vectorised sampler's episode semantics (sample_worker, kin_poly/core/agent_ar.py:518-606) and of the update paths
+that consume its TrajBatchEgo fields.  The reference's own memory rows cannot be generated here (they need MuJoCo), so the rows are
+checked against what sample_worker defines them to be, field by field, and against the dataset they were drawn from."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STD = np.load(os.path.join(ROOT, "tests", "golden", "standing_neutral.npz"))
+
+
+def _dataset(n_envs, fr_num=12, seed=3):
+    from kinpoly_amd import dataset as D
+    from kinpoly_amd import sim as kpsim
+    from kinpoly_amd.model_compiler import read_kpm
+    fk_sim = kpsim.KpSim(kpsim.KpModel(kpsim.STEP_KPM), n_envs, 0)
+    takes = D.synthetic_takes(fk_sim, STD["qpos"], n_per_action=1, T_range=(fr_num + 4, fr_num + 12), body_mass=read_kpm(kpsim.STEP_KPM)["body_mass"], seed=seed)
+    return D.StateARDataset(takes, fr_num=fr_num, seed=seed, device=fk_sim.device), fk_sim
+
+
+def _tracking_policy_actions(env, obs):
+    """the kinematic action that reproduces the current pose (step_ar encoding): a stand-in for a trained policy"""
+    cur = env.sim.get("qpos")
+    a = torch.zeros((env.n, 80), device=env.device)
+    a[:, :74] = torch.cat([cur[:, 2:3], obs[:, 1:5], cur[:, 7:]], 1)
+    return a
+
+
+def test_every_episode_draws_a_new_clip_and_feeds_freq_dict():
+    from kinpoly_amd.env import BatchedHumanoidAREnv
+    from kinpoly_amd.nets import KinPolicy
+    from kinpoly_amd.rollout import EpisodeSource, VectorSampler
+    n, T, fr = 32, 10, 12
+    ds, _ = _dataset(n, fr)
+    torch.manual_seed(0)
+    env = BatchedHumanoidAREnv(n, 0, mode="train", seed=0)
+    src2 = EpisodeSource(dataset=ds, sampling_temp=0.3, sampling_freq=0.5)     # no context network: episodes start on the clip's first frame
+    pol = KinPolicy().to(env.device)                                  # random init: episodes end within a step or two -> many turnovers
+    sampler = VectorSampler(env, pol, source=src2, pool_depth=T, record_full=True)
+    b = sampler.sample(T)
+    assert sampler.pool_exhausted == 0
+    done = (b.masks == 0)
+    n_done = int(done.sum())
+    assert n_done > n, "random-init policies should end many episodes"
+    # freq_dict got one [percent, fr_start] entry per finished episode, under the take the episode ran on
+    assert sum(len(v) for v in src2.freq_dict.values()) == n_done == len(b.episodes["percent"])
+    for k, v in src2.freq_dict.items():
+        for pc, fs in v:
+            assert 0 < pc <= 1.0 and 0 <= fs <= ds.get_seq_len(ds.takes.index(k)) - fr
+    # v_metas: (take, fr_start, fr_num) of the clip each row was sampled on; constant inside an episode, re-drawn after a done
+    vm = b.v_metas.cpu().numpy(); es = b.episode_start.cpu().numpy(); dn = done.cpu().numpy()
+    assert (vm[..., 2] == fr).all()
+    same = (vm[:, 1:, :2] == vm[:, :-1, :2]).all(-1)
+    assert same[~dn[:, :-1]].all(), "the clip changed in the middle of an episode"
+    assert (es[:, 1:] == dn[:, :-1]).all() and es[:, 0].all()
+    changed = (~same)[dn[:, :-1]].mean()
+    assert changed > 0.5, "finished envs must move to freshly drawn clips"
+    # gt_target_qpos = ar_context['qpos'][cur_t + 1] of THAT clip: look it up in the dataset
+    gt = b.gt_target_qpos.cpu().numpy()
+    t_in_ep = np.zeros((n, T), int)
+    for t in range(1, T):
+        t_in_ep[:, t] = np.where(es[:, t], 0, t_in_ep[:, t - 1] + 1)
+    for e in range(0, n, 5):
+        for t in range(T):
+            ti, fs = int(vm[e, t, 0]), int(vm[e, t, 1])
+            np.testing.assert_allclose(gt[e, t], ds.data["qpos"][ti][fs + t_in_ep[e, t] + 1].numpy(), atol=1e-6)
+    # chaining of the recorded rows (agent_ar.py:556-598): res_qpos[t] == curr_qpos[t + 1] and next_state[t] == state[t + 1] inside an episode
+    inside = ~dn[:, :-1]
+    np.testing.assert_array_equal(b.res_qpos.cpu().numpy()[:, :-1][inside], b.curr_qpos.cpu().numpy()[:, 1:][inside])
+    np.testing.assert_array_equal(b.next_states.cpu().numpy()[:, :-1][inside], b.states.cpu().numpy()[:, 1:][inside])
+    assert b.cc_action.shape == (n, T, 75) and b.cc_state.shape == (n, T, 784) and torch.isfinite(b.cc_state).all() and (b.exps == 1).all()
+    # a new episode starts on its clip's init pose
+    st = es.copy(); st[:, 0] = False
+    e_idx, t_idx = np.nonzero(st)
+    for e, t in list(zip(e_idx, t_idx))[:20]:
+        ti, fs = int(vm[e, t, 0]), int(vm[e, t, 1])
+        np.testing.assert_allclose(b.curr_qpos[e, t].cpu().numpy()[7:], ds.data["qpos"][ti][fs].numpy()[7:], atol=1e-6)
+
+
+def test_hidden_state_carries_across_calls_and_ppo_ratio_starts_at_one():
+    """episodes that continue from the previous sample() call keep their GRU state (RolloutBatch.hx0), so the means the
+    update recomputes are the behaviour policy's: with mean actions the recorded actions ARE those means."""
+    from kinpoly_amd.env import BatchedHumanoidAREnv, standing_context
+    from kinpoly_amd.nets import KinPolicy
+    from kinpoly_amd.rollout import VectorSampler
+    n, T = 16, 6
+    torch.manual_seed(1)
+    env = BatchedHumanoidAREnv(n, 0, mode="test", seed=1)
+    env.reward_cfg.body_diff_thresh = 1e9                          # nothing fails: episodes span both calls
+    env.load_context(standing_context(n, 40, STD["qpos"], STD["qvel"], env.sim))
+    pol = KinPolicy().to(env.device)
+    with torch.no_grad():
+        pol.action_fc.weight.mul_(0.01); pol.action_fc.bias.zero_()
+    sampler = VectorSampler(env, pol, mean_action=True)
+    b1 = sampler.sample(T)
+    b2 = sampler.sample(T)
+    assert not bool(b2.episode_start.any()) and float(b2.hx0.abs().max()) > 0
+    assert torch.equal(b2.states[:, 0], b1.last_states)
+    with torch.no_grad():
+        m2 = pol.unroll(b2.states, b2.episode_start, b2.hx0)
+        m2_wrong = pol.unroll(b2.states, b2.episode_start)
+    err, err_wrong = float((m2 - b2.actions).abs().max()), float((m2_wrong - b2.actions).abs().max())
+    assert err < 1e-6 and err_wrong > 20 * max(err, 1e-8), (err, err_wrong)
+    # horizon cut: the last row keeps mask 1 and GAE bootstraps with V(last_states) instead of treating it as terminal
+    from kinpoly_amd import sim as kpsim
+    assert float(b2.masks[:, -1].min()) == 1.0
+    v = torch.rand((n, T), device=env.device); lv = torch.rand(n, device=env.device)
+    adv_b, _ = kpsim.gae(b2.rewards.contiguous(), b2.masks.contiguous(), v, 0.95, 0.95, lv)
+    adv_0, _ = kpsim.gae(b2.rewards.contiguous(), b2.masks.contiguous(), v, 0.95, 0.95)
+    want_last = b2.rewards[:, -1] + 0.95 * lv - v[:, -1]
+    assert torch.allclose(adv_b[:, -1], want_last, atol=1e-6) and torch.allclose(adv_0[:, -1], b2.rewards[:, -1] - v[:, -1], atol=1e-6)
+
+
+def test_lr_schedules_and_controller_update():
+    """LambdaLR of agent_ar.py:215-225 (nepoch_fix, nepoch) stepped per iteration; joint_controller: update_controller moves the
+    UHC policy with the kinematic policy's advantages (agent_ar.py:774-794)."""
+    from kinpoly_amd.agent import AgentAR
+    from kinpoly_amd.env import standing_context
+    from kinpoly_amd import sim as kpsim
+    n, T = 32, 8
+    fk_sim = kpsim.KpSim(kpsim.KpModel(), n, 0)
+
+    def context_fn(m):
+        ctx = standing_context(m, T + 2, STD["qpos"], STD["qvel"], fk_sim, torch.zeros(m))
+        ctx["obj_pose"] = torch.tensor([0.0, 0, 0, 1, 0, 0, 0], device=ctx["qpos"].device).repeat(m, T + 2, 1)
+        return ctx
+    agent = AgentAR(n, context_fn, device=0, horizon=T, num_optim_epoch=2, num_step_update=1, use_init_context=False,
+                    num_epoch_fix=1, num_epoch=4, joint_controller=True, pool_depth=T)
+    cc_before = [p.detach().clone() for p in agent.env.cc_policy.parameters()]
+    lrs = []
+    for it in range(4):
+        info = agent.optimize_policy(it)
+        lrs.append(info["policy_lr"])
+        assert np.isfinite(info["surr_loss"]) and np.isfinite(info["cc_surr_loss"]) and np.isfinite(info["step_loss"])
+    rule = [1e-5 * (1.0 - max(0, e - 1) / float(4 - 1 + 1)) for e in (1, 2, 3, 4)]      # epoch counter after per_epoch_update
+    np.testing.assert_allclose(lrs, rule, rtol=1e-6)
+    moved = sum(float((p.detach() - q).abs().max()) for p, q in zip(agent.env.cc_policy.parameters(), cc_before))
+    assert moved > 0, "update_controller did not touch the UHC policy"
+
+
+def test_two_rank_agent_keeps_parameters_identical():
+    """SURVEY 8(e) on one device: two ranks (gloo, both on cuda:0) shard the envs, all-gather advantages / returns, all-reduce
+    gradients; after optimize_policy the policy / value parameters are bit-identical across ranks and differ from the initial ones."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", KP_SHARED_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
+           os.path.join(ROOT, "tests", "_ddp_agent_worker.py")]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "DDP_AGENT_OK" in out.stdout, out.stdout[-2000:]

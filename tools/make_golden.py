@@ -353,6 +353,21 @@ def gen_traj_ar_net(hum):
              shapes=np.array([list(v.shape) + [0] * (2 - v.dim()) for v in net.state_dict().values()]),
              **{"in_" + k: v for k, v in data.items()}, init_qpos=init_qpos, init_qvel=init_qvel, context_feat_rnn=ctx_feat,
              ar_qpos=fp["qpos"].numpy(), ar_qvel=fp["qvel"].numpy(), action=fp["action"].numpy(), state_dim=net.state_dim, context_dim=net.context_dim)
+    # PolicyAR.initialize_rnn + forward(mode="train") (policy_ar.py:104-122, 216-240): the padded [T_max, n_episodes] re-unroll of the
+    # GRU over a flat batch whose episodes are cut by masks == 0, run on a duck-typed `self` that holds the same seeded TrajARNet
+    import kin_poly.models.policy_ar as par
+    nb = 14
+    masks = torch.ones(nb); masks[[2, 6, 7, 13]] = 0          # episodes of 3, 4, 1 and 6 rows
+    v_metas = torch.zeros((nb, 3))
+    states = torch.tensor(rng.normal(size=(nb, net.state_dim)) * 0.5)
+    stub = types.SimpleNamespace(traj_ar_net=net, state_dim=net.state_dim, action_dim=80, policy_v=1, mode="train",
+                                 action_log_std=torch.ones(1, 80) * -3.2)
+    stub.get_action = lambda st: par.PolicyAR.get_action(stub, st)
+    par.PolicyAR.initialize_rnn(stub, (masks, v_metas))
+    with torch.no_grad():
+        _, mean, _ = par.PolicyAR.forward(stub, states)
+    np.savez(os.path.join(OUT, "unroll.npz"), seed=9, states=states.numpy(), masks=masks.numpy(), action_mean=mean.numpy(),
+             num_episode=stub.num_episode, max_episode_len=stub.max_episode_len)
     from scipy.ndimage import gaussian_filter1d
     x = rng.normal(size=(12, 69))
     np.savez(os.path.join(OUT, "smooth.npz"), x=x, y=gaussian_filter1d(x, 1, axis=0))
