@@ -9,8 +9,18 @@ per GPU: kinematic policy (GRU+MLP) -> step_ar -> target
 termination + reward -> AR obs (105) -> device-side auto-reset.  Inputs are synthetic and resident in HBM
 before the timed region (standing clip contexts, seeded random-init networks).
 
+Workloads (all BASELINE configs[2] env-steps at 4096 envs/GPU unless noted):
+    tracked      (default, the metric) episodes that last: the kinematic policy's GEMMs run, its output is replaced by the clip's own pose +
+                 N(0, e^-3.2) exploration noise -- what a pretrained kinematic policy emits (the reference starts RL from a supervised one)
+    random_init  seeded random-init networks: the body-diff termination ends (almost) every episode after one step, so every timed step
+                 contains the device-side reset (round 1's headline; secondary now)
+    wild_eval    BASELINE configs[4]: the --wild evaluation path (humanoid_smpl_neutral_mesh_all.xml, mode "test" = mean actions of both
+                 policies, no GT termination, fail-safe on), inference only
+
 Prints ONE JSON line on rank 0 (see the task contract) with `roofline` (dominant kernel kp_step_queue_kernel = kp_step_kernel scheduled as jobs,
-live HIP-event launch durations) and, at N = 1, `cpu_baseline` (the fp64 oracle port in 35 single-threaded worker processes).
+live HIP-event launch durations; `traffic` / `valu` only from a rocprofv3 --pmc pass of THIS command and workload committed under profiles/)
+and, at N = 1, `mfma` (the policy GEMMs timed in isolation), secondary workloads and `cpu_baseline` (the fp64 oracle port in 35
+single-threaded worker processes, with its counted FLOPs per env-step).
 """
 import argparse
 import json
@@ -29,21 +39,29 @@ ENVS_PER_GPU = 4096
 CLIP_LEN = 100                      # fr_num (config/statear/kin_poly.yml:11)
 ALGO_BYTES_PER_ENV_STEP = 2772      # humanoid-only compulsory fp32 traffic of do_simulation
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8.0 TB/s spec
+VALU_FP32_PEAK_TFLOPS = 157.3       # 256 CUs x 4 SIMDs x 64 lanes x 2 (FMA) x 2.4 GHz (vector fp32; MI355X spec sheet)
+MFMA_FP32_PEAK_TFLOPS = 157.3       # dense fp32 matrix peak (spec sheet): the policy / value GEMMs run in fp32
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r02")
 
 
-def build_engine(device_index, seed, threads):
+def build_engine(device_index, seed, threads, workload="tracked"):
     from kinpoly_amd.env import BatchedHumanoidAREnv, standing_context
     from kinpoly_amd.nets import KinPolicy, enable_tuned_gemms
     from kinpoly_amd.rollout import VectorSampler
     build_engine.tuned = enable_tuned_gemms()
     torch.manual_seed(seed)
     std = np.load(os.path.join(ROOT, "tests", "golden", "standing_neutral.npz"))
-    env = BatchedHumanoidAREnv(ENVS_PER_GPU, device_index, mode="train", seed=seed, model_options={"threads_per_env": threads, **({"substeps_per_job": int(os.environ["KP_SUBSTEPS_PER_JOB"])} if "KP_SUBSTEPS_PER_JOB" in os.environ else {})})
+    wild = workload == "wild_eval"
+    opts = {"threads_per_env": threads, **({"substeps_per_job": int(os.environ["KP_SUBSTEPS_PER_JOB"])} if "KP_SUBSTEPS_PER_JOB" in os.environ else {})}
+    env = BatchedHumanoidAREnv(ENVS_PER_GPU, device_index, mode="test" if wild else "train", wild=wild, seed=seed, model_options=opts)
     policy = KinPolicy().to(env.device).float()
     g = torch.Generator().manual_seed(seed)
     headings = (torch.rand(ENVS_PER_GPU, generator=g) * 2 - 1) * np.pi
-    env.load_context(standing_context(ENVS_PER_GPU, CLIP_LEN, std["qpos"], std["qvel"], env.sim, headings))
-    sampler = VectorSampler(env, policy)
+    ctx = standing_context(ENVS_PER_GPU, CLIP_LEN, std["qpos"], std["qvel"], env.sim, headings)
+    if wild:            # the kinematic roll-out the fail-safe falls back to (ar_context['ar_qpos' / 'ar_qvel']): the clip itself
+        ctx["ar_qpos"], ctx["ar_qvel"] = ctx["qpos"].clone(), torch.zeros((ENVS_PER_GPU, CLIP_LEN, 75), device=env.device)
+    env.load_context(ctx)
+    sampler = VectorSampler(env, policy, mean_action=wild)
     sampler.start()
     return env, policy, sampler, std
 
@@ -58,20 +76,49 @@ def tracking_action(env):
     return a
 
 
-def rollout_steps(sampler, k, a_track=None):
-    """k batched env-steps without keeping the experience (identical work to VectorSampler.sample's loop body)."""
+def rollout_steps(sampler, k, a_track=None, wild=False):
+    """k batched env-steps without keeping the experience (identical work to VectorSampler.sample's loop body).
+    wild: the eval_ar_policy.py --wild loop (:196-215): mean actions, an env that terminates early is put back on the kinematic
+    roll-out (ar_fail_safe) and keeps going, an env that finishes its clip starts it again."""
     env, pol = sampler.env, sampler.policy
     n_done = torch.zeros((), dtype=torch.int64, device=env.device)
     with torch.no_grad():
         for _ in range(k):
-            action, sampler.hx = pol.select_action(sampler.obs, sampler.hx, False, env.gen)
+            action, sampler.hx = pol.select_action(sampler.obs, sampler.hx, wild, env.gen)
             if a_track is not None:                              # the policy's GEMMs ran; a trained policy's output stands in for theirs
-                action = action * 0.0 + a_track + 0.04 * torch.randn(action.shape, device=action.device, generator=env.gen)
-            _, _, done, info = env.step(action.contiguous())
-            n_done += done.sum()
+                action = action * 0.0 + a_track + (0.0 if wild else 0.04) * torch.randn(action.shape, device=action.device, generator=env.gen)
+            obs, _, done, info = env.step(action.contiguous())
+            if wild:
+                early = done & (info["percent"] != 1)
+                env.ar_fail_safe(early)                          # masked, device side
+                done = done & ~early
+                n_done += early.sum()
+            else:
+                n_done += done.sum()
             sampler.obs = env.reset(done).clone()
             sampler.hx = sampler.hx * (~done).float().unsqueeze(1)
     return n_done
+
+
+def policy_gemm_probe(env, policy, iters=30):
+    """The MFMA side of an env-step in isolation: kinematic policy (GRU cell + MLP 1129-1024-512-256-80) and PolicyMCP (8 primitives
+    784-512-256-75 + composer 784-300-200-8) forward on the bench's batch, fp32, timed with events on torch's stream.  FLOPs = 2 x MACs."""
+    n = env.n
+    obs = torch.randn((n, 105), device=env.device); hx = torch.randn((n, 1024), device=env.device); cc = torch.randn((n, 784), device=env.device)
+    macs = (105 * 3072 + 1024 * 3072) + (1129 * 1024 + 1024 * 512 + 512 * 256 + 256 * 80) + 8 * (784 * 512 + 512 * 256 + 256 * 75) + (784 * 300 + 300 * 200 + 200 * 8)
+    with torch.no_grad():
+        for _ in range(5):
+            policy.select_action(obs, hx, True); env.cc_policy.select_action(cc, True)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            policy.select_action(obs, hx, True); env.cc_policy.select_action(cc, True)
+        e1.record(); e1.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    tf = 2.0 * macs * n / (ms * 1e-3) / 1e12
+    return {"gemm_flops_per_env_step": 2 * macs, "ms_per_step_isolated": ms, "achieved_tflops": tf, "peak_tflops": MFMA_FP32_PEAK_TFLOPS, "frac": tf / MFMA_FP32_PEAK_TFLOPS,
+            "note": "policy GEMMs + their elementwise epilogues through hipBLASLt / rocBLAS (MFMA, fp32 in / fp32 accumulate), timed outside the env-step; "
+                    "inside the step they overlap nothing (one stream), so ms_per_step_isolated / ms_per_step is their share of the step"}
 
 
 def cpu_baseline(std, seconds_budget=15.0):
@@ -81,8 +128,10 @@ def cpu_baseline(std, seconds_budget=15.0):
     from kinpoly_amd.model_compiler import DEFAULT_KPM, read_kpm
     from kinpoly_amd.nets import KinPolicy, PolicyMCP
     from oracle import np_oracle as O
+    from oracle import kpo
     from oracle.kpo import OracleSim
     torch.set_num_threads(1)
+    kpo.flops_reset()
     kpm = read_kpm(DEFAULT_KPM)
     bp, bi, par = kpm["body_pos"].reshape(24, 3), kpm["body_ipos"].reshape(24, 3), kpm["body_parent"]
     torch.manual_seed(0)
@@ -119,7 +168,7 @@ def cpu_baseline(std, seconds_budget=15.0):
             if fail or time.perf_counter() - t0 > seconds_budget:
                 break
     dt = time.perf_counter() - t0
-    return {"value": n_steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+    return {"value": n_steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "port", "physics_flops_per_env_step": kpo.flops() / max(n_steps, 1),
             "sample": f"{n_steps} env-steps of the same standing-clip rollout (fp64 C physics oracle + numpy obs/reward + fp64 torch policies, 1 thread) in {dt:.1f} s; host has {os.cpu_count()} cores"}
 
 
@@ -132,19 +181,56 @@ def cpu_baseline_workers(std, workers, seconds_budget=15.0):
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(seconds_budget)]
     t0 = time.perf_counter()
     procs = [subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for _ in range(workers)]
-    steps, wall = 0, 0.0
+    steps, wall, flops = 0, 0.0, 0.0
     for p in procs:
         try:
             out, _ = p.communicate(timeout=seconds_budget * 4 + 120)
             rec = json.loads(out.strip().splitlines()[-1])
-            steps += rec["steps"]; wall = max(wall, rec["seconds"])
+            steps += rec["steps"]; wall = max(wall, rec["seconds"]); flops += rec.get("flops", 0.0)
         except Exception:
             p.kill()
             raise
-    return {"value": steps / wall, "unit": "env-steps/s", "cores": workers, "kind": "port",
+    return {"value": steps / wall, "unit": "env-steps/s", "cores": workers, "kind": "port", "physics_flops_per_env_step": flops / max(steps, 1),
             "sample": f"{steps} env-steps of the same standing-clip rollout in {workers} single-threaded worker processes (fp64 C physics oracle + numpy obs/reward "
                       f"+ fp64 torch policies each; the reference samples with 35 such workers) over {wall:.1f} s of rollout ({time.perf_counter() - t0:.1f} s with start-up); "
                       f"host has {os.cpu_count()} cores"}
+
+
+WORKLOAD_DESC = {
+    "tracked": "BASELINE configs[2] rollout: kin_poly.yml dynamics-regulated env-step (kin GRU policy, step_ar, target FK, UHC obs+ZFilter+PolicyMCP, 15 substeps "
+               "SPD+RFC+contact, term/reward, AR obs, auto-reset), standing MoCap clip, seeded networks; episodes that last: the kinematic policy's GEMMs "
+               "run, its output is replaced by the clip pose + N(0, e^-3.2) noise (what a pretrained kinematic policy emits)",
+    "random_init": "BASELINE configs[2] rollout, same env-step, seeded random-init networks: every env terminates and is reset on (almost) every step",
+    "wild_eval": "BASELINE configs[4]: --wild eval_ar_policy path (humanoid_smpl_neutral_mesh_all.xml, mode test: mean actions of both policies, no GT "
+                 "termination, fail-safe on), batched inference, standing clip",
+}
+
+
+def run_workload(workload, device_index, seed, threads, steps, warmup, barrier=None):
+    """Build the engine for `workload`, run `warmup` untimed + `steps` timed env-steps.  Returns (record, env, policy, sampler, std)."""
+    env, policy, sampler, std = build_engine(device_index, seed, threads, workload)
+    a_track = None
+    if workload in ("tracked", "wild_eval"):
+        a_track = tracking_action(env)
+        sampler.start()
+    wild = workload == "wild_eval"
+    rollout_steps(sampler, warmup, a_track, wild)
+    env.sim.timing_reset()
+    if barrier is not None:
+        barrier()
+    else:
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n_done = rollout_steps(sampler, steps, a_track, wild)
+    if barrier is not None:
+        barrier()
+    else:
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kern_s, n_launch = env.sim.timing_mean_seconds()
+    diag = env.sim.diag()
+    rec = {"elapsed": elapsed, "kern_s": kern_s, "n_launch": n_launch, "diag": diag, "n_done": float(n_done.item())}
+    return rec, env, policy, sampler, std
 
 
 def main():
@@ -152,17 +238,16 @@ def main():
         std = np.load(os.path.join(ROOT, "tests", "golden", "standing_neutral.npz"))
         r = cpu_baseline(std, float(sys.argv[2]))
         n = int(r["sample"].split()[0])
-        print(json.dumps({"steps": n, "seconds": n / r["value"]}), flush=True)
+        print(json.dumps({"steps": n, "seconds": n / r["value"], "flops": r["physics_flops_per_env_step"] * n}), flush=True)
         return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--threads-per-env", type=int, default=int(os.environ.get("KP_THREADS_PER_ENV", "64")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=("random_init", "tracked"), default="random_init",
-                    help="random_init (default, BASELINE configs[2]): seeded random-init networks; tracked: same step, but the kinematic "
-                         "policy's output is replaced by the clip's own pose + exploration noise, i.e. episodes that last (secondary figure)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads and the GEMM probe (profiling runs)")
+    ap.add_argument("--workload", choices=tuple(WORKLOAD_DESC), default="tracked")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -182,84 +267,78 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    env, policy, sampler, std = build_engine(local_rank, 4 + rank, args.threads_per_env)
-    a_track = None
-    if args.workload == "tracked":
-        a_track = tracking_action(env)
-        sampler.start()
-    rollout_steps(sampler, args.warmup, a_track)
-    env.sim.timing_reset()
-
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    barrier()
-    t0 = time.perf_counter()
-    n_done = rollout_steps(sampler, args.steps, a_track)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    rec, env, policy, sampler, std = run_workload(args.workload, local_rank, 4 + rank, args.threads_per_env, args.steps, args.warmup, barrier)
+    elapsed = rec["elapsed"]
     if world > 1:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cpu" if shared else "cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kern_s, n_launch = env.sim.timing_mean_seconds()
-    diag = env.sim.diag()
+    kern_s, n_launch, diag = rec["kern_s"], rec["n_launch"], rec["diag"]
     cost = env.sim.launch_cost().astype(np.float64)
 
     if rank == 0:
         value = ENVS_PER_GPU * world * args.steps / elapsed
         algo_bytes = ALGO_BYTES_PER_ENV_STEP * ENVS_PER_GPU
         achieved = algo_bytes / kern_s / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-        # what actually bounds the kernel: VALU issue.  Counts and kernel duration both from the committed PMC pass (tools/pmc_step.py workload)
-        valu = None
-        if os.path.exists(pmc):
-            valu = json.load(open(pmc)).get("issue")
+        kernel_name = "kp_step_queue_kernel" if int(env.model.get_option("substeps_per_job")) > 0 else "kp_step_kernel"
+        # HBM bytes / instruction counts: ONLY from a rocprofv3 --pmc pass of this same command and workload (tools/profile_bench.sh writes
+        # profiles/r02/pmc_bench_<workload>.json); otherwise null -- nothing canned from another workload enters the line
+        traffic, traffic_src, valu = None, None, None
+        pmc_path = os.path.join(PROFILE_DIR, f"pmc_bench_{args.workload}.json")
+        if os.path.exists(pmc_path):
+            pj = json.load(open(pmc_path))
+            traffic = pj.get("hbm_bytes_per_launch")
+            traffic_src = {"file": os.path.relpath(pmc_path, ROOT), "command": pj.get("command"), "launch_ms_in_those_passes": pj.get("launch_ms"),
+                           "note": "separate rocprofv3 --pmc passes of this command (FETCH_SIZE x2 per the guide's gfx950 correction, WRITE_SIZE as reported), "
+                                   "median per launch of the same kernel; not measured in this run"}
+            valu = pj.get("issue")
         out = {
             "metric": "env-steps/sec (whole node) at 4096 envs/GPU, 69-DoF SMPL", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2] rollout: kin_poly.yml dynamics-regulated env-step (kin GRU policy, step_ar, target FK, "
-                                   "UHC obs+ZFilter+PolicyMCP, 15 substeps SPD+RFC+contact, term/reward, AR obs, auto-reset), standing MoCap clip, "
-                                   "random-init seeded networks" + ("; SECONDARY workload 'tracked': kinematic policy output replaced by the clip pose + N(0, 0.04) noise" if args.workload == "tracked" else ""), "envs_per_gpu": ENVS_PER_GPU, "substeps": 15, "clip_len": CLIP_LEN,
+            "config": {"workload": WORKLOAD_DESC[args.workload], "workload_id": args.workload, "envs_per_gpu": ENVS_PER_GPU, "substeps": 15, "clip_len": CLIP_LEN,
                        "threads_per_env": args.threads_per_env, "parallelism": f"env-sharded x{world}",
                        "gemm_selection": "kinpoly_amd/assets/tunableop_gfx950.csv (rocBLAS / hipBLASLt solution per shape, fp32)" if getattr(build_engine, "tuned", False) else "library default"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "kp_step_queue_kernel" if int(env.model.get_option("substeps_per_job")) > 0 else "kp_step_kernel", "launch_ms": kern_s * 1e3, "launches_timed": n_launch,
-                         "algorithmic_bytes_per_launch": algo_bytes,
-                         "note": "latency/VALU-bound tree recursion with state resident in LDS: compulsory HBM traffic is tiny by construction (DESIGN.md)",
+                         "traffic": traffic, "traffic_over_algorithmic": (traffic / algo_bytes) if traffic else None, "traffic_source": traffic_src,
+                         "kernel": kernel_name, "launch_ms": kern_s * 1e3, "launches_timed": n_launch, "algorithmic_bytes_per_launch": algo_bytes,
+                         "limiter": "valu-issue / dependent-chain latency (state resident in LDS: the compulsory HBM traffic is tiny by construction, DESIGN.md section 6)",
                          "valu": valu},
             "kernel_share_of_step": kern_s / (elapsed / args.steps),
-            "contacts_mean": float(diag[:, 0].mean()), "newton_iters_per_substep": float(diag[:, 1].mean() / 15.0), "hessian_factorisations_per_substep": float((diag[:, 3] >> 8).mean() / 15.0), "bad_envs": int((diag[:, 2] != 0).sum()),
-            # random-init networks put the kinematic target far from the humanoid, so (as in the reference with untrained weights) the
-            # body-diff termination (humanoid_ar_v1.py:303-309) fires on almost every step: each timed step includes the device-side reset
-            "episodes_ended_per_step_frac": float(n_done.item()) / (ENVS_PER_GPU * args.steps),
+            "contacts_mean": float(diag[:, 0].mean()), "newton_iters_per_substep": float(diag[:, 1].mean() / 15.0),
+            "hessian_factorisations_per_substep": float((diag[:, 3] >> 8).mean() / 15.0),
+            "bad_envs": int(((diag[:, 2] & 255) != 0).sum()), "newton_cap_hits": int((diag[:, 2] >> 8).sum()),
+            "episodes_ended_per_step_frac": rec["n_done"] / (ENVS_PER_GPU * args.steps),
             # per-env shader-clock cycles of the last launch (kp_sim_launch_cost): what the launch would take if its waves were perfectly
             # packed on the 2048 resident slots vs its longest env
             "launch_balance": {"substeps_per_job": int(env.model.get_option("substeps_per_job")), "sum_env_cycles_over_2048_slots_ms": float(cost.sum() / 2048 / 2.38e6),
                                "longest_env_ms": float(cost.max() / 2.38e6), "median_env_ms": float(np.median(cost) / 2.38e6)},
         }
-        if world == 1 and args.workload == "random_init":
-            # secondary figure (not the metric): the same step with episodes that last -- see --workload tracked
+        if world == 1 and not args.no_secondary:
             try:
-                a_tr = tracking_action(env)
-                sampler.start()
-                rollout_steps(sampler, 20, a_tr)
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                nd = rollout_steps(sampler, 60, a_tr)
-                torch.cuda.synchronize()
-                dt = time.perf_counter() - t1
-                out["secondary_tracked_workload"] = {"value": ENVS_PER_GPU * 60 / dt, "unit": "env-steps/s", "ms_per_step": dt / 60 * 1e3, "steps": 60, "warmup": 20,
-                                                     "episodes_ended_per_step_frac": float(nd.item()) / (ENVS_PER_GPU * 60),
-                                                     "note": "kinematic policy output replaced by the clip pose + N(0, e^-3.2) noise (its GEMMs still run): what a pretrained policy emits"}
+                out["mfma"] = policy_gemm_probe(env, policy)
             except Exception as ex:
-                out["secondary_tracked_workload"] = {"error": type(ex).__name__}
+                out["mfma"] = {"error": type(ex).__name__}
+            del sampler, env, policy
+            torch.cuda.empty_cache()
+            out["secondary_workloads"] = {}
+            for wl in [w for w in WORKLOAD_DESC if w != args.workload]:
+                try:
+                    r2, e2, p2, s2, _ = run_workload(wl, local_rank, 4 + rank, args.threads_per_env, 40, 15)
+                    out["secondary_workloads"][wl] = {"value": ENVS_PER_GPU * 40 / r2["elapsed"], "unit": "env-steps/s", "ms_per_step": r2["elapsed"] / 40 * 1e3, "steps": 40, "warmup": 15,
+                                                      "launch_ms": r2["kern_s"] * 1e3, "contacts_mean": float(r2["diag"][:, 0].mean()),
+                                                      "newton_iters_per_substep": float(r2["diag"][:, 1].mean() / 15.0),
+                                                      ("fail_safe_per_step_frac" if wl == "wild_eval" else "episodes_ended_per_step_frac"): r2["n_done"] / (ENVS_PER_GPU * 40),
+                                                      "workload": WORKLOAD_DESC[wl]}
+                    del r2, e2, p2, s2
+                    torch.cuda.empty_cache()
+                except Exception as ex:
+                    out["secondary_workloads"][wl] = {"error": f"{type(ex).__name__}: {ex}"[:200]}
         if world == 1 and not args.no_cpu_baseline:
             workers = min(35, os.cpu_count() or 1)
             try:
@@ -267,6 +346,13 @@ def main():
             except Exception as ex:        # e.g. no room for 35 interpreters: fall back to the one-core figure
                 out["cpu_baseline"] = cpu_baseline(std)
                 out["cpu_baseline"]["sample"] += f" (multi-worker run failed: {type(ex).__name__})"
+            # algorithmic FLOPs of the reference formulation (counted in the fp64 oracle on its rollout) x the GPU's env-step rate
+            fl = out["cpu_baseline"].get("physics_flops_per_env_step")
+            if fl:
+                out["roofline"]["valu_flops"] = {"physics_flops_per_env_step_oracle": fl, "achieved_tflops": fl * value / world / 1e12, "peak_tflops": VALU_FP32_PEAK_TFLOPS,
+                                                 "frac": fl * value / world / 1e12 / VALU_FP32_PEAK_TFLOPS,
+                                                 "note": "FLOPs counted at the loop bodies of the fp64 oracle (dense stable-PD Cholesky, sparse L'DL, dense Newton Hessian: the arithmetic "
+                                                         "the reference + MuJoCo execute) on the random-init standing rollout of the CPU baseline; the HIP kernel's matrix-free passes do fewer"}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -54,6 +54,7 @@ static void kpc_normalize(double *a) { double n = sqrt(kpc_dot(a, a)); a[0] /= n
 /* mjccd_support: farthest point of the shape in world direction dir (unit), inflated by `margin` along dir  [MJ-ext] */
 static void kpc_support(const kpc_shape *s, const double *dir, double margin, double *out) {
     double l[3], p[3];
+    FL(15 + 21 + (s->type == 2 ? 5 * s->nvert : 6));
     for (int k = 0; k < 3; k++) l[k] = s->mat[k] * dir[0] + s->mat[3 + k] * dir[1] + s->mat[6 + k] * dir[2];   /* R^T dir */
     if (s->type == 0) { for (int k = 0; k < 3; k++) p[k] = (l[k] > 0 ? 1.0 : -1.0) * s->size[k]; }
     else if (s->type == 1) {
@@ -220,6 +221,7 @@ static int kpo_convex(const kpc_shape *g1, const kpc_shape *g2, double margin, k
  * NEIGHBOURS on the hull graph (in graph order) that are within the margin.  plane = world z = 0 (the floor geom of the XML).
  * nbr / nbr_adr: hull graph (model compiler).  Contact position = vertex - normal * dist / 2. */
 static int kpo_plane_mesh(const kpc_shape *h, const int *nbr_adr, const int *nbr, double margin, double rbound, kpc_contact *con) {
+    FL(6 * h->nvert);
     int best = -1; double bd = 1e300, bw[3] = {0, 0, 0};
     for (int v = 0; v < h->nvert; v++) {
         const double *p = h->verts + 3 * v;

@@ -102,13 +102,24 @@ typedef struct {
     int solver_niter;
 } kpo_data;
 
+/* floating-point operation counter (multiplications + additions + divisions + square roots / trigonometric calls, counted at the loop
+ * bodies below) of everything executed since kpo_flops_reset(): the "algorithmic FLOPs of the reference formulation" bench.py reports
+ * (dense mj_fullM + Cholesky stable-PD, sparse L'DL, dense Newton Hessian -- the arithmetic MuJoCo + the reference's Python execute,
+ * not the matrix-free passes of the HIP kernel). */
+static double kpo_flops = 0.0;
+#define FL(n) (kpo_flops += (double)(n))
+void kpo_flops_reset(void) { kpo_flops = 0.0; }
+double kpo_flops_get(void) { return kpo_flops; }
+
 /* ------------------------------------------------------------------ small math */
 static void v3_cross(double *r, const double *a, const double *b) {
+    FL(9);
     double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
     r[0] = x; r[1] = y; r[2] = z;
 }
-static double v3_dot(const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static double v3_dot(const double *a, const double *b) { FL(5); return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 static void quat_mul(double *r, const double *a, const double *b) { /* r = a (x) b, (w,x,y,z) */
+    FL(28);
     double w = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
     double x = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
     double y = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
@@ -116,17 +127,20 @@ static void quat_mul(double *r, const double *a, const double *b) { /* r = a (x)
     r[0] = w; r[1] = x; r[2] = y; r[3] = z;
 }
 static void quat_normalize(double *q) { /* mju_normalize4: zero quat -> identity */
+    FL(12);
     double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
     if (n < MJ_MINVAL) { q[0] = 1; q[1] = q[2] = q[3] = 0; }
     else { q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n; }
 }
 static void quat2mat(double *m, const double *q) {
+    FL(37);
     double w = q[0], x = q[1], y = q[2], z = q[3];
     m[0] = w * w + x * x - y * y - z * z; m[1] = 2 * (x * y - w * z); m[2] = 2 * (x * z + w * y);
     m[3] = 2 * (x * y + w * z); m[4] = w * w - x * x + y * y - z * z; m[5] = 2 * (y * z - w * x);
     m[6] = 2 * (x * z - w * y); m[7] = 2 * (y * z + w * x); m[8] = w * w - x * x - y * y + z * z;
 }
 static void mat_mulvec(double *r, const double *m, const double *v) {
+    FL(15);
     double x = m[0] * v[0] + m[1] * v[1] + m[2] * v[2];
     double y = m[3] * v[0] + m[4] * v[1] + m[5] * v[2];
     double z = m[6] * v[0] + m[7] * v[1] + m[8] * v[2];
@@ -134,6 +148,7 @@ static void mat_mulvec(double *r, const double *m, const double *v) {
 }
 /* spatial: inert = [Ixx Iyy Izz Ixy Ixz Iyz | hx hy hz | m], v = [ang; lin]  (mju_mulInertVec) */
 static void inert_mulvec(double *f, const double *I, const double *v) {
+    FL(42);
     const double *w = v, *l = v + 3, *h = I + 6;
     double m = I[9];
     f[0] = I[0] * w[0] + I[3] * w[1] + I[4] * w[2] + (h[1] * l[2] - h[2] * l[1]);
@@ -144,12 +159,14 @@ static void inert_mulvec(double *f, const double *I, const double *v) {
     f[5] = m * l[2] - (h[0] * w[1] - h[1] * w[0]);
 }
 static void cross_motion(double *r, const double *v, const double *s) { /* mju_crossMotion */
+    FL(3);
     double a[3], b[3], c[3];
     v3_cross(a, v, s); v3_cross(b, v, s + 3); v3_cross(c, v + 3, s);
     r[0] = a[0]; r[1] = a[1]; r[2] = a[2];
     r[3] = b[0] + c[0]; r[4] = b[1] + c[1]; r[5] = b[2] + c[2];
 }
 static void cross_force(double *r, const double *v, const double *f) { /* mju_crossForce */
+    FL(3);
     double a[3], b[3], c[3];
     v3_cross(a, v, f); v3_cross(b, v + 3, f + 3); v3_cross(c, v, f + 3);
     r[0] = a[0] + b[0]; r[1] = a[1] + b[1]; r[2] = a[2] + b[2];
@@ -245,6 +262,7 @@ static void kpo_kinematics(const kpo_model *m, kpo_data *d) {
             for (int j = 0; j < 3; j++) {
                 double R[9]; quat2mat(R, q);
                 mat_mulvec(d->xaxis[6 + 3 * (b - 1) + j], R, ax_local[j]);
+                FL(10);
                 double h = 0.5 * ang[j], s = sin(h);
                 double qj[4] = {cos(h), ax_local[j][0] * s, ax_local[j][1] * s, ax_local[j][2] * s};
                 double qn[4]; quat_mul(qn, q, qj); memcpy(q, qn, 32);
@@ -253,17 +271,19 @@ static void kpo_kinematics(const kpo_model *m, kpo_data *d) {
             memcpy(d->xquat[b], q, 32); quat2mat(d->xmat[b], q);
         }
         double io[3]; mat_mulvec(io, d->xmat[b], m->body_ipos[b]);
+        FL(6);
         for (int k = 0; k < 3; k++) d->xipos[b][k] = d->xpos[b][k] + io[k];
     }
     /* subtree COM of the root = whole-humanoid COM */
     double M = 0, c[3] = {0, 0, 0};
-    for (int b = 0; b < m->nb; b++) { M += m->body_mass[b]; for (int k = 0; k < 3; k++) c[k] += m->body_mass[b] * d->xipos[b][k]; }
+    for (int b = 0; b < m->nb; b++) { FL(7); M += m->body_mass[b]; for (int k = 0; k < 3; k++) c[k] += m->body_mass[b] * d->xipos[b][k]; }
     for (int k = 0; k < 3; k++) d->subtree_com[k] = c[k] / M;
     /* cinert: body inertia about subtree_com, world axes */
     for (int b = 0; b < m->nb; b++) {
         const double *R = d->xmat[b], *Ib = m->body_inertia[b];
         double I3[9] = {Ib[0], Ib[3], Ib[4], Ib[3], Ib[1], Ib[5], Ib[4], Ib[5], Ib[2]};
         double T[9], W[9];
+        FL(90 + 36);
         for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double s = 0; for (int k = 0; k < 3; k++) s += R[3 * i + k] * I3[3 * k + j]; T[3 * i + j] = s; }
         for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double s = 0; for (int k = 0; k < 3; k++) s += T[3 * i + k] * R[3 * j + k]; W[3 * i + j] = s; }
         double r[3] = {d->xipos[b][0] - d->subtree_com[0], d->xipos[b][1] - d->subtree_com[1], d->xipos[b][2] - d->subtree_com[2]};
@@ -288,6 +308,7 @@ static void kpo_kinematics(const kpo_model *m, kpo_data *d) {
 /* composite rigid body -> qM (sparse), mj_crb  [MJ-ext] */
 static void kpo_crb(const kpo_model *m, kpo_data *d) {
     memcpy(d->crb, d->cinert, sizeof(d->crb));
+    FL(10 * (m->nb - 1));
     for (int b = m->nb - 1; b > 0; b--) for (int k = 0; k < 10; k++) d->crb[m->body_parent[b]][k] += d->crb[b][k];
     memset(d->qM, 0, sizeof(d->qM));
     for (int i = 0; i < m->nv; i++) {
@@ -296,6 +317,7 @@ static void kpo_crb(const kpo_model *m, kpo_data *d) {
         d->qM[adr] = m->dof_armature[i];
         for (int j = i; j >= 0; j = m->dof_parent[j], adr++) {
             double s = 0; for (int k = 0; k < 6; k++) s += d->cdof[j][k] * buf[k];
+            FL(13);
             d->qM[adr] += s;
         }
     }
@@ -309,6 +331,7 @@ static void kpo_factor_sparse(const kpo_model *m, const double *qM, double *qLD,
         while (i >= 0) {
             double tmp = qLD[Mki] / qLD[Mkk];
             int cnt = m->dof_madr[i + 1] - m->dof_madr[i];
+            FL(1 + 2 * cnt);
             for (int c = 0; c < cnt; c++) qLD[m->dof_madr[i] + c] -= tmp * qLD[Mki + c];
             qLD[Mki] = tmp;
             i = m->dof_parent[i]; Mki++;
@@ -318,10 +341,11 @@ static void kpo_factor_sparse(const kpo_model *m, const double *qM, double *qLD,
 }
 static void kpo_solve_sparse(const kpo_model *m, const double *qLD, const double *diaginv, double *x) {
     for (int i = m->nv - 1; i >= 0; i--) {
-        if (x[i] != 0) { int adr = m->dof_madr[i] + 1; for (int j = m->dof_parent[i]; j >= 0; j = m->dof_parent[j], adr++) x[j] -= qLD[adr] * x[i]; }
+        if (x[i] != 0) { int adr = m->dof_madr[i] + 1; for (int j = m->dof_parent[i]; j >= 0; j = m->dof_parent[j], adr++) { FL(2); x[j] -= qLD[adr] * x[i]; } }
     }
+    FL(m->nv);
     for (int i = 0; i < m->nv; i++) x[i] *= diaginv[i];
-    for (int i = 0; i < m->nv; i++) { int adr = m->dof_madr[i] + 1; for (int j = m->dof_parent[i]; j >= 0; j = m->dof_parent[j], adr++) x[i] -= qLD[adr] * x[j]; }
+    for (int i = 0; i < m->nv; i++) { int adr = m->dof_madr[i] + 1; for (int j = m->dof_parent[i]; j >= 0; j = m->dof_parent[j], adr++) { FL(2); x[i] -= qLD[adr] * x[j]; } }
 }
 /* dense nv x nv from sparse (mj_fullM) */
 void kpo_fullM(const kpo_model *m, const kpo_data *d, double *M) {
@@ -331,7 +355,7 @@ void kpo_fullM(const kpo_model *m, const kpo_data *d, double *M) {
 static void kpo_mulM(const kpo_model *m, const double *qM, const double *v, double *r) {
     for (int i = 0; i < m->nv; i++) r[i] = 0;
     for (int i = 0; i < m->nv; i++) { int adr = m->dof_madr[i]; r[i] += qM[adr] * v[i]; adr++;
-        for (int j = m->dof_parent[i]; j >= 0; j = m->dof_parent[j], adr++) { r[i] += qM[adr] * v[j]; r[j] += qM[adr] * v[i]; } }
+        for (int j = m->dof_parent[i]; j >= 0; j = m->dof_parent[j], adr++) { FL(4); r[i] += qM[adr] * v[j]; r[j] += qM[adr] * v[i]; } }
 }
 
 /* mj_comVel + mj_rne(flg_acc=0) -> qfrc_bias  [MJ-ext] */
@@ -354,10 +378,12 @@ static void kpo_vel_bias(const kpo_model *m, kpo_data *d) {
             }
         }
         memcpy(d->cvel[b], cv, 48); memcpy(d->cacc[b], ca, 48);
+        FL(b == 0 ? 6 * 24 : 3 * 24); FL(6);
         double Ia[6], Iv[6], cf[6];
         inert_mulvec(Ia, d->cinert[b], ca); inert_mulvec(Iv, d->cinert[b], cv); cross_force(cf, cv, Iv);
         for (int c = 0; c < 6; c++) d->cfrc[b][c] = Ia[c] + cf[c];
     }
+    FL(6 * (m->nb - 1) + 11 * m->nv);
     for (int b = m->nb - 1; b > 0; b--) for (int c = 0; c < 6; c++) d->cfrc[m->body_parent[b]][c] += d->cfrc[b][c];
     for (int i = 0; i < m->nv; i++) { double s = 0; for (int c = 0; c < 6; c++) s += d->cdof[i][c] * d->cfrc[m->dof_body[i]][c]; d->qfrc_bias[i] = s; }
 }
@@ -415,6 +441,7 @@ static void kpo_point_jac(const kpo_model *m, const kpo_data *d, int ent, const 
         int last = ent == 0 ? 5 : 6 + 3 * (ent - 1) + 2;
         for (int i = last; i >= 0; i = m->dof_parent[i]) {
             double wxr[3]; v3_cross(wxr, d->cdof[i], r);
+            FL(9);
             for (int k = 0; k < 3; k++) Jp[k][i] += sign * (d->cdof[i][3 + k] + wxr[k]);
         }
     } else {
@@ -567,6 +594,7 @@ static void kpo_make_constraint(const kpo_model *m, kpo_data *d) {
         for (int e = 0; e < 4; e++) {
             int t = 1 + e / 2; double sgn = (e & 1) ? -1.0 : 1.0;
             double vel = 0;
+            FL(14 * nv + 6);
             for (int i = 0; i < nv; i++) {
                 double jn = fr[0] * Jp[0][i] + fr[1] * Jp[1][i] + fr[2] * Jp[2][i];
                 double jt = fr[3 * t] * Jp[0][i] + fr[3 * t + 1] * Jp[1][i] + fr[3 * t + 2] * Jp[2][i];
@@ -585,6 +613,7 @@ static void kpo_make_constraint(const kpo_model *m, kpo_data *d) {
 static int chol_factor(double *A, int n) { /* lower, in place */
     for (int j = 0; j < n; j++) {
         double s = A[j * n + j];
+        FL(2 * j + 2 + (double)(n - j - 1) * (2 * j + 1));
         for (int k = 0; k < j; k++) s -= A[j * n + k] * A[j * n + k];
         if (s <= 0) return -1;
         s = sqrt(s); A[j * n + j] = s;
@@ -593,6 +622,7 @@ static int chol_factor(double *A, int n) { /* lower, in place */
     return 0;
 }
 static void chol_solve(const double *L, int n, double *x) {
+    FL(2.0 * n * n);
     for (int i = 0; i < n; i++) { double s = x[i]; for (int k = 0; k < i; k++) s -= L[i * n + k] * x[k]; x[i] = s / L[i * n + i]; }
     for (int i = n - 1; i >= 0; i--) { double s = x[i]; for (int k = i + 1; k < n; k++) s -= L[k * n + i] * x[k]; x[i] = s / L[i * n + i]; }
 }
@@ -609,13 +639,14 @@ static double kpo_cost(const kpo_model *m, kpo_data *d, const double *qacc, doub
     int nv = kpo_nvt(m, d);
     double Ma[NVT_MAX]; kpo_mulM_full(m, d, qacc, Ma);
     double cost = 0;
+    FL(5 * nv + 2.0 * nv * d->nefc);
     for (int i = 0; i < nv; i++) cost += 0.5 * (Ma[i] - d->qfrc_smooth[i]) * (qacc[i] - d->qacc_smooth[i]);
     for (int i = 0; i < nv; i++) d->qfrc_constraint[i] = 0;
     for (int e = 0; e < d->nefc; e++) {
         double jar = -d->efc_aref[e];
         for (int i = 0; i < nv; i++) jar += d->efc_J[e][i] * qacc[i];
         if (jar_out) jar_out[e] = jar;
-        if (jar < 0) { cost += 0.5 * d->efc_D[e] * jar * jar; d->efc_force[e] = -d->efc_D[e] * jar; for (int i = 0; i < nv; i++) d->qfrc_constraint[i] += d->efc_J[e][i] * d->efc_force[e]; }
+        if (jar < 0) { FL(5 + 2 * nv); cost += 0.5 * d->efc_D[e] * jar * jar; d->efc_force[e] = -d->efc_D[e] * jar; for (int i = 0; i < nv; i++) d->qfrc_constraint[i] += d->efc_J[e][i] * d->efc_force[e]; }
         else d->efc_force[e] = 0;
     }
     if (grad) for (int i = 0; i < nv; i++) grad[i] = Ma[i] - d->qfrc_smooth[i] - d->qfrc_constraint[i];
@@ -631,6 +662,7 @@ typedef struct { int ne; double g0, h0; const double *jar, *jv, *D; int evals; }
 typedef struct { double alpha, cost, deriv[2]; } kpo_ls_pnt;
 static void kpo_ls_eval(kpo_ls_ctx *c, kpo_ls_pnt *p) {            /* PrimalEval: cost relative to alpha = 0 and its two derivatives */
     double a = p->alpha, cost = a * c->g0 + 0.5 * a * a * c->h0, d1 = c->g0 + a * c->h0, d2 = c->h0;
+    FL(8 + 10.0 * c->ne);
     for (int e = 0; e < c->ne; e++) {
         double x0 = c->jar[e], x = x0 + a * c->jv[e];
         if (x < 0) { cost += 0.5 * c->D[e] * x * x; d1 += c->D[e] * x * c->jv[e]; d2 += c->D[e] * c->jv[e] * c->jv[e]; }
@@ -699,7 +731,7 @@ static void kpo_solve_constraint(const kpo_model *m, kpo_data *d) {
         memcpy(H, Mfull, sizeof(double) * nv * nv);
         for (int e = 0; e < ne; e++) if (jar[e] < 0) {
             double D = d->efc_D[e]; const double *J = d->efc_J[e];
-            for (int i = 0; i < nv; i++) if (J[i] != 0) { double a = D * J[i]; for (int j = 0; j <= i; j++) H[i * nv + j] += a * J[j]; }
+            for (int i = 0; i < nv; i++) if (J[i] != 0) { FL(1 + 2 * (i + 1)); double a = D * J[i]; for (int j = 0; j <= i; j++) H[i * nv + j] += a * J[j]; }
         }
         for (int i = 0; i < nv; i++) for (int j = 0; j < i; j++) H[j * nv + i] = H[i * nv + j];
         if (chol_factor(H, nv)) break;
@@ -707,6 +739,7 @@ static void kpo_solve_constraint(const kpo_model *m, kpo_data *d) {
         chol_solve(H, nv, search);
         /* line search on phi(a) = cost(qacc + a * search), a convex piecewise quadratic */
         kpo_mulM_full(m, d, search, Mv);
+        FL(2.0 * ne * nv + 4 * nv);
         for (int e = 0; e < ne; e++) { double s = 0; for (int i = 0; i < nv; i++) s += d->efc_J[e][i] * search[i]; jv[e] = s; }
         double g0 = 0, h0 = 0; /* Gauss part: derivative at alpha: g0 + alpha*h0 */
         for (int i = 0; i < nv; i++) { g0 += search[i] * (grad[i] + d->qfrc_constraint[i]); h0 += search[i] * Mv[i]; }
@@ -801,6 +834,7 @@ static void kpo_desired_accel(const kpo_model *m, const kpo_data *d, const doubl
     int nv = m->nv; double dt = m->timestep;
     kpo_fullM(m, d, A);
     for (int i = 0; i < nv; i++) A[i * nv + i] += k_d[i] * dt;
+    FL(6 * nv);
     for (int i = 0; i < nv; i++) q_accel[i] = -d->qfrc_bias[i] - k_p[i] * qpos_err[i] - k_d[i] * qvel_err[i];
     chol_factor(A, nv); chol_solve(A, nv, q_accel);
 }

@@ -52,6 +52,7 @@ def lib():
         L.kpo_solveM.argtypes = [P, P, D]
         L.kpo_get_contacts.argtypes = [P, I, D, D]
         L.kpo_get_contact_normals.argtypes = [P, D]
+        L.kpo_flops_get.restype = C.c_double
         L.kpo_set_geoms.argtypes = [P, C.c_int, D]
         L.kpo_set_object.argtypes = [P, C.c_int, D, C.c_int, D, D, D]
         L.kpo_clear_objects.argtypes = [P]
@@ -262,3 +263,12 @@ def narrowphase(kind, a=None, b=None, verts_a=None, verts_b=None, graph=None, ma
                           None if br is None else _dp(br), None if vb is None else _dp(vb), 0 if vb is None else len(vb),
                           None if adr is None else ip(adr), None if nbr is None else ip(nbr), float(margin), float(rbound), _dp(out))
     return out[:n].copy()
+
+
+def flops_reset():
+    lib().kpo_flops_reset()
+
+
+def flops():
+    """floating-point operations the oracle executed since flops_reset() (counted at its loop bodies, see kp_oracle.c)."""
+    return float(lib().kpo_flops_get())
