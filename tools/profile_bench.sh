@@ -9,10 +9,10 @@ OUT=gpurun_out/r02_prof/$WL
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 CMD="python bench.py --workload $WL --steps 30 --warmup 10 --no-cpu-baseline --no-secondary"
-rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o stats -- $CMD > "$OUT/bench_stats.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- $CMD > "$OUT/bench_stats.log" 2>&1
 for C in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU"; do
     TAG=$(echo "$C" | tr ' ' '+')
-    rocprofv3 --pmc $C -d "$OUT/pmc_$TAG" -o pmc -- $CMD > "$OUT/pmc_$TAG.log" 2>&1
+    rocprofv3 --pmc $C --output-format csv -d "$OUT/pmc_$TAG" -o pmc -- $CMD > "$OUT/pmc_$TAG.log" 2>&1
 done
 find "$OUT" -name "*.csv" | head -20
 python tools/make_pmc_summary.py "$OUT" "$WL" "$CMD" > "$OUT/summary.log" 2>&1
