@@ -163,6 +163,18 @@ int kp_gae(int n_envs, int T, const float* rewards, const float* masks, const fl
 int kp_gae_bootstrap(int n_envs, int T, const float* rewards, const float* masks, const float* values, const float* last_values,
                      float gamma, float tau, float* advantages, float* returns, void* hip_stream);
 
+/* GRU re-unroll of the PPO / supervised updates (policy_ar.py:104-122, 216-240), one time step of torch.nn.GRUCell
+ * semantics over n rows, all arrays contiguous float32 device pointers:
+ *   forward : gi [n,3H] = x_t W_ih^T + b_ih, gh [n,3H] = hm_prev W_hh^T + b_hh (the caller's GEMMs), hm_prev [n,H] = previous hidden state
+ *             already zeroed at episode starts -> h_out [n,H]; hm_next [n,H] (optional) = h_out * next_keep[row] (next_keep [n] = 1 - episode
+ *             start flag of step t + 1, or NULL), the next step's GEMM input.
+ *   backward: dh_out [n,H] (gradient reaching h_t from outside the recurrence, may be NULL), carry [n,H] * carry_keep [n] (gradient from
+ *             step t + 1, may be NULL) -> dgi [n,3H], dgh [n,3H] (the caller forms carry' = dgh W_hh + dhz and dW_hh += dgh^T hm_prev), dhz [n,H]. */
+int kp_gru_gates_forward(int n, int H, const float* gi, const float* gh, const float* hm_prev, const float* next_keep, float* h_out, float* hm_next,
+                         void* hip_stream);
+int kp_gru_gates_backward(int n, int H, const float* gi, const float* gh, const float* hm_prev, const float* dh_out, const float* carry,
+                          const float* carry_keep, float* dgi, float* dgh, float* dhz, void* hip_stream);
+
 /* restore a complete simulator state (what MjSimState + the derived arrays would hold): qpos/qvel and the
  * state (qpos_d/qvel_d) the stale derived quantities belong to; runs the forward pass on the latter. */
 int kp_sim_set_full_state(kp_sim*, const float* qpos, const float* qvel, const float* qpos_d, const float* qvel_d, const uint8_t* env_mask);

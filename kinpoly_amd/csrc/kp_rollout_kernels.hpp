@@ -160,4 +160,48 @@ __global__ void k_gae(int n, int T, const float* __restrict__ rewards, const flo
     }
 }
 
+// ---------------------------------------------------------------- GRU re-unroll of the updates
+// The PPO epochs and the supervised step update re-run the kinematic policy's GRU over the whole batch (policy_ar.py:104-122, 216-240:
+// padded [T_max, n_episodes] re-pack, hidden state zero at every episode start).  Here the batch is env-major / time-stepped:
+//     gi_t = x_t W_ih^T + b_ih  for all t in ONE GEMM,   gh_t = hm_{t-1} W_hh^T + b_hh  one GEMM per step (MFMA, library),
+// and these two kernels do everything else of a step, forward and backward, in one pass over [N, H]:
+//     r = sigma(gi_r + gh_r), z = sigma(gi_z + gh_z), n = tanh(gi_n + r gh_n), h = (1 - z) n + z hm_prev     (torch.nn.GRUCell)
+// hm = h masked by the NEXT step's episode-start flag, ready to be the next step's GEMM input.
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+__global__ void k_gru_gates_fwd(int n, int H, const float* __restrict__ gi, const float* __restrict__ gh, const float* __restrict__ hm_prev,
+                                const float* __restrict__ next_keep, float* __restrict__ h_out, float* __restrict__ hm_next) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)n * H) return;
+    const int e = (int)(i / H), j = (int)(i - (size_t)e * H);
+    const float* a = gi + (size_t)e * 3 * H; const float* b = gh + (size_t)e * 3 * H;
+    const float r = sigmoidf_(a[j] + b[j]), z = sigmoidf_(a[H + j] + b[H + j]), nn = tanhf(a[2 * H + j] + r * b[2 * H + j]);
+    const float h = (1.0f - z) * nn + z * hm_prev[i];
+    h_out[i] = h;
+    if (hm_next) hm_next[i] = next_keep ? h * next_keep[e] : h;
+}
+
+// dh = dh_out (gradient reaching h_t from its consumers outside the recurrence) + carry * carry_keep (from step t + 1 through hm_t).
+// Outputs: dgi (3H: gradient of gi_t), dgh (3H: gradient of gh_t, the GEMM operand), dhz = dh * z (the direct path into hm_{t-1}).
+__global__ void k_gru_gates_bwd(int n, int H, const float* __restrict__ gi, const float* __restrict__ gh, const float* __restrict__ hm_prev,
+                                const float* __restrict__ dh_out, const float* __restrict__ carry, const float* __restrict__ carry_keep,
+                                float* __restrict__ dgi, float* __restrict__ dgh, float* __restrict__ dhz) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)n * H) return;
+    const int e = (int)(i / H), j = (int)(i - (size_t)e * H);
+    const float* a = gi + (size_t)e * 3 * H; const float* b = gh + (size_t)e * 3 * H;
+    const float ghn = b[2 * H + j];
+    const float r = sigmoidf_(a[j] + b[j]), z = sigmoidf_(a[H + j] + b[H + j]), nn = tanhf(a[2 * H + j] + r * ghn);
+    float dh = dh_out ? dh_out[i] : 0.f;
+    if (carry) dh += carry[i] * (carry_keep ? carry_keep[e] : 1.0f);
+    const float dn = dh * (1.0f - z), dz = dh * (hm_prev[i] - nn);
+    const float dan = dn * (1.0f - nn * nn);           // d(gi_n)
+    const float dr = dan * ghn;
+    const float dar = dr * r * (1.0f - r), daz = dz * z * (1.0f - z);
+    float* gi_o = dgi + (size_t)e * 3 * H; float* gh_o = dgh + (size_t)e * 3 * H;
+    gi_o[j] = dar; gi_o[H + j] = daz; gi_o[2 * H + j] = dan;
+    gh_o[j] = dar; gh_o[H + j] = daz; gh_o[2 * H + j] = dan * r;
+    dhz[i] = dh * z;
+}
+
 }  // namespace kp

@@ -643,6 +643,22 @@ int kp_gae(int n, int T, const float* rewards, const float* masks, const float* 
     return kp_gae_bootstrap(n, T, rewards, masks, values, nullptr, gamma, tau, adv, ret, stream);
 }
 
+int kp_gru_gates_forward(int n, int H, const float* gi, const float* gh, const float* hm_prev, const float* next_keep, float* h_out, float* hm_next, void* stream) {
+    if (n <= 0 || H <= 0 || !gi || !gh || !hm_prev || !h_out) return fail("kp_gru_gates_forward: bad arguments");
+    const size_t tot = (size_t)n * H;
+    hipLaunchKernelGGL(kp::k_gru_gates_fwd, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, H, gi, gh, hm_prev, next_keep, h_out, hm_next);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+int kp_gru_gates_backward(int n, int H, const float* gi, const float* gh, const float* hm_prev, const float* dh_out, const float* carry, const float* carry_keep,
+                          float* dgi, float* dgh, float* dhz, void* stream) {
+    if (n <= 0 || H <= 0 || !gi || !gh || !hm_prev || !dgi || !dgh || !dhz) return fail("kp_gru_gates_backward: bad arguments");
+    const size_t tot = (size_t)n * H;
+    hipLaunchKernelGGL(kp::k_gru_gates_bwd, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, H, gi, gh, hm_prev, dh_out, carry, carry_keep, dgi, dgh, dhz);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
 int kp_sim_set_full_state(kp_sim* s, const float* qpos, const float* qvel, const float* qpos_d, const float* qvel_d, const uint8_t* mask) {
     if (!s || !qpos || !qvel || !qpos_d || !qvel_d) return fail("kp_sim_set_full_state: null argument");
     HIP_OK(hipSetDevice(s->device));

@@ -173,7 +173,19 @@ class KinPolicy(nn.Module):
         """Training-time forward over an env-major rollout [N, T, state_dim]: re-runs the GRU through time,
         zeroing the hidden state where `episode_start[n, t]` (what initialize_rnn + the padded [T_max,
         n_episodes] re-pack do in the reference, policy_ar.py:104-122,216-234).  hx0 [N, H]: hidden state the behaviour
-        policy held before row 0 (episodes that continue from the previous sample() call; default zeros).  Returns means [N, T, A]."""
+        policy held before row 0 (episodes that continue from the previous sample() call; default zeros).  Returns means [N, T, A].
+        On the device the recurrence is the fused node of kinpoly_amd/gru_unroll.py (HIP gate kernels + one GEMM per step, weight
+        gradients as one GEMM) and the MLP runs once over all N * T rows; on the CPU (fp64 fixtures) it is the plain GRUCell loop."""
+        if not (states.is_cuda and states.dtype == torch.float32):
+            return self.unroll_reference(states, episode_start, hx0)
+        from .gru_unroll import gru_unroll
+        N, T, _ = states.shape
+        h = gru_unroll(self.action_rnn.rnn_f, states, episode_start, hx0)                      # [N, T, H]
+        x = torch.cat((states, h), dim=2).reshape(N * T, -1)
+        return self.action_fc(self.action_mlp(x)).view(N, T, -1)
+
+    def unroll_reference(self, states, episode_start, hx0=None):
+        """The same computation as a Python loop of T GRUCell + MLP steps (the shape of the reference's own loop; parity baseline)."""
         N, T, _ = states.shape
         hx = self.init_hidden(N, states.device) if hx0 is None else hx0.to(states.dtype)
         outs = []

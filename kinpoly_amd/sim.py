@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "kp_sim_step_begin", "kp_sim_obs_ar", "kp_sim_term_reward", "kp_gae", "kp_sim_set_full_state", "kp_sim_fk",
     "kp_sim_timing_reset", "kp_sim_timing_mean_seconds", "kp_sim_phase_cycles", "kp_sim_set_objects", "kp_sim_set_obj_state",
     "kp_sim_launch_cost", "kp_job_schedule", "kp_sim_fk_backward", "kp_sim_set_stream", "kp_sim_status_device", "kp_sim_mass_matrix",
-    "kp_sim_contacts", "kp_gae_bootstrap",
+    "kp_sim_contacts", "kp_gae_bootstrap", "kp_gru_gates_forward", "kp_gru_gates_backward",
 ]
 
 
@@ -91,6 +91,8 @@ def load_library(path: str | None = None):
     L.kp_sim_term_reward.argtypes = [P, C.POINTER(KpCtx), C.POINTER(KpRewardCfg), F, F, U8, F]; L.kp_sim_term_reward.restype = C.c_int
     L.kp_gae.argtypes = [C.c_int, C.c_int, F, F, F, C.c_float, C.c_float, F, F, C.c_void_p]; L.kp_gae.restype = C.c_int
     L.kp_gae_bootstrap.argtypes = [C.c_int, C.c_int, F, F, F, F, C.c_float, C.c_float, F, F, C.c_void_p]; L.kp_gae_bootstrap.restype = C.c_int
+    L.kp_gru_gates_forward.argtypes = [C.c_int, C.c_int, F, F, F, F, F, F, C.c_void_p]; L.kp_gru_gates_forward.restype = C.c_int
+    L.kp_gru_gates_backward.argtypes = [C.c_int, C.c_int, F, F, F, F, F, F, F, F, F, C.c_void_p]; L.kp_gru_gates_backward.restype = C.c_int
     L.kp_sim_set_full_state.argtypes = [P, F, F, F, F, U8]; L.kp_sim_set_full_state.restype = C.c_int
     L.kp_sim_timing_reset.argtypes = [P]; L.kp_sim_timing_reset.restype = C.c_int
     L.kp_sim_timing_mean_seconds.argtypes = [P, C.POINTER(C.c_int)]; L.kp_sim_timing_mean_seconds.restype = C.c_double

@@ -272,3 +272,58 @@ def test_floor_contacts_follow_the_hull_graph_rule(kp):
         np.testing.assert_allclose(h["dist"], c["dist"], atol=2e-6)
         np.testing.assert_allclose(h["pos"], c["pos"], atol=2e-6)
     assert max(len(h["body"]) for h in hip) >= 16
+
+
+def test_fused_gru_unroll_matches_gru_cell_loop_forward_and_backward(kp):
+    """the fused recurrence (kinpoly_amd/gru_unroll.py: HIP gate kernels, one recurrent GEMM per step, weight gradients as
+    one GEMM) vs torch.nn.GRUCell stepped in a Python loop: hidden states and the gradients of W_ih, W_hh, b_ih, b_hh and hx0 under a
+    smooth loss, with mid-batch episode starts.  (The MLP on top is the same torch module on both paths; its relu makes parameter
+    gradients jump with 1-ulp changes of its input, so the recurrence is compared on its own.)"""
+    from kinpoly_amd.gru_unroll import gru_unroll
+    from kinpoly_amd.nets import KinPolicy
+    torch.manual_seed(3)
+    pol = KinPolicy().cuda()
+    cell = pol.action_rnn.rnn_f
+    N, T = 48, 9
+    states = torch.randn((N, T, 105), device="cuda") * 0.5
+    starts = torch.rand((N, T), device="cuda") < 0.25
+    starts[:, 0] = torch.rand(N, device="cuda") < 0.5
+    hx0 = (torch.randn((N, 1024), device="cuda") * 0.3).requires_grad_(True)
+    w = torch.randn((N, T, 1024), device="cuda")
+
+    def loop():
+        hx, outs = hx0, []
+        for t in range(T):
+            hx = cell(states[:, t], hx * (~starts[:, t]).float().unsqueeze(1))
+            outs.append(hx)
+        return torch.stack(outs, 1)
+    res = []
+    for fn in (lambda: gru_unroll(cell, states, starts, hx0), loop):
+        for p in cell.parameters():
+            p.grad = None
+        hx0.grad = None
+        h = fn()
+        (h * w).sum().backward()
+        res.append((h.detach().clone(), [p.grad.detach().clone() for p in cell.parameters()] + [hx0.grad.detach().clone()]))
+    assert float((res[0][0] - res[1][0]).abs().max()) < 1e-6
+    for a, b in zip(res[0][1], res[1][1]):
+        assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max())), (tuple(a.shape), float((a - b).abs().max()), float(b.abs().max()))
+    # the whole policy head on top: same means as the per-step loop, and episode starts cut the recurrence
+    with torch.no_grad():
+        m_f, m_l = pol.unroll(states, starts, hx0.detach()), pol.unroll_reference(states, starts, hx0.detach())
+        m_z = pol.unroll(states, starts, torch.zeros_like(hx0))
+    assert float((m_f - m_l).abs().max()) < 2e-5
+    cut = starts[:, 0]
+    assert torch.equal(m_f[cut], m_z[cut]) and not torch.allclose(m_f[~cut], m_z[~cut])
+
+
+def test_fused_unroll_matches_reference_padded_forward_fp32(kp, golden):
+    from tests.test_context_cpu import _net_from_fixture
+    g, gt = golden("unroll"), golden("traj_ar_net")
+    net = _net_from_fixture(gt, torch.float32).cuda()
+    masks = g["masks"]
+    N, T = 2, 7
+    starts = np.concatenate([[True], masks[:-1] == 0]).reshape(N, T); starts[:, 0] = True
+    with torch.no_grad():
+        means = net.unroll(dev(g["states"]).view(N, T, -1), torch.tensor(starts, device="cuda"))
+    np.testing.assert_allclose(means.reshape(N * T, -1).double().cpu().numpy(), g["action_mean"], atol=3e-4)
