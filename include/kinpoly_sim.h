@@ -47,7 +47,8 @@ void kp_model_free(kp_model*);
  * scheduling only (results do not depend on them): "substeps_per_job" (default 3; 0 = one workgroup per env and control step):
  * with more envs than resident wavefront slots a control step is cut into jobs of that many substeps (the last job; with "job_taper"
  * = 1, the default, each earlier job is two substeps longer: 15 = 7 + 5 + 3) which resident waves pull from a FIFO, so that the
- * launch does not end on the tail of its longest envs; "queue_slots" (0 = CUs x 8, x 6 with objects);
+ * launch does not end on the tail of its longest envs; "queue_slots" (0 = CUs x 8, x 6 with objects); "queue_fence" (0/1, default 1: the job hand-over is an agent-scope
+ * release / acquire fence pair around relaxed write-through accesses, correct by the HIP memory model; 0 = without the fences, +0.5 %);
  * "lpt_order" (0/1, default 0: longest-env-first workgroup order for the plain launch). */
 int kp_model_set_option(kp_model*, const char* name, double value);
 double kp_model_get_option(const kp_model*, const char* name);

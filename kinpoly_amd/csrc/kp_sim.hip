@@ -24,7 +24,7 @@ int fail(const std::string& m) { g_err = m; return -1; }
 
 struct kp_model {
     kp::HostModel h;
-    int contact = 1, limits = 1, stale = 1, solver_iter = 100, threads = 64, dynamic_objects = 1, lpt_order = 0, substeps_per_job = 3, queue_slots = 0, job_taper = 1;
+    int contact = 1, limits = 1, stale = 1, solver_iter = 100, threads = 64, dynamic_objects = 1, lpt_order = 0, substeps_per_job = 3, queue_slots = 0, job_taper = 1, queue_fence = 1;
     double solver_tol = 1e-8, gravity_z = -9.81;   // solver_iter / solver_tol: mjOption.iterations / tolerance of the reference model (kp_model_load)
 };
 
@@ -231,7 +231,7 @@ int launch_step(kp_sim* s, const float* action, int nsub, const uint8_t* mask, b
         }
     }
     const bool queue = nsub > 0 && parts > 1 && s->model->threads == 64 && s->n > slots && s->n <= 0xFFFFFF && !s->prof && !A.order;   // env ids take 24 bits of a queue entry
-    A.jobq = s->jobq; A.jobctr = s->jobctr; A.n_parts = queue ? parts : 1;
+    A.jobq = s->jobq; A.jobctr = s->jobctr; A.n_parts = queue ? parts : 1; A.queue_fence = s->model->queue_fence;
     A.part_sub_lo = A.part_sub_hi = 0;
     for (int k = 0; queue && k < parts; k++) (k < 8 ? A.part_sub_lo : A.part_sub_hi) |= (unsigned long long)(sizes[k] & 255) << (8 * (k & 7));
     if (queue) {
@@ -289,6 +289,7 @@ int kp_model_set_option(kp_model* m, const char* name, double v) {
     else if (k == "dynamic_objects") m->dynamic_objects = v != 0;
     else if (k == "lpt_order") m->lpt_order = v != 0;
     else if (k == "job_taper") m->job_taper = v != 0;
+    else if (k == "queue_fence") m->queue_fence = v != 0;
     else if (k == "queue_slots") { if (v < 0) return fail("queue_slots must be >= 0 (0 = resident wave slots of the device)"); m->queue_slots = (int)v; }
     else if (k == "substeps_per_job") { if (v < 0 || v > 255) return fail("substeps_per_job must be 0 (whole control step per workgroup) .. 255"); m->substeps_per_job = (int)v; }
     else if (k == "threads_per_env") { if (v != 64 && v != 128 && v != 256) return fail("threads_per_env must be 64, 128 or 256"); m->threads = (int)v; }
@@ -309,6 +310,7 @@ double kp_model_get_option(const kp_model* m, const char* name) {
     if (k == "substeps_per_job") return m->substeps_per_job;
     if (k == "queue_slots") return m->queue_slots;
     if (k == "job_taper") return m->job_taper;
+    if (k == "queue_fence") return m->queue_fence;
     if (k == "threads_per_env") return m->threads;
     if (k == "timestep") return m->h.opt[kp::OPT_TIMESTEP];
     if (k == "lds_bytes_per_env") return (double)sizeof(kp::EnvLds);

@@ -60,6 +60,7 @@ struct StepArgs {
     unsigned* jobq;
     unsigned* jobctr;
     int n_parts;
+    int queue_fence;           // 1: the hand-over is a release (publish) / acquire (consume) pair at agent scope instead of relaxed sc1 accesses + s_waitcnt
     unsigned long long part_sub_lo, part_sub_hi;   // substeps of job 0 .. 15, one byte each (sum = n_substeps); packed so that no lookup indexes the kernel argument
 };
 
@@ -1800,6 +1801,15 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 2 : 1)) void kp_forward_kernel(Step
 // that of kp_step_kernel bit for bit.  Progress: indices are claimed in order, so a wave that waits for entry idx waits for a publish by
 // a wave that is running a job; if nothing is running every entry below n_envs * n_parts has been published.  A bounded spin turns
 // any violation of that argument into an error flag (jobctr[2]) instead of a hung queue.
+// Memory ordering of the hand-over, two variants (model option "queue_fence"):
+//   1 (default)  the state arrays a later job reads are written / read as relaxed agent-scope atomics (sc1 write-through accesses), and the
+//                publish is bracketed by __builtin_amdgcn_fence(release, agent) on the producing wave and fence(acquire, agent) after the
+//                consuming load: a release / acquire pair, correct by the HIP memory model.
+//   0            the round-1 form without the two fences: s_waitcnt vmcnt(0) alone orders the sc1 stores before the publish.  Correct on
+//                gfx950 by what sc1 means in hardware only.
+// Both are bit-identical in results (test_job_queue_schedule_is_bit_identical).  Measured on MI355X, 4096 envs standing + contact
+// (tools/queue_fence_bench.py, profiles/r02/queue_fence_bench.log): 3.818 ms (0) vs 3.837 ms (1) per launch -- the fences cost 0.5 %, so
+// the variant that is correct by construction is the default.
 template <bool OBJ>
 __global__ __launch_bounds__(64, 2) void kp_step_queue_kernel(StepArgs A) {
     const unsigned total = (unsigned)A.n_envs * (unsigned)A.n_parts;
@@ -1814,10 +1824,12 @@ __global__ __launch_bounds__(64, 2) void kp_step_queue_kernel(StepArgs A) {
             if (++spins > (1u << 21)) { if (threadIdx.x == 0) atomicExch(&A.jobctr[2], 1u); return; }
         }
         asm volatile("" ::: "memory");                        // the job's (sc1) state loads stay behind the load that saw the entry
+        if (A.queue_fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // memory-model variant: acquire side of the publish below
         e = (unsigned)__builtin_amdgcn_readfirstlane((int)e);
         const int env = (int)(e & 0xFFFFFFu), part = (int)(e >> 24);
         step_body<64, OBJ, false, true>(A, env, part);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // every lane's write-through state store has been acknowledged ...
+        if (A.queue_fence) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // memory-model variant: release all of this wave's stores at agent scope
         if (part + 1 < A.n_parts && threadIdx.x == 0) {                // ... before the env's next job becomes visible
             const unsigned pos = atomicAdd(&A.jobctr[1], 1u);
             __hip_atomic_store(&A.jobq[pos], (unsigned)env | ((unsigned)(part + 1) << 24), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -225,10 +225,10 @@ def test_job_queue_schedule_is_bit_identical(kp):
     qpos, qvel = make_states(n, 41, lift=0.0, vel=0.5, noise=0.2)
     act = np.random.default_rng(42).normal(size=(n, 75)) * 0.2
     ref, dref = _run_sched(kp, kp.KpModel(substeps_per_job=0), n, qpos, qvel, act)
-    for spj, slots in ((5, 48), (4, 7), (1, 48)):
-        got, dg = _run_sched(kp, kp.KpModel(substeps_per_job=spj, queue_slots=slots), n, qpos, qvel, act)
+    for spj, slots, fence in ((5, 48, 0), (4, 7, 0), (1, 48, 0), (5, 48, 1)):     # fence = 1: the release / acquire variant of the hand-over
+        got, dg = _run_sched(kp, kp.KpModel(substeps_per_job=spj, queue_slots=slots, queue_fence=fence), n, qpos, qvel, act)
         for a_, b_ in zip(ref, got):
-            assert (a_ == b_).all(), f"substeps_per_job={spj} slots={slots}"
+            assert (a_ == b_).all(), f"substeps_per_job={spj} slots={slots} queue_fence={fence}"
         assert (dref == dg).all()
     mask = (np.arange(n) % 3 != 1).astype(np.uint8)             # masked envs still pass through the queue (their jobs are empty)
     refm, drefm = _run_sched(kp, kp.KpModel(substeps_per_job=0), n, qpos, qvel, act, mask=mask)
