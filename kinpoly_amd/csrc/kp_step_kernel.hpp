@@ -636,17 +636,19 @@ __device__ __forceinline__ void collide(EnvLds& s, const DevTables& T, const Par
                     if (dmin > P.margin) continue;
                     const int idx = __builtin_amdgcn_readfirstlane(__ffsll((long long)__ballot(xw.z == dmin)) - 1);
                     const int n0 = T.vert_nbr_adr[vadr + idx], n1 = T.vert_nbr_adr[vadr + idx + 1];
-                    int cnt = 0;
-                    for (int k = -1; k < n1 - n0 && cnt < D_CON_PER_GEOM; k++) {
-                        const int j = k < 0 ? idx : (int)T.vert_nbr[n0 + k];
-                        const float zj = bcast_lane(xw.z, j);
-                        if (k >= 0 && zj > P.margin) continue;
-                        if (ncon < D_MAXCON) {
-                            if (tid == j) put_contact<OBJ>(s, ncon, v3(xw.x, xw.y, xw.z - 0.5f * xw.z), xw.z, v3(0.f, 0.f, 1.f), b, -1, 0.f);
-                            ncon++;
-                        }
-                        cnt++;
-                    }
+                    // lane k < deg takes neighbour k of the support vertex (one coalesced load of the list), fetches that vertex from the
+                    // lane that holds it, and ranks itself among the qualifying neighbours in list order with a ballot
+                    const int deg = n1 - n0;
+                    const int j = tid < deg ? (int)T.vert_nbr[n0 + tid] : 0;
+                    const V3 xj = v3(__shfl(xw.x, j, 64), __shfl(xw.y, j, 64), __shfl(xw.z, j, 64));
+                    const bool ok = tid < deg && !(xj.z > P.margin);
+                    const unsigned long long m = __ballot(ok);
+                    const int rank = __popcll(m & ((1ull << tid) - 1ull));
+                    const int cnt = 1 + min(__popcll(m), D_CON_PER_GEOM - 1);
+                    const int room = D_MAXCON - ncon;
+                    if (tid == idx && room > 0) put_contact<OBJ>(s, ncon, v3(xw.x, xw.y, xw.z - 0.5f * xw.z), xw.z, v3(0.f, 0.f, 1.f), b, -1, 0.f);
+                    if (ok && rank < D_CON_PER_GEOM - 1 && 1 + rank < room) put_contact<OBJ>(s, ncon + 1 + rank, v3(xj.x, xj.y, xj.z - 0.5f * xj.z), xj.z, v3(0.f, 0.f, 1.f), b, -1, 0.f);
+                    ncon += min(cnt, max(room, 0));
                 } else if constexpr (OBJ) {
                     // mjc_Convex (libccd MPR): geom 1 = the box / cylinder, geom 2 = the hull; one contact, normal into the hull
                     EnvLdsObj& so = static_cast<EnvLdsObj&>(s);
