@@ -1,0 +1,72 @@
+/* kinpoly_kpm.h -- the compiled-model blob ("KPM1") kp_model_load() reads: format specification.
+ *
+ * The reference hands MuJoCo an XML (mujoco_py.load_model_from_path, uhc/khrylib/rl/envs/common/mujoco_env.py:23) and libmujoco
+ * compiles it.  This engine's compiler is kinpoly_amd/model_compiler.py (XML + binary STL hulls + config/uhc/uhc.yml -> blob); a host
+ * in another language can either run that module once at build time or write the blob itself from this description -- the loader
+ * (kinpoly_amd/csrc/kp_model.hpp) and the oracle's loader (oracle/kp_oracle.c) depend on nothing else.
+ *
+ * Layout (little endian):
+ *     u32 magic = 0x314D504B ('KPM1') | u32 version (6) | u32 n_entries | kpm_entry[n_entries] | payload
+ *     payload arrays are 8-byte aligned; an entry's `off` is the byte offset from the start of the file.
+ */
+#ifndef KINPOLY_KPM_H
+#define KINPOLY_KPM_H
+#include <stdint.h>
+
+#define KPM_MAGIC 0x314D504Bu
+#define KPM_VERSION 6u
+
+typedef struct {
+    char name[32];      /* zero padded */
+    uint32_t dtype;     /* 0 = float64, 1 = int32 */
+    uint32_t pad;
+    uint64_t count;     /* number of elements */
+    uint64_t off;       /* byte offset of the array */
+} kpm_entry;            /* 56 bytes */
+
+/* Entries (nb = 24 bodies, nv = 75 dofs, nu = 69 hinges; all arrays row-major; lengths in elements).
+ *
+ *  name             type  length    meaning
+ *  dims             i32   9         nb, nv, nq, nu, nM (= 1221, length of MuJoCo's sparse qM), nvert, n_objects, n_object_geoms, condim
+ *  body_parent      i32   nb        parent body (-1 for the pelvis); bodies are in depth-first order (subtree of b = [b, b + body_subtree[b]))
+ *  body_depth       i32   nb        tree level (0 .. 8)
+ *  body_subtree     i32   nb        number of bodies in the subtree rooted at b (itself included)
+ *  body_pos         f64   3 nb      origin of the body frame in the parent frame (all rest orientations are identity)
+ *  body_ipos        f64   3 nb      centre of mass in the body frame
+ *  body_mass        f64   nb        kg (mesh volume x 1000 kg/m^3, MuJoCo's default density)
+ *  body_inertia     f64   6 nb      inertia about the COM in body axes: xx yy zz xy xz yz
+ *  body_gpos0       f64   3 nb      body origins at qpos0 in the world frame (the XML's coordinate="global" positions)
+ *  body_rbound      f64   nb        bounding-sphere radius of the hull about the body origin (mid phase)
+ *  body_diffw       f64   nb        env.jpos_diffw (ones; kin_poly/envs/humanoid_ar_v1.py:59)
+ *  uhc_b_diffw      f64   nb        cfg.b_diffw of the UHC reward (uhc.yml body_params)
+ *  body_invweight0  f64   2 nb      mjModel.body_invweight0 (translational, rotational) at qpos0: contact impedance scaling
+ *  dof_invweight0   f64   nv        mjModel.dof_invweight0: joint-limit impedance scaling
+ *  dof_body         i32   nv        body each dof belongs to: dofs 0..5 the free root (3 world translations, 3 body-axis rotations),
+ *                                   then three hinges per body in the order z, y, x
+ *  dof_parent       i32   nv        previous dof on the path to the root (-1), MuJoCo's dof_parentid
+ *  dof_depth        i32   nv        number of ancestors of the dof
+ *  dof_madr         i32   nv + 1    start of dof i's row in the sparse qM (row i holds i and its ancestors)
+ *  dof_armature     f64   nv        joint armature (0 on the root, 0.01 on hinges; XML :12, :49)
+ *  jnt_range        f64   2 nu      hinge limits in radians (lo, hi)
+ *  jnt_limited      i32   nu        1 if the limit is active
+ *  vert_adr         i32   nb + 1    first hull vertex of every body in `verts`
+ *  verts            f64   3 nvert   convex-hull vertices in the body frame (<= 64 per body)
+ *  vert_nbr_adr     i32   nvert + 1 hull graph: the neighbours of (global) vertex v are vert_nbr[vert_nbr_adr[v] .. vert_nbr_adr[v + 1])
+ *  vert_nbr         i32   *         neighbour lists, hull-LOCAL vertex ids, in qhull facet order (MuJoCo's mesh_graph; used by mjc_PlaneConvex)
+ *  kp, kd           f64   nu        stable-PD gains (uhc.yml joint_params columns 1, 2)
+ *  torque_lim       f64   nu        torque clamp (column 5)
+ *  a_scale          f64   nu        action scale (column 4)
+ *  opt              f64   26        timestep, gravity[3], solref[2], solimp[5], friction[3] (slide, spin, roll), margin, impratio, meaninertia,
+ *                                   residual_force_scale, residual_force_lim, base_rot[4] (w x y z), solver iterations, solver tolerance,
+ *                                   nv of the whole reference scene (humanoid + 5 free objects = 105: Newton termination scale)
+ *  obj_geoms        f64   18 ng     collision geoms of the free objects (chair, box, table, Can, step): object id, type (0 box, 1 cylinder),
+ *                                   size[3] (half sizes | radius, half height, 0), pos[3] and rotation[9] in the object's body frame, mass
+ *  obj_geom_adr     i32   nobj + 1  first geom of every object
+ *  obj_mass         f64   nobj      total mass
+ *  obj_inertial     f64   13 nobj   mass, COM[3], inertia about the COM in body axes (xx yy zz xy xz yz), invweight0 (translational,
+ *                                   rotational), free-joint armature
+ *  M0               f64   nv nv     dense joint-space inertia at qpos0 (diagnostic; not read by the simulator)
+ *
+ * Unknown entries are ignored; a blob without `vert_nbr_adr` / `vert_nbr` (version < 6) is rejected.
+ */
+#endif
