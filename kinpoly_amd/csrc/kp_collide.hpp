@@ -49,10 +49,18 @@ __device__ __forceinline__ D3 mulmat(const double* m, D3 v) {
     return D3{m[0] * v.x + m[1] * v.y + m[2] * v.z, m[3] * v.x + m[4] * v.y + m[5] * v.z, m[6] * v.x + m[7] * v.y + m[8] * v.z};
 }
 __device__ __forceinline__ float bcast_lane(float v, int lane) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane)); }
-__device__ __forceinline__ double wave_max_d(double v) {             // butterfly over the 64 lanes (every lane gets the maximum)
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) v = fmax(v, __shfl_xor(v, m, 64));
-    return v;
+#define KP_DPP64(v, CTRL) ([&]() { const unsigned long long u_ = __builtin_bit_cast(unsigned long long, (v)); \
+    const int lo_ = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u_, CTRL, 0xF, 0xF, true), hi_ = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u_ >> 32), CTRL, 0xF, 0xF, true); \
+    return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi_ << 32) | (unsigned long long)(unsigned)lo_); }())
+__device__ __forceinline__ double readlane_d(double v, int lane) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, lane), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), lane);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+// wave-wide fp64 maximum without LDS traffic: xor butterflies inside each 16-lane row with DPP, the four row maxima meet through v_readlane
+__device__ __forceinline__ double wave_max_d(double v) {
+    v = fmax(v, KP_DPP64(v, 0xB1)); v = fmax(v, KP_DPP64(v, 0x4E)); v = fmax(v, KP_DPP64(v, 0x141)); v = fmax(v, KP_DPP64(v, 0x140));
+    return fmax(fmax(readlane_d(v, 0), readlane_d(v, 16)), fmax(readlane_d(v, 32), readlane_d(v, 48)));
 }
 
 // ---- support functions (mjccd_support): farthest point along the unit world direction dir, inflated by margin along dir
@@ -76,18 +84,18 @@ struct GeomSupport {                 // box (type 0) / z-axis cylinder (type 1);
         return center() + mulmat(R, p) + margin * dir;
     }
 };
-struct HullSupport {                 // lane v < nv holds body-frame vertex v of the hull; exhaustive arg-max, first maximum
-    D3 xb, com, vert; double R[9]; bool has;
-    __device__ __forceinline__ HullSupport(V3 xb_, const float* R_, V3 com_, V3 vert_, bool has_) : xb(d3(xb_)), com(d3(com_)), vert(d3(vert_)), has(has_) {
+struct HullSupport {                 // lane v < nv holds body-frame vertex v of the hull (fp32 model data); exhaustive arg-max in fp64, first maximum
+    D3 xb, com; V3 vert; double R[9]; bool has;
+    __device__ __forceinline__ HullSupport(V3 xb_, const float* R_, V3 com_, V3 vert_, bool has_) : xb(d3(xb_)), com(d3(com_)), vert(vert_), has(has_) {
         for (int k = 0; k < 9; k++) R[k] = R_[k];
     }
     __device__ __forceinline__ D3 center() const { return com; }
     __device__ __forceinline__ D3 operator()(D3 dir, double margin) const {
         const D3 l = mulmat_t(R, dir);
-        const double d = has ? dot(l, vert) : -1.0e300;
+        const double d = has ? dot(l, d3(vert)) : -1.0e300;
         const double dmax = wave_max_d(d);
         const int idx = __builtin_amdgcn_readfirstlane(__ffsll((long long)__ballot(d == dmax)) - 1);
-        const D3 p = d3(__shfl(vert.x, idx, 64), __shfl(vert.y, idx, 64), __shfl(vert.z, idx, 64));
+        const D3 p = d3((double)bcast_lane(vert.x, idx), (double)bcast_lane(vert.y, idx), (double)bcast_lane(vert.z, idx));
         return xb + mulmat(R, p) + margin * dir;
     }
 };
@@ -133,7 +141,7 @@ __device__ __forceinline__ double pt_tri_dist2(D3 x0, D3 B, D3 C, D3& w) {    //
 }
 // 0 = the inflated shapes intersect: depth, dir (from shape A towards shape B), pos.  -1 = no intersection.
 template <class SA, class SB>
-__device__ __noinline__ int mpr(const SA& A, const SB& B, double margin, double& depth, D3& dir_out, D3& pos) {
+__device__ __forceinline__ int mpr(const SA& A, const SB& B, double margin, double& depth, D3& dir_out, D3& pos) {
     Sup p0, p1, p2, p3, v4;
     p0.v1 = A.center(); p0.v2 = B.center(); p0.v = p0.v1 - p0.v2;
     if (c_eq(p0.v.x, 0.0) && c_eq(p0.v.y, 0.0) && c_eq(p0.v.z, 0.0)) p0.v.x += C_EPS * 10.0;

@@ -577,6 +577,20 @@ __device__ __forceinline__ void spd_torque_rfc(EnvLds& s, const DevTables& T, co
 }
 
 // ---------------------------------------------------------------- collision (first wavefront)
+// signed distance of world point x to a box (type 0) / z-axis cylinder (type 1) geom record
+__device__ __forceinline__ float geom_sdf(const float* g, V3 x) {
+    const float* R = g + 7;
+    const V3 r = x - ld3(g + 4);
+    const V3 l = v3(R[0] * r.x + R[3] * r.y + R[6] * r.z, R[1] * r.x + R[4] * r.y + R[7] * r.z, R[2] * r.x + R[5] * r.y + R[8] * r.z);
+    if (g[0] == 0.f) {
+        const V3 q = v3(fabsf(l.x) - g[1], fabsf(l.y) - g[2], fabsf(l.z) - g[3]);
+        const V3 o = v3(fmaxf(q.x, 0.f), fmaxf(q.y, 0.f), fmaxf(q.z, 0.f));
+        return sqrtf(dot(o, o)) + fminf(fmaxf(q.x, fmaxf(q.y, q.z)), 0.f);
+    }
+    const float qr = sqrtf(l.x * l.x + l.y * l.y) - g[1], qz = fabsf(l.z) - g[2];
+    const float orr = fmaxf(qr, 0.f), oz = fmaxf(qz, 0.f);
+    return sqrtf(orr * orr + oz * oz) + fminf(fmaxf(qr, qz), 0.f);
+}
 __device__ __forceinline__ float geom_rbound(const float* g) { return g[0] == 0.f ? sqrtf(g[1] * g[1] + g[2] * g[2] + g[3] * g[3]) : sqrtf(g[1] * g[1] + g[2] * g[2]); }
 
 // one lane appends a contact: vertex-side entity A (0..23 hull, 24 + k object slot), surface-side entity B (-1 world / static geom),
@@ -609,6 +623,10 @@ __device__ __forceinline__ void collide(EnvLds& s, const DevTables& T, const Par
                     const float* g = static_cast<EnvLdsObj&>(s).geom + 17 * gi;
                     const V3 dx = xb - ld3(g + 4);
                     if (sqrtf(dot(dx, dx)) - rb - geom_rbound(g) > P.margin) continue;
+                    // second, exact-safe cull: the hull lies inside the sphere (body origin, rbound) and a signed distance is 1-Lipschitz, so
+                    // no point of it is closer to the primitive than sdf(origin) - rbound; only pairs that cannot touch are dropped (the
+                    // 0.1 mm slack keeps fp32 rounding of this test away from the margin).  Saves the MPR query for most near misses.
+                    if (geom_sdf(g, xb) - rb > P.margin + 1e-4f) continue;
                     mybits |= 2u << gi;
                 }
             }
