@@ -33,7 +33,7 @@ class AgentAR:
     def __init__(self, n_envs, context_fn=None, device=0, horizon=99, seed=4, wild=False, use_init_context=True,
                  policy_lr=1e-5, value_lr=3e-4, supervised_lr=5e-4, num_optim_epoch=10, num_step_update=20, gamma=0.95, tau=0.95,
                  clip_epsilon=0.2, rl_update=True, step_update=True, model_options=None, dataset=None, sampling_temp=0.3, sampling_freq=0.5,
-                 pool_depth=2, num_epoch_fix=100, num_epoch=10000, joint_controller=False):
+                 pool_depth=2, num_epoch_fix=100, num_epoch=10000, joint_controller=False, grad_joint=False, grad_alternate=False):
         rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
         enable_tuned_gemms()          # library GEMM solution per shape (rollout and update shapes at 4096 envs); selection only
         torch.manual_seed(seed + rank)
@@ -50,6 +50,7 @@ class AgentAR:
                                     ctx_builder=self.ctx_builder if use_init_context else None,
                                     sampling_temp=sampling_temp, sampling_freq=sampling_freq, fix_height=False)
         self.horizon, self.rl_update, self.step_update, self.num_step_update = horizon, rl_update, step_update, num_step_update
+        self.grad_joint, self.grad_alternate = grad_joint, grad_alternate       # policy_specs.grad_joint / grad_alternate (agent_ar.py:703, 746-747)
         self.trainer = PPOTrainer(self.policy_net, self.value_net, gamma, tau, clip_epsilon, policy_lr, value_lr, num_optim_epoch,
                                   num_epoch_fix=num_epoch_fix, num_epoch=num_epoch, cc_policy=self.env.cc_policy if joint_controller else None)
         self.opt_sup = torch.optim.Adam([p for p in self.policy_net.parameters() if p.requires_grad], lr=supervised_lr)
@@ -77,10 +78,13 @@ class AgentAR:
         torch.cuda.synchronize(self.device)
         t1 = time.time()
         info = {}
-        if self.rl_update:
-            info.update(self.trainer.update(batch))
-        if self.step_update:
-            info["step_loss"] = update_supervised_step(self.policy_net, self.opt_sup, self.fk, batch, self.num_step_update, _allreduce_grads)
+        if self.grad_joint:               # update_params' other branch (agent_ar.py:746-747): surrogate + supervised loss in one step
+            info.update(self.trainer.update_joint(batch, self.fk, self.grad_alternate, self.epoch, self.opt_sup))
+        else:
+            if self.rl_update:
+                info.update(self.trainer.update(batch))
+            if self.step_update:
+                info["step_loss"] = update_supervised_step(self.policy_net, self.opt_sup, self.fk, batch, self.num_step_update, _allreduce_grads)
         self.sched_sup.step()
         torch.cuda.synchronize(self.device)
         t2 = time.time()

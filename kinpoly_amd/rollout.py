@@ -322,6 +322,45 @@ class PPOTrainer:
             stats["cc_surr_loss"] = self.update_controller(batch, adv, ind)
         return stats
 
+    def update_joint(self, batch: RolloutBatch, fk, grad_alternate: bool = False, epoch: int = 0, sup_optimizer=None, bootstrap: bool = True):
+        """AgentAR.update_policy_joint (agent_ar.py:796-850; `grad_joint` runs): per epoch one value step, then the PPO surrogate and the
+        supervised one-step loss (TrajARNet.step on the mean action + compute_loss_lite against the GT next pose) in ONE policy step,
+        loss = 10 * loss_step + surr; with `grad_alternate` odd epochs take the surrogate step and even epochs the supervised step (on
+        `sup_optimizer`, the reference's policy_net.optimizer).  fk: kinpoly_amd.supervised.TorchFK."""
+        from .supervised import compute_loss_lite, kinematic_step
+        assert batch.curr_qpos is not None and batch.gt_target_qpos is not None, "sample with record_qpos=True"
+        N, T, _ = batch.states.shape
+        flat_states = batch.states.reshape(N * T, -1)
+        curr, tgt = batch.curr_qpos.reshape(N * T, 76), batch.gt_target_qpos.reshape(N * T, 76)
+        with torch.no_grad():
+            values = self.value(flat_states).view(N, T)
+            last_v = self.value(batch.last_states).view(N) if (bootstrap and batch.last_states is not None) else None
+            means = self.policy.unroll(batch.states, batch.episode_start, batch.hx0)
+            fixed_log_probs = self.policy.log_prob(means.reshape(N * T, -1), batch.actions.reshape(N * T, -1))
+            tgt_wbpos = fk.wbpos(tgt)
+        adv, ret = estimate_advantages(batch.rewards, batch.masks, values, self.gamma, self.tau, self.group, last_v)
+        adv, ret = adv.reshape(-1, 1), ret.reshape(-1, 1)
+        stats = {}
+        for _ in range(self.num_optim_epoch):
+            vloss = (self.value(flat_states) - ret).pow(2).mean()
+            self.opt_v.zero_grad(); vloss.backward(); _allreduce_grads(list(self.value.parameters()), self.group); self.opt_v.step()
+            means = self.policy.unroll(batch.states, batch.episode_start, batch.hx0).reshape(N * T, -1)
+            surr = ppo_surrogate(self.policy.log_prob(means, batch.actions.reshape(N * T, -1)), fixed_log_probs, adv, self.clip_epsilon)
+            loss_step, _ = compute_loss_lite(fk, kinematic_step(curr, means), tgt, gt_wbpos=tgt_wbpos)
+            if grad_alternate:
+                if epoch % 2 == 1:
+                    self.opt_p.zero_grad(); surr.backward(); self._clip(); self.opt_p.step()
+                else:
+                    opt = sup_optimizer if sup_optimizer is not None else self.opt_p
+                    opt.zero_grad(); loss_step.backward()
+                    _allreduce_grads([p for g in opt.param_groups for p in g["params"]], self.group)
+                    opt.step()
+            else:
+                loss = loss_step * 10 + surr
+                self.opt_p.zero_grad(); loss.backward(); self._clip(); self.opt_p.step()
+            stats = {"value_loss": float(vloss.detach()), "surr_loss": float(surr.detach()), "step_loss": float(loss_step.detach())}
+        return stats
+
     def update_controller(self, batch: RolloutBatch, adv, ind=None):
         """AgentAR.update_controller (agent_ar.py:774-794): PPO epochs on env.cc_policy over the recorded (cc_state, cc_action) with the
         kinematic policy's advantages; no value step."""

@@ -145,6 +145,29 @@ def test_lr_schedules_and_controller_update():
     assert moved > 0, "update_controller did not touch the UHC policy"
 
 
+def test_joint_policy_update_runs_both_forms():
+    """update_policy_joint (agent_ar.py:796-850, `grad_joint`): loss = 10 * supervised step loss + PPO surrogate in one policy step, and the
+    `grad_alternate` form (odd epochs surrogate, even epochs supervised)."""
+    from kinpoly_amd.agent import AgentAR
+    from kinpoly_amd.env import standing_context
+    from kinpoly_amd import sim as kpsim
+    n, T = 32, 6
+    fk_sim = kpsim.KpSim(kpsim.KpModel(), n, 0)
+
+    def context_fn(m):
+        ctx = standing_context(m, T + 2, STD["qpos"], STD["qvel"], fk_sim, torch.zeros(m))
+        ctx["obj_pose"] = torch.tensor([0.0, 0, 0, 1, 0, 0, 0], device=ctx["qpos"].device).repeat(m, T + 2, 1)
+        return ctx
+    for alt in (False, True):
+        agent = AgentAR(n, context_fn, device=0, horizon=T, num_optim_epoch=2, use_init_context=False, pool_depth=T, grad_joint=True, grad_alternate=alt)
+        before = torch.cat([p.detach().reshape(-1) for p in agent.policy_net.parameters()]).clone()
+        for it in range(2):
+            info = agent.optimize_policy(it)
+            assert np.isfinite(info["surr_loss"]) and np.isfinite(info["step_loss"]) and np.isfinite(info["value_loss"])
+        after = torch.cat([p.detach().reshape(-1) for p in agent.policy_net.parameters()])
+        assert float((after - before).abs().max()) > 0
+
+
 def test_two_rank_agent_keeps_parameters_identical():
     """SURVEY 8(e) on one device: two ranks (gloo, both on cuda:0) shard the envs, all-gather advantages / returns, all-reduce
     gradients; after optimize_policy the policy / value parameters are bit-identical across ranks and differ from the initial ones."""
