@@ -121,10 +121,11 @@ def policy_gemm_probe(env, policy, iters=30):
                     "inside the step they overlap nothing (one stream), so ms_per_step_isolated / ms_per_step is their share of the step"}
 
 
-def cpu_baseline(std, seconds_budget=15.0):
+def cpu_baseline(std, seconds_budget=15.0, tracked=True):
     """The fp64 oracle port of the same env-step on ONE host core: C physics (oracle/kp_oracle.c) + numpy
     obs / FK / reward (oracle/np_oracle.py) + fp64 torch policies on 1 thread (the reference samples on CPU,
-    OMP_NUM_THREADS=1, agent_ar.py:29,654)."""
+    OMP_NUM_THREADS=1, agent_ar.py:29,654).  tracked: the metric's workload -- the kinematic policy runs, its output is replaced by the clip
+    pose + N(0, 0.04) noise (episodes last); False: the random-init rollout."""
     from kinpoly_amd.model_compiler import DEFAULT_KPM, read_kpm
     from kinpoly_amd.nets import KinPolicy, PolicyMCP
     from oracle import np_oracle as O
@@ -143,16 +144,20 @@ def cpu_baseline(std, seconds_budget=15.0):
     obj_rel = np.concatenate([O.transform_vec(-head[:3], head[3:], "heading"), O.quaternion_multiply(O.quaternion_inverse(O.get_heading_q(head[3:])), [1, 0, 0, 0])])
     one_hot, hv = np.zeros(4), np.zeros(6)
     gt_bquat = fk0["bquat"].reshape(-1)
+    rng = np.random.default_rng(os.getpid())
     n_steps, t0 = 0, time.perf_counter()
     while time.perf_counter() - t0 < seconds_budget:
         sim.reset(qpos0, qvel0)
         hx = torch.zeros(1, 1024, dtype=torch.float64)
         x = {k: sim.get(k) for k in ("qpos", "qvel", "xpos", "xquat", "xipos")}
         obs = O.obs_ar(x["qpos"], x["xpos"].reshape(24, 3), x["xquat"].reshape(24, 4), head, hv, obj_rel, one_hot, None)
+        obs0 = obs.copy()
         for t in range(CLIP_LEN - 1):
             with torch.no_grad():
                 a, hx = kin.select_action(torch.from_numpy(obs)[None], hx)
             a = a[0].numpy()
+            if tracked:                                                  # tracking_action(): root height, de-headed root quaternion, joint angles of the clip
+                a = np.concatenate([qpos0[2:3], obs0[1:5], qpos0[7:], np.zeros(6)]) + 0.04 * rng.standard_normal(80)
             prev_bquat = O.get_body_quat(x["qpos"]); prev_hpos = np.concatenate([x["xpos"].reshape(24, 3)[13], x["xquat"].reshape(24, 4)[13]])
             tgt = O.qpos_fk(O.step_ar(x["qpos"], a), bp, bi, par)
             cc_obs = O.zfilter(O.obs_cc(x["qpos"], x["qvel"], x["xpos"].reshape(24, 3), x["xquat"].reshape(24, 4), x["xipos"].reshape(24, 3), tgt), 0.0, 1.0, 5.0)
@@ -169,7 +174,7 @@ def cpu_baseline(std, seconds_budget=15.0):
                 break
     dt = time.perf_counter() - t0
     return {"value": n_steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "port", "physics_flops_per_env_step": kpo.flops() / max(n_steps, 1),
-            "sample": f"{n_steps} env-steps of the same standing-clip rollout (fp64 C physics oracle + numpy obs/reward + fp64 torch policies, 1 thread) in {dt:.1f} s; host has {os.cpu_count()} cores"}
+            "sample": f"{n_steps} env-steps of the same standing-clip rollout ({'tracked' if tracked else 'random-init'} workload; fp64 C physics oracle + numpy obs/reward + fp64 torch policies, 1 thread) in {dt:.1f} s; host has {os.cpu_count()} cores"}
 
 
 def cpu_baseline_workers(std, workers, seconds_budget=15.0):
@@ -191,7 +196,7 @@ def cpu_baseline_workers(std, workers, seconds_budget=15.0):
             p.kill()
             raise
     return {"value": steps / wall, "unit": "env-steps/s", "cores": workers, "kind": "port", "physics_flops_per_env_step": flops / max(steps, 1),
-            "sample": f"{steps} env-steps of the same standing-clip rollout in {workers} single-threaded worker processes (fp64 C physics oracle + numpy obs/reward "
+            "sample": f"{steps} env-steps of the same standing-clip rollout (the metric's tracked workload) in {workers} single-threaded worker processes (fp64 C physics oracle + numpy obs/reward "
                       f"+ fp64 torch policies each; the reference samples with 35 such workers) over {wall:.1f} s of rollout ({time.perf_counter() - t0:.1f} s with start-up); "
                       f"host has {os.cpu_count()} cores"}
 
@@ -352,7 +357,7 @@ def main():
                 out["roofline"]["valu_flops"] = {"physics_flops_per_env_step_oracle": fl, "achieved_tflops": fl * value / world / 1e12, "peak_tflops": VALU_FP32_PEAK_TFLOPS,
                                                  "frac": fl * value / world / 1e12 / VALU_FP32_PEAK_TFLOPS,
                                                  "note": "FLOPs counted at the loop bodies of the fp64 oracle (dense stable-PD Cholesky, sparse L'DL, dense Newton Hessian: the arithmetic "
-                                                         "the reference + MuJoCo execute) on the random-init standing rollout of the CPU baseline; the HIP kernel's matrix-free passes do fewer"}
+                                                         "the reference + MuJoCo execute) on the CPU baseline's run of the same workload; the HIP kernel's matrix-free passes do fewer"}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -40,7 +40,7 @@ __device__ __forceinline__ bool c_eq(double a, double b) {
     a = fabs(a); b = fabs(b);
     return b > a ? ab < C_EPS * b : ab < C_EPS * a;
 }
-__device__ __forceinline__ D3 c_normalize(D3 a) { const double n = sqrt(dot(a, a)); return d3(a.x / n, a.y / n, a.z / n); }
+__device__ __forceinline__ D3 c_normalize(D3 a) { const double inv = 1.0 / sqrt(dot(a, a)); return d3(a.x * inv, a.y * inv, a.z * inv); }   // one fp64 division instead of three (an fp64 division is ~15 instructions); within 1 ulp of a / |a|
 __device__ __forceinline__ V3 c_normalize(V3 a) { const float n = sqrtf(dot(a, a)); return v3(a.x / n, a.y / n, a.z / n); }
 __device__ __forceinline__ D3 mulmat_t(const double* m, D3 v) {      // R^T v
     return D3{m[0] * v.x + m[3] * v.y + m[6] * v.z, m[1] * v.x + m[4] * v.y + m[7] * v.z, m[2] * v.x + m[5] * v.y + m[8] * v.z};
