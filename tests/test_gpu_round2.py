@@ -243,6 +243,11 @@ def test_contact_sets_match_oracle_contact_by_contact(kp):
         if len(c["body"]) == 0:
             continue
         n_contacts += len(c["body"])
+
+        def canon(x):      # the order of the contacts inside one geom pair carries no meaning (box - box clipping may start its polygon elsewhere in fp32)
+            key = np.lexsort((np.round(x["pos"][:, 2], 4), np.round(x["pos"][:, 1], 4), np.round(x["pos"][:, 0], 4), x["b2"], x["body"]))
+            return {k: v[key] for k, v in x.items()}
+        c, h = canon(c), canon(h)
         np.testing.assert_allclose(h["dist"], c["dist"], atol=2e-5, err_msg=f"scene {e}")
         np.testing.assert_allclose(h["pos"], c["pos"], atol=2e-5, err_msg=f"scene {e}")
         np.testing.assert_allclose(h["normal"], c["normal"], atol=2e-4, err_msg=f"scene {e}")
