@@ -18,8 +18,8 @@ NQ, NV, NU, NB, NM = 76, 75, 69, 24, 1221
 
 
 def build(force: bool = False):
-    src = os.path.join(_HERE, "kp_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("kp_oracle.c", "kp_collide.h", "Makefile")]
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return _LIB_PATH
 
