@@ -65,16 +65,16 @@ struct StepArgs {
 };
 
 // wave-wide sum without LDS traffic: xor butterflies inside each 16-lane row with DPP (quad_perm, row_half_mirror,
-// row_mirror), then the four row sums are combined through v_readlane.  Every lane gets the same bits.
+// row_mirror), then the row sums travel up with row_bcast:15 (rows 1, 3 += lane 15 of the row below) and row_bcast:31 (rows 2, 3 +=
+// lane 31), so lane 63 holds (r2 + r3) + (r0 + r1) and one v_readlane hands it to every lane.
 __device__ __forceinline__ float wave_sum(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // xor 1
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // xor 2
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // half mirror
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row mirror
-    const int vi = __builtin_bit_cast(int, v);
-    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 16));
-    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 48));
-    return (r0 + r1) + (r2 + r3);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false)); // row_bcast:15
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, false)); // row_bcast:31
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // wave-wide minimum, same exchange pattern (every lane gets the result)
@@ -446,32 +446,42 @@ __device__ __forceinline__ void aba_solve(EnvLds& s, const Params& P, const Lane
             }
             if (bwrench) pA += (rowok ? 1.f : 0.f) * bwrench[6 * b + (rowok ? r : 5)];
         }
-        if (contact_inertia && active && s.con_start[b + 1] > s.con_start[b]) {
-            const V3 o = ld3(s.xpos);
-            float Krow[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            const float mu = P.mu, mu2 = P.mu * P.mu;
-            for (int c = s.con_start[b]; c < s.con_start[b + 1]; c++) {
-                const V3 p = ld3(s.con_pos + 3 * c) - o;
-                const float Dc = s.con_D[c], jn = s.jar3[3 * c], jt1 = s.jar3[3 * c + 1], jt2 = s.jar3[3 * c + 2];
-                const float a0 = row_val(0, mu, jn, jt1, jt2) < 0.f, a1 = row_val(1, mu, jn, jt1, jt2) < 0.f;
-                const float a2 = row_val(2, mu, jn, jt1, jt2) < 0.f, a3 = row_val(3, mu, jn, jt1, jt2) < 0.f;
-                // G = sum_e a_e dir_e dir_e^T with dir_e = n +- mu t1, n +- mu t2; in frame coordinates (n, t1, t2):
-                const float gnn = a0 + a1 + a2 + a3, g11 = mu2 * (a0 + a1), g22 = mu2 * (a2 + a3), gn1 = mu * (a0 - a1), gn2 = mu * (a2 - a3);
-                const Frame fr = contact_frame<OBJ>(s, c);
-                V3 Pr;  // row r of P = [[p]x ; 1]:  K = D P G P^T, row r = [p x q ; q] with q = D (P_r G)
-                if (r == 0) Pr = v3(0.f, -p.z, p.y); else if (r == 1) Pr = v3(p.z, 0.f, -p.x); else if (r == 2) Pr = v3(-p.y, p.x, 0.f);
-                else Pr = v3(r == 3 ? 1.f : 0.f, r == 4 ? 1.f : 0.f, r == 5 ? 1.f : 0.f);
-                const V3 pf = frame_comp(fr, Pr);
-                const V3 q = frame_world(fr, v3(Dc * (gnn * pf.x + gn1 * pf.y + gn2 * pf.z), Dc * (gn1 * pf.x + g11 * pf.y), Dc * (gn2 * pf.x + g22 * pf.z)));
-                const V3 pq = cross(p, q);
-                Krow[0] += pq.x; Krow[1] += pq.y; Krow[2] += pq.z; Krow[3] += q.x; Krow[4] += q.y; Krow[5] += q.z;
-            }
+        if (contact_inertia && active) {
+            // active pyramid rows come from con_act (active_set_changed ran on this iterate); the next contact's operands are
+            // requested before this one's arithmetic, so the loop pays one LDS round trip, not one per contact
+            const int c0 = s.con_start[b], c1 = s.con_start[b + 1];
+            if (c1 > c0) {
+                const V3 o = ld3(s.xpos);
+                float Krow[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                const float mu = P.mu, mu2 = P.mu * P.mu;
+                V3 pn = ld3(s.con_pos + 3 * c0);
+                float Dn = s.con_D[c0];
+                unsigned an = s.con_act[c0];
+                for (int c = c0; c < c1; c++) {
+                    const V3 p = pn - o;
+                    const float Dc = Dn;
+                    const unsigned am = an;
+                    const int cn = min(c + 1, c1 - 1);
+                    pn = ld3(s.con_pos + 3 * cn); Dn = s.con_D[cn]; an = s.con_act[cn];
+                    const float a0 = (am & 1u) ? 1.f : 0.f, a1 = (am & 2u) ? 1.f : 0.f, a2 = (am & 4u) ? 1.f : 0.f, a3 = (am & 8u) ? 1.f : 0.f;
+                    // G = sum_e a_e dir_e dir_e^T with dir_e = n +- mu t1, n +- mu t2; in frame coordinates (n, t1, t2):
+                    const float gnn = a0 + a1 + a2 + a3, g11 = mu2 * (a0 + a1), g22 = mu2 * (a2 + a3), gn1 = mu * (a0 - a1), gn2 = mu * (a2 - a3);
+                    const Frame fr = contact_frame<OBJ>(s, c);
+                    V3 Pr;  // row r of P = [[p]x ; 1]:  K = D P G P^T, row r = [p x q ; q] with q = D (P_r G)
+                    if (r == 0) Pr = v3(0.f, -p.z, p.y); else if (r == 1) Pr = v3(p.z, 0.f, -p.x); else if (r == 2) Pr = v3(-p.y, p.x, 0.f);
+                    else Pr = v3(r == 3 ? 1.f : 0.f, r == 4 ? 1.f : 0.f, r == 5 ? 1.f : 0.f);
+                    const V3 pf = frame_comp(fr, Pr);
+                    const V3 q = frame_world(fr, v3(Dc * (gnn * pf.x + gn1 * pf.y + gn2 * pf.z), Dc * (gn1 * pf.x + g11 * pf.y), Dc * (gn2 * pf.x + g22 * pf.z)));
+                    const V3 pq = cross(p, q);
+                    Krow[0] += pq.x; Krow[1] += pq.y; Krow[2] += pq.z; Krow[3] += q.x; Krow[4] += q.y; Krow[5] += q.z;
+                }
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const int c = L.col[k];
-                float v = Krow[0];
-                v = c == 1 ? Krow[1] : v; v = c == 2 ? Krow[2] : v; v = c == 3 ? Krow[3] : v; v = c == 4 ? Krow[4] : v; v = c == 5 ? Krow[5] : v;
-                if (rowok && c < 6) IAx[k] += v;
+                for (int k = 0; k < 8; k++) {
+                    const int c = L.col[k];
+                    float v = Krow[0];
+                    v = c == 1 ? Krow[1] : v; v = c == 2 ? Krow[2] : v; v = c == 3 ? Krow[3] : v; v = c == 4 ? Krow[4] : v; v = c == 5 ? Krow[5] : v;
+                    if (rowok && c < 6) IAx[k] += v;
+                }
             }
         }
         if (lev == 0) {
@@ -816,6 +826,30 @@ __device__ __forceinline__ void eval_rows(EnvLds& s, const float* vec, float* ou
     KP_SYNC();
 }
 
+// sa[b] = sum of the body wrenches sw over the subtree of b (bodies are in depth-first order: the subtree is [b, b + bsub[b])), summed in
+// ascending body order.  The trip count is wave-uniform (the largest subtree among the wave's items) and the LDS reads go out in
+// batches of 8 before the first add: a per-lane loop over its own subtree pays one LDS round trip per element (24 for the root).
+// Reads past the subtree (at most 7 records, still inside EnvLds) are discarded by the select.
+template <int NT>
+__device__ __forceinline__ void subtree_sums(EnvLds& s, int tid) {
+    for (int base = 0; base < D_NB * 6; base += NT) {
+        const int it = base + tid;
+        const bool ok = it < D_NB * 6;
+        const int b = ok ? it / 6 : 0, c = ok ? it - 6 * b : 0, n = ok ? (int)s.bsub[b] : 0;
+        const float* src = s.sw + 6 * b + c;
+        float acc = 0.f;
+        for (int k0 = 0; __builtin_amdgcn_ballot_w64(k0 < n) != 0ull; k0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = src[6 * (k0 + j)];
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc += (k0 + j < n) ? v[j] : 0.f;
+        }
+        if (ok) s.sa[it] = acc;
+    }
+    KP_SYNC();
+}
+
 // out = M (va - vb) (with_inertia; acc6 [24][6] must hold the body spatial accelerations of va - vb) - J^T f(jar) (with_forces)
 template <int NT, bool OBJ>
 __device__ __forceinline__ void wrench_project(EnvLds& s, const Params& P, const float* acc6, const float* va, const float* vb, float* out, bool with_inertia, bool with_forces, int tid) {
@@ -823,28 +857,30 @@ __device__ __forceinline__ void wrench_project(EnvLds& s, const Params& P, const
         const int b = tid;
         S6 W = with_inertia ? inert_mul(s.cinert + 10 * b, lds6(acc6 + 6 * b)) : S6{v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f)};
         if (with_forces) {
-            const V3 o = ld3(s.xpos);
-            for (int c = s.con_start[b]; c < s.con_start[b + 1]; c++) {
-                const float Dc = s.con_D[c], jn = s.jar3[3 * c], jt1 = s.jar3[3 * c + 1], jt2 = s.jar3[3 * c + 2];
-                float fe[4];
+            const int c0 = s.con_start[b], c1 = s.con_start[b + 1];
+            if (c1 > c0) {
+                const V3 o = ld3(s.xpos);
+                // the next contact's operands are requested before this one's arithmetic (one LDS round trip for the loop, not one per contact)
+                float Dn = s.con_D[c0];
+                V3 jn3 = ld3(s.jar3 + 3 * c0), pn = ld3(s.con_pos + 3 * c0);
+                for (int c = c0; c < c1; c++) {
+                    const float Dc = Dn, jn = jn3.x, jt1 = jn3.y, jt2 = jn3.z;
+                    const V3 p = pn - o;
+                    const int cn = min(c + 1, c1 - 1);
+                    Dn = s.con_D[cn]; jn3 = ld3(s.jar3 + 3 * cn); pn = ld3(s.con_pos + 3 * cn);
+                    float fe[4];
 #pragma unroll
-                for (int e = 0; e < 4; e++) { float x = row_val(e, P.mu, jn, jt1, jt2); fe[e] = x < 0.f ? -Dc * x : 0.f; }
-                // sum_e f_e (n +- mu t_k) in frame coordinates, then to world
-                const V3 F = frame_world(contact_frame<OBJ>(s, c), v3(fe[0] + fe[1] + fe[2] + fe[3], P.mu * (fe[0] - fe[1]), P.mu * (fe[2] - fe[3])));
-                V3 p = ld3(s.con_pos + 3 * c) - o;
-                W.a = W.a - cross(p, F); W.l = W.l - F;
+                    for (int e = 0; e < 4; e++) { float x = row_val(e, P.mu, jn, jt1, jt2); fe[e] = x < 0.f ? -Dc * x : 0.f; }
+                    // sum_e f_e (n +- mu t_k) in frame coordinates, then to world
+                    const V3 F = frame_world(contact_frame<OBJ>(s, c), v3(fe[0] + fe[1] + fe[2] + fe[3], P.mu * (fe[0] - fe[1]), P.mu * (fe[2] - fe[3])));
+                    W.a = W.a - cross(p, F); W.l = W.l - F;
+                }
             }
         }
         sts6(s.sw + 6 * b, W);
     }
     KP_SYNC();
-    for (int it = tid; it < D_NB * 6; it += NT) {
-        int b = it / 6, c = it - 6 * b, n = s.bsub[b];
-        float acc = 0.f;
-        for (int k = b; k < b + n; k++) acc += s.sw[6 * k + c];
-        s.sa[it] = acc;
-    }
-    KP_SYNC();
+    subtree_sums<NT>(s, tid);
     for (int d = tid; d < D_NV; d += NT) {
         float v = dot6(lds6(s.cdof + 6 * d), lds6(s.sa + 6 * s.dbody[d]));
         if (with_inertia) v += s.arm[d] * (va[d] - (vb ? vb[d] : 0.f));
@@ -936,6 +972,51 @@ __device__ __forceinline__ int first_clean_level(EnvLds& s, const Params& P, int
     return (int)m + 1;
 }
 
+// exact minimiser of the cost along the search direction: root of phi'(alpha) = g0 + alpha h0 + sum_rows D (jar + alpha jv)_- jv by
+// safeguarded Newton steps on the piecewise-linear phi'.  Every lane keeps its rows in registers for the whole search -- one contact
+// (four pyramid rows a + alpha b with a = row(jar), b = row(jv)) and ceil(69 / NT) joint-limit rows -- so an evaluation is a few
+// FMAs per row and two wave sums, without LDS traffic.
+template <int NT>
+__device__ __forceinline__ float line_search(EnvLds& s, const Params& P, float g0, float h0, int tid) {
+    static_assert(D_MAXCON <= 64 && NT >= 64, "one contact per lane");
+    float ra[4], rb[4], rD[4];
+    {
+        const bool ok = tid < s.ncon;
+        const int k = ok ? tid : 0;
+        const float Dc = ok ? s.con_D[k] : 0.f;
+        const float jn = ok ? s.jar3[3 * k] : 0.f, jt1 = ok ? s.jar3[3 * k + 1] : 0.f, jt2 = ok ? s.jar3[3 * k + 2] : 0.f;
+        const float vn = ok ? s.jv3[3 * k] : 0.f, vt1 = ok ? s.jv3[3 * k + 1] : 0.f, vt2 = ok ? s.jv3[3 * k + 2] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; e++) { ra[e] = row_val(e, P.mu, jn, jt1, jt2); rb[e] = row_val(e, P.mu, vn, vt1, vt2); rD[e] = Dc * rb[e]; }
+    }
+    constexpr int LR = (D_NU + NT - 1) / NT;
+    float la[LR], lb[LR], lD[LR];
+#pragma unroll
+    for (int n = 0; n < LR; n++) {
+        const int j = tid + n * NT, jj = j < D_NU ? j : 0;
+        const bool ok = j < D_NU && s.lim_sgn[jj] != 0.f;
+        la[n] = ok ? s.lim_jar[jj] : 0.f; lb[n] = ok ? s.lim_jv[jj] : 0.f; lD[n] = ok ? s.lim_D[jj] * lb[n] : 0.f;
+    }
+    float alpha = 0.f, lo = 0.f, hi = 3.0e38f;
+    for (int ls = 0; ls < 20; ls++) {
+        float d1 = 0.f, d2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; e++) { const float x = fmaf(alpha, rb[e], ra[e]); if (x < 0.f) { d1 += x * rD[e]; d2 += rb[e] * rD[e]; } }
+#pragma unroll
+        for (int n = 0; n < LR; n++) { const float x = fmaf(alpha, lb[n], la[n]); if (x < 0.f) { d1 += x * lD[n]; d2 += lb[n] * lD[n]; } }
+        d1 = block_sum<NT>(s, d1, tid); d2 = block_sum<NT>(s, d2, tid);
+        const float dphi = g0 + alpha * h0 + d1, ddphi = h0 + d2;
+        if (!(ddphi > 0.f)) break;
+        if (dphi < 0.f) lo = alpha; else hi = alpha;
+        float an = alpha - dphi / ddphi;
+        if (!(an > lo && an < hi)) an = hi < 1.0e38f ? 0.5f * (lo + hi) : 2.0f * alpha + 1.0f;
+        const float step = an - alpha;
+        alpha = an;
+        if (fabsf(step) <= 1e-6f * fabsf(alpha)) break;
+    }
+    return alpha;
+}
+
 // constraint solve: Newton on the primal problem (mj_solNewton) with an exact line search.  Returns iterations.
 // On entry sv holds the spatial accelerations of qacc_s (left by the smooth aba_solve), jv3 holds aref.
 template <int NT, bool OBJ>
@@ -1005,32 +1086,7 @@ __device__ __forceinline__ int solve_constraints(EnvLds& s, const Params& P, con
         float g0 = 2.0f * quad_form_M<NT>(s, s.sv, sacc, s.search, nullptr, s.qacc, s.qacc_s, tid);
         float h0 = 2.0f * quad_form_M<NT>(s, s.sv, s.sv, s.search, nullptr, s.search, nullptr, tid);
         g0 = block_sum<NT>(s, g0, tid); h0 = block_sum<NT>(s, h0, tid);
-        float alpha = 0.f, lo = 0.f, hi = 3.0e38f;
-        for (int ls = 0; ls < 20; ls++) {
-            float d1 = 0.f, d2 = 0.f;
-            for (int k = tid; k < s.ncon; k += NT) {
-                const float Dc = s.con_D[k];
-                const float vn = s.jv3[3 * k], vt1 = s.jv3[3 * k + 1], vt2 = s.jv3[3 * k + 2];
-                const float jn = s.jar3[3 * k] + alpha * vn, jt1 = s.jar3[3 * k + 1] + alpha * vt1, jt2 = s.jar3[3 * k + 2] + alpha * vt2;
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    float x = row_val(e, P.mu, jn, jt1, jt2);
-                    if (x < 0.f) { float jv = row_val(e, P.mu, vn, vt1, vt2); d1 += Dc * x * jv; d2 += Dc * jv * jv; }
-                }
-            }
-            for (int j = tid; j < D_NU; j += NT) {
-                if (s.lim_sgn[j] != 0.f) { float jv = s.lim_jv[j], x = s.lim_jar[j] + alpha * jv; if (x < 0.f) { d1 += s.lim_D[j] * x * jv; d2 += s.lim_D[j] * jv * jv; } }
-            }
-            d1 = block_sum<NT>(s, d1, tid); d2 = block_sum<NT>(s, d2, tid);
-            float dphi = g0 + alpha * h0 + d1, ddphi = h0 + d2;
-            if (!(ddphi > 0.f)) break;
-            if (dphi < 0.f) lo = alpha; else hi = alpha;
-            float an = alpha - dphi / ddphi;
-            if (!(an > lo && an < hi)) an = hi < 1.0e38f ? 0.5f * (lo + hi) : 2.0f * alpha + 1.0f;
-            float step = an - alpha;
-            alpha = an;
-            if (fabsf(step) <= 1e-6f * fabsf(alpha)) break;
-        }
+        const float alpha = line_search<NT>(s, P, g0, h0, tid);
         if (!(alpha > 0.f)) { done = true; break; }
         for (int i = tid; i < D_NV; i += NT) s.qacc[i] += alpha * s.search[i];
         for (int i = tid; i < D_NB * 6; i += NT) sacc[i] += alpha * s.sv[i];
@@ -1519,32 +1575,7 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
         float h0 = 2.0f * quad_form_M<NT>(s, s.sv, s.sv, s.search, nullptr, s.search, nullptr, tid);
         if (tid < no6) { g0 += s.osrch[tid] * s.omres[tid]; h0 += s.osrch[tid] * s.oMv[tid]; }
         g0 = block_sum<NT>(s, g0, tid); h0 = block_sum<NT>(s, h0, tid);
-        float alpha = 0.f, lo = 0.f, hi = 3.0e38f;
-        for (int ls = 0; ls < 20; ls++) {
-            float d1 = 0.f, d2 = 0.f;
-            for (int k = tid; k < s.ncon; k += NT) {
-                const float Dc = s.con_D[k];
-                const float vn = s.jv3[3 * k], vt1 = s.jv3[3 * k + 1], vt2 = s.jv3[3 * k + 2];
-                const float jn = s.jar3[3 * k] + alpha * vn, jt1 = s.jar3[3 * k + 1] + alpha * vt1, jt2 = s.jar3[3 * k + 2] + alpha * vt2;
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const float x = row_val(e, P.mu, jn, jt1, jt2);
-                    if (x < 0.f) { const float jv = row_val(e, P.mu, vn, vt1, vt2); d1 += Dc * x * jv; d2 += Dc * jv * jv; }
-                }
-            }
-            for (int j = tid; j < D_NU; j += NT) {
-                if (s.lim_sgn[j] != 0.f) { const float jv = s.lim_jv[j], x = s.lim_jar[j] + alpha * jv; if (x < 0.f) { d1 += s.lim_D[j] * x * jv; d2 += s.lim_D[j] * jv * jv; } }
-            }
-            d1 = block_sum<NT>(s, d1, tid); d2 = block_sum<NT>(s, d2, tid);
-            const float dphi = g0 + alpha * h0 + d1, ddphi = h0 + d2;
-            if (!(ddphi > 0.f)) break;
-            if (dphi < 0.f) lo = alpha; else hi = alpha;
-            float an = alpha - dphi / ddphi;
-            if (!(an > lo && an < hi)) an = hi < 1.0e38f ? 0.5f * (lo + hi) : 2.0f * alpha + 1.0f;
-            const float step = an - alpha;
-            alpha = an;
-            if (fabsf(step) <= 1e-6f * fabsf(alpha)) break;
-        }
+        const float alpha = line_search<NT>(s, P, g0, h0, tid);
         if (!(alpha > 0.f)) { done = true; break; }
         for (int i = tid; i < D_NV; i += NT) s.qacc[i] += alpha * s.search[i];
         for (int i = tid; i < D_NB * 6; i += NT) sacc[i] += alpha * s.sv[i];
