@@ -347,16 +347,20 @@ __device__ __forceinline__ void aba_elim3(EnvLds& s, const Lane8& L, const float
     }
 }
 
-__device__ __forceinline__ float aba_fwd3(EnvLds& s, const Lane8& L, float* out, int d0, bool store_ok, float a) {
+// WARM: the pass also carries dl = spatial acceleration induced by (warm - out), the difference between a second generalized vector
+// and the solution (the Newton solve's warm-start candidate against qacc_smooth), at three FMAs per body and level
+template <bool WARM = false>
+__device__ __forceinline__ float aba_fwd3(EnvLds& s, const Lane8& L, float* out, int d0, bool store_ok, float a, const float* warm = nullptr, float* dl = nullptr) {
     const int r = L.r;
     const int rc = r < 6 ? r : 5;
     const float rmask = r < 6 ? 1.f : 0.f;
-    float Ud[3], sd[3], ujd[3], Did[3];
+    float Ud[3], sd[3], ujd[3], Did[3], wd[3];
 #pragma unroll
     for (int j = 0; j < 3; j++) {
         const int d = d0 + j;
         Ud[j] = rmask * s.U[6 * d + rc]; sd[j] = s.cdof[6 * d + rc];
         ujd[j] = s.uj[d]; Did[j] = s.Dinv[d];
+        if (WARM) wd[j] = warm[d];
     }
     float qo[3];
 #pragma unroll
@@ -364,6 +368,7 @@ __device__ __forceinline__ float aba_fwd3(EnvLds& s, const Lane8& L, float* out,
         const float qdd = (ujd[j] - sum8(Ud[j] * a)) * Did[j];
         qo[j] = qdd;
         a += qdd * sd[j];
+        if (WARM) *dl += (wd[j] - qdd) * sd[j];
     }
     if (store_ok && r == 0) {
 #pragma unroll
@@ -373,7 +378,8 @@ __device__ __forceinline__ float aba_fwd3(EnvLds& s, const Lane8& L, float* out,
 }
 
 // root->leaves pass: joint accelerations from (U, 1/D, u) and the parent's spatial acceleration; leaves them in sv
-__device__ __forceinline__ void aba_forward(EnvLds& s, const Lane8& L, float* out, int lev_max = D_NLEV - 1) {
+template <bool WARM = false>
+__device__ __forceinline__ void aba_forward(EnvLds& s, const Lane8& L, float* out, int lev_max = D_NLEV - 1, const float* warm = nullptr, float* dacc = nullptr) {
     const int r = L.r;
     const bool rowok = r < 6;
 #pragma nounroll
@@ -383,21 +389,25 @@ __device__ __forceinline__ void aba_forward(EnvLds& s, const Lane8& L, float* ou
         const bool active = bq != 31;
         const int b = active ? bq : 0;
         float a = (rowok && par != 31) ? s.sv[6 * (par == 31 ? 0 : par) + r] : 0.f;
+        float dl = 0.f;
+        if (WARM) dl = (rowok && par != 31) ? dacc[6 * (par == 31 ? 0 : par) + r] : 0.f;
         if (lev == 0) {
-            a = aba_fwd3(s, L, out, 0, active, a);
-            a = aba_fwd3(s, L, out, 3, active, a);
+            a = aba_fwd3<WARM>(s, L, out, 0, active, a, warm, &dl);
+            a = aba_fwd3<WARM>(s, L, out, 3, active, a, warm, &dl);
         } else {
-            a = aba_fwd3(s, L, out, b == 0 ? 6 : 6 + 3 * (b - 1), active, a);
+            a = aba_fwd3<WARM>(s, L, out, b == 0 ? 6 : 6 + 3 * (b - 1), active, a, warm, &dl);
         }
-        if (active && rowok) s.sv[6 * b + r] = a;
+        if (active && rowok) { s.sv[6 * b + r] = a; if (WARM) dacc[6 * b + r] = dl; }
         KP_SYNC();
     }
 }
 
-template <int NT, bool OBJ>
+template <int NT, bool OBJ, bool WARM = false>
 // lev_clean: tree levels >= lev_clean carry no active contact row and no active joint limit, so their articulated inertias, U and
 // 1/D are the ones the smooth solve (same M, no extra armature) left in LDS this substep: only the bias-force half runs there.
-__device__ __forceinline__ void aba_solve(EnvLds& s, const Params& P, const Lane8& L, const float* rhs, float* out, bool contact_inertia, int tid, int lev_clean = D_NLEV, const float* bwrench = nullptr) {
+// WARM: the root->leaves pass also leaves dacc[b] = spatial acceleration of body b induced by warm - out (see aba_fwd3).
+__device__ __forceinline__ void aba_solve(EnvLds& s, const Params& P, const Lane8& L, const float* rhs, float* out, bool contact_inertia, int tid, int lev_clean = D_NLEV, const float* bwrench = nullptr,
+                                          const float* warm = nullptr, float* dacc = nullptr) {
     const int r = L.r;
     const bool rowok = r < 6;
 #pragma nounroll
@@ -497,7 +507,7 @@ __device__ __forceinline__ void aba_solve(EnvLds& s, const Params& P, const Lane
         }
         KP_SYNC();
     }
-    aba_forward(s, L, out);
+    aba_forward<WARM>(s, L, out, D_NLEV - 1, warm, dacc);
 }
 
 // out = H^-1 (rhs + J_body^T wrench) with the factorisation (U, 1/D) the last aba_solve left in LDS: the bias-force half of the
@@ -804,24 +814,28 @@ __device__ __forceinline__ void make_constraint(EnvLds& s, const DevTables& T, c
     KP_SYNC();
 }
 
-// contact-frame residuals of all rows for the spatial accelerations in sv:  out3 = frame^T (point accel) [- aref]
+// contact-frame residuals of all rows for the body spatial accelerations in acc (default: sv) and the generalized vector vec [- vec_b]:
+// out3 = frame^T (point accel) [- aref] [+ jar3];  sub_aref: subtract the reference acceleration (jv3 / lim_aref);  add_base: add the
+// residuals already in jar3 / lim_jar (rows are linear: residual(q + dq) = residual(q) + J dq)
 template <int NT, bool OBJ>
-__device__ __forceinline__ void eval_rows(EnvLds& s, const float* vec, float* out3, float* lim_rows, bool sub_aref, int tid) {
+__device__ __forceinline__ void eval_rows(EnvLds& s, const float* vec, float* out3, float* lim_rows, bool sub_aref, int tid, const float* acc = nullptr, const float* vec_b = nullptr, bool add_base = false) {
     const V3 o = ld3(s.xpos);
+    if (!acc) acc = s.sv;
     for (int c = tid; c < s.ncon; c += NT) {
-        S6 S = lds6(s.sv + 6 * s.con_body[c]);
+        S6 S = lds6(acc + 6 * s.con_body[c]);
         V3 ap = S.l + cross(S.a, ld3(s.con_pos + 3 * c) - o);
         if (OBJ) {
             const int b2 = static_cast<const EnvLdsObj&>(s).con_b2[c];
-            if (b2 >= 0) { const S6 S2 = lds6(s.sv + 6 * b2); ap = ap - (S2.l + cross(S2.a, ld3(s.con_pos + 3 * c) - o)); }
+            if (b2 >= 0) { const S6 S2 = lds6(acc + 6 * b2); ap = ap - (S2.l + cross(S2.a, ld3(s.con_pos + 3 * c) - o)); }
         }
         V3 a = frame_comp(contact_frame<OBJ>(s, c), ap);
         if (sub_aref) { a.x -= s.jv3[3 * c]; a.y -= s.jv3[3 * c + 1]; a.z -= s.jv3[3 * c + 2]; }
+        if (add_base) { a.x += s.jar3[3 * c]; a.y += s.jar3[3 * c + 1]; a.z += s.jar3[3 * c + 2]; }
         out3[3 * c] = a.x; out3[3 * c + 1] = a.y; out3[3 * c + 2] = a.z;
     }
     for (int j = tid; j < D_NU; j += NT) {
         float sg = s.lim_sgn[j];
-        lim_rows[j] = sg != 0.f ? sg * vec[6 + j] - (sub_aref ? s.lim_aref[j] : 0.f) : 0.f;
+        lim_rows[j] = sg != 0.f ? sg * (vec[6 + j] - (vec_b ? vec_b[6 + j] : 0.f)) - (sub_aref ? s.lim_aref[j] : 0.f) + (add_base ? s.lim_jar[j] : 0.f) : 0.f;
     }
     KP_SYNC();
 }
@@ -1032,16 +1046,13 @@ __device__ __forceinline__ int solve_constraints(EnvLds& s, const Params& P, con
     // The Gauss part of the problem is carried in body form: sacc[b] = spatial acceleration of body b induced by qacc - qacc_s, so
     // M (qacc - qacc_s) never has to be projected on the dofs on its own (it rides along with the gradient's projection).
     float* sacc = s.Mv;        // [24][6] over Mv + mres (152 floats)
-    // candidate B: warm start = s.qacc (qacc of the previous substep / control step), mj_fwdConstraint's rule
+    // candidate B: warm start = s.qacc (qacc of the previous substep / control step), mj_fwdConstraint's rule.  The smooth solve's
+    // root->leaves pass already left sacc = spatial accelerations of qacc - qacc_s (aba_solve<.., WARM>), and the rows are linear, so
+    // its residuals are candidate A's plus the rows of the difference: no second accumulation pass, aref is not needed again.
     {
-        float* wj3 = s.jv3;    // in place over aref (each lane reads its aref, writes its residual; aref is not needed afterwards);
+        float* wj3 = s.jv3;    // over aref (not needed afterwards)
         float* wlim = s.x;     // U must stay as the smooth solve left it (aba_solve's clean levels)
-        for (int i = tid; i < D_NB * 6; i += NT) sacc[i] = s.sv[i];            // accelerations of qacc_s
-        KP_SYNC();
-        spatial_accumulate<NT>(s, s.qacc, depth, tid);
-        eval_rows<NT, OBJ>(s, s.qacc, wj3, wlim, true, tid);
-        for (int i = tid; i < D_NB * 6; i += NT) sacc[i] = s.sv[i] - sacc[i];
-        KP_SYNC();
+        eval_rows<NT, OBJ>(s, s.qacc, wj3, wlim, false, tid, sacc, s.qacc_s, true);
         float cw = primal_cost<NT>(s, P, sacc, wj3, wlim, tid);
         if (cw < cost) {
             cost = cw;
@@ -1694,7 +1705,8 @@ __device__ __forceinline__ void step_body(StepArgs A, const int env_in, const in
         if (!P.stale) spd_torque_rfc<NT, OBJ>(s, T, P, L8, depth, tid);
         for (int i = tid; i < D_NV; i += NT) s.extra[i] = 0.f;
         KP_SYNC();
-        aba_solve<NT, OBJ>(s, P, L8, s.applied, s.qacc_s, false, tid, D_NLEV, s.fb);   // qacc_smooth = M^-1 qfrc_smooth; sv = its spatial accel
+        // qacc_smooth = M^-1 qfrc_smooth; sv = its spatial accelerations; floor-only kernel: Mv/mres = those of (warm start - qacc_smooth) for the Newton solve
+        aba_solve<NT, OBJ, !OBJ>(s, P, L8, s.applied, s.qacc_s, false, tid, D_NLEV, s.fb, s.qacc, s.Mv);
         KP_T(4)
         if constexpr (OBJ) niter_total += solve_constraints_obj<NT>(s, P, L8, depth, tid, nfact_total, ncap_total);
         else niter_total += solve_constraints<NT, OBJ>(s, P, L8, depth, tid, nfact_total, ncap_total);
