@@ -402,12 +402,24 @@ __device__ __forceinline__ void aba_forward(EnvLds& s, const Lane8& L, float* ou
     }
 }
 
+// bit lev set: the body this lane serves at tree level lev has contacts (con_start is fixed for the substep, so the Newton
+// factorisations test a register instead of reading two LDS words per level)
+__device__ __forceinline__ unsigned contact_levels(const EnvLds& s, const Lane8& L) {
+    unsigned m = 0;
+#pragma unroll
+    for (int lev = 0; lev < D_NLEV; lev++) {
+        const int bq = (int)((L.sb >> (5 * lev)) & 31ull), b = bq != 31 ? bq : 0;
+        if (bq != 31 && s.con_start[b + 1] > s.con_start[b]) m |= 1u << lev;
+    }
+    return m;
+}
+
 template <int NT, bool OBJ, bool WARM = false>
 // lev_clean: tree levels >= lev_clean carry no active contact row and no active joint limit, so their articulated inertias, U and
 // 1/D are the ones the smooth solve (same M, no extra armature) left in LDS this substep: only the bias-force half runs there.
 // WARM: the root->leaves pass also leaves dacc[b] = spatial acceleration of body b induced by warm - out (see aba_fwd3).
 __device__ __forceinline__ void aba_solve(EnvLds& s, const Params& P, const Lane8& L, const float* rhs, float* out, bool contact_inertia, int tid, int lev_clean = D_NLEV, const float* bwrench = nullptr,
-                                          const float* warm = nullptr, float* dacc = nullptr) {
+                                          const float* warm = nullptr, float* dacc = nullptr, unsigned conlev = 0xFFFFFFFFu) {
     const int r = L.r;
     const bool rowok = r < 6;
 #pragma nounroll
@@ -456,7 +468,7 @@ __device__ __forceinline__ void aba_solve(EnvLds& s, const Params& P, const Lane
             }
             if (bwrench) pA += (rowok ? 1.f : 0.f) * bwrench[6 * b + (rowok ? r : 5)];
         }
-        if (contact_inertia && active) {
+        if (contact_inertia && active && ((conlev >> lev) & 1u)) {     // conlev: this lane's body at this level carries contacts (contact_levels)
             // active pyramid rows come from con_act (active_set_changed ran on this iterate); the next contact's operands are
             // requested before this one's arithmetic, so the loop pays one LDS round trip, not one per contact
             const int c0 = s.con_start[b], c1 = s.con_start[b + 1];
@@ -943,9 +955,10 @@ __device__ __forceinline__ void spatial_accumulate(EnvLds& s, const float* vec, 
     }
 }
 
-// records the active pyramid rows of every contact; returns 1 on the lanes that saw a change since the last call
+// records the active pyramid rows of every contact; returns 1 on the lanes that saw a change since the last call.  deep: running
+// maximum of the tree level of the hulls that carry an active row (first_clean_level's contact half, from the same row values)
 template <int NT>
-__device__ __forceinline__ float active_set_changed(EnvLds& s, const Params& P, int tid) {
+__device__ __forceinline__ float active_set_changed(EnvLds& s, const Params& P, int tid, float& deep) {
     float changed = 0.f;
     for (int c = tid; c < s.ncon; c += NT) {
         const float jn = s.jar3[3 * c], jt1 = s.jar3[3 * c + 1], jt2 = s.jar3[3 * c + 2];
@@ -954,25 +967,17 @@ __device__ __forceinline__ float active_set_changed(EnvLds& s, const Params& P, 
         for (int e = 0; e < 4; e++) m |= (row_val(e, P.mu, jn, jt1, jt2) < 0.f ? 1u : 0u) << e;
         if (m != s.con_act[c]) changed = 1.f;
         s.con_act[c] = (unsigned char)m;
+        const int b = s.con_body[c];
+        if (m != 0u && b < D_NB) deep = fmaxf(deep, (float)s.bdep[b]);      // object-side contacts do not touch the humanoid tree
     }
     return changed;
 }
 
 // first tree level below every active constraint: 1 + the deepest level holding a body with an active contact row or a dof with
-// an active joint limit (jar < 0); the root level always counts as dirty
+// an active joint limit (jar < 0); the root level always counts as dirty.  deep: per-lane maxima gathered by active_set_changed and
+// the gradient loop
 template <int NT>
-__device__ __forceinline__ int first_clean_level(EnvLds& s, const Params& P, int tid) {
-    float deep = 0.f;
-    for (int c = tid; c < s.ncon; c += NT) {
-        const int b = s.con_body[c];
-        if (b >= D_NB) continue;                                 // object-side contacts do not touch the humanoid tree
-        const float jn = s.jar3[3 * c], jt1 = s.jar3[3 * c + 1], jt2 = s.jar3[3 * c + 2];
-        bool act = false;
-#pragma unroll
-        for (int e = 0; e < 4; e++) act |= row_val(e, P.mu, jn, jt1, jt2) < 0.f;
-        if (act) deep = fmaxf(deep, (float)s.bdep[b]);
-    }
-    for (int j = tid; j < D_NU; j += NT) if (s.lim_jar[j] < 0.f && s.lim_D[j] != 0.f) deep = fmaxf(deep, (float)s.bdep[s.dbody[6 + j]]);
+__device__ __forceinline__ int first_clean_level(EnvLds& s, float deep, int tid) {
     float m = -wave_min(-deep);
     if (NT > 64) {
         KP_SYNC();
@@ -1066,10 +1071,11 @@ __device__ __forceinline__ int solve_constraints(EnvLds& s, const Params& P, con
     }
     int it = 0, lev_hist = 1;
     bool done = false;          // left the loop through one of mj_solNewton's termination tests (not the iteration cap)
+    const unsigned conlev = contact_levels(s, L8);
     for (; it < P.max_iter; it++) {
         // gradient = M (qacc - qacc_s) - J^T f: one projection of the body wrenches I_b sacc_b - contact forces
         wrench_project<NT, OBJ>(s, P, sacc, s.qacc, s.qacc_s, s.grad, true, true, tid);
-        float g2 = 0.f, changed = 0.f;
+        float g2 = 0.f, changed = 0.f, deep = 0.f;
         for (int i = tid; i < D_NV; i += NT) {
             float g = s.grad[i];
             g2 += g * g;
@@ -1077,8 +1083,9 @@ __device__ __forceinline__ int solve_constraints(EnvLds& s, const Params& P, con
             const float ex = (i >= 6 && s.lim_jar[i - 6] < 0.f) ? s.lim_D[i - 6] : 0.f;
             if (ex != s.extra[i]) changed = 1.f;
             s.extra[i] = ex;
+            if (ex != 0.f) deep = fmaxf(deep, (float)s.bdep[s.dbody[i]]);     // active joint limit: its body's level is dirty
         }
-        changed += active_set_changed<NT>(s, P, tid);
+        changed += active_set_changed<NT>(s, P, tid, deep);
         g2 = block_sum<NT>(s, g2, tid);
         changed = block_sum<NT>(s, changed, tid);
         KP_SYNC();
@@ -1087,8 +1094,8 @@ __device__ __forceinline__ int solve_constraints(EnvLds& s, const Params& P, con
         // stands the factorisation of the previous iteration is reused (mj_solNewton updates its Cholesky factor the same way)
         if (it == 0 || changed > 0.f) {
             // levels an earlier factorisation of this substep rewrote no longer hold the smooth solve's factors: the clean range only shrinks
-            lev_hist = max(lev_hist, first_clean_level<NT>(s, P, tid));
-            aba_solve<NT, OBJ>(s, P, L8, s.x, s.search, true, tid, lev_hist);
+            lev_hist = max(lev_hist, first_clean_level<NT>(s, deep, tid));
+            aba_solve<NT, OBJ>(s, P, L8, s.x, s.search, true, tid, lev_hist, nullptr, nullptr, nullptr, conlev);
             nfact++;
         }
         else aba_resolve(s, L8, s.x, nullptr, s.search);
@@ -1497,7 +1504,7 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
         // gradient: humanoid dofs (mres - J^T f) and object wrenches
         wrench_project<NT, true>(s, P, sacc, s.qacc, s.qacc_s, s.grad, true, true, tid);
         if (nobj > 0) { con_prepare<NT>(s, P, tid); obj_gradient(s, tid); }
-        float g2 = 0.f, changed = 0.f;
+        float g2 = 0.f, changed = 0.f, deep = 0.f;
         for (int i = tid; i < D_NV; i += NT) {
             const float g = s.grad[i];
             g2 += g * g;
@@ -1505,8 +1512,9 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
             const float ex = (i >= 6 && s.lim_jar[i - 6] < 0.f) ? s.lim_D[i - 6] : 0.f;
             if (ex != s.extra[i]) changed = 1.f;
             s.extra[i] = ex;
+            if (ex != 0.f) deep = fmaxf(deep, (float)s.bdep[s.dbody[i]]);     // active joint limit: its body's level is dirty
         }
-        changed += active_set_changed<NT>(s, P, tid);
+        changed += active_set_changed<NT>(s, P, tid, deep);
         if (tid < nobj) {   // gradient in joint coordinates: [g_l ; R^T (g_a + r x g_l)], r = o - body origin
             const S6 g = lds6(s.ogr + 6 * tid);
             const V3 t = g.a + cross(ld3(s.xpos) - ld3(s.oq + 7 * tid), g.l);
@@ -1538,7 +1546,7 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
         // the Schur-complement columns when a hull touches an object, pass n: the back-substitution)
         if (refactor) {
             if (no6 > 0) obj_hessian(s, P, s.ogr, -1.0f, tid);
-            lev_hist = max(lev_hist, first_clean_level<NT>(s, P, tid));   // the clean range only shrinks within a substep
+            lev_hist = max(lev_hist, first_clean_level<NT>(s, deep, tid));   // the clean range only shrinks within a substep
             aba_solve<NT, true>(s, P, L8, s.x, s.search, true, tid, lev_hist);     // y0 = H_hh^-1 (-g_h); sv = its spatial accelerations
             if (couple) { obj_coupling_u(s, P, s.ot, tid); if (tid < no6) s.Sm[ST * tid + no6] += s.ot[tid]; KP_SYNC(); }     // rhs_o -= H_oh y0
         }
