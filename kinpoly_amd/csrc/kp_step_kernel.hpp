@@ -138,8 +138,9 @@ __device__ __forceinline__ V3 frame_world(const Frame& f, V3 c) { return c.x * f
 // Phases, so that the level-serial chain stays short:
 //   0. half-angle sin/cos of all 69 hinge angles, one lane per hinge (scratch: s.U, free outside the ABA passes), then per
 //      body (parallel) the local rotation qz qy qx and the second / third hinge axis in the parent frame;
-//   K. level-synchronous chain (lane = body): world pose, motion axes cdof, spatial velocity cvel and the
-//      velocity-product acceleration cacc (mj_kinematics + mj_comVel + the forward half of mj_rne);
+//   K. two short level-synchronous chains (lane = body) with a body-parallel block between them: world pose; then motion axes cdof
+//      and each body's own velocity terms; then spatial velocity cvel and the velocity-product acceleration cacc
+//      (mj_kinematics + mj_comVel + the forward half of mj_rne);
 //   B. body-parallel (24 lanes at once): COM, world inertia about o, body wrench fb = I a + v x* I v.  qfrc_bias itself
 //      (backward half of mj_rne: subtree sums + projection on the dofs) is never formed: the solves take fb as bias force.
 template <int NT>
@@ -177,37 +178,59 @@ __device__ __forceinline__ void forward_kin_bias(EnvLds& s, const DevTables& T, 
         sts6(s.sv, S6{ww, vl}); sts6(s.sa, S6{v3(0.f, 0.f, 0.f), v3(-P.gx, -P.gy, -P.gz) + cross(vl, ww)});
     }
     KP_SYNC();
+    // K1. pose chain (level-synchronous, lane = body): world position and orientation only
 #pragma nounroll
     for (int lev = 1; lev < D_NLEV; lev++) {
         if (depth == lev) {
             const int b = tid;
             const int p = s.bpar[b];
-            const int d0 = 6 + 3 * (b - 1);
-            // one LDS round: parent pose / velocity / acceleration, own joint state
-            const V3 o = ld3(s.xpos);
-            Q4 q = Q4{s.xquat[4 * p], s.xquat[4 * p + 1], s.xquat[4 * p + 2], s.xquat[4 * p + 3]};
+            const Q4 q = Q4{s.xquat[4 * p], s.xquat[4 * p + 1], s.xquat[4 * p + 2], s.xquat[4 * p + 3]};
             const V3 ppos = ld3(s.xpos + 3 * p);
-            S6 cv = lds6(s.sv + 6 * p), ca = lds6(s.sa + 6 * p);
-            const float qds[3] = {s.qvel[d0], s.qvel[d0 + 1], s.qvel[d0 + 2]};
             const float* f = jf + 10 * b;
             const Q4 ql = Q4{f[0], f[1], f[2], f[3]};
-            const V3 a1 = ld3(f + 4), a2 = ld3(f + 7);
-            float R[9];
-            q2mat(q, R);                                       // parent rotation: the three hinge axes are R e_z, R a1, R a2
-            const V3 pos = ppos + mulmat(R, bpos);
-            const V3 r = o - pos;
-            const V3 axes[3] = {v3(R[2], R[5], R[8]), mulmat(R, a1), mulmat(R, a2)};
-#pragma unroll
-            for (int j = 0; j < 3; j++) {
-                const S6 cd = S6{axes[j], cross(axes[j], r)};
-                sts6(s.cdof + 6 * (d0 + j), cd);
-                const S6 cdd = cross_motion(cv, cd);
-                cv = cv + qds[j] * cd; ca = ca + qds[j] * cdd;
-            }
-            q = qnormalize(qmul(q, ql));
+            const V3 pos = ppos + qrot(q, bpos);
+            const Q4 qn = qnormalize(qmul(q, ql));
             st3(s.xpos + 3 * b, pos);
-            s.xquat[4 * b] = q.w; s.xquat[4 * b + 1] = q.x; s.xquat[4 * b + 2] = q.y; s.xquat[4 * b + 3] = q.z;
-            sts6(s.sv + 6 * b, cv); sts6(s.sa + 6 * b, ca);
+            s.xquat[4 * b] = qn.w; s.xquat[4 * b + 1] = qn.x; s.xquat[4 * b + 2] = qn.y; s.xquat[4 * b + 3] = qn.z;
+        }
+        KP_SYNC();
+    }
+    // K2. body-parallel: motion axes of the three hinges (about o) and the body's own share of the velocity chain.  With
+    // run_j = sum_{i<j} qd_i cdof_i the level-serial recursion  cv += qd_j cdof_j,  ca += qd_j (cv x cdof_j)  splits into
+    //   cv_b = cv_p + dv,   ca_b = ca_p + cv_p x dv + loc,   dv = run_3,   loc = sum_j qd_j (run_j x cdof_j)
+    // (x = cross_motion, bilinear), so that only two 6-vector updates per body remain on the chain.
+    S6 dv = S6{v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f)}, loc = dv;
+    if (tid >= 1 && tid < D_NB) {
+        const int b = tid;
+        const int p = s.bpar[b];
+        const int d0 = 6 + 3 * (b - 1);
+        const V3 o = ld3(s.xpos);
+        const Q4 q = Q4{s.xquat[4 * p], s.xquat[4 * p + 1], s.xquat[4 * p + 2], s.xquat[4 * p + 3]};
+        const V3 r = o - ld3(s.xpos + 3 * b);
+        const float qds[3] = {s.qvel[d0], s.qvel[d0 + 1], s.qvel[d0 + 2]};
+        const float* f = jf + 10 * b;
+        const V3 a1 = ld3(f + 4), a2 = ld3(f + 7);
+        float R[9];
+        q2mat(q, R);                                           // parent rotation: the three hinge axes are R e_z, R a1, R a2
+        const V3 axes[3] = {v3(R[2], R[5], R[8]), mulmat(R, a1), mulmat(R, a2)};
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const S6 cd = S6{axes[j], cross(axes[j], r)};
+            sts6(s.cdof + 6 * (d0 + j), cd);
+            if (j > 0) loc = loc + qds[j] * cross_motion(dv, cd);
+            dv = dv + qds[j] * cd;
+        }
+    }
+    KP_SYNC();
+    // K3. velocity chain (level-synchronous): spatial velocity cvel and velocity-product acceleration cacc
+#pragma nounroll
+    for (int lev = 1; lev < D_NLEV; lev++) {
+        if (depth == lev) {
+            const int b = tid;
+            const int p = s.bpar[b];
+            const S6 cvp = lds6(s.sv + 6 * p), cap = lds6(s.sa + 6 * p);
+            sts6(s.sv + 6 * b, cvp + dv);
+            sts6(s.sa + 6 * b, cap + cross_motion(cvp, dv) + loc);
         }
         KP_SYNC();
     }
