@@ -537,7 +537,10 @@ __device__ __forceinline__ void aba_solve(EnvLds& s, const Params& P, const Lane
         }
         if (active && rowok) {
 #pragma unroll
-            for (int k = 0; k < 8; k++) if (L.col[k] < 6 && r <= L.col[k]) s.IAa[22 * b + L.idx21[k]] = IAx[k];
+            for (int k = 0; k < 8; k++) {      // upper triangle only; the other lanes' copies go to a scrap word instead of eight exec-masked stores
+                float* dst = (L.col[k] < 6 && r <= L.col[k]) ? s.IAa + 22 * b + L.idx21[k] : s.red + 7;
+                *dst = IAx[k];
+            }
             s.pAa[6 * b + r] = pA;
         }
         KP_SYNC();
