@@ -1042,7 +1042,9 @@ __device__ __forceinline__ float line_search(EnvLds& s, const Params& P, float g
         const bool ok = j < D_NU && s.lim_sgn[jj] != 0.f;
         la[n] = ok ? s.lim_jar[jj] : 0.f; lb[n] = ok ? s.lim_jv[jj] : 0.f; lD[n] = ok ? s.lim_D[jj] * lb[n] : 0.f;
     }
-    float alpha = 0.f, lo = 0.f, hi = 3.0e38f;
+    // The search direction solves H search = -grad with the Hessian of the current active set, so phi'(0) = -phi''(0) and the Newton
+    // step from alpha = 0 is 1: the first evaluation happens there, bracketed by lo = 0 (descent direction).
+    float alpha = 1.f, lo = 0.f, hi = 3.0e38f;
     for (int ls = 0; ls < 20; ls++) {
         float d1 = 0.f, d2 = 0.f;
 #pragma unroll
@@ -1051,9 +1053,9 @@ __device__ __forceinline__ float line_search(EnvLds& s, const Params& P, float g
         for (int n = 0; n < LR; n++) { const float x = fmaf(alpha, lb[n], la[n]); if (x < 0.f) { d1 += x * lD[n]; d2 += lb[n] * lD[n]; } }
         d1 = block_sum<NT>(s, d1, tid); d2 = block_sum<NT>(s, d2, tid);
         const float dphi = g0 + alpha * h0 + d1, ddphi = h0 + d2;
-        if (!(ddphi > 0.f)) break;
+        if (!(ddphi > 0.f)) { if (ls == 0) alpha = 0.f; break; }
         if (dphi < 0.f) lo = alpha; else hi = alpha;
-        float an = alpha - dphi / ddphi;
+        float an = alpha - dphi * rcp_nr(ddphi);
         if (!(an > lo && an < hi)) an = hi < 1.0e38f ? 0.5f * (lo + hi) : 2.0f * alpha + 1.0f;
         const float step = an - alpha;
         alpha = an;
