@@ -86,7 +86,7 @@ def rollout_steps(sampler, k, a_track=None, wild=False):
         for _ in range(k):
             action, sampler.hx = pol.select_action(sampler.obs, sampler.hx, wild, env.gen)
             if a_track is not None:                              # the policy's GEMMs ran; a trained policy's output stands in for theirs
-                action = action * 0.0 + a_track + (0.0 if wild else 0.04) * torch.randn(action.shape, device=action.device, generator=env.gen)
+                action = a_track if wild else torch.add(a_track, torch.randn(action.shape, device=action.device, generator=env.gen), alpha=0.04)
             obs, _, done, info = env.step(action.contiguous())
             if wild:
                 early = done & (info["percent"] != 1)
@@ -96,7 +96,7 @@ def rollout_steps(sampler, k, a_track=None, wild=False):
             else:
                 n_done += done.sum()
             sampler.obs = env.reset(done).clone()
-            sampler.hx = sampler.hx * (~done).float().unsqueeze(1)
+            sampler.hx = sampler.hx.masked_fill(done.unsqueeze(1), 0.0)
     return n_done
 
 

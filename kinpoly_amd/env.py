@@ -159,11 +159,16 @@ class BatchedHumanoidAREnv:
             self.obj_qpos = self.obj7 = None
         self._ctx_struct = self.sim.make_ctx(T, c["head_pose"], c["head_vels"], c["obj_head_relative_poses"], c["action_one_hot"],
                                              c["gt_bquat"], c["gt_wbpos"], self.cur_t, obj_qpos=self.obj7, row=self.row)
+        self._refresh_len()
 
     @property
     def ctx_len(self):
-        """ar_context['len'] of every env's current clip (int32 [N])."""
-        return self.row_len[self.row.long()]
+        """ar_context['len'] of every env's current clip (int32 [N]); cached, refreshed when rows or lengths change."""
+        return self._clen
+
+    def _refresh_len(self):
+        self._clen = self.row_len[self.row.long()]
+        self._t_end = self._clen.clamp(max=int(min(self.env_episode_len, 2 ** 31 - 1)))      # the step that ends the episode (:291-293)
 
     def set_rows(self, new_row: torch.Tensor, env_mask: torch.Tensor | None = None):
         """Put the masked envs on other context rows (device op, no copy): the new episode's clip of agent_ar.py:519-535.
@@ -173,6 +178,7 @@ class BatchedHumanoidAREnv:
             self.row.copy_(nr)
         else:
             self.row.copy_(torch.where(env_mask.to(self.device, torch.bool), nr, self.row))
+        self._refresh_len()
 
     def ctx_rows(self, key):
         """ctx[key] gathered to the envs' current rows: [N, ...]."""
@@ -231,11 +237,11 @@ class BatchedHumanoidAREnv:
             self.obj7.copy_(torch.where(self._obj_has[:, None], torch.gather(self._obj35, 1, self._obj_cols), self.obj7))
         self.cur_t += 1
         reward, info6, fail, diffs = sim.term_reward(self._ctx_struct, self.reward_cfg, self._reward, self._info, self._fail, self._diffs)
-        clen = self.ctx_len
-        end = (self.cur_t >= self.env_episode_len) | (self.cur_t >= clen)
-        done = fail.bool() | end
+        end = self.cur_t >= self._t_end                  # cur_t >= env_episode_len or cur_t >= ar_context len (:291-293)
+        failed = fail.view(torch.bool).clone()           # the kernel writes 0 / 1 into a buffer the next step reuses
+        done = failed | end
         obs = sim.obs_ar(self._ctx_struct, self._obs)
-        info = {"fail": fail.bool(), "end": end, "percent": self.cur_t.float() / clen, "cc_action": cc_action, "cc_state": cc_obs,
+        info = {"fail": failed, "end": end, "percent": self.cur_t / self._clen, "cc_action": cc_action, "cc_state": cc_obs,
                 "custom_reward": reward, "custom_info": info6, "body_diff": diffs}
         return obs, torch.ones(self.n, device=self.device), done, info
 

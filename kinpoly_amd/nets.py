@@ -126,7 +126,7 @@ class PolicyMCP(nn.Module):
         mean, log_std = self.forward(x)
         if mean_action:
             return mean
-        return mean + torch.exp(log_std) * torch.randn(mean.shape, device=mean.device, dtype=mean.dtype, generator=generator)
+        return torch.addcmul(mean, torch.exp(log_std), torch.randn(mean.shape, device=mean.device, dtype=mean.dtype, generator=generator))
 
 
 class _StepRNN(nn.Module):
@@ -161,7 +161,7 @@ class KinPolicy(nn.Module):
         if mean_action:
             return mean, hx
         noise = torch.randn(mean.shape, device=mean.device, dtype=mean.dtype, generator=generator)
-        return mean + torch.exp(self.action_log_std) * noise, hx
+        return torch.addcmul(mean, torch.exp(self.action_log_std), noise), hx
 
     def log_prob(self, mean, action):
         """DiagGaussian.log_prob summed over the action dims (uhc/khrylib/rl/core/distributions.py:22-23)."""

@@ -150,7 +150,7 @@ class VectorSampler:
         elif self.source is not None:
             self._refill()
         f = lambda *s: torch.empty((N, T, *s), device=dev)  # noqa: E731
-        S, A, R, M = f(105), f(80), f(), f()
+        S, A, R = f(105), f(80), f()
         E = torch.empty((N, T), dtype=torch.bool, device=dev); F = torch.empty((N, T), dtype=torch.bool, device=dev)
         Q = f(76) if self.record_qpos else None
         G = f(76) if self.record_qpos else None
@@ -175,7 +175,6 @@ class VectorSampler:
             A[:, t] = action
             R[:, t] = info["custom_reward"]
             F[:, t] = info["fail"]
-            M[:, t] = (~done).float()
             D[:, t] = done; PC[:, t] = info["percent"]; MT[:, t] = meta
             if full:
                 NS[:, t] = obs; RQ[:, t] = env.sim.get("qpos"); CA[:, t] = info["cc_action"]; CS[:, t] = info["cc_state"]
@@ -188,8 +187,9 @@ class VectorSampler:
                 self.level = torch.where(over, self.level, nxt)
                 env.set_rows((self.level * N + ar).to(torch.int32), done)
             self.obs = env.reset(done).clone()
-            self.hx = self.hx * (~done).float().unsqueeze(1)
+            self.hx = self.hx.masked_fill(done.unsqueeze(1), 0.0)
             self.fresh = done
+        M = (~D).float()
         # one host transfer per call: finished episodes -> freq_dict, launch status
         status = int(env.sim.status_tensor()[2])
         if status:
