@@ -49,8 +49,8 @@ struct Params {
 
 // ------------------------------------------------------------------ LDS layout (floats): ~19.8 KB
 struct __attribute__((aligned(16))) EnvLds {
-    float qpos[76], qvel[76], tq[76], act[76];
-    float xpos[72], xquat[96], xipos[72];
+    float qpos[76], qvel[76];             // PD targets and actions are read from their HBM rows once per substep (spd_torque_rfc)
+    float xpos[72], xquat[96];            // body COMs (xipos) are recomputed where they are read: collision centres, the read-out
     float cinert[240];                    // body spatial inertia about o, world axes (10 floats / body)
     float cdof[450];                      // motion axis of every dof [ang; lin] about o
     float sv[156], sa[144], sw[144];      // per-body spatial scratch (velocity / acceleration / wrench); sv[144..155]: the two object slots
@@ -59,16 +59,18 @@ struct __attribute__((aligned(16))) EnvLds {
                                           // record 24 are kept 0 so that padded / absent operands load a zero without exec masking
     float arm[76];                        // dof armature
     float fb[144];                        // bias wrench of every body (gyroscopic + Coriolis + gravity), about o: enters the ABA passes as pA
-    float qacc_s[76], qacc[76], grad[76], search[76], Mv[76], mres[76], x[76], extra[76];
-    float applied_pad[2], applied[6], ctrl[72];   // applied ++ ctrl is qfrc_applied + qfrc_actuator as one 76-vector
-    float con_pos[D_MAXCON * 3], con_dist[D_MAXCON], con_D[D_MAXCON];
-    int con_body[D_MAXCON];
-    int con_start[D_NB + 3];              // contacts are grouped by the entity carrying the vertex: 24 hulls, then the object slots
+    float qacc_s[76], qacc[76], search[76], Mv[76], mres[76], x[76], extra[76];
+    float applied_pad[2], applied[6], ctrl[72];   // applied ++ ctrl is qfrc_applied + qfrc_actuator as one 76-vector: written by spd_torque_rfc, read by
+                                          // the smooth solve; between that solve and the next substep the same words hold the Newton gradient
+    __device__ __forceinline__ float* grad() { return applied; }
+    float con_pos[D_MAXCON * 3], con_D[D_MAXCON];   // con_D: contact distance from collide() until make_constraint() turns it into the row weight D
     float jar3[D_MAXCON * 3], jv3[D_MAXCON * 3];   // contact-frame (normal, t1, t2) residuals J qacc - aref and J search
     float lim_sgn[72], lim_aref[72], lim_D[72], lim_jar[72], lim_jv[72];
     float red[8];
     unsigned char bpar[D_NB], bsub[D_NB], bdep[D_NB], dbody[76];
     unsigned char con_act[D_MAXCON];      // active pyramid rows (4 bits) of every contact at the last factorisation
+    unsigned char con_body[D_MAXCON];     // entity carrying the vertex: 0..23 hull, 24 + k object slot k
+    unsigned char con_start[D_NB + 4];    // contacts are grouped by that entity: 24 hulls, then the object slots (values <= D_MAXCON)
     int ncon, nlim, flag;
 };
 

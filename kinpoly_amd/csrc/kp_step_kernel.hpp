@@ -241,7 +241,6 @@ __device__ __forceinline__ void forward_kin_bias(EnvLds& s, const DevTables& T, 
         q2mat(Q4{s.xquat[4 * b], s.xquat[4 * b + 1], s.xquat[4 * b + 2], s.xquat[4 * b + 3]}, R);
         const S6 cv = lds6(s.sv + 6 * b), ca = lds6(s.sa + 6 * b);
         const V3 xi = pos + mulmat(R, ld3(T.body_ipos + 3 * b));
-        st3(s.xipos + 3 * b, xi);
         const float* Ib = T.body_inertia + 6 * b;
         float I3[9] = {Ib[0], Ib[3], Ib[4], Ib[3], Ib[1], Ib[5], Ib[4], Ib[5], Ib[2]};
         float Tm[9], W[9];
@@ -595,18 +594,19 @@ __device__ __forceinline__ void aba_resolve(EnvLds& s, const Lane8& L, const flo
 
 // ---------------------------------------------------------------- stable-PD torque + residual force (reference controller)
 template <int NT, bool OBJ>
-__device__ __forceinline__ void spd_torque_rfc(EnvLds& s, const DevTables& T, const Params& P, const Lane8& L8, int depth, int tid) {
+// tq / act: this env's rows of the PD target and the action in HBM (null: zeros); read here once per substep instead of living in LDS
+__device__ __forceinline__ void spd_torque_rfc(EnvLds& s, const DevTables& T, const Params& P, const Lane8& L8, int depth, int tid, const float* __restrict__ tq, const float* __restrict__ act) {
     for (int i = tid; i < D_NV; i += NT) {
         float ep = 0.f, kp = 0.f, kd = 0.f;
         if (i >= 6) {
             int j = i - 6;
-            float q = s.qpos[i + 1], base = s.tq[i + 1];
+            float q = s.qpos[i + 1], base = tq ? tq[i + 1] : 0.f;
             // the reference's 2 pi unwrap loops (humanoid_im.py:447-452) in closed form: no trip count that depends on the data, so a
             // non-finite or absurd target cannot spin the wavefront (it yields a non-finite state, which diag flags)
             const float dq = base - q;
             if (dq > 3.14159265358979f) base -= 6.28318530717959f * ceilf((dq - 3.14159265358979f) * 0.159154943091895f);
             else if (dq < -3.14159265358979f) base += 6.28318530717959f * ceilf((-dq - 3.14159265358979f) * 0.159154943091895f);
-            float target = base + s.act[j] * T.ascale[j];
+            float target = base + (act ? act[j] : 0.f) * T.ascale[j];
             kp = T.kp[j]; kd = T.kd[j];
             ep = q + s.qvel[i] * P.h - target;
         }
@@ -618,16 +618,19 @@ __device__ __forceinline__ void spd_torque_rfc(EnvLds& s, const DevTables& T, co
     aba_solve<NT, OBJ>(s, P, L8, s.x, s.x, false, tid, D_NLEV, s.fb);
     for (int j = tid; j < D_NU; j += NT) {
         int i = j + 6;
-        float tq = -T.kp[j] * s.search[i] - T.kd[j] * (s.qvel[i] + s.x[i] * P.h);
+        float tau = -T.kp[j] * s.search[i] - T.kd[j] * (s.qvel[i] + s.x[i] * P.h);
         float lim = T.tlim[j];
-        s.ctrl[j] = fminf(fmaxf(tq, -lim), lim);
+        s.ctrl[j] = fminf(fmaxf(tau, -lim), lim);
     }
     if (tid == 0) {  // rfc_implicit
         Q4 cq = qmul(Q4{s.qpos[3], s.qpos[4], s.qpos[5], s.qpos[6]}, Q4{P.br_inv[0], P.br_inv[1], P.br_inv[2], P.br_inv[3]});
         float hn = sqrtf(cq.w * cq.w + cq.z * cq.z);
         Q4 hq = Q4{cq.w / hn, 0.f, 0.f, cq.z / hn};
-        V3 f = qrot(hq, v3(s.act[69] * P.rfc_scale, s.act[70] * P.rfc_scale, s.act[71] * P.rfc_scale));
-        float vf[6] = {f.x, f.y, f.z, s.act[72] * P.rfc_scale, s.act[73] * P.rfc_scale, s.act[74] * P.rfc_scale};
+        float ar[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) ar[k] = act ? act[69 + k] : 0.f;
+        V3 f = qrot(hq, v3(ar[0] * P.rfc_scale, ar[1] * P.rfc_scale, ar[2] * P.rfc_scale));
+        float vf[6] = {f.x, f.y, f.z, ar[3] * P.rfc_scale, ar[4] * P.rfc_scale, ar[5] * P.rfc_scale};
 #pragma unroll
         for (int k = 0; k < 6; k++) s.applied[k] = fminf(fmaxf(vf[k], -P.rfc_lim), P.rfc_lim);
     }
@@ -656,7 +659,7 @@ __device__ __forceinline__ float geom_rbound(const float* g) { return g[0] == 0.
 template <bool OBJ>
 __device__ __forceinline__ void put_contact(EnvLds& s, int c, V3 pos, float dist, V3 nrm, int A, int B, float iw2) {
     st3(s.con_pos + 3 * c, pos);
-    s.con_dist[c] = dist; s.con_body[c] = A;
+    s.con_D[c] = dist; s.con_body[c] = (unsigned char)A;          // con_D holds the distance until make_constraint
     if constexpr (OBJ) {
         EnvLdsObj& so = static_cast<EnvLdsObj&>(s);
         st3(so.con_n + 3 * c, nrm); so.con_iw2[c] = iw2; so.con_b2[c] = (signed char)B;
@@ -730,7 +733,7 @@ __device__ __forceinline__ void collide(EnvLds& s, const DevTables& T, const Par
                     EnvLdsObj& so = static_cast<EnvLdsObj&>(s);
                     const float* g = so.geom + 17 * gi;
                     const GeomSupport ga(g);
-                    const HullSupport hb(xb, R, ld3(s.xipos + 3 * b), v, tid < nvb);
+                    const HullSupport hb(xb, R, xb + mulmat(R, ld3(T.body_ipos + 3 * b)), v, tid < nvb);       // centre = the body's COM (xipos)
                     Contact c;
                     if (convex_pair(ga, hb, P.margin, c) && ncon < D_MAXCON) {
                         if (tid == 0) put_contact<OBJ>(s, ncon, c.pos, c.dist, c.n, b, so.gobj[gi] < 0 ? -1 : D_NB + so.gobj[gi], g[16]);
@@ -818,7 +821,7 @@ __device__ __forceinline__ void make_constraint(EnvLds& s, const DevTables& T, c
     const V3 o = ld3(s.xpos);
     for (int c = tid; c < s.ncon; c += NT) {
         int b = s.con_body[c];
-        float r = s.con_dist[c] - P.margin;
+        float r = s.con_D[c] - P.margin;                    // collide() left the distance here
         float imp = impedance(P, r);
         float iwA = T.body_invw[b < D_NB ? b : 0];
         if (OBJ && b >= D_NB) iwA = static_cast<EnvLdsObj&>(s).oc[13 * (b - D_NB) + 10];
@@ -1102,10 +1105,10 @@ __device__ __forceinline__ int solve_constraints(EnvLds& s, const Params& P, con
     const unsigned conlev = contact_levels(s, L8);
     for (; it < P.max_iter; it++) {
         // gradient = M (qacc - qacc_s) - J^T f: one projection of the body wrenches I_b sacc_b - contact forces
-        wrench_project<NT, OBJ>(s, P, sacc, s.qacc, s.qacc_s, s.grad, true, true, tid);
+        wrench_project<NT, OBJ>(s, P, sacc, s.qacc, s.qacc_s, s.grad(), true, true, tid);
         float g2 = 0.f, changed = 0.f, deep = 0.f;
         for (int i = tid; i < D_NV; i += NT) {
-            float g = s.grad[i];
+            float g = s.grad()[i];
             g2 += g * g;
             s.x[i] = -g;
             const float ex = (i >= 6 && s.lim_jar[i - 6] < 0.f) ? s.lim_D[i - 6] : 0.f;
@@ -1530,11 +1533,11 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
     bool done = false;          // left the loop through one of mj_solNewton's termination tests (not the iteration cap)
     for (; it < P.max_iter; it++) {
         // gradient: humanoid dofs (mres - J^T f) and object wrenches
-        wrench_project<NT, true>(s, P, sacc, s.qacc, s.qacc_s, s.grad, true, true, tid);
+        wrench_project<NT, true>(s, P, sacc, s.qacc, s.qacc_s, s.grad(), true, true, tid);
         if (nobj > 0) { con_prepare<NT>(s, P, tid); obj_gradient(s, tid); }
         float g2 = 0.f, changed = 0.f, deep = 0.f;
         for (int i = tid; i < D_NV; i += NT) {
-            const float g = s.grad[i];
+            const float g = s.grad()[i];
             g2 += g * g;
             s.x[i] = -g;
             const float ex = (i >= 6 && s.lim_jar[i - 6] < 0.f) ? s.lim_D[i - 6] : 0.f;
@@ -1581,7 +1584,7 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
         if (!(refactor && no6 == 0)) {
             int kj = refactor ? (couple ? 0 : no6) : -1;
             while (true) {
-                const float* rhsp = nullptr; const float* wr = nullptr; float* outp = s.grad;     // scratch: -grad already sits in s.x
+                const float* rhsp = nullptr; const float* wr = nullptr; float* outp = s.grad();     // scratch: -grad already sits in s.x
                 if (kj == -1) { rhsp = s.x; outp = s.search; }
                 else if (kj < no6) {
                     if (!((cmask >> (kj / 6)) & 1u)) { kj += 6; continue; }     // no hull presses on this object: H_ho e = 0, column done
@@ -1672,9 +1675,11 @@ __device__ __forceinline__ void step_body(StepArgs A, const int env_in, const in
     const V3 bpos = tid < D_NB ? ld3(T.body_pos + 3 * tid) : v3(0.f, 0.f, 0.f);
 
     // ---- load: derived state first (the state the last forward pass ran on), then the real state
-    for (int i = tid; i < D_NQ; i += NT) { s.qpos[i] = gld<Q>(A.qpos_d + (size_t)env * D_NQ + i); s.tq[i] = A.target_qpos ? A.target_qpos[(size_t)env * D_NQ + i] : 0.f; }
+    const float* tq_row = A.target_qpos ? A.target_qpos + (size_t)env * D_NQ : nullptr;
+    const float* act_row = A.action ? A.action + (size_t)env * D_NV : nullptr;
+    for (int i = tid; i < D_NQ; i += NT) s.qpos[i] = gld<Q>(A.qpos_d + (size_t)env * D_NQ + i);
     for (int i = tid; i < D_NV; i += NT) {
-        s.qvel[i] = gld<Q>(A.qvel_d + (size_t)env * D_NV + i); s.act[i] = A.action ? A.action[(size_t)env * D_NV + i] : 0.f;
+        s.qvel[i] = gld<Q>(A.qvel_d + (size_t)env * D_NV + i);
         s.arm[i] = T.dof_armature[i]; s.dbody[i] = T.dof_body[i]; s.extra[i] = 0.f; s.qacc[i] = gld<Q>(A.warm + (size_t)env * D_NV + i);
     }
     if (tid < D_NB) { s.bpar[tid] = (unsigned char)(T.body_parent[tid] < 0 ? 0 : T.body_parent[tid]); s.bsub[tid] = T.body_subtree[tid]; s.bdep[tid] = T.body_depth[tid]; }
@@ -1724,7 +1729,7 @@ __device__ __forceinline__ void step_body(StepArgs A, const int env_in, const in
     for (int sub = 0; sub < A.n_substeps; sub++) {
         if (prof) t0 = __builtin_readcyclecounter();
         // stale mode: the controller sees M / bias of the previous forward pass (cinert, cdof, bias still in LDS)
-        if (P.stale) spd_torque_rfc<NT, OBJ>(s, T, P, L8, depth, tid);
+        if (P.stale) spd_torque_rfc<NT, OBJ>(s, T, P, L8, depth, tid, tq_row, act_row);
         KP_T(0)
         // ---- mj_forward at the current state
 #pragma unroll
@@ -1735,10 +1740,20 @@ __device__ __forceinline__ void step_body(StepArgs A, const int env_in, const in
         if constexpr (OBJ) obj_forward(s, P, tid);
         KP_T(1)
         collide<NT, OBJ>(s, T, P, tid);
+        if (A.dbg_contacts && sub == A.n_substeps - 1) {      // test hook: the contact set of the last collision pass (con_D still holds the distance)
+            float* o = A.dbg_contacts + (size_t)env * (1 + D_MAXCON * 9);
+            if (tid == 0) o[0] = (float)s.ncon;
+            for (int c = tid; c < s.ncon; c += NT) {
+                float* r = o + 1 + 9 * c;
+                r[0] = (float)s.con_body[c]; r[2] = s.con_D[c]; r[3] = s.con_pos[3 * c]; r[4] = s.con_pos[3 * c + 1]; r[5] = s.con_pos[3 * c + 2];
+                if constexpr (OBJ) { const EnvLdsObj& so = static_cast<const EnvLdsObj&>(s); r[1] = (float)so.con_b2[c]; r[6] = so.con_n[3 * c]; r[7] = so.con_n[3 * c + 1]; r[8] = so.con_n[3 * c + 2]; }
+                else { r[1] = -1.f; r[6] = 0.f; r[7] = 0.f; r[8] = 1.f; }
+            }
+        }
         KP_T(2)
         make_constraint<NT, OBJ>(s, T, P, tid);                 // needs sv = cvel: before any aba_solve
         KP_T(3)
-        if (!P.stale) spd_torque_rfc<NT, OBJ>(s, T, P, L8, depth, tid);
+        if (!P.stale) spd_torque_rfc<NT, OBJ>(s, T, P, L8, depth, tid, tq_row, act_row);
         for (int i = tid; i < D_NV; i += NT) s.extra[i] = 0.f;
         KP_SYNC();
         // qacc_smooth = M^-1 qfrc_smooth; sv = its spatial accelerations; floor-only kernel: Mv/mres = those of (warm start - qacc_smooth) for the Newton solve
@@ -1785,7 +1800,11 @@ __device__ __forceinline__ void step_body(StepArgs A, const int env_in, const in
 #pragma unroll
     for (int n = 0; n < (D_NV + NT - 1) / NT; n++) { int i = tid + n * NT; if (i < D_NV) gst<Q>(A.qvel_d + (size_t)env * D_NV + i, qd_save_v[n]); }
     if (!Q || part == A.n_parts - 1) {      // read-outs: the last job of the control step only (earlier jobs' copies could land later from another L2)
-        for (int i = tid; i < 72; i += NT) { A.xpos[(size_t)env * 72 + i] = s.xpos[i]; A.xipos[(size_t)env * 72 + i] = s.xipos[i]; }
+        for (int i = tid; i < 72; i += NT) A.xpos[(size_t)env * 72 + i] = s.xpos[i];
+        if (tid < D_NB) {                   // xipos = xpos + R ipos of the same forward pass
+            const V3 xi = ld3(s.xpos + 3 * tid) + qrot(Q4{s.xquat[4 * tid], s.xquat[4 * tid + 1], s.xquat[4 * tid + 2], s.xquat[4 * tid + 3]}, ld3(T.body_ipos + 3 * tid));
+            st3(A.xipos + (size_t)env * 72 + 3 * tid, xi);
+        }
         for (int i = tid; i < 96; i += NT) A.xquat[(size_t)env * 96 + i] = s.xquat[i];
     }
     if constexpr (OBJ) {
@@ -1795,16 +1814,6 @@ __device__ __forceinline__ void step_body(StepArgs A, const int env_in, const in
                 if (tid < 7) { const float v = s.oq[7 * k + tid]; bad |= !(fabsf(v) < 1e10f); gst<Q>(A.obj_qpos + (size_t)env * 35 + 7 * oi + tid, v); }
                 if (tid < 6) { gst<Q>(A.obj_qvel + (size_t)env * 30 + 6 * oi + tid, s.ov[6 * k + tid]); gst<Q>(A.obj_warm + (size_t)env * 6 * D_MAXOBJ + 6 * k + tid, s.oqa[6 * k + tid]); }
             }
-        }
-    }
-    if (A.dbg_contacts && A.n_substeps > 0) {      // test hook: the contact set of the last collision pass
-        float* o = A.dbg_contacts + (size_t)env * (1 + D_MAXCON * 9);
-        if (tid == 0) o[0] = (float)s.ncon;
-        for (int c = tid; c < s.ncon; c += NT) {
-            float* r = o + 1 + 9 * c;
-            r[0] = (float)s.con_body[c]; r[2] = s.con_dist[c]; r[3] = s.con_pos[3 * c]; r[4] = s.con_pos[3 * c + 1]; r[5] = s.con_pos[3 * c + 2];
-            if constexpr (OBJ) { const EnvLdsObj& so = static_cast<const EnvLdsObj&>(s); r[1] = (float)so.con_b2[c]; r[6] = so.con_n[3 * c]; r[7] = so.con_n[3 * c + 1]; r[8] = so.con_n[3 * c + 2]; }
-            else { r[1] = -1.f; r[6] = 0.f; r[7] = 0.f; r[8] = 1.f; }
         }
     }
     if (bad) atomicOr(&s.flag, 1);
@@ -1858,8 +1867,8 @@ __global__ __launch_bounds__(64) void kp_mass_kernel(StepArgs A, float* __restri
         for (int i = tid; i < D_NV; i += NT) s.x[i] = i == j ? 1.f : 0.f;
         KP_SYNC();
         spatial_accumulate<NT>(s, s.x, depth, tid);
-        wrench_project<NT, false>(s, P, s.sv, s.x, nullptr, s.grad, true, false, tid);
-        for (int d = tid; d < D_NV; d += NT) Mout[((size_t)env * D_NV + d) * D_NV + j] = s.grad[d];
+        wrench_project<NT, false>(s, P, s.sv, s.x, nullptr, s.grad(), true, false, tid);
+        for (int d = tid; d < D_NV; d += NT) Mout[((size_t)env * D_NV + d) * D_NV + j] = s.grad()[d];
         KP_SYNC();
     }
 }
