@@ -65,7 +65,8 @@ struct __attribute__((aligned(16))) EnvLds {
     __device__ __forceinline__ float* grad() { return applied; }
     float con_pos[D_MAXCON * 3], con_D[D_MAXCON];   // con_D: contact distance from collide() until make_constraint() turns it into the row weight D
     float jar3[D_MAXCON * 3], jv3[D_MAXCON * 3];   // contact-frame (normal, t1, t2) residuals J qacc - aref and J search
-    float lim_sgn[72], lim_aref[72], lim_D[72], lim_jar[72], lim_jv[72];
+    float lim_D[72], lim_jar[72], lim_jv[72];   // joint-limit rows: lim_D = sign x weight (sign: +1 lower / -1 upper limit violated, 0 = no row);
+                                          // lim_jv holds the reference acceleration until the first J search product overwrites it
     float red[8];
     unsigned char bpar[D_NB], bsub[D_NB], bdep[D_NB], dbody[76];
     unsigned char con_act[D_MAXCON];      // active pyramid rows (4 bits) of every contact at the last factorisation
@@ -79,13 +80,12 @@ constexpr int D_MAXGEOM = 8;            // must equal MAXGEOM in oracle/kp_oracl
 constexpr int D_MAXOBJ = 2;             // must equal MAXOBJ in oracle/kp_oracle.c
 struct __attribute__((aligned(16))) EnvLdsObj : EnvLds {
     float con_n[D_MAXCON * 3];          // contact normal (world), pointing from the surface (floor / geom) into the vertex' entity
-    float con_iw2[D_MAXCON];            // invweight0 of the second body (0 for the floor)
     float geom[D_MAXGEOM * 17];         // type, size[3], pos[3], mat[9], invweight  (world frame)
     int ngeom, ngeom_static, nobj;
     // ---- dynamic free objects (slot k = entity 24 + k): spatial quantities about o like everything else
     signed char gobj[D_MAXGEOM];        // slot owning world geom g (-1: static)
-    signed char con_b2[D_MAXCON];       // entity carrying the surface: -1 world / static geom, 24 + k
-    float lgeom[D_MAXGEOM * 16];        // body-frame geoms of the dynamic objects, aligned with geom[]
+    signed char con_b2[D_MAXCON];       // entity carrying the surface: -1 the floor, -2 - g static geom g (its invweight0 is geom[17 g + 16]), 24 + k
+    unsigned char ggi[D_MAXGEOM];       // model geom (row of DevTables::obj_geoms: the body-frame geom) behind world geom g of a dynamic object
     float oq[D_MAXOBJ * 7], ov[D_MAXOBJ * 6], oc[D_MAXOBJ * 13];
     float oR[D_MAXOBJ * 9];
     float oI[D_MAXOBJ * 10], oIe[D_MAXOBJ * 10];   // spatial inertia (true / with the free-joint armature)

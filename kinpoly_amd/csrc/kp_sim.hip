@@ -220,7 +220,9 @@ int launch_step(kp_sim* s, const float* action, int nsub, const uint8_t* mask, b
     // more envs than resident wave slots: schedule the control step as jobs of substeps_per_job substeps pulled from a FIFO by one
     // resident wave per slot (kp_step_queue_kernel) instead of one workgroup per env, which ends on a long tail
     const int spj = s->model->substeps_per_job;
-    const int slots = s->model->queue_slots > 0 ? s->model->queue_slots : (obj ? s->wave_slots / 8 * 6 : s->wave_slots);
+    // resident waves: LDS is allocated in 1 280-byte granules, 128 per CU (tools/micro/lds_granule_probe.hip); 256 VGPRs allow 8 waves per CU
+    const int per_cu = std::min(8, 128 / (int)((lds + 1279) / 1280));
+    const int slots = s->model->queue_slots > 0 ? s->model->queue_slots : s->wave_slots / 8 * per_cu;
     int sizes[16], parts = 0;
     if (spj > 0 && nsub > 0) {
         parts = job_schedule(nsub, spj, s->model->job_taper, sizes);

@@ -657,12 +657,13 @@ __device__ __forceinline__ float geom_rbound(const float* g) { return g[0] == 0.
 // one lane appends a contact: vertex-side entity A (0..23 hull, 24 + k object slot), surface-side entity B (-1 world / static geom),
 // normal pointing from B's geom into A's
 template <bool OBJ>
-__device__ __forceinline__ void put_contact(EnvLds& s, int c, V3 pos, float dist, V3 nrm, int A, int B, float iw2) {
+// B: entity carrying the surface (-1 floor, -2 - g static geom g, 24 + k object slot k); its invweight0 is looked up by make_constraint
+__device__ __forceinline__ void put_contact(EnvLds& s, int c, V3 pos, float dist, V3 nrm, int A, int B) {
     st3(s.con_pos + 3 * c, pos);
     s.con_D[c] = dist; s.con_body[c] = (unsigned char)A;          // con_D holds the distance until make_constraint
     if constexpr (OBJ) {
         EnvLdsObj& so = static_cast<EnvLdsObj&>(s);
-        st3(so.con_n + 3 * c, nrm); so.con_iw2[c] = iw2; so.con_b2[c] = (signed char)B;
+        st3(so.con_n + 3 * c, nrm); so.con_b2[c] = (signed char)B;
     }
 }
 
@@ -725,8 +726,8 @@ __device__ __forceinline__ void collide(EnvLds& s, const DevTables& T, const Par
                     const int rank = __popcll(m & ((1ull << tid) - 1ull));
                     const int cnt = 1 + min(__popcll(m), D_CON_PER_GEOM - 1);
                     const int room = D_MAXCON - ncon;
-                    if (tid == idx && room > 0) put_contact<OBJ>(s, ncon, v3(xw.x, xw.y, xw.z - 0.5f * xw.z), xw.z, v3(0.f, 0.f, 1.f), b, -1, 0.f);
-                    if (ok && rank < D_CON_PER_GEOM - 1 && 1 + rank < room) put_contact<OBJ>(s, ncon + 1 + rank, v3(xj.x, xj.y, xj.z - 0.5f * xj.z), xj.z, v3(0.f, 0.f, 1.f), b, -1, 0.f);
+                    if (tid == idx && room > 0) put_contact<OBJ>(s, ncon, v3(xw.x, xw.y, xw.z - 0.5f * xw.z), xw.z, v3(0.f, 0.f, 1.f), b, -1);
+                    if (ok && rank < D_CON_PER_GEOM - 1 && 1 + rank < room) put_contact<OBJ>(s, ncon + 1 + rank, v3(xj.x, xj.y, xj.z - 0.5f * xj.z), xj.z, v3(0.f, 0.f, 1.f), b, -1);
                     ncon += min(cnt, max(room, 0));
                 } else if constexpr (OBJ) {
                     // mjc_Convex (libccd MPR): geom 1 = the box / cylinder, geom 2 = the hull; one contact, normal into the hull
@@ -736,7 +737,7 @@ __device__ __forceinline__ void collide(EnvLds& s, const DevTables& T, const Par
                     const HullSupport hb(xb, R, xb + mulmat(R, ld3(T.body_ipos + 3 * b)), v, tid < nvb);       // centre = the body's COM (xipos)
                     Contact c;
                     if (convex_pair(ga, hb, P.margin, c) && ncon < D_MAXCON) {
-                        if (tid == 0) put_contact<OBJ>(s, ncon, c.pos, c.dist, c.n, b, so.gobj[gi] < 0 ? -1 : D_NB + so.gobj[gi], g[16]);
+                        if (tid == 0) put_contact<OBJ>(s, ncon, c.pos, c.dist, c.n, b, so.gobj[gi] < 0 ? -2 - gi : D_NB + so.gobj[gi]);
                         ncon++;
                     }
                 }
@@ -775,7 +776,7 @@ __device__ __forceinline__ void collide(EnvLds& s, const DevTables& T, const Par
                     const int gb = __ffs((int)bits) - 2;
                     bits &= bits - 1u;
                     const float* h = gb < 0 ? nullptr : so.geom + 17 * gb;
-                    int n = 0, entB = -1; float iw2 = 0.f, sgn = 1.f;
+                    int n = 0, entB = -1; float sgn = 1.f;
                     if (gb < 0) {
                         if (g[0] == 0.f) {
                             // mjc_PlaneBox: lane = corner (bit 0 / 1 / 2 = +x / +y / +z); corners that point up or lie beyond the margin
@@ -792,7 +793,7 @@ __device__ __forceinline__ void collide(EnvLds& s, const DevTables& T, const Par
                     } else {
                         // geom 1 = the lower geom type (cylinder < box), then the lower geom id (ga); the stored normal runs from gb into ga
                         const bool a_first = !(g[0] == 0.f && h[0] != 0.f);
-                        entB = D_NB + so.gobj[gb]; iw2 = h[16]; sgn = a_first ? -1.f : 1.f;
+                        entB = D_NB + so.gobj[gb]; sgn = a_first ? -1.f : 1.f;
                         if (g[0] == 0.f && h[0] == 0.f) {
                             if (tid == 0) n = box_box(g, h, P.margin, rec, s.U);
                             n = __builtin_amdgcn_readfirstlane(n);
@@ -804,7 +805,7 @@ __device__ __forceinline__ void collide(EnvLds& s, const DevTables& T, const Par
                         }
                     }
                     n = min(n, D_MAXCON - ncon);
-                    if (tid < n) put_contact<OBJ>(s, ncon + tid, ld3(rec + 7 * tid + 1), rec[7 * tid], sgn * ld3(rec + 7 * tid + 4), D_NB + ka, entB, iw2);
+                    if (tid < n) put_contact<OBJ>(s, ncon + tid, ld3(rec + 7 * tid + 1), rec[7 * tid], sgn * ld3(rec + 7 * tid + 4), D_NB + ka, entB);
                     ncon += n;
                 }
             }
@@ -825,7 +826,13 @@ __device__ __forceinline__ void make_constraint(EnvLds& s, const DevTables& T, c
         float imp = impedance(P, r);
         float iwA = T.body_invw[b < D_NB ? b : 0];
         if (OBJ && b >= D_NB) iwA = static_cast<EnvLdsObj&>(s).oc[13 * (b - D_NB) + 10];
-        float dA = (iwA + (OBJ ? static_cast<EnvLdsObj&>(s).con_iw2[c] : 0.f)) * (1.0f + P.mu * P.mu);
+        float iwB = 0.f;
+        if (OBJ) {                                         // invweight0 of the surface's entity: static geom / object slot / floor (0)
+            const EnvLdsObj& so = static_cast<const EnvLdsObj&>(s);
+            const int b2 = so.con_b2[c];
+            if (b2 >= D_NB) iwB = so.oc[13 * (b2 - D_NB) + 10]; else if (b2 < -1) iwB = so.geom[17 * (-2 - b2) + 16];
+        }
+        float dA = (iwA + iwB) * (1.0f + P.mu * P.mu);
         float Rn = fmaxf(1e-15f, (1.0f - imp) * dA / imp);
         s.con_D[c] = 1.0f / (2.0f * P.mu * P.mu * Rn);
         S6 cv = lds6(s.sv + 6 * b);                         // sv still holds cvel from forward_kin_bias (objects: obj_forward)
@@ -850,13 +857,13 @@ __device__ __forceinline__ void make_constraint(EnvLds& s, const DevTables& T, c
                 atomicAdd(&s.nlim, 1);
             }
         }
-        s.lim_sgn[j] = sgn; s.lim_aref[j] = aref; s.lim_D[j] = Dl;
+        s.lim_jv[j] = aref; s.lim_D[j] = sgn * Dl;          // signed weight; aref sits in lim_jv until the first J search product
     }
     KP_SYNC();
 }
 
 // contact-frame residuals of all rows for the body spatial accelerations in acc (default: sv) and the generalized vector vec [- vec_b]:
-// out3 = frame^T (point accel) [- aref] [+ jar3];  sub_aref: subtract the reference acceleration (jv3 / lim_aref);  add_base: add the
+// out3 = frame^T (point accel) [- aref] [+ jar3];  sub_aref: subtract the reference acceleration (jv3 / lim_jv);  add_base: add the
 // residuals already in jar3 / lim_jar (rows are linear: residual(q + dq) = residual(q) + J dq)
 template <int NT, bool OBJ>
 __device__ __forceinline__ void eval_rows(EnvLds& s, const float* vec, float* out3, float* lim_rows, bool sub_aref, int tid, const float* acc = nullptr, const float* vec_b = nullptr, bool add_base = false) {
@@ -875,8 +882,8 @@ __device__ __forceinline__ void eval_rows(EnvLds& s, const float* vec, float* ou
         out3[3 * c] = a.x; out3[3 * c + 1] = a.y; out3[3 * c + 2] = a.z;
     }
     for (int j = tid; j < D_NU; j += NT) {
-        float sg = s.lim_sgn[j];
-        lim_rows[j] = sg != 0.f ? sg * (vec[6 + j] - (vec_b ? vec_b[6 + j] : 0.f)) - (sub_aref ? s.lim_aref[j] : 0.f) + (add_base ? s.lim_jar[j] : 0.f) : 0.f;
+        const float Ds = s.lim_D[j], sg = Ds > 0.f ? 1.f : (Ds < 0.f ? -1.f : 0.f);
+        lim_rows[j] = sg != 0.f ? sg * (vec[6 + j] - (vec_b ? vec_b[6 + j] : 0.f)) - (sub_aref ? s.lim_jv[j] : 0.f) + (add_base ? s.lim_jar[j] : 0.f) : 0.f;
     }
     KP_SYNC();
 }
@@ -939,7 +946,7 @@ __device__ __forceinline__ void wrench_project(EnvLds& s, const Params& P, const
     for (int d = tid; d < D_NV; d += NT) {
         float v = dot6(lds6(s.cdof + 6 * d), lds6(s.sa + 6 * s.dbody[d]));
         if (with_inertia) v += s.arm[d] * (va[d] - (vb ? vb[d] : 0.f));
-        if (with_forces && d >= 6) { float jr = s.lim_jar[d - 6]; if (jr < 0.f) v -= s.lim_sgn[d - 6] * (-s.lim_D[d - 6] * jr); }
+        if (with_forces && d >= 6) { float jr = s.lim_jar[d - 6]; if (jr < 0.f) v += s.lim_D[d - 6] * jr; }      // - sign * (-D jar): lim_D is signed
         out[d] = v;
     }
     KP_SYNC();
@@ -965,7 +972,7 @@ __device__ __forceinline__ float primal_cost(EnvLds& s, const Params& P, const f
 #pragma unroll
         for (int e = 0; e < 4; e++) { float x = row_val(e, P.mu, jn, jt1, jt2); if (x < 0.f) c += 0.5f * Dc * x * x; }
     }
-    for (int j = tid; j < D_NU; j += NT) { float x = lim_jar[j]; if (x < 0.f) c += 0.5f * s.lim_D[j] * x * x; }
+    for (int j = tid; j < D_NU; j += NT) { float x = lim_jar[j]; if (x < 0.f) c += 0.5f * fabsf(s.lim_D[j]) * x * x; }
     return block_sum<NT>(s, c, tid);
 }
 
@@ -1042,8 +1049,8 @@ __device__ __forceinline__ float line_search(EnvLds& s, const Params& P, float g
 #pragma unroll
     for (int n = 0; n < LR; n++) {
         const int j = tid + n * NT, jj = j < D_NU ? j : 0;
-        const bool ok = j < D_NU && s.lim_sgn[jj] != 0.f;
-        la[n] = ok ? s.lim_jar[jj] : 0.f; lb[n] = ok ? s.lim_jv[jj] : 0.f; lD[n] = ok ? s.lim_D[jj] * lb[n] : 0.f;
+        const bool ok = j < D_NU && s.lim_D[jj] != 0.f;
+        la[n] = ok ? s.lim_jar[jj] : 0.f; lb[n] = ok ? s.lim_jv[jj] : 0.f; lD[n] = ok ? fabsf(s.lim_D[jj]) * lb[n] : 0.f;
     }
     // The search direction solves H search = -grad with the Hessian of the current active set, so phi'(0) = -phi''(0) and the Newton
     // step from alpha = 0 is 1: the first evaluation happens there, bracketed by lo = 0 (descent direction).
@@ -1111,7 +1118,7 @@ __device__ __forceinline__ int solve_constraints(EnvLds& s, const Params& P, con
             float g = s.grad()[i];
             g2 += g * g;
             s.x[i] = -g;
-            const float ex = (i >= 6 && s.lim_jar[i - 6] < 0.f) ? s.lim_D[i - 6] : 0.f;
+            const float ex = (i >= 6 && s.lim_jar[i - 6] < 0.f) ? fabsf(s.lim_D[i - 6]) : 0.f;
             if (ex != s.extra[i]) changed = 1.f;
             s.extra[i] = ex;
             if (ex != 0.f) deep = fmaxf(deep, (float)s.bdep[s.dbody[i]]);     // active joint limit: its body's level is dirty
@@ -1140,7 +1147,7 @@ __device__ __forceinline__ int solve_constraints(EnvLds& s, const Params& P, con
         for (int i = tid; i < D_NV; i += NT) s.qacc[i] += alpha * s.search[i];
         for (int i = tid; i < D_NB * 6; i += NT) sacc[i] += alpha * s.sv[i];
         for (int k = tid; k < 3 * s.ncon; k += NT) s.jar3[k] += alpha * s.jv3[k];
-        for (int j = tid; j < D_NU; j += NT) if (s.lim_sgn[j] != 0.f) s.lim_jar[j] += alpha * s.lim_jv[j];
+        for (int j = tid; j < D_NU; j += NT) if (s.lim_D[j] != 0.f) s.lim_jar[j] += alpha * s.lim_jv[j];
         KP_SYNC();
         float newcost = primal_cost<NT>(s, P, sacc, s.jar3, s.lim_jar, tid);
         float improvement = P.scale * (cost - newcost);
@@ -1193,7 +1200,7 @@ __device__ __forceinline__ V3 con_force(const EnvLdsObj& s, const Params& P, int
 }
 
 // pose-dependent quantities of the objects (lane = slot), their world geoms (lane = geom); spatial velocity -> sv[24 + k]
-__device__ __forceinline__ void obj_forward(EnvLdsObj& s, const Params& P, int tid) {
+__device__ __forceinline__ void obj_forward(EnvLdsObj& s, const DevTables& T, const Params& P, int tid) {
     const V3 o = ld3(s.xpos);
     if (tid < s.nobj) {
         const int k = tid;
@@ -1240,7 +1247,7 @@ __device__ __forceinline__ void obj_forward(EnvLdsObj& s, const Params& P, int t
     KP_SYNC();
     if (tid >= s.ngeom_static && tid < s.ngeom) {
         const int k = s.gobj[tid];
-        const float* l = s.lgeom + 16 * tid;
+        const float* l = T.obj_geoms + 18 * s.ggi[tid] + 1;      // body-frame geom: type, size[3], pos[3], mat[9] (L2-resident table)
         const float* R = s.oR + 9 * k;
         float* g = s.geom + 17 * tid;
         g[0] = l[0]; g[1] = l[1]; g[2] = l[2]; g[3] = l[3];
@@ -1540,7 +1547,7 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
             const float g = s.grad()[i];
             g2 += g * g;
             s.x[i] = -g;
-            const float ex = (i >= 6 && s.lim_jar[i - 6] < 0.f) ? s.lim_D[i - 6] : 0.f;
+            const float ex = (i >= 6 && s.lim_jar[i - 6] < 0.f) ? fabsf(s.lim_D[i - 6]) : 0.f;
             if (ex != s.extra[i]) changed = 1.f;
             s.extra[i] = ex;
             if (ex != 0.f) deep = fmaxf(deep, (float)s.bdep[s.dbody[i]]);     // active joint limit: its body's level is dirty
@@ -1631,7 +1638,7 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
         for (int i = tid; i < D_NB * 6; i += NT) sacc[i] += alpha * s.sv[i];
         if (tid < no6) { s.oa[tid] += alpha * s.osrch[tid]; s.omres[tid] += alpha * s.oMv[tid]; }
         for (int k = tid; k < 3 * s.ncon; k += NT) s.jar3[k] += alpha * s.jv3[k];
-        for (int j = tid; j < D_NU; j += NT) if (s.lim_sgn[j] != 0.f) s.lim_jar[j] += alpha * s.lim_jv[j];
+        for (int j = tid; j < D_NU; j += NT) if (s.lim_D[j] != 0.f) s.lim_jar[j] += alpha * s.lim_jv[j];
         KP_SYNC();
         const float newcost = primal_cost<NT>(s, P, sacc, s.jar3, s.lim_jar, tid) + obj_gauss(s);
         const float improvement = P.scale * (cost - newcost);
@@ -1702,8 +1709,7 @@ __device__ __forceinline__ void step_body(StepArgs A, const int env_in, const in
             if (tid < 6) { s.ov[6 * k + tid] = gld<Q>(A.obj_qvel + (size_t)env * 30 + 6 * oi + tid); s.oqa[6 * k + tid] = gld<Q>(A.obj_warm + (size_t)env * 6 * D_MAXOBJ + 6 * k + tid); }
             if (tid < 13) s.oc[13 * k + tid] = T.obj_inertial[13 * oi + tid];
             for (int gi = T.obj_geom_adr[oi]; gi < T.obj_geom_adr[oi + 1] && ng < D_MAXGEOM; gi++, ng++) {
-                if (tid < 16) s.lgeom[16 * ng + tid] = T.obj_geoms[18 * gi + 1 + tid];
-                if (tid == 0) s.gobj[ng] = (signed char)k;
+                if (tid == 0) { s.gobj[ng] = (signed char)k; s.ggi[ng] = (unsigned char)gi; }
             }
         }
         if (tid == 0) { s.ngeom_static = ngs; s.ngeom = ng; s.nobj = nobj; }
@@ -1737,7 +1743,7 @@ __device__ __forceinline__ void step_body(StepArgs A, const int env_in, const in
 #pragma unroll
         for (int n = 0; n < (D_NV + NT - 1) / NT; n++) { int i = tid + n * NT; if (i < D_NV) qd_save_v[n] = s.qvel[i]; }
         forward_kin_bias<NT>(s, T, P, depth, bpos, tid);
-        if constexpr (OBJ) obj_forward(s, P, tid);
+        if constexpr (OBJ) obj_forward(s, T, P, tid);
         KP_T(1)
         collide<NT, OBJ>(s, T, P, tid);
         if (A.dbg_contacts && sub == A.n_substeps - 1) {      // test hook: the contact set of the last collision pass (con_D still holds the distance)
@@ -1746,7 +1752,7 @@ __device__ __forceinline__ void step_body(StepArgs A, const int env_in, const in
             for (int c = tid; c < s.ncon; c += NT) {
                 float* r = o + 1 + 9 * c;
                 r[0] = (float)s.con_body[c]; r[2] = s.con_D[c]; r[3] = s.con_pos[3 * c]; r[4] = s.con_pos[3 * c + 1]; r[5] = s.con_pos[3 * c + 2];
-                if constexpr (OBJ) { const EnvLdsObj& so = static_cast<const EnvLdsObj&>(s); r[1] = (float)so.con_b2[c]; r[6] = so.con_n[3 * c]; r[7] = so.con_n[3 * c + 1]; r[8] = so.con_n[3 * c + 2]; }
+                if constexpr (OBJ) { const EnvLdsObj& so = static_cast<const EnvLdsObj&>(s); r[1] = so.con_b2[c] < 0 ? -1.f : (float)so.con_b2[c]; r[6] = so.con_n[3 * c]; r[7] = so.con_n[3 * c + 1]; r[8] = so.con_n[3 * c + 2]; }
                 else { r[1] = -1.f; r[6] = 0.f; r[7] = 0.f; r[8] = 1.f; }
             }
         }
