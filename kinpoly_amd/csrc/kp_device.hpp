@@ -4,7 +4,7 @@
 // step (15 substeps); HBM is touched only at kernel entry (qpos/qvel/action/target) and exit
 // (qpos/qvel + stale kinematics for the observation kernels).  Lanes map to bodies (24), dofs (75),
 // hull vertices (<=64 per hull) or contacts depending on the phase.  The layout is sized so that
-// 8 environments fit in the 160 KiB LDS of one CU.
+// 8 environments (7 with free objects) fit in the 160 KiB LDS of one CU.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -47,7 +47,7 @@ struct Params {
     int max_iter, contact, limits, stale;
 };
 
-// ------------------------------------------------------------------ LDS layout (floats): ~19.8 KB
+// ------------------------------------------------------------------ LDS layout: 18 128 B (15 allocation granules of 1 280 B; 8 envs per CU)
 struct __attribute__((aligned(16))) EnvLds {
     float qpos[76], qvel[76];             // PD targets and actions are read from their HBM rows once per substep (spd_torque_rfc)
     float xpos[72], xquat[96];            // body COMs (xipos) are recomputed where they are read: collision centres, the read-out
