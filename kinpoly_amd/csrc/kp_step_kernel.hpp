@@ -1511,17 +1511,16 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
     eval_rows<NT, true>(s, s.qacc_s, s.jar3, s.lim_jar, true, tid);
     float cost = primal_cost<NT>(s, P, nullptr, s.jar3, s.lim_jar, tid);
     float* sacc = s.Mv;        // body spatial accelerations of qacc - qacc_s ([24][6] over Mv + mres), see solve_constraints
-    // candidate B: warm start
+    // candidate B: warm start.  The smooth solve's root->leaves pass left sacc = accelerations of (warm start - qacc_smooth) for the hulls
+    // (aba_solve<.., WARM>); the object slots of the same array (entities 24, 25: the last four floats run into x) take oa - oas, and the
+    // rows are linear: residuals = candidate A's + J (difference).
     {
-        float* wj3 = s.jv3;    // in place over aref; U stays as the smooth solve left it (aba_solve's clean levels)
-        float* wlim = s.x;
-        for (int i = tid; i < D_NB * 6; i += NT) sacc[i] = s.sv[i];
+        float* wj3 = s.jv3;    // over aref (not needed afterwards); U stays as the smooth solve left it (aba_solve's clean levels)
+        float* wlim = s.x + 4; // x[0..3] hold the tail of the second object slot of sacc during this block
+        static_assert(offsetof(EnvLds, x) == offsetof(EnvLds, Mv) + 152 * sizeof(float), "sacc's object slots continue into x");
+        if (tid < no6) sacc[6 * D_NB + tid] = s.oa[tid] - s.oas[tid];
         KP_SYNC();
-        spatial_accumulate<NT>(s, s.qacc, depth, tid);
-        if (tid < no6) s.sv[6 * D_NB + tid] = s.oa[tid];
-        KP_SYNC();
-        eval_rows<NT, true>(s, s.qacc, wj3, wlim, true, tid);
-        for (int i = tid; i < D_NB * 6; i += NT) sacc[i] = s.sv[i] - sacc[i];
+        eval_rows<NT, true>(s, s.qacc, wj3, wlim, false, tid, sacc, s.qacc_s, true);
         if (tid < nobj) sts6(s.omres + 6 * tid, inert_mul(s.oIe + 10 * tid, lds6(s.oa + 6 * tid) + (-1.0f) * lds6(s.oas + 6 * tid)));
         KP_SYNC();
         const float cw = primal_cost<NT>(s, P, sacc, wj3, wlim, tid) + obj_gauss(s);
@@ -1762,8 +1761,8 @@ __device__ __forceinline__ void step_body(StepArgs A, const int env_in, const in
         if (!P.stale) spd_torque_rfc<NT, OBJ>(s, T, P, L8, depth, tid, tq_row, act_row);
         for (int i = tid; i < D_NV; i += NT) s.extra[i] = 0.f;
         KP_SYNC();
-        // qacc_smooth = M^-1 qfrc_smooth; sv = its spatial accelerations; floor-only kernel: Mv/mres = those of (warm start - qacc_smooth) for the Newton solve
-        aba_solve<NT, OBJ, !OBJ>(s, P, L8, s.applied, s.qacc_s, false, tid, D_NLEV, s.fb, s.qacc, s.Mv);
+        // qacc_smooth = M^-1 qfrc_smooth; sv = its spatial accelerations; Mv/mres = those of (warm start - qacc_smooth) for the Newton solve
+        aba_solve<NT, OBJ, true>(s, P, L8, s.applied, s.qacc_s, false, tid, D_NLEV, s.fb, s.qacc, s.Mv);
         KP_T(4)
         if constexpr (OBJ) niter_total += solve_constraints_obj<NT>(s, P, L8, depth, tid, nfact_total, ncap_total);
         else niter_total += solve_constraints<NT, OBJ>(s, P, L8, depth, tid, nfact_total, ncap_total);
