@@ -302,6 +302,16 @@ def main():
                            "note": "separate rocprofv3 --pmc passes of this command (FETCH_SIZE x2 per the guide's gfx950 correction, WRITE_SIZE as reported), "
                                    "median per launch of the same kernel; not measured in this run"}
             valu = pj.get("issue")
+        # instruction issue: instructions per env-step from that PMC pass, wave cycles per env-step live from this run's last
+        # launch (kp_sim_launch_cost), against what two waves per SIMD can issue (tools/micro/valu_probe.hip: one instruction per 2.9 SIMD cycles)
+        issue = None
+        if valu and valu.get("valu_insts_per_launch"):
+            insts = (valu["valu_insts_per_launch"] + valu.get("salu_insts_per_launch", 0.0) + valu.get("lds_insts_per_launch", 0.0)) / ENVS_PER_GPU
+            cyc = float(cost.mean())
+            issue = {"wave_insts_per_env_step": insts, "wave_cycles_per_env_step": cyc, "wave_cycles_per_inst": cyc / insts, "waves_per_simd": 2,
+                     "simd_cycles_per_inst": cyc / insts / 2.0, "attainable_simd_cycles_per_inst_at_2_waves": 2.9, "frac_of_attainable_issue": 2.9 / (cyc / insts / 2.0),
+                     "note": "instructions: VALU + SALU + LDS wave-instructions of the PMC pass named in traffic_source; cycles: shader clock inside the jobs of this run's last launch "
+                             "(hand-overs included, tail of the launch excluded); a third wave per SIMD buys ~1 % (profiles/r02/occupancy_premise.log)"}
         out = {
             "metric": "env-steps/sec (whole node) at 4096 envs/GPU, 69-DoF SMPL", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -312,8 +322,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_over_algorithmic": (traffic / algo_bytes) if traffic else None, "traffic_source": traffic_src,
                          "kernel": kernel_name, "launch_ms": kern_s * 1e3, "launches_timed": n_launch, "algorithmic_bytes_per_launch": algo_bytes,
-                         "limiter": "valu-issue / dependent-chain latency (state resident in LDS: the compulsory HBM traffic is tiny by construction, DESIGN.md section 6)",
-                         "valu": valu},
+                         "limiter": "wave-level instruction issue: the SIMDs are saturated by their two resident waves (state lives in LDS, so the compulsory HBM traffic is tiny by construction; DESIGN.md section 6)",
+                         "valu": valu, "issue": issue},
             "kernel_share_of_step": kern_s / (elapsed / args.steps),
             "contacts_mean": float(diag[:, 0].mean()), "newton_iters_per_substep": float(diag[:, 1].mean() / 15.0),
             "hessian_factorisations_per_substep": float((diag[:, 3] >> 8).mean() / 15.0),
