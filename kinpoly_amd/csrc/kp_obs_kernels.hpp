@@ -88,6 +88,7 @@ __global__ __launch_bounds__(256) void k_target_fk(int n, const float* __restric
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int e = blockIdx.x * 4 + w;
     const bool live = e < n && !(mask && !mask[e]);
+    if (!__syncthreads_or(live)) return;             // masked resets touch a few rows: a block whose four rows are all masked out leaves at once
     if (live) {
         const float* q = tq + (size_t)e * D_NQ;
         for (int i = lane; i < D_NQ; i += 64) sq[w][i] = q[i];
