@@ -332,3 +332,40 @@ def test_fused_unroll_matches_reference_padded_forward_fp32(kp, golden):
     with torch.no_grad():
         means = net.unroll(dev(g["states"]).view(N, T, -1), torch.tensor(starts, device="cuda"))
     np.testing.assert_allclose(means.reshape(N * T, -1).double().cpu().numpy(), g["action_mean"], atol=3e-4)
+
+
+def test_resting_box_depth_matches_the_closed_form_on_the_device(kp):
+    """The known answer of tests/test_physics_oracle.py (soft-contact model in closed form: 16 D(r) k d(r) |r| = m g) for the HIP
+    kernel's own coupled solve: the free step box alone on the floor settles at dist = r* + margin on its four mjc_PlaneBox corners."""
+    from scipy.optimize import brentq
+    from kinpoly_amd.model_compiler import STEP_KPM, read_kpm
+    kpm = read_kpm(STEP_KPM)
+    opt = kpm["opt"]
+    inert = kpm["obj_inertial"].reshape(-1, 13)[4]
+    mass, invw = inert[0], inert[10]
+    tc, dr, (d0, dw, width, mid, power), mu, margin = max(opt[4], 2 * opt[0]), opt[5], opt[6:11], opt[11], opt[14]
+
+    def load(r):
+        x = min(abs(r) / width, 1.0)
+        y = x * x / mid if x <= mid else 1.0 - (1.0 - x) ** 2 / (1.0 - mid)
+        d = d0 + y * (dw - d0)
+        R = (1.0 - d) / d * (1.0 + mu * mu) * invw
+        return 16.0 * d * abs(r) / (dw * dw * tc * tc * dr * dr) / (2.0 * mu * mu * R) - mass * 9.81
+    r_star = -brentq(lambda x: load(-x), 1e-9, 0.5 * width)
+
+    n = 4
+    blk = np.zeros((n, 35))
+    for i in range(5):
+        blk[:, 7 * i: 7 * i + 3] = [(i + 1) * 100, 100, 0]
+    blk[:, 28:35] = [0.0, 0.0, 0.3705, 1, 0, 0, 0]                  # the step box on the floor, 30 m from the humanoid
+    qpos = np.tile(STD["qpos"], (n, 1)); qpos[:, 0] += 30
+    sim = kp.KpSim(kp.KpModel(STEP_KPM), n)
+    sim.record_contacts()
+    sim.set_objects(dev(blk)); sim.set_state(dev(qpos), dev(np.zeros((n, 75)))); sim.set_target(dev(qpos))
+    for _ in range(100):
+        sim.step_ctrl(dev(np.zeros((n, 75))), 15)
+    c = sim.contacts()[0]
+    mine = c["body"] == 24
+    assert mine.sum() == 4 and np.all(c["b2"][mine] == -1)
+    assert float(sim.get("obj_qvel")[0, 24:30].abs().max()) < 1e-4
+    np.testing.assert_allclose(c["dist"][mine], r_star + margin, rtol=2e-3)      # fp32 positions at z = 0.37 m resolve 3e-8 m of a 9e-4 m gap

@@ -246,3 +246,48 @@ def test_objects_rest_and_carry_load():
         fzs.append(sum((J[lim + r, 75 + 2] * f[lim + r]) for r in range(4 * len(b1)) if b1[rows[r]] == 24 and b2[rows[r]] == -1))
     # the floor under the step carries humanoid + step on average (the stance bounces a little on its soft contacts)
     assert abs(np.mean(fzs[2:]) - total) < 0.1 * total and o.get("qpos")[2] > q[2] - 0.05
+
+
+def test_resting_box_sinks_to_the_closed_form_depth_of_the_soft_contact_model():
+    """Known answer from MuJoCo's documented constraint model alone (computation.html#soft-constraint-model): a box at rest on the
+    plane carries its weight on four corner contacts (mjc_PlaneBox).  With zero velocity and acceleration every pyramid row has
+    residual -aref = k d(r) r, force f = -D k d(r) r per row, D = 1 / (2 mu^2 R), R = (1 - d) / d * (1 + mu^2) * invweight0, and the
+    four rows of a contact add up to the normal force (their tangential parts cancel):  16 D(r) k d(r) |r| = m g  fixes r = dist - margin."""
+    from kinpoly_amd.model_compiler import STEP_KPM
+    from scipy.optimize import brentq
+    kpm = read_kpm(STEP_KPM)
+    opt = kpm["opt"]
+    inert = kpm["obj_inertial"].reshape(-1, 13)[4]                # the step box: mass, ..., invweight0 (translational) at [10]
+    mass, invw = inert[0], inert[10]
+    tc, dr, solimp, mu, margin = max(opt[4], 2 * opt[0]), opt[5], opt[6:11], opt[11], opt[14]
+    d0, dw, width, mid, power = solimp
+    assert power == 2.0                                            # the closed form below is written for the model's impedance power
+
+    def imp(r):
+        x = min(abs(r) / width, 1.0)
+        y = x * x / mid if x <= mid else 1.0 - (1.0 - x) ** 2 / (1.0 - mid)
+        return d0 + y * (dw - d0)
+
+    k = 1.0 / (dw * dw * tc * tc * dr * dr)
+
+    def load(r):                                                  # normal force of the four contacts at depth r < 0, minus the weight
+        d = imp(r)
+        R = (1.0 - d) / d * (1.0 + mu * mu) * invw
+        return 16.0 * k * d * abs(r) / (2.0 * mu * mu * R) - mass * 9.81
+    r_star = -brentq(lambda x: load(-x), 1e-9, 0.5 * width)
+
+    o = OracleSim(kpm=STEP_KPM)
+    og = kpm["obj_geoms"].reshape(-1, 18)
+    half_h = og[og[:, 0].astype(int) == 4][0, 4]                   # box half height (size[2])
+    o.set_object(0, kpm, 4, [0.0, 0.0, half_h, 1, 0, 0, 0])
+    q = STD["qpos"].copy(); q[0] += 30
+    o.reset(q, np.zeros(75))
+    for _ in range(1500):
+        o.step()
+    o.forward()
+    c = o.contacts_full()
+    mine = c["body"] == 24
+    assert mine.sum() == 4 and np.all(c["b2"][mine] == -1)
+    bq, bv = o.get_object(0)
+    assert np.abs(bv).max() < 1e-6                                 # at rest
+    np.testing.assert_allclose(c["dist"][mine], r_star + margin, rtol=2e-4)
