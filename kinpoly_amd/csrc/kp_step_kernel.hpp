@@ -965,15 +965,18 @@ __device__ __forceinline__ float quad_form_M(const EnvLds& s, const float* acca,
 // primal cost at the current iterate:  0.5 (qacc - qacc_s)^T M (qacc - qacc_s) + sum 0.5 D jar_-^2.  sacc = body spatial
 // accelerations of qacc - qacc_s (null: qacc = qacc_s, Gauss term 0)
 template <int NT>
-__device__ __forceinline__ float primal_cost(EnvLds& s, const Params& P, const float* sacc, const float* jar3, const float* lim_jar, int tid) {
+// gauss_out (optional): receives the Gauss term alone (the Newton loop then carries it forward in closed form along each search direction)
+__device__ __forceinline__ float primal_cost(EnvLds& s, const Params& P, const float* sacc, const float* jar3, const float* lim_jar, int tid, float* gauss_out = nullptr) {
     float c = sacc ? quad_form_M<NT>(s, sacc, sacc, s.qacc, s.qacc_s, s.qacc, s.qacc_s, tid) : 0.f;
+    float gauss = 0.f;
+    if (gauss_out) { gauss = block_sum<NT>(s, c, tid); *gauss_out = gauss; c = 0.f; }
     for (int k = tid; k < s.ncon; k += NT) {
         const float Dc = s.con_D[k], jn = jar3[3 * k], jt1 = jar3[3 * k + 1], jt2 = jar3[3 * k + 2];
 #pragma unroll
         for (int e = 0; e < 4; e++) { float x = row_val(e, P.mu, jn, jt1, jt2); if (x < 0.f) c += 0.5f * Dc * x * x; }
     }
     for (int j = tid; j < D_NU; j += NT) { float x = lim_jar[j]; if (x < 0.f) c += 0.5f * fabsf(s.lim_D[j]) * x * x; }
-    return block_sum<NT>(s, c, tid);
+    return gauss + block_sum<NT>(s, c, tid);
 }
 
 // spatial "acceleration" of every body induced by a generalized vector (what aba_solve leaves in sv)
@@ -1030,27 +1033,28 @@ __device__ __forceinline__ int first_clean_level(EnvLds& s, float deep, int tid)
 // exact minimiser of the cost along the search direction: root of phi'(alpha) = g0 + alpha h0 + sum_rows D (jar + alpha jv)_- jv by
 // safeguarded Newton steps on the piecewise-linear phi'.  Every lane keeps its rows in registers for the whole search -- one contact
 // (four pyramid rows a + alpha b with a = row(jar), b = row(jv)) and ceil(69 / NT) joint-limit rows -- so an evaluation is a few
-// FMAs per row and two wave sums, without LDS traffic.
+// FMAs per row and two wave sums, without LDS traffic.  rowcost: the rows' share of the cost at the returned alpha.
 template <int NT>
-__device__ __forceinline__ float line_search(EnvLds& s, const Params& P, float g0, float h0, int tid) {
+__device__ __forceinline__ float line_search(EnvLds& s, const Params& P, float g0, float h0, int tid, float& rowcost) {
     static_assert(D_MAXCON <= 64 && NT >= 64, "one contact per lane");
-    float ra[4], rb[4], rD[4];
+    float ra[4], rb[4], rD[4], Dc;
     {
         const bool ok = tid < s.ncon;
         const int k = ok ? tid : 0;
-        const float Dc = ok ? s.con_D[k] : 0.f;
+        Dc = ok ? s.con_D[k] : 0.f;
         const float jn = ok ? s.jar3[3 * k] : 0.f, jt1 = ok ? s.jar3[3 * k + 1] : 0.f, jt2 = ok ? s.jar3[3 * k + 2] : 0.f;
         const float vn = ok ? s.jv3[3 * k] : 0.f, vt1 = ok ? s.jv3[3 * k + 1] : 0.f, vt2 = ok ? s.jv3[3 * k + 2] : 0.f;
 #pragma unroll
         for (int e = 0; e < 4; e++) { ra[e] = row_val(e, P.mu, jn, jt1, jt2); rb[e] = row_val(e, P.mu, vn, vt1, vt2); rD[e] = Dc * rb[e]; }
     }
     constexpr int LR = (D_NU + NT - 1) / NT;
-    float la[LR], lb[LR], lD[LR];
+    float la[LR], lb[LR], lD[LR], lW[LR];
 #pragma unroll
     for (int n = 0; n < LR; n++) {
         const int j = tid + n * NT, jj = j < D_NU ? j : 0;
         const bool ok = j < D_NU && s.lim_D[jj] != 0.f;
-        la[n] = ok ? s.lim_jar[jj] : 0.f; lb[n] = ok ? s.lim_jv[jj] : 0.f; lD[n] = ok ? fabsf(s.lim_D[jj]) * lb[n] : 0.f;
+        lW[n] = ok ? fabsf(s.lim_D[jj]) : 0.f;
+        la[n] = ok ? s.lim_jar[jj] : 0.f; lb[n] = ok ? s.lim_jv[jj] : 0.f; lD[n] = lW[n] * lb[n];
     }
     // The search direction solves H search = -grad with the Hessian of the current active set, so phi'(0) = -phi''(0) and the Newton
     // step from alpha = 0 is 1: the first evaluation happens there, bracketed by lo = 0 (descent direction).
@@ -1071,6 +1075,13 @@ __device__ __forceinline__ float line_search(EnvLds& s, const Params& P, float g
         alpha = an;
         if (fabsf(step) <= 1e-6f * fabsf(alpha)) break;
     }
+    // constraint part of the cost at the step taken: sum over the rows of 0.5 D (a + alpha b)_-^2 (the caller adds the Gauss term in closed form)
+    float rc = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; e++) { const float x = fmaf(alpha, rb[e], ra[e]); if (x < 0.f) rc += 0.5f * Dc * x * x; }
+#pragma unroll
+    for (int n = 0; n < LR; n++) { const float x = fmaf(alpha, lb[n], la[n]); if (x < 0.f) rc += 0.5f * lW[n] * x * x; }
+    rowcost = block_sum<NT>(s, rc, tid);
     return alpha;
 }
 
@@ -1086,6 +1097,7 @@ __device__ __forceinline__ int solve_constraints(EnvLds& s, const Params& P, con
     // candidate A: qacc_smooth (M qacc_s = qfrc_smooth => Gauss term 0); sv holds its spatial accelerations
     eval_rows<NT, OBJ>(s, s.qacc_s, s.jar3, s.lim_jar, true, tid);
     float cost = primal_cost<NT>(s, P, nullptr, s.jar3, s.lim_jar, tid);
+    float gauss = 0.f;         // Gauss term 0.5 (qacc - qacc_s)^T M (qacc - qacc_s) of the iterate: exact quadratic along a search direction, carried forward
     // The Gauss part of the problem is carried in body form: sacc[b] = spatial acceleration of body b induced by qacc - qacc_s, so
     // M (qacc - qacc_s) never has to be projected on the dofs on its own (it rides along with the gradient's projection).
     float* sacc = s.Mv;        // [24][6] over Mv + mres (152 floats)
@@ -1096,9 +1108,10 @@ __device__ __forceinline__ int solve_constraints(EnvLds& s, const Params& P, con
         float* wj3 = s.jv3;    // over aref (not needed afterwards)
         float* wlim = s.x;     // U must stay as the smooth solve left it (aba_solve's clean levels)
         eval_rows<NT, OBJ>(s, s.qacc, wj3, wlim, false, tid, sacc, s.qacc_s, true);
-        float cw = primal_cost<NT>(s, P, sacc, wj3, wlim, tid);
+        float gw;
+        float cw = primal_cost<NT>(s, P, sacc, wj3, wlim, tid, &gw);
         if (cw < cost) {
-            cost = cw;
+            cost = cw; gauss = gw;
             for (int k = tid; k < 3 * s.ncon; k += NT) s.jar3[k] = wj3[k];
             for (int j = tid; j < D_NU; j += NT) s.lim_jar[j] = wlim[j];
         } else {
@@ -1142,14 +1155,18 @@ __device__ __forceinline__ int solve_constraints(EnvLds& s, const Params& P, con
         float g0 = 2.0f * quad_form_M<NT>(s, s.sv, sacc, s.search, nullptr, s.qacc, s.qacc_s, tid);
         float h0 = 2.0f * quad_form_M<NT>(s, s.sv, s.sv, s.search, nullptr, s.search, nullptr, tid);
         g0 = block_sum<NT>(s, g0, tid); h0 = block_sum<NT>(s, h0, tid);
-        const float alpha = line_search<NT>(s, P, g0, h0, tid);
+        float rowcost;
+        const float alpha = line_search<NT>(s, P, g0, h0, tid, rowcost);
         if (!(alpha > 0.f)) { done = true; break; }
         for (int i = tid; i < D_NV; i += NT) s.qacc[i] += alpha * s.search[i];
         for (int i = tid; i < D_NB * 6; i += NT) sacc[i] += alpha * s.sv[i];
         for (int k = tid; k < 3 * s.ncon; k += NT) s.jar3[k] += alpha * s.jv3[k];
         for (int j = tid; j < D_NU; j += NT) if (s.lim_D[j] != 0.f) s.lim_jar[j] += alpha * s.lim_jv[j];
         KP_SYNC();
-        float newcost = primal_cost<NT>(s, P, sacc, s.jar3, s.lim_jar, tid);
+        // cost at the new iterate without another pass over bodies and rows: the Gauss term is quadratic along the search direction
+        // (g0 = search^T M (qacc - qacc_s), h0 = search^T M search), the rows' share comes from the line search's registers
+        gauss += alpha * (g0 + 0.5f * alpha * h0);
+        float newcost = gauss + rowcost;
         float improvement = P.scale * (cost - newcost);
         cost = newcost;
         if (improvement < P.tol) { it++; done = true; break; }
@@ -1510,6 +1527,7 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
     KP_SYNC();
     eval_rows<NT, true>(s, s.qacc_s, s.jar3, s.lim_jar, true, tid);
     float cost = primal_cost<NT>(s, P, nullptr, s.jar3, s.lim_jar, tid);
+    float gauss = 0.f;         // Gauss term of the iterate (humanoid + objects), carried forward in closed form as in solve_constraints
     float* sacc = s.Mv;        // body spatial accelerations of qacc - qacc_s ([24][6] over Mv + mres), see solve_constraints
     // candidate B: warm start.  The smooth solve's root->leaves pass left sacc = accelerations of (warm start - qacc_smooth) for the hulls
     // (aba_solve<.., WARM>); the object slots of the same array (entities 24, 25: the last four floats run into x) take oa - oas, and the
@@ -1523,9 +1541,11 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
         eval_rows<NT, true>(s, s.qacc, wj3, wlim, false, tid, sacc, s.qacc_s, true);
         if (tid < nobj) sts6(s.omres + 6 * tid, inert_mul(s.oIe + 10 * tid, lds6(s.oa + 6 * tid) + (-1.0f) * lds6(s.oas + 6 * tid)));
         KP_SYNC();
-        const float cw = primal_cost<NT>(s, P, sacc, wj3, wlim, tid) + obj_gauss(s);
+        float gw;
+        const float og = obj_gauss(s);
+        const float cw = primal_cost<NT>(s, P, sacc, wj3, wlim, tid, &gw) + og;
         if (cw < cost) {
-            cost = cw;
+            cost = cw; gauss = gw + og;
             for (int k = tid; k < 3 * s.ncon; k += NT) s.jar3[k] = wj3[k];
             for (int j = tid; j < D_NU; j += NT) s.lim_jar[j] = wlim[j];
         } else {
@@ -1631,7 +1651,8 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
         float h0 = 2.0f * quad_form_M<NT>(s, s.sv, s.sv, s.search, nullptr, s.search, nullptr, tid);
         if (tid < no6) { g0 += s.osrch[tid] * s.omres[tid]; h0 += s.osrch[tid] * s.oMv[tid]; }
         g0 = block_sum<NT>(s, g0, tid); h0 = block_sum<NT>(s, h0, tid);
-        const float alpha = line_search<NT>(s, P, g0, h0, tid);
+        float rowcost;
+        const float alpha = line_search<NT>(s, P, g0, h0, tid, rowcost);
         if (!(alpha > 0.f)) { done = true; break; }
         for (int i = tid; i < D_NV; i += NT) s.qacc[i] += alpha * s.search[i];
         for (int i = tid; i < D_NB * 6; i += NT) sacc[i] += alpha * s.sv[i];
@@ -1639,7 +1660,8 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
         for (int k = tid; k < 3 * s.ncon; k += NT) s.jar3[k] += alpha * s.jv3[k];
         for (int j = tid; j < D_NU; j += NT) if (s.lim_D[j] != 0.f) s.lim_jar[j] += alpha * s.lim_jv[j];
         KP_SYNC();
-        const float newcost = primal_cost<NT>(s, P, sacc, s.jar3, s.lim_jar, tid) + obj_gauss(s);
+        gauss += alpha * (g0 + 0.5f * alpha * h0);             // g0 / h0 include the object dofs
+        const float newcost = gauss + rowcost;
         const float improvement = P.scale * (cost - newcost);
         cost = newcost;
         if (improvement < P.tol) { it++; done = true; break; }

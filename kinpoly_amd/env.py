@@ -77,6 +77,7 @@ class BatchedHumanoidAREnv:
         self._next_qpos, self._cc_obs, self._obs = f(76), f(784), f(105)
         self._reward, self._info, self._diffs = torch.empty(self.n, device=self.device), f(6), f(2)
         self._fail = torch.empty(self.n, dtype=torch.uint8, device=self.device)
+        self._unit_reward = torch.ones(self.n, device=self.device)
 
     # ------------------------------------------------------------------ reference surface
     def seed(self, seed):
@@ -243,7 +244,7 @@ class BatchedHumanoidAREnv:
         obs = sim.obs_ar(self._ctx_struct, self._obs)
         info = {"fail": failed, "end": end, "percent": self.cur_t / self._clen, "cc_action": cc_action, "cc_state": cc_obs,
                 "custom_reward": reward, "custom_info": info6, "body_diff": diffs}
-        return obs, torch.ones(self.n, device=self.device), done, info
+        return obs, self._unit_reward, done, info        # the env's own reward is the constant 1.0 (humanoid_ar_v1.py:311); one shared read-only tensor
 
     # getters (device tensors; reference names)
     def get_humanoid_qpos(self):
