@@ -1034,7 +1034,9 @@ __device__ __forceinline__ int first_clean_level(EnvLds& s, float deep, int tid)
 // safeguarded Newton steps on the piecewise-linear phi'.  Every lane keeps its rows in registers for the whole search -- one contact
 // (four pyramid rows a + alpha b with a = row(jar), b = row(jv)) and ceil(69 / NT) joint-limit rows -- so an evaluation is a few
 // FMAs per row and two wave sums, without LDS traffic.  rowcost: the rows' share of the cost at the returned alpha.
-template <int NT>
+// ROWCOST = false leaves rowcost alone (the object kernel keeps its full cost evaluation: its register allocation is tight enough that
+// three more live values across the search moved spills into the articulated-body loops, + 8 % on every object scene)
+template <int NT, bool ROWCOST = true>
 __device__ __forceinline__ float line_search(EnvLds& s, const Params& P, float g0, float h0, int tid, float& rowcost) {
     static_assert(D_MAXCON <= 64 && NT >= 64, "one contact per lane");
     float ra[4], rb[4], rD[4], Dc;
@@ -1053,8 +1055,9 @@ __device__ __forceinline__ float line_search(EnvLds& s, const Params& P, float g
     for (int n = 0; n < LR; n++) {
         const int j = tid + n * NT, jj = j < D_NU ? j : 0;
         const bool ok = j < D_NU && s.lim_D[jj] != 0.f;
-        lW[n] = ok ? fabsf(s.lim_D[jj]) : 0.f;
-        la[n] = ok ? s.lim_jar[jj] : 0.f; lb[n] = ok ? s.lim_jv[jj] : 0.f; lD[n] = lW[n] * lb[n];
+        const float w = ok ? fabsf(s.lim_D[jj]) : 0.f;
+        if (ROWCOST) lW[n] = w;
+        la[n] = ok ? s.lim_jar[jj] : 0.f; lb[n] = ok ? s.lim_jv[jj] : 0.f; lD[n] = w * lb[n];
     }
     // The search direction solves H search = -grad with the Hessian of the current active set, so phi'(0) = -phi''(0) and the Newton
     // step from alpha = 0 is 1: the first evaluation happens there, bracketed by lo = 0 (descent direction).
@@ -1075,13 +1078,14 @@ __device__ __forceinline__ float line_search(EnvLds& s, const Params& P, float g
         alpha = an;
         if (fabsf(step) <= 1e-6f * fabsf(alpha)) break;
     }
-    // constraint part of the cost at the step taken: sum over the rows of 0.5 D (a + alpha b)_-^2 (the caller adds the Gauss term in closed form)
-    float rc = 0.f;
+    if (ROWCOST) {   // constraint part of the cost at the step taken: sum over the rows of 0.5 D (a + alpha b)_-^2 (the caller adds the Gauss term in closed form)
+        float rc = 0.f;
 #pragma unroll
-    for (int e = 0; e < 4; e++) { const float x = fmaf(alpha, rb[e], ra[e]); if (x < 0.f) rc += 0.5f * Dc * x * x; }
+        for (int e = 0; e < 4; e++) { const float x = fmaf(alpha, rb[e], ra[e]); if (x < 0.f) rc += 0.5f * Dc * x * x; }
 #pragma unroll
-    for (int n = 0; n < LR; n++) { const float x = fmaf(alpha, lb[n], la[n]); if (x < 0.f) rc += 0.5f * lW[n] * x * x; }
-    rowcost = block_sum<NT>(s, rc, tid);
+        for (int n = 0; n < LR; n++) { const float x = fmaf(alpha, lb[n], la[n]); if (x < 0.f) rc += 0.5f * lW[n] * x * x; }
+        rowcost = block_sum<NT>(s, rc, tid);
+    }
     return alpha;
 }
 
@@ -1527,7 +1531,6 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
     KP_SYNC();
     eval_rows<NT, true>(s, s.qacc_s, s.jar3, s.lim_jar, true, tid);
     float cost = primal_cost<NT>(s, P, nullptr, s.jar3, s.lim_jar, tid);
-    float gauss = 0.f;         // Gauss term of the iterate (humanoid + objects), carried forward in closed form as in solve_constraints
     float* sacc = s.Mv;        // body spatial accelerations of qacc - qacc_s ([24][6] over Mv + mres), see solve_constraints
     // candidate B: warm start.  The smooth solve's root->leaves pass left sacc = accelerations of (warm start - qacc_smooth) for the hulls
     // (aba_solve<.., WARM>); the object slots of the same array (entities 24, 25: the last four floats run into x) take oa - oas, and the
@@ -1541,11 +1544,9 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
         eval_rows<NT, true>(s, s.qacc, wj3, wlim, false, tid, sacc, s.qacc_s, true);
         if (tid < nobj) sts6(s.omres + 6 * tid, inert_mul(s.oIe + 10 * tid, lds6(s.oa + 6 * tid) + (-1.0f) * lds6(s.oas + 6 * tid)));
         KP_SYNC();
-        float gw;
-        const float og = obj_gauss(s);
-        const float cw = primal_cost<NT>(s, P, sacc, wj3, wlim, tid, &gw) + og;
+        const float cw = primal_cost<NT>(s, P, sacc, wj3, wlim, tid) + obj_gauss(s);
         if (cw < cost) {
-            cost = cw; gauss = gw + og;
+            cost = cw;
             for (int k = tid; k < 3 * s.ncon; k += NT) s.jar3[k] = wj3[k];
             for (int j = tid; j < D_NU; j += NT) s.lim_jar[j] = wlim[j];
         } else {
@@ -1651,8 +1652,8 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
         float h0 = 2.0f * quad_form_M<NT>(s, s.sv, s.sv, s.search, nullptr, s.search, nullptr, tid);
         if (tid < no6) { g0 += s.osrch[tid] * s.omres[tid]; h0 += s.osrch[tid] * s.oMv[tid]; }
         g0 = block_sum<NT>(s, g0, tid); h0 = block_sum<NT>(s, h0, tid);
-        float rowcost;
-        const float alpha = line_search<NT>(s, P, g0, h0, tid, rowcost);
+        float unused;
+        const float alpha = line_search<NT, false>(s, P, g0, h0, tid, unused);
         if (!(alpha > 0.f)) { done = true; break; }
         for (int i = tid; i < D_NV; i += NT) s.qacc[i] += alpha * s.search[i];
         for (int i = tid; i < D_NB * 6; i += NT) sacc[i] += alpha * s.sv[i];
@@ -1660,8 +1661,7 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
         for (int k = tid; k < 3 * s.ncon; k += NT) s.jar3[k] += alpha * s.jv3[k];
         for (int j = tid; j < D_NU; j += NT) if (s.lim_D[j] != 0.f) s.lim_jar[j] += alpha * s.lim_jv[j];
         KP_SYNC();
-        gauss += alpha * (g0 + 0.5f * alpha * h0);             // g0 / h0 include the object dofs
-        const float newcost = gauss + rowcost;
+        const float newcost = primal_cost<NT>(s, P, sacc, s.jar3, s.lim_jar, tid) + obj_gauss(s);
         const float improvement = P.scale * (cost - newcost);
         cost = newcost;
         if (improvement < P.tol) { it++; done = true; break; }

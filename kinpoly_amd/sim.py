@@ -64,7 +64,7 @@ def load_library(path: str | None = None):
     global _lib
     if _lib is not None:
         return _lib
-    path = path or _build.LIB
+    path = path or os.environ.get("KP_SIM_LIBRARY") or _build.LIB      # KP_SIM_LIBRARY: another build of the same ABI (A/B measurements)
     if not os.path.exists(path):
         raise KinPolyNativeError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                  "(hipcc --offload-arch=gfx950). There is no CPU fallback.")

@@ -30,7 +30,7 @@ def patch(s):
         eval_rows<NT, OBJ>''', '''        else aba_resolve(s, L8, s.x, nullptr, s.search);
         NP(2)
         eval_rows<NT, OBJ>''')
-    rep("        const float alpha = line_search<NT>(s, P, g0, h0, tid);\n", "        NP(3)\n        const float alpha = line_search<NT>(s, P, g0, h0, tid);\n        NP(4)\n")
+    rep("        const float alpha = line_search<NT>(s, P, g0, h0, tid, rowcost);\n", "        NP(3)\n        const float alpha = line_search<NT>(s, P, g0, h0, tid, rowcost);\n        NP(4)\n")
     rep('''        cost = newcost;
         if (improvement < P.tol) { it++; done = true; break; }''', '''        cost = newcost;
         NP(5)
@@ -59,11 +59,11 @@ def patch_gradient(s):
         "    unsigned long long t0_ = __builtin_readcyclecounter();\n"
         "#define NP(i) { unsigned long long t1_ = __builtin_readcyclecounter(); np[i] += t1_ - t0_; t0_ = t1_; }\n"
         "    if (s.ncon == 0 && s.nlim == 0) {")
-    rep("wrench_project<NT, OBJ>(s, P, sacc, s.qacc, s.qacc_s, s.grad, true, true, tid);",
-        "NP(5) wrench_project<NT, OBJ>(s, P, sacc, s.qacc, s.qacc_s, s.grad, true, true, tid, np); t0_ = __builtin_readcyclecounter();")
+    rep("wrench_project<NT, OBJ>(s, P, sacc, s.qacc, s.qacc_s, s.grad(), true, true, tid);",
+        "NP(5) wrench_project<NT, OBJ>(s, P, sacc, s.qacc, s.qacc_s, s.grad(), true, true, tid, np); t0_ = __builtin_readcyclecounter();")
     rep("        KP_SYNC();\n        if (P.scale * sqrtf(g2) < P.tol) { done = true; break; }",
         "        KP_SYNC();\n        NP(3)\n        if (P.scale * sqrtf(g2) < P.tol) { done = true; break; }")
-    rep("lev_hist = max(lev_hist, first_clean_level<NT>(s, P, tid));", "lev_hist = max(lev_hist, first_clean_level<NT>(s, P, tid)); NP(4)")
+    rep("lev_hist = max(lev_hist, first_clean_level<NT>(s, deep, tid));", "lev_hist = max(lev_hist, first_clean_level<NT>(s, deep, tid)); NP(4)")
     rep("#define KP_T(i) if (prof) { t1 = __builtin_readcyclecounter(); pc[i] += t1 - t0; t0 = t1; }", "#define KP_T(i)")
     rep("else niter_total += solve_constraints<NT, OBJ>(s, P, L8, depth, tid, nfact_total, ncap_total);",
         "else niter_total += solve_constraints<NT, OBJ>(s, P, L8, depth, tid, nfact_total, ncap_total, pc);")
@@ -76,23 +76,23 @@ def patch_factor(s):
         nonlocal s
         assert a in s, a[:70]
         s = s.replace(a, b, 1)
-    rep("bool contact_inertia, int tid, int lev_clean = D_NLEV, const float* bwrench = nullptr) {\n",
-        "bool contact_inertia, int tid, int lev_clean = D_NLEV, const float* bwrench = nullptr, unsigned long long* np = nullptr) {\n"
+    rep("const float* warm = nullptr, float* dacc = nullptr, unsigned conlev = 0xFFFFFFFFu) {\n",
+        "const float* warm = nullptr, float* dacc = nullptr, unsigned conlev = 0xFFFFFFFFu, unsigned long long* np = nullptr) {\n"
         "    unsigned long long t0_ = __builtin_readcyclecounter();\n"
         "#define NPA(i) if (np) { unsigned long long t1_ = __builtin_readcyclecounter(); np[i] += t1_ - t0_; t0_ = t1_; }\n")
     rep("            if (active && rowok) s.pAa[6 * b + r] = pA;\n            KP_SYNC();\n            continue;",
         "            if (active && rowok) s.pAa[6 * b + r] = pA;\n            KP_SYNC();\n            NPA(3)\n            continue;")
-    rep("        if (contact_inertia && active && s.con_start[b + 1] > s.con_start[b]) {", "        NPA(0)\n        if (contact_inertia && active && s.con_start[b + 1] > s.con_start[b]) {")
+    rep("        if (contact_inertia && active && ((conlev >> lev) & 1u)) {", "        NPA(0)\n        if (contact_inertia && active && ((conlev >> lev) & 1u)) {")
     rep("        if (lev == 0) {\n            aba_elim3(s, L, rhs, 3, active, IAx, pA);", "        NPA(1)\n        if (lev == 0) {\n            aba_elim3(s, L, rhs, 3, active, IAx, pA);")
-    rep("            s.pAa[6 * b + r] = pA;\n        }\n        KP_SYNC();\n    }\n    aba_forward(s, L, out);\n}",
-        "            s.pAa[6 * b + r] = pA;\n        }\n        KP_SYNC();\n        NPA(2)\n    }\n    aba_forward(s, L, out);\n    NPA(4)\n}")
+    rep("            s.pAa[6 * b + r] = pA;\n        }\n        KP_SYNC();\n    }\n    aba_forward<WARM>(s, L, out, D_NLEV - 1, warm, dacc);\n}",
+        "            s.pAa[6 * b + r] = pA;\n        }\n        KP_SYNC();\n        NPA(2)\n    }\n    aba_forward<WARM>(s, L, out, D_NLEV - 1, warm, dacc);\n    NPA(4)\n}")
     rep("int depth, int tid, int& nfact, int& ncap) {\n    if (s.ncon == 0 && s.nlim == 0) {",
         "int depth, int tid, int& nfact, int& ncap, unsigned long long* np) {\n"
         "    unsigned long long t0_ = __builtin_readcyclecounter();\n"
         "#define NP(i) { unsigned long long t1_ = __builtin_readcyclecounter(); np[i] += t1_ - t0_; t0_ = t1_; }\n"
         "    if (s.ncon == 0 && s.nlim == 0) {")
-    rep("            aba_solve<NT, OBJ>(s, P, L8, s.x, s.search, true, tid, lev_hist);",
-        "            NP(5) aba_solve<NT, OBJ>(s, P, L8, s.x, s.search, true, tid, lev_hist, nullptr, np); t0_ = __builtin_readcyclecounter();")
+    rep("            aba_solve<NT, OBJ>(s, P, L8, s.x, s.search, true, tid, lev_hist, nullptr, nullptr, nullptr, conlev);",
+        "            NP(5) aba_solve<NT, OBJ>(s, P, L8, s.x, s.search, true, tid, lev_hist, nullptr, nullptr, nullptr, conlev, np); t0_ = __builtin_readcyclecounter();")
     rep("#define KP_T(i) if (prof) { t1 = __builtin_readcyclecounter(); pc[i] += t1 - t0; t0 = t1; }", "#define KP_T(i)")
     rep("else niter_total += solve_constraints<NT, OBJ>(s, P, L8, depth, tid, nfact_total, ncap_total);",
         "else niter_total += solve_constraints<NT, OBJ>(s, P, L8, depth, tid, nfact_total, ncap_total, pc);")
