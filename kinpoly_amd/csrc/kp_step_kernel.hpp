@@ -595,7 +595,7 @@ __device__ __forceinline__ void aba_resolve(EnvLds& s, const Lane8& L, const flo
 // ---------------------------------------------------------------- stable-PD torque + residual force (reference controller)
 template <int NT, bool OBJ>
 // tq / act: this env's rows of the PD target and the action in HBM (null: zeros); read here once per substep instead of living in LDS
-__device__ __forceinline__ void spd_torque_rfc(EnvLds& s, const DevTables& T, const Params& P, const Lane8& L8, int depth, int tid, const float* __restrict__ tq, const float* __restrict__ act) {
+__device__ __forceinline__ void spd_torque_rfc(EnvLds& s, const DevTables& T, const Params& P, const Lane8& L8, int tid, const float* __restrict__ tq, const float* __restrict__ act) {
     for (int i = tid; i < D_NV; i += NT) {
         float ep = 0.f, kp = 0.f, kd = 0.f;
         if (i >= 6) {
@@ -1092,7 +1092,7 @@ __device__ __forceinline__ float line_search(EnvLds& s, const Params& P, float g
 // constraint solve: Newton on the primal problem (mj_solNewton) with an exact line search.  Returns iterations.
 // On entry sv holds the spatial accelerations of qacc_s (left by the smooth aba_solve), jv3 holds aref.
 template <int NT, bool OBJ>
-__device__ __forceinline__ int solve_constraints(EnvLds& s, const Params& P, const Lane8& L8, int depth, int tid, int& nfact, int& ncap) {
+__device__ __forceinline__ int solve_constraints(EnvLds& s, const Params& P, const Lane8& L8, int tid, int& nfact, int& ncap) {
     if (s.ncon == 0 && s.nlim == 0) {
         for (int i = tid; i < D_NV; i += NT) s.qacc[i] = s.qacc_s[i];
         KP_SYNC();
@@ -1501,7 +1501,7 @@ __device__ __forceinline__ void obj_integrate(EnvLdsObj& s, const Params& P, int
 // (q_humanoid, a_object...).  The Newton system is solved exactly by block elimination: the articulated-body pass factorises
 // the humanoid block, 6 n_obj + 1 bias-only passes form the Schur complement on the objects when a hull touches one.
 template <int NT>
-__device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params& P, const Lane8& L8, int depth, int tid, int& nfact, int& ncap) {
+__device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params& P, const Lane8& L8, int tid, int& nfact, int& ncap) {
     constexpr int ST = 6 * D_MAXOBJ + 1;
     const int nobj = s.nobj, no6 = 6 * nobj;
     // smooth acceleration of the objects: I_eff a = -bias wrench
@@ -1756,7 +1756,7 @@ __device__ __forceinline__ void step_body(StepArgs A, const int env_in, const in
     for (int sub = 0; sub < A.n_substeps; sub++) {
         if (prof) t0 = __builtin_readcyclecounter();
         // stale mode: the controller sees M / bias of the previous forward pass (cinert, cdof, bias still in LDS)
-        if (P.stale) spd_torque_rfc<NT, OBJ>(s, T, P, L8, depth, tid, tq_row, act_row);
+        if (P.stale) spd_torque_rfc<NT, OBJ>(s, T, P, L8, tid, tq_row, act_row);
         KP_T(0)
         // ---- mj_forward at the current state
 #pragma unroll
@@ -1780,14 +1780,14 @@ __device__ __forceinline__ void step_body(StepArgs A, const int env_in, const in
         KP_T(2)
         make_constraint<NT, OBJ>(s, T, P, tid);                 // needs sv = cvel: before any aba_solve
         KP_T(3)
-        if (!P.stale) spd_torque_rfc<NT, OBJ>(s, T, P, L8, depth, tid, tq_row, act_row);
+        if (!P.stale) spd_torque_rfc<NT, OBJ>(s, T, P, L8, tid, tq_row, act_row);
         for (int i = tid; i < D_NV; i += NT) s.extra[i] = 0.f;
         KP_SYNC();
         // qacc_smooth = M^-1 qfrc_smooth; sv = its spatial accelerations; Mv/mres = those of (warm start - qacc_smooth) for the Newton solve
         aba_solve<NT, OBJ, true>(s, P, L8, s.applied, s.qacc_s, false, tid, D_NLEV, s.fb, s.qacc, s.Mv);
         KP_T(4)
-        if constexpr (OBJ) niter_total += solve_constraints_obj<NT>(s, P, L8, depth, tid, nfact_total, ncap_total);
-        else niter_total += solve_constraints<NT, OBJ>(s, P, L8, depth, tid, nfact_total, ncap_total);
+        if constexpr (OBJ) niter_total += solve_constraints_obj<NT>(s, P, L8, tid, nfact_total, ncap_total);
+        else niter_total += solve_constraints<NT, OBJ>(s, P, L8, tid, nfact_total, ncap_total);
         KP_T(5)
         maxcon = max(maxcon, s.ncon);
         // ---- semi-implicit Euler (mj_Euler, no damping)

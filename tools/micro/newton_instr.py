@@ -13,8 +13,8 @@ def patch(s):
         nonlocal s
         assert a in s, a[:70]
         s = s.replace(a, b, 1)
-    rep('''__device__ __forceinline__ int solve_constraints(EnvLds& s, const Params& P, const Lane8& L8, int depth, int tid, int& nfact, int& ncap) {
-    if (s.ncon == 0 && s.nlim == 0) {''', '''__device__ __forceinline__ int solve_constraints(EnvLds& s, const Params& P, const Lane8& L8, int depth, int tid, int& nfact, int& ncap, unsigned long long* np) {
+    rep('''__device__ __forceinline__ int solve_constraints(EnvLds& s, const Params& P, const Lane8& L8, int tid, int& nfact, int& ncap) {
+    if (s.ncon == 0 && s.nlim == 0) {''', '''__device__ __forceinline__ int solve_constraints(EnvLds& s, const Params& P, const Lane8& L8, int tid, int& nfact, int& ncap, unsigned long long* np) {
     unsigned long long t0_ = __builtin_readcyclecounter();
 #define NP(i) { unsigned long long t1_ = __builtin_readcyclecounter(); np[i] += t1_ - t0_; t0_ = t1_; }
     if (s.ncon == 0 && s.nlim == 0) {''')
@@ -36,8 +36,8 @@ def patch(s):
         NP(5)
         if (improvement < P.tol) { it++; done = true; break; }''')
     rep("#define KP_T(i) if (prof) { t1 = __builtin_readcyclecounter(); pc[i] += t1 - t0; t0 = t1; }", "#define KP_T(i)")
-    rep("else niter_total += solve_constraints<NT, OBJ>(s, P, L8, depth, tid, nfact_total, ncap_total);",
-        "else niter_total += solve_constraints<NT, OBJ>(s, P, L8, depth, tid, nfact_total, ncap_total, pc);")
+    rep("else niter_total += solve_constraints<NT, OBJ>(s, P, L8, tid, nfact_total, ncap_total);",
+        "else niter_total += solve_constraints<NT, OBJ>(s, P, L8, tid, nfact_total, ncap_total, pc);")
     return s
 
 
@@ -54,8 +54,8 @@ def patch_gradient(s):
         "    if (tid < D_NB) {")
     rep("    KP_SYNC();\n    subtree_sums<NT>(s, tid);\n", "    KP_SYNC();\n    NPW(0)\n    subtree_sums<NT>(s, tid);\n    NPW(1)\n")
     rep("        out[d] = v;\n    }\n    KP_SYNC();\n}", "        out[d] = v;\n    }\n    KP_SYNC();\n    NPW(2)\n}")
-    rep("int depth, int tid, int& nfact, int& ncap) {\n    if (s.ncon == 0 && s.nlim == 0) {",
-        "int depth, int tid, int& nfact, int& ncap, unsigned long long* np) {\n"
+    rep("const Lane8& L8, int tid, int& nfact, int& ncap) {\n    if (s.ncon == 0 && s.nlim == 0) {",
+        "const Lane8& L8, int tid, int& nfact, int& ncap, unsigned long long* np) {\n"
         "    unsigned long long t0_ = __builtin_readcyclecounter();\n"
         "#define NP(i) { unsigned long long t1_ = __builtin_readcyclecounter(); np[i] += t1_ - t0_; t0_ = t1_; }\n"
         "    if (s.ncon == 0 && s.nlim == 0) {")
@@ -65,8 +65,8 @@ def patch_gradient(s):
         "        KP_SYNC();\n        NP(3)\n        if (P.scale * sqrtf(g2) < P.tol) { done = true; break; }")
     rep("lev_hist = max(lev_hist, first_clean_level<NT>(s, deep, tid));", "lev_hist = max(lev_hist, first_clean_level<NT>(s, deep, tid)); NP(4)")
     rep("#define KP_T(i) if (prof) { t1 = __builtin_readcyclecounter(); pc[i] += t1 - t0; t0 = t1; }", "#define KP_T(i)")
-    rep("else niter_total += solve_constraints<NT, OBJ>(s, P, L8, depth, tid, nfact_total, ncap_total);",
-        "else niter_total += solve_constraints<NT, OBJ>(s, P, L8, depth, tid, nfact_total, ncap_total, pc);")
+    rep("else niter_total += solve_constraints<NT, OBJ>(s, P, L8, tid, nfact_total, ncap_total);",
+        "else niter_total += solve_constraints<NT, OBJ>(s, P, L8, tid, nfact_total, ncap_total, pc);")
     return s
 
 
@@ -86,16 +86,16 @@ def patch_factor(s):
     rep("        if (lev == 0) {\n            aba_elim3(s, L, rhs, 3, active, IAx, pA);", "        NPA(1)\n        if (lev == 0) {\n            aba_elim3(s, L, rhs, 3, active, IAx, pA);")
     rep("            s.pAa[6 * b + r] = pA;\n        }\n        KP_SYNC();\n    }\n    aba_forward<WARM>(s, L, out, D_NLEV - 1, warm, dacc);\n}",
         "            s.pAa[6 * b + r] = pA;\n        }\n        KP_SYNC();\n        NPA(2)\n    }\n    aba_forward<WARM>(s, L, out, D_NLEV - 1, warm, dacc);\n    NPA(4)\n}")
-    rep("int depth, int tid, int& nfact, int& ncap) {\n    if (s.ncon == 0 && s.nlim == 0) {",
-        "int depth, int tid, int& nfact, int& ncap, unsigned long long* np) {\n"
+    rep("const Lane8& L8, int tid, int& nfact, int& ncap) {\n    if (s.ncon == 0 && s.nlim == 0) {",
+        "const Lane8& L8, int tid, int& nfact, int& ncap, unsigned long long* np) {\n"
         "    unsigned long long t0_ = __builtin_readcyclecounter();\n"
         "#define NP(i) { unsigned long long t1_ = __builtin_readcyclecounter(); np[i] += t1_ - t0_; t0_ = t1_; }\n"
         "    if (s.ncon == 0 && s.nlim == 0) {")
     rep("            aba_solve<NT, OBJ>(s, P, L8, s.x, s.search, true, tid, lev_hist, nullptr, nullptr, nullptr, conlev);",
         "            NP(5) aba_solve<NT, OBJ>(s, P, L8, s.x, s.search, true, tid, lev_hist, nullptr, nullptr, nullptr, conlev, np); t0_ = __builtin_readcyclecounter();")
     rep("#define KP_T(i) if (prof) { t1 = __builtin_readcyclecounter(); pc[i] += t1 - t0; t0 = t1; }", "#define KP_T(i)")
-    rep("else niter_total += solve_constraints<NT, OBJ>(s, P, L8, depth, tid, nfact_total, ncap_total);",
-        "else niter_total += solve_constraints<NT, OBJ>(s, P, L8, depth, tid, nfact_total, ncap_total, pc);")
+    rep("else niter_total += solve_constraints<NT, OBJ>(s, P, L8, tid, nfact_total, ncap_total);",
+        "else niter_total += solve_constraints<NT, OBJ>(s, P, L8, tid, nfact_total, ncap_total, pc);")
     return s
 
 
