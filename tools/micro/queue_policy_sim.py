@@ -102,6 +102,8 @@ if __name__ == "__main__":
         print(f"== {kind}: measured launch {ms1:.3f} ms; env cycles mean {cost.mean() / 1e6:.2f} M p50 {np.percentile(cost, 50) / 1e6:.2f} p90 {np.percentile(cost, 90) / 1e6:.2f} "
               f"p99 {np.percentile(cost, 99) / 1e6:.2f} max {cost.max() / 1e6:.2f} M = {cost.max() / CLK / 1e3:.3f} ms; sum / 2048 = {(cost + 3 * HAND).sum() / 2048 / CLK / 1e3:.3f} ms; "
               f"corr with the previous launch {np.corrcoef(cost, prev)[0, 1]:.2f}")
+        for theta in (1.1, 1.25, 1.4, 1.6, 2.0):
+            print(f"   jobs (7, 5, 3): priority lane for jobs that ran > {theta} x the mean: makespan {simulate(cost, (7, 5, 3), 2048, 'prio', prev, theta) / CLK / 1e3:.3f} ms")
         for sizes in ((7, 5, 3), (5, 4, 3, 2, 1), (15,)):
             for pol in ("fifo", "lpt_prev", "lpt_true", "prio", "prio_lpt_prev", "continue_first"):
                 if len(sizes) == 1 and pol not in ("fifo", "lpt_prev", "lpt_true"):
