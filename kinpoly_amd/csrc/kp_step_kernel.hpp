@@ -1142,7 +1142,7 @@ __device__ __forceinline__ int solve_constraints(EnvLds& s, const Params& P, con
         }
         changed += active_set_changed<NT>(s, P, tid, deep);
         g2 = block_sum<NT>(s, g2, tid);
-        changed = block_sum<NT>(s, changed, tid);
+        changed = (NT == 64) ? (__ballot(changed > 0.f) != 0ull ? 1.f : 0.f) : block_sum<NT>(s, changed, tid);     // one wave: a ballot is the whole reduction
         KP_SYNC();
         if (P.scale * sqrtf(g2) < P.tol) { done = true; break; }
         // search = -H^-1 grad,  H = M + J^T D_active J : articulated-body pass with contact inertia; while the active set
@@ -1579,7 +1579,7 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
             g2 += dot(g.l, g.l) + dot(t, t);
         }
         g2 = block_sum<NT>(s, g2, tid);
-        changed = block_sum<NT>(s, changed, tid);
+        changed = (NT == 64) ? (__ballot(changed > 0.f) != 0ull ? 1.f : 0.f) : block_sum<NT>(s, changed, tid);     // one wave: a ballot is the whole reduction
         KP_SYNC();
         if (P.scale * sqrtf(g2) < P.tol) { done = true; break; }
         // search direction
