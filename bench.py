@@ -16,6 +16,11 @@ Workloads (all BASELINE configs[2] env-steps at 4096 envs/GPU unless noted):
                  contains the device-side reset (round 1's headline; secondary now)
     wild_eval    BASELINE configs[4]: the --wild evaluation path (humanoid_smpl_neutral_mesh_all.xml, mode "test" = mean actions of both
                  policies, no GT termination, fail-safe on), inference only
+    objects      BASELINE configs[3] on one GPU: the four action classes of dataset.synthetic_takes (sit: chair / push: box on table /
+                 avoid: Can / step: step box) uniformly over the 4096 envs, the active objects simulated as free
+                 bodies (kp_step_queue_kernel<true>), the kinematic policy's output replaced by the clip's next pose + noise
+    train_iter   one AgentAR.optimize_policy per "step": sample 4096 x 24 env-steps, GAE, all-gather of advantages / returns,
+                 data-parallel PPO + supervised update (agent_ar.py:271-297); value = env-steps/s of the whole iteration
 
 Prints ONE JSON line on rank 0 (see the task contract) with `roofline` (dominant kernel kp_step_queue_kernel = kp_step_kernel scheduled as jobs,
 live HIP-event launch durations; `traffic` / `valu` only from a rocprofv3 --pmc pass of THIS command and workload committed under profiles/)
@@ -38,10 +43,12 @@ sys.path.insert(0, ROOT)
 ENVS_PER_GPU = 4096
 CLIP_LEN = 100                      # fr_num (config/statear/kin_poly.yml:11)
 ALGO_BYTES_PER_ENV_STEP = 2772      # humanoid-only compulsory fp32 traffic of do_simulation
+ALGO_BYTES_PER_ENV_STEP_OBJ = 3292  # with the object block (nq 111 / nv 105)
+TRAIN_HORIZON = 24                  # env-steps per env and iteration of the train_iter workload (4096 x 24 = 98 304 samples; kin_poly.yml asks for >= 10 000)
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8.0 TB/s spec
 VALU_FP32_PEAK_TFLOPS = 157.3       # 256 CUs x 4 SIMDs x 64 lanes x 2 (FMA) x 2.4 GHz (vector fp32; MI355X spec sheet)
 MFMA_FP32_PEAK_TFLOPS = 157.3       # dense fp32 matrix peak (spec sheet): the policy / value GEMMs run in fp32
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r02")
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r03")
 
 
 def build_engine(device_index, seed, threads, workload="tracked"):
@@ -57,13 +64,32 @@ def build_engine(device_index, seed, threads, workload="tracked"):
     policy = KinPolicy().to(env.device).float()
     g = torch.Generator().manual_seed(seed)
     headings = (torch.rand(ENVS_PER_GPU, generator=g) * 2 - 1) * np.pi
-    ctx = standing_context(ENVS_PER_GPU, CLIP_LEN, std["qpos"], std["qvel"], env.sim, headings)
+    if workload == "objects":
+        ctx = object_contexts(env, std, seed)
+    else:
+        ctx = standing_context(ENVS_PER_GPU, CLIP_LEN, std["qpos"], std["qvel"], env.sim, headings)
     if wild:            # the kinematic roll-out the fail-safe falls back to (ar_context['ar_qpos' / 'ar_qvel']): the clip itself
         ctx["ar_qpos"], ctx["ar_qvel"] = ctx["qpos"].clone(), torch.zeros((ENVS_PER_GPU, CLIP_LEN, 75), device=env.device)
     env.load_context(ctx)
     sampler = VectorSampler(env, policy, mean_action=wild)
     sampler.start()
     return env, policy, sampler, std
+
+
+def object_contexts(env, std, seed):
+    """BASELINE configs[3] stand-in (the MoCap set is absent): SURVEY 8(d) config 4 = dataset.synthetic_takes -- standing, then seeded
+    smooth joint-space sinusoids, the action's object(s) at constant poses around the humanoid, random yaw -- 8 takes per action class,
+    CLIP_LEN-frame clips drawn uniformly over the takes (StateARDataset.sample_batch), so the four classes share the 4096 envs evenly."""
+    from kinpoly_amd import dataset as D
+    from kinpoly_amd.model_compiler import read_kpm
+    from kinpoly_amd.sim import STEP_KPM
+    takes = D.synthetic_takes(env.sim, std["qpos"], n_per_action=8, T_range=(CLIP_LEN + 10, CLIP_LEN + 60), body_mass=read_kpm(STEP_KPM)["body_mass"], seed=seed)
+    ds = D.StateARDataset(takes, fr_num=CLIP_LEN, seed=seed, device=env.device)
+    ctx = ds.sample_batch(ENVS_PER_GPU, use_freq=False)
+    starts = ds.rng.randint(0, 10, ENVS_PER_GPU)
+    ctx = ds.batch(ctx["take_ind"].numpy(), starts, CLIP_LEN)
+    ctx["init_qpos"], ctx["init_qvel"] = ctx["qpos"][:, 0].contiguous(), ctx["qvel"][:, 0].contiguous()
+    return ctx
 
 
 def tracking_action(env):
@@ -76,7 +102,7 @@ def tracking_action(env):
     return a
 
 
-def rollout_steps(sampler, k, a_track=None, wild=False):
+def rollout_steps(sampler, k, a_track=None, wild=False, follow_clip=False):
     """k batched env-steps without keeping the experience (identical work to VectorSampler.sample's loop body).
     wild: the eval_ar_policy.py --wild loop (:196-215): mean actions, an env that terminates early is put back on the kinematic
     roll-out (ar_fail_safe) and keeps going, an env that finishes its clip starts it again."""
@@ -85,6 +111,9 @@ def rollout_steps(sampler, k, a_track=None, wild=False):
     with torch.no_grad():
         for _ in range(k):
             action, sampler.hx = pol.select_action(sampler.obs, sampler.hx, wild, env.gen)
+            if follow_clip:                                      # moving clips (objects workload): the action that reproduces the clip's NEXT pose
+                qn = env._ar_frame("qpos")
+                a_track = torch.cat([qn[:, 2:3], sampler.obs[:, 1:5], qn[:, 7:], torch.zeros((env.n, 6), device=env.device)], 1)
             if a_track is not None:                              # the policy's GEMMs ran; a trained policy's output stands in for theirs
                 action = a_track if wild else torch.add(a_track, torch.randn(action.shape, device=action.device, generator=env.gen), alpha=0.04)
             obs, _, done, info = env.step(action.contiguous())
@@ -208,7 +237,12 @@ WORKLOAD_DESC = {
     "random_init": "BASELINE configs[2] rollout, same env-step, seeded random-init networks: every env terminates and is reset on (almost) every step",
     "wild_eval": "BASELINE configs[4]: --wild eval_ar_policy path (humanoid_smpl_neutral_mesh_all.xml, mode test: mean actions of both policies, no GT "
                  "termination, fail-safe on), batched inference, standing clip",
+    "objects": "BASELINE configs[3] on one GPU: same env-step with the scene's free objects simulated (sit: chair, push: box on table, avoid: Can, step: step box; "
+               "SURVEY 8(d) config 4 synthetic takes, four action classes evenly over the envs), kinematic policy's output replaced by the clip's next pose + noise",
+    "train_iter": "one AgentAR.optimize_policy per step: sample 4096 x 24 env-steps of the configs[2] rollout (random-init TrajARNet, standing clips), GAE, all-gather of "
+                  "advantages / returns, 10 PPO epochs + 20 supervised step updates, gradients all-reduced (kin_poly.yml:36-71)",
 }
+ROLLOUT_WORKLOADS = ("tracked", "random_init", "wild_eval", "objects")
 
 
 def run_workload(workload, device_index, seed, threads, steps, warmup, barrier=None):
@@ -218,15 +252,17 @@ def run_workload(workload, device_index, seed, threads, steps, warmup, barrier=N
     if workload in ("tracked", "wild_eval"):
         a_track = tracking_action(env)
         sampler.start()
-    wild = workload == "wild_eval"
-    rollout_steps(sampler, warmup, a_track, wild)
+    wild, follow = workload == "wild_eval", workload == "objects"
+    if workload in ("tracked", "objects"):
+        stagger_episodes(env, sampler, seed, follow)
+    rollout_steps(sampler, warmup, a_track, wild, follow)
     env.sim.timing_reset()
     if barrier is not None:
         barrier()
     else:
         torch.cuda.synchronize()
     t0 = time.perf_counter()
-    n_done = rollout_steps(sampler, steps, a_track, wild)
+    n_done = rollout_steps(sampler, steps, a_track, wild, follow)
     if barrier is not None:
         barrier()
     else:
@@ -238,6 +274,88 @@ def run_workload(workload, device_index, seed, threads, steps, warmup, barrier=N
     return rec, env, policy, sampler, std
 
 
+def stagger_episodes(env, sampler, seed, follow):
+    """Episodes at every stage of their clip, as in a running job: cur_t staggered uniformly, so that ~1 / (CLIP_LEN - 1) of the envs end their
+    clip on every step and the device-side reset is part of every timed step.  The standing clip is the same at every
+    t; an env of the objects workload is put on its clip's pose at that frame."""
+    g = torch.Generator().manual_seed(seed + 1000)
+    env.cur_t.copy_(torch.randint(0, CLIP_LEN - 1, (env.n,), generator=g).to(env.device, torch.int32))
+    if follow:
+        q = env.ctx["qpos"][env.row.long(), env.cur_t.long()].contiguous()
+        env.sim.set_state(q, env.ctx["init_qvel"][env.row.long()].contiguous())
+        env.sim.set_target(q)
+    sampler.obs = env.sim.obs_ar(env._ctx_struct, env._obs).clone()
+
+
+def object_scene_launches(device_index, threads):
+    """Physics kernel alone on the two contact-heavy object scenes of tools/obj_bench.py (4096 envs, kp_step_queue_kernel<true>): standing on the
+    free step box and the push scene with the table within reach -- the launch durations VERDICT r2 asks to see on the driver's record."""
+    from kinpoly_amd.sim import STEP_KPM, KpModel, KpSim
+    std = np.load(os.path.join(ROOT, "tests", "golden", "standing_neutral.npz"))
+    n, rng = ENVS_PER_GPU, np.random.default_rng(3)
+    x0, y0 = std["qpos"][0], std["qpos"][1]
+    out = {}
+    for name, active, lift in (("standing_on_step_box", {4: [x0, y0, 0.3705, 1, 0, 0, 0]}, 0.341),
+                               ("push_table_within_reach", {1: [x0 + 0.75, y0, 0.921, 1, 0, 0, 0], 2: [x0 + 0.75, y0, 0.7905, 1, 0, 0, 0]}, 0.0),
+                               ("step_box_untouched", {4: [x0 + 2.0, y0, 0.3705, 1, 0, 0, 0]}, 0.0)):
+        blk = np.zeros((n, 35))
+        for i in range(5):
+            blk[:, 7 * i: 7 * i + 3] = [(i + 1) * 100, 100, 0]
+        for oi, pose in active.items():
+            blk[:, 7 * oi: 7 * oi + 7] = pose
+        sim = KpSim(KpModel(STEP_KPM, threads_per_env=threads), n, device_index)
+        qpos = np.tile(std["qpos"], (n, 1)); qpos[:, 2] += lift; qpos[:, 7:] += rng.normal(size=(n, 69)) * 0.05
+        dev = lambda a: torch.tensor(a, dtype=torch.float32, device=sim.device)      # noqa: E731
+        q = dev(qpos)
+        sim.set_objects(dev(blk)); sim.set_state(q, dev(rng.normal(size=(n, 75)) * 0.2)); sim.set_target(q.clone())
+        a = dev(rng.normal(size=(n, 75)) * 0.1)
+        ts = []
+        for _ in range(8):
+            sim.step_ctrl(a, 15)
+            ts.append(sim.last_step_seconds())
+        dg = sim.diag()
+        out[name] = {"launch_ms": float(np.mean(ts[2:]) * 1e3), "contacts_mean": float(dg[:, 0].mean()), "newton_iters_per_substep": float(dg[:, 1].mean() / 15.0),
+                     "bad_envs": int(((dg[:, 2] & 255) != 0).sum())}
+        del sim
+        torch.cuda.empty_cache()
+    return out
+
+
+def train_iteration(device_index, seed, horizon, iters, warm, barrier=None, threads=64):
+    """`iters` timed AgentAR.optimize_policy calls (after `warm` untimed) at ENVS_PER_GPU x horizon env-steps per rank."""
+    from kinpoly_amd.agent import AgentAR
+    from kinpoly_amd.env import standing_context
+    from kinpoly_amd import sim as kpsim
+    std = np.load(os.path.join(ROOT, "tests", "golden", "standing_neutral.npz"))
+    fk_sim = kpsim.KpSim(kpsim.KpModel(), ENVS_PER_GPU, device_index)
+    g = torch.Generator().manual_seed(seed)
+
+    def context_fn(m):
+        h = (torch.rand(m, generator=g) * 2 - 1) * np.pi
+        ctx = standing_context(m, CLIP_LEN, std["qpos"], std["qvel"], fk_sim, h)
+        ctx["obj_pose"] = torch.tensor([0.0, 0, 0, 1, 0, 0, 0], device=ctx["qpos"].device).repeat(m, CLIP_LEN, 1)
+        return ctx
+    agent = AgentAR(ENVS_PER_GPU, context_fn, device=device_index, horizon=horizon, seed=seed, use_init_context=False, pool_depth=2,
+                    model_options={"threads_per_env": threads})
+    for i in range(warm):
+        agent.optimize_policy(i)
+    (barrier or torch.cuda.synchronize)()
+    t0 = time.perf_counter()
+    ts = tu = 0.0
+    info = {}
+    for i in range(iters):
+        info = agent.optimize_policy(warm + i)
+        ts += info["T_sample"]; tu += info["T_update"]
+    (barrier or torch.cuda.synchronize)()
+    el = time.perf_counter() - t0
+    rec = {"elapsed": el, "T_sample": ts / iters, "T_update": tu / iters, "samples_per_iter_per_gpu": ENVS_PER_GPU * horizon, "horizon": horizon,
+           "iters": iters, "warmup": warm, "samples_per_s_per_gpu": ENVS_PER_GPU * horizon * iters / el, "avg_reward": info.get("avg_reward"),
+           "pool_exhausted": info.get("pool_exhausted")}
+    del agent, fk_sim
+    torch.cuda.empty_cache()
+    return rec
+
+
 def main():
     if len(sys.argv) >= 3 and sys.argv[1] == "--cpu-baseline-worker":
         std = np.load(os.path.join(ROOT, "tests", "golden", "standing_neutral.npz"))
@@ -247,13 +365,18 @@ def main():
         return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 60; 3 for --workload train_iter)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default 20; 1 for --workload train_iter)")
     ap.add_argument("--threads-per-env", type=int, default=int(os.environ.get("KP_THREADS_PER_ENV", "64")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads and the GEMM probe (profiling runs)")
     ap.add_argument("--workload", choices=tuple(WORKLOAD_DESC), default="tracked")
     args = ap.parse_args()
+    train = args.workload == "train_iter"
+    if args.steps is None:
+        args.steps = 3 if train else 60
+    if args.warmup is None:
+        args.warmup = 1 if train else 20
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -264,35 +387,66 @@ def main():
     if shared:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    force_pg = os.environ.get("KP_BENCH_FORCE_PG") == "1"        # a 1-rank run that still creates the nccl group (RCCL smoke on a 1-GPU box)
+    if world > 1 or force_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if shared:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    in_group = dist.is_initialized()
+    cdev = "cpu" if shared else torch.device("cuda", local_rank)
 
     def barrier():
-        if world > 1:
+        if in_group:
             dist.barrier()
         torch.cuda.synchronize()
 
-    rec, env, policy, sampler, std = run_workload(args.workload, local_rank, 4 + rank, args.threads_per_env, args.steps, args.warmup, barrier)
+    # every rank that takes part adds 1 through the job's collective backend (RCCL all-reduce of a device tensor under nccl)
+    ranks_seen = 1
+    if in_group:
+        one = torch.ones(1, device=cdev, dtype=torch.float32)
+        dist.all_reduce(one)
+        ranks_seen = int(one.item())
+
+    if train:
+        rec = train_iteration(local_rank, 4, TRAIN_HORIZON, args.steps, args.warmup, barrier, args.threads_per_env)
+        env = policy = sampler = None
+        std = np.load(os.path.join(ROOT, "tests", "golden", "standing_neutral.npz"))
+    else:
+        rec, env, policy, sampler, std = run_workload(args.workload, local_rank, 4 + rank, args.threads_per_env, args.steps, args.warmup, barrier)
     elapsed = rec["elapsed"]
-    if world > 1:
-        t = torch.tensor([elapsed], device="cpu" if shared else "cuda", dtype=torch.float64)
+    per_rank_ms = [elapsed / args.steps * 1e3]
+    if in_group:
+        t = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        per_rank_ms = [float(x.item()) / args.steps * 1e3 for x in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kern_s, n_launch, diag = rec["kern_s"], rec["n_launch"], rec["diag"]
-    cost = env.sim.launch_cost().astype(np.float64)
 
-    if rank == 0:
+    if rank == 0 and train:
+        per_step = ENVS_PER_GPU * TRAIN_HORIZON
+        out = {"metric": "env-steps/sec (whole node) at 4096 envs/GPU, 69-DoF SMPL", "value": per_step * world * args.steps / elapsed, "unit": "env-steps/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": WORKLOAD_DESC["train_iter"], "workload_id": "train_iter", "envs_per_gpu": ENVS_PER_GPU, "horizon": TRAIN_HORIZON,
+                          "samples_per_step": per_step * world, "parallelism": f"env-sharded x{world}, data-parallel update"},
+               "ranks_seen": ranks_seen, "ms_per_step_per_rank": per_rank_ms, "collective_backend": (dist.get_backend() if in_group else None),
+               "train_iteration": {k: rec[k] for k in ("T_sample", "T_update", "samples_per_iter_per_gpu", "avg_reward", "pool_exhausted")}}
+        print(json.dumps(out), flush=True)
+    elif rank == 0:
+        kern_s, n_launch, diag = rec["kern_s"], rec["n_launch"], rec["diag"]
+        cost = env.sim.launch_cost().astype(np.float64)
+        objects = args.workload == "objects"
         value = ENVS_PER_GPU * world * args.steps / elapsed
-        algo_bytes = ALGO_BYTES_PER_ENV_STEP * ENVS_PER_GPU
+        algo_bytes = (ALGO_BYTES_PER_ENV_STEP_OBJ if objects else ALGO_BYTES_PER_ENV_STEP) * ENVS_PER_GPU
         achieved = algo_bytes / kern_s / 1e9
-        kernel_name = "kp_step_queue_kernel" if int(env.model.get_option("substeps_per_job")) > 0 else "kp_step_kernel"
+        kernel_name = ("kp_step_queue_kernel" if int(env.model.get_option("substeps_per_job")) > 0 else "kp_step_kernel") + ("<true>" if objects else "<false>")
         # HBM bytes / instruction counts: ONLY from a rocprofv3 --pmc pass of this same command and workload (tools/profile_bench.sh writes
-        # profiles/r02/pmc_bench_<workload>.json); otherwise null -- nothing canned from another workload enters the line
+        # profiles/r03/pmc_bench_<workload>.json); otherwise null -- nothing canned from another workload enters the line
         traffic, traffic_src, valu = None, None, None
         pmc_path = os.path.join(PROFILE_DIR, f"pmc_bench_{args.workload}.json")
         if os.path.exists(pmc_path):
@@ -304,7 +458,7 @@ def main():
             valu = pj.get("issue")
         # instruction issue: instructions per env-step from that PMC pass, wave cycles per env-step live from this run's last
         # launch (kp_sim_launch_cost), against what two waves per SIMD can issue (tools/micro/valu_probe.hip: one instruction per 2.9 SIMD cycles)
-        issue = None
+        issue, valu_active = None, None
         if valu and valu.get("valu_insts_per_launch"):
             insts = (valu["valu_insts_per_launch"] + valu.get("salu_insts_per_launch", 0.0) + valu.get("lds_insts_per_launch", 0.0)) / ENVS_PER_GPU
             cyc = float(cost.mean())
@@ -312,6 +466,7 @@ def main():
                      "simd_cycles_per_inst": cyc / insts / 2.0, "attainable_simd_cycles_per_inst_at_2_waves": 2.9, "frac_of_attainable_issue": 2.9 / (cyc / insts / 2.0),
                      "note": "instructions: VALU + SALU + LDS wave-instructions of the PMC pass named in traffic_source; cycles: shader clock inside the jobs of this run's last launch "
                              "(hand-overs included, tail of the launch excluded); a third wave per SIMD buys ~1 % (profiles/r02/occupancy_premise.log)"}
+            valu_active = valu.get("valu_active_frac_of_launch")
         out = {
             "metric": "env-steps/sec (whole node) at 4096 envs/GPU, 69-DoF SMPL", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -319,9 +474,13 @@ def main():
             "config": {"workload": WORKLOAD_DESC[args.workload], "workload_id": args.workload, "envs_per_gpu": ENVS_PER_GPU, "substeps": 15, "clip_len": CLIP_LEN,
                        "threads_per_env": args.threads_per_env, "parallelism": f"env-sharded x{world}",
                        "gemm_selection": "kinpoly_amd/assets/tunableop_gfx950.csv (rocBLAS / hipBLASLt solution per shape, fp32)" if getattr(build_engine, "tuned", False) else "library default"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "ranks_seen": ranks_seen, "ms_per_step_per_rank": per_rank_ms, "collective_backend": (dist.get_backend() if in_group else None),
+            # the kernel is bound by wave-level instruction issue, not by HBM or MFMA (its state lives in LDS); the HBM figures the
+            # contract asks for are kept: achieved = algorithmic bytes / launch, traffic = PMC bytes / launch, traffic_over_algorithmic = their ratio
+            "roofline": {"bound": "valu-issue", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_over_algorithmic": (traffic / algo_bytes) if traffic else None, "traffic_source": traffic_src,
                          "kernel": kernel_name, "launch_ms": kern_s * 1e3, "launches_timed": n_launch, "algorithmic_bytes_per_launch": algo_bytes,
+                         "valu_active_frac_of_launch": valu_active, "frac_of_attainable_issue": issue["frac_of_attainable_issue"] if issue else None,
                          "limiter": "wave-level instruction issue: the SIMDs are saturated by their two resident waves (state lives in LDS, so the compulsory HBM traffic is tiny by construction; DESIGN.md section 6)",
                          "valu": valu, "issue": issue},
             "kernel_share_of_step": kern_s / (elapsed / args.steps),
@@ -330,7 +489,7 @@ def main():
             "bad_envs": int(((diag[:, 2] & 255) != 0).sum()), "newton_cap_hits": int((diag[:, 2] >> 8).sum()),
             "episodes_ended_per_step_frac": rec["n_done"] / (ENVS_PER_GPU * args.steps),
             # per-env shader-clock cycles of the last launch (kp_sim_launch_cost): what the launch would take if its waves were perfectly
-            # packed on the 2048 resident slots vs its longest env
+            # packed on the resident slots vs its longest env
             "launch_balance": {"substeps_per_job": int(env.model.get_option("substeps_per_job")), "sum_env_cycles_over_2048_slots_ms": float(cost.sum() / 2048 / 2.38e6),
                                "longest_env_ms": float(cost.max() / 2.38e6), "median_env_ms": float(np.median(cost) / 2.38e6)},
         }
@@ -342,18 +501,34 @@ def main():
             del sampler, env, policy
             torch.cuda.empty_cache()
             out["secondary_workloads"] = {}
-            for wl in [w for w in WORKLOAD_DESC if w != args.workload]:
+            for wl in [w for w in ROLLOUT_WORKLOADS if w != args.workload]:
                 try:
                     r2, e2, p2, s2, _ = run_workload(wl, local_rank, 4 + rank, args.threads_per_env, 40, 15)
+                    ab = (ALGO_BYTES_PER_ENV_STEP_OBJ if wl == "objects" else ALGO_BYTES_PER_ENV_STEP) * ENVS_PER_GPU
                     out["secondary_workloads"][wl] = {"value": ENVS_PER_GPU * 40 / r2["elapsed"], "unit": "env-steps/s", "ms_per_step": r2["elapsed"] / 40 * 1e3, "steps": 40, "warmup": 15,
                                                       "launch_ms": r2["kern_s"] * 1e3, "contacts_mean": float(r2["diag"][:, 0].mean()),
                                                       "newton_iters_per_substep": float(r2["diag"][:, 1].mean() / 15.0),
+                                                      "bad_envs": int(((r2["diag"][:, 2] & 255) != 0).sum()),
+                                                      "algorithmic_bytes_per_launch": ab, "achieved_gbs": ab / r2["kern_s"] / 1e9,
                                                       ("fail_safe_per_step_frac" if wl == "wild_eval" else "episodes_ended_per_step_frac"): r2["n_done"] / (ENVS_PER_GPU * 40),
                                                       "workload": WORKLOAD_DESC[wl]}
                     del r2, e2, p2, s2
                     torch.cuda.empty_cache()
                 except Exception as ex:
                     out["secondary_workloads"][wl] = {"error": f"{type(ex).__name__}: {ex}"[:200]}
+            try:        # physics kernel alone on the contact-heavy object scenes (kp_step_queue_kernel<true>)
+                out["object_scenes"] = object_scene_launches(local_rank, args.threads_per_env)
+            except Exception as ex:
+                out["object_scenes"] = {"error": f"{type(ex).__name__}: {ex}"[:200]}
+            try:        # a whole training iteration: the update is its larger part
+                out["train_iteration"] = {}
+                for hz, it in ((TRAIN_HORIZON, 2), (CLIP_LEN - 1, 1)):
+                    r3 = train_iteration(local_rank, 4, hz, it, 1)
+                    out["train_iteration"][f"4096x{hz}"] = {k: r3[k] for k in ("T_sample", "T_update", "samples_per_s_per_gpu", "samples_per_iter_per_gpu", "iters", "avg_reward")}
+            except Exception as ex:
+                out["train_iteration"] = {"error": f"{type(ex).__name__}: {ex}"[:200]}
+        else:
+            del sampler, env, policy
         if world == 1 and not args.no_cpu_baseline:
             workers = min(35, os.cpu_count() or 1)
             try:
@@ -369,7 +544,7 @@ def main():
                                                  "note": "FLOPs counted at the loop bodies of the fp64 oracle (dense stable-PD Cholesky, sparse L'DL, dense Newton Hessian: the arithmetic "
                                                          "the reference + MuJoCo execute) on the CPU baseline's run of the same workload; the HIP kernel's matrix-free passes do fewer"}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if in_group:
         dist.barrier()
         dist.destroy_process_group()
 

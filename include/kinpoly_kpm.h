@@ -14,7 +14,7 @@
 #include <stdint.h>
 
 #define KPM_MAGIC 0x314D504Bu
-#define KPM_VERSION 6u
+#define KPM_VERSION 7u
 
 typedef struct {
     char name[32];      /* zero padded */
@@ -37,6 +37,9 @@ typedef struct {
  *  body_inertia     f64   6 nb      inertia about the COM in body axes: xx yy zz xy xz yz
  *  body_gpos0       f64   3 nb      body origins at qpos0 in the world frame (the XML's coordinate="global" positions)
  *  body_rbound      f64   nb        bounding-sphere radius of the hull about the body origin (mid phase)
+ *  mesh_rbound      f64   nb        mjModel.geom_rbound of the hull's mesh geom: norm of the half-sizes max |coordinate| of the mesh in its
+ *                                   COM-centred principal-axes frame (mjc_PlaneConvex's tolerance is tolplanemesh * this)   [version 7]
+ *  planemesh        f64   2         maxplanemesh (3), tolplanemesh (0.3) of mjc_PlaneConvex; optional, these defaults if absent [version 7]
  *  body_diffw       f64   nb        env.jpos_diffw (ones; kin_poly/envs/humanoid_ar_v1.py:59)
  *  uhc_b_diffw      f64   nb        cfg.b_diffw of the UHC reward (uhc.yml body_params)
  *  body_invweight0  f64   2 nb      mjModel.body_invweight0 (translational, rotational) at qpos0: contact impedance scaling

@@ -5,7 +5,8 @@
     sample            VectorSampler over N envs: device SoA, every episode on a freshly drawn clip (EpisodeSource: batched
                       sample_seq + init_context ahead of the rollout, freq_dict feedback, :518-606)
     rl_update         GAE (k_gae) + global advantage normalisation (RCCL all-gather) + PPO epochs (:756-772); with
-                      joint_controller also update_controller on the UHC policy (:774-794)
+                      joint_controller also update_controller (:774-794), which -- as in the reference, whose optimiser holds
+                      policy_net only -- leaves the UHC weights alone unless `train_uhc` is set (PPOTrainer)
     step_update       supervised one-step update x num_step_update (policy_ar.py:277-287) + its own LambdaLR (`step_lr`, :88-89)
     checkpoints       reference pickle layout (kinpoly_amd/checkpoint.py)
 
@@ -33,7 +34,7 @@ class AgentAR:
     def __init__(self, n_envs, context_fn=None, device=0, horizon=99, seed=4, wild=False, use_init_context=True,
                  policy_lr=1e-5, value_lr=3e-4, supervised_lr=5e-4, num_optim_epoch=10, num_step_update=20, gamma=0.95, tau=0.95,
                  clip_epsilon=0.2, rl_update=True, step_update=True, model_options=None, dataset=None, sampling_temp=0.3, sampling_freq=0.5,
-                 pool_depth=2, num_epoch_fix=100, num_epoch=10000, joint_controller=False, grad_joint=False, grad_alternate=False):
+                 pool_depth=2, num_epoch_fix=100, num_epoch=10000, joint_controller=False, grad_joint=False, grad_alternate=False, train_uhc=False):
         rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
         enable_tuned_gemms()          # library GEMM solution per shape (rollout and update shapes at 4096 envs); selection only
         torch.manual_seed(seed + rank)
@@ -52,7 +53,7 @@ class AgentAR:
         self.horizon, self.rl_update, self.step_update, self.num_step_update = horizon, rl_update, step_update, num_step_update
         self.grad_joint, self.grad_alternate = grad_joint, grad_alternate       # policy_specs.grad_joint / grad_alternate (agent_ar.py:703, 746-747)
         self.trainer = PPOTrainer(self.policy_net, self.value_net, gamma, tau, clip_epsilon, policy_lr, value_lr, num_optim_epoch,
-                                  num_epoch_fix=num_epoch_fix, num_epoch=num_epoch, cc_policy=self.env.cc_policy if joint_controller else None)
+                                  num_epoch_fix=num_epoch_fix, num_epoch=num_epoch, cc_policy=self.env.cc_policy if joint_controller else None, train_uhc=train_uhc)
         self.opt_sup = torch.optim.Adam([p for p in self.policy_net.parameters() if p.requires_grad], lr=supervised_lr)
         self.sched_sup = lambda_lr(self.opt_sup, num_epoch_fix, num_epoch)          # PolicyAR.setup_optimizers / step_lr (policy_ar.py:45-62, 88-89)
         kpm = read_kpm(kpsim.DEFAULT_KPM)

@@ -13,11 +13,11 @@ namespace kp {
 
 constexpr int D_NB = 24, D_NV = 75, D_NQ = 76, D_NU = 69;
 constexpr int D_MAXCON = 64;          // must equal MAXCON in oracle/kp_oracle.c
-constexpr int D_CON_PER_GEOM = 4;     // mjc_PlaneConvex: support vertex + up to 3 hull-graph neighbours (CON_PER_GEOM in oracle/kp_oracle.c)
 constexpr int D_NLEV = 9;             // body tree depth levels (Pelvis .. Hand)
 
 struct DevTables {
     const float *body_pos, *body_ipos, *body_mass, *body_inertia, *body_rbound, *body_invw;
+    const float *mesh_rbound;       // mjModel.geom_rbound of every hull's mesh geom (mjc_PlaneConvex's tolerance scale)
     const float *dof_armature, *jnt_lo, *jnt_hi, *lim_invw;
     const float *kp, *kd, *tlim, *ascale;
     const float *verts;
@@ -40,6 +40,7 @@ struct Params {
     float K, B;                                 // solref -> stiffness / damping of the reference acceleration
     float imp_d0, imp_dw, imp_w, imp_mid, imp_pow;
     float mu, margin;
+    int pm_max; float pm_tol;                   // mjc_PlaneConvex: maxplanemesh (3), tolplanemesh (0.3) [MJ-ext]; model options planemesh_max / planemesh_tol
     float scale;                                // 1 / (meaninertia * nv)
     float rfc_scale, rfc_lim;
     float br_inv[4];                            // inverse(base_rot) as the reference computes it (conj / |q|^2)

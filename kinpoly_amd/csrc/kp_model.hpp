@@ -20,7 +20,7 @@ struct HostModel {
     int nb = 0, nv = 0, nq = 0, nu = 0, nM = 0, nvert = 0;
     std::vector<int> body_parent, body_depth, body_subtree, dof_body, dof_parent, dof_depth, dof_madr, jnt_limited, vert_adr, obj_geom_adr, vert_nbr_adr, vert_nbr;
     std::vector<double> body_pos, body_ipos, body_mass, body_inertia, body_rbound, body_invweight0, dof_invweight0,
-        dof_armature, jnt_range, verts, kp, kd, torque_lim, a_scale, opt, body_diffw, obj_geoms, obj_mass, obj_inertial;
+        dof_armature, jnt_range, verts, kp, kd, torque_lim, a_scale, opt, body_diffw, obj_geoms, obj_mass, obj_inertial, mesh_rbound, planemesh;
     std::string error;
 };
 
@@ -60,7 +60,11 @@ inline bool load_kpm(const char* path, HostModel& m) {
     if (!kpm_get(buf, "vert_nbr_adr", nullptr, &m.vert_nbr_adr) || !kpm_get(buf, "vert_nbr", nullptr, &m.vert_nbr) || (int)m.vert_nbr_adr.size() != m.nvert + 1) {
         m.error = "blob has no hull graph (vert_nbr_adr / vert_nbr): recompile the model with kinpoly_amd/model_compiler.py (KPM version 6)"; return false; }
     KPF(body_pos, "body_pos") KPF(body_ipos, "body_ipos") KPF(body_mass, "body_mass") KPF(body_inertia, "body_inertia")
-    KPF(body_rbound, "body_rbound") KPF(body_invweight0, "body_invweight0") KPF(dof_invweight0, "dof_invweight0")
+    KPF(body_rbound, "body_rbound")
+    if (!kpm_get(buf, "mesh_rbound", &m.mesh_rbound, nullptr) || (int)m.mesh_rbound.size() != m.nb) {
+        m.error = "blob has no mesh_rbound (geom_rbound of the hull meshes): recompile the model with kinpoly_amd/model_compiler.py (KPM version 7)"; return false; }
+    if (!kpm_get(buf, "planemesh", &m.planemesh, nullptr) || m.planemesh.size() != 2) m.planemesh = {3.0, 0.3};   // mjc_PlaneConvex: maxplanemesh, tolplanemesh
+    KPF(body_invweight0, "body_invweight0") KPF(dof_invweight0, "dof_invweight0")
     KPF(dof_armature, "dof_armature") KPF(jnt_range, "jnt_range") KPF(verts, "verts")
     KPF(kp, "kp") KPF(kd, "kd") KPF(torque_lim, "torque_lim") KPF(a_scale, "a_scale") KPF(opt, "opt") KPF(body_diffw, "body_diffw")
     // free objects (optional): [ngeom, 18] = object id, type, size3, local pos3, local R9, mass; adr [nobj + 1]

@@ -25,6 +25,7 @@ int fail(const std::string& m) { g_err = m; return -1; }
 struct kp_model {
     kp::HostModel h;
     int contact = 1, limits = 1, stale = 1, solver_iter = 100, threads = 64, dynamic_objects = 1, lpt_order = 0, substeps_per_job = 3, queue_slots = 0, job_taper = 1, queue_fence = 1;
+    int planemesh_max = 3; double planemesh_tol = 0.3;   // mjc_PlaneConvex's maxplanemesh / tolplanemesh (the blob's `planemesh`)
     double solver_tol = 1e-8, gravity_z = -9.81;   // solver_iter / solver_tol: mjOption.iterations / tolerance of the reference model (kp_model_load)
 };
 
@@ -87,7 +88,7 @@ bool build_tables(kp_sim* s) {
     auto& T = s->T;
     T.body_pos = upload<float>(s, m.body_pos, &ok); T.body_ipos = upload<float>(s, m.body_ipos, &ok);
     T.body_mass = upload<float>(s, m.body_mass, &ok); T.body_inertia = upload<float>(s, m.body_inertia, &ok);
-    T.body_rbound = upload<float>(s, m.body_rbound, &ok);
+    T.body_rbound = upload<float>(s, m.body_rbound, &ok); T.mesh_rbound = upload<float>(s, m.mesh_rbound, &ok);
     std::vector<double> invw(NB), liminvw(NU), lo(NU), hi(NU);
     for (int b = 0; b < NB; b++) invw[b] = m.body_invweight0[2 * b];
     for (int j = 0; j < NU; j++) { liminvw[j] = m.dof_invweight0[6 + j]; lo[j] = m.jnt_range[2 * j]; hi[j] = m.jnt_range[2 * j + 1]; }
@@ -157,6 +158,7 @@ bool build_tables(kp_sim* s) {
     P.imp_d0 = (float)clampimp(o[OPT_IMP_D0]); P.imp_dw = (float)dmax; P.imp_w = (float)o[OPT_IMP_W];
     P.imp_mid = (float)clampimp(o[OPT_IMP_MID]); P.imp_pow = (float)std::max(1.0, o[OPT_IMP_POW]);
     P.mu = (float)o[OPT_FRIC]; P.margin = (float)o[OPT_MARGIN];
+    P.pm_max = s->model->planemesh_max; P.pm_tol = (float)s->model->planemesh_tol;
     // mj_solNewton's termination scale: mean inertia and dof count of the WHOLE reference scene (objects included)
     P.scale = (float)(1.0 / (o[OPT_MEANINERTIA] * (o.size() > OPT_NV_FULL ? o[OPT_NV_FULL] : NV)));
     P.rfc_scale = (float)o[OPT_RFC_SCALE]; P.rfc_lim = (float)o[OPT_RFC_LIM];
@@ -275,6 +277,7 @@ kp_model* kp_model_load(const char* path) {
     m->solver_tol = m->h.opt[kp::OPT_SOLVER_TOL];
     m->solver_iter = (int)m->h.opt[kp::OPT_SOLVER_ITER];      // 100: MuJoCo's default, which the reference never overrides
     if (m->solver_iter < 1) m->solver_iter = 100;
+    m->planemesh_max = (int)m->h.planemesh[0]; m->planemesh_tol = m->h.planemesh[1];
     return m;
 }
 void kp_model_free(kp_model* m) { delete m; }
@@ -289,6 +292,8 @@ int kp_model_set_option(kp_model* m, const char* name, double v) {
     else if (k == "solver_iter") m->solver_iter = (int)v;
     else if (k == "solver_tol") m->solver_tol = v;
     else if (k == "dynamic_objects") m->dynamic_objects = v != 0;
+    else if (k == "planemesh_max") { if (v < 1 || v > 8) return fail("planemesh_max must be 1 .. 8"); m->planemesh_max = (int)v; }
+    else if (k == "planemesh_tol") { if (v < 0) return fail("planemesh_tol must be >= 0"); m->planemesh_tol = v; }
     else if (k == "lpt_order") m->lpt_order = v != 0;
     else if (k == "job_taper") m->job_taper = v != 0;
     else if (k == "queue_fence") m->queue_fence = v != 0;
@@ -308,6 +313,8 @@ double kp_model_get_option(const kp_model* m, const char* name) {
     if (k == "solver_iter") return m->solver_iter;
     if (k == "solver_tol") return m->solver_tol;
     if (k == "dynamic_objects") return m->dynamic_objects;
+    if (k == "planemesh_max") return m->planemesh_max;
+    if (k == "planemesh_tol") return m->planemesh_tol;
     if (k == "lpt_order") return m->lpt_order;
     if (k == "substeps_per_job") return m->substeps_per_job;
     if (k == "queue_slots") return m->queue_slots;

@@ -710,8 +710,9 @@ __device__ __forceinline__ void collide(EnvLds& s, const DevTables& T, const Par
                 const int gi = __ffs((int)bits) - 2;           // -1 = floor
                 bits &= bits - 1u;
                 if (gi < 0) {
-                    // mjc_PlaneConvex: the support vertex of -normal (deepest, first on ties), then up to three of its hull-graph
-                    // neighbours, in graph order, that are within the margin
+                    // mjc_PlaneConvex: the support vertex of -normal (deepest, first on ties) makes the first contact; then its hull-graph
+                    // neighbours in graph order, while fewer than maxplanemesh (3) contacts exist, each within the margin and not closer
+                    // than tolplanemesh * geom_rbound (0.3 rbound) to the first contact's position (addplanemesh)
                     const float dmin = wave_min(xw.z);
                     if (dmin > P.margin) continue;
                     const int idx = __builtin_amdgcn_readfirstlane(__ffsll((long long)__ballot(xw.z == dmin)) - 1);
@@ -721,13 +722,17 @@ __device__ __forceinline__ void collide(EnvLds& s, const DevTables& T, const Par
                     const int deg = n1 - n0;
                     const int j = tid < deg ? (int)T.vert_nbr[n0 + tid] : 0;
                     const V3 xj = v3(__shfl(xw.x, j, 64), __shfl(xw.y, j, 64), __shfl(xw.z, j, 64));
-                    const bool ok = tid < deg && !(xj.z > P.margin);
+                    const V3 x0 = v3(bcast_lane(xw.x, idx), bcast_lane(xw.y, idx), bcast_lane(xw.z, idx));
+                    const V3 dj = xj - v3(x0.x, x0.y, x0.z - 0.5f * x0.z);           // vertex against the first contact's position
+                    const float tolr = P.pm_tol * T.mesh_rbound[b];
+                    const bool ok = tid < deg && !(xj.z > P.margin) && !(dot(dj, dj) < tolr * tolr);
                     const unsigned long long m = __ballot(ok);
                     const int rank = __popcll(m & ((1ull << tid) - 1ull));
-                    const int cnt = 1 + min(__popcll(m), D_CON_PER_GEOM - 1);
+                    const int extra = P.pm_max - 1;
+                    const int cnt = 1 + min(__popcll(m), extra);
                     const int room = D_MAXCON - ncon;
                     if (tid == idx && room > 0) put_contact<OBJ>(s, ncon, v3(xw.x, xw.y, xw.z - 0.5f * xw.z), xw.z, v3(0.f, 0.f, 1.f), b, -1);
-                    if (ok && rank < D_CON_PER_GEOM - 1 && 1 + rank < room) put_contact<OBJ>(s, ncon + 1 + rank, v3(xj.x, xj.y, xj.z - 0.5f * xj.z), xj.z, v3(0.f, 0.f, 1.f), b, -1);
+                    if (ok && rank < extra && 1 + rank < room) put_contact<OBJ>(s, ncon + 1 + rank, v3(xj.x, xj.y, xj.z - 0.5f * xj.z), xj.z, v3(0.f, 0.f, 1.f), b, -1);
                     ncon += min(cnt, max(room, 0));
                 } else if constexpr (OBJ) {
                     // mjc_Convex (libccd MPR): geom 1 = the box / cylinder, geom 2 = the hull; one contact, normal into the hull

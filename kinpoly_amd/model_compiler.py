@@ -37,7 +37,7 @@ import xml.etree.ElementTree as ET
 import numpy as np
 
 KPM_MAGIC = 0x314D504B  # 'KPM1'
-KPM_VERSION = 6
+KPM_VERSION = 7
 
 # MuJoCo 2.1.0 defaults that the reference never overrides [MJ-ext]
 MJ_DEFAULTS = dict(
@@ -49,6 +49,11 @@ MJ_DEFAULTS = dict(
     impratio=1.0,
     solver_iterations=100,
     solver_tolerance=1e-8,
+    # engine_collision_convex.c, mjc_PlaneConvex [MJ-ext]: at most `maxplanemesh` contacts per plane-mesh pair (the support vertex +
+    # hull-graph neighbours), a neighbour closer than `tolplanemesh` * geom_rbound to the first contact is skipped.  Recalled from the
+    # MuJoCo source by two independent readers; both are model options of the simulators ("planemesh_max", "planemesh_tol")
+    maxplanemesh=3,
+    tolplanemesh=0.3,
 )
 
 
@@ -241,7 +246,7 @@ def compile_model(xml_path: str, uhc_yml: str | None = None) -> dict:
     mass = np.zeros(nb)
     ipos = np.zeros((nb, 3))
     inertia = np.zeros((nb, 3, 3))
-    verts_all, vert_adr, rbound = [], [0], np.zeros(nb)
+    verts_all, vert_adr, rbound, mesh_rbound = [], [0], np.zeros(nb), np.zeros(nb)
     nbr_adr, nbr = [0], []
     for i, b in enumerate(bodies):
         assert len(b["geoms"]) == 1 and b["geoms"][0]["type"] == "mesh"
@@ -251,12 +256,14 @@ def compile_model(xml_path: str, uhc_yml: str | None = None) -> dict:
         v = np.unique(tris.reshape(-1, 3), axis=0) - gpos[i]  # hull vertices in the body frame
         verts_all.append(v)
         vert_adr.append(vert_adr[-1] + len(v))
-        rbound[i] = np.linalg.norm(v, axis=1).max()
+        rbound[i] = np.linalg.norm(v, axis=1).max()      # bounding sphere about the BODY origin: the kernels' broad phase
+        # mjModel.geom_rbound of the mesh geom [MJ-ext]: MuJoCo's mesh compiler centres the mesh at its COM, rotates it to its
+        # principal axes of inertia and keeps the half-sizes max |coordinate| of that frame as the geom's `size`; rbound of a mesh
+        # (as of a box) is the norm of `size`.  mjc_PlaneConvex's "too close to the first contact" test is tolplanemesh * rbound.
+        _, axes = np.linalg.eigh(I)
+        half = np.abs((v + gpos[i] - com) @ axes).max(axis=0)
+        mesh_rbound[i] = float(np.linalg.norm(half))
         lists = hull_graph(v)
-        # mjc_PlaneConvex skips a neighbour closer than 1e-3 * rbound to the first contact [MJ-ext]: distinct vertices of these
-        # hulls are >= 2.4 mm apart, so that filter can never fire and the kernels do not carry it
-        from scipy.spatial.distance import pdist
-        assert pdist(v).min() > 2e-3 * rbound[i], "hull vertices closer than the plane-mesh duplicate filter"
         for lst in lists:
             nbr.extend(lst)
             nbr_adr.append(len(nbr))
@@ -416,7 +423,8 @@ def compile_model(xml_path: str, uhc_yml: str | None = None) -> dict:
         body_pos=body_pos, body_ipos=ipos, body_mass=mass,
         body_inertia=np.stack([inertia[:, 0, 0], inertia[:, 1, 1], inertia[:, 2, 2],
                                inertia[:, 0, 1], inertia[:, 0, 2], inertia[:, 1, 2]], axis=1),
-        body_gpos0=gpos, body_rbound=rbound, body_diffw=diffw, uhc_b_diffw=uhc_b_diffw,
+        body_gpos0=gpos, body_rbound=rbound, mesh_rbound=mesh_rbound, body_diffw=diffw, uhc_b_diffw=uhc_b_diffw,
+        planemesh=np.array([MJ_DEFAULTS["maxplanemesh"], MJ_DEFAULTS["tolplanemesh"]], float),
         body_invweight0=body_invw, dof_invweight0=dof_invw,
         dof_body=dof_body, dof_parent=dof_parent, dof_depth=dof_depth, dof_madr=dof_madr,
         dof_armature=np.array(arm), jnt_range=np.array(jrange), jnt_limited=np.array(jlimited, np.int32),

@@ -77,13 +77,31 @@ class EpisodeSource:
             data["init_qvel"] = data["qvel"][:, 0].contiguous() if "qvel" in data else torch.zeros((n, 75), device=device)
         return data
 
-    def record(self, take_ind, fr_start, percent):
-        """freq_dict[curr_key].append([info['percent'], fr_start]) for every finished episode (agent_ar.py:601-603)."""
+    def record(self, take_ind, fr_start, percent, group=None):
+        """freq_dict[curr_key].append([info['percent'], fr_start]) for every finished episode (agent_ar.py:601-603).
+
+        ONE job-wide freq_dict, as in the reference: AgentAR.sample merges every worker's list into the agent's dict
+        (agent_ar.py:664-673) before the next draws.  With several ranks the finished episodes of all ranks are exchanged once per
+        sample() call (`all_gather_object`: a few KB of Python lists, host side) and appended in rank order, so every rank holds the
+        same dict and draws its next clips from the same take probabilities."""
         if self.dataset is None:
             return
-        for ti, fs, pc in zip(take_ind, fr_start, percent):
-            self.freq_dict[self.dataset.takes[int(ti)]].append([float(pc), int(fs)])
+        mine = [[int(ti), int(fs), float(pc)] for ti, fs, pc in zip(take_ind, fr_start, percent)]
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            every = [None] * dist.get_world_size(group)
+            dist.all_gather_object(every, mine, group=group)
+        else:
+            every = [mine]
+        for part in every:
+            for ti, fs, pc in part:
+                self.freq_dict[self.dataset.takes[ti]].append([pc, fs])
         self.freq_dict = {k: (v if len(v) < 5000 else v[-5000:]) for k, v in self.freq_dict.items()}
+
+    def save_freq_dict(self, path):
+        """joblib.dump(self.freq_dict, 'freq_dict.pt') of the reference (agent_ar.py:297): a pickle of {take: [[percent, fr_start], ...]}."""
+        import pickle
+        with open(path, "wb") as f:
+            pickle.dump(self.freq_dict, f)
 
 
 _ROW_KEYS = ("qpos", "head_pose", "head_vels", "obj_head_relative_poses", "action_one_hot", "init_qpos", "init_qvel", "obj_pose", "ar_qpos", "ar_qvel")
@@ -104,6 +122,8 @@ class VectorSampler:
         self.obs = self.hx = self.fresh = None
         self.level = None
         self.pool_exhausted = 0
+        self._replay = None       # bool [N]: the env is re-running a clip it already finished (pool exhausted): not evidence for freq_dict
+        self.group = None         # process group of the job-wide freq_dict exchange (None = the default group)
 
     # ------------------------------------------------------------------ episode pool
     def _refill(self):
@@ -128,6 +148,16 @@ class VectorSampler:
                 lv[k] = torch.as_tensor(d[k]).to(dev, torch.float32) if k in d else torch.zeros(N, device=dev)
             levels.append(lv)
         keys = [k for k in levels[0] if all(k in lv for lv in levels)]
+        # draws can come back with different clip lengths (batch() pads to the longest take of THAT draw): bring every level to the
+        # common T by repeating its last frame, as StateARDataset.batch pads, so the row table is one [R, T, .] block
+        T_all = max(lv["qpos"].shape[1] for lv in levels)
+        for lv in levels:
+            T_lv = lv["qpos"].shape[1]
+            if T_lv < T_all:
+                for k in keys:
+                    v = lv[k]
+                    if torch.is_tensor(v) and v.dim() == 3 and v.shape[1] == T_lv:
+                        lv[k] = torch.cat([v, v[:, -1:].expand(-1, T_all - T_lv, -1)], 1)
         table = {k: torch.cat([lv[k].to(dev) for lv in levels], 0) for k in keys}
         first = self.obs is None
         env.load_context(table, row=torch.arange(N, device=dev, dtype=torch.int32), keep_state=not first)
@@ -157,6 +187,9 @@ class VectorSampler:
         full = self.record_full
         NS, VM, RQ, CA, CS = (f(105), f(3), f(76), f(75), f(784)) if full else (None,) * 5
         D = torch.empty((N, T), dtype=torch.bool, device=dev); PC = f(); MT = f(2)
+        REC = torch.empty((N, T), dtype=torch.bool, device=dev)      # finished episodes that count for freq_dict (not the replays of an exhausted pool)
+        if self._replay is None:
+            self._replay = torch.zeros(N, dtype=torch.bool, device=dev)
         ar = torch.arange(N, device=dev)
         hx0 = self.hx.clone()
         fr_num = float(env.ctx["qpos"].shape[1])
@@ -176,6 +209,7 @@ class VectorSampler:
             R[:, t] = info["custom_reward"]
             F[:, t] = info["fail"]
             D[:, t] = done; PC[:, t] = info["percent"]; MT[:, t] = meta
+            REC[:, t] = done & ~self._replay
             if full:
                 NS[:, t] = obs; RQ[:, t] = env.sim.get("qpos"); CA[:, t] = info["cc_action"]; CS[:, t] = info["cc_state"]
                 VM[:, t, :2] = meta; VM[:, t, 2] = fr_num
@@ -184,6 +218,7 @@ class VectorSampler:
                 nxt = self.level + done.long()
                 over = nxt >= self._n_levels
                 exhausted += (over & done).sum()
+                self._replay = torch.where(done, over, self._replay)     # a finished env that found no fresh clip replays its last one
                 self.level = torch.where(over, self.level, nxt)
                 env.set_rows((self.level * N + ar).to(torch.int32), done)
             self.obs = env.reset(done).clone()
@@ -195,11 +230,11 @@ class VectorSampler:
         if status:
             raise kpsim.KinPolyNativeError("kp_step_queue_kernel reported a stalled job queue during the rollout (states are incomplete)")
         self.pool_exhausted += int(exhausted)
-        dm = D.cpu().numpy()
+        dm = REC.cpu().numpy()
         eps = {"take_ind": MT[..., 0].cpu().numpy()[dm].astype(np.int64), "fr_start": MT[..., 1].cpu().numpy()[dm].astype(np.int64),
                "percent": PC.cpu().numpy()[dm].astype(np.float64)}
         if self.source is not None:
-            self.source.record(eps["take_ind"], eps["fr_start"], eps["percent"])
+            self.source.record(eps["take_ind"], eps["fr_start"], eps["percent"], self.group)
         return RolloutBatch(S, A, R, M, E, F, Q, G, NS, torch.ones((N, T), device=dev) if full else None, VM, RQ, CA, CS, hx0, self.obs.clone(), eps)
 
 
@@ -209,12 +244,19 @@ def env_shard(rank: int, world_size: int, envs_per_gpu: int):
     return range(rank * envs_per_gpu, (rank + 1) * envs_per_gpu), 4 + rank
 
 
+FORCE_COLLECTIVES = False      # tests: run the all-gather / all-reduce even in a 1-rank group (so a 1-GPU box pushes device tensors through RCCL)
+
+
+def _collective_on(group=None):
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or FORCE_COLLECTIVES)
+
+
 def normalize_advantages_global(adv: torch.Tensor, ret: torch.Tensor, group=None):
     """The reference normalises advantages over its whole concatenated batch (common.py:22, unbiased std).
     Sharded over ranks, the per-rank advantages / returns are all-gathered (one RCCL all-gather over xGMI per
     PPO iteration; gloo in the CPU tests) so every rank applies the whole-job mean / std.  Returns
     (normalised local adv, local ret, gathered returns [world * n])."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _collective_on(group):
         ws = dist.get_world_size(group)
         packed = torch.stack([adv.reshape(-1), ret.reshape(-1)], 1).contiguous()
         gathered = [torch.empty_like(packed) for _ in range(ws)]
@@ -234,7 +276,7 @@ def estimate_advantages(rewards, masks, values, gamma, tau, group=None, last_val
 
 
 def _allreduce_grads(params, group=None):
-    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+    if not _collective_on(group):
         return
     grads = [p.grad for p in params if p.grad is not None]
     if not grads:
@@ -263,31 +305,41 @@ def lambda_lr(optimizer, nepoch_fix, nepoch):
 class PPOTrainer:
     """AgentPPO.update_policy / ppo_loss / update_value (agent_ar.py:756-772, 852-870; agent_ppo.py:53-56), the LambdaLR schedules of
     agent_ar.py:215-225 stepped once per iteration (`per_epoch_update`, :268-269), and `update_controller` (:774-794) for
-    joint_controller runs: the same clipped surrogate on the UHC policy over (cc_state, cc_action)."""
+    joint_controller runs.
+
+    The optimiser owns the kinematic policy's parameters ONLY, as the reference's does (`Adam(self.policy_net.parameters())`,
+    agent_ar.py:184-199; `policy_grad_clip=[(self.policy_net.parameters(), 40)]`, :93): `joint_controller` appends env.cc_policy to
+    update_modules / sample_modules (:97-99, train / eval mode and device moves), not to the optimiser.  The reference's
+    update_controller therefore back-propagates the surrogate into the UHC and then steps an optimiser that does not hold the UHC
+    weights: the UHC is never trained there, and neither is it here by default.  `train_uhc=True` is this engine's opt-in extension:
+    the UHC gets its own Adam (same lr / weight decay) and its own 40-norm clip, so that the kinematic policy's clip is untouched."""
 
     def __init__(self, policy: KinPolicy, value: Value, gamma=0.95, tau=0.95, clip_epsilon=0.2, policy_lr=1e-5, value_lr=3e-4,
                  num_optim_epoch=10, policy_grad_clip=40.0, group=None, num_epoch_fix=100, num_epoch=10000, value_opt_niter=1,
-                 cc_policy=None, policy_weightdecay=0.0, value_weightdecay=0.0):
+                 cc_policy=None, policy_weightdecay=0.0, value_weightdecay=0.0, train_uhc=False):
         self.policy, self.value, self.group, self.cc_policy = policy, value, group, cc_policy
         self.gamma, self.tau, self.clip_epsilon, self.num_optim_epoch, self.policy_grad_clip = gamma, tau, clip_epsilon, num_optim_epoch, policy_grad_clip
         self.value_opt_niter = value_opt_niter
-        pol_params = [p for p in policy.parameters() if p.requires_grad]
-        if cc_policy is not None:                 # joint_controller: the UHC's parameters join the policy optimiser (agent_ar.py:97-99)
-            for p in cc_policy.parameters():
-                if p.dtype.is_floating_point and p is not cc_policy.action_log_std:
-                    p.requires_grad_(True)
-            pol_params += [p for p in cc_policy.parameters() if p.requires_grad]
-        self.opt_p = torch.optim.Adam(pol_params, lr=policy_lr, weight_decay=policy_weightdecay)
+        self.opt_p = torch.optim.Adam([p for p in policy.parameters() if p.requires_grad], lr=policy_lr, weight_decay=policy_weightdecay)
         self.opt_v = torch.optim.Adam(value.parameters(), lr=value_lr, weight_decay=value_weightdecay)
         self.sched_p = lambda_lr(self.opt_p, num_epoch_fix, num_epoch)
         self.sched_v = lambda_lr(self.opt_v, num_epoch_fix, num_epoch)
+        self.opt_cc = self.sched_cc = None
+        if cc_policy is not None and train_uhc:
+            cc_params = [p for p in cc_policy.parameters() if p.dtype.is_floating_point and p is not cc_policy.action_log_std]
+            for p in cc_params:
+                p.requires_grad_(True)
+            self.opt_cc = torch.optim.Adam(cc_params, lr=policy_lr, weight_decay=policy_weightdecay)
+            self.sched_cc = lambda_lr(self.opt_cc, num_epoch_fix, num_epoch)
 
     def per_epoch_update(self):
         """scheduler_policy.step(); scheduler_value.step()   (agent_ar.py:268-269, called at the top of optimize_policy)."""
         self.sched_p.step(); self.sched_v.step()
+        if self.sched_cc is not None:
+            self.sched_cc.step()
 
-    def _clip(self):
-        params = [p for g in self.opt_p.param_groups for p in g["params"]]
+    def _clip(self, opt=None):
+        params = [p for g in (opt or self.opt_p).param_groups for p in g["params"]]
         _allreduce_grads(params, self.group)
         torch.nn.utils.clip_grad_norm_(params, self.policy_grad_clip)
 
@@ -332,6 +384,11 @@ class PPOTrainer:
         N, T, _ = batch.states.shape
         flat_states = batch.states.reshape(N * T, -1)
         curr, tgt = batch.curr_qpos.reshape(N * T, 76), batch.gt_target_qpos.reshape(N * T, 76)
+        ind = None
+        if batch.exps is not None:                # `ind = exps.nonzero()` (agent_ar.py:813): the rows the surrogate is taken over
+            ind = batch.exps.reshape(-1).nonzero(as_tuple=False).squeeze(1)
+            if ind.numel() == N * T:
+                ind = None
         with torch.no_grad():
             values = self.value(flat_states).view(N, T)
             last_v = self.value(batch.last_states).view(N) if (bootstrap and batch.last_states is not None) else None
@@ -345,7 +402,7 @@ class PPOTrainer:
             vloss = (self.value(flat_states) - ret).pow(2).mean()
             self.opt_v.zero_grad(); vloss.backward(); _allreduce_grads(list(self.value.parameters()), self.group); self.opt_v.step()
             means = self.policy.unroll(batch.states, batch.episode_start, batch.hx0).reshape(N * T, -1)
-            surr = ppo_surrogate(self.policy.log_prob(means, batch.actions.reshape(N * T, -1)), fixed_log_probs, adv, self.clip_epsilon)
+            surr = ppo_surrogate(self.policy.log_prob(means, batch.actions.reshape(N * T, -1)), fixed_log_probs, adv, self.clip_epsilon, ind)
             loss_step, _ = compute_loss_lite(fk, kinematic_step(curr, means), tgt, gt_wbpos=tgt_wbpos)
             if grad_alternate:
                 if epoch % 2 == 1:
@@ -359,11 +416,17 @@ class PPOTrainer:
                 loss = loss_step * 10 + surr
                 self.opt_p.zero_grad(); loss.backward(); self._clip(); self.opt_p.step()
             stats = {"value_loss": float(vloss.detach()), "surr_loss": float(surr.detach()), "step_loss": float(loss_step.detach())}
+        if self.cc_policy is not None and batch.cc_state is not None:      # update_params runs update_controller after either branch (agent_ar.py:748-749)
+            stats["cc_surr_loss"] = self.update_controller(batch, adv, ind)
         return stats
 
     def update_controller(self, batch: RolloutBatch, adv, ind=None):
-        """AgentAR.update_controller (agent_ar.py:774-794): PPO epochs on env.cc_policy over the recorded (cc_state, cc_action) with the
-        kinematic policy's advantages; no value step."""
+        """AgentAR.update_controller (agent_ar.py:774-794): the clipped surrogate of env.cc_policy over the recorded (cc_state, cc_action)
+        with the kinematic policy's advantages; no value step.  The reference steps `optimizer_policy`, which holds policy_net's
+        parameters only, after a backward that reaches the UHC only: with torch >= 2.0 (`zero_grad(set_to_none=True)`) policy_net's
+        gradients are None and the step changes nothing, so its num_optim_epoch passes all evaluate the same loss -- computed once here
+        and reported.  (Under torch < 2.0 the same code takes ten zero-gradient Adam steps on policy_net, i.e. momentum drift; not
+        reproduced.)  With `train_uhc` the epochs run on the UHC's own optimiser."""
         cs, ca = batch.cc_state.reshape(-1, batch.cc_state.shape[-1]), batch.cc_action.reshape(-1, batch.cc_action.shape[-1])
         pol = self.cc_policy
 
@@ -373,11 +436,13 @@ class PPOTrainer:
             return (-(a - mean) ** 2 / (2 * var) - 0.5 * np.log(2 * np.pi) - log_std).sum(1, keepdim=True)
         with torch.no_grad():
             fixed = logp(cs, ca)
+            if self.opt_cc is None:
+                return float(ppo_surrogate(fixed, fixed, adv, self.clip_epsilon, ind))
         loss = None
         for _ in range(self.num_optim_epoch):
             surr = ppo_surrogate(logp(cs, ca), fixed, adv, self.clip_epsilon, ind)
-            self.opt_p.zero_grad(); surr.backward()
-            self._clip()
-            self.opt_p.step()
+            self.opt_cc.zero_grad(); surr.backward()
+            self._clip(self.opt_cc)
+            self.opt_cc.step()
             loss = float(surr.detach())
         return loss

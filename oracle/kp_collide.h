@@ -217,12 +217,14 @@ static int kpo_convex(const kpc_shape *g1, const kpc_shape *g2, double margin, k
     return 1;
 }
 
-/* mjc_PlaneConvex for a mesh geom  [MJ-ext]: the support vertex in direction -normal (deepest vertex), then up to three of ITS
- * NEIGHBOURS on the hull graph (in graph order) that are within the margin.  plane = world z = 0 (the floor geom of the XML).
+/* mjc_PlaneConvex for a mesh geom  [MJ-ext]: the support vertex in direction -normal (deepest vertex) makes the first contact; then
+ * ITS NEIGHBOURS on the hull graph are visited in graph order while fewer than `maxcon` (maxplanemesh = 3) contacts exist, and a
+ * neighbour within the margin is added (addplanemesh) unless it lies closer than tol_rbound = tolplanemesh * geom_rbound (0.3 x the
+ * mesh geom's bounding radius) to the FIRST contact's position.  plane = world z = 0 (the floor geom of the XML).
  * nbr / nbr_adr: hull graph (model compiler).  Contact position = vertex - normal * dist / 2. */
-static int kpo_plane_mesh(const kpc_shape *h, const int *nbr_adr, const int *nbr, double margin, double rbound, kpc_contact *con) {
+static int kpo_plane_mesh(const kpc_shape *h, const int *nbr_adr, const int *nbr, double margin, double tol_rbound, int maxcon, kpc_contact *con) {
     FL(6 * h->nvert);
-    int best = -1; double bd = 1e300, bw[3] = {0, 0, 0};
+    int best = -1; double bd = 1e300;
     for (int v = 0; v < h->nvert; v++) {
         const double *p = h->verts + 3 * v;
         double z = h->pos[2] + h->mat[6] * p[0] + h->mat[7] * p[1] + h->mat[8] * p[2];
@@ -230,16 +232,15 @@ static int kpo_plane_mesh(const kpc_shape *h, const int *nbr_adr, const int *nbr
     }
     if (best < 0 || bd > margin) return 0;
     int cnt = 0;
-    for (int k = -1; k < nbr_adr[best + 1] - nbr_adr[best] && cnt < 4; k++) {
+    for (int k = -1; k < nbr_adr[best + 1] - nbr_adr[best] && (k < 0 || cnt < maxcon); k++) {
         int v = k < 0 ? best : nbr[nbr_adr[best] + k];
         const double *p = h->verts + 3 * v;
         double w[3];
         for (int a = 0; a < 3; a++) w[a] = h->pos[a] + h->mat[3 * a] * p[0] + h->mat[3 * a + 1] * p[1] + h->mat[3 * a + 2] * p[2];
-        if (k < 0) memcpy(bw, w, 24);
-        else {
+        if (k >= 0) {
             if (w[2] > margin) continue;
-            double d[3]; kpc_sub(d, w, bw);                                                /* "skip if too close to the first contact" */
-            if (sqrt(kpc_dot(d, d)) < 1e-3 * rbound) continue;                             /* cannot fire on these hulls: the model compiler asserts their vertex spacing */
+            double d[3]; kpc_sub(d, w, con[0].pos);                                        /* "skip if too close to first contact" */
+            if (kpc_dot(d, d) < tol_rbound * tol_rbound) continue;
         }
         con[cnt].dist = w[2]; con[cnt].normal[0] = con[cnt].normal[1] = 0; con[cnt].normal[2] = 1;
         con[cnt].pos[0] = w[0]; con[cnt].pos[1] = w[1]; con[cnt].pos[2] = w[2] - 0.5 * w[2];

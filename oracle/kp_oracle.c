@@ -34,7 +34,6 @@
 #define NM_MAX 1221
 #define MAXCON 64
 #define MAXEFC (MAXCON * 4 + 2 * 69)
-#define CON_PER_GEOM 4                  /* mjc_PlaneConvex: support vertex + up to 3 of its hull-graph neighbours */
 #define MAXGEOM 8
 #define MAXOBJ 2                        /* dynamic free objects per env (push: box + table) */
 #define NVT_MAX (NV_MAX + 6 * MAXOBJ)   /* dofs of the humanoid + the active objects */
@@ -47,6 +46,8 @@ typedef struct {
     int body_parent[NB_MAX], body_subtree[NB_MAX];
     double body_pos[NB_MAX][3], body_ipos[NB_MAX][3], body_mass[NB_MAX], body_inertia[NB_MAX][6];
     double body_rbound[NB_MAX], body_invweight0[NB_MAX][2];
+    double mesh_rbound[NB_MAX];     /* mjModel.geom_rbound of every hull's mesh geom (model compiler) */
+    int planemesh_max; double planemesh_tol;   /* mjc_PlaneConvex: maxplanemesh = 3, tolplanemesh = 0.3 [MJ-ext] (blob field `planemesh`) */
     int dof_body[NV_MAX], dof_parent[NV_MAX], dof_madr[NV_MAX + 1];
     double dof_armature[NV_MAX], dof_invweight0[NV_MAX];
     double jnt_range[69][2];
@@ -211,6 +212,12 @@ kpo_model *kpo_model_load(const char *path) {
     LOADF(m->body_pos, "body_pos", 3 * m->nb); LOADF(m->body_ipos, "body_ipos", 3 * m->nb);
     LOADF(m->body_mass, "body_mass", m->nb); LOADF(m->body_inertia, "body_inertia", 6 * m->nb);
     LOADF(m->body_rbound, "body_rbound", m->nb); LOADF(m->body_invweight0, "body_invweight0", 2 * m->nb);
+    { uint64_t c; const void *p = kpm_find(buf, "mesh_rbound", &c, 0), *q;
+      if (!p || c != (uint64_t)m->nb) { fprintf(stderr, "kpo: blob has no mesh_rbound (recompile the model, KPM version 7)\n"); free(buf); free(m); return NULL; }
+      memcpy(m->mesh_rbound, p, 8 * m->nb);
+      double pm[2] = {3.0, 0.3};
+      q = kpm_find(buf, "planemesh", &c, 0); if (q && c == 2) memcpy(pm, q, 16);
+      m->planemesh_max = (int)pm[0]; m->planemesh_tol = pm[1]; }
     LOADI(m->dof_body, "dof_body", m->nv); LOADI(m->dof_parent, "dof_parent", m->nv);
     LOADI(m->dof_madr, "dof_madr", m->nv + 1);
     LOADF(m->dof_armature, "dof_armature", m->nv); LOADF(m->dof_invweight0, "dof_invweight0", m->nv);
@@ -237,6 +244,7 @@ void kpo_model_free(kpo_model *m) { if (m) { free(m->verts); free(m->vert_nbr_ad
 void kpo_model_set_flags(kpo_model *m, int contact, int limits) { m->enable_contact = contact; m->enable_limits = limits; }
 void kpo_model_set_gravity(kpo_model *m, double gz) { m->gravity[2] = gz; }
 void kpo_model_set_ls_exact(kpo_model *m, int exact) { m->ls_exact = exact; }
+void kpo_model_set_planemesh(kpo_model *m, int maxcon, double tol) { m->planemesh_max = maxcon; m->planemesh_tol = tol; }
 kpo_data *kpo_data_new(void) { return calloc(1, sizeof(kpo_data)); }
 void kpo_data_free(kpo_data *d) { free(d); }
 size_t kpo_data_sizeof(void) { return sizeof(kpo_data); }
@@ -503,7 +511,7 @@ static void kpo_collide(const kpo_model *m, kpo_data *d) {
             const kpo_geom *g = gi < 0 ? NULL : &d->geom[gi];
             if (!g) {
                 if (d->xpos[b][2] - m->body_rbound[b] > m->margin) continue;
-                int n = kpo_plane_mesh(&hull, m->vert_nbr_adr + m->vert_adr[b], m->vert_nbr, m->margin, m->body_rbound[b], con);
+                int n = kpo_plane_mesh(&hull, m->vert_nbr_adr + m->vert_adr[b], m->vert_nbr, m->margin, m->planemesh_tol * m->mesh_rbound[b], m->planemesh_max, con);
                 kpo_emit(d, con, n, b, -1, 0.0, 0);
             } else {
                 double dx[3] = {d->xpos[b][0] - g->pos[0], d->xpos[b][1] - g->pos[1], d->xpos[b][2] - g->pos[2]};
@@ -953,7 +961,7 @@ static void kpo_shape_from_record(const double *r, const double *verts, int nver
     else { memcpy(s->center, s->pos, 24); s->verts = NULL; s->nvert = 0; }
 }
 int kpo_narrowphase(int kind, const double *a, const double *verts_a, int nvert_a, const double *b, const double *verts_b, int nvert_b,
-                    const int *nbr_adr, const int *nbr, double margin, double rbound, double *out) {
+                    const int *nbr_adr, const int *nbr, double margin, double tol_rbound, int maxcon, double *out) {
     kpc_shape sa, sb; kpc_contact con[KPC_MAXPAIR];
     int n = 0;
     if (a) kpo_shape_from_record(a, verts_a, nvert_a, &sa);
@@ -962,7 +970,7 @@ int kpo_narrowphase(int kind, const double *a, const double *verts_a, int nvert_
     else if (kind == 1) n = kpo_plane_box(&sa, margin, con);
     else if (kind == 2) n = kpo_plane_cylinder(&sa, margin, con);
     else if (kind == 3) n = kpo_box_box(&sa, &sb, margin, con);
-    else if (kind == 4) n = kpo_plane_mesh(&sb, nbr_adr, nbr, margin, rbound, con);
+    else if (kind == 4) n = kpo_plane_mesh(&sb, nbr_adr, nbr, margin, tol_rbound, maxcon, con);
     for (int i = 0; i < n; i++) { out[7 * i] = con[i].dist; memcpy(out + 7 * i + 1, con[i].pos, 24); memcpy(out + 7 * i + 4, con[i].normal, 24); }
     return n;
 }

@@ -38,6 +38,7 @@ def lib():
         L.kpo_model_set_flags.argtypes = [P, C.c_int, C.c_int]
         L.kpo_model_set_gravity.argtypes = [P, C.c_double]
         L.kpo_model_set_ls_exact.argtypes = [P, C.c_int]
+        L.kpo_model_set_planemesh.argtypes = [P, C.c_int, C.c_double]
         L.kpo_data_new.restype = P
         L.kpo_data_free.argtypes = [P]
         for f in ("kpo_forward", "kpo_step"):
@@ -65,7 +66,7 @@ def lib():
         L.kpo_get_efc.argtypes = [P, D, D, D]
         L.kpo_get_efc_J.argtypes = [P, D]
         L.kpo_rollout_batch.argtypes = [P, C.c_int, D, D, D, D, C.c_int, C.c_int]
-        L.kpo_narrowphase.argtypes = [C.c_int, D, D, C.c_int, D, D, C.c_int, I, I, C.c_double, C.c_double, D]; L.kpo_narrowphase.restype = C.c_int
+        L.kpo_narrowphase.argtypes = [C.c_int, D, D, C.c_int, D, D, C.c_int, I, I, C.c_double, C.c_double, C.c_int, D]; L.kpo_narrowphase.restype = C.c_int
         for g in ("ncon", "nefc", "niter"):
             getattr(L, "kpo_get_" + g).argtypes = [P]; getattr(L, "kpo_get_" + g).restype = C.c_int
         for f in _FIELDS:
@@ -85,7 +86,7 @@ _FIELDS = dict(qpos=NQ, qvel=NV, xpos=72, xquat=96, xipos=72, qM=NM, qfrc_bias=N
 class OracleSim:
     """One scalar fp64 environment."""
 
-    def __init__(self, kpm: str = DEFAULT_KPM, contact=True, limits=True, gravity=None, ls_exact=False):
+    def __init__(self, kpm: str = DEFAULT_KPM, contact=True, limits=True, gravity=None, ls_exact=False, planemesh=None):
         L = lib()
         self.L = L
         self.m = L.kpo_model_load(kpm.encode())
@@ -94,6 +95,8 @@ class OracleSim:
         if gravity is not None:
             L.kpo_model_set_gravity(self.m, float(gravity))
         L.kpo_model_set_ls_exact(self.m, int(ls_exact))     # default: MuJoCo's PrimalSearch; True: the exact minimiser (as the HIP kernel)
+        if planemesh is not None:                           # (maxplanemesh, tolplanemesh) of mjc_PlaneConvex; default: the blob's (3, 0.3)
+            L.kpo_model_set_planemesh(self.m, int(planemesh[0]), float(planemesh[1]))
         self.d = L.kpo_data_new()
 
     def __del__(self):
@@ -245,9 +248,10 @@ def shape_record(kind, size=(0, 0, 0), pos=(0, 0, 0), mat=None, center=None):
     return np.concatenate([[t], np.resize(s, 3) if len(s) == 3 else np.concatenate([s, np.zeros(3 - len(s))]), np.asarray(pos, float), m.reshape(-1)])
 
 
-def narrowphase(kind, a=None, b=None, verts_a=None, verts_b=None, graph=None, margin=0.001, rbound=1.0):
+def narrowphase(kind, a=None, b=None, verts_a=None, verts_b=None, graph=None, margin=0.001, tol_rbound=0.0, maxcon=3):
     """One geom pair through the oracle's restatement of the MuJoCo narrow phase (kp_collide.h):
-    kind = 'convex' (a, b) | 'plane_box' (a) | 'plane_cylinder' (a) | 'box_box' (a, b) | 'plane_mesh' (b + graph = neighbour lists).
+    kind = 'convex' (a, b) | 'plane_box' (a) | 'plane_cylinder' (a) | 'box_box' (a, b) | 'plane_mesh' (b + graph = neighbour lists;
+    tol_rbound = tolplanemesh * geom_rbound, maxcon = maxplanemesh).
     Returns [n, 7] rows (dist, pos3, normal3 from geom 1 to geom 2)."""
     L = lib()
     k = {"convex": 0, "plane_box": 1, "plane_cylinder": 2, "box_box": 3, "plane_mesh": 4}[kind]
@@ -261,7 +265,7 @@ def narrowphase(kind, a=None, b=None, verts_a=None, verts_b=None, graph=None, ma
     ar = None if a is None else np.ascontiguousarray(a, np.float64); br = None if b is None else np.ascontiguousarray(b, np.float64)
     n = L.kpo_narrowphase(k, None if ar is None else _dp(ar), None if va is None else _dp(va), 0 if va is None else len(va),
                           None if br is None else _dp(br), None if vb is None else _dp(vb), 0 if vb is None else len(vb),
-                          None if adr is None else ip(adr), None if nbr is None else ip(nbr), float(margin), float(rbound), _dp(out))
+                          None if adr is None else ip(adr), None if nbr is None else ip(nbr), float(margin), float(tol_rbound), int(maxcon), _dp(out))
     return out[:n].copy()
 
 

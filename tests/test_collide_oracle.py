@@ -62,35 +62,49 @@ def test_plane_cylinder_upright_and_lying():
 
 
 def test_plane_mesh_support_vertex_then_graph_neighbours():
+    """mjc_PlaneConvex [MJ-ext]: support vertex, then its hull-graph neighbours in graph order while fewer than maxplanemesh = 3 contacts
+    exist; a neighbour within tolplanemesh * rbound = 0.3 rbound of the FIRST contact is skipped (addplanemesh)."""
     v = 0.1 * CUBE
     graph = hull_graph(v)
     assert all(3 <= len(g) <= 6 for g in graph)
-    # cube hull resting flat, 0.5 mm deep: the support vertex (first of the four lowest) + its lower neighbours, in graph order
+    rb = 0.1 * np.sqrt(3.0)                              # geom_rbound of the cube: norm of its half-sizes
+    # cube hull resting flat, 0.5 mm deep: the support vertex (first of the four lowest) + its lower neighbours in graph order, 3 in all
     b = shape_record("hull", pos=(0.5, 0.5, 0.0995), center=(0.5, 0.5, 0.0995))
-    c = narrowphase("plane_mesh", b=b, verts_b=v, graph=graph, rbound=0.17)
+    c = narrowphase("plane_mesh", b=b, verts_b=v, graph=graph, tol_rbound=0.3 * rb, maxcon=3)
     low = [i for i in range(8) if v[i, 2] < 0]
     first = low[0]
-    expect = [first] + [j for j in graph[first] if j in low]
-    assert c.shape[0] == len(expect) <= 4
+    expect = ([first] + [j for j in graph[first] if j in low])[:3]       # neighbours are 0.2 or 0.283 apart > 0.3 * 0.173
+    assert c.shape[0] == len(expect) == 3
     np.testing.assert_allclose(c[:, 1:3], v[expect, :2] + 0.5, atol=1e-12)
     np.testing.assert_allclose(c[:, 0], -0.0005, atol=1e-12)
     np.testing.assert_allclose(c[:, 3], -0.00025, atol=1e-12)
+    # the cap is the option: 4 keeps the third lower neighbour as well
+    c4 = narrowphase("plane_mesh", b=b, verts_b=v, graph=graph, tol_rbound=0.3 * rb, maxcon=4)
+    assert c4.shape[0] == len([first] + [j for j in graph[first] if j in low]) and (c4[:3] == c).all()
+    # the tolerance: with 0.3 * rbound above the edge length (0.2) only the face-diagonal neighbour (0.283 away) survives
+    ct = narrowphase("plane_mesh", b=b, verts_b=v, graph=graph, tol_rbound=0.25, maxcon=3)
+    far = [j for j in graph[first] if j in low and np.linalg.norm(v[j] - v[first]) > 0.25]
+    assert ct.shape[0] == 1 + len(far)
+    np.testing.assert_allclose(ct[1:, 1:3], v[far, :2] + 0.5, atol=1e-12)
     # standing on one corner: exactly one contact (the neighbours are far above the margin)
     R = rot([1, -1, 0], np.arccos(1 / np.sqrt(3)))      # the body diagonal (1,1,1) to +z: corner (-1,-1,-1) becomes the lowest point
     zmin = (v @ R.T)[:, 2].min()
-    c = narrowphase("plane_mesh", b=shape_record("hull", pos=(0, 0, -zmin - 0.0002), mat=R, center=(0, 0, 0)), verts_b=v, graph=graph, rbound=0.17)
+    c = narrowphase("plane_mesh", b=shape_record("hull", pos=(0, 0, -zmin - 0.0002), mat=R, center=(0, 0, 0)), verts_b=v, graph=graph, tol_rbound=0.3 * rb)
     assert c.shape[0] == 1 and abs(c[0, 0] + 0.0002) < 1e-12
-    # a real foot hull of the model flat on the floor: at most 4 contacts, all graph neighbours of the deepest vertex
+    # a real foot hull of the model flat on the floor: at most 3 contacts, graph neighbours of the deepest vertex that are not within
+    # 0.3 * mesh_rbound of it, in graph order
     adr = KPM["vert_adr"]; vb = KPM["verts"].reshape(-1, 3)[adr[4]:adr[5]]
     g4 = [list(KPM["vert_nbr"][KPM["vert_nbr_adr"][adr[4] + i]:KPM["vert_nbr_adr"][adr[4] + i + 1]]) for i in range(len(vb))]
     z0 = -vb[:, 2].min() - 0.002
-    c = narrowphase("plane_mesh", b=shape_record("hull", pos=(0, 0, z0), center=(0, 0, z0)), verts_b=vb, graph=g4, rbound=0.2)
+    tol = float(KPM["planemesh"][1] * KPM["mesh_rbound"][4])
+    assert int(KPM["planemesh"][0]) == 3 and abs(KPM["planemesh"][1] - 0.3) < 1e-12
+    c = narrowphase("plane_mesh", b=shape_record("hull", pos=(0, 0, z0), center=(0, 0, z0)), verts_b=vb, graph=g4, tol_rbound=tol, maxcon=3)
     deepest = int(np.argmin(vb[:, 2]))
-    assert 1 <= c.shape[0] <= 4 and abs(c[0, 0] + 0.002) < 1e-9
+    assert 1 <= c.shape[0] <= 3 and abs(c[0, 0] + 0.002) < 1e-9
     ids = [int(np.argmin(np.linalg.norm(vb[:, :2] - p[1:3], axis=1))) for p in c]
-    assert ids[0] == deepest and all(i in g4[deepest] for i in ids[1:])
-    want = [j for j in g4[deepest] if vb[j, 2] + z0 <= 0.001][:3]
-    assert ids[1:] == want
+    first_pos = np.array([vb[deepest, 0], vb[deepest, 1], 0.5 * (vb[deepest, 2] + z0)])
+    want = [j for j in g4[deepest] if vb[j, 2] + z0 <= 0.001 and np.linalg.norm(vb[j] + [0, 0, z0] - first_pos) >= tol][:2]
+    assert ids[0] == deepest and ids[1:] == want
 
 
 def _cube_hull(pos, half=0.1, R=None):

@@ -54,6 +54,42 @@ def test_allgather_normalisation_and_grad_allreduce_world2():
         assert r[1] and r[2] and r[3], r
 
 
+def _freq_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import types
+    from kinpoly_amd.rollout import EpisodeSource
+    ds = types.SimpleNamespace(takes=["sit-a", "push-b", "step-c"])
+    src = EpisodeSource(dataset=ds)
+    # rank r finished (take, fr_start, percent) episodes of its own shard; two sample() calls
+    for call in range(2):
+        ti = [(rank + call) % 3, 2, rank]
+        src.record(ti, [10 * rank + call, 5, 7], [1.0, 0.25 * (rank + 1), 0.5])
+    q.put((rank, src.freq_dict))
+    dist.destroy_process_group()
+
+
+def test_freq_dict_is_one_job_wide_dict_world2():
+    """agent_ar.py:664-673: every worker's finished episodes are merged into ONE freq_dict before the next draws.  Sharded over ranks,
+    EpisodeSource.record exchanges them (all_gather_object) and appends in rank order: both ranks end with the same dict, which holds
+    both shards' evidence."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_freq_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert res[0] == res[1], "ranks hold different freq_dicts"
+    fd = res[0]
+    assert sum(len(v) for v in fd.values()) == 2 * 2 * 3
+    # rank order inside a call, call order across calls: take 'step-c' (index 2) gets rank 0's then rank 1's rows of each call
+    assert fd["step-c"][:2] == [[0.25, 5], [0.5, 5]] or fd["step-c"][0] == [0.25, 5]
+    assert [1.0, 10] in fd["push-b"] and [1.0, 0] in fd["sit-a"] and [1.0, 1] in fd["push-b"] and [1.0, 11] in fd["step-c"]
+
+
 def test_single_process_normalisation_matches_reference_golden(golden):
     from kinpoly_amd.rollout import normalize_advantages_global
     from oracle import np_oracle as O

@@ -257,8 +257,8 @@ def test_contact_sets_match_oracle_contact_by_contact(kp):
 
 
 def test_floor_contacts_follow_the_hull_graph_rule(kp):
-    """mjc_PlaneConvex on the device: per hull the deepest vertex plus at most three of its hull-graph neighbours -- never more than
-    four contacts per hull, and the same set as the oracle on feet-flat, lying and half-buried states."""
+    """mjc_PlaneConvex on the device: per hull the deepest vertex plus hull-graph neighbours not within 0.3 rbound of it -- never more
+    than maxplanemesh = 3 contacts per hull, and the same set as the oracle on feet-flat, lying and half-buried states."""
     n = 24
     qpos, qvel, act = _buried_states(n, 3)
     qpos[:8] = STD["qpos"]; qpos[:8, 2] -= np.linspace(0.0, 0.03, 8)          # feet pressed flat into the floor
@@ -273,10 +273,10 @@ def test_floor_contacts_follow_the_hull_graph_rule(kp):
         o.reset(q32[e], v32[e])
         c, h = o.contacts_full(), hip[e]
         assert list(c["body"]) == list(h["body"])
-        assert len(h["body"]) == 0 or np.bincount(h["body"]).max() <= 4
+        assert len(h["body"]) == 0 or np.bincount(h["body"]).max() <= 3
         np.testing.assert_allclose(h["dist"], c["dist"], atol=2e-6)
         np.testing.assert_allclose(h["pos"], c["pos"], atol=2e-6)
-    assert max(len(h["body"]) for h in hip) >= 16
+    assert max(len(h["body"]) for h in hip) >= 10
 
 
 def test_fused_gru_unroll_matches_gru_cell_loop_forward_and_backward(kp):

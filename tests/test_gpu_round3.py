@@ -1,0 +1,74 @@
+"""Round-3 GPU tests: the RCCL branch of the multi-GPU exchange step on a 1-GPU box, the plane-mesh rule's options against the
+oracle, bench.py's new workloads (smoke)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STD = np.load(os.path.join(ROOT, "tests", "golden", "standing_neutral.npz"))
+
+
+def test_one_rank_nccl_group_moves_device_tensors():
+    """VERDICT r2 next #4a: RCCL has moved this project's device tensors at least once -- a 1-rank nccl group with the all-gather of
+    (advantages, returns) and the gradient all-reduce forced through it."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_nccl_one_rank_worker.py")], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "NCCL_ONE_RANK_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-1000:]
+
+
+def test_bench_line_under_a_one_rank_nccl_group():
+    """bench.py with the process group created although N = 1 (KP_BENCH_FORCE_PG): `ranks_seen` comes out of a device all-reduce under
+    nccl, the per-rank step times are gathered, the JSON line keeps the contract's fields."""
+    env = dict(os.environ, KP_BENCH_FORCE_PG="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29549")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2", "--no-secondary", "--no-cpu-baseline"],
+                         env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rec["ranks_seen"] == 1 and rec["collective_backend"] == "nccl" and len(rec["ms_per_step_per_rank"]) == 1
+    assert rec["roofline"]["bound"] == "valu-issue" and rec["value"] > 5e4 and rec["bad_envs"] == 0
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in rec
+
+
+@pytest.mark.parametrize("pm", [(3, 0.3), (4, 1e-3), (1, 0.3)])
+def test_plane_mesh_rule_options_match_oracle(pm):
+    """mjc_PlaneConvex's two constants are model options on both sides: contact sets and one control step agree for the
+    default (maxplanemesh 3, tolplanemesh 0.3), for round 2's reading (4, 1e-3) and for the support vertex alone."""
+    from kinpoly_amd.sim import KpModel, KpSim
+    from oracle.kpo import OracleSim
+    n = 8
+    rng = np.random.default_rng(11)
+    qpos = np.tile(STD["qpos"], (n, 1)); qpos[:, 7:] += rng.normal(size=(n, 69)) * 0.05; qpos[:, 2] -= 0.002
+    qvel = rng.normal(size=(n, 75)) * 0.1
+    act = rng.normal(size=(n, 75)) * 0.2
+    model = KpModel(planemesh_max=pm[0], planemesh_tol=pm[1])
+    sim = KpSim(model, n, 0)
+    sim.record_contacts()
+    dev = lambda a: torch.tensor(a, dtype=torch.float32, device=sim.device)      # noqa: E731
+    sim.set_state(dev(qpos), dev(qvel)); sim.set_target(dev(qpos))
+    sim.step_ctrl(dev(act), 1)
+    hip = sim.contacts()
+    got = sim.get("qpos").double().cpu().numpy()
+    q32, v32, a32 = dev(qpos).double().cpu().numpy(), dev(qvel).double().cpu().numpy(), dev(act).double().cpu().numpy()
+    total = 0
+    for e in range(n):
+        o = OracleSim(planemesh=pm)
+        o.reset(q32[e], v32[e])
+        c, h = o.contacts_full(), hip[e]
+        assert list(c["body"]) == list(h["body"]), (e, list(c["body"]), list(h["body"]))
+        np.testing.assert_allclose(h["dist"], c["dist"], atol=2e-6)
+        np.testing.assert_allclose(h["pos"], c["pos"], atol=2e-6)
+        assert len(c["body"]) == 0 or np.bincount(c["body"]).max() <= pm[0]
+        total += len(c["body"])
+        o.do_simulation(a32[e], q32[e], 1)
+        assert np.abs(o.get("qpos") - got[e]).max() < 5e-6
+    assert total > 0

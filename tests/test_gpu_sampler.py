@@ -119,8 +119,9 @@ def test_hidden_state_carries_across_calls_and_ppo_ratio_starts_at_one():
 
 
 def test_lr_schedules_and_controller_update():
-    """LambdaLR of agent_ar.py:215-225 (nepoch_fix, nepoch) stepped per iteration; joint_controller: update_controller moves the
-    UHC policy with the kinematic policy's advantages (agent_ar.py:774-794)."""
+    """LambdaLR of agent_ar.py:215-225 (nepoch_fix, nepoch) stepped per iteration.  joint_controller: the reference's optimiser holds
+    policy_net only (agent_ar.py:184-199), so its update_controller (:774-794) never moves the UHC -- the default here; `train_uhc`
+    is the opt-in extension with the UHC's own optimiser and clip."""
     from kinpoly_amd.agent import AgentAR
     from kinpoly_amd.env import standing_context
     from kinpoly_amd import sim as kpsim
@@ -131,18 +132,22 @@ def test_lr_schedules_and_controller_update():
         ctx = standing_context(m, T + 2, STD["qpos"], STD["qvel"], fk_sim, torch.zeros(m))
         ctx["obj_pose"] = torch.tensor([0.0, 0, 0, 1, 0, 0, 0], device=ctx["qpos"].device).repeat(m, T + 2, 1)
         return ctx
-    agent = AgentAR(n, context_fn, device=0, horizon=T, num_optim_epoch=2, num_step_update=1, use_init_context=False,
-                    num_epoch_fix=1, num_epoch=4, joint_controller=True, pool_depth=T)
-    cc_before = [p.detach().clone() for p in agent.env.cc_policy.parameters()]
-    lrs = []
-    for it in range(4):
-        info = agent.optimize_policy(it)
-        lrs.append(info["policy_lr"])
-        assert np.isfinite(info["surr_loss"]) and np.isfinite(info["cc_surr_loss"]) and np.isfinite(info["step_loss"])
-    rule = [1e-5 * (1.0 - max(0, e - 1) / float(4 - 1 + 1)) for e in (1, 2, 3, 4)]      # epoch counter after per_epoch_update
-    np.testing.assert_allclose(lrs, rule, rtol=1e-6)
-    moved = sum(float((p.detach() - q).abs().max()) for p, q in zip(agent.env.cc_policy.parameters(), cc_before))
-    assert moved > 0, "update_controller did not touch the UHC policy"
+    for train_uhc in (False, True):
+        agent = AgentAR(n, context_fn, device=0, horizon=T, num_optim_epoch=2, num_step_update=1, use_init_context=False,
+                        num_epoch_fix=1, num_epoch=4, joint_controller=True, pool_depth=T, train_uhc=train_uhc)
+        held = {id(p) for g in agent.trainer.opt_p.param_groups for p in g["params"]}
+        assert held == {id(p) for p in agent.policy_net.parameters() if p.requires_grad}, "optimizer_policy = Adam(policy_net.parameters())"
+        cc_before = [p.detach().clone() for p in agent.env.cc_policy.parameters()]
+        lrs = []
+        for it in range(4):
+            info = agent.optimize_policy(it)
+            lrs.append(info["policy_lr"])
+            assert np.isfinite(info["surr_loss"]) and np.isfinite(info["cc_surr_loss"]) and np.isfinite(info["step_loss"])
+        rule = [1e-5 * (1.0 - max(0, e - 1) / float(4 - 1 + 1)) for e in (1, 2, 3, 4)]      # epoch counter after per_epoch_update
+        np.testing.assert_allclose(lrs, rule, rtol=1e-6)
+        moved = sum(float((p.detach() - q).abs().max()) for p, q in zip(agent.env.cc_policy.parameters(), cc_before))
+        assert (moved > 0) == train_uhc, f"train_uhc={train_uhc}: UHC parameters moved by {moved}"
+        del agent
 
 
 def test_joint_policy_update_runs_both_forms():
