@@ -63,59 +63,84 @@ __device__ __forceinline__ double wave_max_d(double v) {
     return fmax(fmax(readlane_d(v, 0), readlane_d(v, 16)), fmax(readlane_d(v, 32), readlane_d(v, 48)));
 }
 
-// ---- support functions (mjccd_support): farthest point along the unit world direction dir, inflated by margin along dir
-struct GeomSupport {                 // box (type 0) / z-axis cylinder (type 1); record = type, size[3], pos[3], mat[9]
-    double type, size[3], pos[3], R[9];
-    __device__ __forceinline__ explicit GeomSupport(const float* g) {
-        type = g[0];
-        for (int k = 0; k < 3; k++) { size[k] = g[1 + k]; pos[k] = g[4 + k]; }
-        for (int k = 0; k < 9; k++) R[k] = g[7 + k];
-    }
-    __device__ __forceinline__ D3 center() const { return d3(pos[0], pos[1], pos[2]); }
+// ---- support functions (mjccd_support): farthest point along the unit world direction dir, inflated by margin along dir.
+// Both functors read their shape from LDS on every query (wave-uniform addresses: broadcast reads) instead of carrying it in registers:
+// the MPR program is wave-uniform, so everything it keeps live costs a VGPR per value on all 64 lanes, and the register file of the object
+// kernel is what its articulated-body loops need (tools/micro/spill_report.py).
+struct GeomSupport {                 // box (type 0) / z-axis cylinder (type 1); record (LDS) = type, size[3], pos[3], mat[9]
+    const float* g;
+    __device__ __forceinline__ explicit GeomSupport(const float* g_) : g(g_) {}
+    __device__ __forceinline__ D3 center() const { return d3((double)g[4], (double)g[5], (double)g[6]); }
     __device__ __forceinline__ D3 operator()(D3 dir, double margin) const {
+        double R[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) R[k] = (double)g[7 + k];
         const D3 l = mulmat_t(R, dir);
+        const double s0 = (double)g[1], s1 = (double)g[2], s2 = (double)g[3];
         D3 p;
-        if (type == 0.0) p = d3(l.x > 0.0 ? size[0] : -size[0], l.y > 0.0 ? size[1] : -size[1], l.z > 0.0 ? size[2] : -size[2]);
+        if (g[0] == 0.f) p = d3(l.x > 0.0 ? s0 : -s0, l.y > 0.0 ? s1 : -s1, l.z > 0.0 ? s2 : -s2);
         else {
             const double n = sqrt(l.x * l.x + l.y * l.y);
-            p = n > 1e-15 ? d3(l.x / n * size[0], l.y / n * size[0], 0.0) : d3(0.0, 0.0, 0.0);
-            p.z = l.z > 0.0 ? size[1] : (l.z < 0.0 ? -size[1] : 0.0);
+            p = n > 1e-15 ? d3(l.x / n * s0, l.y / n * s0, 0.0) : d3(0.0, 0.0, 0.0);
+            p.z = l.z > 0.0 ? s1 : (l.z < 0.0 ? -s1 : 0.0);
         }
         return center() + mulmat(R, p) + margin * dir;
     }
 };
 struct HullSupport {                 // lane v < nv holds body-frame vertex v of the hull (fp32 model data); exhaustive arg-max in fp64, first maximum
-    D3 xb, com; V3 vert; double R[9]; bool has;
-    __device__ __forceinline__ HullSupport(V3 xb_, const float* R_, V3 com_, V3 vert_, bool has_) : xb(d3(xb_)), com(d3(com_)), vert(vert_), has(has_) {
-        for (int k = 0; k < 9; k++) R[k] = R_[k];
-    }
-    __device__ __forceinline__ D3 center() const { return com; }
+    const float* h;                  // LDS: xb[3], com[3], R[9] of the hull (written by hull_support_store)
+    V3 vert; bool has;
+    __device__ __forceinline__ HullSupport(const float* h_, V3 vert_, bool has_) : h(h_), vert(vert_), has(has_) {}
+    __device__ __forceinline__ D3 center() const { return d3((double)h[3], (double)h[4], (double)h[5]); }
     __device__ __forceinline__ D3 operator()(D3 dir, double margin) const {
+        double R[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) R[k] = (double)h[6 + k];
         const D3 l = mulmat_t(R, dir);
         const double d = has ? dot(l, d3(vert)) : -1.0e300;
         const double dmax = wave_max_d(d);
         const int idx = __builtin_amdgcn_readfirstlane(__ffsll((long long)__ballot(d == dmax)) - 1);
         const D3 p = d3((double)bcast_lane(vert.x, idx), (double)bcast_lane(vert.y, idx), (double)bcast_lane(vert.z, idx));
-        return xb + mulmat(R, p) + margin * dir;
+        return d3((double)h[0], (double)h[1], (double)h[2]) + mulmat(R, p) + margin * dir;
     }
 };
+// every lane stores the same (wave-uniform) values: no exec-mask change, one LDS write per word
+__device__ __forceinline__ void hull_support_store(float* h, V3 xb, V3 com, const float* R) {
+    st3(h, xb); st3(h + 3, com);
+#pragma unroll
+    for (int k = 0; k < 9; k++) h[6 + k] = R[k];
+}
 
 // ---- libccd MPR (ccdMPRPenetration).  Every lane runs the same scalar program; the two support functors may use wave collectives.
-struct Sup { D3 v, v1, v2; };
+// A portal vertex is a point v = v1 - v2 of the Minkowski difference with its two witnesses.  Only v takes part in the iteration; the
+// witnesses are read once, by findPos, so they live in LDS: slot k (0 = v0 ... 3 = v3, 4 = the candidate v4) = 6 doubles at pm + 6 k.
 template <class SA, class SB>
-__device__ __forceinline__ Sup mink(const SA& a, const SB& b, D3 dir, double margin) {
-    Sup s; s.v1 = a(dir, margin); s.v2 = b(d3(-dir.x, -dir.y, -dir.z), margin); s.v = s.v1 - s.v2; return s;
+__device__ __forceinline__ D3 mink(const SA& a, const SB& b, D3 dir, double margin, double* pm, int slot) {
+    const D3 v1 = a(dir, margin), v2 = b(d3(-dir.x, -dir.y, -dir.z), margin);
+    double* m = pm + 6 * slot;
+    m[0] = v1.x; m[1] = v1.y; m[2] = v1.z; m[3] = v2.x; m[4] = v2.y; m[5] = v2.z;
+    return v1 - v2;
 }
-__device__ __forceinline__ D3 portal_dir(const Sup& p1, const Sup& p2, const Sup& p3) { return c_normalize(cross(p2.v - p1.v, p3.v - p1.v)); }
-__device__ __forceinline__ bool reach_tol(const Sup& p1, const Sup& p2, const Sup& p3, const Sup& v4, D3 dir) {
-    const double dv4 = dot(v4.v, dir);
-    const double m = fmin(dv4 - dot(p1.v, dir), fmin(dv4 - dot(p2.v, dir), dv4 - dot(p3.v, dir)));
+__device__ __forceinline__ void slot_copy(double* pm, int dst, int src) {
+#pragma unroll
+    for (int k = 0; k < 6; k++) pm[6 * dst + k] = pm[6 * src + k];
+}
+__device__ __forceinline__ D3 slot_v1(const double* pm, int k) { return d3(pm[6 * k], pm[6 * k + 1], pm[6 * k + 2]); }
+__device__ __forceinline__ D3 slot_v2(const double* pm, int k) { return d3(pm[6 * k + 3], pm[6 * k + 4], pm[6 * k + 5]); }
+__device__ __forceinline__ D3 portal_dir(D3 p1, D3 p2, D3 p3) { return c_normalize(cross(p2 - p1, p3 - p1)); }
+__device__ __forceinline__ bool reach_tol(D3 p1, D3 p2, D3 p3, D3 v4, D3 dir) {
+    const double dv4 = dot(v4, dir);
+    const double m = fmin(dv4 - dot(p1, dir), fmin(dv4 - dot(p2, dir), dv4 - dot(p3, dir)));
     return c_eq(m, C_MPR_TOL) || m < C_MPR_TOL;
 }
-__device__ __forceinline__ void expand_portal(const Sup& p0, Sup& p1, Sup& p2, Sup& p3, const Sup& v4) {
-    const D3 v4v0 = cross(v4.v, p0.v);
-    if (dot(p1.v, v4v0) > 0.0) { if (dot(p2.v, v4v0) > 0.0) p1 = v4; else p3 = v4; }
-    else { if (dot(p3.v, v4v0) > 0.0) p2 = v4; else p1 = v4; }
+// replaces one portal vertex by v4 (slot 4); returns nothing: p1..p3 and the witness slots are updated together
+__device__ __forceinline__ void expand_portal(D3 p0, D3& p1, D3& p2, D3& p3, D3 v4, double* pm) {
+    const D3 v4v0 = cross(v4, p0);
+    int k;
+    if (dot(p1, v4v0) > 0.0) k = dot(p2, v4v0) > 0.0 ? 1 : 3;
+    else k = dot(p3, v4v0) > 0.0 ? 2 : 1;
+    if (k == 1) p1 = v4; else if (k == 2) p2 = v4; else p3 = v4;
+    slot_copy(pm, k, 4);
 }
 __device__ __forceinline__ double pt_seg_dist2(D3 x0, D3 b, D3& w) {          // closest point of segment x0-b to the origin
     const D3 d = b - x0;
@@ -140,68 +165,77 @@ __device__ __forceinline__ double pt_tri_dist2(D3 x0, D3 B, D3 C, D3& w) {    //
     return dist;
 }
 // 0 = the inflated shapes intersect: depth, dir (from shape A towards shape B), pos.  -1 = no intersection.
+// pm: 30 doubles of LDS scratch (8-byte aligned) for the witnesses of the portal vertices.
 template <class SA, class SB>
-__device__ __forceinline__ int mpr(const SA& A, const SB& B, double margin, double& depth, D3& dir_out, D3& pos) {
-    Sup p0, p1, p2, p3, v4;
-    p0.v1 = A.center(); p0.v2 = B.center(); p0.v = p0.v1 - p0.v2;
-    if (c_eq(p0.v.x, 0.0) && c_eq(p0.v.y, 0.0) && c_eq(p0.v.z, 0.0)) p0.v.x += C_EPS * 10.0;
-    D3 dir = c_normalize(d3(-p0.v.x, -p0.v.y, -p0.v.z));
-    p1 = mink(A, B, dir, margin);
-    double dt = dot(p1.v, dir);
+__device__ __forceinline__ int mpr(const SA& A, const SB& B, double margin, double& depth, D3& dir_out, D3& pos, double* pm) {
+    D3 p0, p1, p2, p3, v4;
+    {
+        const D3 c1 = A.center(), c2 = B.center();
+        pm[0] = c1.x; pm[1] = c1.y; pm[2] = c1.z; pm[3] = c2.x; pm[4] = c2.y; pm[5] = c2.z;
+        p0 = c1 - c2;
+    }
+    if (c_eq(p0.x, 0.0) && c_eq(p0.y, 0.0) && c_eq(p0.z, 0.0)) p0.x += C_EPS * 10.0;
+    D3 dir = c_normalize(d3(-p0.x, -p0.y, -p0.z));
+    p1 = mink(A, B, dir, margin, pm, 1);
+    double dt = dot(p1, dir);
     if (c_is_zero(dt) || dt < 0.0) return -1;
-    dir = cross(p0.v, p1.v);
+    dir = cross(p0, p1);
     if (c_is_zero(dot(dir, dir))) {
-        pos = 0.5 * (p1.v1 + p1.v2);
-        if (c_eq(p1.v.x, 0.0) && c_eq(p1.v.y, 0.0) && c_eq(p1.v.z, 0.0)) { depth = 0.0; dir_out = d3(0.0, 0.0, 0.0); return 0; }
-        depth = sqrt(dot(p1.v, p1.v)); dir_out = c_normalize(p1.v);
+        pos = 0.5 * (slot_v1(pm, 1) + slot_v2(pm, 1));
+        if (c_eq(p1.x, 0.0) && c_eq(p1.y, 0.0) && c_eq(p1.z, 0.0)) { depth = 0.0; dir_out = d3(0.0, 0.0, 0.0); return 0; }
+        depth = sqrt(dot(p1, p1)); dir_out = c_normalize(p1);
         return 0;
     }
     dir = c_normalize(dir);
-    p2 = mink(A, B, dir, margin);
-    dt = dot(p2.v, dir);
+    p2 = mink(A, B, dir, margin, pm, 2);
+    dt = dot(p2, dir);
     if (c_is_zero(dt) || dt < 0.0) return -1;
-    dir = c_normalize(cross(p1.v - p0.v, p2.v - p0.v));
-    if (dot(dir, p0.v) > 0.0) { const Sup t = p1; p1 = p2; p2 = t; dir = d3(-dir.x, -dir.y, -dir.z); }
+    dir = c_normalize(cross(p1 - p0, p2 - p0));
+    if (dot(dir, p0) > 0.0) {
+        const D3 t = p1; p1 = p2; p2 = t; dir = d3(-dir.x, -dir.y, -dir.z);
+        slot_copy(pm, 4, 1); slot_copy(pm, 1, 2); slot_copy(pm, 2, 4);
+    }
     for (int guard = 0; guard < 64; guard++) {
-        p3 = mink(A, B, dir, margin);
-        dt = dot(p3.v, dir);
+        p3 = mink(A, B, dir, margin, pm, 3);
+        dt = dot(p3, dir);
         if (c_is_zero(dt) || dt < 0.0) return -1;
         bool cont = false;
-        dt = dot(cross(p1.v, p3.v), p0.v);
-        if (dt < 0.0 && !c_is_zero(dt)) { p2 = p3; cont = true; }
-        if (!cont) { dt = dot(cross(p3.v, p2.v), p0.v); if (dt < 0.0 && !c_is_zero(dt)) { p1 = p3; cont = true; } }
+        dt = dot(cross(p1, p3), p0);
+        if (dt < 0.0 && !c_is_zero(dt)) { p2 = p3; slot_copy(pm, 2, 3); cont = true; }
+        if (!cont) { dt = dot(cross(p3, p2), p0); if (dt < 0.0 && !c_is_zero(dt)) { p1 = p3; slot_copy(pm, 1, 3); cont = true; } }
         if (!cont) break;
-        dir = c_normalize(cross(p1.v - p0.v, p2.v - p0.v));
+        dir = c_normalize(cross(p1 - p0, p2 - p0));
     }
     for (int guard = 0; guard < 64; guard++) {                           // refinePortal
         dir = portal_dir(p1, p2, p3);
-        dt = dot(dir, p1.v);
+        dt = dot(dir, p1);
         if (c_is_zero(dt) || dt > 0.0) break;
-        v4 = mink(A, B, dir, margin);
-        dt = dot(v4.v, dir);
+        v4 = mink(A, B, dir, margin, pm, 4);
+        dt = dot(v4, dir);
         if (!(c_is_zero(dt) || dt > 0.0) || reach_tol(p1, p2, p3, v4, dir)) return -1;
-        expand_portal(p0, p1, p2, p3, v4);
+        expand_portal(p0, p1, p2, p3, v4, pm);
     }
     for (int it = 0;; it++) {                                            // findPenetr
         dir = portal_dir(p1, p2, p3);
-        v4 = mink(A, B, dir, margin);
+        v4 = mink(A, B, dir, margin, pm, 4);
         if (reach_tol(p1, p2, p3, v4, dir) || it > C_MPR_ITER) {
             D3 w;
-            depth = sqrt(pt_tri_dist2(p1.v, p2.v, p3.v, w));
+            depth = sqrt(pt_tri_dist2(p1, p2, p3, w));
             if (c_is_zero(depth)) w = dir;
             dir_out = c_normalize(w);
             // findPos: barycentric coordinates of the origin in the tetrahedron (v0, v1, v2, v3)
-            double b0 = dot(cross(p1.v, p2.v), p3.v), b1 = dot(cross(p3.v, p2.v), p0.v), b2 = dot(cross(p0.v, p1.v), p3.v), b3 = dot(cross(p2.v, p1.v), p0.v);
+            double b0 = dot(cross(p1, p2), p3), b1 = dot(cross(p3, p2), p0), b2 = dot(cross(p0, p1), p3), b3 = dot(cross(p2, p1), p0);
             double sum = b0 + b1 + b2 + b3;
             if (c_is_zero(sum) || sum < 0.0) {
-                b0 = 0.0; b1 = dot(cross(p2.v, p3.v), dir); b2 = dot(cross(p3.v, p1.v), dir); b3 = dot(cross(p1.v, p2.v), dir);
+                b0 = 0.0; b1 = dot(cross(p2, p3), dir); b2 = dot(cross(p3, p1), dir); b3 = dot(cross(p1, p2), dir);
                 sum = b1 + b2 + b3;
             }
-            const D3 q1 = b0 * p0.v1 + b1 * p1.v1 + b2 * p2.v1 + b3 * p3.v1, q2 = b0 * p0.v2 + b1 * p1.v2 + b2 * p2.v2 + b3 * p3.v2;
+            const D3 q1 = b0 * slot_v1(pm, 0) + b1 * slot_v1(pm, 1) + b2 * slot_v1(pm, 2) + b3 * slot_v1(pm, 3);
+            const D3 q2 = b0 * slot_v2(pm, 0) + b1 * slot_v2(pm, 1) + b2 * slot_v2(pm, 2) + b3 * slot_v2(pm, 3);
             pos = (0.5 / sum) * (q1 + q2);
             return 0;
         }
-        expand_portal(p0, p1, p2, p3, v4);
+        expand_portal(p0, p1, p2, p3, v4, pm);
     }
 }
 
@@ -209,9 +243,9 @@ struct Contact { float dist; V3 pos, n; };
 
 // mjc_Convex: shapes inflated by margin / 2, dist = margin - depth, normal = libccd's direction (geom 1 -> geom 2)
 template <class SA, class SB>
-__device__ __forceinline__ int convex_pair(const SA& g1, const SB& g2, float margin, Contact& c) {
+__device__ __forceinline__ int convex_pair(const SA& g1, const SB& g2, float margin, Contact& c, double* pm) {
     double depth; D3 dir, pos;
-    if (mpr(g1, g2, 0.5 * (double)margin, depth, dir, pos) != 0) return 0;
+    if (mpr(g1, g2, 0.5 * (double)margin, depth, dir, pos, pm) != 0) return 0;
     if (dir.x == 0.0 && dir.y == 0.0 && dir.z == 0.0) return 0;
     c.dist = (float)((double)margin - depth); c.n = f3(dir); c.pos = f3(pos);
     return 1;

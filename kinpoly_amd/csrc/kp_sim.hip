@@ -123,26 +123,57 @@ bool build_tables(kp_sim* s) {
     lev_start[D_NLEV + 1] = (int)lev_body.size();
     if ((int)lev_body.size() != NB || lev_start[D_NLEV] != NB) return false;  // tree deeper than D_NLEV levels
     T.lev_start = upload<uint8_t>(s, lev_start, &ok); T.lev_body = upload<uint8_t>(s, lev_body, &ok);
-    // static schedule of the 8-lanes-per-body tree passes: lane = 8 * slot + row; per level one word
-    //   body | parent << 5 | child0 << 10 | child1 << 15 | child2 << 20 | active << 25      (31 = none)
-    std::vector<unsigned> sched(64 * D_NLEV, 0);
-    for (int lev = 0; lev < D_NLEV; lev++) {
-        int nb = lev_start[lev + 1] - lev_start[lev];
-        if (nb > 8) return false;
-        for (int slot = 0; slot < 8; slot++)
-            for (int r = 0; r < 8; r++) {
-                unsigned w = 0;
-                if (slot < nb) {
-                    int b = lev_body[lev_start[lev] + slot];
-                    int ch[3] = {31, 31, 31}, nc = 0;
-                    for (int k = b + 1; k < NB; k++) if (m.body_parent[k] == b) { if (nc >= 3) return false; ch[nc++] = k; }
-                    int par = m.body_parent[b] < 0 ? 31 : m.body_parent[b];
-                    w = (unsigned)b | ((unsigned)par << 5) | ((unsigned)ch[0] << 10) | ((unsigned)ch[1] << 15) | ((unsigned)ch[2] << 20) | (1u << 25);
-                }
-                sched[(8 * slot + r) * D_NLEV + lev] = w;
+    // static schedule of the 8-lanes-per-body tree passes (Lane8, kp_step_kernel.hpp): lane = 8 * slot + row, 28 words per lane, built
+    // here once so that the kernels load it instead of deriving it (they re-read it at the top of every solve to keep it out of the
+    // registers in between)
+    std::vector<unsigned> tab(64 * 28, 0u);
+    unsigned multi = 0;
+    for (int lev = 0; lev < D_NLEV; lev++)
+        for (int i = lev_start[lev]; i < lev_start[lev + 1]; i++) {
+            int nc = 0;
+            for (int k = lev_body[i] + 1; k < NB; k++) if (m.body_parent[k] == lev_body[i]) nc++;
+            if (nc > 3) return false;
+            if (nc > 1) multi |= 1u << lev;
+        }
+    for (int tid = 0; tid < 64; tid++) {
+        const int slot = tid >> 3, r = tid & 7;
+        unsigned long long sb = 0, sp = 0, sc[3] = {0, 0, 0};
+        for (int lev = 0; lev < D_NLEV; lev++) {
+            const int nb = lev_start[lev + 1] - lev_start[lev];
+            if (nb > 8) return false;
+            unsigned long long b = 31, par = 31, ch[3] = {24, 24, 24};      // no body in this slot: 31; absent child: the zero record 24
+            if (slot < nb) {
+                const int body = lev_body[lev_start[lev] + slot];
+                b = (unsigned)body; par = m.body_parent[body] < 0 ? 31u : (unsigned)m.body_parent[body];
+                int nc = 0;
+                for (int k = body + 1; k < NB; k++) if (m.body_parent[k] == body) ch[nc++] = (unsigned)k;
             }
+            sb |= b << (5 * lev); sp |= par << (5 * lev);
+            for (int c = 0; c < 3; c++) sc[c] |= ch[c] << (5 * lev);
+        }
+        unsigned* w = tab.data() + 28 * tid;
+        w[0] = (unsigned)sb; w[1] = (unsigned)(sb >> 32); w[2] = (unsigned)sp; w[3] = (unsigned)(sp >> 32);
+        for (int c = 0; c < 3; c++) { w[4 + 2 * c] = (unsigned)sc[c]; w[5 + 2 * c] = (unsigned)(sc[c] >> 32); }
+        w[10] = multi;
+        for (int k = 0; k < 8; k++) {
+            const int kx = k < 4 ? k : 11 - k;          // XOR order {0,1,2,3,7,6,5,4}: register k holds column r ^ kx
+            const int c = r ^ kx;
+            int idx = 0; float sg = 0.f;
+            if (r < 6 && c < 6) {                       // entry (r, c) of the 6x6 spatial inertia from the 10 floats [Ixx Iyy Izz Ixy Ixz Iyz | h | m]
+                if (r < 3 && c < 3) { idx = (r == c) ? r : r + c + 2; sg = 1.f; }
+                else if (r >= 3 && c >= 3) { idx = 9; sg = (r == c) ? 1.f : 0.f; }
+                else {
+                    const int a = r < 3 ? r : c, l = (r < 3 ? c : r) - 3;   // [h]x(a, l)
+                    if (a != l) { idx = 6 + (3 - a - l); sg = (l == (a + 2) % 3) ? 1.f : -1.f; }
+                }
+            }
+            const int rr = r < c ? r : c, cc = r < c ? c : r;
+            const int idx21 = (r < 6 && c < 6) ? (rr * (13 - rr)) / 2 + (cc - rr) : 21;   // 21 = the always-zero slot of a record
+            w[12 + k] = (unsigned)c | ((unsigned)idx << 4) | ((unsigned)idx21 << 8);
+            std::memcpy(&w[20 + k], &sg, 4);
+        }
     }
-    T.sched8 = upload<uint32_t>(s, sched, &ok);
+    T.sched8 = upload<uint32_t>(s, tab, &ok);
     T.obj_inertial = nullptr; T.obj_geoms = nullptr; T.obj_geom_adr = nullptr; T.n_obj = 0;
     if (!m.obj_geoms.empty() && m.obj_inertial.size() == 13 * m.obj_mass.size()) {
         T.obj_inertial = upload<float>(s, m.obj_inertial, &ok); T.obj_geoms = upload<float>(s, m.obj_geoms, &ok);

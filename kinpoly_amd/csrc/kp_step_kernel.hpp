@@ -33,6 +33,14 @@ namespace kp {
 
 #define KP_SYNC() __syncthreads()
 
+// An opaque copy of a lane index.  Everything the compiler derives from threadIdx.x alone (per-lane table addresses, the Lane8 schedule)
+// is invariant over the substep loop and over the job loop of the queue kernel, so LLVM hoists it all to the kernel entry and then has
+// ~150 such values live across the whole kernel: with the narrow phases' own demand that is far beyond the 256 VGPRs two waves per SIMD
+// leave each wave, and the allocator parks them in scratch and reloads them at every use (839 scratch instructions in the object kernel,
+// tools/micro/spill_report.py).  Re-deriving them from a laundered index per substep / per solve costs a few address adds and keeps
+// their live ranges inside the phase that uses them.
+__device__ __forceinline__ int kp_launder(int x) { asm volatile("" : "+v"(x)); return x; }
+
 struct StepArgs {
     DevTables T;
     Params P;
@@ -289,40 +297,30 @@ struct Lane8 {
     int idx21[8];    // index into the 21-float symmetric storage
     unsigned long long sb, sp, sc0, sc1, sc2;  // 5 bits per level: body, parent, children (31 = none) of this lane's slot
     unsigned multi;  // bit lev set: some body of that level has more than one child (wave-uniform; only levels 0 and 3 of the SMPL tree)
-    __device__ __forceinline__ void init(int tid, const uint32_t* __restrict__ sched8) {
+    // The per-lane schedule comes ready-made from the host (kp_sim.hip: build_lane8_table, 28 dwords per lane): seven 16-byte loads
+    // and a few bit-field extracts, cheap enough to redo at the top of every solve instead of keeping 45 registers alive between them.
+    //   words 0..9   sb, sp, sc0, sc1, sc2 (64 bit each: 5 bits per tree level = body / parent / children of this lane's slot;
+    //                31 = no body at that level, absent child -> the zero record 24)
+    //   word  10     multi (bit lev: some body of that level has more than one child; only levels 0 and 3 of the SMPL tree)
+    //   words 12..19 per register k: col | ciidx << 4 | idx21 << 8     (column r ^ KX[k], index into the 10-float body inertia, index into the 21-float symmetric storage)
+    //   words 20..27 per register k: cisgn as float
+    __device__ __forceinline__ void init(int tid, const uint32_t* __restrict__ tab) {
         slot = tid >> 3; r = tid & 7;
-        sb = sp = sc0 = sc1 = sc2 = 0ull;
-        unsigned mm = 0;
-#pragma unroll
-        for (int l = 0; l < D_NLEV; l++) {
-            const unsigned w = tid < 64 ? sched8[tid * D_NLEV + l] : 0u;
-            const bool act = (w >> 25) & 1u;
-            sb |= (unsigned long long)(act ? (w & 31u) : 31u) << (5 * l);
-            sp |= (unsigned long long)(act ? ((w >> 5) & 31u) : 31u) << (5 * l);
-            const unsigned k0 = (w >> 10) & 31u, k1 = (w >> 15) & 31u, k2 = (w >> 20) & 31u;   // absent child -> zero record 24
-            sc0 |= (unsigned long long)((act && k0 != 31u) ? k0 : 24u) << (5 * l);
-            sc1 |= (unsigned long long)((act && k1 != 31u) ? k1 : 24u) << (5 * l);
-            sc2 |= (unsigned long long)((act && k2 != 31u) ? k2 : 24u) << (5 * l);
-            if (__ballot(act && k1 != 31u) != 0ull) mm |= 1u << l;
+        const uint4* q = reinterpret_cast<const uint4*>(tab + 28 * (tid & 63));
+        const uint4 w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3], w4 = q[4], w5 = q[5], w6 = q[6];
+        sb = (unsigned long long)w0.x | ((unsigned long long)w0.y << 32); sp = (unsigned long long)w0.z | ((unsigned long long)w0.w << 32);
+        sc0 = (unsigned long long)w1.x | ((unsigned long long)w1.y << 32); sc1 = (unsigned long long)w1.z | ((unsigned long long)w1.w << 32);
+        sc2 = (unsigned long long)w2.x | ((unsigned long long)w2.y << 32); multi = w2.z;
+        if (tid >= 64) {            // threads_per_env = 128 / 256: only the first wavefront serves the tree passes (31 = no body, 24 = zero record)
+            sb = sp = 0x1FFFFFFFFFFFull;
+            sc0 = sc1 = sc2 = 0x18C6318C6318ull;      // 24 in every 5-bit field of the 9 levels
         }
-        multi = mm;
+        const unsigned pk[8] = {w3.x, w3.y, w3.z, w3.w, w4.x, w4.y, w4.z, w4.w};
+        const unsigned sg[8] = {w5.x, w5.y, w5.z, w5.w, w6.x, w6.y, w6.z, w6.w};
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            const int kx = k < 4 ? k : 11 - k;
-            const int c = r ^ kx;
-            col[k] = c;
-            int idx = 0; float sg = 0.f;
-            if (r < 6 && c < 6) {
-                if (r < 3 && c < 3) { idx = (r == c) ? r : r + c + 2; sg = 1.f; }
-                else if (r >= 3 && c >= 3) { idx = 9; sg = (r == c) ? 1.f : 0.f; }
-                else {
-                    const int a = r < 3 ? r : c, l = (r < 3 ? c : r) - 3;   // [h]x(a, l)
-                    if (a != l) { idx = 6 + (3 - a - l); sg = (l == (a + 2) % 3) ? 1.f : -1.f; }
-                }
-            }
-            ciidx[k] = idx; cisgn[k] = sg;
-            const int rr = r < c ? r : c, cc = r < c ? c : r;
-            idx21[k] = (r < 6 && c < 6) ? (rr * (13 - rr)) / 2 + (cc - rr) : 21;   // 21 = the always-zero slot of a record
+            col[k] = (int)(pk[k] & 7u); ciidx[k] = (int)((pk[k] >> 4) & 15u); idx21[k] = (int)((pk[k] >> 8) & 31u);
+            cisgn[k] = __builtin_bit_cast(float, sg[k]);
         }
     }
 };
@@ -667,6 +665,13 @@ __device__ __forceinline__ void put_contact(EnvLds& s, int c, V3 pos, float dist
     }
 }
 
+// LDS scratch of the MPR query (witnesses of the portal vertices, 30 doubles) inside s.U, which is free outside the ABA passes:
+// U[0, 96) box-box polygon, U[96, 152) contact records of a pair, U[160, 220) this, U[232, 247) hull record of the support functor
+__device__ __forceinline__ double* mpr_scratch(EnvLds& s) {
+    static_assert(offsetof(EnvLds, U) % 8 == 0, "s.U must be 8-byte aligned for the fp64 MPR scratch");
+    return reinterpret_cast<double*>(s.U + 160);
+}
+
 // mj_collision of the scene.  Mid phase in parallel: lane = hull body (then lane = object geom) tests all its targets (bit 0 = floor,
 // bit j = geom j - 1) with bounding spheres; the serial part visits only the pairs that passed, in the oracle's order (entity-major,
 // floor first), so contact indices and the con_start[] grouping are the oracle's.  Narrow phases: kp_collide.hpp.
@@ -739,9 +744,11 @@ __device__ __forceinline__ void collide(EnvLds& s, const DevTables& T, const Par
                     EnvLdsObj& so = static_cast<EnvLdsObj&>(s);
                     const float* g = so.geom + 17 * gi;
                     const GeomSupport ga(g);
-                    const HullSupport hb(xb, R, xb + mulmat(R, ld3(T.body_ipos + 3 * b)), v, tid < nvb);       // centre = the body's COM (xipos)
+                    float* hrec = s.U + 232;                              // hull record of the support functor (LDS scratch: s.U is free outside the ABA passes)
+                    hull_support_store(hrec, xb, xb + mulmat(R, ld3(T.body_ipos + 3 * b)), R);       // centre = the body's COM (xipos)
+                    const HullSupport hb(hrec, v, tid < nvb);
                     Contact c;
-                    if (convex_pair(ga, hb, P.margin, c) && ncon < D_MAXCON) {
+                    if (convex_pair(ga, hb, P.margin, c, mpr_scratch(s)) && ncon < D_MAXCON) {
                         if (tid == 0) put_contact<OBJ>(s, ncon, c.pos, c.dist, c.n, b, so.gobj[gi] < 0 ? -2 - gi : D_NB + so.gobj[gi]);
                         ncon++;
                     }
@@ -805,7 +812,7 @@ __device__ __forceinline__ void collide(EnvLds& s, const DevTables& T, const Par
                         } else {
                             const GeomSupport s1(a_first ? g : h), s2(a_first ? h : g);
                             Contact c;
-                            n = convex_pair(s1, s2, P.margin, c);
+                            n = convex_pair(s1, s2, P.margin, c, mpr_scratch(s));
                             if (n && tid == 0) put_rec(rec, 0, c.dist, c.pos, c.n);
                         }
                     }
@@ -1563,6 +1570,7 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
     }
     int it = 0, lev_hist = 1;
     bool done = false;          // left the loop through one of mj_solNewton's termination tests (not the iteration cap)
+    const unsigned conlev = contact_levels(s, L8);
     for (; it < P.max_iter; it++) {
         // gradient: humanoid dofs (mres - J^T f) and object wrenches
         wrench_project<NT, true>(s, P, sacc, s.qacc, s.qacc_s, s.grad(), true, true, tid);
@@ -1610,7 +1618,7 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
         if (refactor) {
             if (no6 > 0) obj_hessian(s, P, s.ogr, -1.0f, tid);
             lev_hist = max(lev_hist, first_clean_level<NT>(s, deep, tid));   // the clean range only shrinks within a substep
-            aba_solve<NT, true>(s, P, L8, s.x, s.search, true, tid, lev_hist);     // y0 = H_hh^-1 (-g_h); sv = its spatial accelerations
+            aba_solve<NT, true>(s, P, L8, s.x, s.search, true, tid, lev_hist, nullptr, nullptr, nullptr, conlev);     // y0 = H_hh^-1 (-g_h); sv = its spatial accelerations
             if (couple) { obj_coupling_u(s, P, s.ot, tid); if (tid < no6) s.Sm[ST * tid + no6] += s.ot[tid]; KP_SYNC(); }     // rhs_o -= H_oh y0
         }
         if (!(refactor && no6 == 0)) {
@@ -1696,16 +1704,14 @@ __device__ __forceinline__ void step_body(StepArgs A, const int env_in, const in
     else if (part >= 0) A.n_substeps = (int)(((part < 8 ? A.part_sub_lo >> (8 * part) : A.part_sub_hi >> (8 * (part - 8)))) & 255ull);   // this job's share of the control step
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     typename std::conditional<OBJ, EnvLdsObj, EnvLds>::type& s = *reinterpret_cast<typename std::conditional<OBJ, EnvLdsObj, EnvLds>::type*>(smem_raw);
-    const int tid = threadIdx.x;
+    const int tid0 = threadIdx.x;
+    const int tid = tid0;
     const int env = env_in;
     if (env >= A.n_envs) return;
     if (A.env_mask && !A.env_mask[env]) return;
     const unsigned long long t_launch = __builtin_readcyclecounter();
     const DevTables& T = A.T;
     const Params& P = A.P;
-    const int depth = tid < D_NB ? T.body_depth[tid] : -1;
-    Lane8 L8; L8.init(tid, T.sched8);
-    const V3 bpos = tid < D_NB ? ld3(T.body_pos + 3 * tid) : v3(0.f, 0.f, 0.f);
 
     // ---- load: derived state first (the state the last forward pass ran on), then the real state
     const float* tq_row = A.target_qpos ? A.target_qpos + (size_t)env * D_NQ : nullptr;
@@ -1741,34 +1747,52 @@ __device__ __forceinline__ void step_body(StepArgs A, const int env_in, const in
         if (tid == 0) { s.ngeom_static = ngs; s.ngeom = ng; s.nobj = nobj; }
     }
     KP_SYNC();
-    forward_kin_bias<NT>(s, T, P, depth, bpos, tid);
     float qd_save_q[(D_NQ + NT - 1) / NT], qd_save_v[(D_NV + NT - 1) / NT];
-#pragma unroll
-    for (int n = 0; n < (D_NQ + NT - 1) / NT; n++) { int i = tid + n * NT; qd_save_q[n] = i < D_NQ ? s.qpos[i] : 0.f; }
-#pragma unroll
-    for (int n = 0; n < (D_NV + NT - 1) / NT; n++) { int i = tid + n * NT; qd_save_v[n] = i < D_NV ? s.qvel[i] : 0.f; }
-    KP_SYNC();
-    if (A.n_substeps > 0) {
-        for (int i = tid; i < D_NQ; i += NT) s.qpos[i] = gld<Q>(A.qpos + (size_t)env * D_NQ + i);
-        for (int i = tid; i < D_NV; i += NT) s.qvel[i] = gld<Q>(A.qvel + (size_t)env * D_NV + i);
-        KP_SYNC();
-    }
     int niter_total = 0, maxcon = 0, nfact_total = 0, ncap_total = 0;
     unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
     const bool prof = A.prof != nullptr;
 #define KP_T(i) if (prof) { t1 = __builtin_readcyclecounter(); pc[i] += t1 - t0; t0 = t1; }
-    const unsigned long long tstart = prof ? __builtin_readcyclecounter() : 0;
-    for (int sub = 0; sub < A.n_substeps; sub++) {
+    unsigned long long tstart = 0;
+    // One loop, one inlined copy of every phase.  Pass -1 is the entry pass: the forward pass on the derived state the job was handed
+    // (qpos_d / qvel_d), after which the real state is loaded; passes 0 .. n - 1 are the substeps; in fresh mode (stale_kinematics = 0)
+    // pass n is the forward pass on the final state.  Running the entry pass through the SAME code as a substep's forward pass is what
+    // makes a control step cut into jobs bit-identical to an uncut one (two inlined copies need not contract their FMAs alike), and it
+    // keeps the kernel's code a third shorter.
+    const int last_pass = (A.n_substeps > 0 && !P.stale) ? A.n_substeps : A.n_substeps - 1;
+    for (int sub = -1; sub <= last_pass; sub++) {
+        // per-lane invariants are re-derived from a laundered lane index every pass (see kp_launder): table addresses, the body's tree
+        // level and offset, and -- at the top of each solve -- the Lane8 schedule
+        const int tid = kp_launder(tid0);
+        const int depth = tid < D_NB ? (int)s.bdep[tid] : -1;
+        const V3 bpos = tid < D_NB ? ld3(T.body_pos + 3 * tid) : v3(0.f, 0.f, 0.f);
+        const bool substep = sub >= 0 && sub < A.n_substeps;
+        if (prof && sub == 0) tstart = __builtin_readcyclecounter();
         if (prof) t0 = __builtin_readcyclecounter();
         // stale mode: the controller sees M / bias of the previous forward pass (cinert, cdof, bias still in LDS)
-        if (P.stale) spd_torque_rfc<NT, OBJ>(s, T, P, L8, tid, tq_row, act_row);
+        if (substep && P.stale) { Lane8 La; La.init(kp_launder(tid), T.sched8); spd_torque_rfc<NT, OBJ>(s, T, P, La, tid, tq_row, act_row); }
         KP_T(0)
         // ---- mj_forward at the current state
+        if (sub >= 0) {
 #pragma unroll
-        for (int n = 0; n < (D_NQ + NT - 1) / NT; n++) { int i = tid + n * NT; if (i < D_NQ) qd_save_q[n] = s.qpos[i]; }
+            for (int n = 0; n < (D_NQ + NT - 1) / NT; n++) { int i = tid + n * NT; if (i < D_NQ) qd_save_q[n] = s.qpos[i]; }
 #pragma unroll
-        for (int n = 0; n < (D_NV + NT - 1) / NT; n++) { int i = tid + n * NT; if (i < D_NV) qd_save_v[n] = s.qvel[i]; }
+            for (int n = 0; n < (D_NV + NT - 1) / NT; n++) { int i = tid + n * NT; if (i < D_NV) qd_save_v[n] = s.qvel[i]; }
+        }
         forward_kin_bias<NT>(s, T, P, depth, bpos, tid);
+        if (sub < 0) {          // entry pass: the derived state is what the forward pass just ran on (quaternion normalised); now the real state
+#pragma unroll
+            for (int n = 0; n < (D_NQ + NT - 1) / NT; n++) { int i = tid + n * NT; qd_save_q[n] = i < D_NQ ? s.qpos[i] : 0.f; }
+#pragma unroll
+            for (int n = 0; n < (D_NV + NT - 1) / NT; n++) { int i = tid + n * NT; qd_save_v[n] = i < D_NV ? s.qvel[i] : 0.f; }
+            KP_SYNC();
+            if (A.n_substeps > 0) {
+                for (int i = tid; i < D_NQ; i += NT) s.qpos[i] = gld<Q>(A.qpos + (size_t)env * D_NQ + i);
+                for (int i = tid; i < D_NV; i += NT) s.qvel[i] = gld<Q>(A.qvel + (size_t)env * D_NV + i);
+                KP_SYNC();
+            }
+            continue;
+        }
+        if (!substep) continue;         // fresh mode's exit pass: outputs are the kinematics of the final state
         if constexpr (OBJ) obj_forward(s, T, P, tid);
         KP_T(1)
         collide<NT, OBJ>(s, T, P, tid);
@@ -1785,10 +1809,11 @@ __device__ __forceinline__ void step_body(StepArgs A, const int env_in, const in
         KP_T(2)
         make_constraint<NT, OBJ>(s, T, P, tid);                 // needs sv = cvel: before any aba_solve
         KP_T(3)
-        if (!P.stale) spd_torque_rfc<NT, OBJ>(s, T, P, L8, tid, tq_row, act_row);
+        if (!P.stale) { Lane8 La; La.init(kp_launder(tid), T.sched8); spd_torque_rfc<NT, OBJ>(s, T, P, La, tid, tq_row, act_row); }
         for (int i = tid; i < D_NV; i += NT) s.extra[i] = 0.f;
         KP_SYNC();
         // qacc_smooth = M^-1 qfrc_smooth; sv = its spatial accelerations; Mv/mres = those of (warm start - qacc_smooth) for the Newton solve
+        Lane8 L8; L8.init(kp_launder(tid), T.sched8);          // lives through the smooth solve and the Newton solve
         aba_solve<NT, OBJ, true>(s, P, L8, s.applied, s.qacc_s, false, tid, D_NLEV, s.fb, s.qacc, s.Mv);
         KP_T(4)
         if constexpr (OBJ) niter_total += solve_constraints_obj<NT>(s, P, L8, tid, nfact_total, ncap_total);
@@ -1815,13 +1840,6 @@ __device__ __forceinline__ void step_body(StepArgs A, const int env_in, const in
     if (prof && tid == 0 && A.n_substeps > 0) {
         pc[7] = __builtin_readcyclecounter() - tstart;
         for (int k = 0; k < 8; k++) A.prof[8 * (size_t)env + k] = pc[k];
-    }
-    if (A.n_substeps > 0 && !P.stale) {  // fresh mode: outputs are the kinematics of the final state
-#pragma unroll
-        for (int n = 0; n < (D_NQ + NT - 1) / NT; n++) { int i = tid + n * NT; if (i < D_NQ) qd_save_q[n] = s.qpos[i]; }
-#pragma unroll
-        for (int n = 0; n < (D_NV + NT - 1) / NT; n++) { int i = tid + n * NT; if (i < D_NV) qd_save_v[n] = s.qvel[i]; }
-        forward_kin_bias<NT>(s, T, P, depth, bpos, tid);
     }
     // ---- store
     bool bad = false;

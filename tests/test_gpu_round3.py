@@ -32,7 +32,9 @@ def test_bench_line_under_a_one_rank_nccl_group():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2", "--no-secondary", "--no-cpu-baseline"],
                          env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert lines, "no JSON line on stdout:\n" + out.stdout[-1500:] + out.stderr[-1500:]
+    rec = json.loads(lines[-1])
     assert rec["ranks_seen"] == 1 and rec["collective_backend"] == "nccl" and len(rec["ms_per_step_per_rank"]) == 1
     assert rec["roofline"]["bound"] == "valu-issue" and rec["value"] > 5e4 and rec["bad_envs"] == 0
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
