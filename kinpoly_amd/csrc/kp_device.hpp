@@ -54,7 +54,7 @@ struct __attribute__((aligned(16))) EnvLds {
     float xpos[72], xquat[96];            // body COMs (xipos) are recomputed where they are read: collision centres, the read-out
     float cinert[240];                    // body spatial inertia about o, world axes (10 floats / body)
     float cdof[450];                      // motion axis of every dof [ang; lin] about o
-    float sv[156], sa[144], sw[144];      // per-body spatial scratch (velocity / acceleration / wrench); sv[144..155]: the two object slots
+    float sv[156];                        // per-body spatial scratch (velocity / acceleration); sv[144..155]: the two object slots
     float U[450], Dinv[76], uj[76];       // articulated-body pass: U_j = IA s_j, 1/D_j, u_j
     float IAa[25 * 22], pAa[25 * 6];      // articulated inertia / bias force handed to the parent; slot 21 of a record and
                                           // record 24 are kept 0 so that padded / absent operands load a zero without exec masking
@@ -65,9 +65,13 @@ struct __attribute__((aligned(16))) EnvLds {
                                           // the smooth solve; between that solve and the next substep the same words hold the Newton gradient
     __device__ __forceinline__ float* grad() { return applied; }
     float con_pos[D_MAXCON * 3], con_D[D_MAXCON];   // con_D: contact distance from collide() until make_constraint() turns it into the row weight D
-    float jar3[D_MAXCON * 3], jv3[D_MAXCON * 3];   // contact-frame (normal, t1, t2) residuals J qacc - aref and J search
-    float lim_D[72], lim_jar[72], lim_jv[72];   // joint-limit rows: lim_D = sign x weight (sign: +1 lower / -1 upper limit violated, 0 = no row);
-                                          // lim_jv holds the reference acceleration until the first J search product overwrites it
+    float jar3[D_MAXCON * 3];             // contact-frame (normal, t1, t2) residuals J qacc - aref
+    float lim_D[72], lim_jar[72];         // joint-limit rows: lim_D = sign x weight (sign: +1 lower / -1 upper limit violated, 0 = no row)
+    // jv3 | lim_jv | sa | sw are contiguous: between the gradient and the row evaluation of a Newton iteration all four are dead, and the
+    // object kernel's batched Schur-complement columns use the 552 floats as one scratch block (schur_columns)
+    float jv3[D_MAXCON * 3];              // J search per contact (and aref until the first J search product)
+    float lim_jv[72];                     // J search per joint-limit row; holds the reference acceleration until the first J search product overwrites it
+    float sa[144], sw[144];               // per-body spatial scratch (acceleration / wrench); contact forces of the object solve live in sa ++ sw[0, 48)
     float red[8];
     unsigned char bpar[D_NB], bsub[D_NB], bdep[D_NB], dbody[76];
     unsigned char con_act[D_MAXCON];      // active pyramid rows (4 bits) of every contact at the last factorisation

@@ -1509,6 +1509,125 @@ __device__ __forceinline__ void obj_integrate(EnvLdsObj& s, const Params& P, int
     }
 }
 
+// Schur-complement columns of the object block, all at once.  Column j of  S = H_oo - H_oh H_hh^-1 H_ho  needs z_j = H_hh^-1 (H_ho e_j):
+// a bias-force-only pass through the articulated-body factorisation whose right-hand side is a set of body wrenches on the hulls that
+// touch object k(j) (-K_c e_j), and of whose result only the spatial accelerations of the touching hulls are read (H_oh z_j = sum K_c a).
+// So only the union of the touching hulls' paths to the root takes part, and the columns are independent: lane = (column, row of the
+// 6-vector), 8 columns x 8 rows per round, the bodies of the path visited one after the other (leaves -> root in descending body order,
+// root -> leaves ascending; bodies are in depth-first order, so a per-depth accumulator is all the hand-up needs).  Replaces 6 n_obj
+// passes of aba_resolve + hull_coupling_wrench + obj_coupling_u (12 passes per factorisation in the push scene) by one or two rounds.
+// Scratch: the 552 contiguous floats jv3 | lim_jv | sa | sw (dead between the gradient and the row evaluation): per-depth accumulators
+// [9][nc][6] + the joint-space right-hand sides u of the path's dofs [npd][nc]; nc = columns per round is what fits.
+constexpr int D_SCHUR_SCRATCH = D_MAXCON * 3 + 72 + 144 + 144;
+__device__ __forceinline__ void schur_columns(EnvLdsObj& s, const Params& P, unsigned cmask, int tid) {
+    static_assert(offsetof(EnvLds, lim_jv) == offsetof(EnvLds, jv3) + sizeof(float) * D_MAXCON * 3 && offsetof(EnvLds, sa) == offsetof(EnvLds, lim_jv) + sizeof(float) * 72 &&
+                  offsetof(EnvLds, sw) == offsetof(EnvLds, sa) + sizeof(float) * 144, "jv3 | lim_jv | sa | sw must be contiguous");
+    constexpr int ST = 6 * D_MAXOBJ + 1;
+    const int jl = tid >> 3, r = tid & 7;
+    const bool rowok = r < 6;
+    const int rc = rowok ? r : 5;
+    const float rmask = rowok ? 1.f : 0.f;
+    const V3 o = ld3(s.xpos);
+    // hulls that press on an object with an active row, and the union of their paths to the root (subtree of b = bodies [b, b + bsub[b]))
+    bool mine = false;
+    if (tid < D_NB)
+        for (int c = s.con_start[tid]; c < s.con_start[tid + 1]; c++) { const int B = s.con_b2[c]; if (B >= D_NB && ((cmask >> (B - D_NB)) & 1u)) mine = true; }
+    const unsigned touch = (unsigned)__ballot(mine);
+    const unsigned subtree = tid < D_NB ? ((s.bsub[tid] >= 32 ? 0xFFFFFFFFu : ((1u << s.bsub[tid]) - 1u)) << tid) : 0u;
+    const unsigned path = (unsigned)__ballot((touch & subtree) != 0u);
+    if (path == 0u) return;
+    const int npd = 3 * __popc(path) + 3;                       // dofs on the path (the root has six)
+    const int ncmax = min(8, D_SCHUR_SCRATCH / (54 + npd));     // >= 4
+    const int ncols = 6 * __popc(cmask);
+    float* ACC = s.jv3;                                          // [9 levels][ncmax][6]
+    float* UU = ACC + 54 * ncmax;                                // [npd][ncmax]
+    const int nobj = s.nobj;
+    for (int c0 = 0; c0 < ncols; c0 += ncmax) {
+        const int nc = min(ncmax, ncols - c0);
+        const bool colok = jl < nc;
+        const int jc = colok ? jl : 0;
+        const int gcol = (cmask == 2u ? 6 : 0) + c0 + jc;        // column of the object system
+        const int kcol = gcol / 6, icol = gcol - 6 * kcol;
+        for (int i = tid; i < 54 * ncmax; i += 64) ACC[i] = 0.f;
+        KP_SYNC();
+        // ---- leaves -> root: bias forces.  ACC[level][column][row] belongs to lane (column, row) alone.
+        unsigned todo = path;
+        while (todo) {
+            const int b = 31 - __clz((int)todo);
+            todo &= ~(1u << b);
+            const int d = s.bdep[b];
+            float* acc = ACC + (d * ncmax + jc) * 6;
+            float pA = (colok && rowok) ? acc[r] : 0.f;
+            if ((touch >> b) & 1u) {                             // right-hand side: + (K_c e_icol)[r] for this hull's contacts on object kcol
+                V3 Pi, Pr;                                       // rows of P = [[p]x ; 1]: K_c = P M P^T, entry (r, i) = P_r . (M P_i)
+                for (int c = s.con_start[b]; c < s.con_start[b + 1]; c++) {
+                    if ((int)s.con_b2[c] - D_NB != kcol) continue;
+                    const V3 p = ld3(s.con_pos + 3 * c) - o;
+                    if (icol == 0) Pi = v3(0.f, -p.z, p.y); else if (icol == 1) Pi = v3(p.z, 0.f, -p.x); else if (icol == 2) Pi = v3(-p.y, p.x, 0.f);
+                    else Pi = v3(icol == 3 ? 1.f : 0.f, icol == 4 ? 1.f : 0.f, icol == 5 ? 1.f : 0.f);
+                    if (r == 0) Pr = v3(0.f, -p.z, p.y); else if (r == 1) Pr = v3(p.z, 0.f, -p.x); else if (r == 2) Pr = v3(-p.y, p.x, 0.f);
+                    else Pr = v3(r == 3 ? 1.f : 0.f, r == 4 ? 1.f : 0.f, r == 5 ? 1.f : 0.f);
+                    const float* m = s.cM + 6 * c;
+                    const V3 w = v3(m[0] * Pi.x + m[3] * Pi.y + m[4] * Pi.z, m[3] * Pi.x + m[1] * Pi.y + m[5] * Pi.z, m[4] * Pi.x + m[5] * Pi.y + m[2] * Pi.z);
+                    pA += rmask * dot(Pr, w);
+                }
+            }
+            const int slot0 = b == 0 ? 0 : 3 + 3 * __popc(path & ((1u << b) - 1u));
+            for (int g = 0; g < (b == 0 ? 2 : 1); g++) {
+                const int d0 = b == 0 ? (g == 0 ? 3 : 0) : 6 + 3 * (b - 1), sl = b == 0 ? d0 : slot0;
+#pragma unroll
+                for (int j = 2; j >= 0; j--) {
+                    const int dd = d0 + j;
+                    const float u = -sum8(rmask * s.cdof[6 * dd + rc] * pA);
+                    pA += rmask * s.U[6 * dd + rc] * (u * s.Dinv[dd]);
+                    if (colok && r == 0) UU[(sl + j) * ncmax + jc] = u;
+                }
+            }
+            if (colok && rowok) {
+                acc[r] = 0.f;
+                if (b > 0) ACC[((d - 1) * ncmax + jc) * 6 + r] += pA;
+            }
+        }
+        KP_SYNC();
+        // ---- root -> leaves: spatial accelerations (ACC now holds them per level); at a touching hull, H_oh z accumulates per object
+        float cpl0 = 0.f, cpl1 = 0.f;
+        todo = path;
+        while (todo) {
+            const int b = __ffs((int)todo) - 1;
+            todo &= todo - 1u;
+            const int d = s.bdep[b];
+            float a = (b > 0 && colok && rowok) ? ACC[((d - 1) * ncmax + jc) * 6 + r] : 0.f;
+            const int slot0 = b == 0 ? 0 : 3 + 3 * __popc(path & ((1u << b) - 1u));
+            for (int g = 0; g < (b == 0 ? 2 : 1); g++) {
+                const int d0 = b == 0 ? (g == 0 ? 0 : 3) : 6 + 3 * (b - 1), sl = b == 0 ? d0 : slot0;
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    const int dd = d0 + j;
+                    const float qdd = (UU[(sl + j) * ncmax + jc] - sum8(rmask * s.U[6 * dd + rc] * a)) * s.Dinv[dd];
+                    a += qdd * s.cdof[6 * dd + rc];
+                }
+            }
+            if (colok && rowok) ACC[(d * ncmax + jc) * 6 + r] = a;
+            if ((touch >> b) & 1u) {
+                KP_SYNC();
+                const S6 ab = lds6(ACC + (d * ncmax + jc) * 6);             // the column's whole 6-vector (its six row lanes just stored it)
+                for (int c = s.con_start[b]; c < s.con_start[b + 1]; c++) {
+                    const int B = s.con_b2[c];
+                    if (B < D_NB) continue;
+                    const S6 w = con_Kp(s, c, ab, o);
+                    const float wr = r == 0 ? w.a.x : r == 1 ? w.a.y : r == 2 ? w.a.z : r == 3 ? w.l.x : r == 4 ? w.l.y : w.l.z;
+                    if (B == D_NB) cpl0 += wr; else cpl1 += wr;
+                }
+            }
+        }
+        if (colok && rowok) {
+            s.Sm[r * ST + gcol] += cpl0;
+            if (nobj > 1) s.Sm[(6 + r) * ST + gcol] += cpl1;
+        }
+        KP_SYNC();
+    }
+}
+
 // the constraint solve with free objects in the scene: same Newton iteration as solve_constraints on the joint unknowns
 // (q_humanoid, a_object...).  The Newton system is solved exactly by block elimination: the articulated-body pass factorises
 // the humanoid block, 6 n_obj + 1 bias-only passes form the Schur complement on the objects when a hull touches one.
@@ -1599,10 +1718,8 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
         const bool refactor = it == 0 || changed > 0.f;
         nfact += refactor;
         int cslot = -1;                                   // object slot this lane's hull contact presses on with an active row
-        float cdep = 0.f;                                 // deepest tree level of a hull that touches an object
         for (int c = tid; c < s.con_start[D_NB]; c += NT) {
             if (s.con_b2[c] < D_NB) continue;
-            cdep = fmaxf(cdep, (float)s.bdep[s.con_body[c]]);
             const float jn = s.jar3[3 * c], jt1 = s.jar3[3 * c + 1], jt2 = s.jar3[3 * c + 2];
             bool act = false;
 #pragma unroll
@@ -1611,49 +1728,31 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
         }
         const unsigned cmask = (__ballot(cslot == 0) != 0ull ? 1u : 0u) | (__ballot(cslot == 1) != 0ull ? 2u : 0u);
         const bool couple = cmask != 0u;
-        const int lev_cpl = (int)(-wave_min(-cdep));     // Schur-complement columns only load, and are only read at, bodies down to here
         // H = [[H_hh, H_ho], [H_oh, H_oo]] by block elimination.  refactor: one articulated-body factorisation of H_hh (+ the object
-        // rows); the passes below only push right-hand sides through it (pass -1: y0 when the factors are reused, passes 0..n-1:
-        // the Schur-complement columns when a hull touches an object, pass n: the back-substitution)
+        // rows), then -- when a hull presses on an object -- the Schur-complement columns (schur_columns); the dense object system; and
+        // one more pass through the factorisation for the back-substitution
         if (refactor) {
             if (no6 > 0) obj_hessian(s, P, s.ogr, -1.0f, tid);
             lev_hist = max(lev_hist, first_clean_level<NT>(s, deep, tid));   // the clean range only shrinks within a substep
             aba_solve<NT, true>(s, P, L8, s.x, s.search, true, tid, lev_hist, nullptr, nullptr, nullptr, conlev);     // y0 = H_hh^-1 (-g_h); sv = its spatial accelerations
             if (couple) { obj_coupling_u(s, P, s.ot, tid); if (tid < no6) s.Sm[ST * tid + no6] += s.ot[tid]; KP_SYNC(); }     // rhs_o -= H_oh y0
         }
-        if (!(refactor && no6 == 0)) {
-            int kj = refactor ? (couple ? 0 : no6) : -1;
-            while (true) {
-                const float* rhsp = nullptr; const float* wr = nullptr; float* outp = s.grad();     // scratch: -grad already sits in s.x
-                if (kj == -1) { rhsp = s.x; outp = s.search; }
-                else if (kj < no6) {
-                    if (!((cmask >> (kj / 6)) & 1u)) { kj += 6; continue; }     // no hull presses on this object: H_ho e = 0, column done
-                    if (tid < no6) s.oMv[tid] = tid == kj ? 1.f : 0.f;
-                    KP_SYNC();
-                    hull_coupling_wrench(s, P, kj / 6, s.oMv, -1.0f, tid);      // H_ho e_kj as body wrenches
-                    wr = s.sw;
-                } else {
-                    dense_solve(s, no6, tid, refactor);
-                    if (tid < no6) s.osrch[tid] = s.Sm[ST * tid + no6];
-                    KP_SYNC();
-                    if (!couple) break;
-                    hull_coupling_wrench(s, P, -1, s.osrch, 1.0f, tid);         // -H_ho da
-                    rhsp = s.x; wr = s.sw; outp = s.search;
-                }
-                aba_resolve(s, L8, rhsp, wr, outp, (kj >= 0 && kj < no6) ? lev_cpl : D_NLEV - 1);
-                if (kj == no6) break;
-                if (kj == -1) {
-                    if (no6 == 0) break;
-                    if (tid < no6) s.Sm[ST * tid + no6] = -s.ogr[tid];
-                    KP_SYNC();
-                    if (couple) { obj_coupling_u(s, P, s.ot, tid); if (tid < no6) s.Sm[ST * tid + no6] += s.ot[tid]; KP_SYNC(); }
-                    kj = no6;
-                    continue;
-                }
-                obj_coupling_u(s, P, s.ot, tid);                                // -H_oh z
-                if (tid < no6) s.Sm[ST * tid + kj] += s.ot[tid];
+        if (refactor && couple) schur_columns(s, P, cmask, tid);          // S = H_oo - H_oh H_hh^-1 H_ho, all columns in one or two rounds
+        if (!refactor) {                                                  // factors reused: y0 = H_hh^-1 (-g_h) through them, then the object right-hand side
+            aba_resolve(s, L8, s.x, nullptr, s.search);
+            if (no6 > 0) {
+                if (tid < no6) s.Sm[ST * tid + no6] = -s.ogr[tid];
                 KP_SYNC();
-                kj++;
+                if (couple) { obj_coupling_u(s, P, s.ot, tid); if (tid < no6) s.Sm[ST * tid + no6] += s.ot[tid]; KP_SYNC(); }
+            }
+        }
+        if (no6 > 0) {
+            dense_solve(s, no6, tid, refactor);
+            if (tid < no6) s.osrch[tid] = s.Sm[ST * tid + no6];
+            KP_SYNC();
+            if (couple) {                                                 // back-substitution: search = H_hh^-1 (-g_h - H_ho da)
+                hull_coupling_wrench(s, P, -1, s.osrch, 1.0f, tid);
+                aba_resolve(s, L8, s.x, s.sw, s.search);
             }
         }
         if (tid < no6) s.sv[6 * D_NB + tid] = s.osrch[tid];

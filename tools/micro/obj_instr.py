@@ -27,14 +27,9 @@ def patch(s):
         nfact += refactor;''', '''        NP(1)
         const bool refactor = it == 0 || changed > 0.f;
         nfact += refactor;''')
-    rep('''        if (!(refactor && no6 == 0)) {
-            int kj = refactor ? (couple ? 0 : no6) : -1;''', '''        NP(2)
-        if (!(refactor && no6 == 0)) {
-            int kj = refactor ? (couple ? 0 : no6) : -1;''')
-    rep('''                } else {
-                    dense_solve(s, no6, tid, refactor);''', '''                } else {
-                    NP(3)
-                    dense_solve(s, no6, tid, refactor);''')
+    rep('''        if (refactor && couple) schur_columns(s, P, cmask, tid);''', '''        NP(2)
+        if (refactor && couple) schur_columns(s, P, cmask, tid);
+        NP(3)''')
     rep('''        if (tid < no6) s.sv[6 * D_NB + tid] = s.osrch[tid];
         KP_SYNC();
         eval_rows<NT, true>(s, s.search, s.jv3, s.lim_jv, false, tid);''', '''        NP(4)

@@ -1,0 +1,26 @@
+"""The tail of the objects workload's launch: the envs that take longest in the last control step -- action class, contacts, Newton iterations,
+factorisations, object state."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import bench
+steps = int(os.environ.get("STEPS", "40"))
+rec, env, policy, sampler, std = bench.run_workload("objects", 0, 4, 64, steps, 10)
+d = np.asarray(rec["diag"])
+cost = env.sim.launch_cost().astype(np.float64)
+cls = env.ctx["action_one_hot"][env.row.long()].argmax(1).cpu().numpy()
+names = ("sit", "push", "avoid", "step")
+print("launch ms %.3f  cost unit per env: mean %.0f median %.0f p99 %.0f max %.0f" % (rec["kern_s"] * 1e3, cost.mean(), np.median(cost), np.percentile(cost, 99), cost.max()))
+oq = env.sim.get("obj_qpos").cpu().numpy(); ov = env.sim.get("obj_qvel").cpu().numpy()
+qp = env.sim.get("qpos").cpu().numpy()
+order = np.argsort(-cost)
+for e in order[:16]:
+    a = cls[e]
+    print(f"env {e} class {names[a]} cost {cost[e] / np.median(cost):.1f}x median  contacts {d[e, 0]} (max {d[e, 3] & 255}) newton it/substep {d[e, 1] / 15:.1f} nfact/substep {(d[e, 3] >> 8) / 15:.1f} cap hits {d[e, 2] >> 8}"
+          f" cur_t {int(env.cur_t[e])} root z {qp[e, 2]:.2f} obj speed {np.abs(ov[e]).max():.2f}")
+for a in range(4):
+    m = cls == a
+    print(names[a], "n", m.sum(), "cost/median mean %.2f p99 %.2f max %.2f" % (cost[m].mean() / np.median(cost), np.percentile(cost[m], 99) / np.median(cost), cost[m].max() / np.median(cost)),
+          "newton it/substep mean %.2f p99 %.2f max %.2f" % (d[m, 1].mean() / 15, np.percentile(d[m, 1], 99) / 15, d[m, 1].max() / 15))
