@@ -49,7 +49,8 @@ void kp_model_free(kp_model*);
  * = 1, the default, each earlier job is two substeps longer: 15 = 7 + 5 + 3) which resident waves pull from a FIFO, so that the
  * launch does not end on the tail of its longest envs; "queue_slots" (0 = CUs x 8, x 6 with objects); "queue_fence" (0/1, default 1: the job hand-over is an agent-scope
  * release / acquire fence pair around relaxed write-through accesses, correct by the HIP memory model; 0 = without the fences, +0.5 %);
- * "lpt_order" (0/1, default 0: longest-env-first workgroup order for the plain launch). */
+ * "lpt_order" (1 / 0 / -1 = default: on when free objects are simulated): longest-env-first order of the workgroups (plain launch) or of the
+ * envs' first jobs in the FIFO, from the previous control step's per-env cycles. */
 int kp_model_set_option(kp_model*, const char* name, double value);
 double kp_model_get_option(const kp_model*, const char* name);
 
@@ -219,8 +220,8 @@ int kp_sim_get(kp_sim*, int field, float* out);
 int kp_sim_diag(kp_sim*, int32_t* out_host);
 
 /* shader-clock cycles >> 10 every env took inside the last kp_sim_step_ctrl launch, uint32 [N], HOST pointer; synchronises.
- * With model option "lpt_order" = 1 (default 0) the next launch starts the envs longest-first from these (workgroup order
- * only: results do not depend on it; measured gain is within noise because an env's cost correlates only 0.6 step to step). */
+ * With model option "lpt_order" on (default: when free objects are simulated) the next launch starts the envs longest-first from these
+ * (launch / queue order only: results do not depend on it). */
 int kp_sim_launch_cost(kp_sim*, uint32_t* out_host);
 
 /* the job sizes kp_sim_step_ctrl uses for a control step of n_substeps when it schedules through the job queue (host arithmetic, no
@@ -242,6 +243,8 @@ double kp_sim_timing_mean_seconds(kp_sim*, int* n_launches);
  * {stable-PD, kinematics+bias, collision, constraint set-up, smooth solve, contact solve, integrate, total}.
  * Collected only if the environment variable KP_PROFILE=1 was set at kp_sim_create.  Synchronises. */
 int kp_sim_phase_cycles(kp_sim*, double* out8_host);
+/* the same per environment: out_host [N, 8] (the tail of a launch is a few environments, not the mean). */
+int kp_sim_phase_cycles_env(kp_sim*, double* out_host);
 
 const char* kp_last_error(void);
 const char* kp_version(void);

@@ -24,7 +24,7 @@ int fail(const std::string& m) { g_err = m; return -1; }
 
 struct kp_model {
     kp::HostModel h;
-    int contact = 1, limits = 1, stale = 1, solver_iter = 100, threads = 64, dynamic_objects = 1, lpt_order = 0, substeps_per_job = 3, queue_slots = 0, job_taper = 1, queue_fence = 1;
+    int contact = 1, limits = 1, stale = 1, solver_iter = 100, threads = 64, dynamic_objects = 1, lpt_order = -1, substeps_per_job = 3, queue_slots = 0, job_taper = 1, queue_fence = 1;
     int planemesh_max = 3; double planemesh_tol = 0.3;   // mjc_PlaneConvex's maxplanemesh / tolplanemesh (the blob's `planemesh`)
     double solver_tol = 1e-8, gravity_z = -9.81;   // solver_iter / solver_tol: mjOption.iterations / tolerance of the reference model (kp_model_load)
 };
@@ -226,10 +226,6 @@ int launch_step(kp_sim* s, const float* action, int nsub, const uint8_t* mask, b
     A.geoms = s->geoms; A.ngeom = s->ngeom; A.dbg_contacts = s->dbg_contacts;
     A.obj_slot = s->obj_slot; A.obj_qpos = s->obj_qpos; A.obj_qvel = s->obj_qvel; A.obj_warm = s->obj_warm;
     A.order = nullptr; A.cost = s->cost;
-    if (nsub > 0 && s->model->lpt_order) {      // longest env first: order the workgroups by the cycles of the previous control step
-        hipLaunchKernelGGL(kp::k_lpt_order, dim3(1), dim3(1024), 0, s->stream, s->n, s->cost, s->order);
-        A.order = s->order;
-    }
     const bool obj = s->has_objects;
     if (obj && s->model->threads != 64) return fail("object contact needs threads_per_env = 64");
     size_t lds = obj ? sizeof(kp::EnvLdsObj) : sizeof(kp::EnvLds);
@@ -248,6 +244,13 @@ int launch_step(kp_sim* s, const float* action, int nsub, const uint8_t* mask, b
         s->ring_used++;
     }
     if (time_it) HIP_OK(hipEventRecord(e0, s->stream));
+    // lpt_order: 1 on, 0 off, -1 (default) on when the scene's objects are simulated: an env whose hulls press on objects stays the launch's
+    // longest for many control steps, so starting it first shortens the launch (objects workload 7.21 -> 6.62 ms); floor-only costs are not
+    // predictable from step to step (correlation 0.25 .. 0.55) and gain nothing
+    if (nsub > 0 && (s->model->lpt_order > 0 || (s->model->lpt_order < 0 && s->has_objects))) {      // longest env first (inside the timed bracket): order the workgroups / the queue's first jobs by the cycles of the previous control step
+        hipLaunchKernelGGL(kp::k_lpt_order, dim3(1), dim3(1024), 0, s->stream, s->n, s->cost, s->order);
+        A.order = s->order;
+    }
 #define KP_LAUNCH(NT_) do { if (nsub > 0) hipLaunchKernelGGL((kp::kp_step_kernel<NT_, false>), dim3(s->n), dim3(NT_), lds, s->stream, A); \
                             else hipLaunchKernelGGL((kp::kp_forward_kernel<NT_, false>), dim3(s->n), dim3(NT_), lds, s->stream, A); } while (0)
     // more envs than resident wave slots: schedule the control step as jobs of substeps_per_job substeps pulled from a FIFO by one
@@ -265,13 +268,14 @@ int launch_step(kp_sim* s, const float* action, int nsub, const uint8_t* mask, b
             if (sum == nsub) { parts = np; std::copy(tmp, tmp + np, sizes); }
         }
     }
-    const bool queue = nsub > 0 && parts > 1 && s->model->threads == 64 && s->n > slots && s->n <= 0xFFFFFF && !s->prof && !A.order;   // env ids take 24 bits of a queue entry
+    const bool queue = nsub > 0 && parts > 1 && s->model->threads == 64 && s->n > slots && s->n <= 0xFFFFFF && !s->prof;   // env ids take 24 bits of a queue entry
     A.jobq = s->jobq; A.jobctr = s->jobctr; A.n_parts = queue ? parts : 1; A.queue_fence = s->model->queue_fence;
     A.part_sub_lo = A.part_sub_hi = 0;
     for (int k = 0; queue && k < parts; k++) (k < 8 ? A.part_sub_lo : A.part_sub_hi) |= (unsigned long long)(sizes[k] & 255) << (8 * (k & 7));
     if (queue) {
         const unsigned total = (unsigned)s->n * (unsigned)parts;
-        hipLaunchKernelGGL(kp::k_queue_init, dim3((total + 255) / 256), dim3(256), 0, s->stream, s->n, total, s->jobq, s->jobctr);   // inside the timed bracket
+        hipLaunchKernelGGL(kp::k_queue_init, dim3((total + 255) / 256), dim3(256), 0, s->stream, s->n, total, s->jobq, s->jobctr, A.order);   // inside the timed bracket
+        A.order = nullptr;                                              // the queue kernel addresses envs by their queue entry
         if (obj) hipLaunchKernelGGL((kp::kp_step_queue_kernel<true>), dim3(slots), dim3(64), lds, s->stream, A);
         else hipLaunchKernelGGL((kp::kp_step_queue_kernel<false>), dim3(slots), dim3(64), lds, s->stream, A);
     } else
@@ -325,7 +329,7 @@ int kp_model_set_option(kp_model* m, const char* name, double v) {
     else if (k == "dynamic_objects") m->dynamic_objects = v != 0;
     else if (k == "planemesh_max") { if (v < 1 || v > 8) return fail("planemesh_max must be 1 .. 8"); m->planemesh_max = (int)v; }
     else if (k == "planemesh_tol") { if (v < 0) return fail("planemesh_tol must be >= 0"); m->planemesh_tol = v; }
-    else if (k == "lpt_order") m->lpt_order = v != 0;
+    else if (k == "lpt_order") m->lpt_order = v < 0 ? -1 : (v != 0);
     else if (k == "job_taper") m->job_taper = v != 0;
     else if (k == "queue_fence") m->queue_fence = v != 0;
     else if (k == "queue_slots") { if (v < 0) return fail("queue_slots must be >= 0 (0 = resident wave slots of the device)"); m->queue_slots = (int)v; }
@@ -767,6 +771,17 @@ int kp_sim_phase_cycles(kp_sim* s, double* out) {
     std::vector<unsigned long long> h((size_t)s->n * 8);
     HIP_OK(hipMemcpy(h.data(), s->prof, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
     for (int k = 0; k < 8; k++) { double acc = 0; for (int e = 0; e < s->n; e++) acc += (double)h[(size_t)e * 8 + k]; out[k] = acc / s->n; }
+    return 0;
+}
+
+int kp_sim_phase_cycles_env(kp_sim* s, double* out) {
+    if (!s || !out) return fail("kp_sim_phase_cycles_env: null argument");
+    if (!s->prof) return fail("kp_sim_phase_cycles_env: create the simulator with KP_PROFILE=1");
+    HIP_OK(hipSetDevice(s->device));
+    HIP_OK(hipStreamSynchronize(s->stream));
+    std::vector<unsigned long long> h((size_t)s->n * 8);
+    HIP_OK(hipMemcpy(h.data(), s->prof, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < h.size(); i++) out[i] = (double)h[i];
     return 0;
 }
 

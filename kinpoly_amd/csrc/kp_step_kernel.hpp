@@ -2094,9 +2094,11 @@ __global__ __launch_bounds__(64, 2) void kp_step_queue_kernel(StepArgs A) {
     }
 }
 
-__global__ void k_queue_init(int n_envs, unsigned total, unsigned* __restrict__ jobq, unsigned* __restrict__ jobctr) {
+// order (optional): the envs' first jobs enter the FIFO longest-env-first (k_lpt_order on the previous control step's cycles) instead of in
+// env order, so that the env whose three jobs take longest does not also start last
+__global__ void k_queue_init(int n_envs, unsigned total, unsigned* __restrict__ jobq, unsigned* __restrict__ jobctr, const int* __restrict__ order) {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < total) jobq[i] = i < (unsigned)n_envs ? i : 0xFFFFFFFFu;
+    if (i < total) jobq[i] = i < (unsigned)n_envs ? (order ? (unsigned)order[i] : i) : 0xFFFFFFFFu;
     if (i == 0) { jobctr[0] = 0u; jobctr[1] = (unsigned)n_envs; }
 }
 

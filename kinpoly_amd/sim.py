@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "kp_sim_step_begin", "kp_sim_obs_ar", "kp_sim_term_reward", "kp_gae", "kp_sim_set_full_state", "kp_sim_fk",
     "kp_sim_timing_reset", "kp_sim_timing_mean_seconds", "kp_sim_phase_cycles", "kp_sim_set_objects", "kp_sim_set_obj_state",
     "kp_sim_launch_cost", "kp_job_schedule", "kp_sim_fk_backward", "kp_sim_set_stream", "kp_sim_status_device", "kp_sim_mass_matrix",
-    "kp_sim_contacts", "kp_gae_bootstrap", "kp_gru_gates_forward", "kp_gru_gates_backward",
+    "kp_sim_contacts", "kp_gae_bootstrap", "kp_gru_gates_forward", "kp_gru_gates_backward", "kp_sim_phase_cycles_env",
 ]
 
 
@@ -97,6 +97,7 @@ def load_library(path: str | None = None):
     L.kp_sim_timing_reset.argtypes = [P]; L.kp_sim_timing_reset.restype = C.c_int
     L.kp_sim_timing_mean_seconds.argtypes = [P, C.POINTER(C.c_int)]; L.kp_sim_timing_mean_seconds.restype = C.c_double
     L.kp_sim_phase_cycles.argtypes = [P, C.POINTER(C.c_double)]; L.kp_sim_phase_cycles.restype = C.c_int
+    L.kp_sim_phase_cycles_env.argtypes = [P, C.c_void_p]; L.kp_sim_phase_cycles_env.restype = C.c_int
     L.kp_job_schedule.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]; L.kp_job_schedule.restype = C.c_int
     L.kp_sim_launch_cost.argtypes = [P, C.c_void_p]; L.kp_sim_launch_cost.restype = C.c_int
     L.kp_sim_set_objects.argtypes = [P, F, U8]; L.kp_sim_set_objects.restype = C.c_int
@@ -327,6 +328,13 @@ class KpSim:
         out = (C.c_double * 8)()
         _check(self.L.kp_sim_phase_cycles(self.h, out), "kp_sim_phase_cycles")
         return dict(zip(("spd", "kin_bias", "collide", "constraint", "smooth", "contact", "integrate", "total"), list(out)))
+
+    def phase_cycles_env(self):
+        """per-env shader-clock cycles of the last control step's phases, numpy [N, 8] (KP_PROFILE=1)."""
+        import numpy as np
+        out = np.zeros((self.n, 8), np.float64)
+        _check(self.L.kp_sim_phase_cycles_env(self.h, out.ctypes.data_as(C.c_void_p)), "kp_sim_phase_cycles_env")
+        return out
 
     def launch_cost(self):
         """shader-clock cycles every env took in the last control-step launch (numpy uint64 [N])."""

@@ -49,29 +49,37 @@ for e in range(n):
     scenes.append(objs)
 action = rng.normal(size=(n, 75)) * 0.2
 dev = lambda x: torch.tensor(x, dtype=torch.float32, device="cuda")  # noqa: E731
-sim = KpSim(KpModel(STEP_KPM), n)
+_pm = [float(x) for x in os.environ['KP_PLANEMESH'].split(',')] if 'KP_PLANEMESH' in os.environ else None      # (maxplanemesh, tolplanemesh) on both sides
+sim = KpSim(KpModel(STEP_KPM, **({'planemesh_max': _pm[0], 'planemesh_tol': _pm[1]} if _pm else {})), n)
+# both sides get the SAME inputs: what the device holds after the fp32 conversion (the oracle used to get the unrounded doubles)
+r32 = lambda x: np.asarray(x, np.float32).astype(np.float64)  # noqa: E731
+blk, qpos, qvel, action = r32(blk), r32(qpos), r32(qvel), r32(action)
+scenes = [{oi: list(blk[e, 7 * oi: 7 * oi + 7]) for oi in sc} for e, sc in enumerate(scenes)]
 sim.set_objects(dev(blk)); sim.set_state(dev(qpos), dev(qvel)); sim.set_target(dev(qpos))
 a_t = dev(action)
 maxc = np.zeros(n, int); its = np.zeros(n, int)
+traj_h, traj_o = [], []
 for _ in range(nstep):
     sim.step_ctrl(a_t, 15)
     dg = sim.diag(); maxc = np.maximum(maxc, dg[:, 3] & 255); its += dg[:, 1]
     assert dg[:, 2].max() == 0, "non-finite state"
-got = sim.get("qpos").double().cpu().numpy(); gobj = sim.get("obj_qpos").double().cpu().numpy()
-eh, eo = [], []
+    traj_h.append(sim.get("qpos").double().cpu().numpy()); traj_o.append(sim.get("obj_qpos").double().cpu().numpy())
+eh, eo = np.zeros((nstep, n)), np.zeros((nstep, n))
 for e in range(n):
-    o = OracleSim(kpm=STEP_KPM)
+    o = OracleSim(kpm=STEP_KPM, planemesh=_pm)
     for slot, oi in enumerate(sorted(scenes[e])):
         o.set_object(slot, kpm, oi, scenes[e][oi])
     o.reset(qpos[e], qvel[e])
-    for _ in range(nstep):
+    for t in range(nstep):
         o.do_simulation(action[e], qpos[e], 15)
-    eh.append(np.abs(o.get("qpos") - got[e]).max())
-    eo.append(max(np.abs(o.get_object(slot)[0] - gobj[e, 7 * oi: 7 * oi + 7]).max() for slot, oi in enumerate(sorted(scenes[e]))))
-eh, eo = np.array(eh), np.array(eo)
-print(f"{n} scenes x {nstep} control steps (seed {seed}): humanoid |dqpos| median {np.median(eh):.2e} p90 {np.quantile(eh, .9):.2e} max {eh.max():.2e}; "
-      f"objects median {np.median(eo):.2e} p90 {np.quantile(eo, .9):.2e} max {eo.max():.2e}; contacts max {maxc.max()} mean {maxc.mean():.1f}; "
-      f"newton it/substep {its.mean() / 15 / nstep:.2f}; scenes above 1e-4: {int(((eh > 1e-4) | (eo > 1e-4)).sum())}")
-worst = np.argsort(-np.maximum(eh, eo))[:5]
+        eh[t, e] = np.abs(o.get("qpos") - traj_h[t][e]).max()
+        eo[t, e] = max(np.abs(o.get_object(slot)[0] - traj_o[t][e, 7 * oi: 7 * oi + 7]).max() for slot, oi in enumerate(sorted(scenes[e])))
+step1 = np.maximum(eh[0], eo[0])
+ehl, eol = eh[-1], eo[-1]
+print(f"{n} scenes x {nstep} control steps (seed {seed}): humanoid |dqpos| median {np.median(ehl):.2e} p90 {np.quantile(ehl, .9):.2e} max {ehl.max():.2e}; "
+      f"objects median {np.median(eol):.2e} p90 {np.quantile(eol, .9):.2e} max {eol.max():.2e}; contacts max {maxc.max()} mean {maxc.mean():.1f}; "
+      f"newton it/substep {its.mean() / 15 / nstep:.2f}; scenes above 1e-4: {int(((ehl > 1e-4) | (eol > 1e-4)).sum())}; "
+      f"after the FIRST control step: median {np.median(step1):.2e} max {step1.max():.2e}, above 1e-4: {int((step1 > 1e-4).sum())}, above 1e-3: {int((step1 > 1e-3).sum())}")
+worst = np.argsort(-np.maximum(ehl, eol))[:5]
 for e in worst:
-    print(f"  scene {e}: objects {sorted(scenes[e])} err humanoid {eh[e]:.2e} object {eo[e]:.2e} contacts {maxc[e]}")
+    print(f"  scene {e}: objects {sorted(scenes[e])} err per control step humanoid {['%.1e' % x for x in eh[:, e]]} object {['%.1e' % x for x in eo[:, e]]} contacts {maxc[e]}")
