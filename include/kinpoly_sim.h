@@ -41,7 +41,8 @@ typedef struct kp_sim kp_sim;
  * kinpoly_amd/model_compiler.py compiles from the same XML + STL hulls + uhc.yml gains. */
 kp_model* kp_model_load(const char* kpm_path);
 void kp_model_free(kp_model*);
-/* options: "contact" (0/1), "limits" (0/1), "gravity_z", "stale_kinematics" (0/1, default 1: SPD and
+/* options: "contact" (0/1), "limits" (0/1), "gravity_z" ("gravity_x", "gravity_y": mjOption.gravity, 0 in the reference's XML; tilted-plane tests),
+ * "actuation" (0/1, default 1; 0: ctrl = qfrc_applied = 0, i.e. do_simulation without compute_torque / rfc: torque-free motion for tests), "stale_kinematics" (0/1, default 1: SPD and
  * read-outs see the one-substep-stale derived quantities mujoco-py exposes), "solver_iter" (default: the blob's
  * mjOption.iterations = 100; cap hits are counted in kp_sim_diag), "solver_tol", "threads_per_env" (64/128/256), "dynamic_objects" (0/1);
  * scheduling only (results do not depend on them): "substeps_per_job" (default 3; 0 = one workgroup per env and control step):

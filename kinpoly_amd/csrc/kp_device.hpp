@@ -45,7 +45,7 @@ struct Params {
     float rfc_scale, rfc_lim;
     float br_inv[4];                            // inverse(base_rot) as the reference computes it (conj / |q|^2)
     float tol;
-    int max_iter, contact, limits, stale;
+    int max_iter, contact, limits, stale, actuation;
 };
 
 // ------------------------------------------------------------------ LDS layout: 18 128 B (15 allocation granules of 1 280 B; 8 envs per CU)

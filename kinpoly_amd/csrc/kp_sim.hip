@@ -26,7 +26,8 @@ struct kp_model {
     kp::HostModel h;
     int contact = 1, limits = 1, stale = 1, solver_iter = 100, threads = 64, dynamic_objects = 1, lpt_order = -1, substeps_per_job = 3, queue_slots = 0, job_taper = 1, queue_fence = 1;
     int planemesh_max = 3; double planemesh_tol = 0.3;   // mjc_PlaneConvex's maxplanemesh / tolplanemesh (the blob's `planemesh`)
-    double solver_tol = 1e-8, gravity_z = -9.81;   // solver_iter / solver_tol: mjOption.iterations / tolerance of the reference model (kp_model_load)
+    int actuation = 1;            // 0: no stable-PD torque, no residual force (ctrl = qfrc_applied = 0): torque-free flight for the energy test
+    double solver_tol = 1e-8, gravity_z = -9.81, gravity_x = 0.0, gravity_y = 0.0;   // solver_iter / solver_tol: mjOption.iterations / tolerance of the reference model (kp_model_load)
 };
 
 struct kp_sim {
@@ -183,7 +184,7 @@ bool build_tables(kp_sim* s) {
     auto& P = s->P;
     const auto& o = m.opt;
     auto clampimp = [](double v) { return std::min(0.9999, std::max(0.0001, v)); };
-    P.h = (float)o[OPT_TIMESTEP]; P.gx = (float)o[OPT_GX]; P.gy = (float)o[OPT_GY]; P.gz = (float)s->model->gravity_z;
+    P.h = (float)o[OPT_TIMESTEP]; P.gx = (float)s->model->gravity_x; P.gy = (float)s->model->gravity_y; P.gz = (float)s->model->gravity_z;
     double tc = std::max(o[OPT_SOLREF_TC], 2 * o[OPT_TIMESTEP]), dr = o[OPT_SOLREF_DR], dmax = clampimp(o[OPT_IMP_DW]);
     P.K = (float)(1.0 / (dmax * dmax * tc * tc * dr * dr)); P.B = (float)(2.0 / (dmax * tc));
     P.imp_d0 = (float)clampimp(o[OPT_IMP_D0]); P.imp_dw = (float)dmax; P.imp_w = (float)o[OPT_IMP_W];
@@ -197,7 +198,7 @@ bool build_tables(kp_sim* s) {
     P.br_inv[0] = (float)(o[OPT_BR_W] / bn); P.br_inv[1] = (float)(-o[OPT_BR_X] / bn);
     P.br_inv[2] = (float)(-o[OPT_BR_Y] / bn); P.br_inv[3] = (float)(-o[OPT_BR_Z] / bn);
     P.tol = (float)s->model->solver_tol; P.max_iter = s->model->solver_iter;
-    P.contact = s->model->contact; P.limits = s->model->limits; P.stale = s->model->stale;
+    P.contact = s->model->contact; P.limits = s->model->limits; P.stale = s->model->stale; P.actuation = s->model->actuation;
     return ok;
 }
 
@@ -308,7 +309,7 @@ const char* kp_version(void) { return "kinpoly_sim 0.1 (gfx950)"; }
 kp_model* kp_model_load(const char* path) {
     kp_model* m = new kp_model();
     if (!kp::load_kpm(path, m->h)) { fail("kp_model_load: " + m->h.error); delete m; return nullptr; }
-    m->gravity_z = m->h.opt[kp::OPT_GZ];
+    m->gravity_z = m->h.opt[kp::OPT_GZ]; m->gravity_x = m->h.opt[kp::OPT_GX]; m->gravity_y = m->h.opt[kp::OPT_GY];
     m->solver_tol = m->h.opt[kp::OPT_SOLVER_TOL];
     m->solver_iter = (int)m->h.opt[kp::OPT_SOLVER_ITER];      // 100: MuJoCo's default, which the reference never overrides
     if (m->solver_iter < 1) m->solver_iter = 100;
@@ -323,6 +324,9 @@ int kp_model_set_option(kp_model* m, const char* name, double v) {
     if (k == "contact") m->contact = v != 0;
     else if (k == "limits") m->limits = v != 0;
     else if (k == "gravity_z") m->gravity_z = v;
+    else if (k == "gravity_x") m->gravity_x = v;
+    else if (k == "gravity_y") m->gravity_y = v;
+    else if (k == "actuation") m->actuation = v != 0;
     else if (k == "stale_kinematics") m->stale = v != 0;
     else if (k == "solver_iter") m->solver_iter = (int)v;
     else if (k == "solver_tol") m->solver_tol = v;
@@ -344,6 +348,9 @@ double kp_model_get_option(const kp_model* m, const char* name) {
     if (k == "contact") return m->contact;
     if (k == "limits") return m->limits;
     if (k == "gravity_z") return m->gravity_z;
+    if (k == "gravity_x") return m->gravity_x;
+    if (k == "gravity_y") return m->gravity_y;
+    if (k == "actuation") return m->actuation;
     if (k == "stale_kinematics") return m->stale;
     if (k == "solver_iter") return m->solver_iter;
     if (k == "solver_tol") return m->solver_tol;

@@ -1868,7 +1868,11 @@ __device__ __forceinline__ void step_body(StepArgs A, const int env_in, const in
         if (prof && sub == 0) tstart = __builtin_readcyclecounter();
         if (prof) t0 = __builtin_readcyclecounter();
         // stale mode: the controller sees M / bias of the previous forward pass (cinert, cdof, bias still in LDS)
-        if (substep && P.stale) { Lane8 La; La.init(kp_launder(tid), T.sched8); spd_torque_rfc<NT, OBJ>(s, T, P, La, tid, tq_row, act_row); }
+        if (substep && P.stale && P.actuation) { Lane8 La; La.init(kp_launder(tid), T.sched8); spd_torque_rfc<NT, OBJ>(s, T, P, La, tid, tq_row, act_row); }
+        if (substep && !P.actuation) {              // model option "actuation" = 0: ctrl = qfrc_applied = 0 (torque-free motion; tests)
+            for (int i = tid; i < 78; i += NT) s.applied[i] = 0.f;          // applied[6] ++ ctrl[72]
+            KP_SYNC();
+        }
         KP_T(0)
         // ---- mj_forward at the current state
         if (sub >= 0) {
@@ -1908,7 +1912,7 @@ __device__ __forceinline__ void step_body(StepArgs A, const int env_in, const in
         KP_T(2)
         make_constraint<NT, OBJ>(s, T, P, tid);                 // needs sv = cvel: before any aba_solve
         KP_T(3)
-        if (!P.stale) { Lane8 La; La.init(kp_launder(tid), T.sched8); spd_torque_rfc<NT, OBJ>(s, T, P, La, tid, tq_row, act_row); }
+        if (!P.stale && P.actuation) { Lane8 La; La.init(kp_launder(tid), T.sched8); spd_torque_rfc<NT, OBJ>(s, T, P, La, tid, tq_row, act_row); }
         for (int i = tid; i < D_NV; i += NT) s.extra[i] = 0.f;
         KP_SYNC();
         // qacc_smooth = M^-1 qfrc_smooth; sv = its spatial accelerations; Mv/mres = those of (warm start - qacc_smooth) for the Newton solve

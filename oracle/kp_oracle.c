@@ -243,6 +243,7 @@ kpo_model *kpo_model_load(const char *path) {
 void kpo_model_free(kpo_model *m) { if (m) { free(m->verts); free(m->vert_nbr_adr); free(m->vert_nbr); free(m); } }
 void kpo_model_set_flags(kpo_model *m, int contact, int limits) { m->enable_contact = contact; m->enable_limits = limits; }
 void kpo_model_set_gravity(kpo_model *m, double gz) { m->gravity[2] = gz; }
+void kpo_model_set_gravity3(kpo_model *m, double gx, double gy, double gz) { m->gravity[0] = gx; m->gravity[1] = gy; m->gravity[2] = gz; }
 void kpo_model_set_ls_exact(kpo_model *m, int exact) { m->ls_exact = exact; }
 void kpo_model_set_planemesh(kpo_model *m, int maxcon, double tol) { m->planemesh_max = maxcon; m->planemesh_tol = tol; }
 kpo_data *kpo_data_new(void) { return calloc(1, sizeof(kpo_data)); }
@@ -852,8 +853,12 @@ void kpo_compute_torque(const kpo_model *m, const kpo_data *d, const double *ctr
     double k_p[NV_MAX] = {0}, k_d[NV_MAX] = {0}, qpos_err[NV_MAX] = {0}, qvel_err[NV_MAX], q_accel[NV_MAX];
     for (int j = 0; j < nu; j++) {
         double base = target_qpos[7 + j], q = d->qpos[7 + j];
-        while (base - q > M_PI) base -= 2 * M_PI;
-        while (base - q < -M_PI) base += 2 * M_PI;
+        /* the reference's unwrap loops (humanoid_im.py:447-452); a state that has blown up (|base - q| beyond 1e6, where subtracting
+         * 2 pi no longer changes a double's neighbourhood) would spin them forever: such a state is garbage either way, leave it */
+        if (fabs(base - q) < 1e6) {
+            while (base - q > M_PI) base -= 2 * M_PI;
+            while (base - q < -M_PI) base += 2 * M_PI;
+        }
         double target = base + ctrl[j] * m->a_scale[j];
         k_p[6 + j] = m->kp[j]; k_d[6 + j] = m->kd[j];
         qpos_err[6 + j] = q + d->qvel[6 + j] * dt - target;

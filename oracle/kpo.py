@@ -37,6 +37,7 @@ def lib():
         L.kpo_model_free.argtypes = [P]
         L.kpo_model_set_flags.argtypes = [P, C.c_int, C.c_int]
         L.kpo_model_set_gravity.argtypes = [P, C.c_double]
+        L.kpo_model_set_gravity3.argtypes = [P, C.c_double, C.c_double, C.c_double]
         L.kpo_model_set_ls_exact.argtypes = [P, C.c_int]
         L.kpo_model_set_planemesh.argtypes = [P, C.c_int, C.c_double]
         L.kpo_data_new.restype = P
@@ -92,8 +93,11 @@ class OracleSim:
         self.m = L.kpo_model_load(kpm.encode())
         assert self.m, f"cannot load {kpm}"
         L.kpo_model_set_flags(self.m, int(contact), int(limits))
-        if gravity is not None:
-            L.kpo_model_set_gravity(self.m, float(gravity))
+        if gravity is not None:                              # scalar: gravity z; 3-vector: the whole mjOption.gravity (tilted-plane tests)
+            if np.ndim(gravity) == 0:
+                L.kpo_model_set_gravity(self.m, float(gravity))
+            else:
+                L.kpo_model_set_gravity3(self.m, float(gravity[0]), float(gravity[1]), float(gravity[2]))
         L.kpo_model_set_ls_exact(self.m, int(ls_exact))     # default: MuJoCo's PrimalSearch; True: the exact minimiser (as the HIP kernel)
         if planemesh is not None:                           # (maxplanemesh, tolplanemesh) of mjc_PlaneConvex; default: the blob's (3, 0.3)
             L.kpo_model_set_planemesh(self.m, int(planemesh[0]), float(planemesh[1]))

@@ -6,6 +6,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+if os.path.join(ROOT, "tests") not in sys.path:          # tests/known_answers.py (closed forms shared by the CPU and GPU tests)
+    sys.path.insert(1, os.path.join(ROOT, "tests"))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 

@@ -74,3 +74,114 @@ def test_plane_mesh_rule_options_match_oracle(pm):
         o.do_simulation(a32[e], q32[e], 1)
         assert np.abs(o.get("qpos") - got[e]).max() < 5e-6
     assert total > 0
+
+
+# ------------------------------------------------------------------ known answers of MuJoCo's documented model on the device (tests/known_answers.py; the
+# oracle's twins are in tests/test_physics_oracle.py).  Reference call site: sim.step(), uhc/envs/humanoid_im.py:527.
+def _box_alone_sim(n, z, **model_options):
+    import known_answers as K
+    from kinpoly_amd.sim import STEP_KPM, KpModel, KpSim
+    sim = KpSim(KpModel(STEP_KPM, **model_options), n, 0)
+    blk = np.zeros((n, 35))
+    for i in range(5):
+        blk[:, 7 * i: 7 * i + 3] = [(i + 1) * 100, 100, 0]
+    blk[:, 28:35] = [0.0, 0.0, z, 1, 0, 0, 0]
+    q = np.tile(STD["qpos"], (n, 1)); q[:, 0] += 30
+    dev = lambda a: torch.tensor(a, dtype=torch.float32, device=sim.device)      # noqa: E731
+    sim.set_objects(dev(blk)); sim.set_state(dev(q), dev(np.zeros((n, 75)))); sim.set_target(dev(q))
+    return sim, dev(np.zeros((n, 75))), K
+
+
+def test_known_answer_drop_on_the_device():
+    """(i) the flat box dropped from 2 mm above the contact margin follows the scalar soft-contact recurrence written from MuJoCo's documented
+    model (k, b, solimp impedance, pyramidal row weights, semi-implicit Euler): every substep for 600 substeps, fp32 against the fp64 recurrence."""
+    import known_answers as K
+    z0 = float(np.float32(K.box_origin_height(K.MARGIN + 0.002)))
+    sim, act, _ = _box_alone_sim(2, z0)
+    zs = []
+    for _ in range(600):
+        sim.step_ctrl(act, 1)
+        zs.append(float(sim.get("obj_qpos")[0, 30]))
+    ref = K.drop_recurrence(z0, 600)
+    assert np.abs(np.array(zs) - ref).max() < 2e-6               # ulp of z = 0.37 in fp32 is 3e-8; the trajectory spans 3 mm
+    rest = K.box_origin_height(K.MARGIN) - np.array(zs)[-1]
+    assert rest == pytest.approx(K.box_origin_height(K.MARGIN) - ref[-1], abs=3e-7) and int(sim.diag()[:, 2].max()) == 0
+
+
+def test_known_answer_friction_on_the_device():
+    """(ii) + (v): creep velocity inside the pyramid = m g sin(theta) / sum_c 2 mu^2 D_c b along the contact frame's axes (t1 = y, t2 = -x for
+    the plane's normal z: mju_makeFrame) and along their diagonal; at tan(theta) = 0.9 the box holds along both axes and runs away along
+    the diagonal (pyramid: limit mu on an axis, mu / sqrt 2 between them); at 1.3 it runs away along an axis."""
+    import known_answers as K
+    z_rest = K.box_origin_height(0.00089)
+    s2 = np.sqrt(0.5)
+
+    def run(u, tan):
+        th = np.arctan(tan)
+        sim, act, _ = _box_alone_sim(2, z_rest, gravity_x=K.G * np.sin(th) * u[0], gravity_y=K.G * np.sin(th) * u[1], gravity_z=-K.G * np.cos(th))
+        sim.record_contacts()
+        sim.step_ctrl(act, 270)
+        v = sim.get("obj_qvel")[0, 24:30].double().cpu().numpy()
+        c = sim.contacts()[0]
+        return v[0] * u[0] + v[1] * u[1], c["dist"][c["body"] == 24], th
+    for u in ((1.0, 0.0), (0.0, 1.0), (s2, s2)):
+        v, dists, th = run(u, 0.3)
+        assert len(dists) == 4
+        assert v == pytest.approx(K.creep_velocity(K.BOX_MASS * K.G * np.sin(th), dists), rel=2e-3)
+    hold_x, hold_y, slide_d, slide_x = run((1.0, 0.0), 0.9)[0], run((0.0, 1.0), 0.9)[0], run((s2, s2), 0.9)[0], run((1.0, 0.0), 1.3)[0]
+    assert 0 < hold_x < 0.02 and 0 < hold_y < 0.02 and slide_d > 0.5 and slide_x > 0.5
+
+
+@pytest.mark.parametrize("j", [6, 50])
+def test_known_answer_hinge_limit_on_the_device(j):
+    """(iii) a hinge pushed past +180 degrees by its saturated actuator settles at |r| = torque_lim (1 - dmax) invweight0 / (k dmax^2)."""
+    import known_answers as K
+    from kinpoly_amd.model_compiler import DEFAULT_KPM, read_kpm
+    from kinpoly_amd.sim import KpModel, KpSim
+    kpm = read_kpm(DEFAULT_KPM)
+    sim = KpSim(KpModel(contact=0, gravity_z=0.0), 4, 0)
+    q = np.tile(STD["qpos"], (4, 1)); q[:, 2] += 2.0; q[:, 7 + j] = 3.0
+    act = np.zeros((4, 75)); act[:, j] = 6.0
+    dev = lambda a: torch.tensor(a, dtype=torch.float32, device=sim.device)      # noqa: E731
+    sim.set_state(dev(q), dev(np.zeros((4, 75)))); sim.set_target(dev(q))
+    a = dev(act)
+    for _ in range(60):
+        sim.step_ctrl(a, 15)
+    pred = K.limit_penetration(kpm["torque_lim"][j], kpm["dof_invweight0"][6 + j])
+    got = sim.get("qpos")[:, 7 + j].double().cpu().numpy() - np.pi
+    assert got == pytest.approx(pred, rel=1e-3) and float(sim.get("qvel").abs().max()) < 0.05
+
+
+def test_known_answer_free_flight_energy_on_the_device():
+    """(iv) BASELINE configs[1], torque-free (model option actuation = 0), 1500 substeps on 64 envs: total energy (computed in fp64 from the
+    device's states with the oracle's mass matrix as the calculator) drifts by the symplectic Euler's closed form -1/2 m g^2 h^2 per
+    substep for the falling centre of mass; the internal energy stays bounded."""
+    from kinpoly_amd.model_compiler import DEFAULT_KPM, read_kpm
+    from kinpoly_amd.sim import KpModel, KpSim
+    from oracle.kpo import OracleSim
+    kpm = read_kpm(DEFAULT_KPM)
+    mass, h = kpm["body_mass"], float(kpm["opt"][0])
+    n = 64
+    rng = np.random.default_rng(5)
+    q = np.tile(STD["qpos"], (n, 1)); q[:, 2] += 10; q[:, 7:] += rng.normal(size=(n, 69)) * 0.2
+    v = np.concatenate([rng.normal(size=(n, 3)), rng.normal(size=(n, 72)) * 0.5], 1)
+    sim = KpSim(KpModel(contact=0, limits=0, actuation=0), n, 0)
+    dev = lambda a: torch.tensor(a, dtype=torch.float32, device=sim.device)      # noqa: E731
+    sim.set_state(dev(q), dev(v)); sim.set_target(dev(q))
+    q0, v0 = sim.get("qpos").double().cpu().numpy(), sim.get("qvel").double().cpu().numpy()
+    act = dev(np.zeros((n, 75)))
+    for _ in range(100):
+        sim.step_ctrl(act, 15)
+    q1, v1 = sim.get("qpos").double().cpu().numpy(), sim.get("qvel").double().cpu().numpy()
+    o = OracleSim(contact=False, limits=False)
+
+    def energy(qq, vv):
+        o.set_state_raw(qq, vv); o.forward()
+        xi = o.get("xipos").reshape(24, 3)
+        pe = 9.81 * float((mass * xi[:, 2]).sum())
+        return 0.5 * vv @ o.fullM() @ vv + pe, pe
+    closed = -0.5 * mass.sum() * 9.81 ** 2 * h * h * 1500
+    for e in range(0, n, 7):
+        (e0, pe0), (e1, _) = energy(q0[e], v0[e]), energy(q1[e], v1[e])
+        assert abs((e1 - e0) - closed) < 0.05 * (e0 - pe0) + 0.05, (e, e1 - e0, closed)
+    assert int(sim.diag()[:, 2].max()) == 0

@@ -291,3 +291,149 @@ def test_resting_box_sinks_to_the_closed_form_depth_of_the_soft_contact_model():
     bq, bv = o.get_object(0)
     assert np.abs(bv).max() < 1e-6                                 # at rest
     np.testing.assert_allclose(c["dist"][mine], r_star + margin, rtol=2e-4)
+
+
+# ------------------------------------------------------------------ known answers of MuJoCo's documented model (tests/known_answers.py); the
+# HIP kernel's twins are in tests/test_gpu_round3.py.  Call site of everything below in the reference: sim.step(), uhc/envs/humanoid_im.py:527.
+def _box_alone(z, gravity=None):
+    """the free step box on the plane, the humanoid parked 30 m away and 50 m up (it free-falls for the length of these tests)"""
+    import known_answers as K
+    from kinpoly_amd.model_compiler import STEP_KPM
+    o = OracleSim(kpm=STEP_KPM, gravity=gravity)
+    o.set_object(0, K.KPM, K.STEP_OBJ, [0.0, 0.0, z, 1, 0, 0, 0])
+    q = STD["qpos"].copy(); q[0] += 30; q[2] += 50
+    o.reset(q, np.zeros(75))
+    return o
+
+
+def test_known_answer_drop_follows_the_scalar_soft_contact_recurrence():
+    """(i) computation.html 'Soft constraint model' + modeling.html 'solref / solimp': a flat box dropped from 2 mm above the contact margin.
+    Reference acceleration aref = -b v - k d(r) r with k = 1 / (dmax^2 tc^2 dr^2), b = 2 / (dmax tc), tc = max(solref[0], 2 h); impedance
+    d(r) by the solimp sigmoid; pyramidal row regulariser R = (1 - d) / d (1 + mu^2) invweight0, weight 1 / (2 mu^2 R), sixteen rows that
+    all see a_z - aref; semi-implicit Euler.  The scalar recurrence written from those statements (known_answers.drop_recurrence) is the
+    oracle's trajectory substep by substep: free fall, impact, the critically damped approach to the resting depth."""
+    import known_answers as K
+    z0 = K.box_origin_height(K.MARGIN + 0.002)
+    o = _box_alone(z0)
+    zs = []
+    for _ in range(600):
+        o.step()
+        zs.append(o.get_object(0)[0][2])
+    ref = K.drop_recurrence(z0, 600)
+    assert np.abs(np.array(zs) - ref).max() < 1e-12
+    depth = K.box_origin_height(K.MARGIN) - ref            # penetration of the margin
+    assert depth.max() > 1.1e-3 and abs(depth[-1] - depth[-50]) < 1e-12 and 0.05e-3 < depth[-1] < 0.2e-3     # overshoot on impact, then rest
+    # critically damped: after the impact the depth approaches its resting value from one side, without ringing
+    k0 = int(np.argmax(depth))
+    tail = depth[k0 + 40:] - depth[-1]
+    assert (tail > -1e-9).all() and (np.diff(tail) < 1e-12).all()
+
+
+def test_known_answer_friction_creep_and_pyramid_cone_limits():
+    """(ii) computation.html 'Friction cones' (pyramidal): gravity tilted by theta puts the tangential load m g sin(theta) on the box.
+    Inside the pyramid the load is carried by the (n + mu t, n - mu t) row pair of every contact, whose force difference is the viscous
+    -2 mu^2 D b v_t: the box creeps at v = m g sin(theta) / sum_c 2 mu^2 D_c b (closed form; D_c from each contact's depth) -- along the
+    frame axes t1 = y, t2 = -x and along their diagonal alike.  The cone itself is the pyramid: at tan(theta) = 0.9 (mu = 1) the box holds
+    along the axes (limit mu) and runs away along the diagonal (limit mu / sqrt 2); at tan(theta) = 1.3 it runs away along an axis too."""
+    import known_answers as K
+    z_rest = K.box_origin_height(0.00089)
+    s2 = np.sqrt(0.5)
+
+    def run(u, tan):
+        th = np.arctan(tan)
+        o = _box_alone(z_rest, gravity=[K.G * np.sin(th) * u[0], K.G * np.sin(th) * u[1], -K.G * np.cos(th)])
+        for _ in range(270):
+            o.step()
+        v = o.get_object(0)[1]
+        o.forward()
+        c = o.contacts_full()
+        return v[0] * u[0] + v[1] * u[1], c["dist"][c["body"] == 24], th
+    for u in ((1.0, 0.0), (0.0, 1.0), (s2, s2)):
+        v, dists, th = run(u, 0.3)
+        assert len(dists) == 4
+        assert v == pytest.approx(K.creep_velocity(K.BOX_MASS * K.G * np.sin(th), dists), rel=1e-6)
+    hold_x, hold_y, slide_d, slide_x = run((1.0, 0.0), 0.9)[0], run((0.0, 1.0), 0.9)[0], run((s2, s2), 0.9)[0], run((1.0, 0.0), 1.3)[0]
+    assert 0 < hold_x < 0.02 and 0 < hold_y < 0.02 and slide_d > 0.5 and slide_x > 0.5
+
+
+@pytest.mark.parametrize("j", [6, 50])
+def test_known_answer_hinge_limit_penetration(j):
+    """(iii) joint limits are the same soft constraint with one row, R = (1 - d) / d * dof_invweight0: a hinge driven past its +180 degree
+    limit by a saturated actuator (stable-PD asked for 6 rad more: torque = torque_lim) settles where D k d |r| = torque, i.e.
+    |r| = torque (1 - dmax) invweight0 / (k dmax^2) beyond the solimp width.  No gravity, no contacts; the rest of the body is held by its PD."""
+    import known_answers as K
+    o = OracleSim(contact=False, gravity=0.0)
+    q = STD["qpos"].copy(); q[2] += 2.0; q[7 + j] = 3.0
+    o.reset(q, np.zeros(75))
+    act = np.zeros(75); act[j] = 6.0
+    for _ in range(60):
+        o.do_simulation(act, q, 15)
+    pred = K.limit_penetration(KPM["torque_lim"][j], KPM["dof_invweight0"][6 + j])
+    assert o.get("qpos")[7 + j] - np.pi == pytest.approx(pred, rel=2e-4) and np.abs(o.get("qvel")).max() < 0.05
+
+
+def _energy(o, qpos, qvel):
+    o.set_state_raw(qpos, qvel); o.forward()
+    M = o.fullM(); xi = o.get("xipos").reshape(24, 3)
+    return 0.5 * qvel @ M @ qvel + 9.81 * float((MASS * xi[:, 2]).sum())
+
+
+def test_known_answer_free_flight_energy_drift():
+    """(iv) BASELINE configs[1]: torque-free flight, no contact, 1500 substeps.  Semi-implicit Euler (v += h a, q += h v) is symplectic: the
+    energy of the falling centre of mass drifts by exactly -1/2 m g^2 h^2 per substep, the internal (rotational / joint) energy stays bounded."""
+    rng = np.random.default_rng(5)
+    o = OracleSim(contact=False, limits=False)
+    q = STD["qpos"].copy(); q[2] += 10; q[7:] += rng.normal(size=69) * 0.2
+    v = np.concatenate([rng.normal(size=3), rng.normal(size=72) * 0.5])
+    e0 = _energy(o, q, v)
+    ke0 = e0 - 9.81 * float((MASS * o.get("xipos").reshape(24, 3)[:, 2]).sum())
+    o.reset(q, v)
+    for _ in range(1500):
+        o.step()
+    e1 = _energy(o, o.get("qpos").copy(), o.get("qvel").copy())
+    closed = -0.5 * MASS.sum() * 9.81 ** 2 * H * H * 1500
+    assert abs((e1 - e0) - closed) < 0.05 * ke0, (e1 - e0, closed, ke0)
+
+
+def test_known_answer_contact_frame_and_pyramid_rows():
+    """(v) mju_makeFrame [MJ-ext] and the pyramidal basis (computation.html 'Friction cones'): for a contact with normal n the four rows of
+    the constraint Jacobian are (n + mu t1, n - mu t1, n + mu t2, n - mu t2) . (point Jacobian), t1 = the part of y (or of z when n is
+    within 60 degrees of y) orthogonal to n, t2 = n x t1.  Read from efc_J at the translational columns of a free box: tilted boxes on
+    the plane keep n = z (t1 = y, t2 = -x); a box resting on a tilted box gives an oblique n."""
+    import known_answers as K
+    from kinpoly_amd.model_compiler import STEP_KPM
+    rot = lambda ax, a: np.concatenate([[np.cos(a / 2)], np.sin(a / 2) * np.asarray(ax, float) / np.linalg.norm(ax)])      # noqa: E731
+    o = OracleSim(kpm=STEP_KPM)
+    # slot 0: the step box rotated 35 degrees about an oblique axis (one corner 0.1 mm inside the plane's margin); slot 1: the small box flat
+    # on its upper face, 0.5 mm inside
+    qa = rot([1.0, 2.0, 0.3], 0.6)
+    R = O.quaternion_matrix3(qa)
+    og = K.KPM["obj_geoms"].reshape(-1, 18)
+    g4, g1 = og[og[:, 0].astype(int) == 4][0], og[og[:, 0].astype(int) == 1][0]
+    corners = np.array([[sx * g4[2], sy * g4[3], sz * g4[4]] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)]) + g4[5:8]
+    origin4 = np.array([0.0, 0.0, 0.0009 - (corners @ R.T)[:, 2].min()])
+    face = origin4 + R @ (g4[5:8] + [0.0, 0.0, g4[4]])                   # centre of the upper face, normal R e_z
+    centre1 = face + R @ [0.0, 0.0, g1[4] - 0.0005]
+    o.set_object(0, K.KPM, 4, [*origin4, *qa])
+    o.set_object(1, K.KPM, 1, [*(centre1 - R @ g1[5:8]), *qa])
+    q = STD["qpos"].copy(); q[0] += 30; q[2] += 50
+    o.reset(q, np.zeros(75))
+    o.forward()
+    c = o.contacts_full(); J = o.efc_J_full()
+    assert len(c["body"]) > 0
+    lim = o.nefc - 4 * len(c["body"])
+    seen_oblique = False
+    for i, (a, b, n) in enumerate(zip(c["body"], c["b2"], c["normal"])):
+        rows = K.pyramid_rows(n)
+        for e in range(4):
+            jr = J[lim + 4 * i + e]
+            if a >= 24:                                               # entity carrying the first geom's counterpart: moves along +row
+                np.testing.assert_allclose(jr[75 + 6 * (a - 24): 78 + 6 * (a - 24)], rows[e], atol=1e-12)
+            if b >= 24:
+                np.testing.assert_allclose(jr[75 + 6 * (b - 24): 78 + 6 * (b - 24)], -rows[e], atol=1e-12)
+        seen_oblique |= bool(a >= 24 and b >= 24 and abs(n[2]) < 0.95)
+    assert seen_oblique, "the box-on-tilted-box contact was not generated"
+    n, t1, t2 = K.make_frame([0.0, 0.0, 1.0])
+    np.testing.assert_allclose(t1, [0, 1, 0]); np.testing.assert_allclose(t2, [-1, 0, 0])
+    n, t1, t2 = K.make_frame([0.1, 0.9, 0.2])                           # within 60 degrees of y: reference axis z
+    assert abs(t1 @ n) < 1e-15 and t1[2] > 0.9 and np.allclose(np.cross(n, t1), t2)
