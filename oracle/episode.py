@@ -1,0 +1,86 @@
+"""CPU restatement of the rollout driver's episode loop -- TEST INFRASTRUCTURE (only tests/ may import this).
+
+AgentAR.sample_worker (kin_poly/core/agent_ar.py:510-606) for ONE environment, composed from the pieces that are pinned elsewhere:
+np_oracle (step_ar, qpos_fk, get_full_obs_v1, get_ar_obs_v1, calc_body_diff / calc_body_gt_diff, dynamic_supervision_v1), the fp64 C
+physics (OracleSim.do_simulation) and fp64 copies of the two policies.  It emits the twelve memory fields of push_memory (:612-644) row by
+row, in the order the reference's worker pushes them:
+
+    state, action, mask, next_state, reward, exp, v_meta, gt_target_qpos, curr_qpos, res_qpos, cc_action, cc_state
+
+Episode semantics followed line by line:
+    env.load_context + reset       humanoid_ar_v1.py:83-88, 334-387: state <- init_qpos / init_qvel, target = FK(init), cur_t = 0
+    action = select_action(state)  agent_ar.py:545-549 (mean action in this oracle: deterministic); the GRU state is zeroed per episode
+                                   (PolicyAR.init_context, policy_ar.py:177-180)
+    gt_qpos = ar_context['qpos'][cur_t + 1]; curr_qpos = get_humanoid_qpos()        :553-554
+    env.step                       humanoid_ar_v1.py:243-323 (mode 'train': GT-diff termination on; UHC mean action as with joint_controller)
+    reward = dynamic_supervision_v1(env, ...)                                        :563-565, reward_function.py:931-995
+    mask = 0 if done else 1; exp = 1                                                :578-581
+    done -> the episode ends; the caller starts the next one (on the same clip when there is no dataset, as VectorSampler does)
+"""
+import numpy as np
+import torch
+
+from . import np_oracle as O
+from .kpo import OracleSim
+
+
+class EpisodeOracle:
+    def __init__(self, kpm, kin_policy, cc_policy, body_diff_thresh=10.0, body_diff_gt_thresh=12.0, dt=1.0 / 30.0):
+        """kin_policy / cc_policy: fp64 CPU copies of kinpoly_amd.nets.KinPolicy / PolicyMCP (the networks under test are not the subject
+        here; their forward is pinned by tests/golden/policies.npz and traj_ar_net.npz)."""
+        self.bp, self.bi, self.par = kpm["body_pos"].reshape(24, 3), kpm["body_ipos"].reshape(24, 3), kpm["body_parent"]
+        self.diffw = kpm["body_diffw"]
+        self.kin, self.mcp = kin_policy, cc_policy
+        self.th, self.th_gt, self.dt = body_diff_thresh, body_diff_gt_thresh, dt
+        self.sim = OracleSim()
+
+    def _x(self):
+        x = {k: self.sim.get(k) for k in ("qpos", "qvel", "xpos", "xquat", "xipos")}
+        return x["qpos"], x["qvel"], x["xpos"].reshape(24, 3), x["xquat"].reshape(24, 4), x["xipos"].reshape(24, 3)
+
+    def rollout(self, ctx, T, v_meta=(0.0, 0.0)):
+        """ctx: numpy dict of ONE clip (qpos [L, 76], head_pose [L, 7], head_vels [L, 6], obj_head_relative_poses [L, 7], action_one_hot [4],
+        init_qpos [76], init_qvel [75]).  Runs T env-steps, starting a new episode on the same clip after every `done`.  Returns the
+        memory fields as arrays [T, .] plus 'done' / 'fail' / 'percent'."""
+        L = ctx["qpos"].shape[0]
+        clip_len = L - 1                                            # ar_context['len'] (humanoid_ar_v1.py:84-88)
+        gt = [O.qpos_fk(q, self.bp, self.bi, self.par) for q in ctx["qpos"]]
+        rows = {k: [] for k in ("state", "action", "mask", "next_state", "reward", "exp", "v_meta", "gt_target_qpos", "curr_qpos", "res_qpos",
+                                "cc_action", "cc_state", "done", "fail", "percent", "episode_start")}
+        state = None
+        for _ in range(T):
+            fresh = state is None
+            if fresh:                                              # load_context + reset
+                self.sim.reset(ctx["init_qpos"], ctx["init_qvel"])
+                cur_t = 0
+                hx = torch.zeros((1, self.kin.rnn_hdim), dtype=torch.float64)
+                qpos, qvel, xp, xq, xi = self._x()
+                state = O.obs_ar(qpos, xp, xq, ctx["head_pose"][0], ctx["head_vels"][0], ctx["obj_head_relative_poses"][0], ctx["action_one_hot"], None)
+            with torch.no_grad():
+                a, hx = self.kin.select_action(torch.from_numpy(state)[None], hx, True)
+            a = a[0].numpy()
+            gt_qpos = ctx["qpos"][min(cur_t + 1, L - 1)]
+            qpos, qvel, xp, xq, xi = self._x()
+            curr_qpos = qpos.copy()
+            # ---- env.step
+            prev_bquat = O.get_body_quat(qpos); prev_hpos = np.concatenate([xp[13], xq[13]])
+            tgt = O.qpos_fk(O.step_ar(qpos, a), self.bp, self.bi, self.par)
+            cc_obs = O.zfilter(O.obs_cc(qpos, qvel, xp, xq, xi, tgt), 0.0, 1.0, 5.0)
+            with torch.no_grad():
+                cc_a = self.mcp.action_mean(torch.from_numpy(cc_obs)[None])[0].numpy()
+            self.sim.do_simulation(cc_a, tgt["qpos"], 15)
+            cur_t += 1
+            qpos, qvel, xp, xq, xi = self._x()
+            fail = bool(O.calc_body_diff(xp, tgt["wbpos"], self.diffw) > self.th or O.calc_body_diff(xp, gt[min(cur_t, L - 1)]["wbpos"], self.diffw) > self.th_gt)
+            end = cur_t >= clip_len
+            done = fail or end
+            t_ctx = min(cur_t, L - 1)
+            next_state = O.obs_ar(qpos, xp, xq, ctx["head_pose"][t_ctx], ctx["head_vels"][t_ctx], ctx["obj_head_relative_poses"][t_ctx], ctx["action_one_hot"], None)
+            r, _ = O.dynamic_supervision_v1(np.concatenate([xp[13], xq[13]]), prev_hpos, O.get_body_quat(qpos), prev_bquat, xp, tgt, ctx["head_pose"][t_ctx],
+                                            gt[t_ctx]["bquat"].reshape(-1), gt[t_ctx - 1]["bquat"].reshape(-1), self.dt, O.REWARD_WEIGHTS)
+            for k, v in (("state", state), ("action", a), ("mask", 0.0 if done else 1.0), ("next_state", next_state), ("reward", r), ("exp", 1.0),
+                         ("v_meta", np.array([v_meta[0], v_meta[1], float(L)])), ("gt_target_qpos", gt_qpos), ("curr_qpos", curr_qpos), ("res_qpos", qpos.copy()),
+                         ("cc_action", cc_a), ("cc_state", cc_obs), ("done", done), ("fail", fail), ("percent", cur_t / clip_len), ("episode_start", fresh)):
+                rows[k].append(v)
+            state = None if done else next_state
+        return {k: np.asarray(v) for k, v in rows.items()}

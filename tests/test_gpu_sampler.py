@@ -182,3 +182,59 @@ def test_two_rank_agent_keeps_parameters_identical():
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "DDP_AGENT_OK" in out.stdout, out.stdout[-2000:]
+
+
+def test_sampler_rows_match_the_cpu_episode_loop():
+    """a1 as a PARITY test (VERDICT r2 next #3a): VectorSampler's TrajBatchEgo rows against oracle/episode.py, the CPU restatement of
+    sample_worker (agent_ar.py:538-606) composed of the pinned np_oracle pieces, the fp64 C physics and fp64 copies of both policies.  Two
+    envs x 14 steps with mean actions: env 0 tracks its 7-frame clip and ends it twice ('end' at cur_t = 6, reset, again); env 1's clip has
+    its GT a metre above the humanoid, so the GT-diff termination (train mode, humanoid_ar_v1.py:303-306) fails it on every step.  All
+    twelve memory fields, field by field, plus the GRU state being zeroed at every episode start."""
+    import copy
+    from kinpoly_amd.env import BatchedHumanoidAREnv, standing_context
+    from kinpoly_amd.model_compiler import STEP_KPM, read_kpm
+    from kinpoly_amd.nets import KinPolicy
+    from kinpoly_amd.rollout import VectorSampler
+    from oracle.episode import EpisodeOracle
+    n, L, T = 2, 7, 14
+    torch.manual_seed(7)
+    env = BatchedHumanoidAREnv(n, 0, mode="train", joint_controller=True, seed=7)        # joint_controller: the UHC acts with its mean (humanoid_ar_v1.py:267-268)
+    ctx = standing_context(n, L, STD["qpos"], STD["qvel"], env.sim, torch.tensor([0.4, -1.1]))
+    ctx["qpos"][1, :, 2] += 1.0                                      # env 1: the GT clip floats a metre above the state the episode starts in
+    env.load_context(ctx)
+    pol = KinPolicy().to(env.device)
+    obs0 = env.reset().clone()
+    with torch.no_grad():                                            # a policy whose mean tracks the standing pose, modulated a little by its GRU / MLP path
+        pol.action_fc.weight.mul_(0.02); pol.action_fc.bias.zero_()
+        q0 = ctx["init_qpos"]
+        pol.action_fc.bias[:74] = torch.cat([q0[0, 2:3], torch.tensor([1.0, 0, 0, 0], device=env.device), q0[0, 7:]])
+    sampler = VectorSampler(env, pol, mean_action=True, record_full=True)
+    b = sampler.sample(T)
+    kpm = read_kpm(STEP_KPM)
+    ep = EpisodeOracle(kpm, copy.deepcopy(pol).double().cpu(), copy.deepcopy(env.cc_policy).double().cpu())
+    c = {k: v.double().cpu().numpy() for k, v in ctx.items()}
+    saw_end = saw_fail = False
+    for e in range(n):
+        one = {k: (c[k][e] if c[k].ndim > 1 else c[k]) for k in ("qpos", "head_pose", "head_vels", "obj_head_relative_poses", "action_one_hot", "init_qpos", "init_qvel")}
+        want = ep.rollout(one, T)
+        g = lambda x: x[e].double().cpu().numpy()      # noqa: E731
+        np.testing.assert_array_equal(g(b.masks), want["mask"])
+        np.testing.assert_array_equal(g(b.episode_start).astype(bool), want["episode_start"].astype(bool))
+        np.testing.assert_array_equal(g(b.fails).astype(bool), want["fail"].astype(bool))
+        np.testing.assert_array_equal(g(b.exps), want["exp"])
+        np.testing.assert_array_equal(g(b.v_metas), want["v_meta"])
+        np.testing.assert_allclose(g(b.gt_target_qpos), want["gt_target_qpos"], atol=1e-6)
+        np.testing.assert_allclose(g(b.states), want["state"], atol=2e-3)
+        np.testing.assert_allclose(g(b.actions), want["action"], atol=2e-3)
+        np.testing.assert_allclose(g(b.curr_qpos), want["curr_qpos"], atol=2e-3)
+        np.testing.assert_allclose(g(b.res_qpos), want["res_qpos"], atol=2e-3)
+        np.testing.assert_allclose(g(b.next_states), want["next_state"], atol=2e-3)
+        np.testing.assert_allclose(g(b.rewards), want["reward"], atol=5e-3)
+        np.testing.assert_allclose(g(b.cc_state), want["cc_state"], atol=5e-3)
+        np.testing.assert_allclose(g(b.cc_action), want["cc_action"], atol=2e-2)
+        # the first rows (no accumulated fp32 / fp64 drift yet) at kernel accuracy
+        np.testing.assert_allclose(g(b.states)[0], want["state"][0], atol=5e-5)
+        np.testing.assert_allclose(g(b.res_qpos)[0], want["res_qpos"][0], atol=1e-4)
+        saw_end |= bool((want["done"] & ~want["fail"]).any()); saw_fail |= bool(want["fail"].any())
+    assert saw_end and saw_fail
+    assert (b.masks[0] == 0).sum() == 2 and (b.masks[1] == 0).all()
