@@ -108,26 +108,27 @@ def rollout_steps(sampler, k, a_track=None, wild=False, follow_clip=False):
     wild: the eval_ar_policy.py --wild loop (:196-215): mean actions, an env that terminates early is put back on the kinematic
     roll-out (ar_fail_safe) and keeps going, an env that finishes its clip starts it again."""
     env, pol = sampler.env, sampler.policy
-    n_done = torch.zeros((), dtype=torch.int64, device=env.device)
+    n_early = torch.zeros((), dtype=torch.int64, device=env.device)
+    env.done_count.zero_()
     with torch.no_grad():
-        for _ in range(k):
-            action, sampler.hx = pol.select_action(sampler.obs, sampler.hx, wild, env.gen)
+        # exploration noise of the whole call in one launch: 80 kinematic + 75 UHC (+ 80 for the stand-in action's noise)
+        noise = None if wild else torch.randn((k, env.n, 235), device=env.device, generator=env.gen)
+        for t in range(k):
+            action, sampler.hx = pol.select_action(sampler.obs, sampler.hx, wild, env.gen, None if wild else noise[t, :, :80])
             if follow_clip:                                      # moving clips (objects workload): the action that reproduces the clip's NEXT pose
                 qn = env._ar_frame("qpos")
                 a_track = torch.cat([qn[:, 2:3], sampler.obs[:, 1:5], qn[:, 7:], torch.zeros((env.n, 6), device=env.device)], 1)
             if a_track is not None:                              # the policy's GEMMs ran; a trained policy's output stands in for theirs
-                action = a_track if wild else torch.add(a_track, torch.randn(action.shape, device=action.device, generator=env.gen), alpha=0.04)
-            obs, _, done, info = env.step(action.contiguous())
+                action = a_track if wild else torch.add(a_track, noise[t, :, 155:], alpha=0.04)
+            obs, _, done, info = env.step(action.contiguous(), need_obs=False, cc_noise=None if wild else noise[t, :, 80:155])
             if wild:
                 early = done & (info["percent"] != 1)
                 env.ar_fail_safe(early)                          # masked, device side
                 done = done & ~early
-                n_done += early.sum()
-            else:
-                n_done += done.sum()
-            sampler.obs = env.reset(done).clone()
+                n_early += early.sum()
+            sampler.obs = env.reset(done)
             sampler.hx = sampler.hx.masked_fill(done.unsqueeze(1), 0.0)
-    return n_done
+    return n_early if wild else env.done_count.to(torch.int64)[0]       # episodes ended: counted inside kp_sim_post_step
 
 
 def policy_gemm_probe(env, policy, iters=30):

@@ -115,6 +115,10 @@ int kp_sim_step_ctrl(kp_sim*, const float* cc_action, int n_substeps, const uint
 /* HumanoidAREnv.step_ar(a)   (humanoid_ar_v1.py:216-241): kin_action [N,80] -> next_qpos [N,76] */
 int kp_sim_step_kin(kp_sim*, const float* kin_action, float* next_qpos);
 
+/* The head of HumanoidAREnv.step in one launch (humanoid_ar_v1.py:246-256): kp_sim_step_begin + kp_sim_step_kin + kp_sim_set_target with the
+ * kinematic step's result -- prev_bquat / prev_hpos recorded, target = qpos_fk(step_ar(kin_action)).  kin_action [N,80]. */
+int kp_sim_step_head(kp_sim*, const float* kin_action);
+
 /* get_full_obs_v1() [N,784]   (humanoid_im.py:144-233), optional ZFilter(update=False) + clip
  * (zfilter.py:58-67): pass mean/std [784] device pointers or NULL, clip <= 0 disables clipping. */
 int kp_sim_obs_cc(kp_sim*, float* out, const float* zf_mean, const float* zf_std, float clip);
@@ -156,6 +160,18 @@ typedef struct {
 } kp_reward_cfg;
 int kp_sim_term_reward(kp_sim*, const kp_ctx* ctx, const kp_reward_cfg* cfg, float* reward, float* info, uint8_t* fail, float* diffs);
 
+/* The tail of HumanoidAREnv.step in one launch (humanoid_ar_v1.py:288-316): cur_t += 1 (in place; cur_t must be ctx->cur_t), termination and
+ * reward as kp_sim_term_reward with the incremented cur_t, then end = cur_t >= min(env_episode_len, ar_context['len']), done = fail || end,
+ * percent = cur_t / ar_context['len'].  row_len: int32 [R] = ar_context['len'] of every context row (env e reads row_len[ctx->row[e]]).
+ * done / end: uint8 [N]; percent: float [N]; done_count (optional, may be NULL): int32 device counter incremented by the number of done envs. */
+int kp_sim_post_step(kp_sim*, const kp_ctx* ctx, const kp_reward_cfg* cfg, int32_t* cur_t, const int32_t* row_len, int env_episode_len,
+                     float* reward, float* info, uint8_t* fail, float* diffs, uint8_t* done, uint8_t* end, float* percent, int32_t* done_count);
+
+/* Masked reset in one gather + sim.forward() (mujoco_env.py:86-103, humanoid_ar_v1.py:334-387): for the envs with env_mask != 0 (NULL: all)
+ * qpos / qvel <- init_qpos / init_qvel [R, 76] / [R, 75] of context row row[e] (NULL: row e), cur_t[e] = 0 (cur_t may be NULL), warm start
+ * zeroed, derived quantities recomputed; set_target != 0: target = qpos_fk(init_qpos) for those envs as reset_model does (:384-386). */
+int kp_sim_reset_rows(kp_sim*, const float* init_qpos, const float* init_qvel, const int32_t* row, const uint8_t* env_mask, int32_t* cur_t, int set_target);
+
 /* estimate_advantages before normalisation (uhc/khrylib/rl/core/common.py:5-20) on an env-major
  * [N,T] layout (each env's T rows contiguous, time increasing).  All pointers device, float32. */
 int kp_gae(int n_envs, int T, const float* rewards, const float* masks, const float* values, float gamma, float tau,
@@ -165,6 +181,11 @@ int kp_gae(int n_envs, int T, const float* rewards, const float* masks, const fl
  * last_values may be NULL (= kp_gae). */
 int kp_gae_bootstrap(int n_envs, int T, const float* rewards, const float* masks, const float* values, const float* last_values,
                      float gamma, float tau, float* advantages, float* returns, void* hip_stream);
+
+/* PolicyMCP.forward / select_action after the primitives' and the composer's GEMMs (uhc/core/policy_mcp.py:30-38, uhc/khrylib/rl/core/policy.py:12-15):
+ * out [n, A] = sum_k softmax(logits [n, K])_k * prim [K, n, A]  (+ stdv [A] * noise [n, A], rows noise_stride floats apart, when noise != NULL).
+ * All device float32; logits are the composer MLP's output BEFORE its softmax. */
+int kp_mcp_compose(int n, int K, int A, const float* logits, const float* prim, const float* noise, int noise_stride, const float* stdv, float* out, void* hip_stream);
 
 /* GRU re-unroll of the PPO / supervised updates (policy_ar.py:104-122, 216-240), one time step of torch.nn.GRUCell
  * semantics over n rows, all arrays contiguous float32 device pointers:

@@ -81,9 +81,13 @@ __global__ void k_step_kin(int n, const float* __restrict__ qpos, const float* _
 // ---------------------------------------------------------------- target FK: one wavefront per row, lane = body, level-synchronous chain in LDS
 // (256-thread blocks = 4 rows).  Row loads and stores are coalesced; the 9-level parent chain goes through LDS.
 struct TargetBufs { float *qpos, *wbpos, *wbquat, *bquat, *com; };
+// KinStep (optional, K.act != null): the head of HumanoidAREnv.step in the same launch (humanoid_ar_v1.py:246-256) -- the prev_bquat /
+// prev_hpos records of the CURRENT state (k_snapshot), next_qpos = step_ar(action) (k_step_kin) computed straight into the row the FK
+// runs on; `tq` is then the current qpos.  Three launches of the env-step become one.
+struct KinStep { const float *act, *xpos, *xquat; float *prev_bquat, *prev_hpos; float dt; };
 __global__ __launch_bounds__(256) void k_target_fk(int n, const float* __restrict__ tq, const uint8_t* __restrict__ mask, TargetBufs B,
                                                     const float* __restrict__ body_pos, const float* __restrict__ body_ipos, const int8_t* __restrict__ parent,
-                                                    const uint8_t* __restrict__ depth) {
+                                                    const uint8_t* __restrict__ depth, KinStep K = KinStep{nullptr, nullptr, nullptr, nullptr, nullptr, 0.f}) {
     __shared__ float sq[4][80], swq[4][D_NB * 4], swp[4][D_NB * 3];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int e = blockIdx.x * 4 + w;
@@ -91,7 +95,29 @@ __global__ __launch_bounds__(256) void k_target_fk(int n, const float* __restric
     if (!__syncthreads_or(live)) return;             // masked resets touch a few rows: a block whose four rows are all masked out leaves at once
     if (live) {
         const float* q = tq + (size_t)e * D_NQ;
-        for (int i = lane; i < D_NQ; i += 64) sq[w][i] = q[i];
+        if (K.act) {
+            const float* a = K.act + (size_t)e * 80;
+            if (lane < D_NB) {                      // prev_bquat = get_body_quat(), prev_hpos = get_head() of the state before the step
+                const Q4 r = lane == 0 ? Q4{q[3], q[4], q[5], q[6]} : q_euler_sxyz(q[7 + 3 * (lane - 1)], q[8 + 3 * (lane - 1)], q[9 + 3 * (lane - 1)]);
+                float* o = K.prev_bquat + ((size_t)e * D_NB + lane) * 4;
+                o[0] = r.w; o[1] = r.x; o[2] = r.y; o[3] = r.z;
+                if (lane == 13) {
+                    for (int k = 0; k < 3; k++) K.prev_hpos[(size_t)e * 7 + k] = K.xpos[(size_t)e * 72 + 39 + k];
+                    for (int k = 0; k < 4; k++) K.prev_hpos[(size_t)e * 7 + 3 + k] = K.xquat[(size_t)e * 96 + 52 + k];
+                }
+            }
+            if (lane == 32) {                       // step_ar's root part (:216-241), same arithmetic as k_step_kin
+                const Q4 rot = Q4{q[3], q[4], q[5], q[6]};
+                const V3 linv = q_mul_vec(q_heading(rot), v3(a[74], a[75], a[76]));
+                const V3 angv = q_mul_vec(rot, v3(a[77], a[78], a[79]));
+                const Q4 nr = qmul(q_from_expmap(K.dt * angv), rot);
+                sq[w][0] = q[0] + linv.x * K.dt; sq[w][1] = q[1] + linv.y * K.dt; sq[w][2] = a[0];
+                sq[w][3] = nr.w; sq[w][4] = nr.x; sq[w][5] = nr.y; sq[w][6] = nr.z;
+            }
+            for (int j = lane; j < D_NU; j += 64) sq[w][7 + j] = a[5 + j];
+        } else {
+            for (int i = lane; i < D_NQ; i += 64) sq[w][i] = q[i];
+        }
     }
     __syncthreads();
     const int b = lane;

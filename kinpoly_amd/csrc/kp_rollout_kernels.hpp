@@ -84,14 +84,27 @@ struct RewardW { float w_hp, w_hq, w_p, w_jp, w_act_p, w_act_v, k_hp, k_hq, k_p,
 
 // inputs are AFTER do_simulation and cur_t += 1: qpos fresh, xpos/xquat stale (as the reference reads them).
 // 32 lanes per env (lane = body, 24 active), 8 envs per 256-thread block; the per-body terms are summed by an xor butterfly.
+// POST = true is the fused tail of HumanoidAREnv.step (humanoid_ar_v1.py:288-316): cur_t += 1 first (written back by the env's lane 0
+// after every lane has read it), then the same termination / reward, then end = cur_t >= min(env_episode_len, ar_context['len']),
+// done = fail or end, percent = cur_t / ar_context['len'] -- one launch instead of the add, the compare, the or, the division and two copies.
+struct PostStep {
+    int* cur_t;                 // [N] in / out (the same buffer CtxDev::cur_t points to)
+    const int* row_len;         // [R] ar_context['len'] of every context row
+    int episode_len;            // cc_cfg.env_episode_len
+    uint8_t *done, *end;        // [N]
+    float* percent;             // [N]
+    int* done_count;            // optional: += number of done envs (a rollout loop's episode counter, no extra reduction launch)
+};
+template <bool POST>
 __global__ __launch_bounds__(256) void k_term_reward(int n, CtxDev C, RewardW W, const float* __restrict__ qpos, const float* __restrict__ xpos,
                               const float* __restrict__ xquat, const float* __restrict__ t_wbpos, const float* __restrict__ t_bquat,
                               const float* __restrict__ prev_bquat, const float* __restrict__ prev_hpos, const float* __restrict__ diffw,
-                              float* __restrict__ reward, float* __restrict__ info, uint8_t* __restrict__ fail, float* __restrict__ diffs) {
+                              float* __restrict__ reward, float* __restrict__ info, uint8_t* __restrict__ fail, float* __restrict__ diffs, PostStep PS) {
     const int b = threadIdx.x & 31, e_raw = blockIdx.x * 8 + (threadIdx.x >> 5);
     const bool valid = e_raw < n;
     const int e = valid ? e_raw : 0;
-    int t = C.cur_t[e];
+    const int t_now = C.cur_t[e] + (POST ? 1 : 0);
+    int t = t_now;
     t = t < 1 ? 1 : (t >= C.T ? C.T - 1 : t);
     const float* q = qpos + (size_t)e * D_NQ;
     const float* xp = xpos + (size_t)e * 72;
@@ -138,8 +151,31 @@ __global__ __launch_bounds__(256) void k_term_reward(int n, CtxDev C, RewardW W,
     reward[e] = W.w_hp * hp_r + W.w_hq * hq_r + W.w_p * p_r + W.w_jp * jp_r + W.w_act_p * gt_r + W.w_act_v * av_r;
     float* inf = info + (size_t)e * 6;
     inf[0] = hp_r; inf[1] = hq_r; inf[2] = p_r; inf[3] = jp_r; inf[4] = gt_r; inf[5] = av_r;
-    fail[e] = (bd > W.thresh) || (W.use_gt && bgd > W.gt_thresh) || !(bd == bd);
+    const bool failed = (bd > W.thresh) || (W.use_gt && bgd > W.gt_thresh) || !(bd == bd);
+    fail[e] = failed;
     diffs[2 * e] = bd; diffs[2 * e + 1] = bgd;
+    if (POST) {
+        const int clen = PS.row_len[C.r(e)];
+        const bool ended = t_now >= (clen < PS.episode_len ? clen : PS.episode_len);
+        PS.cur_t[e] = t_now;
+        PS.end[e] = ended; PS.done[e] = failed || ended;
+        PS.percent[e] = (float)t_now / (float)clen;
+        if (PS.done_count && (failed || ended)) atomicAdd(PS.done_count, 1);
+    }
+}
+
+// Masked reset of HumanoidAREnv (mujoco_env.py:86-103 + humanoid_ar_v1.py:334-387) for the envs with mask != 0: cur_t = 0 and
+// qpos / qvel (and the derived-state copies) <- ar_context['init_qpos' / 'init_qvel'] of the env's context row, warm start zeroed.  One
+// launch instead of a masked fill, an index conversion, two gathers and three masked row copies; sim.forward() and the target FK follow.
+__global__ void k_reset_rows(int n, const float* __restrict__ init_qpos, const float* __restrict__ init_qvel, const int* __restrict__ row,
+                             const uint8_t* __restrict__ mask, int* __restrict__ cur_t, float* __restrict__ qpos, float* __restrict__ qvel,
+                             float* __restrict__ qpos_d, float* __restrict__ qvel_d, float* __restrict__ warm) {
+    const int e = blockIdx.x, i = threadIdx.x;          // one 128-thread block per env
+    if (e >= n || (mask && !mask[e])) return;
+    const size_t r = row ? (size_t)row[e] : (size_t)e;
+    if (i < D_NQ) { const float v = init_qpos[r * D_NQ + i]; qpos[(size_t)e * D_NQ + i] = v; qpos_d[(size_t)e * D_NQ + i] = v; }
+    if (i < D_NV) { const float v = init_qvel[r * D_NV + i]; qvel[(size_t)e * D_NV + i] = v; qvel_d[(size_t)e * D_NV + i] = v; warm[(size_t)e * D_NV + i] = 0.f; }
+    if (i == 0 && cur_t) cur_t[e] = 0;
 }
 
 // reverse scan per env over an env-major [N, T] layout (time contiguous per env), masks cut episodes
@@ -168,6 +204,28 @@ __global__ void k_gae(int n, int T, const float* __restrict__ rewards, const flo
 //     r = sigma(gi_r + gh_r), z = sigma(gi_z + gh_z), n = tanh(gi_n + r gh_n), h = (1 - z) n + z hm_prev     (torch.nn.GRUCell)
 // hm = h masked by the NEXT step's episode-start flag, ready to be the next step's GEMM input.
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// PolicyMCP's mixing stage (uhc/core/policy_mcp.py:30-38) in one pass: weight = softmax(composer output) over the K primitives,
+// mean = sum_k weight_k * prim_k, optionally action = mean + std * noise (select_action, policy.py:12-15).  prim is the third batched GEMM's
+// output in its own layout [K, N, A] (no transpose pass); one thread per (env, action dim), the K <= 16 logits of an env are re-read by its A threads (L1).
+__global__ void k_mcp_compose(int n, int K, int A, const float* __restrict__ logits, const float* __restrict__ prim, const float* __restrict__ noise,
+                              int noise_stride, const float* __restrict__ stdv, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)n * A) return;
+    const int e = (int)(i / A), a = (int)(i - (size_t)e * A);
+    const float* lg = logits + (size_t)e * K;
+    float mx = lg[0];
+    for (int k = 1; k < K; k++) mx = fmaxf(mx, lg[k]);
+    float den = 0.f, acc = 0.f;
+    for (int k = 0; k < K; k++) {
+        const float w = expf(lg[k] - mx);
+        den += w;
+        acc += w * prim[((size_t)k * n + e) * A + a];
+    }
+    float v = acc / den;
+    if (noise) v += stdv[a] * noise[(size_t)e * noise_stride + a];
+    out[i] = v;
+}
 
 __global__ void k_gru_gates_fwd(int n, int H, const float* __restrict__ gi, const float* __restrict__ gh, const float* __restrict__ hm_prev,
                                 const float* __restrict__ next_keep, float* __restrict__ h_out, float* __restrict__ hm_next) {

@@ -567,6 +567,17 @@ int kp_sim_step_ctrl(kp_sim* s, const float* action, int nsub, const uint8_t* ma
     return launch_step(s, action, nsub, mask, true);
 }
 
+int kp_sim_step_head(kp_sim* s, const float* act) {
+    if (!s || !act) return fail("kp_sim_step_head: null argument");
+    HIP_OK(hipSetDevice(s->device));
+    kp::TargetBufs B{s->t_qpos, s->t_wbpos, s->t_wbquat, s->t_bquat, s->t_com};
+    kp::KinStep K{act, s->xpos, s->xquat, s->prev_bquat, s->prev_hpos, 1.0f / 30.0f};
+    hipLaunchKernelGGL(kp::k_target_fk, dim3((s->n + 3) / 4), dim3(256), 0, s->stream, s->n, s->qpos, (const uint8_t*)nullptr, B, s->T.body_pos, s->T.body_ipos,
+                       s->T.body_parent, s->T.body_depth, K);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
 int kp_sim_step_kin(kp_sim* s, const float* act, float* next_qpos) {
     if (!s || !act || !next_qpos) return fail("kp_sim_step_kin: null argument");
     HIP_OK(hipSetDevice(s->device));
@@ -679,9 +690,38 @@ int kp_sim_term_reward(kp_sim* s, const kp_ctx* c, const kp_reward_cfg* w, float
     HIP_OK(hipSetDevice(s->device));
     kp::RewardW W{w->w_hp, w->w_hq, w->w_p, w->w_jp, w->w_act_p, w->w_act_v, w->k_hp, w->k_hq, w->k_p, w->k_jp, w->k_act_p, w->k_act_v,
                   w->dt, w->body_diff_thresh, w->body_diff_gt_thresh, w->use_gt_term};
-    hipLaunchKernelGGL(kp::k_term_reward, dim3((s->n + 7) / 8), dim3(256), 0, s->stream, s->n, to_dev(c), W, s->qpos, s->xpos, s->xquat,
-                       s->t_wbpos, s->t_bquat, s->prev_bquat, s->prev_hpos, s->diffw, reward, info, failp, diffs);
+    hipLaunchKernelGGL(kp::k_term_reward<false>, dim3((s->n + 7) / 8), dim3(256), 0, s->stream, s->n, to_dev(c), W, s->qpos, s->xpos, s->xquat,
+                       s->t_wbpos, s->t_bquat, s->prev_bquat, s->prev_hpos, s->diffw, reward, info, failp, diffs, kp::PostStep{});
     HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int kp_sim_post_step(kp_sim* s, const kp_ctx* c, const kp_reward_cfg* w, int32_t* cur_t, const int32_t* row_len, int env_episode_len,
+                     float* reward, float* info, uint8_t* failp, float* diffs, uint8_t* done, uint8_t* end, float* percent, int32_t* done_count) {
+    if (!s || !c || !w || !cur_t || !row_len || !reward || !info || !failp || !diffs || !done || !end || !percent || !c->head_pose || !c->gt_bquat || !c->gt_wbpos || c->T < 2)
+        return fail("kp_sim_post_step: bad arguments");
+    if (c->cur_t != cur_t) return fail("kp_sim_post_step: cur_t must be the buffer the context reads (kp_ctx.cur_t)");
+    HIP_OK(hipSetDevice(s->device));
+    kp::RewardW W{w->w_hp, w->w_hq, w->w_p, w->w_jp, w->w_act_p, w->w_act_v, w->k_hp, w->k_hq, w->k_p, w->k_jp, w->k_act_p, w->k_act_v,
+                  w->dt, w->body_diff_thresh, w->body_diff_gt_thresh, w->use_gt_term};
+    kp::PostStep PS{cur_t, row_len, env_episode_len, done, end, percent, done_count};
+    hipLaunchKernelGGL(kp::k_term_reward<true>, dim3((s->n + 7) / 8), dim3(256), 0, s->stream, s->n, to_dev(c), W, s->qpos, s->xpos, s->xquat,
+                       s->t_wbpos, s->t_bquat, s->prev_bquat, s->prev_hpos, s->diffw, reward, info, failp, diffs, PS);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int kp_sim_reset_rows(kp_sim* s, const float* init_qpos, const float* init_qvel, const int32_t* row, const uint8_t* mask, int32_t* cur_t, int set_target) {
+    if (!s || !init_qpos || !init_qvel) return fail("kp_sim_reset_rows: null argument");
+    HIP_OK(hipSetDevice(s->device));
+    hipLaunchKernelGGL(kp::k_reset_rows, dim3(s->n), dim3(128), 0, s->stream, s->n, init_qpos, init_qvel, row, mask, cur_t, s->qpos, s->qvel, s->qpos_d, s->qvel_d, s->warm);
+    HIP_OK(hipGetLastError());
+    if (int rc = launch_step(s, nullptr, 0, mask, false)) return rc;      // sim.forward(): derived quantities at the new state
+    if (set_target) {                                                     // target = smpl_humanoid.qpos_fk(init_qpos) (humanoid_ar_v1.py:384-386): the state just written
+        kp::TargetBufs B{s->t_qpos, s->t_wbpos, s->t_wbquat, s->t_bquat, s->t_com};
+        hipLaunchKernelGGL(kp::k_target_fk, dim3((s->n + 3) / 4), dim3(256), 0, s->stream, s->n, s->qpos, mask, B, s->T.body_pos, s->T.body_ipos, s->T.body_parent, s->T.body_depth);
+        HIP_OK(hipGetLastError());
+    }
     return 0;
 }
 
@@ -694,6 +734,14 @@ int kp_gae_bootstrap(int n, int T, const float* rewards, const float* masks, con
 }
 int kp_gae(int n, int T, const float* rewards, const float* masks, const float* values, float gamma, float tau, float* adv, float* ret, void* stream) {
     return kp_gae_bootstrap(n, T, rewards, masks, values, nullptr, gamma, tau, adv, ret, stream);
+}
+
+int kp_mcp_compose(int n, int K, int A, const float* logits, const float* prim, const float* noise, int noise_stride, const float* stdv, float* out, void* stream) {
+    if (n <= 0 || K <= 0 || K > 64 || A <= 0 || !logits || !prim || !out || (noise && !stdv)) return fail("kp_mcp_compose: bad arguments");
+    const size_t tot = (size_t)n * A;
+    hipLaunchKernelGGL(kp::k_mcp_compose, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, K, A, logits, prim, noise, noise_stride, stdv, out);
+    HIP_OK(hipGetLastError());
+    return 0;
 }
 
 int kp_gru_gates_forward(int n, int H, const float* gi, const float* gh, const float* hm_prev, const float* next_keep, float* h_out, float* hm_next, void* stream) {

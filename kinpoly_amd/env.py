@@ -74,9 +74,13 @@ class BatchedHumanoidAREnv:
         self.action_dim, self.obs_dim, self.cc_action_dim = 80, kpsim.AR_OBS_DIM, kpsim.CC_ACTION_DIM
         # persistent I/O buffers (no per-step allocation)
         f = lambda d: torch.empty((self.n, d), dtype=torch.float32, device=self.device)  # noqa: E731
-        self._next_qpos, self._cc_obs, self._obs = f(76), f(784), f(105)
-        self._reward, self._info, self._diffs = torch.empty(self.n, device=self.device), f(6), f(2)
-        self._fail = torch.empty(self.n, dtype=torch.uint8, device=self.device)
+        self._next_qpos, self._cc_obs, self._obs, self._obs_next = f(76), f(784), f(105), f(105)
+        # what step() hands back lives in two alternating sets of buffers: a returned tensor stays valid until the next-but-one step()
+        u8 = lambda: torch.empty(self.n, dtype=torch.uint8, device=self.device)  # noqa: E731
+        self._outs = [dict(reward=torch.empty(self.n, device=self.device), info=f(6), diffs=f(2), fail=u8(), done=u8(), end=u8(),
+                           percent=torch.empty(self.n, device=self.device)) for _ in range(2)]
+        self._flip = 0
+        self.done_count = torch.zeros(1, dtype=torch.int32, device=self.device)      # episodes ended since the caller last zeroed it (kp_sim_post_step)
         self._unit_reward = torch.ones(self.n, device=self.device)
 
     # ------------------------------------------------------------------ reference surface
@@ -160,6 +164,11 @@ class BatchedHumanoidAREnv:
             self.obj_qpos = self.obj7 = None
         self._ctx_struct = self.sim.make_ctx(T, c["head_pose"], c["head_vels"], c["obj_head_relative_poses"], c["action_one_hot"],
                                              c["gt_bquat"], c["gt_wbpos"], self.cur_t, obj_qpos=self.obj7, row=self.row)
+        # rows a reset starts from (reset_model, humanoid_ar_v1.py:339-341): the kinematic roll-out's first frame in ar_mode, else init_qpos / init_qvel
+        if self.ar_mode:
+            self._init_q, self._init_v = c["ar_qpos"][:, 0].contiguous(), c["ar_qvel"][:, 0].contiguous()
+        else:
+            self._init_q, self._init_v = c["init_qpos"].contiguous(), c["init_qvel"].contiguous()
         self._refresh_len()
 
     @property
@@ -169,7 +178,6 @@ class BatchedHumanoidAREnv:
 
     def _refresh_len(self):
         self._clen = self.row_len[self.row.long()]
-        self._t_end = self._clen.clamp(max=int(min(self.env_episode_len, 2 ** 31 - 1)))      # the step that ends the episode (:291-293)
 
     def set_rows(self, new_row: torch.Tensor, env_mask: torch.Tensor | None = None):
         """Put the masked envs on other context rows (device op, no copy): the new episode's clip of agent_ar.py:519-535.
@@ -185,16 +193,21 @@ class BatchedHumanoidAREnv:
         """ctx[key] gathered to the envs' current rows: [N, ...]."""
         return self.ctx[key][self.row.long()]
 
-    def reset(self, env_mask: torch.Tensor | None = None):
-        """sim.reset(); cur_t = 0; reset_model(): state <- ar_context init_qpos/init_qvel, target = FK(init) (:334-387)."""
-        m8 = None if env_mask is None else env_mask.to(self.device, torch.uint8).contiguous()
-        mb = None if env_mask is None else env_mask.to(self.device, torch.bool)
+    @staticmethod
+    def _mask8(env_mask, device):
+        """bool / uint8 mask -> uint8 view (a bool tensor's bytes are 0 / 1: no conversion launch)"""
         if env_mask is None:
-            self.cur_t.zero_()
-        else:
-            self.cur_t.masked_fill_(mb, 0)
-        r = self.row.long()
+            return None
+        m = env_mask.to(device)
+        return (m.view(torch.uint8) if m.dtype == torch.bool else m.to(torch.uint8)).contiguous()
+
+    def reset(self, env_mask: torch.Tensor | None = None):
+        """sim.reset(); cur_t = 0; reset_model(): state <- ar_context init_qpos/init_qvel, target = FK(init) (:334-387).  The humanoid's part is
+        one gather launch + sim.forward() + the target FK (kp_sim_reset_rows)."""
+        m8 = self._mask8(env_mask, self.device)
         if self.obj_qpos is not None:
+            mb = None if m8 is None else m8.view(torch.bool)
+            r = self.row.long()
             if mb is None:
                 self.obj_qpos.copy_(self._row_obj_qpos[r]); self._obj_has.copy_(self._row_obj_has[r]); self._obj_cols.copy_(self._row_obj_cols[r])
             else:
@@ -204,12 +217,7 @@ class BatchedHumanoidAREnv:
             self.sim.set_objects(self.obj_qpos, m8)
             fresh = torch.where(self._obj_has[:, None], torch.gather(self.obj_qpos, 1, self._obj_cols), self._row_obj7[r])
             self.obj7.copy_(fresh if mb is None else torch.where(mb[:, None], fresh, self.obj7))
-        if self.ar_mode:                          # reset_model (:339-341): start from the kinematic roll-out's first frame
-            q0, v0 = self.ctx["ar_qpos"][r, 0].contiguous(), self.ctx["ar_qvel"][r, 0].contiguous()
-        else:
-            q0, v0 = self.ctx["init_qpos"][r].contiguous(), self.ctx["init_qvel"][r].contiguous()
-        self.sim.set_state(q0, v0, m8)
-        self.sim.set_target(q0, m8)
+        self.sim.reset_rows(self._init_q, self._init_v, self.row, m8, self.cur_t, set_target=True)
         return self.sim.obs_ar(self._ctx_struct, self._obs)
 
     def _ar_frame(self, key):
@@ -219,32 +227,36 @@ class BatchedHumanoidAREnv:
 
     def ar_fail_safe(self, env_mask: torch.Tensor | None = None):
         """HumanoidAREnv.ar_fail_safe (:327-331): put the humanoid back on the kinematic roll-out (objects keep their state)."""
-        m8 = None if env_mask is None else env_mask.to(self.device, torch.uint8).contiguous()
-        self.sim.set_state(self._ar_frame("ar_qpos"), self._ar_frame("ar_qvel"), m8)
+        self.sim.set_state(self._ar_frame("ar_qpos"), self._ar_frame("ar_qvel"), self._mask8(env_mask, self.device))
 
-    def step(self, a: torch.Tensor):
+    def step(self, a: torch.Tensor, need_obs: bool = True, cc_noise: torch.Tensor | None = None):
+        """One batched HumanoidAREnv.step.  need_obs=False skips get_ar_obs_v1 (a sampler that resets finished envs right after the step and
+        does not record next_states gets its observation from reset()); cc_noise [N, 75]: standard-normal draws for the UHC's exploration
+        made ahead by the caller.  The returned tensors live in two alternating buffer sets: valid until the next-but-one step()."""
         sim = self.sim
-        sim.step_begin()
-        sim.step_kin(a, self._next_qpos)
-        sim.set_target(self._ar_frame("ar_qpos") if self.ar_mode else self._next_qpos)     # ar_mode: the UHC tracks the kinematic roll-out (:263-264)
+        if self.ar_mode:                 # the UHC tracks the kinematic roll-out (:263-264)
+            sim.step_begin()
+            sim.set_target(self._ar_frame("ar_qpos"))
+        else:
+            sim.step_head(a)             # prev_bquat / prev_hpos, next_qpos = step_ar(a), target = qpos_fk(next_qpos): one launch
         rs = self.cc_running_state
         cc_obs = sim.obs_cc(self._cc_obs, rs.mean, rs.std, rs.clip)
         mean_action = self.mode == "test" or (self.mode == "train" and self.joint_controller)
         with torch.no_grad():
-            cc_action = self.cc_policy.select_action(cc_obs, mean_action, self.gen).contiguous()
+            cc_action = self.cc_policy.select_action(cc_obs, mean_action, self.gen, cc_noise).contiguous()
         sim.step_ctrl(cc_action, self.frame_skip)
         if self.obj7 is not None:
             sim.get("obj_qpos", self._obj35)
             self.obj7.copy_(torch.where(self._obj_has[:, None], torch.gather(self._obj35, 1, self._obj_cols), self.obj7))
-        self.cur_t += 1
-        reward, info6, fail, diffs = sim.term_reward(self._ctx_struct, self.reward_cfg, self._reward, self._info, self._fail, self._diffs)
-        end = self.cur_t >= self._t_end                  # cur_t >= env_episode_len or cur_t >= ar_context len (:291-293)
-        failed = fail.view(torch.bool).clone()           # the kernel writes 0 / 1 into a buffer the next step reuses
-        done = failed | end
-        obs = sim.obs_ar(self._ctx_struct, self._obs)
-        info = {"fail": failed, "end": end, "percent": self.cur_t / self._clen, "cc_action": cc_action, "cc_state": cc_obs,
-                "custom_reward": reward, "custom_info": info6, "body_diff": diffs}
-        return obs, self._unit_reward, done, info        # the env's own reward is the constant 1.0 (humanoid_ar_v1.py:311); one shared read-only tensor
+        # cur_t += 1; fail (body diffs), reward, end / done / percent in one launch (:288-316)
+        self._flip ^= 1
+        o = self._outs[self._flip]
+        sim.post_step(self._ctx_struct, self.reward_cfg, self.cur_t, self.row_len, int(min(self.env_episode_len, 2 ** 31 - 1)),
+                      o["reward"], o["info"], o["fail"], o["diffs"], o["done"], o["end"], o["percent"], self.done_count)
+        obs = sim.obs_ar(self._ctx_struct, self._obs_next) if need_obs else None
+        info = {"fail": o["fail"].view(torch.bool), "end": o["end"].view(torch.bool), "percent": o["percent"], "cc_action": cc_action, "cc_state": cc_obs,
+                "custom_reward": o["reward"], "custom_info": o["info"], "body_diff": o["diffs"]}
+        return obs, self._unit_reward, o["done"].view(torch.bool), info        # the env's own reward is the constant 1.0 (humanoid_ar_v1.py:311); one shared read-only tensor
 
     # getters (device tensors; reference names)
     def get_humanoid_qpos(self):

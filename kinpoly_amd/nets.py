@@ -105,28 +105,56 @@ class PolicyMCP(nn.Module):
             self._fused = (ver, tuple(t.detach().contiguous() for t in (w1, b1, w2, b2, w3, b3)))
         return self._fused[1]
 
-    def action_mean(self, x):
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+    def _primitives_fused(self, x):
+        """the K primitive MLPs as three (batched) GEMMs; returns their outputs in the GEMM's own layout [K, N, A]"""
+        w1, b1, w2, b2, w3, b3 = self._fuse()
+        K = self.num_primitive
+        h = torch._addmm_activation(b1, x, w1.t())                   # [N, K*h1], relu in the GEMM epilogue
+        h = h.view(x.shape[0], K, -1).transpose(0, 1)                # [K, N, h1]
+        h = torch.relu(torch.baddbmm(b2.unsqueeze(1), h, w2))        # [K, N, h2]
+        return torch.baddbmm(b3.unsqueeze(1), h, w3)                 # [K, N, A]
+
+    def _inference(self, x):
+        return not (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()))
+
+    def action_mean(self, x, noise=None):
+        """sum_k softmax(composer(x))_k * net_k(x).  Inference path on the device in fp32: three batched GEMMs for the primitives, the
+        composer's GEMMs, and ONE mixing kernel (kp_mcp_compose: softmax + weighted sum + optional mean + std * noise) that reads the last
+        GEMM's [K, N, A] output as it is -- instead of a transpose view, a softmax, a broadcast multiply, a sum and an addcmul."""
+        if not self._inference(x):
             x_all = torch.stack([net(x) for net in self.nets], dim=1)  # training path: plain modules
-        else:
-            w1, b1, w2, b2, w3, b3 = self._fuse()
-            K = self.num_primitive
-            h = torch._addmm_activation(b1, x, w1.t())                   # [N, K*h1], relu in the GEMM epilogue
-            h = h.view(x.shape[0], K, -1).transpose(0, 1)                # [K, N, h1]
-            h = torch.relu(torch.baddbmm(b2.unsqueeze(1), h, w2))        # [K, N, h2]
-            x_all = torch.baddbmm(b3.unsqueeze(1), h, w3).transpose(0, 1)  # [N, K, A]
-        weight = self.composer(x)
-        return torch.sum(weight[:, :, None] * x_all, dim=1)
+            return torch.sum(self.composer(x)[:, :, None] * x_all, dim=1)
+        prim = self._primitives_fused(x)
+        if x.is_cuda and x.dtype == torch.float32:
+            from . import sim as kpsim
+            logits = self.composer[0](x)                              # the composer MLP before its softmax
+            return kpsim.mcp_compose(logits.contiguous(), prim.contiguous(), noise, None if noise is None else self.std())
+        mean = torch.sum(self.composer(x)[:, :, None] * prim.transpose(0, 1), dim=1)
+        return mean if noise is None else torch.addcmul(mean, self.std().to(mean.dtype), noise)
+
+    def std(self):
+        """exp(action_log_std) [A], cached until the parameter changes (one launch less per env-step)"""
+        p = self.action_log_std
+        key = (p._version, p.data_ptr())
+        if getattr(self, "_std_key", None) != key:
+            self._std_key, self._std = key, torch.exp(p.detach()).reshape(-1).contiguous()
+        return self._std
 
     def forward(self, x):
         mean = self.action_mean(x)
         return mean, self.action_log_std.expand_as(mean)
 
-    def select_action(self, x, mean_action=False, generator=None):
-        mean, log_std = self.forward(x)
+    def select_action(self, x, mean_action=False, generator=None, noise=None):
+        """mean action, or a sample mean + exp(log_std) * eps; `noise` [N, A]: standard-normal draws made ahead by the caller (a rollout draws
+        the whole horizon's noise in one launch) instead of a randn here."""
         if mean_action:
-            return mean
-        return torch.addcmul(mean, torch.exp(log_std), torch.randn(mean.shape, device=mean.device, dtype=mean.dtype, generator=generator))
+            return self.action_mean(x)
+        if noise is None:
+            noise = torch.randn((x.shape[0], self.action_log_std.shape[1]), device=x.device, dtype=x.dtype, generator=generator)
+        if self._inference(x):
+            return self.action_mean(x, noise)
+        mean, log_std = self.forward(x)
+        return torch.addcmul(mean, torch.exp(log_std), noise)
 
 
 class _StepRNN(nn.Module):
@@ -156,12 +184,21 @@ class KinPolicy(nn.Module):
         x = torch.cat((state, hx), dim=1)
         return self.action_fc(self.action_mlp(x)), hx
 
-    def select_action(self, state, hx, mean_action=False, generator=None):
+    def std(self):
+        p = self.action_log_std
+        key = (p._version, p.data_ptr(), p.dtype)
+        if getattr(self, "_std_key", None) != key:
+            self._std_key, self._std = key, torch.exp(p.detach())
+        return self._std
+
+    def select_action(self, state, hx, mean_action=False, generator=None, noise=None):
+        """noise [N, A]: standard-normal draws made ahead by the caller (see PolicyMCP.select_action)"""
         mean, hx = self.get_action(state, hx)
         if mean_action:
             return mean, hx
-        noise = torch.randn(mean.shape, device=mean.device, dtype=mean.dtype, generator=generator)
-        return torch.addcmul(mean, torch.exp(self.action_log_std), noise), hx
+        if noise is None:
+            noise = torch.randn(mean.shape, device=mean.device, dtype=mean.dtype, generator=generator)
+        return torch.addcmul(mean, self.std(), noise), hx
 
     def log_prob(self, mean, action):
         """DiagGaussian.log_prob summed over the action dims (uhc/khrylib/rl/core/distributions.py:22-23)."""

@@ -194,17 +194,20 @@ class VectorSampler:
         hx0 = self.hx.clone()
         fr_num = float(env.ctx["qpos"].shape[1])
         exhausted = torch.zeros((), dtype=torch.int64, device=dev)
+        # the exploration noise of both policies for the whole horizon in one launch: [T, N, 80 kinematic + 75 UHC]
+        cc_mean = env.mode == "test" or (env.mode == "train" and env.joint_controller)
+        noise = None if (self.mean_action and cc_mean) else torch.randn((T, N, 155), device=dev, generator=env.gen)
         for t in range(T):
             S[:, t] = self.obs
             E[:, t] = self.fresh
-            action, self.hx = pol.select_action(self.obs, self.hx, self.mean_action, env.gen)
+            action, self.hx = pol.select_action(self.obs, self.hx, self.mean_action, env.gen, None if noise is None else noise[t, :, :80])
             action = action.contiguous()
             row = env.row.long()
             if self.record_qpos:
                 Q[:, t] = env.sim.get("qpos")
                 G[:, t] = env.ctx["qpos"][row, torch.minimum(env.cur_t.long() + 1, env.ctx_len.long())]
             meta = env.row_meta[row]
-            obs, _, done, info = env.step(action)
+            obs, _, done, info = env.step(action, need_obs=full, cc_noise=None if noise is None else noise[t, :, 80:])
             A[:, t] = action
             R[:, t] = info["custom_reward"]
             F[:, t] = info["fail"]
@@ -221,9 +224,9 @@ class VectorSampler:
                 self._replay = torch.where(done, over, self._replay)     # a finished env that found no fresh clip replays its last one
                 self.level = torch.where(over, self.level, nxt)
                 env.set_rows((self.level * N + ar).to(torch.int32), done)
-            self.obs = env.reset(done).clone()
+            self.obs = env.reset(done)          # env._obs: step() writes its own observation elsewhere, so this stays valid through the next step
             self.hx = self.hx.masked_fill(done.unsqueeze(1), 0.0)
-            self.fresh = done
+            self.fresh = D[:, t]                # `done` itself lives in a buffer the step after next reuses
         M = (~D).float()
         # one host transfer per call: finished episodes -> freq_dict, launch status
         status = int(env.sim.status_tensor()[2])

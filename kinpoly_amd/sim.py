@@ -35,6 +35,7 @@ ABI_SYMBOLS = [
     "kp_sim_timing_reset", "kp_sim_timing_mean_seconds", "kp_sim_phase_cycles", "kp_sim_set_objects", "kp_sim_set_obj_state",
     "kp_sim_launch_cost", "kp_job_schedule", "kp_sim_fk_backward", "kp_sim_set_stream", "kp_sim_status_device", "kp_sim_mass_matrix",
     "kp_sim_contacts", "kp_gae_bootstrap", "kp_gru_gates_forward", "kp_gru_gates_backward", "kp_sim_phase_cycles_env",
+    "kp_sim_post_step", "kp_sim_reset_rows", "kp_mcp_compose", "kp_sim_step_head",
 ]
 
 
@@ -81,6 +82,7 @@ def load_library(path: str | None = None):
     L.kp_sim_set_target.argtypes = [P, F, U8]; L.kp_sim_set_target.restype = C.c_int
     L.kp_sim_step_ctrl.argtypes = [P, F, C.c_int, U8]; L.kp_sim_step_ctrl.restype = C.c_int
     L.kp_sim_step_kin.argtypes = [P, F, F]; L.kp_sim_step_kin.restype = C.c_int
+    L.kp_sim_step_head.argtypes = [P, F]; L.kp_sim_step_head.restype = C.c_int
     L.kp_sim_obs_cc.argtypes = [P, F, F, F, C.c_float]; L.kp_sim_obs_cc.restype = C.c_int
     L.kp_field_dim.argtypes = [C.c_int]; L.kp_field_dim.restype = C.c_int
     L.kp_sim_get.argtypes = [P, C.c_int, F]; L.kp_sim_get.restype = C.c_int
@@ -89,6 +91,9 @@ def load_library(path: str | None = None):
     L.kp_sim_step_begin.argtypes = [P]; L.kp_sim_step_begin.restype = C.c_int
     L.kp_sim_obs_ar.argtypes = [P, C.POINTER(KpCtx), F]; L.kp_sim_obs_ar.restype = C.c_int
     L.kp_sim_term_reward.argtypes = [P, C.POINTER(KpCtx), C.POINTER(KpRewardCfg), F, F, U8, F]; L.kp_sim_term_reward.restype = C.c_int
+    L.kp_sim_post_step.argtypes = [P, C.POINTER(KpCtx), C.POINTER(KpRewardCfg), C.c_void_p, C.c_void_p, C.c_int, F, F, U8, F, U8, U8, F, C.c_void_p]; L.kp_sim_post_step.restype = C.c_int
+    L.kp_sim_reset_rows.argtypes = [P, F, F, C.c_void_p, U8, C.c_void_p, C.c_int]; L.kp_sim_reset_rows.restype = C.c_int
+    L.kp_mcp_compose.argtypes = [C.c_int, C.c_int, C.c_int, F, F, F, C.c_int, F, F, C.c_void_p]; L.kp_mcp_compose.restype = C.c_int
     L.kp_gae.argtypes = [C.c_int, C.c_int, F, F, F, C.c_float, C.c_float, F, F, C.c_void_p]; L.kp_gae.restype = C.c_int
     L.kp_gae_bootstrap.argtypes = [C.c_int, C.c_int, F, F, F, F, C.c_float, C.c_float, F, F, C.c_void_p]; L.kp_gae_bootstrap.restype = C.c_int
     L.kp_gru_gates_forward.argtypes = [C.c_int, C.c_int, F, F, F, F, F, F, C.c_void_p]; L.kp_gru_gates_forward.restype = C.c_int
@@ -234,6 +239,10 @@ class KpSim:
     def step_ctrl(self, cc_action, n_substeps=15, env_mask=None):
         _check(self.L.kp_sim_step_ctrl(self.h, _ptr(cc_action, self.n, CC_ACTION_DIM), int(n_substeps), _mask_ptr(env_mask, self.n)), "kp_sim_step_ctrl")
 
+    def step_head(self, kin_action):
+        """step_begin + step_kin + set_target(step_kin's result) in one launch (kp_sim_step_head)"""
+        _check(self.L.kp_sim_step_head(self.h, _ptr(kin_action, self.n, KIN_ACTION_DIM)), "kp_sim_step_head")
+
     def step_kin(self, kin_action, out=None):
         out = self._new(NQ) if out is None else out
         _check(self.L.kp_sim_step_kin(self.h, _ptr(kin_action, self.n, KIN_ACTION_DIM), _ptr(out, self.n, NQ)), "kp_sim_step_kin")
@@ -311,6 +320,21 @@ class KpSim:
                                          C.c_void_p(fail.data_ptr()), _ptr(diffs, self.n, 2)), "kp_sim_term_reward")
         return reward, info, fail, diffs
 
+    def post_step(self, ctx: "KpCtx", cfg: "KpRewardCfg", cur_t, row_len, episode_len, reward, info, fail, diffs, done, end, percent, done_count=None):
+        """cur_t += 1; termination + reward; end / done / percent -- the tail of HumanoidAREnv.step in one launch (kp_sim_post_step)."""
+        _check(self.L.kp_sim_post_step(self.h, C.byref(ctx), C.byref(cfg), C.c_void_p(cur_t.data_ptr()), C.c_void_p(row_len.data_ptr()), int(episode_len),
+                                       C.c_void_p(reward.data_ptr()), _ptr(info, self.n, 6), C.c_void_p(fail.data_ptr()), _ptr(diffs, self.n, 2),
+                                       C.c_void_p(done.data_ptr()), C.c_void_p(end.data_ptr()), C.c_void_p(percent.data_ptr()),
+                                       None if done_count is None else C.c_void_p(done_count.data_ptr())), "kp_sim_post_step")
+
+    def reset_rows(self, init_qpos, init_qvel, row=None, env_mask=None, cur_t=None, set_target=True):
+        """masked reset from context rows: state <- init rows, cur_t = 0, sim.forward(), target = FK(init) (kp_sim_reset_rows)."""
+        for t, d in ((init_qpos, NQ), (init_qvel, NV)):
+            if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.dim() == 2 and t.shape[1] == d):
+                raise ValueError("init rows must be contiguous float32 device tensors [R, dim]")
+        _check(self.L.kp_sim_reset_rows(self.h, C.c_void_p(init_qpos.data_ptr()), C.c_void_p(init_qvel.data_ptr()), None if row is None else C.c_void_p(row.data_ptr()),
+                                        _mask_ptr(env_mask, self.n), None if cur_t is None else C.c_void_p(cur_t.data_ptr()), int(bool(set_target))), "kp_sim_reset_rows")
+
     def diag(self) -> np.ndarray:
         out = np.zeros((self.n, 4), np.int32)
         _check(self.L.kp_sim_diag(self.h, out.ctypes.data_as(C.c_void_p)), "kp_sim_diag")
@@ -355,6 +379,25 @@ def job_schedule(n_substeps: int, substeps_per_job: int = 3, taper: bool = True)
     if n < 0:
         raise KinPolyNativeError(f"kp_job_schedule: {L.kp_last_error().decode()}")
     return list(out[:n])
+
+
+def mcp_compose(logits: torch.Tensor, prim: torch.Tensor, noise: torch.Tensor | None = None, std: torch.Tensor | None = None, out: torch.Tensor | None = None):
+    """sum_k softmax(logits)_k * prim[k] (+ std * noise): PolicyMCP's mixing stage in one launch (kp_mcp_compose).  logits [N, K], prim [K, N, A]
+    contiguous float32 device tensors; noise [N, A] may be a column slice of a wider buffer (row stride = noise.stride(0))."""
+    L = load_library()
+    K, n, A = prim.shape
+    if not (logits.is_cuda and logits.dtype == torch.float32 and logits.is_contiguous() and tuple(logits.shape) == (n, K) and prim.dtype == torch.float32 and prim.is_contiguous()):
+        raise ValueError("mcp_compose: logits [N, K] and prim [K, N, A] must be contiguous float32 device tensors")
+    nz, stride = None, 0
+    if noise is not None:
+        if not (noise.is_cuda and noise.dtype == torch.float32 and tuple(noise.shape) == (n, A) and noise.stride(1) == 1 and std is not None and std.is_contiguous() and std.numel() == A):
+            raise ValueError("mcp_compose: noise [N, A] (unit column stride) needs std [A]")
+        nz, stride = C.c_void_p(noise.data_ptr()), int(noise.stride(0))
+    out = torch.empty((n, A), device=prim.device, dtype=torch.float32) if out is None else out
+    stream = torch.cuda.current_stream(prim.device).cuda_stream
+    _check(L.kp_mcp_compose(n, K, A, C.c_void_p(logits.data_ptr()), C.c_void_p(prim.data_ptr()), nz, stride, None if std is None else C.c_void_p(std.data_ptr()),
+                            C.c_void_p(out.data_ptr()), C.c_void_p(stream)), "kp_mcp_compose")
+    return out
 
 
 def gae(rewards: torch.Tensor, masks: torch.Tensor, values: torch.Tensor, gamma: float, tau: float, last_values: torch.Tensor | None = None):

@@ -1,5 +1,5 @@
-"""Fold the rocprofv3 passes of tools/profile_bench.sh into the JSON bench.py reads (profiles/r02/pmc_bench_<workload>.json) and copy
-the kernel-stats CSV next to it.    python tools/make_pmc_summary.py <gpurun_out/r02_prof/WL> <workload> "<command>" """
+"""Fold the rocprofv3 passes of tools/profile_bench.sh into the JSON bench.py reads (profiles/r03/pmc_bench_<workload>.json) and copy
+the kernel-stats CSV next to it.    python tools/make_pmc_summary.py <gpurun_out/r03_prof/WL> <workload> "<command>" """
 import csv
 import glob
 import json
@@ -9,9 +9,10 @@ import sys
 
 src, wl, cmd = sys.argv[1], sys.argv[2], sys.argv[3]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-dst = os.path.join(ROOT, "gpurun_out", "r02_prof", "summary")
+dst = os.path.join(ROOT, "gpurun_out", "r03_prof", "summary")
 os.makedirs(dst, exist_ok=True)
 KERNEL = "kp_step_queue_kernel"
+N_SIMD, CLOCK_GHZ = 1024, 2.35          # 256 CUs x 4 SIMDs; shader clock under this kernel (tools/micro/queue_timeline.py)
 
 
 def counters(tag):
@@ -27,7 +28,7 @@ def counters(tag):
 
 def launch_ms():
     for path in glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True):
-        shutil.copy(path, os.path.join(dst, f"r02_kernel_stats_{wl}.csv"))
+        shutil.copy(path, os.path.join(dst, f"r03_kernel_stats_{wl}.csv"))
         with open(path) as f:
             for row in csv.DictReader(f):
                 if KERNEL in row.get("Name", ""):
@@ -47,5 +48,8 @@ if "FETCH_SIZE" in fs and "WRITE_SIZE" in ws:
 if "SQ_INSTS_VALU" in iss:
     out["issue"] = {"valu_insts_per_launch": iss.get("SQ_INSTS_VALU"), "salu_insts_per_launch": iss.get("SQ_INSTS_SALU"), "lds_insts_per_launch": iss.get("SQ_INSTS_LDS"),
                     "sq_wave_cycles_quad": cyc.get("SQ_WAVE_CYCLES"), "sq_busy_cycles_quad": cyc.get("SQ_BUSY_CYCLES"), "sq_active_inst_valu_quad": cyc.get("SQ_ACTIVE_INST_VALU")}
+if "issue" in out and out["issue"].get("sq_active_inst_valu_quad") and ms:
+    # SQ_ACTIVE_INST_VALU counts in units of 4 cycles summed over the SIMDs: fraction of the launch during which a SIMD issues VALU work
+    out["issue"]["valu_active_frac_of_launch"] = out["issue"]["sq_active_inst_valu_quad"] * 4.0 / (N_SIMD * ms * 1e-3 * CLOCK_GHZ * 1e9)
 json.dump(out, open(os.path.join(dst, f"pmc_bench_{wl}.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
