@@ -1,6 +1,9 @@
 """Record the fastest rocBLAS / hipBLASLt solution for every GEMM shape of the 4096-env rollout step with torch's TunableOp and
 write kinpoly_amd/assets/tunableop_gfx950.csv (read by kinpoly_amd.nets.enable_tuned_gemms).  Run on the GPU box:
-    python tools/tune_gemms.py && cp gpurun_out/tune/tunableop_gfx950_0.csv kinpoly_amd/assets/tunableop_gfx950.csv"""
+    python tools/tune_gemms.py && cp gpurun_out/tune/tunableop_gfx950_0.csv kinpoly_amd/assets/tunableop_gfx950.csv
+The update's shapes (98 304-row MLP GEMMs, the recurrent [4096, 1024] x [1024, 3072] addmm with bias, the weight-gradient GEMMs) are recorded by
+    KP_TUNE=1 KP_ITERS=1 python tools/update_profile.py        (writes gpurun_out/tune/tunableop_update_0.csv; merge the new rows into the asset)
+Round 3: the recurrent forward GEMM alone went 267 -> 183 us (it ran on the library's default pick), T_update 0.957 -> 0.846 s at 4096 x 24."""
 import os
 import sys
 
