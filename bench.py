@@ -518,6 +518,9 @@ def main():
                     torch.cuda.empty_cache()
                 except Exception as ex:
                     out["secondary_workloads"][wl] = {"error": f"{type(ex).__name__}: {ex}"[:200]}
+            # the headline's workload is named at top level, next to the other workloads' rates (round 1's headline was random_init)
+            out["workload_id"] = args.workload
+            out["values_by_workload"] = {args.workload: value, **{k: v.get("value") for k, v in out["secondary_workloads"].items()}}
             try:        # physics kernel alone on the contact-heavy object scenes (kp_step_queue_kernel<true>)
                 out["object_scenes"] = object_scene_launches(local_rank, args.threads_per_env)
             except Exception as ex:
