@@ -4,6 +4,9 @@
 //
 //   hipcc --offload-arch=gfx950 -O2 -Iinclude examples/c_abi_demo.cpp -Lkinpoly_amd -lkinpoly_sim -Wl,-rpath,'$ORIGIN/../kinpoly_amd' -o examples/c_abi_demo
 //   examples/c_abi_demo kinpoly_amd/assets/smpl_humanoid.kpm tests/golden/standing_neutral_qpos.f32 4096 10
+//   examples/c_abi_demo --compile assets/mujoco_models/humanoid_smpl_neutral_mesh_all.xml config/uhc/uhc.yml out.kpm     (needs no GPU)
+// The second form is mujoco_py.load_model_from_path's stand-in without Python: kp_model_compile reads the reference's XML, its STL meshes and
+// the PD-gain table of uhc.yml and writes the blob the first form loads (a model argument ending in .xml is compiled on the spot).
 //
 // Every call below is an entry point of include/kinpoly_sim.h; errors come back as negative return codes + kp_last_error().
 #include <hip/hip_runtime.h>
@@ -11,6 +14,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "kinpoly_sim.h"
@@ -19,13 +23,19 @@
 #define HK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
 int main(int argc, char** argv) {
+    if (argc >= 5 && std::string(argv[1]) == "--compile") {
+        if (kp_model_compile(argv[2], argv[3][0] == '-' ? nullptr : argv[3], argv[4]) != 0) { std::fprintf(stderr, "kp_model_compile: %s\n", kp_last_error()); return 1; }
+        std::printf("compiled %s -> %s\n", argv[2], argv[4]);
+        return 0;
+    }
     if (argc < 3) { std::fprintf(stderr, "usage: %s model.kpm standing_qpos.f32 [n_envs] [control_steps]\n", argv[0]); return 2; }
     const int n = argc > 3 ? std::atoi(argv[3]) : 4096, steps = argc > 4 ? std::atoi(argv[4]) : 10;
     std::vector<float> q0(KP_NQ);
     if (FILE* f = std::fopen(argv[2], "rb")) { size_t r = std::fread(q0.data(), sizeof(float), KP_NQ, f); std::fclose(f); if (r != KP_NQ) return 2; }
     else { std::perror(argv[2]); return 2; }
 
-    kp_model* model = kp_model_load(argv[1]);
+    const std::string mpath = argv[1];
+    kp_model* model = mpath.size() > 4 && mpath.substr(mpath.size() - 4) == ".xml" ? kp_model_load_xml(argv[1], std::getenv("KP_UHC_YML")) : kp_model_load(argv[1]);
     if (!model) { std::fprintf(stderr, "kp_model_load: %s\n", kp_last_error()); return 1; }
     hipStream_t stream;
     HK(hipStreamCreate(&stream));

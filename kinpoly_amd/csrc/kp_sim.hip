@@ -6,6 +6,8 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <cstdio>
+#include <unistd.h>
 #include <string>
 #include <vector>
 
@@ -861,3 +863,31 @@ double kp_sim_timing_mean_seconds(kp_sim* s, int* n_launches) {
 }
 
 }  // extern "C"
+
+// ---- model compiler behind the ABI (host only).  Included last: its `#pragma clang fp contract(off)` (bit-reproducible double arithmetic,
+// shared rule for rule with kinpoly_amd/model_compiler.py) must not reach the kernels above.
+#include "kp_compile.hpp"
+
+extern "C" {
+
+int kp_model_compile(const char* xml_path, const char* uhc_yml_path, const char* out_kpm_path) {
+    if (!xml_path || !out_kpm_path) return fail("kp_model_compile: null argument");
+    std::string err;
+    if (kpc::compile(xml_path, uhc_yml_path, out_kpm_path, err) != 0) return fail("kp_model_compile: " + err);
+    return 0;
+}
+
+kp_model* kp_model_load_xml(const char* xml_path, const char* uhc_yml_path) {
+    if (!xml_path) { fail("kp_model_load_xml: null argument"); return nullptr; }
+    char tmpl[] = "/tmp/kp_model_XXXXXX";
+    const int fd = mkstemp(tmpl);
+    if (fd < 0) { fail("kp_model_load_xml: cannot create a temporary file"); return nullptr; }
+    close(fd);
+    kp_model* m = nullptr;
+    if (kp_model_compile(xml_path, uhc_yml_path, tmpl) == 0) m = kp_model_load(tmpl);
+    std::remove(tmpl);
+    return m;
+}
+
+}  // extern "C"
+

@@ -75,38 +75,88 @@ def polyhedron_mass_props(tris: np.ndarray, density: float):
     Signed tetrahedra against the vertex centroid; |volume| per tetra so that the triangle
     winding does not matter for a convex hull (what MuJoCo 2.1's mesh compiler does for
     meshes, [MJ-ext]).  Inertia returned as full 3x3 in the mesh frame about the COM.
-    """
-    ref = tris.reshape(-1, 3).mean(axis=0)
-    a = tris[:, 0] - ref
-    b = tris[:, 1] - ref
-    c = tris[:, 2] - ref
-    vol6 = np.abs(np.einsum("ij,ij->i", a, np.cross(b, c)))  # 6 * tetra volume
-    vol = vol6 / 6.0
-    V = vol.sum()
-    cent = (a + b + c) / 4.0  # tetra centroid (4th vertex at origin=ref)
-    com_rel = (vol[:, None] * cent).sum(axis=0) / V
-    # second-moment integral over each tetra with one vertex at the origin:
-    #   int x x^T dV = V/20 * (sum_i v_i v_i^T + (sum_i v_i)(sum_i v_i)^T), v_0 = 0
-    s = a + b + c
-    C = np.zeros((3, 3))
-    for va in (a, b, c):
-        C += np.einsum("i,ij,ik->jk", vol / 20.0, va, va)
-    C += np.einsum("i,ij,ik->jk", vol / 20.0, s, s)
-    # shift covariance to the COM
-    C -= V * np.outer(com_rel, com_rel)
-    inertia = (np.trace(C) * np.eye(3) - C) * density
-    return V * density, ref + com_rel, inertia
+    Plain loops in the order kinpoly_amd/csrc/kp_compile.hpp::mass_props runs them (the two compilers write the same bytes)."""
+    ref = [0.0, 0.0, 0.0]
+    for t in tris:
+        for vtx in t:
+            ref = [ref[0] + float(vtx[0]), ref[1] + float(vtx[1]), ref[2] + float(vtx[2])]
+    n3 = 3.0 * float(len(tris))
+    ref = [ref[0] / n3, ref[1] / n3, ref[2] / n3]
+    V = 0.0
+    cr = [0.0, 0.0, 0.0]
+    C = [0.0] * 9
+    for t in tris:
+        a = [float(t[0][k]) - ref[k] for k in range(3)]; b = [float(t[1][k]) - ref[k] for k in range(3)]; c = [float(t[2][k]) - ref[k] for k in range(3)]
+        bc = [b[1] * c[2] - b[2] * c[1], b[2] * c[0] - b[0] * c[2], b[0] * c[1] - b[1] * c[0]]
+        vol = abs(a[0] * bc[0] + a[1] * bc[1] + a[2] * bc[2]) / 6.0
+        V += vol
+        for k in range(3):
+            cr[k] += vol * ((a[k] + b[k] + c[k]) / 4.0)
+        sv = [a[0] + b[0] + c[0], a[1] + b[1] + c[1], a[2] + b[2] + c[2]]
+        for q in (a, b, c, sv):
+            for i in range(3):
+                for j in range(3):
+                    C[3 * i + j] += (vol / 20.0) * q[i] * q[j]
+    cm = [cr[0] / V, cr[1] / V, cr[2] / V]
+    for i in range(3):
+        for j in range(3):
+            C[3 * i + j] -= V * cm[i] * cm[j]
+    tr = C[0] + C[4] + C[8]
+    inertia = np.array([[((tr if i == j else 0.0) - C[3 * i + j]) * density for j in range(3)] for i in range(3)])
+    return V * density, np.array([ref[0] + cm[0], ref[1] + cm[1], ref[2] + cm[2]]), inertia
 
 
-def hull_graph(v: np.ndarray):
-    """Vertex adjacency of the convex hull of `v` [n,3] (every row must be a hull vertex), as ordered neighbour lists.
+def eigh3(A):
+    """eigenvectors (columns) of a symmetric 3 x 3 by cyclic Jacobi rotations: the same sweeps as kp_compile.hpp::eigh3"""
+    a = [[float(A[i][j]) for j in range(3)] for i in range(3)]
+    v = [[1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0]]
+    for _ in range(64):
+        off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2]
+        if off < 1e-40:
+            break
+        for p in range(2):
+            for q in range(p + 1, 3):
+                if abs(a[p][q]) < 1e-300:
+                    continue
+                th = (a[q][q] - a[p][p]) / (2.0 * a[p][q])
+                tt = (1.0 if th >= 0 else -1.0) / (abs(th) + math.sqrt(th * th + 1.0))
+                c = 1.0 / math.sqrt(tt * tt + 1.0); s_ = tt * c
+                for k in range(3):
+                    akp, akq = a[k][p], a[k][q]; a[k][p] = c * akp - s_ * akq; a[k][q] = s_ * akp + c * akq
+                for k in range(3):
+                    apk, aqk = a[p][k], a[q][k]; a[p][k] = c * apk - s_ * aqk; a[q][k] = s_ * apk + c * aqk
+                for k in range(3):
+                    vkp, vkq = v[k][p], v[k][q]; v[k][p] = c * vkp - s_ * vkq; v[k][q] = s_ * vkp + c * vkq
+    return np.array(v)
 
-    MuJoCo's mesh compiler runs qhull ("qhull Qt": triangulated facets) on the mesh vertices and stores, per hull vertex, the
-    list of vertices it shares a facet edge with (`mesh_graph`; user_mesh.cc MakeGraph) [MJ-ext]: facets are visited in qhull's
-    order, and each facet appends, for each of its three vertices, the other two if not yet listed.  scipy.spatial.ConvexHull
-    drives the same qhull with the same option, so the lists -- and their order, which decides WHICH neighbours make contacts
-    when more than three qualify -- are rebuilt the same way here.  (What cannot be reproduced: MuJoCo's own vertex numbering
-    of the un-welded STL triangles, which only permutes ties.)"""
+
+def seq_sum(x, axis=-1):
+    """left-to-right sum (np.sum adds pairwise): the order the C++ compiler's loops accumulate in"""
+    return np.take(np.cumsum(x, axis=axis), -1, axis=axis)
+
+
+def gauss_jordan_inverse(A):
+    """Gauss-Jordan with partial pivoting, row operation by row operation as kp_compile.hpp::invert (LAPACK would round differently)"""
+    A = np.array(A, float); n = A.shape[0]
+    inv = np.eye(n)
+    for c in range(n):
+        p = c + int(np.argmax(np.abs(A[c:, c])))
+        if p != c:
+            A[[p, c]] = A[[c, p]]; inv[[p, c]] = inv[[c, p]]
+        d = 1.0 / A[c, c]
+        A[c] *= d; inv[c] *= d
+        for r in range(n):
+            if r != c and A[r, c] != 0.0:
+                f = A[r, c]
+                A[r] -= f * A[c]; inv[r] -= f * inv[c]
+    return inv
+
+
+def hull_graph_qhull(v: np.ndarray):
+    """Vertex adjacency of the convex hull of `v` [n,3] through qhull ("Qt": triangulated facets, the option MuJoCo's mesh compiler uses),
+    neighbour lists in qhull's facet order.  Kept as a cross-check of hull_graph's edge set (tests/test_host_cpu.py): the two agree except for
+    WHICH diagonal triangulates a coplanar face and for the order of a vertex's neighbours -- both are artefacts of qhull's run on ITS input order,
+    and MuJoCo's own input order (its STL import) cannot be reproduced anyway [MJ-ext]."""
     from scipy.spatial import ConvexHull
     h = ConvexHull(v, qhull_options="Qt")
     assert len(h.vertices) == len(v), "mesh has vertices inside its convex hull"
@@ -116,6 +166,77 @@ def hull_graph(v: np.ndarray):
             for c in range(3):
                 if c != a and int(tri[c]) not in lists[int(tri[a])]:
                     lists[int(tri[a])].append(int(tri[c]))
+    return lists
+
+
+def hull_graph(v: np.ndarray):
+    """Vertex adjacency of the convex hull of `v` [n,3] (every row a hull vertex, n <= 64), built by a rule that needs no library and that the
+    C++ compiler (kinpoly_amd/csrc/kp_compile.hpp) restates operation for operation, so both write the same graph:
+
+      * a vertex triple (i < j < k) spans a FACE when every other vertex lies on one side of its plane (|signed distance| <= 1e-9 m counts as
+        on the plane); the face is the set of all vertices on that plane;
+      * a face's boundary edges are hull edges; a face with more than three vertices (coplanar STL quads) is triangulated as a fan from its
+        lowest-numbered vertex, the fan's diagonals are edges too (MuJoCo's mesh graph comes from qhull's TRIANGULATED facets, so coplanar
+        faces contribute diagonals there as well -- which ones is qhull's business, see hull_graph_qhull);
+      * the neighbours of a vertex are listed in ascending vertex number (vertices are numbered by np.unique's lexicographic row order).
+
+    mjc_PlaneConvex takes the first maxplanemesh - 1 qualifying neighbours in list order; with MuJoCo's own vertex numbering unknowable, any
+    fixed order is as (un)verifiable as qhull's [MJ-ext]."""
+    n = len(v)
+    assert 4 <= n <= 64
+    tol = 1e-9
+    adj = np.zeros((n, n), bool)
+    seen = set()
+    for i in range(n):
+        for j in range(i + 1, n):
+            eij = v[j] - v[i]
+            for k in range(j + 1, n):
+                eik = v[k] - v[i]
+                nx = eij[1] * eik[2] - eij[2] * eik[1]; ny = eij[2] * eik[0] - eij[0] * eik[2]; nz = eij[0] * eik[1] - eij[1] * eik[0]
+                ln = math.sqrt(nx * nx + ny * ny + nz * nz)
+                if ln < 1e-14:
+                    continue
+                nx /= ln; ny /= ln; nz /= ln
+                pos = neg = False
+                face = []
+                for m in range(n):
+                    d = nx * (v[m][0] - v[i][0]) + ny * (v[m][1] - v[i][1]) + nz * (v[m][2] - v[i][2])
+                    if d > tol:
+                        pos = True
+                    elif d < -tol:
+                        neg = True
+                    else:
+                        face.append(m)
+                    if pos and neg:
+                        break
+                if pos and neg:
+                    continue
+                key = tuple(face)
+                if key in seen:
+                    continue
+                seen.add(key)
+                if pos:                                    # outward normal: every other vertex behind the plane
+                    nx, ny, nz = -nx, -ny, -nz
+                # order the face's vertices counter-clockwise about the outward normal, starting from its lowest-numbered vertex
+                cx = sum(v[m][0] for m in face) / len(face); cy = sum(v[m][1] for m in face) / len(face); cz = sum(v[m][2] for m in face) / len(face)
+                f0 = face[0]
+                ux, uy, uz = v[f0][0] - cx, v[f0][1] - cy, v[f0][2] - cz
+                wx, wy, wz = ny * uz - nz * uy, nz * ux - nx * uz, nx * uy - ny * ux      # n x u
+                ang = []
+                for m in face:
+                    px, py, pz = v[m][0] - cx, v[m][1] - cy, v[m][2] - cz
+                    ang.append((math.atan2(px * wx + py * wy + pz * wz, px * ux + py * uy + pz * uz), m))
+                ring = [f0] + [m for a_, m in sorted(x for x in ang if x[1] != f0)]
+                # angles of the others are measured from f0's direction: wrap negatives so that the ring runs 0 .. 2 pi
+                ring = [f0] + [m for a_, m in sorted(((a_ if a_ > 0 else a_ + 2 * math.pi), m) for a_, m in ang if m != f0)]
+                L = len(ring)
+                for t in range(L):
+                    a_, b_ = ring[t], ring[(t + 1) % L]
+                    adj[a_, b_] = adj[b_, a_] = True
+                for t in range(2, L - 1):                  # fan diagonals from the lowest-numbered vertex
+                    adj[f0, ring[t]] = adj[ring[t], f0] = True
+    lists = [[int(m) for m in np.nonzero(adj[i])[0]] for i in range(n)]
+    assert all(len(x) >= 3 for x in lists), "mesh has vertices inside its convex hull"
     return lists
 
 
@@ -199,9 +320,9 @@ def parse_xml(xml_path: str):
 
 # --------------------------------------------------------------------------- dynamics at qpos0 (numpy, host)
 def _mass_matrix_qpos0(parent, gpos, com_g, mass, inertia_w, dof_body, dof_axis, dof_is_trans, armature):
-    """Dense M(qpos0) = sum_b Jv^T m Jv + Jw^T I Jw  (kinetic-energy form; host-only, runs once)."""
+    """Dense M(qpos0) = sum_b Jv^T m Jv + Jw^T I Jw  (kinetic-energy form; host-only, runs once), accumulated in the order of
+    kp_compile.hpp (per body, per row d1: s = sum_k m Jv[k, d1] Jv[k, :] + Jw[k, :] (I Jw[:, d1])[k])."""
     nb, nv = len(parent), len(dof_body)
-    # ancestor mask
     anc = np.zeros((nb, nb), bool)
     for b in range(nb):
         k = b
@@ -220,11 +341,19 @@ def _mass_matrix_qpos0(parent, gpos, com_g, mass, inertia_w, dof_body, dof_axis,
             if dof_is_trans[d]:
                 Jv[:, d] = ax
             else:
+                r = com_g[b] - gpos[dof_body[d]]
                 Jw[:, d] = ax
-                Jv[:, d] = np.cross(ax, com_g[b] - gpos[dof_body[d]])
-        M += mass[b] * Jv.T @ Jv + Jw.T @ inertia_w[b] @ Jw
+                Jv[:, d] = [ax[1] * r[2] - ax[2] * r[1], ax[2] * r[0] - ax[0] * r[2], ax[0] * r[1] - ax[1] * r[0]]
+        I = inertia_w[b]
+        for d1 in range(nv):
+            iw = [(I[k, 0] * Jw[0, d1] + I[k, 1] * Jw[1, d1]) + I[k, 2] * Jw[2, d1] for k in range(3)]
+            srow = np.zeros(nv)
+            for k in range(3):
+                srow = srow + ((mass[b] * Jv[k, d1]) * Jv[k, :] + Jw[k, :] * iw[k])
+            M[d1, :] += srow
         Js.append((Jv, Jw))
-    M += np.diag(armature)
+    for d in range(nv):
+        M[d, d] += armature[d]
     return M, Js
 
 
@@ -256,13 +385,14 @@ def compile_model(xml_path: str, uhc_yml: str | None = None) -> dict:
         v = np.unique(tris.reshape(-1, 3), axis=0) - gpos[i]  # hull vertices in the body frame
         verts_all.append(v)
         vert_adr.append(vert_adr[-1] + len(v))
-        rbound[i] = np.linalg.norm(v, axis=1).max()      # bounding sphere about the BODY origin: the kernels' broad phase
+        rbound[i] = float(np.sqrt((v[:, 0] * v[:, 0] + v[:, 1] * v[:, 1]) + v[:, 2] * v[:, 2]).max())      # bounding sphere about the BODY origin: the kernels' broad phase
         # mjModel.geom_rbound of the mesh geom [MJ-ext]: MuJoCo's mesh compiler centres the mesh at its COM, rotates it to its
         # principal axes of inertia and keeps the half-sizes max |coordinate| of that frame as the geom's `size`; rbound of a mesh
         # (as of a box) is the norm of `size`.  mjc_PlaneConvex's "too close to the first contact" test is tolplanemesh * rbound.
-        _, axes = np.linalg.eigh(I)
-        half = np.abs((v + gpos[i] - com) @ axes).max(axis=0)
-        mesh_rbound[i] = float(np.linalg.norm(half))
+        axes = eigh3(I)
+        d = (v + gpos[i]) - com
+        half = [float(np.abs((d[:, 0] * axes[0, c] + d[:, 1] * axes[1, c]) + d[:, 2] * axes[2, c]).max()) for c in range(3)]
+        mesh_rbound[i] = math.sqrt(half[0] * half[0] + half[1] * half[1] + half[2] * half[2])
         lists = hull_graph(v)
         for lst in lists:
             nbr.extend(lst)
@@ -322,17 +452,19 @@ def compile_model(xml_path: str, uhc_yml: str | None = None) -> dict:
     # ---- qpos0 constants for the constraint model [MJ-ext: engine_setconst.c set0]
     com_g = gpos + ipos
     M0, Js = _mass_matrix_qpos0(parent, gpos, com_g, mass, inertia, dof_body, dof_axis, dof_trans, np.array(arm))
-    Minv = np.linalg.inv(M0)
+    Minv = gauss_jordan_inverse(M0)
     body_invw = np.zeros((nb, 2))
     for b in range(nb):
-        Jv, Jw = Js[b]
-        A = np.vstack([Jv, Jw]) @ Minv @ np.vstack([Jv, Jw]).T
-        body_invw[b, 0] = np.trace(A[:3, :3]) / 3.0
-        body_invw[b, 1] = np.trace(A[3:, 3:]) / 3.0
+        for part, J in enumerate(Js[b]):                      # trace of J Minv J^T over the three translational / rotational rows
+            tr = 0.0
+            for k in range(3):
+                t = seq_sum(Minv * J[k][None, :], axis=1)     # t[d1] = sum_d2 Minv[d1, d2] J[k, d2], left to right
+                tr += float(seq_sum(J[k] * t))
+            body_invw[b, part] = tr / 3.0
     dinv = np.diag(Minv).copy()
     dof_invw = dinv.copy()
-    dof_invw[0:3] = dinv[0:3].mean()
-    dof_invw[3:6] = dinv[3:6].mean()
+    dof_invw[0:3] = ((dinv[0] + dinv[1]) + dinv[2]) / 3.0
+    dof_invw[3:6] = ((dinv[3] + dinv[4]) + dinv[5]) / 3.0
     # (meaninertia: see the free-object section below -- it spans all dofs of the scene)
 
     # ---- floor
@@ -390,32 +522,61 @@ def compile_model(xml_path: str, uhc_yml: str | None = None) -> dict:
     obj_arm = float(px["joint_default"].get("armature", 0.0))
     obj_inertial = np.zeros((nobj, 13))
     obj_trace = 0.0
-    for oi in range(nobj):
-        gs = [g for g in obj_geoms if int(g[0]) == oi]
-        mo = sum(g[17] for g in gs)
-        com = sum(g[17] * g[5:8] for g in gs) / mo
-        Io = np.zeros((3, 3))
+    for oi in range(nobj):                                   # plain loops in kp_compile.hpp's order (same bytes from both compilers)
+        gs = [[float(x) for x in g] for g in obj_geoms if int(g[0]) == oi]
+        mo = 0.0
         for g in gs:
-            mg, sz, Rg = g[17], g[2:5], g[8:17].reshape(3, 3)
+            mo += g[17]
+        com = [0.0, 0.0, 0.0]
+        for g in gs:
+            for k in range(3):
+                com[k] += g[17] * g[5 + k]
+        com = [com[0] / mo, com[1] / mo, com[2] / mo]
+        Io = [0.0] * 9
+        for g in gs:
+            mg, sz, Rg = g[17], g[2:5], g[8:17]
             if int(g[1]) == 0:      # box, half sizes
-                Il = np.diag([mg / 3.0 * (sz[1] ** 2 + sz[2] ** 2), mg / 3.0 * (sz[0] ** 2 + sz[2] ** 2), mg / 3.0 * (sz[0] ** 2 + sz[1] ** 2)])
+                Il = [mg / 3.0 * (sz[1] * sz[1] + sz[2] * sz[2]), mg / 3.0 * (sz[0] * sz[0] + sz[2] * sz[2]), mg / 3.0 * (sz[0] * sz[0] + sz[1] * sz[1])]
             else:                   # cylinder along local z: radius, half height
-                ixx = mg * (3.0 * sz[0] ** 2 + (2.0 * sz[1]) ** 2) / 12.0
-                Il = np.diag([ixx, ixx, 0.5 * mg * sz[0] ** 2])
-            dd = g[5:8] - com
-            Io += Rg @ Il @ Rg.T + mg * (dd @ dd * np.eye(3) - np.outer(dd, dd))
+                ixx = mg * (3.0 * sz[0] * sz[0] + (2.0 * sz[1]) * (2.0 * sz[1])) / 12.0
+                Il = [ixx, ixx, 0.5 * mg * sz[0] * sz[0]]
+            dd = [g[5] - com[0], g[6] - com[1], g[7] - com[2]]
+            d2 = dd[0] * dd[0] + dd[1] * dd[1] + dd[2] * dd[2]
+            for i in range(3):
+                for j in range(3):
+                    s_ = 0.0
+                    for k in range(3):
+                        s_ += Rg[3 * i + k] * Il[k] * Rg[3 * j + k]
+                    Io[3 * i + j] += s_ + mg * ((d2 if i == j else 0.0) - dd[i] * dd[j])
         # generalized mass matrix of the free joint at the identity pose: dofs = [lin (world); ang (body axes, about the body origin)]
-        rx = np.array([[0, -com[2], com[1]], [com[2], 0, -com[0]], [-com[1], com[0], 0]])
-        Jv = np.hstack([np.eye(3), -rx]); Jw = np.hstack([np.zeros((3, 3)), np.eye(3)])
-        Mo = mo * Jv.T @ Jv + Jw.T @ Io @ Jw + obj_arm * np.eye(6)
-        A = np.vstack([Jv, Jw]) @ np.linalg.inv(Mo) @ np.vstack([Jv, Jw]).T
-        obj_inertial[oi] = [mo, *com, Io[0, 0], Io[1, 1], Io[2, 2], Io[0, 1], Io[0, 2], Io[1, 2],
-                            np.trace(A[:3, :3]) / 3.0, np.trace(A[3:, 3:]) / 3.0, obj_arm]
-        obj_trace += float(np.trace(Mo))
+        rx = [0.0, -com[2], com[1], com[2], 0.0, -com[0], -com[1], com[0], 0.0]
+        Jv = [[0.0] * 6 for _ in range(3)]; Jw = [[0.0] * 6 for _ in range(3)]
+        for i in range(3):
+            for j in range(3):
+                Jv[i][j] = 1.0 if i == j else 0.0; Jv[i][3 + j] = -rx[3 * i + j]; Jw[i][3 + j] = 1.0 if i == j else 0.0
+        Mo = np.zeros((6, 6))
+        for a_ in range(6):
+            for b_ in range(6):
+                s_ = 0.0
+                for k in range(3):
+                    s_ += mo * Jv[k][a_] * Jv[k][b_]
+                for k in range(3):
+                    for l_ in range(3):
+                        s_ += Jw[k][a_] * Io[3 * k + l_] * Jw[l_][b_]
+                Mo[a_, b_] = s_ + (obj_arm if a_ == b_ else 0.0)
+        Moi = gauss_jordan_inverse(Mo)
+        trv = trw = 0.0
+        for k in range(3):
+            for a_ in range(6):
+                for b_ in range(6):
+                    trv += Jv[k][a_] * Moi[a_, b_] * Jv[k][b_]; trw += Jw[k][a_] * Moi[a_, b_] * Jw[k][b_]
+        obj_inertial[oi] = [mo, *com, Io[0], Io[4], Io[8], Io[1], Io[2], Io[5], trv / 3.0, trw / 3.0, obj_arm]
+        for a_ in range(6):
+            obj_trace += float(Mo[a_, a_])
     # mjModel.stat.meaninertia is the mean diagonal of qM at qpos0 over ALL dofs of the scene, objects included, and the
     # solver's termination scale is 1 / (meaninertia * nv) with the scene's nv [MJ-ext]: both are kept as the reference has them.
     nv_full = nv + 6 * nobj
-    meaninertia = float((np.trace(M0) + obj_trace) / nv_full)
+    meaninertia = float((float(seq_sum(np.diag(M0))) + obj_trace) / nv_full)
 
     model = dict(
         dims=np.array([nb, nv, nv + 1, nu, nM, len(verts), len(px["objects"]), len(obj_geoms), condim], np.int32),

@@ -35,7 +35,7 @@ ABI_SYMBOLS = [
     "kp_sim_timing_reset", "kp_sim_timing_mean_seconds", "kp_sim_phase_cycles", "kp_sim_set_objects", "kp_sim_set_obj_state",
     "kp_sim_launch_cost", "kp_job_schedule", "kp_sim_fk_backward", "kp_sim_set_stream", "kp_sim_status_device", "kp_sim_mass_matrix",
     "kp_sim_contacts", "kp_gae_bootstrap", "kp_gru_gates_forward", "kp_gru_gates_backward", "kp_sim_phase_cycles_env",
-    "kp_sim_post_step", "kp_sim_reset_rows", "kp_mcp_compose", "kp_sim_step_head",
+    "kp_sim_post_step", "kp_sim_reset_rows", "kp_mcp_compose", "kp_sim_step_head", "kp_model_compile", "kp_model_load_xml",
 ]
 
 
@@ -72,6 +72,8 @@ def load_library(path: str | None = None):
     L = C.CDLL(path)
     P, F, U8 = C.c_void_p, C.c_void_p, C.c_void_p
     L.kp_model_load.restype = P; L.kp_model_load.argtypes = [C.c_char_p]
+    L.kp_model_compile.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p]; L.kp_model_compile.restype = C.c_int
+    L.kp_model_load_xml.restype = P; L.kp_model_load_xml.argtypes = [C.c_char_p, C.c_char_p]
     L.kp_model_free.argtypes = [P]
     L.kp_model_set_option.argtypes = [P, C.c_char_p, C.c_double]; L.kp_model_set_option.restype = C.c_int
     L.kp_model_get_option.argtypes = [P, C.c_char_p]; L.kp_model_get_option.restype = C.c_double
@@ -124,10 +126,20 @@ def _check(rc, what):
         raise KinPolyNativeError(f"{what}: {load_library().kp_last_error().decode()}")
 
 
+def compile_model_native(xml_path: str, uhc_yml: str | None, out_kpm: str):
+    """kp_model_compile: the XML + STL + uhc.yml -> blob compiler behind the C ABI (kinpoly_amd/csrc/kp_compile.hpp; needs no GPU)."""
+    L = load_library()
+    _check(L.kp_model_compile(xml_path.encode(), None if uhc_yml is None else uhc_yml.encode(), out_kpm.encode()), "kp_model_compile")
+
+
 class KpModel:
-    def __init__(self, kpm_path: str = DEFAULT_KPM, **options):
+    def __init__(self, kpm_path: str = DEFAULT_KPM, xml: tuple | None = None, **options):
+        """kpm_path: a compiled blob; or xml=(xml_path, uhc_yml_path or None): compile the reference's scene on the spot (kp_model_load_xml)."""
         self.L = load_library()
-        self.h = self.L.kp_model_load(kpm_path.encode())
+        if xml is not None:
+            self.h = self.L.kp_model_load_xml(xml[0].encode(), None if xml[1] is None else xml[1].encode())
+        else:
+            self.h = self.L.kp_model_load(kpm_path.encode())
         if not self.h:
             raise KinPolyNativeError(f"kp_model_load: {self.L.kp_last_error().decode()}")
         for k, v in options.items():

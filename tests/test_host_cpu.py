@@ -125,3 +125,105 @@ def test_job_schedule_host_logic():
                     assert all(a >= b for a, b in zip(sz[1:], sz[2:]))
     with pytest.raises(kpsim.KinPolyNativeError):
         kpsim.job_schedule(0, 3, True)
+
+
+# ------------------------------------------------------------------ the model compiler behind the C ABI (kp_model_compile; needs no GPU)
+def _write_stl(path, verts, faces):
+    import struct
+    with open(path, "wb") as f:
+        f.write(b"\0" * 80 + struct.pack("<I", len(faces)))
+        for a, b, c in faces:
+            f.write(struct.pack("<12fH", 0.0, 0.0, 0.0, *verts[a], *verts[b], *verts[c], 0))
+
+
+def _toy_scene(tmp):
+    """a three-body tree (free root + two 3-hinge children) on irregular octahedron hulls, a plane and one free box + cylinder object: the
+    constructs of the reference's XML (assets/mujoco_models/humanoid_smpl_neutral_mesh_all_step.xml) in miniature, written by the test"""
+    rng = np.random.default_rng(7)
+    faces = [(0, 2, 4), (2, 1, 4), (1, 3, 4), (3, 0, 4), (2, 0, 5), (1, 2, 5), (3, 1, 5), (0, 3, 5)]
+    os.makedirs(os.path.join(tmp, "geom"))
+    pos = {"A": (0.1, -0.2, 0.9), "B": (0.2, -0.1, 0.5), "C": (0.25, -0.15, 0.1)}
+    for nm, p in pos.items():
+        base = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], float) * rng.uniform(0.05, 0.12, size=(6, 1))
+        v = (base + rng.normal(size=(6, 3)) * 0.005 + np.array(p)).astype(np.float32)
+        _write_stl(os.path.join(tmp, "geom", nm + ".stl"), v.tolist(), faces)
+    hinges = lambda n, p: "".join(f'<joint name="{n}_{a}" type="hinge" pos="{p[0]} {p[1]} {p[2]}" axis="{ax}" range="-180 180"/>'     # noqa: E731
+                                  for a, ax in (("z", "0 0 1"), ("y", "0 1 0"), ("x", "1 0 0")))
+    xml = f"""<mujoco model="toy">
+  <compiler angle="degree" inertiafromgeom="true" coordinate="global"/>
+  <!-- a comment with <tags/> inside -->
+  <default><joint damping="0.0" armature="0.01" limited="true"/><geom condim="1" margin="0.001" conaffinity="7"/></default>
+  <option timestep="0.002"/>
+  <asset><mesh file="./geom/A.stl"/><mesh file="./geom/B.stl"/><mesh file="./geom/C.stl"/></asset>
+  <worldbody>
+    <geom condim="3" friction="1. .1 .1" name="floor" pos="0 0 0" size="100 100 .2" type="plane"/>
+    <body name="A" pos="0.1 -0.2 0.9"><joint name="A" pos="0.1 -0.2 0.9" limited="false" type="free" armature="0"/><geom type="mesh" mesh="A"/>
+      <body name="B" pos="0.2 -0.1 0.5">{hinges("B", pos["B"])}<geom type="mesh" mesh="B"/>
+        <body name="C" pos="0.25 -0.15 0.1">{hinges("C", pos["C"])}<geom type="mesh" mesh="C"/></body>
+      </body>
+    </body>
+    <body name="thing" pos="0 0 0"><joint limited="false" name="thing" type="free"/>
+      <geom type="box" size="0.2 0.1 0.05" pos="0 0.1 -0.2" euler="14 0 30" condim="3" mass="3.5"/>
+      <geom type="cylinder" size="0.03 0.2" pos="0.1 0 0.1" condim="3" mass="1.25"/></body>
+  </worldbody>
+</mujoco>
+"""
+    open(os.path.join(tmp, "toy.xml"), "w").write(xml)
+    yml = ("residual_force_scale: 150.0\njoint_params:\n  # name, kp, kd, a_ref, a_scale, torque_limit\n" +
+           "".join(f'  - ["{b}_{a}" , {100.0 + 10 * i}, {10.0 + i}, 0.0, 1.0, {50.0 + i}]\n' for i, (b, a) in enumerate((b, a) for b in "BC" for a in "zyx")) +
+           'body_params:\n- ["B" , 1.0]\n- ["C" , 0.0]\ndata_specs:\n  dataset_name: toy\n  base_rot: [0.5, 0.5, 0.5, 0.5]\n')
+    open(os.path.join(tmp, "toy.yml"), "w").write(yml)
+    return os.path.join(tmp, "toy.xml"), os.path.join(tmp, "toy.yml")
+
+
+def test_native_model_compiler_writes_the_python_compilers_bytes(tmp_path):
+    """kp_model_compile (kinpoly_amd/csrc/kp_compile.hpp: XML subset reader, binary STL, mesh inertia, hull graph, M(qpos0) and its
+    inverse, uhc.yml gains, free objects) against kinpoly_amd/model_compiler.py, the compiler the shipped blobs and every fixture came
+    from: the two blobs are equal BYTE FOR BYTE on a scene the test writes itself and -- where the reference tree is present -- on both of
+    the reference's scenes; the shipped blobs are what either compiler writes."""
+    from kinpoly_amd import model_compiler as mc
+    from kinpoly_amd import sim
+    xml, yml = _toy_scene(str(tmp_path))
+    a, b = str(tmp_path / "native.kpm"), str(tmp_path / "python.kpm")
+    sim.compile_model_native(xml, yml, a)
+    mc.write_kpm(mc.compile_model(xml, yml), b)
+    ka, kb = mc.read_kpm(a), mc.read_kpm(b)
+    assert list(ka) == list(kb)
+    for k in kb:
+        if not k.startswith("_"):
+            assert ka[k].tobytes() == kb[k].tobytes(), k
+    assert open(a, "rb").read() == open(b, "rb").read()
+    assert ka["dims"][0] == 3 and ka["dims"][1] == 12 and ka["dims"][6] == 1 and ka["dims"][7] == 2 and ka["opt"][17] == 150.0 and list(ka["uhc_b_diffw"]) == [1.0, 1.0, 0.0]
+    # errors come back as return codes with a text, not as crashes
+    with pytest.raises(sim.KinPolyNativeError, match="cannot read"):
+        sim.compile_model_native(str(tmp_path / "missing.xml"), None, a)
+    open(tmp_path / "bad.xml", "w").write('<mujoco><compiler angle="radian"/></mujoco>')
+    with pytest.raises(sim.KinPolyNativeError, match="compiler element"):
+        sim.compile_model_native(str(tmp_path / "bad.xml"), None, a)
+    ref = "/root/reference/assets/mujoco_models/"
+    if os.path.exists(ref + "humanoid_smpl_neutral_mesh_all.xml"):
+        for name, shipped in (("humanoid_smpl_neutral_mesh_all.xml", mc.DEFAULT_KPM), ("humanoid_smpl_neutral_mesh_all_step.xml", mc.STEP_KPM)):
+            sim.compile_model_native(ref + name, "/root/reference/config/uhc/uhc.yml", a)
+            assert open(a, "rb").read() == open(shipped, "rb").read(), f"{shipped} is not what kp_model_compile writes from {name}"
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/assets/mujoco_models/humanoid_smpl_neutral_mesh_all.xml"), reason="reference tree not present")
+def test_python_model_compiler_and_hull_graph_against_qhull():
+    """(build container only: needs the reference's XML + STL) the Python compiler writes the shipped blob byte for byte, and the hull
+    graph's EDGE SET -- built by the compilers' own rule -- is qhull's ("Qt", what MuJoCo's mesh compiler runs) on all 24 hulls; only the
+    order of a vertex's neighbours differs (ascending vertex number here, qhull's facet order there; MuJoCo's own cannot be known)."""
+    from kinpoly_amd import model_compiler as mc
+    xml = "/root/reference/assets/mujoco_models/humanoid_smpl_neutral_mesh_all.xml"
+    m = mc.compile_model(xml, "/root/reference/config/uhc/uhc.yml")
+    import tempfile
+    with tempfile.TemporaryDirectory() as t:
+        mc.write_kpm(m, os.path.join(t, "m.kpm"))
+        assert open(os.path.join(t, "m.kpm"), "rb").read() == open(mc.DEFAULT_KPM, "rb").read()
+    adr, va, nb_ = m["vert_adr"], m["vert_nbr_adr"], m["vert_nbr"]
+    verts = m["verts"].reshape(-1, 3)
+    for b in range(24):
+        v = verts[adr[b]:adr[b + 1]]
+        mine = {(i, int(j)) for i in range(len(v)) for j in nb_[va[adr[b] + i]:va[adr[b] + i + 1]]}
+        qh = mc.hull_graph_qhull(v)
+        assert mine == {(i, j) for i in range(len(v)) for j in qh[i]}, f"hull {b}"
+        assert len(mine) == 2 * (3 * len(v) - 6)          # a triangulated convex polyhedron: E = 3 V - 6
