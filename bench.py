@@ -113,21 +113,23 @@ def rollout_steps(sampler, k, a_track=None, wild=False, follow_clip=False):
     with torch.no_grad():
         # exploration noise of the whole call in one launch: 80 kinematic + 75 UHC (+ 80 for the stand-in action's noise)
         noise = None if wild else torch.randn((k, env.n, 235), device=env.device, generator=env.gen)
+        a_noisy = None
+        if a_track is not None and not wild and not follow_clip:        # the stand-in actions of the whole call in one launch, like the noise
+            a_noisy = torch.add(a_track.unsqueeze(0), noise[:, :, 155:], alpha=0.04)
         for t in range(k):
             action, sampler.hx = pol.select_action(sampler.obs, sampler.hx, wild, env.gen, None if wild else noise[t, :, :80])
             if follow_clip:                                      # moving clips (objects workload): the action that reproduces the clip's NEXT pose
                 qn = env._ar_frame("qpos")
                 a_track = torch.cat([qn[:, 2:3], sampler.obs[:, 1:5], qn[:, 7:], torch.zeros((env.n, 6), device=env.device)], 1)
             if a_track is not None:                              # the policy's GEMMs ran; a trained policy's output stands in for theirs
-                action = a_track if wild else torch.add(a_track, noise[t, :, 155:], alpha=0.04)
+                action = a_track if wild else (a_noisy[t] if a_noisy is not None else torch.add(a_track, noise[t, :, 155:], alpha=0.04))
             obs, _, done, info = env.step(action.contiguous(), need_obs=False, cc_noise=None if wild else noise[t, :, 80:155])
             if wild:
                 early = done & (info["percent"] != 1)
                 env.ar_fail_safe(early)                          # masked, device side
                 done = done & ~early
                 n_early += early.sum()
-            sampler.obs = env.reset(done)
-            sampler.hx = sampler.hx.masked_fill(done.unsqueeze(1), 0.0)
+            sampler.obs = env.reset(done, policy_state=sampler.hx)        # finished envs: state, target, observation and the GRU state in one pass
     return n_early if wild else env.done_count.to(torch.int64)[0]       # episodes ended: counted inside kp_sim_post_step
 
 

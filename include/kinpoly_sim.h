@@ -176,8 +176,12 @@ int kp_sim_post_step(kp_sim*, const kp_ctx* ctx, const kp_reward_cfg* cfg, int32
 
 /* Masked reset in one gather + sim.forward() (mujoco_env.py:86-103, humanoid_ar_v1.py:334-387): for the envs with env_mask != 0 (NULL: all)
  * qpos / qvel <- init_qpos / init_qvel [R, 76] / [R, 75] of context row row[e] (NULL: row e), cur_t[e] = 0 (cur_t may be NULL), warm start
- * zeroed, derived quantities recomputed; set_target != 0: target = qpos_fk(init_qpos) for those envs as reset_model does (:384-386). */
-int kp_sim_reset_rows(kp_sim*, const float* init_qpos, const float* init_qvel, const int32_t* row, const uint8_t* env_mask, int32_t* cur_t, int set_target);
+ * zeroed, derived quantities recomputed; set_target != 0: target = qpos_fk(init_qpos) for those envs as reset_model does (:384-386).
+ * aux_rows (optional, may be NULL): caller-owned float [N, aux_cols] device rows zeroed for the same envs -- per-episode state that lives
+ * outside the simulator, i.e. the kinematic policy's GRU hidden state (PolicyAR.reset / action_rnn.initialize at every episode start,
+ * kin_poly/models/policy_ar.py:124-131). */
+int kp_sim_reset_rows(kp_sim*, const float* init_qpos, const float* init_qvel, const int32_t* row, const uint8_t* env_mask, int32_t* cur_t, int set_target,
+                      float* aux_rows, int aux_cols);
 
 /* estimate_advantages before normalisation (uhc/khrylib/rl/core/common.py:5-20) on an env-major
  * [N,T] layout (each env's T rows contiguous, time increasing).  All pointers device, float32. */
@@ -193,6 +197,21 @@ int kp_gae_bootstrap(int n_envs, int T, const float* rewards, const float* masks
  * out [n, A] = sum_k softmax(logits [n, K])_k * prim [K, n, A]  (+ stdv [A] * noise [n, A], rows noise_stride floats apart, when noise != NULL).
  * All device float32; logits are the composer MLP's output BEFORE its softmax. */
 int kp_mcp_compose(int n, int K, int A, const float* logits, const float* prim, const float* noise, int noise_stride, const float* stdv, float* out, void* hip_stream);
+
+/* PolicyMCP's last layer AND its mixing stage in one fp32 MFMA kernel (same reference lines): with h2 [K, n, J] the raw output of the second
+ * batched GEMM (no bias, no activation), b2 [K, J], w3 [K, J, ldw >= A] (= nets[k][1].weight^T stacked, rows ldw floats apart; with ldw >= 80,
+ * ldw % 4 == 0 and a 16-byte aligned base the kernel reads it with 16-byte loads: pad the rows to 80), b3 [K, A]:
+ *   out [n, A] = sum_k softmax(logits [n, K])_k * (b3[k] + relu(h2[k] + b2[k]) w3[k])   (+ stdv [A] * noise [n, A] as above)
+ * K <= 16, J a multiple of 64, A <= 80.  All device float32, contiguous except noise (row stride noise_stride). */
+int kp_mcp_tail(int n, int K, int J, int A, const float* h2, const float* b2, const float* w3, int ldw, const float* b3, const float* logits, const float* noise,
+                int noise_stride, const float* stdv, float* out, void* hip_stream);
+
+/* One roll-out step of torch.nn.GRUCell after its two gate GEMMs (TrajARNet.get_action, kin_poly/models/traj_ar_smpl_net.py:333-343;
+ * RNN.forward in step mode, uhc/khrylib/models/rnn.py:24-36): gi [n, 3H] = x W_ih^T and gh [n, 3H] = h_in W_hh^T WITHOUT biases, b_ih / b_hh [3H]
+ * -> h_out [n, H] (may alias h_in); xcat (optional) [n, D + H] <- [state | h_out], the row `torch.cat((state, hx), dim=1)` builds for
+ * the action MLP (state [n, D], D <= H). */
+int kp_gru_cell_step(int n, int H, int D, const float* gi, const float* gh, const float* b_ih, const float* b_hh, const float* h_in, const float* state,
+                     float* h_out, float* xcat, void* hip_stream);
 
 /* GRU re-unroll of the PPO / supervised updates (policy_ar.py:104-122, 216-240), one time step of torch.nn.GRUCell
  * semantics over n rows, all arrays contiguous float32 device pointers:

@@ -169,9 +169,10 @@ __global__ __launch_bounds__(256) void k_term_reward(int n, CtxDev C, RewardW W,
 // launch instead of a masked fill, an index conversion, two gathers and three masked row copies; sim.forward() and the target FK follow.
 __global__ void k_reset_rows(int n, const float* __restrict__ init_qpos, const float* __restrict__ init_qvel, const int* __restrict__ row,
                              const uint8_t* __restrict__ mask, int* __restrict__ cur_t, float* __restrict__ qpos, float* __restrict__ qvel,
-                             float* __restrict__ qpos_d, float* __restrict__ qvel_d, float* __restrict__ warm) {
+                             float* __restrict__ qpos_d, float* __restrict__ qvel_d, float* __restrict__ warm, float* __restrict__ aux_rows, int aux_cols) {
     const int e = blockIdx.x, i = threadIdx.x;          // one 128-thread block per env
     if (e >= n || (mask && !mask[e])) return;
+    for (int c = i; c < aux_cols; c += 128) aux_rows[(size_t)e * aux_cols + c] = 0.f;      // the caller's per-env rows that die with the episode (a recurrent policy's hidden state)
     const size_t r = row ? (size_t)row[e] : (size_t)e;
     if (i < D_NQ) { const float v = init_qpos[r * D_NQ + i]; qpos[(size_t)e * D_NQ + i] = v; qpos_d[(size_t)e * D_NQ + i] = v; }
     if (i < D_NV) { const float v = init_qvel[r * D_NV + i]; qvel[(size_t)e * D_NV + i] = v; qvel_d[(size_t)e * D_NV + i] = v; warm[(size_t)e * D_NV + i] = 0.f; }

@@ -15,6 +15,7 @@
 #include "kp_model.hpp"
 #include "kp_obs_kernels.hpp"
 #include "kp_rollout_kernels.hpp"
+#include "kp_policy_kernels.hpp"
 #include "kp_step_kernel.hpp"
 
 namespace {
@@ -713,10 +714,12 @@ int kp_sim_post_step(kp_sim* s, const kp_ctx* c, const kp_reward_cfg* w, int32_t
     return 0;
 }
 
-int kp_sim_reset_rows(kp_sim* s, const float* init_qpos, const float* init_qvel, const int32_t* row, const uint8_t* mask, int32_t* cur_t, int set_target) {
-    if (!s || !init_qpos || !init_qvel) return fail("kp_sim_reset_rows: null argument");
+int kp_sim_reset_rows(kp_sim* s, const float* init_qpos, const float* init_qvel, const int32_t* row, const uint8_t* mask, int32_t* cur_t, int set_target,
+                      float* aux_rows, int aux_cols) {
+    if (!s || !init_qpos || !init_qvel || (aux_rows && aux_cols <= 0)) return fail("kp_sim_reset_rows: null argument");
     HIP_OK(hipSetDevice(s->device));
-    hipLaunchKernelGGL(kp::k_reset_rows, dim3(s->n), dim3(128), 0, s->stream, s->n, init_qpos, init_qvel, row, mask, cur_t, s->qpos, s->qvel, s->qpos_d, s->qvel_d, s->warm);
+    hipLaunchKernelGGL(kp::k_reset_rows, dim3(s->n), dim3(128), 0, s->stream, s->n, init_qpos, init_qvel, row, mask, cur_t, s->qpos, s->qvel, s->qpos_d, s->qvel_d, s->warm,
+                       aux_rows, aux_rows ? aux_cols : 0);
     HIP_OK(hipGetLastError());
     if (int rc = launch_step(s, nullptr, 0, mask, false)) return rc;      // sim.forward(): derived quantities at the new state
     if (set_target) {                                                     // target = smpl_humanoid.qpos_fk(init_qpos) (humanoid_ar_v1.py:384-386): the state just written
@@ -742,6 +745,32 @@ int kp_mcp_compose(int n, int K, int A, const float* logits, const float* prim, 
     if (n <= 0 || K <= 0 || K > 64 || A <= 0 || !logits || !prim || !out || (noise && !stdv)) return fail("kp_mcp_compose: bad arguments");
     const size_t tot = (size_t)n * A;
     hipLaunchKernelGGL(kp::k_mcp_compose, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, K, A, logits, prim, noise, noise_stride, stdv, out);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int kp_mcp_tail(int n, int K, int J, int A, const float* h2, const float* b2, const float* w3, int ldw, const float* b3, const float* logits, const float* noise,
+                int noise_stride, const float* stdv, float* out, void* stream) {
+    if (n <= 0 || K <= 0 || K > 16 || J <= 0 || J % kp::MCP_CHUNK || A <= 0 || A > 80 || ldw < A || !h2 || !b2 || !w3 || !b3 || !logits || !out || (noise && !stdv))
+        return fail("kp_mcp_tail: bad arguments (K <= 16 primitives, hidden width a multiple of 64, A <= 80 actions, ldw >= A)");
+    const dim3 grid((unsigned)((n + 15) / 16)), block(64 * kp::MCP_WAVES);
+    hipStream_t st = (hipStream_t)stream;
+#define KP_TAIL(NT, V) hipLaunchKernelGGL((kp::k_mcp_tail<NT, V>), grid, block, 0, st, n, K, J, A, h2, b2, w3, ldw, b3, logits, noise, noise_stride, stdv, out)
+    if (A <= 16) KP_TAIL(1, false);
+    else if (A <= 48) KP_TAIL(3, false);
+    else if (ldw >= 80 && ldw % 4 == 0 && ((uintptr_t)w3 & 15) == 0) KP_TAIL(5, true);      // rows padded to 80 columns: 16-byte operand loads
+    else KP_TAIL(5, false);
+#undef KP_TAIL
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int kp_gru_cell_step(int n, int H, int D, const float* gi, const float* gh, const float* b_ih, const float* b_hh, const float* h_in, const float* state,
+                     float* h_out, float* xcat, void* stream) {
+    if (n <= 0 || H <= 0 || !gi || !gh || !b_ih || !b_hh || !h_in || !h_out || (xcat && (!state || D <= 0 || D > H)))
+        return fail("kp_gru_cell_step: bad arguments (the [state | h] row needs state and 0 < D <= H)");
+    const size_t tot = (size_t)n * H;
+    hipLaunchKernelGGL(kp::k_gru_cell_step, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, H, D, gi, gh, b_ih, b_hh, h_in, state, h_out, xcat);
     HIP_OK(hipGetLastError());
     return 0;
 }

@@ -201,9 +201,10 @@ class BatchedHumanoidAREnv:
         m = env_mask.to(device)
         return (m.view(torch.uint8) if m.dtype == torch.bool else m.to(torch.uint8)).contiguous()
 
-    def reset(self, env_mask: torch.Tensor | None = None):
+    def reset(self, env_mask: torch.Tensor | None = None, policy_state: torch.Tensor | None = None):
         """sim.reset(); cur_t = 0; reset_model(): state <- ar_context init_qpos/init_qvel, target = FK(init) (:334-387).  The humanoid's part is
-        one gather launch + sim.forward() + the target FK (kp_sim_reset_rows)."""
+        one gather launch + sim.forward() + the target FK (kp_sim_reset_rows).  policy_state [N, H] (optional): the caller's recurrent policy
+        state, zeroed in place for the same envs by that launch (PolicyAR.reset at every episode start, policy_ar.py:124-131)."""
         m8 = self._mask8(env_mask, self.device)
         if self.obj_qpos is not None:
             mb = None if m8 is None else m8.view(torch.bool)
@@ -217,7 +218,7 @@ class BatchedHumanoidAREnv:
             self.sim.set_objects(self.obj_qpos, m8)
             fresh = torch.where(self._obj_has[:, None], torch.gather(self.obj_qpos, 1, self._obj_cols), self._row_obj7[r])
             self.obj7.copy_(fresh if mb is None else torch.where(mb[:, None], fresh, self.obj7))
-        self.sim.reset_rows(self._init_q, self._init_v, self.row, m8, self.cur_t, set_target=True)
+        self.sim.reset_rows(self._init_q, self._init_v, self.row, m8, self.cur_t, set_target=True, aux_rows=policy_state)
         return self.sim.obs_ar(self._ctx_struct, self._obs)
 
     def _ar_frame(self, key):

@@ -102,12 +102,13 @@ class PolicyMCP(nn.Module):
             b2 = torch.stack([n[0].affine_layers[1].bias for n in self.nets], 0)
             w3 = torch.stack([n[1].weight.t() for n in self.nets], 0)
             b3 = torch.stack([n[1].bias for n in self.nets], 0)
-            self._fused = (ver, tuple(t.detach().contiguous() for t in (w1, b1, w2, b2, w3, b3)))
+            w3p = torch.nn.functional.pad(w3, (0, 80 - w3.shape[2])) if 48 < w3.shape[2] < 80 else w3      # rows of 80: kp_mcp_tail's 16-byte operand loads
+            self._fused = (ver, tuple(t.detach().contiguous() for t in (w1, b1, w2, b2, w3, b3, w3p)))
         return self._fused[1]
 
     def _primitives_fused(self, x):
         """the K primitive MLPs as three (batched) GEMMs; returns their outputs in the GEMM's own layout [K, N, A]"""
-        w1, b1, w2, b2, w3, b3 = self._fuse()
+        w1, b1, w2, b2, w3, b3, _ = self._fuse()
         K = self.num_primitive
         h = torch._addmm_activation(b1, x, w1.t())                   # [N, K*h1], relu in the GEMM epilogue
         h = h.view(x.shape[0], K, -1).transpose(0, 1)                # [K, N, h1]
@@ -118,17 +119,23 @@ class PolicyMCP(nn.Module):
         return not (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()))
 
     def action_mean(self, x, noise=None):
-        """sum_k softmax(composer(x))_k * net_k(x).  Inference path on the device in fp32: three batched GEMMs for the primitives, the
-        composer's GEMMs, and ONE mixing kernel (kp_mcp_compose: softmax + weighted sum + optional mean + std * noise) that reads the last
-        GEMM's [K, N, A] output as it is -- instead of a transpose view, a softmax, a broadcast multiply, a sum and an addcmul."""
+        """sum_k softmax(composer(x))_k * net_k(x).  Inference path on the device in fp32: two (batched) library GEMMs for the primitives' hidden
+        layers, the composer's GEMMs, and ONE fp32 MFMA kernel (kp_mcp_tail) for the rest -- second-layer bias + relu, the K output layers,
+        softmax, weighted sum, optional mean + std * noise -- instead of a bias broadcast, a relu pass, a third batched GEMM with 75 columns,
+        a transpose view, a softmax, a broadcast multiply, a sum and an addcmul."""
         if not self._inference(x):
             x_all = torch.stack([net(x) for net in self.nets], dim=1)  # training path: plain modules
             return torch.sum(self.composer(x)[:, :, None] * x_all, dim=1)
-        prim = self._primitives_fused(x)
-        if x.is_cuda and x.dtype == torch.float32:
+        if x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and self.num_primitive <= 16 and self.action_log_std.shape[1] <= 80:
             from . import sim as kpsim
-            logits = self.composer[0](x)                              # the composer MLP before its softmax
-            return kpsim.mcp_compose(logits.contiguous(), prim.contiguous(), noise, None if noise is None else self.std())
+            w1, b1, w2, b2, _, b3, w3 = self._fuse()
+            K = self.num_primitive
+            if w2.shape[2] % 64 == 0:
+                h = torch._addmm_activation(b1, x, w1.t()).view(x.shape[0], K, -1).transpose(0, 1)     # [K, N, h1], relu in the GEMM epilogue
+                h2 = torch.bmm(h, w2)                                                              # [K, N, h2]: raw, its bias and relu are applied by the tail
+                logits = self.composer[0](x)                                                       # the composer MLP before its softmax
+                return kpsim.mcp_tail(h2, b2, w3, b3, logits.contiguous(), noise, None if noise is None else self.std())
+        prim = self._primitives_fused(x)
         mean = torch.sum(self.composer(x)[:, :, None] * prim.transpose(0, 1), dim=1)
         return mean if noise is None else torch.addcmul(mean, self.std().to(mean.dtype), noise)
 
@@ -180,7 +187,18 @@ class KinPolicy(nn.Module):
         return torch.zeros((n, self.rnn_hdim), device=device or self.action_fc.weight.device, dtype=self.action_fc.weight.dtype)
 
     def get_action(self, state, hx):
-        hx = self.action_rnn.rnn_f(state, hx)
+        cell = self.action_rnn.rnn_f
+        if state.is_cuda and state.dtype == torch.float32 and state.dim() == 2 and not torch.is_grad_enabled() and state.shape[1] <= self.rnn_hdim:
+            # roll-out step on the device: the two gate GEMMs (library, MFMA) + one kernel for the gate math that also writes [state | h'],
+            # the action MLP's input row, in place of gru_cell_forward (+ its backward workspace) and torch.cat
+            from . import sim as kpsim
+            state, hx = state.contiguous(), hx.contiguous()
+            gi = torch.nn.functional.linear(state, cell.weight_ih)
+            gh = torch.nn.functional.linear(hx, cell.weight_hh)
+            x = torch.empty((state.shape[0], state.shape[1] + self.rnn_hdim), device=state.device, dtype=state.dtype)
+            hx = kpsim.gru_cell_step(gi, gh, cell.bias_ih, cell.bias_hh, hx, state, None, x)
+            return self.action_fc(self.action_mlp(x)), hx
+        hx = cell(state, hx)
         x = torch.cat((state, hx), dim=1)
         return self.action_fc(self.action_mlp(x)), hx
 

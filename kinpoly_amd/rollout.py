@@ -224,8 +224,9 @@ class VectorSampler:
                 self._replay = torch.where(done, over, self._replay)     # a finished env that found no fresh clip replays its last one
                 self.level = torch.where(over, self.level, nxt)
                 env.set_rows((self.level * N + ar).to(torch.int32), done)
-            self.obs = env.reset(done)          # env._obs: step() writes its own observation elsewhere, so this stays valid through the next step
-            self.hx = self.hx.masked_fill(done.unsqueeze(1), 0.0)
+            # env._obs: step() writes its own observation elsewhere, so this stays valid through the next step; the same launch zeroes the GRU state
+            # of the finished envs in place (self.hx is this step's fresh output of select_action; hx0 above is a copy)
+            self.obs = env.reset(done, policy_state=self.hx)
             self.fresh = D[:, t]                # `done` itself lives in a buffer the step after next reuses
         M = (~D).float()
         # one host transfer per call: finished episodes -> freq_dict, launch status

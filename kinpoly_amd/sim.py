@@ -36,6 +36,7 @@ ABI_SYMBOLS = [
     "kp_sim_launch_cost", "kp_job_schedule", "kp_sim_fk_backward", "kp_sim_set_stream", "kp_sim_status_device", "kp_sim_mass_matrix",
     "kp_sim_contacts", "kp_gae_bootstrap", "kp_gru_gates_forward", "kp_gru_gates_backward", "kp_sim_phase_cycles_env",
     "kp_sim_post_step", "kp_sim_reset_rows", "kp_mcp_compose", "kp_sim_step_head", "kp_model_compile", "kp_model_load_xml",
+    "kp_mcp_tail", "kp_gru_cell_step",
 ]
 
 
@@ -94,7 +95,9 @@ def load_library(path: str | None = None):
     L.kp_sim_obs_ar.argtypes = [P, C.POINTER(KpCtx), F]; L.kp_sim_obs_ar.restype = C.c_int
     L.kp_sim_term_reward.argtypes = [P, C.POINTER(KpCtx), C.POINTER(KpRewardCfg), F, F, U8, F]; L.kp_sim_term_reward.restype = C.c_int
     L.kp_sim_post_step.argtypes = [P, C.POINTER(KpCtx), C.POINTER(KpRewardCfg), C.c_void_p, C.c_void_p, C.c_int, F, F, U8, F, U8, U8, F, C.c_void_p]; L.kp_sim_post_step.restype = C.c_int
-    L.kp_sim_reset_rows.argtypes = [P, F, F, C.c_void_p, U8, C.c_void_p, C.c_int]; L.kp_sim_reset_rows.restype = C.c_int
+    L.kp_sim_reset_rows.argtypes = [P, F, F, C.c_void_p, U8, C.c_void_p, C.c_int, F, C.c_int]; L.kp_sim_reset_rows.restype = C.c_int
+    L.kp_mcp_tail.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, F, F, F, C.c_int, F, F, F, C.c_int, F, F, C.c_void_p]; L.kp_mcp_tail.restype = C.c_int
+    L.kp_gru_cell_step.argtypes = [C.c_int, C.c_int, C.c_int, F, F, F, F, F, F, F, F, C.c_void_p]; L.kp_gru_cell_step.restype = C.c_int
     L.kp_mcp_compose.argtypes = [C.c_int, C.c_int, C.c_int, F, F, F, C.c_int, F, F, C.c_void_p]; L.kp_mcp_compose.restype = C.c_int
     L.kp_gae.argtypes = [C.c_int, C.c_int, F, F, F, C.c_float, C.c_float, F, F, C.c_void_p]; L.kp_gae.restype = C.c_int
     L.kp_gae_bootstrap.argtypes = [C.c_int, C.c_int, F, F, F, F, C.c_float, C.c_float, F, F, C.c_void_p]; L.kp_gae_bootstrap.restype = C.c_int
@@ -339,13 +342,17 @@ class KpSim:
                                        C.c_void_p(done.data_ptr()), C.c_void_p(end.data_ptr()), C.c_void_p(percent.data_ptr()),
                                        None if done_count is None else C.c_void_p(done_count.data_ptr())), "kp_sim_post_step")
 
-    def reset_rows(self, init_qpos, init_qvel, row=None, env_mask=None, cur_t=None, set_target=True):
-        """masked reset from context rows: state <- init rows, cur_t = 0, sim.forward(), target = FK(init) (kp_sim_reset_rows)."""
+    def reset_rows(self, init_qpos, init_qvel, row=None, env_mask=None, cur_t=None, set_target=True, aux_rows=None):
+        """masked reset from context rows: state <- init rows, cur_t = 0, sim.forward(), target = FK(init) (kp_sim_reset_rows).
+        aux_rows [N, C]: caller-owned per-env rows zeroed for the same envs (the policy's GRU state)."""
+        if aux_rows is not None and not (aux_rows.is_cuda and aux_rows.dtype == torch.float32 and aux_rows.is_contiguous() and aux_rows.dim() == 2 and aux_rows.shape[0] == self.n):
+            raise ValueError("aux_rows must be a contiguous float32 device tensor [N, C]")
         for t, d in ((init_qpos, NQ), (init_qvel, NV)):
             if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.dim() == 2 and t.shape[1] == d):
                 raise ValueError("init rows must be contiguous float32 device tensors [R, dim]")
         _check(self.L.kp_sim_reset_rows(self.h, C.c_void_p(init_qpos.data_ptr()), C.c_void_p(init_qvel.data_ptr()), None if row is None else C.c_void_p(row.data_ptr()),
-                                        _mask_ptr(env_mask, self.n), None if cur_t is None else C.c_void_p(cur_t.data_ptr()), int(bool(set_target))), "kp_sim_reset_rows")
+                                        _mask_ptr(env_mask, self.n), None if cur_t is None else C.c_void_p(cur_t.data_ptr()), int(bool(set_target)),
+                                        None if aux_rows is None else C.c_void_p(aux_rows.data_ptr()), 0 if aux_rows is None else int(aux_rows.shape[1])), "kp_sim_reset_rows")
 
     def diag(self) -> np.ndarray:
         out = np.zeros((self.n, 4), np.int32)
@@ -410,6 +417,50 @@ def mcp_compose(logits: torch.Tensor, prim: torch.Tensor, noise: torch.Tensor | 
     _check(L.kp_mcp_compose(n, K, A, C.c_void_p(logits.data_ptr()), C.c_void_p(prim.data_ptr()), nz, stride, None if std is None else C.c_void_p(std.data_ptr()),
                             C.c_void_p(out.data_ptr()), C.c_void_p(stream)), "kp_mcp_compose")
     return out
+
+
+def mcp_tail(h2: torch.Tensor, b2: torch.Tensor, w3: torch.Tensor, b3: torch.Tensor, logits: torch.Tensor, noise: torch.Tensor | None = None,
+             std: torch.Tensor | None = None, out: torch.Tensor | None = None):
+    """PolicyMCP's last layer + mixing stage (kp_mcp_tail, fp32 MFMA): h2 [K, N, J] raw second-GEMM output, b2 [K, J], w3 [K, J, A] or its
+    rows zero-padded to [K, J, 80] (16-byte operand loads), b3 [K, A], logits [N, K] (composer output before the softmax); noise [N, A] may
+    be a column slice of a wider buffer."""
+    L = load_library()
+    K, n, J = h2.shape
+    A, ldw = b3.shape[1], w3.shape[2]
+    ok = all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in (h2, b2, w3, b3, logits))
+    if not (ok and tuple(b2.shape) == (K, J) and tuple(w3.shape) == (K, J, ldw) and ldw >= A and tuple(b3.shape) == (K, A) and tuple(logits.shape) == (n, K)):
+        raise ValueError("mcp_tail: h2 [K, N, J], b2 [K, J], w3 [K, J, >= A], b3 [K, A], logits [N, K] must be contiguous float32 device tensors")
+    nz, stride = None, 0
+    if noise is not None:
+        if not (noise.is_cuda and noise.dtype == torch.float32 and tuple(noise.shape) == (n, A) and noise.stride(1) == 1 and std is not None and std.is_contiguous() and std.numel() == A):
+            raise ValueError("mcp_tail: noise [N, A] (unit column stride) needs std [A]")
+        nz, stride = C.c_void_p(noise.data_ptr()), int(noise.stride(0))
+    out = torch.empty((n, A), device=h2.device, dtype=torch.float32) if out is None else out
+    stream = torch.cuda.current_stream(h2.device).cuda_stream
+    _check(L.kp_mcp_tail(n, K, J, A, C.c_void_p(h2.data_ptr()), C.c_void_p(b2.data_ptr()), C.c_void_p(w3.data_ptr()), int(ldw), C.c_void_p(b3.data_ptr()),
+                         C.c_void_p(logits.data_ptr()), nz, stride,
+                         None if std is None else C.c_void_p(std.data_ptr()), C.c_void_p(out.data_ptr()), C.c_void_p(stream)), "kp_mcp_tail")
+    return out
+
+
+def gru_cell_step(gi: torch.Tensor, gh: torch.Tensor, b_ih: torch.Tensor, b_hh: torch.Tensor, h: torch.Tensor, state: torch.Tensor | None = None,
+                  h_out: torch.Tensor | None = None, xcat: torch.Tensor | None = None):
+    """GRUCell gate math after the two bias-free gate GEMMs (kp_gru_cell_step): returns h' [N, H]; xcat [N, D + H] <- [state | h'] when given."""
+    L = load_library()
+    n, H = h.shape
+    ok = all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in (gi, gh, b_ih, b_hh, h))
+    if not (ok and tuple(gi.shape) == (n, 3 * H) and tuple(gh.shape) == (n, 3 * H) and b_ih.numel() == 3 * H and b_hh.numel() == 3 * H):
+        raise ValueError("gru_cell_step: gi / gh [N, 3H], b_ih / b_hh [3H], h [N, H] must be contiguous float32 device tensors")
+    D = 0
+    if xcat is not None:
+        D = state.shape[1]
+        if not (state.is_cuda and state.dtype == torch.float32 and state.is_contiguous() and xcat.is_contiguous() and xcat.dtype == torch.float32 and tuple(xcat.shape) == (n, D + H)):
+            raise ValueError("gru_cell_step: xcat must be a contiguous float32 [N, D + H] device tensor next to state [N, D]")
+    h_out = torch.empty_like(h) if h_out is None else h_out
+    stream = torch.cuda.current_stream(h.device).cuda_stream
+    _check(L.kp_gru_cell_step(n, H, D, *(C.c_void_p(t.data_ptr()) for t in (gi, gh, b_ih, b_hh, h)), None if xcat is None else C.c_void_p(state.data_ptr()),
+                              C.c_void_p(h_out.data_ptr()), None if xcat is None else C.c_void_p(xcat.data_ptr()), C.c_void_p(stream)), "kp_gru_cell_step")
+    return h_out
 
 
 def gae(rewards: torch.Tensor, masks: torch.Tensor, values: torch.Tensor, gamma: float, tau: float, last_values: torch.Tensor | None = None):
