@@ -1046,8 +1046,8 @@ __device__ __forceinline__ int first_clean_level(EnvLds& s, float deep, int tid)
 // safeguarded Newton steps on the piecewise-linear phi'.  Every lane keeps its rows in registers for the whole search -- one contact
 // (four pyramid rows a + alpha b with a = row(jar), b = row(jv)) and ceil(69 / NT) joint-limit rows -- so an evaluation is a few
 // FMAs per row and two wave sums, without LDS traffic.  rowcost: the rows' share of the cost at the returned alpha.
-// ROWCOST = false leaves rowcost alone (the object kernel keeps its full cost evaluation: its register allocation is tight enough that
-// three more live values across the search moved spills into the articulated-body loops, + 8 % on every object scene)
+// ROWCOST = false leaves rowcost alone (rounds 1 - 2: the object kernel kept its full cost evaluation because three more live values across
+// the search moved spills into its articulated-body loops; since the round-3 register discipline both solvers take the closed form)
 template <int NT, bool ROWCOST = true>
 __device__ __forceinline__ float line_search(EnvLds& s, const Params& P, float g0, float h0, int tid, float& rowcost) {
     static_assert(D_MAXCON <= 64 && NT >= 64, "one contact per lane");
@@ -1297,8 +1297,10 @@ __device__ __forceinline__ void obj_forward(EnvLdsObj& s, const DevTables& T, co
 // The <= 12 x 12 SPD object system, one row per lane, held in registers (row stride 13 in s.Sm, right-hand side in column n).
 // Gaussian elimination with the pivot row broadcast by v_readlane; rows >= n are identity padding.  refactor = false reuses the
 // multipliers / upper triangle a previous call stored back to s.Sm and only pushes a new right-hand side through them.
-__device__ __forceinline__ void dense_solve(EnvLdsObj& s, int n, int tid, bool refactor) {
-    constexpr int ST = 6 * D_MAXOBJ + 1, NN = 6 * D_MAXOBJ;
+// NN = 6 or 12: compiled for one and for two simulated objects (the elimination is unrolled over NN columns; most scenes hold one object)
+template <int NN>
+__device__ __forceinline__ void dense_solve_n(EnvLdsObj& s, int n, int tid, bool refactor) {
+    constexpr int ST = 6 * D_MAXOBJ + 1;
     float a[NN + 1];
     const bool rowok = tid < n;
 #pragma unroll
@@ -1330,6 +1332,9 @@ __device__ __forceinline__ void dense_solve(EnvLdsObj& s, int n, int tid, bool r
         s.Sm[tid * ST + n] = a[NN];
     }
     KP_SYNC();
+}
+__device__ __forceinline__ void dense_solve(EnvLdsObj& s, int n, int tid, bool refactor) {
+    if (n <= 6) dense_solve_n<6>(s, n, tid, refactor); else dense_solve_n<6 * D_MAXOBJ>(s, n, tid, refactor);
 }
 
 // per contact (lane = contact): the active-row matrix D F G F^T and the contact force at the current residuals
@@ -1662,6 +1667,7 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
     KP_SYNC();
     eval_rows<NT, true>(s, s.qacc_s, s.jar3, s.lim_jar, true, tid);
     float cost = primal_cost<NT>(s, P, nullptr, s.jar3, s.lim_jar, tid);
+    float gauss = 0.f;         // Gauss term of the iterate (hulls + objects), carried forward along the search directions as in solve_constraints
     float* sacc = s.Mv;        // body spatial accelerations of qacc - qacc_s ([24][6] over Mv + mres), see solve_constraints
     // candidate B: warm start.  The smooth solve's root->leaves pass left sacc = accelerations of (warm start - qacc_smooth) for the hulls
     // (aba_solve<.., WARM>); the object slots of the same array (entities 24, 25: the last four floats run into x) take oa - oas, and the
@@ -1675,9 +1681,11 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
         eval_rows<NT, true>(s, s.qacc, wj3, wlim, false, tid, sacc, s.qacc_s, true);
         if (tid < nobj) sts6(s.omres + 6 * tid, inert_mul(s.oIe + 10 * tid, lds6(s.oa + 6 * tid) + (-1.0f) * lds6(s.oas + 6 * tid)));
         KP_SYNC();
-        const float cw = primal_cost<NT>(s, P, sacc, wj3, wlim, tid) + obj_gauss(s);
+        float gw;
+        const float og = obj_gauss(s);
+        const float cw = primal_cost<NT>(s, P, sacc, wj3, wlim, tid, &gw) + og;
         if (cw < cost) {
-            cost = cw;
+            cost = cw; gauss = gw + og;
             for (int k = tid; k < 3 * s.ncon; k += NT) s.jar3[k] = wj3[k];
             for (int j = tid; j < D_NU; j += NT) s.lim_jar[j] = wlim[j];
         } else {
@@ -1764,8 +1772,8 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
         float h0 = 2.0f * quad_form_M<NT>(s, s.sv, s.sv, s.search, nullptr, s.search, nullptr, tid);
         if (tid < no6) { g0 += s.osrch[tid] * s.omres[tid]; h0 += s.osrch[tid] * s.oMv[tid]; }
         g0 = block_sum<NT>(s, g0, tid); h0 = block_sum<NT>(s, h0, tid);
-        float unused;
-        const float alpha = line_search<NT, false>(s, P, g0, h0, tid, unused);
+        float rowcost;
+        const float alpha = line_search<NT>(s, P, g0, h0, tid, rowcost);
         if (!(alpha > 0.f)) { done = true; break; }
         for (int i = tid; i < D_NV; i += NT) s.qacc[i] += alpha * s.search[i];
         for (int i = tid; i < D_NB * 6; i += NT) sacc[i] += alpha * s.sv[i];
@@ -1773,7 +1781,10 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
         for (int k = tid; k < 3 * s.ncon; k += NT) s.jar3[k] += alpha * s.jv3[k];
         for (int j = tid; j < D_NU; j += NT) if (s.lim_D[j] != 0.f) s.lim_jar[j] += alpha * s.lim_jv[j];
         KP_SYNC();
-        const float newcost = primal_cost<NT>(s, P, sacc, s.jar3, s.lim_jar, tid) + obj_gauss(s);
+        // cost at the new iterate in closed form (solve_constraints): the Gauss term of hulls and objects is quadratic along the search
+        // direction (g0, h0 hold both shares), the rows' share comes out of the line search's registers
+        gauss += alpha * (g0 + 0.5f * alpha * h0);
+        const float newcost = gauss + rowcost;
         const float improvement = P.scale * (cost - newcost);
         cost = newcost;
         if (improvement < P.tol) { it++; done = true; break; }

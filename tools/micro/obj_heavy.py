@@ -21,3 +21,6 @@ for tag, idx in (("top 32", order[:32]), ("top 33..256", order[32:256]), ("media
     print(f"{tag}: per substep", {n: int(pe[idx, k].mean() / 15) for k, n in enumerate(names)},
           "contacts %.1f newton it/substep %.2f nfact/substep %.2f" % (d[idx, 0].mean(), d[idx, 1].mean() / 15, (d[idx, 3] >> 8).mean() / 15),
           "classes", np.bincount(cls[idx], minlength=4).tolist(), flush=True)
+for e in order[:8]:
+    print(f"env {e} class {cls[e]}: per substep", {n: int(pe[e, k] / 15) for k, n in enumerate(names)},
+          "contacts %d newton it/substep %.2f nfact/substep %.2f cap hits %d" % (d[e, 0], d[e, 1] / 15, (d[e, 3] >> 8) / 15, d[e, 2] >> 8), flush=True)
