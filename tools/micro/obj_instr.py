@@ -36,10 +36,16 @@ def patch(s):
         if (tid < no6) s.sv[6 * D_NB + tid] = s.osrch[tid];
         KP_SYNC();
         eval_rows<NT, true>(s, s.search, s.jv3, s.lim_jv, false, tid);''')
-    rep('''        const float alpha = line_search<NT, false>(s, P, g0, h0, tid, unused);
-''', '''        const float alpha = line_search<NT, false>(s, P, g0, h0, tid, unused);
+    rep('''        const float alpha = line_search<NT>(s, P, g0, h0, tid, rowcost);
+        if (!(alpha > 0.f)) { done = true; break; }
+        for (int i = tid; i < D_NV; i += NT) s.qacc[i] += alpha * s.search[i];
+        for (int i = tid; i < D_NB * 6; i += NT) sacc[i] += alpha * s.sv[i];
+        if (tid < no6)''', '''        const float alpha = line_search<NT>(s, P, g0, h0, tid, rowcost);
         NP(5)
-''')
+        if (!(alpha > 0.f)) { done = true; break; }
+        for (int i = tid; i < D_NV; i += NT) s.qacc[i] += alpha * s.search[i];
+        for (int i = tid; i < D_NB * 6; i += NT) sacc[i] += alpha * s.sv[i];
+        if (tid < no6)''')
     rep('''        const float improvement = P.scale * (cost - newcost);
         cost = newcost;
         if (improvement < P.tol) { it++; done = true; break; }

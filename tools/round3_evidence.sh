@@ -15,6 +15,9 @@ python tools/obj_bench.py > $E/obj_bench.log 2>&1
 python tools/micro/obj_profile.py > $E/obj_profile_phases.log 2>&1
 KP_OBJ_NEWTON=1 python tools/micro/obj_profile.py > $E/obj_profile_newton.log 2>&1
 python tools/micro/obj_tail.py > $E/obj_tail.log 2>&1
+python tools/micro/obj_heavy.py > $E/obj_heavy_phases.log 2>&1
+KP_OBJ_NEWTON=1 python tools/micro/obj_heavy.py > $E/obj_heavy_newton.log 2>&1
+bash tools/micro/trace_step.sh > $E/trace_step.log 2>&1
 python tools/phase_profile.py > $E/phase_cycles.log 2>&1
 python tools/update_bench.py > $E/update_bench.log 2>&1
 # the three passes of profile_bench.sh per workload: kernel trace + stats, then the --pmc passes (never combined with trace domains)
@@ -24,7 +27,7 @@ cp gpurun_out/r03_prof/summary/* $E/ 2>/dev/null
 mkdir -p profiles/r03 && cp gpurun_out/r03_prof/summary/pmc_bench_*.json profiles/r03/ 2>/dev/null      # bench.py reads the PMC summaries of ITS OWN command from there
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r03_prof/update -o stats -- python tools/update_profile.py > $E/update_profile.log 2>&1
 cp gpurun_out/r03_prof/update/stats_kernel_stats.csv $E/r03_kernel_stats_update.csv 2>/dev/null
-python bench.py > $E/bench_default.json 2> $E/bench_default.err
+( time python bench.py > $E/bench_default.json 2> $E/bench_default.err ) 2> $E/bench_default.time
 python bench.py --workload objects --no-secondary --no-cpu-baseline > $E/bench_objects.json 2> $E/bench_objects.err
 KP_BENCH_FORCE_PG=1 MASTER_PORT=29561 python bench.py --workload train_iter --steps 2 --warmup 1 > $E/bench_train_iter_1rank_nccl.json 2> $E/bench_train_iter.err
 KP_BENCH_SHARED_DEVICE=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29557 bench.py --gpus 2 --steps 20 --warmup 5 2> $E/bench_2rank.err | grep '^{' > $E/bench_2rank_shared_device.json     # gloo prints its own lines on stdout
