@@ -495,6 +495,32 @@ __device__ __forceinline__ void aba_solve(EnvLds& s, const Params& P, const Lane
             if (c1 > c0) {
                 const V3 o = ld3(s.xpos);
                 float Krow[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if constexpr (OBJ) {
+                    // object kernels: M_c = D F G F^T of every contact's active rows is already in LDS for this iterate (con_prepare, lane = contact, which
+                    // also feeds the object rows of the Hessian), so a row of K = P M_c P^T is one symmetric 3 x 3 product and a cross product -- no
+                    // mju_makeFrame, no frame round trip per contact, body row and factorisation
+                    const float* cM = static_cast<const EnvLdsObj&>(s).cM;
+                    V3 pn = ld3(s.con_pos + 3 * c0);
+                    float mn[6];
+#pragma unroll
+                    for (int k = 0; k < 6; k++) mn[k] = cM[6 * c0 + k];
+                    for (int c = c0; c < c1; c++) {
+                        const V3 p = pn - o;
+                        float m[6];
+#pragma unroll
+                        for (int k = 0; k < 6; k++) m[k] = mn[k];
+                        const int cn = min(c + 1, c1 - 1);
+                        pn = ld3(s.con_pos + 3 * cn);
+#pragma unroll
+                        for (int k = 0; k < 6; k++) mn[k] = cM[6 * cn + k];
+                        V3 Pr;  // row r of P = [[p]x ; 1]:  row r of K = [p x q ; q] with q = M_c P_r
+                        if (r == 0) Pr = v3(0.f, -p.z, p.y); else if (r == 1) Pr = v3(p.z, 0.f, -p.x); else if (r == 2) Pr = v3(-p.y, p.x, 0.f);
+                        else Pr = v3(r == 3 ? 1.f : 0.f, r == 4 ? 1.f : 0.f, r == 5 ? 1.f : 0.f);
+                        const V3 q = v3(m[0] * Pr.x + m[3] * Pr.y + m[4] * Pr.z, m[3] * Pr.x + m[1] * Pr.y + m[5] * Pr.z, m[4] * Pr.x + m[5] * Pr.y + m[2] * Pr.z);
+                        const V3 pq = cross(p, q);
+                        Krow[0] += pq.x; Krow[1] += pq.y; Krow[2] += pq.z; Krow[3] += q.x; Krow[4] += q.y; Krow[5] += q.z;
+                    }
+                } else {
                 const float mu = P.mu, mu2 = P.mu * P.mu;
                 V3 pn = ld3(s.con_pos + 3 * c0);
                 float Dn = s.con_D[c0];
@@ -516,6 +542,7 @@ __device__ __forceinline__ void aba_solve(EnvLds& s, const Params& P, const Lane
                     const V3 q = frame_world(fr, v3(Dc * (gnn * pf.x + gn1 * pf.y + gn2 * pf.z), Dc * (gn1 * pf.x + g11 * pf.y), Dc * (gn2 * pf.x + g22 * pf.z)));
                     const V3 pq = cross(p, q);
                     Krow[0] += pq.x; Krow[1] += pq.y; Krow[2] += pq.z; Krow[3] += q.x; Krow[4] += q.y; Krow[5] += q.z;
+                }
                 }
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
@@ -1701,7 +1728,8 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
     for (; it < P.max_iter; it++) {
         // gradient: humanoid dofs (mres - J^T f) and object wrenches
         wrench_project<NT, true>(s, P, sacc, s.qacc, s.qacc_s, s.grad(), true, true, tid);
-        if (nobj > 0) { con_prepare<NT>(s, P, tid); obj_gradient(s, tid); }
+        con_prepare<NT>(s, P, tid);                  // M_c of every contact at this iterate: object rows of the Hessian AND the hulls' contact inertia (aba_solve)
+        if (nobj > 0) obj_gradient(s, tid);
         float g2 = 0.f, changed = 0.f, deep = 0.f;
         for (int i = tid; i < D_NV; i += NT) {
             const float g = s.grad()[i];
