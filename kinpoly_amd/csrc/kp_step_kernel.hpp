@@ -953,7 +953,9 @@ __device__ __forceinline__ void subtree_sums(EnvLds& s, int tid) {
 
 // out = M (va - vb) (with_inertia; acc6 [24][6] must hold the body spatial accelerations of va - vb) - J^T f(jar) (with_forces)
 template <int NT, bool OBJ>
-__device__ __forceinline__ void wrench_project(EnvLds& s, const Params& P, const float* acc6, const float* va, const float* vb, float* out, bool with_inertia, bool with_forces, int tid) {
+// forces (optional): the contacts' world forces at the current residuals, [ncon][3], already evaluated (object kernels: con_prepare, lane = contact)
+__device__ __forceinline__ void wrench_project(EnvLds& s, const Params& P, const float* acc6, const float* va, const float* vb, float* out, bool with_inertia, bool with_forces, int tid,
+                                               const float* forces = nullptr) {
     if (tid < D_NB) {
         const int b = tid;
         S6 W = with_inertia ? inert_mul(s.cinert + 10 * b, lds6(acc6 + 6 * b)) : S6{v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f)};
@@ -961,6 +963,15 @@ __device__ __forceinline__ void wrench_project(EnvLds& s, const Params& P, const
             const int c0 = s.con_start[b], c1 = s.con_start[b + 1];
             if (c1 > c0) {
                 const V3 o = ld3(s.xpos);
+                if (forces) {
+                    V3 Fn = ld3(forces + 3 * c0), pn = ld3(s.con_pos + 3 * c0);
+                    for (int c = c0; c < c1; c++) {
+                        const V3 F = Fn, p = pn - o;
+                        const int cn = min(c + 1, c1 - 1);
+                        Fn = ld3(forces + 3 * cn); pn = ld3(s.con_pos + 3 * cn);
+                        W.a = W.a - cross(p, F); W.l = W.l - F;
+                    }
+                } else {
                 // the next contact's operands are requested before this one's arithmetic (one LDS round trip for the loop, not one per contact)
                 float Dn = s.con_D[c0];
                 V3 jn3 = ld3(s.jar3 + 3 * c0), pn = ld3(s.con_pos + 3 * c0);
@@ -975,6 +986,7 @@ __device__ __forceinline__ void wrench_project(EnvLds& s, const Params& P, const
                     // sum_e f_e (n +- mu t_k) in frame coordinates, then to world
                     const V3 F = frame_world(contact_frame<OBJ>(s, c), v3(fe[0] + fe[1] + fe[2] + fe[3], P.mu * (fe[0] - fe[1]), P.mu * (fe[2] - fe[3])));
                     W.a = W.a - cross(p, F); W.l = W.l - F;
+                }
                 }
             }
         }
@@ -1371,7 +1383,7 @@ __device__ __forceinline__ void con_prepare(EnvLdsObj& s, const Params& P, int t
         const V3 mx = con_DG(s, P, c, v3(1.f, 0.f, 0.f)), my = con_DG(s, P, c, v3(0.f, 1.f, 0.f)), mz = con_DG(s, P, c, v3(0.f, 0.f, 1.f));
         float* m = s.cM + 6 * c;
         m[0] = mx.x; m[1] = my.y; m[2] = mz.z; m[3] = mx.y; m[4] = mx.z; m[5] = my.z;
-        st3(s.sa + 3 * c, con_force(s, P, c));     // contact forces live in sa/sw (192 of 288 floats) until the next wrench_project
+        st3(s.jv3 + 3 * c, con_force(s, P, c));    // contact forces live in jv3 (the previous search direction's rows: dead since the update) until this iteration's eval_rows
     }
     KP_SYNC();
 }
@@ -1499,7 +1511,7 @@ __device__ __forceinline__ void obj_gradient(EnvLdsObj& s, int tid) {
     const bool have = tid < s.ncon;
     const int c = have ? tid : 0;
     const int A = have ? s.con_body[c] : -1, B = have ? (int)s.con_b2[c] : -1;
-    const V3 F = ld3(s.sa + 3 * c), p = ld3(s.con_pos + 3 * c) - o;
+    const V3 F = ld3(s.jv3 + 3 * c), p = ld3(s.con_pos + 3 * c) - o;
     const V3 t = cross(p, F);
     float vals[12];
 #pragma unroll
@@ -1727,8 +1739,8 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
     const unsigned conlev = contact_levels(s, L8);
     for (; it < P.max_iter; it++) {
         // gradient: humanoid dofs (mres - J^T f) and object wrenches
-        wrench_project<NT, true>(s, P, sacc, s.qacc, s.qacc_s, s.grad(), true, true, tid);
-        con_prepare<NT>(s, P, tid);                  // M_c of every contact at this iterate: object rows of the Hessian AND the hulls' contact inertia (aba_solve)
+        con_prepare<NT>(s, P, tid);                  // lane = contact: M_c at this iterate (object rows of the Hessian AND the hulls' contact inertia in aba_solve) and the contact force
+        wrench_project<NT, true>(s, P, sacc, s.qacc, s.qacc_s, s.grad(), true, true, tid, s.jv3);
         if (nobj > 0) obj_gradient(s, tid);
         float g2 = 0.f, changed = 0.f, deep = 0.f;
         for (int i = tid; i < D_NV; i += NT) {
