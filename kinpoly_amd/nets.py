@@ -9,8 +9,9 @@ Parameter names mirror the reference modules so the reference's checkpoints (`po
   KinPolicy    kin_poly/models/traj_ar_smpl_net.py:48-53,333-343 + policy_ar.py:317-320
                (action_rnn.rnn_f = GRUCell, action_mlp, action_fc; fixed log_std, kin_poly.yml:38)
 
-The GEMMs run through hipBLASLt (MFMA) via torch; PolicyMCP fuses its 8 primitive MLPs + composer
-into three batched GEMMs instead of 9 x 3 small ones.
+The large GEMMs run through rocBLAS / hipBLASLt (MFMA) via torch; on the device's inference path PolicyMCP's 8 primitive MLPs are one
+wide GEMM + one batched GEMM + kp_mcp_tail (this repo's fp32 MFMA kernel: the 8 output layers, the composer's softmax and the weighted sum),
+and the kinematic policy's GRU step is two gate GEMMs + kp_gru_cell_step.
 """
 from __future__ import annotations
 
