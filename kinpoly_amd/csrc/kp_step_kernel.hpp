@@ -954,11 +954,14 @@ __device__ __forceinline__ void subtree_sums(EnvLds& s, int tid) {
 // out = M (va - vb) (with_inertia; acc6 [24][6] must hold the body spatial accelerations of va - vb) - J^T f(jar) (with_forces)
 template <int NT, bool OBJ>
 // forces (optional): the contacts' world forces at the current residuals, [ncon][3], already evaluated (object kernels: con_prepare, lane = contact)
+// bias / rhs (optional): body wrenches [24][6] added to, and a generalized force [75] subtracted from, the result: with the bias wrenches fb and
+// rhs = qfrc_applied + qfrc_actuator, out = M va - qfrc_smooth - J^T f, the gradient of the primal problem without a detour through qacc_smooth
 __device__ __forceinline__ void wrench_project(EnvLds& s, const Params& P, const float* acc6, const float* va, const float* vb, float* out, bool with_inertia, bool with_forces, int tid,
-                                               const float* forces = nullptr) {
+                                               const float* forces = nullptr, const float* bias = nullptr, const float* rhs = nullptr) {
     if (tid < D_NB) {
         const int b = tid;
         S6 W = with_inertia ? inert_mul(s.cinert + 10 * b, lds6(acc6 + 6 * b)) : S6{v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f)};
+        if (bias) W = W + lds6(bias + 6 * b);
         if (with_forces) {
             const int c0 = s.con_start[b], c1 = s.con_start[b + 1];
             if (c1 > c0) {
@@ -998,6 +1001,7 @@ __device__ __forceinline__ void wrench_project(EnvLds& s, const Params& P, const
         float v = dot6(lds6(s.cdof + 6 * d), lds6(s.sa + 6 * s.dbody[d]));
         if (with_inertia) v += s.arm[d] * (va[d] - (vb ? vb[d] : 0.f));
         if (with_forces && d >= 6) { float jr = s.lim_jar[d - 6]; if (jr < 0.f) v += s.lim_D[d - 6] * jr; }      // - sign * (-D jar): lim_D is signed
+        if (rhs) v -= rhs[d];
         out[d] = v;
     }
     KP_SYNC();
@@ -1227,6 +1231,81 @@ __device__ __forceinline__ int solve_constraints(EnvLds& s, const Params& P, con
         if (improvement < P.tol) { it++; done = true; break; }
     }
     if (!done) ncap++;          // the solver stopped at opt.iterations: counted per env in diag (flags >> 8)
+    return it;
+}
+
+// The same Newton solve WITHOUT qacc_smooth (floor kernel).  mj_fwdConstraint evaluates two starting points -- qacc_smooth and the warm start --
+// and iterates from the cheaper one; the primal problem is strictly convex, so its minimiser does not depend on the starting point, and its cost
+//     0.5 (a - a_s)^T M (a - a_s) + s(J a - aref)  =  0.5 a^T M a - a^T qfrc_smooth + s(J a - aref) + const
+// needs a_s = M^-1 qfrc_smooth neither for the gradient (M a - qfrc_smooth - J^T f, in body form: I_b sacc_b + fb_b - contact wrenches, projected)
+// nor for the termination tests (|gradient| and the cost DIFFERENCE of consecutive iterates, exact in closed form along the search direction).
+// So the solve starts from the warm start always, and the substep's "smooth" articulated-body factorisation + solve (a fifth of a substep) is not
+// run at all: the FIRST Newton factorisation walks every tree level and so leaves M's own factors on the clean levels, which the later
+// factorisations of the substep reuse exactly as they reused the smooth solve's.  Without constraint rows qacc = M^-1 qfrc_smooth is one plain solve.
+// Results agree with the two-candidate form to the solver's tolerance; the iteration path is MuJoCo's whenever MuJoCo starts from its warm start.
+// On entry: s.qacc = warm start, jv3 / lim_jv = aref, s.applied ++ s.ctrl = qfrc_applied + qfrc_actuator, s.fb = bias wrenches.
+template <int NT>
+__device__ __forceinline__ int solve_constraints_direct(EnvLds& s, const Params& P, const Lane8& L8, int depth, int tid, int& nfact, int& ncap) {
+    if (s.ncon == 0 && s.nlim == 0) {
+        aba_solve<NT, false>(s, P, L8, s.applied, s.qacc, false, tid, D_NLEV, s.fb);
+        return 0;
+    }
+    float* sacc = s.Mv;        // [24][6] over Mv + mres: spatial accelerations of the bodies induced by the iterate qacc
+    float* grad = s.qacc_s;    // the words qacc_smooth would occupy
+    spatial_accumulate<NT>(s, s.qacc, depth, tid);
+    for (int i = tid; i < D_NB * 6; i += NT) sacc[i] = s.sv[i];
+    KP_SYNC();
+    eval_rows<NT, false>(s, s.qacc, s.jar3, s.lim_jar, true, tid, sacc);
+    float rowcost = primal_cost<NT>(s, P, nullptr, s.jar3, s.lim_jar, tid);          // the rows' share of the cost at the iterate
+    int it = 0, lev_hist = 1;
+    bool done = false;          // left the loop through one of mj_solNewton's termination tests (not the iteration cap)
+    const unsigned conlev = contact_levels(s, L8);
+    for (; it < P.max_iter; it++) {
+        wrench_project<NT, false>(s, P, sacc, s.qacc, nullptr, grad, true, true, tid, nullptr, s.fb, s.applied);
+        float g2 = 0.f, changed = 0.f, deep = 0.f;
+        for (int i = tid; i < D_NV; i += NT) {
+            const float g = grad[i];
+            g2 += g * g;
+            s.x[i] = -g;
+            const float ex = (i >= 6 && s.lim_jar[i - 6] < 0.f) ? fabsf(s.lim_D[i - 6]) : 0.f;
+            if (ex != s.extra[i]) changed = 1.f;
+            s.extra[i] = ex;
+            if (ex != 0.f) deep = fmaxf(deep, (float)s.bdep[s.dbody[i]]);     // active joint limit: its body's level is dirty
+        }
+        changed += active_set_changed<NT>(s, P, tid, deep);
+        g2 = block_sum<NT>(s, g2, tid);
+        changed = (NT == 64) ? (__ballot(changed > 0.f) != 0ull ? 1.f : 0.f) : block_sum<NT>(s, changed, tid);
+        KP_SYNC();
+        if (P.scale * sqrtf(g2) < P.tol) { done = true; break; }
+        if (it == 0 || changed > 0.f) {
+            const int clean = first_clean_level<NT>(s, deep, tid);
+            lev_hist = max(lev_hist, clean);
+            // first factorisation of the substep: every level (its clean levels ARE M's factors from then on)
+            aba_solve<NT, false>(s, P, L8, s.x, s.search, true, tid, it == 0 ? D_NLEV : lev_hist, nullptr, nullptr, nullptr, conlev);
+            nfact++;
+        }
+        else aba_resolve(s, L8, s.x, nullptr, s.search);
+        eval_rows<NT, false>(s, s.search, s.jv3, s.lim_jv, false, tid);           // aref (in jv3) is folded into jar3 by now
+        // phi(alpha) = cost(qacc + alpha search): smooth part g0 = search^T (M qacc - qfrc_smooth), h0 = search^T M search, in body form
+        float g0 = 2.0f * quad_form_M<NT>(s, s.sv, sacc, s.search, nullptr, s.qacc, nullptr, tid);
+        float h0 = 2.0f * quad_form_M<NT>(s, s.sv, s.sv, s.search, nullptr, s.search, nullptr, tid);
+        for (int i = tid; i < D_NB * 6; i += NT) g0 += s.sv[i] * s.fb[i];
+        for (int i = tid; i < D_NV; i += NT) g0 -= s.search[i] * s.applied[i];
+        g0 = block_sum<NT>(s, g0, tid); h0 = block_sum<NT>(s, h0, tid);
+        float rownew;
+        const float alpha = line_search<NT>(s, P, g0, h0, tid, rownew);
+        if (!(alpha > 0.f)) { done = true; break; }
+        for (int i = tid; i < D_NV; i += NT) s.qacc[i] += alpha * s.search[i];
+        for (int i = tid; i < D_NB * 6; i += NT) sacc[i] += alpha * s.sv[i];
+        for (int k = tid; k < 3 * s.ncon; k += NT) s.jar3[k] += alpha * s.jv3[k];
+        for (int j = tid; j < D_NU; j += NT) if (s.lim_D[j] != 0.f) s.lim_jar[j] += alpha * s.lim_jv[j];
+        KP_SYNC();
+        // cost(old) - cost(new): the smooth part is an exact quadratic along the search direction, the rows' share comes out of the line search
+        const float improvement = P.scale * ((rowcost - rownew) - alpha * (g0 + 0.5f * alpha * h0));
+        rowcost = rownew;
+        if (improvement < P.tol) { it++; done = true; break; }
+    }
+    if (!done) ncap++;
     return it;
 }
 
@@ -1676,7 +1755,7 @@ __device__ __forceinline__ void schur_columns(EnvLdsObj& s, const Params& P, uns
 // (q_humanoid, a_object...).  The Newton system is solved exactly by block elimination: the articulated-body pass factorises
 // the humanoid block, 6 n_obj + 1 bias-only passes form the Schur complement on the objects when a hull touches one.
 template <int NT>
-__device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params& P, const Lane8& L8, int tid, int& nfact, int& ncap) {
+__device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params& P, const Lane8& L8, int depth, int tid, int& nfact, int& ncap) {
     constexpr int ST = 6 * D_MAXOBJ + 1;
     const int nobj = s.nobj, no6 = 6 * nobj;
     // smooth acceleration of the objects: I_eff a = -bias wrench
@@ -1695,56 +1774,36 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
         if (tid < no6) s.oas[tid] = s.Sm[ST * tid + no6];
         KP_SYNC();
     }
+    // The humanoid's share of the problem in the direct form of solve_constraints_direct: no qacc_smooth, no smooth articulated-body solve, the
+    // start is the warm start, the first factorisation walks every level.  The objects keep their (cheap) smooth accelerations oas: their
+    // share of the Gauss term stays 0.5 (oa - oas)^T I_eff (oa - oas), carried as omres = I_eff (oa - oas).
     if (s.ncon == 0 && s.nlim == 0) {
-        for (int i = tid; i < D_NV; i += NT) s.qacc[i] = s.qacc_s[i];
+        aba_solve<NT, true>(s, P, L8, s.applied, s.qacc, false, tid, D_NLEV, s.fb);
         if (tid < no6) s.oa[tid] = s.oas[tid];
         KP_SYNC();
         return 0;
     }
-    // candidate A: the smooth accelerations (Gauss term 0)
-    if (tid < no6) s.sv[6 * D_NB + tid] = s.oas[tid];
+    float* sacc = s.Mv;        // [24 + 2][6] over Mv + mres (+ x[0..3]): spatial accelerations induced by the iterate (hulls: of qacc; object slots: oa, for the first row evaluation)
+    float* grad = s.qacc_s;    // the words qacc_smooth would occupy
+    static_assert(offsetof(EnvLds, x) == offsetof(EnvLds, Mv) + 152 * sizeof(float), "sacc's object slots continue into x");
+    spatial_accumulate<NT>(s, s.qacc, depth, tid);
+    for (int i = tid; i < D_NB * 6; i += NT) sacc[i] = s.sv[i];
+    if (tid < no6) sacc[6 * D_NB + tid] = s.oa[tid];
+    if (tid < nobj) sts6(s.omres + 6 * tid, inert_mul(s.oIe + 10 * tid, lds6(s.oa + 6 * tid) + (-1.0f) * lds6(s.oas + 6 * tid)));
     KP_SYNC();
-    eval_rows<NT, true>(s, s.qacc_s, s.jar3, s.lim_jar, true, tid);
-    float cost = primal_cost<NT>(s, P, nullptr, s.jar3, s.lim_jar, tid);
-    float gauss = 0.f;         // Gauss term of the iterate (hulls + objects), carried forward along the search directions as in solve_constraints
-    float* sacc = s.Mv;        // body spatial accelerations of qacc - qacc_s ([24][6] over Mv + mres), see solve_constraints
-    // candidate B: warm start.  The smooth solve's root->leaves pass left sacc = accelerations of (warm start - qacc_smooth) for the hulls
-    // (aba_solve<.., WARM>); the object slots of the same array (entities 24, 25: the last four floats run into x) take oa - oas, and the
-    // rows are linear: residuals = candidate A's + J (difference).
-    {
-        float* wj3 = s.jv3;    // over aref (not needed afterwards); U stays as the smooth solve left it (aba_solve's clean levels)
-        float* wlim = s.x + 4; // x[0..3] hold the tail of the second object slot of sacc during this block
-        static_assert(offsetof(EnvLds, x) == offsetof(EnvLds, Mv) + 152 * sizeof(float), "sacc's object slots continue into x");
-        if (tid < no6) sacc[6 * D_NB + tid] = s.oa[tid] - s.oas[tid];
-        KP_SYNC();
-        eval_rows<NT, true>(s, s.qacc, wj3, wlim, false, tid, sacc, s.qacc_s, true);
-        if (tid < nobj) sts6(s.omres + 6 * tid, inert_mul(s.oIe + 10 * tid, lds6(s.oa + 6 * tid) + (-1.0f) * lds6(s.oas + 6 * tid)));
-        KP_SYNC();
-        float gw;
-        const float og = obj_gauss(s);
-        const float cw = primal_cost<NT>(s, P, sacc, wj3, wlim, tid, &gw) + og;
-        if (cw < cost) {
-            cost = cw; gauss = gw + og;
-            for (int k = tid; k < 3 * s.ncon; k += NT) s.jar3[k] = wj3[k];
-            for (int j = tid; j < D_NU; j += NT) s.lim_jar[j] = wlim[j];
-        } else {
-            for (int i = tid; i < D_NV; i += NT) s.qacc[i] = s.qacc_s[i];
-            for (int i = tid; i < D_NB * 6; i += NT) sacc[i] = 0.f;
-            if (tid < no6) { s.oa[tid] = s.oas[tid]; s.omres[tid] = 0.f; }
-        }
-        KP_SYNC();
-    }
+    eval_rows<NT, true>(s, s.qacc, s.jar3, s.lim_jar, true, tid, sacc);
+    float rowcost = primal_cost<NT>(s, P, nullptr, s.jar3, s.lim_jar, tid);          // the rows' share of the cost at the iterate
     int it = 0, lev_hist = 1;
     bool done = false;          // left the loop through one of mj_solNewton's termination tests (not the iteration cap)
     const unsigned conlev = contact_levels(s, L8);
     for (; it < P.max_iter; it++) {
         // gradient: humanoid dofs (mres - J^T f) and object wrenches
         con_prepare<NT>(s, P, tid);                  // lane = contact: M_c at this iterate (object rows of the Hessian AND the hulls' contact inertia in aba_solve) and the contact force
-        wrench_project<NT, true>(s, P, sacc, s.qacc, s.qacc_s, s.grad(), true, true, tid, s.jv3);
+        wrench_project<NT, true>(s, P, sacc, s.qacc, nullptr, grad, true, true, tid, s.jv3, s.fb, s.applied);
         if (nobj > 0) obj_gradient(s, tid);
         float g2 = 0.f, changed = 0.f, deep = 0.f;
         for (int i = tid; i < D_NV; i += NT) {
-            const float g = s.grad()[i];
+            const float g = grad[i];
             g2 += g * g;
             s.x[i] = -g;
             const float ex = (i >= 6 && s.lim_jar[i - 6] < 0.f) ? fabsf(s.lim_D[i - 6]) : 0.f;
@@ -1782,7 +1841,8 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
         if (refactor) {
             if (no6 > 0) obj_hessian(s, P, s.ogr, -1.0f, tid);
             lev_hist = max(lev_hist, first_clean_level<NT>(s, deep, tid));   // the clean range only shrinks within a substep
-            aba_solve<NT, true>(s, P, L8, s.x, s.search, true, tid, lev_hist, nullptr, nullptr, nullptr, conlev);     // y0 = H_hh^-1 (-g_h); sv = its spatial accelerations
+            // the substep's first factorisation walks every level: its clean levels hold M's own factors from then on
+            aba_solve<NT, true>(s, P, L8, s.x, s.search, true, tid, it == 0 ? D_NLEV : lev_hist, nullptr, nullptr, nullptr, conlev);     // y0 = H_hh^-1 (-g_h); sv = its spatial accelerations
             if (couple) { obj_coupling_u(s, P, s.ot, tid); if (tid < no6) s.Sm[ST * tid + no6] += s.ot[tid]; KP_SYNC(); }     // rhs_o -= H_oh y0
         }
         if (refactor && couple) schur_columns(s, P, cmask, tid);          // S = H_oo - H_oh H_hh^-1 H_ho, all columns in one or two rounds
@@ -1808,12 +1868,14 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
         eval_rows<NT, true>(s, s.search, s.jv3, s.lim_jv, false, tid);
         if (tid < nobj) sts6(s.oMv + 6 * tid, inert_mul(s.oIe + 10 * tid, lds6(s.osrch + 6 * tid)));
         KP_SYNC();
-        float g0 = 2.0f * quad_form_M<NT>(s, s.sv, sacc, s.search, nullptr, s.qacc, s.qacc_s, tid);
+        float g0 = 2.0f * quad_form_M<NT>(s, s.sv, sacc, s.search, nullptr, s.qacc, nullptr, tid);      // search^T (M qacc - qfrc_smooth) for the hulls ...
         float h0 = 2.0f * quad_form_M<NT>(s, s.sv, s.sv, s.search, nullptr, s.search, nullptr, tid);
-        if (tid < no6) { g0 += s.osrch[tid] * s.omres[tid]; h0 += s.osrch[tid] * s.oMv[tid]; }
+        for (int i = tid; i < D_NB * 6; i += NT) g0 += s.sv[i] * s.fb[i];
+        for (int i = tid; i < D_NV; i += NT) g0 -= s.search[i] * s.applied[i];
+        if (tid < no6) { g0 += s.osrch[tid] * s.omres[tid]; h0 += s.osrch[tid] * s.oMv[tid]; }                // ... and search^T I_eff (oa - oas) for the objects
         g0 = block_sum<NT>(s, g0, tid); h0 = block_sum<NT>(s, h0, tid);
-        float rowcost;
-        const float alpha = line_search<NT>(s, P, g0, h0, tid, rowcost);
+        float rownew;
+        const float alpha = line_search<NT>(s, P, g0, h0, tid, rownew);
         if (!(alpha > 0.f)) { done = true; break; }
         for (int i = tid; i < D_NV; i += NT) s.qacc[i] += alpha * s.search[i];
         for (int i = tid; i < D_NB * 6; i += NT) sacc[i] += alpha * s.sv[i];
@@ -1821,12 +1883,10 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
         for (int k = tid; k < 3 * s.ncon; k += NT) s.jar3[k] += alpha * s.jv3[k];
         for (int j = tid; j < D_NU; j += NT) if (s.lim_D[j] != 0.f) s.lim_jar[j] += alpha * s.lim_jv[j];
         KP_SYNC();
-        // cost at the new iterate in closed form (solve_constraints): the Gauss term of hulls and objects is quadratic along the search
-        // direction (g0, h0 hold both shares), the rows' share comes out of the line search's registers
-        gauss += alpha * (g0 + 0.5f * alpha * h0);
-        const float newcost = gauss + rowcost;
-        const float improvement = P.scale * (cost - newcost);
-        cost = newcost;
+        // cost(old) - cost(new) in closed form: the Gauss term of hulls and objects is quadratic along the search direction (g0, h0 hold both
+        // shares), the rows' share comes out of the line search's registers
+        const float improvement = P.scale * ((rowcost - rownew) - alpha * (g0 + 0.5f * alpha * h0));
+        rowcost = rownew;
         if (improvement < P.tol) { it++; done = true; break; }
     }
     if (!done) ncap++;          // the solver stopped at opt.iterations: counted per env in diag (flags >> 8)
@@ -1968,10 +2028,13 @@ __device__ __forceinline__ void step_body(StepArgs A, const int env_in, const in
         KP_SYNC();
         // qacc_smooth = M^-1 qfrc_smooth; sv = its spatial accelerations; Mv/mres = those of (warm start - qacc_smooth) for the Newton solve
         Lane8 L8; L8.init(kp_launder(tid), T.sched8);          // lives through the smooth solve and the Newton solve
-        aba_solve<NT, OBJ, true>(s, P, L8, s.applied, s.qacc_s, false, tid, D_NLEV, s.fb, s.qacc, s.Mv);
-        KP_T(4)
-        if constexpr (OBJ) niter_total += solve_constraints_obj<NT>(s, P, L8, tid, nfact_total, ncap_total);
-        else niter_total += solve_constraints<NT, OBJ>(s, P, L8, tid, nfact_total, ncap_total);
+        if constexpr (OBJ) {
+            KP_T(4)                                            // no smooth solve: the Newton solve starts from the warm start (solve_constraints_direct)
+            niter_total += solve_constraints_obj<NT>(s, P, L8, depth, tid, nfact_total, ncap_total);
+        } else {
+            KP_T(4)
+            niter_total += solve_constraints_direct<NT>(s, P, L8, depth, tid, nfact_total, ncap_total);
+        }
         KP_T(5)
         maxcon = max(maxcon, s.ncon);
         // ---- semi-implicit Euler (mj_Euler, no damping)
