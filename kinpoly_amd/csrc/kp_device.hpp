@@ -62,8 +62,7 @@ struct __attribute__((aligned(16))) EnvLds {
     float fb[144];                        // bias wrench of every body (gyroscopic + Coriolis + gravity), about o: enters the ABA passes as pA
     float qacc_s[76], qacc[76], search[76], Mv[76], mres[76], x[76], extra[76];
     float applied_pad[2], applied[6], ctrl[72];   // applied ++ ctrl is qfrc_applied + qfrc_actuator as one 76-vector: written by spd_torque_rfc, read by
-                                          // the smooth solve; between that solve and the next substep the same words hold the Newton gradient
-    __device__ __forceinline__ float* grad() { return applied; }
+                                          // every gradient of the Newton solve (the gradient itself lives in the words of qacc_s)
     float con_pos[D_MAXCON * 3], con_D[D_MAXCON];   // con_D: contact distance from collide() until make_constraint() turns it into the row weight D
     float jar3[D_MAXCON * 3];             // contact-frame (normal, t1, t2) residuals J qacc - aref
     float lim_D[72], lim_jar[72];         // joint-limit rows: lim_D = sign x weight (sign: +1 lower / -1 upper limit violated, 0 = no row)

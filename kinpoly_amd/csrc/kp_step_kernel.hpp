@@ -367,20 +367,16 @@ __device__ __forceinline__ void aba_elim3(EnvLds& s, const Lane8& L, const float
     }
 }
 
-// WARM: the pass also carries dl = spatial acceleration induced by (warm - out), the difference between a second generalized vector
-// and the solution (the Newton solve's warm-start candidate against qacc_smooth), at three FMAs per body and level
-template <bool WARM = false>
-__device__ __forceinline__ float aba_fwd3(EnvLds& s, const Lane8& L, float* out, int d0, bool store_ok, float a, const float* warm = nullptr, float* dl = nullptr) {
+__device__ __forceinline__ float aba_fwd3(EnvLds& s, const Lane8& L, float* out, int d0, bool store_ok, float a) {
     const int r = L.r;
     const int rc = r < 6 ? r : 5;
     const float rmask = r < 6 ? 1.f : 0.f;
-    float Ud[3], sd[3], ujd[3], Did[3], wd[3];
+    float Ud[3], sd[3], ujd[3], Did[3];
 #pragma unroll
     for (int j = 0; j < 3; j++) {
         const int d = d0 + j;
         Ud[j] = rmask * s.U[6 * d + rc]; sd[j] = s.cdof[6 * d + rc];
         ujd[j] = s.uj[d]; Did[j] = s.Dinv[d];
-        if (WARM) wd[j] = warm[d];
     }
     float qo[3];
 #pragma unroll
@@ -388,7 +384,6 @@ __device__ __forceinline__ float aba_fwd3(EnvLds& s, const Lane8& L, float* out,
         const float qdd = (ujd[j] - sum8(Ud[j] * a)) * Did[j];
         qo[j] = qdd;
         a += qdd * sd[j];
-        if (WARM) *dl += (wd[j] - qdd) * sd[j];
     }
     if (store_ok && r == 0) {
 #pragma unroll
@@ -398,8 +393,7 @@ __device__ __forceinline__ float aba_fwd3(EnvLds& s, const Lane8& L, float* out,
 }
 
 // root->leaves pass: joint accelerations from (U, 1/D, u) and the parent's spatial acceleration; leaves them in sv
-template <bool WARM = false>
-__device__ __forceinline__ void aba_forward(EnvLds& s, const Lane8& L, float* out, int lev_max = D_NLEV - 1, const float* warm = nullptr, float* dacc = nullptr) {
+__device__ __forceinline__ void aba_forward(EnvLds& s, const Lane8& L, float* out, int lev_max = D_NLEV - 1) {
     const int r = L.r;
     const bool rowok = r < 6;
 #pragma nounroll
@@ -409,15 +403,13 @@ __device__ __forceinline__ void aba_forward(EnvLds& s, const Lane8& L, float* ou
         const bool active = bq != 31;
         const int b = active ? bq : 0;
         float a = (rowok && par != 31) ? s.sv[6 * (par == 31 ? 0 : par) + r] : 0.f;
-        float dl = 0.f;
-        if (WARM) dl = (rowok && par != 31) ? dacc[6 * (par == 31 ? 0 : par) + r] : 0.f;
         if (lev == 0) {
-            a = aba_fwd3<WARM>(s, L, out, 0, active, a, warm, &dl);
-            a = aba_fwd3<WARM>(s, L, out, 3, active, a, warm, &dl);
+            a = aba_fwd3(s, L, out, 0, active, a);
+            a = aba_fwd3(s, L, out, 3, active, a);
         } else {
-            a = aba_fwd3<WARM>(s, L, out, b == 0 ? 6 : 6 + 3 * (b - 1), active, a, warm, &dl);
+            a = aba_fwd3(s, L, out, b == 0 ? 6 : 6 + 3 * (b - 1), active, a);
         }
-        if (active && rowok) { s.sv[6 * b + r] = a; if (WARM) dacc[6 * b + r] = dl; }
+        if (active && rowok) s.sv[6 * b + r] = a;
         KP_SYNC();
     }
 }
@@ -434,12 +426,12 @@ __device__ __forceinline__ unsigned contact_levels(const EnvLds& s, const Lane8&
     return m;
 }
 
-template <int NT, bool OBJ, bool WARM = false>
+template <int NT, bool OBJ>
 // lev_clean: tree levels >= lev_clean carry no active contact row and no active joint limit, so their articulated inertias, U and
-// 1/D are the ones the smooth solve (same M, no extra armature) left in LDS this substep: only the bias-force half runs there.
-// WARM: the root->leaves pass also leaves dacc[b] = spatial acceleration of body b induced by warm - out (see aba_fwd3).
+// 1/D are the ones the substep's first Newton factorisation (which walks every level; same M, no extra armature there) left in LDS:
+// only the bias-force half runs there.
 __device__ __forceinline__ void aba_solve(EnvLds& s, const Params& P, const Lane8& L, const float* rhs, float* out, bool contact_inertia, int tid, int lev_clean = D_NLEV, const float* bwrench = nullptr,
-                                          const float* warm = nullptr, float* dacc = nullptr, unsigned conlev = 0xFFFFFFFFu) {
+                                          unsigned conlev = 0xFFFFFFFFu) {
     const int r = L.r;
     const bool rowok = r < 6;
 #pragma nounroll
@@ -569,7 +561,7 @@ __device__ __forceinline__ void aba_solve(EnvLds& s, const Params& P, const Lane
         }
         KP_SYNC();
     }
-    aba_forward<WARM>(s, L, out, D_NLEV - 1, warm, dacc);
+    aba_forward(s, L, out, D_NLEV - 1);
 }
 
 // out = H^-1 (rhs + J_body^T wrench) with the factorisation (U, 1/D) the last aba_solve left in LDS: the bias-force half of the
@@ -1144,98 +1136,9 @@ __device__ __forceinline__ float line_search(EnvLds& s, const Params& P, float g
     return alpha;
 }
 
-// constraint solve: Newton on the primal problem (mj_solNewton) with an exact line search.  Returns iterations.
-// On entry sv holds the spatial accelerations of qacc_s (left by the smooth aba_solve), jv3 holds aref.
-template <int NT, bool OBJ>
-__device__ __forceinline__ int solve_constraints(EnvLds& s, const Params& P, const Lane8& L8, int tid, int& nfact, int& ncap) {
-    if (s.ncon == 0 && s.nlim == 0) {
-        for (int i = tid; i < D_NV; i += NT) s.qacc[i] = s.qacc_s[i];
-        KP_SYNC();
-        return 0;
-    }
-    // candidate A: qacc_smooth (M qacc_s = qfrc_smooth => Gauss term 0); sv holds its spatial accelerations
-    eval_rows<NT, OBJ>(s, s.qacc_s, s.jar3, s.lim_jar, true, tid);
-    float cost = primal_cost<NT>(s, P, nullptr, s.jar3, s.lim_jar, tid);
-    float gauss = 0.f;         // Gauss term 0.5 (qacc - qacc_s)^T M (qacc - qacc_s) of the iterate: exact quadratic along a search direction, carried forward
-    // The Gauss part of the problem is carried in body form: sacc[b] = spatial acceleration of body b induced by qacc - qacc_s, so
-    // M (qacc - qacc_s) never has to be projected on the dofs on its own (it rides along with the gradient's projection).
-    float* sacc = s.Mv;        // [24][6] over Mv + mres (152 floats)
-    // candidate B: warm start = s.qacc (qacc of the previous substep / control step), mj_fwdConstraint's rule.  The smooth solve's
-    // root->leaves pass already left sacc = spatial accelerations of qacc - qacc_s (aba_solve<.., WARM>), and the rows are linear, so
-    // its residuals are candidate A's plus the rows of the difference: no second accumulation pass, aref is not needed again.
-    {
-        float* wj3 = s.jv3;    // over aref (not needed afterwards)
-        float* wlim = s.x;     // U must stay as the smooth solve left it (aba_solve's clean levels)
-        eval_rows<NT, OBJ>(s, s.qacc, wj3, wlim, false, tid, sacc, s.qacc_s, true);
-        float gw;
-        float cw = primal_cost<NT>(s, P, sacc, wj3, wlim, tid, &gw);
-        if (cw < cost) {
-            cost = cw; gauss = gw;
-            for (int k = tid; k < 3 * s.ncon; k += NT) s.jar3[k] = wj3[k];
-            for (int j = tid; j < D_NU; j += NT) s.lim_jar[j] = wlim[j];
-        } else {
-            for (int i = tid; i < D_NV; i += NT) s.qacc[i] = s.qacc_s[i];
-            for (int i = tid; i < D_NB * 6; i += NT) sacc[i] = 0.f;
-        }
-        KP_SYNC();
-    }
-    int it = 0, lev_hist = 1;
-    bool done = false;          // left the loop through one of mj_solNewton's termination tests (not the iteration cap)
-    const unsigned conlev = contact_levels(s, L8);
-    for (; it < P.max_iter; it++) {
-        // gradient = M (qacc - qacc_s) - J^T f: one projection of the body wrenches I_b sacc_b - contact forces
-        wrench_project<NT, OBJ>(s, P, sacc, s.qacc, s.qacc_s, s.grad(), true, true, tid);
-        float g2 = 0.f, changed = 0.f, deep = 0.f;
-        for (int i = tid; i < D_NV; i += NT) {
-            float g = s.grad()[i];
-            g2 += g * g;
-            s.x[i] = -g;
-            const float ex = (i >= 6 && s.lim_jar[i - 6] < 0.f) ? fabsf(s.lim_D[i - 6]) : 0.f;
-            if (ex != s.extra[i]) changed = 1.f;
-            s.extra[i] = ex;
-            if (ex != 0.f) deep = fmaxf(deep, (float)s.bdep[s.dbody[i]]);     // active joint limit: its body's level is dirty
-        }
-        changed += active_set_changed<NT>(s, P, tid, deep);
-        g2 = block_sum<NT>(s, g2, tid);
-        changed = (NT == 64) ? (__ballot(changed > 0.f) != 0ull ? 1.f : 0.f) : block_sum<NT>(s, changed, tid);     // one wave: a ballot is the whole reduction
-        KP_SYNC();
-        if (P.scale * sqrtf(g2) < P.tol) { done = true; break; }
-        // search = -H^-1 grad,  H = M + J^T D_active J : articulated-body pass with contact inertia; while the active set
-        // stands the factorisation of the previous iteration is reused (mj_solNewton updates its Cholesky factor the same way)
-        if (it == 0 || changed > 0.f) {
-            // levels an earlier factorisation of this substep rewrote no longer hold the smooth solve's factors: the clean range only shrinks
-            lev_hist = max(lev_hist, first_clean_level<NT>(s, deep, tid));
-            aba_solve<NT, OBJ>(s, P, L8, s.x, s.search, true, tid, lev_hist, nullptr, nullptr, nullptr, conlev);
-            nfact++;
-        }
-        else aba_resolve(s, L8, s.x, nullptr, s.search);
-        eval_rows<NT, OBJ>(s, s.search, s.jv3, s.lim_jv, false, tid);           // aref (in jv3) is folded into jar3 by now
-        // exact line search on phi(alpha): g0 = search^T M (qacc - qacc_s), h0 = search^T M search, both in body form (sv = search's accelerations)
-        float g0 = 2.0f * quad_form_M<NT>(s, s.sv, sacc, s.search, nullptr, s.qacc, s.qacc_s, tid);
-        float h0 = 2.0f * quad_form_M<NT>(s, s.sv, s.sv, s.search, nullptr, s.search, nullptr, tid);
-        g0 = block_sum<NT>(s, g0, tid); h0 = block_sum<NT>(s, h0, tid);
-        float rowcost;
-        const float alpha = line_search<NT>(s, P, g0, h0, tid, rowcost);
-        if (!(alpha > 0.f)) { done = true; break; }
-        for (int i = tid; i < D_NV; i += NT) s.qacc[i] += alpha * s.search[i];
-        for (int i = tid; i < D_NB * 6; i += NT) sacc[i] += alpha * s.sv[i];
-        for (int k = tid; k < 3 * s.ncon; k += NT) s.jar3[k] += alpha * s.jv3[k];
-        for (int j = tid; j < D_NU; j += NT) if (s.lim_D[j] != 0.f) s.lim_jar[j] += alpha * s.lim_jv[j];
-        KP_SYNC();
-        // cost at the new iterate without another pass over bodies and rows: the Gauss term is quadratic along the search direction
-        // (g0 = search^T M (qacc - qacc_s), h0 = search^T M search), the rows' share comes from the line search's registers
-        gauss += alpha * (g0 + 0.5f * alpha * h0);
-        float newcost = gauss + rowcost;
-        float improvement = P.scale * (cost - newcost);
-        cost = newcost;
-        if (improvement < P.tol) { it++; done = true; break; }
-    }
-    if (!done) ncap++;          // the solver stopped at opt.iterations: counted per env in diag (flags >> 8)
-    return it;
-}
-
-// The same Newton solve WITHOUT qacc_smooth (floor kernel).  mj_fwdConstraint evaluates two starting points -- qacc_smooth and the warm start --
-// and iterates from the cheaper one; the primal problem is strictly convex, so its minimiser does not depend on the starting point, and its cost
+// Constraint solve: Newton on the primal problem (mj_solNewton) with an exact line search, WITHOUT qacc_smooth.  Returns iterations.
+// mj_fwdConstraint evaluates two starting points -- qacc_smooth and the warm start -- and iterates from the cheaper one (rounds 1 - 2 did the
+// same); the primal problem is strictly convex, so its minimiser does not depend on the starting point, and its cost
 //     0.5 (a - a_s)^T M (a - a_s) + s(J a - aref)  =  0.5 a^T M a - a^T qfrc_smooth + s(J a - aref) + const
 // needs a_s = M^-1 qfrc_smooth neither for the gradient (M a - qfrc_smooth - J^T f, in body form: I_b sacc_b + fb_b - contact wrenches, projected)
 // nor for the termination tests (|gradient| and the cost DIFFERENCE of consecutive iterates, exact in closed form along the search direction).
@@ -1281,7 +1184,7 @@ __device__ __forceinline__ int solve_constraints_direct(EnvLds& s, const Params&
             const int clean = first_clean_level<NT>(s, deep, tid);
             lev_hist = max(lev_hist, clean);
             // first factorisation of the substep: every level (its clean levels ARE M's factors from then on)
-            aba_solve<NT, false>(s, P, L8, s.x, s.search, true, tid, it == 0 ? D_NLEV : lev_hist, nullptr, nullptr, nullptr, conlev);
+            aba_solve<NT, false>(s, P, L8, s.x, s.search, true, tid, it == 0 ? D_NLEV : lev_hist, nullptr, conlev);
             nfact++;
         }
         else aba_resolve(s, L8, s.x, nullptr, s.search);
@@ -1842,7 +1745,7 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
             if (no6 > 0) obj_hessian(s, P, s.ogr, -1.0f, tid);
             lev_hist = max(lev_hist, first_clean_level<NT>(s, deep, tid));   // the clean range only shrinks within a substep
             // the substep's first factorisation walks every level: its clean levels hold M's own factors from then on
-            aba_solve<NT, true>(s, P, L8, s.x, s.search, true, tid, it == 0 ? D_NLEV : lev_hist, nullptr, nullptr, nullptr, conlev);     // y0 = H_hh^-1 (-g_h); sv = its spatial accelerations
+            aba_solve<NT, true>(s, P, L8, s.x, s.search, true, tid, it == 0 ? D_NLEV : lev_hist, nullptr, conlev);     // y0 = H_hh^-1 (-g_h); sv = its spatial accelerations
             if (couple) { obj_coupling_u(s, P, s.ot, tid); if (tid < no6) s.Sm[ST * tid + no6] += s.ot[tid]; KP_SYNC(); }     // rhs_o -= H_oh y0
         }
         if (refactor && couple) schur_columns(s, P, cmask, tid);          // S = H_oo - H_oh H_hh^-1 H_ho, all columns in one or two rounds
@@ -2026,8 +1929,7 @@ __device__ __forceinline__ void step_body(StepArgs A, const int env_in, const in
         if (!P.stale && P.actuation) { Lane8 La; La.init(kp_launder(tid), T.sched8); spd_torque_rfc<NT, OBJ>(s, T, P, La, tid, tq_row, act_row); }
         for (int i = tid; i < D_NV; i += NT) s.extra[i] = 0.f;
         KP_SYNC();
-        // qacc_smooth = M^-1 qfrc_smooth; sv = its spatial accelerations; Mv/mres = those of (warm start - qacc_smooth) for the Newton solve
-        Lane8 L8; L8.init(kp_launder(tid), T.sched8);          // lives through the smooth solve and the Newton solve
+        Lane8 L8; L8.init(kp_launder(tid), T.sched8);          // lives through the Newton solve
         if constexpr (OBJ) {
             KP_T(4)                                            // no smooth solve: the Newton solve starts from the warm start (solve_constraints_direct)
             niter_total += solve_constraints_obj<NT>(s, P, L8, depth, tid, nfact_total, ncap_total);
@@ -2134,8 +2036,8 @@ __global__ __launch_bounds__(64) void kp_mass_kernel(StepArgs A, float* __restri
         for (int i = tid; i < D_NV; i += NT) s.x[i] = i == j ? 1.f : 0.f;
         KP_SYNC();
         spatial_accumulate<NT>(s, s.x, depth, tid);
-        wrench_project<NT, false>(s, P, s.sv, s.x, nullptr, s.grad(), true, false, tid);
-        for (int d = tid; d < D_NV; d += NT) Mout[((size_t)env * D_NV + d) * D_NV + j] = s.grad()[d];
+        wrench_project<NT, false>(s, P, s.sv, s.x, nullptr, s.qacc_s, true, false, tid);
+        for (int d = tid; d < D_NV; d += NT) Mout[((size_t)env * D_NV + d) * D_NV + j] = s.qacc_s[d];
         KP_SYNC();
     }
 }

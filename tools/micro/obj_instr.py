@@ -14,8 +14,8 @@ def patch(s):
         nonlocal s
         assert a in s, a[:80]
         s = s.replace(a, b, cnt)
-    rep('''__device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params& P, const Lane8& L8, int tid, int& nfact, int& ncap) {
-''', '''__device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params& P, const Lane8& L8, int tid, int& nfact, int& ncap, unsigned long long* np) {
+    rep('''__device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params& P, const Lane8& L8, int depth, int tid, int& nfact, int& ncap) {
+''', '''__device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params& P, const Lane8& L8, int depth, int tid, int& nfact, int& ncap, unsigned long long* np) {
     unsigned long long t0_ = __builtin_readcyclecounter();
 #define NP(i) { unsigned long long t1_ = __builtin_readcyclecounter(); np[i] += t1_ - t0_; t0_ = t1_; }
 ''')
@@ -36,26 +36,24 @@ def patch(s):
         if (tid < no6) s.sv[6 * D_NB + tid] = s.osrch[tid];
         KP_SYNC();
         eval_rows<NT, true>(s, s.search, s.jv3, s.lim_jv, false, tid);''')
-    rep('''        const float alpha = line_search<NT>(s, P, g0, h0, tid, rowcost);
+    rep('''        const float alpha = line_search<NT>(s, P, g0, h0, tid, rownew);
         if (!(alpha > 0.f)) { done = true; break; }
         for (int i = tid; i < D_NV; i += NT) s.qacc[i] += alpha * s.search[i];
         for (int i = tid; i < D_NB * 6; i += NT) sacc[i] += alpha * s.sv[i];
-        if (tid < no6)''', '''        const float alpha = line_search<NT>(s, P, g0, h0, tid, rowcost);
+        if (tid < no6)''', '''        const float alpha = line_search<NT>(s, P, g0, h0, tid, rownew);
         NP(5)
         if (!(alpha > 0.f)) { done = true; break; }
         for (int i = tid; i < D_NV; i += NT) s.qacc[i] += alpha * s.search[i];
         for (int i = tid; i < D_NB * 6; i += NT) sacc[i] += alpha * s.sv[i];
         if (tid < no6)''')
-    rep('''        const float improvement = P.scale * (cost - newcost);
-        cost = newcost;
+    rep('''        rowcost = rownew;
         if (improvement < P.tol) { it++; done = true; break; }
     }
     if (!done) ncap++;          // the solver stopped at opt.iterations: counted per env in diag (flags >> 8)
     return it;
 }
 
-// ---------------------------------------------------------------- the kernel''', '''        const float improvement = P.scale * (cost - newcost);
-        cost = newcost;
+// ---------------------------------------------------------------- the kernel''', '''        rowcost = rownew;
         NP(6)
         if (improvement < P.tol) { it++; done = true; break; }
     }
@@ -65,8 +63,8 @@ def patch(s):
 
 // ---------------------------------------------------------------- the kernel''')
     rep("#define KP_T(i) if (prof) { t1 = __builtin_readcyclecounter(); pc[i] += t1 - t0; t0 = t1; }", "#define KP_T(i)")
-    rep("if constexpr (OBJ) niter_total += solve_constraints_obj<NT>(s, P, L8, tid, nfact_total, ncap_total);",
-        "if constexpr (OBJ) niter_total += solve_constraints_obj<NT>(s, P, L8, tid, nfact_total, ncap_total, pc);")
+    rep("niter_total += solve_constraints_obj<NT>(s, P, L8, depth, tid, nfact_total, ncap_total);",
+        "niter_total += solve_constraints_obj<NT>(s, P, L8, depth, tid, nfact_total, ncap_total, pc);")
     return s
 
 
