@@ -1026,17 +1026,21 @@ __device__ __forceinline__ float primal_cost(EnvLds& s, const Params& P, const f
     return gauss + block_sum<NT>(s, c, tid);
 }
 
-// spatial "acceleration" of every body induced by a generalized vector (what aba_solve leaves in sv)
+// spatial "acceleration" of every body induced by a generalized vector (what aba_solve leaves in sv).  Each body's own share
+// da_b = sum_j vec_j cdof_j is formed body-parallel first, so the level-synchronous chain is one 6-vector add per level (as in the kinematics).
 template <int NT>
-__device__ __forceinline__ void spatial_accumulate(EnvLds& s, const float* vec, int depth, int tid) {
-    for (int lev = 0; lev < D_NLEV; lev++) {
-        if (depth == lev) {
-            const int b = tid;
-            S6 a = b == 0 ? S6{v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f)} : lds6(s.sv + 6 * s.bpar[b]);
-            const int nd = b == 0 ? 6 : 3, d0 = b == 0 ? 0 : 6 + 3 * (b - 1);
-            for (int j = 0; j < nd; j++) a = a + vec[d0 + j] * lds6(s.cdof + 6 * (d0 + j));
-            sts6(s.sv + 6 * b, a);
-        }
+__device__ __forceinline__ void spatial_accumulate(EnvLds& s, const float* vec, int depth, int tid, float* out = nullptr) {
+    if (!out) out = s.sv;
+    S6 da = S6{v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f)};
+    if (tid < D_NB) {
+        const int b = tid, nd = b == 0 ? 6 : 3, d0 = b == 0 ? 0 : 6 + 3 * (b - 1);
+        for (int j = 0; j < nd; j++) da = da + vec[d0 + j] * lds6(s.cdof + 6 * (d0 + j));
+        if (b == 0) sts6(out, da);
+    }
+    KP_SYNC();
+#pragma nounroll
+    for (int lev = 1; lev < D_NLEV; lev++) {
+        if (depth == lev) sts6(out + 6 * tid, lds6(out + 6 * s.bpar[tid]) + da);
         KP_SYNC();
     }
 }
@@ -1155,9 +1159,7 @@ __device__ __forceinline__ int solve_constraints_direct(EnvLds& s, const Params&
     }
     float* sacc = s.Mv;        // [24][6] over Mv + mres: spatial accelerations of the bodies induced by the iterate qacc
     float* grad = s.qacc_s;    // the words qacc_smooth would occupy
-    spatial_accumulate<NT>(s, s.qacc, depth, tid);
-    for (int i = tid; i < D_NB * 6; i += NT) sacc[i] = s.sv[i];
-    KP_SYNC();
+    spatial_accumulate<NT>(s, s.qacc, depth, tid, sacc);
     eval_rows<NT, false>(s, s.qacc, s.jar3, s.lim_jar, true, tid, sacc);
     float rowcost = primal_cost<NT>(s, P, nullptr, s.jar3, s.lim_jar, tid);          // the rows' share of the cost at the iterate
     int it = 0, lev_hist = 1;
@@ -1689,8 +1691,7 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
     float* sacc = s.Mv;        // [24 + 2][6] over Mv + mres (+ x[0..3]): spatial accelerations induced by the iterate (hulls: of qacc; object slots: oa, for the first row evaluation)
     float* grad = s.qacc_s;    // the words qacc_smooth would occupy
     static_assert(offsetof(EnvLds, x) == offsetof(EnvLds, Mv) + 152 * sizeof(float), "sacc's object slots continue into x");
-    spatial_accumulate<NT>(s, s.qacc, depth, tid);
-    for (int i = tid; i < D_NB * 6; i += NT) sacc[i] = s.sv[i];
+    spatial_accumulate<NT>(s, s.qacc, depth, tid, sacc);
     if (tid < no6) sacc[6 * D_NB + tid] = s.oa[tid];
     if (tid < nobj) sts6(s.omres + 6 * tid, inert_mul(s.oIe + 10 * tid, lds6(s.oa + 6 * tid) + (-1.0f) * lds6(s.oas + 6 * tid)));
     KP_SYNC();
