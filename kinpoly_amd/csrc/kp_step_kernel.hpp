@@ -1009,23 +1009,6 @@ __device__ __forceinline__ float quad_form_M(const EnvLds& s, const float* acca,
     return c;
 }
 
-// primal cost at the current iterate:  0.5 (qacc - qacc_s)^T M (qacc - qacc_s) + sum 0.5 D jar_-^2.  sacc = body spatial
-// accelerations of qacc - qacc_s (null: qacc = qacc_s, Gauss term 0)
-template <int NT>
-// gauss_out (optional): receives the Gauss term alone (the Newton loop then carries it forward in closed form along each search direction)
-__device__ __forceinline__ float primal_cost(EnvLds& s, const Params& P, const float* sacc, const float* jar3, const float* lim_jar, int tid, float* gauss_out = nullptr) {
-    float c = sacc ? quad_form_M<NT>(s, sacc, sacc, s.qacc, s.qacc_s, s.qacc, s.qacc_s, tid) : 0.f;
-    float gauss = 0.f;
-    if (gauss_out) { gauss = block_sum<NT>(s, c, tid); *gauss_out = gauss; c = 0.f; }
-    for (int k = tid; k < s.ncon; k += NT) {
-        const float Dc = s.con_D[k], jn = jar3[3 * k], jt1 = jar3[3 * k + 1], jt2 = jar3[3 * k + 2];
-#pragma unroll
-        for (int e = 0; e < 4; e++) { float x = row_val(e, P.mu, jn, jt1, jt2); if (x < 0.f) c += 0.5f * Dc * x * x; }
-    }
-    for (int j = tid; j < D_NU; j += NT) { float x = lim_jar[j]; if (x < 0.f) c += 0.5f * fabsf(s.lim_D[j]) * x * x; }
-    return gauss + block_sum<NT>(s, c, tid);
-}
-
 // spatial "acceleration" of every body induced by a generalized vector (what aba_solve leaves in sv).  Each body's own share
 // da_b = sum_j vec_j cdof_j is formed body-parallel first, so the level-synchronous chain is one 6-vector add per level (as in the kinematics).
 template <int NT>
@@ -1088,7 +1071,9 @@ __device__ __forceinline__ int first_clean_level(EnvLds& s, float deep, int tid)
 // ROWCOST = false leaves rowcost alone (rounds 1 - 2: the object kernel kept its full cost evaluation because three more live values across
 // the search moved spills into its articulated-body loops; since the round-3 register discipline both solvers take the closed form)
 template <int NT, bool ROWCOST = true>
-__device__ __forceinline__ float line_search(EnvLds& s, const Params& P, float g0, float h0, int tid, float& rowcost) {
+// want_rc0: rc0 receives the rows' share of the cost at alpha = 0, i.e. at the iterate the search starts from (the solve's first iteration has no
+// previous line search to take it from)
+__device__ __forceinline__ float line_search(EnvLds& s, const Params& P, float g0, float h0, int tid, float& rowcost, bool want_rc0, float& rc0) {
     static_assert(D_MAXCON <= 64 && NT >= 64, "one contact per lane");
     float ra[4], rb[4], rD[4], Dc;
     {
@@ -1109,6 +1094,14 @@ __device__ __forceinline__ float line_search(EnvLds& s, const Params& P, float g
         const float w = ok ? fabsf(s.lim_D[jj]) : 0.f;
         if (ROWCOST) lW[n] = w;
         la[n] = ok ? s.lim_jar[jj] : 0.f; lb[n] = ok ? s.lim_jv[jj] : 0.f; lD[n] = w * lb[n];
+    }
+    if (ROWCOST && want_rc0) {
+        float rc = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; e++) if (ra[e] < 0.f) rc += 0.5f * Dc * ra[e] * ra[e];
+#pragma unroll
+        for (int n = 0; n < LR; n++) if (la[n] < 0.f) rc += 0.5f * lW[n] * la[n] * la[n];
+        rc0 = block_sum<NT>(s, rc, tid);
     }
     // The search direction solves H search = -grad with the Hessian of the current active set, so phi'(0) = -phi''(0) and the Newton
     // step from alpha = 0 is 1: the first evaluation happens there, bracketed by lo = 0 (descent direction).
@@ -1161,7 +1154,7 @@ __device__ __forceinline__ int solve_constraints_direct(EnvLds& s, const Params&
     float* grad = s.qacc_s;    // the words qacc_smooth would occupy
     spatial_accumulate<NT>(s, s.qacc, depth, tid, sacc);
     eval_rows<NT, false>(s, s.qacc, s.jar3, s.lim_jar, true, tid, sacc);
-    float rowcost = primal_cost<NT>(s, P, nullptr, s.jar3, s.lim_jar, tid);          // the rows' share of the cost at the iterate
+    float rowcost = 0.f;       // the rows' share of the cost at the iterate (the first line search evaluates it at alpha = 0)
     int it = 0, lev_hist = 1;
     bool done = false;          // left the loop through one of mj_solNewton's termination tests (not the iteration cap)
     const unsigned conlev = contact_levels(s, L8);
@@ -1197,8 +1190,9 @@ __device__ __forceinline__ int solve_constraints_direct(EnvLds& s, const Params&
         for (int i = tid; i < D_NB * 6; i += NT) g0 += s.sv[i] * s.fb[i];
         for (int i = tid; i < D_NV; i += NT) g0 -= s.search[i] * s.applied[i];
         g0 = block_sum<NT>(s, g0, tid); h0 = block_sum<NT>(s, h0, tid);
-        float rownew;
-        const float alpha = line_search<NT>(s, P, g0, h0, tid, rownew);
+        float rownew, rc0 = 0.f;
+        const float alpha = line_search<NT>(s, P, g0, h0, tid, rownew, it == 0, rc0);
+        if (it == 0) rowcost = rc0;
         if (!(alpha > 0.f)) { done = true; break; }
         for (int i = tid; i < D_NV; i += NT) s.qacc[i] += alpha * s.search[i];
         for (int i = tid; i < D_NB * 6; i += NT) sacc[i] += alpha * s.sv[i];
@@ -1507,13 +1501,6 @@ __device__ __forceinline__ void obj_gradient(EnvLdsObj& s, int tid) {
     if (tid < 6 * s.nobj) s.ogr[tid] = s.omres[tid] + sum;
     KP_SYNC();
 }
-// 0.5 mres_o . (a_o - a_smooth_o) summed over the objects (every lane gets the value)
-__device__ __forceinline__ float obj_gauss(const EnvLdsObj& s) {
-    float c = 0.f;
-    for (int i = 0; i < 6 * s.nobj; i++) c += 0.5f * s.omres[i] * (s.oa[i] - s.oas[i]);
-    return c;
-}
-
 // spatial -> joint-space acceleration of the objects, then the same semi-implicit Euler step as the humanoid root
 __device__ __forceinline__ void obj_integrate(EnvLdsObj& s, const Params& P, int tid) {
     if (tid < s.nobj) {
@@ -1696,7 +1683,7 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
     if (tid < nobj) sts6(s.omres + 6 * tid, inert_mul(s.oIe + 10 * tid, lds6(s.oa + 6 * tid) + (-1.0f) * lds6(s.oas + 6 * tid)));
     KP_SYNC();
     eval_rows<NT, true>(s, s.qacc, s.jar3, s.lim_jar, true, tid, sacc);
-    float rowcost = primal_cost<NT>(s, P, nullptr, s.jar3, s.lim_jar, tid);          // the rows' share of the cost at the iterate
+    float rowcost = 0.f;       // the rows' share of the cost at the iterate (the first line search evaluates it at alpha = 0)
     int it = 0, lev_hist = 1;
     bool done = false;          // left the loop through one of mj_solNewton's termination tests (not the iteration cap)
     const unsigned conlev = contact_levels(s, L8);
@@ -1778,8 +1765,9 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
         for (int i = tid; i < D_NV; i += NT) g0 -= s.search[i] * s.applied[i];
         if (tid < no6) { g0 += s.osrch[tid] * s.omres[tid]; h0 += s.osrch[tid] * s.oMv[tid]; }                // ... and search^T I_eff (oa - oas) for the objects
         g0 = block_sum<NT>(s, g0, tid); h0 = block_sum<NT>(s, h0, tid);
-        float rownew;
-        const float alpha = line_search<NT>(s, P, g0, h0, tid, rownew);
+        float rownew, rc0 = 0.f;
+        const float alpha = line_search<NT>(s, P, g0, h0, tid, rownew, it == 0, rc0);
+        if (it == 0) rowcost = rc0;
         if (!(alpha > 0.f)) { done = true; break; }
         for (int i = tid; i < D_NV; i += NT) s.qacc[i] += alpha * s.search[i];
         for (int i = tid; i < D_NB * 6; i += NT) sacc[i] += alpha * s.sv[i];
