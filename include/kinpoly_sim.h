@@ -52,9 +52,9 @@ void kp_model_free(kp_model*);
  * "actuation" (0/1, default 1; 0: ctrl = qfrc_applied = 0, i.e. do_simulation without compute_torque / rfc: torque-free motion for tests), "stale_kinematics" (0/1, default 1: SPD and
  * read-outs see the one-substep-stale derived quantities mujoco-py exposes), "solver_iter" (default: the blob's
  * mjOption.iterations = 100; cap hits are counted in kp_sim_diag), "solver_tol", "threads_per_env" (64/128/256), "dynamic_objects" (0/1);
- * scheduling only (results do not depend on them): "substeps_per_job" (default 3; 0 = one workgroup per env and control step):
- * with more envs than resident wavefront slots a control step is cut into jobs of that many substeps (the last job; with "job_taper"
- * = 1, the default, each earlier job is two substeps longer: 15 = 7 + 5 + 3) which resident waves pull from a FIFO, so that the
+ * scheduling only (results do not depend on them): "substeps_per_job" (default 4; 0 = one workgroup per env and control step):
+ * with more envs than resident wavefront slots a control step is cut into jobs of that many substeps (the last job; each earlier job is
+ * "job_taper" substeps longer, default 1: 15 = 6 + 5 + 4; 0 = uniform) which resident waves pull from a FIFO, so that the
  * launch does not end on the tail of its longest envs; "queue_slots" (0 = CUs x 8, x 6 with objects); "queue_fence" (0/1, default 1: the job hand-over is an agent-scope
  * release / acquire fence pair around relaxed write-through accesses, correct by the HIP memory model; 0 = without the fences, +0.5 %);
  * "lpt_order" (1 / 0 / -1 = default: on when free objects are simulated): longest-env-first order of the workgroups (plain launch) or of the
@@ -273,8 +273,8 @@ int kp_sim_diag(kp_sim*, int32_t* out_host);
 int kp_sim_launch_cost(kp_sim*, uint32_t* out_host);
 
 /* the job sizes kp_sim_step_ctrl uses for a control step of n_substeps when it schedules through the job queue (host arithmetic, no
- * device): sizes16[0 .. return value) sum to n_substeps, the last is substeps_per_job (or absorbs a smaller remainder), earlier
- * ones grow by 2 with taper.  Returns the number of jobs (<= 16) or a negative error. */
+ * device): sizes16[0 .. return value) sum to n_substeps, the last is substeps_per_job (or absorbs a smaller remainder), every earlier
+ * one is `taper` substeps longer than the one after it (the first takes what is left).  Returns the number of jobs (<= 16) or a negative error. */
 int kp_job_schedule(int n_substeps, int substeps_per_job, int taper, int* sizes16);
 
 /* seconds the last kp_sim_step_ctrl launch took, measured with HIP events on the sim's stream

@@ -27,7 +27,7 @@ int fail(const std::string& m) { g_err = m; return -1; }
 
 struct kp_model {
     kp::HostModel h;
-    int contact = 1, limits = 1, stale = 1, solver_iter = 100, threads = 64, dynamic_objects = 1, lpt_order = -1, substeps_per_job = 3, queue_slots = 0, job_taper = 1, queue_fence = 1;
+    int contact = 1, limits = 1, stale = 1, solver_iter = 100, threads = 64, dynamic_objects = 1, lpt_order = -1, substeps_per_job = 4, queue_slots = 0, job_taper = 1, queue_fence = 1;
     int planemesh_max = 3; double planemesh_tol = 0.3;   // mjc_PlaneConvex's maxplanemesh / tolplanemesh (the blob's `planemesh`)
     int actuation = 1;            // 0: no stable-PD torque, no residual force (ctrl = qfrc_applied = 0): torque-free flight for the energy test
     double solver_tol = 1e-8, gravity_z = -9.81, gravity_x = 0.0, gravity_y = 0.0;   // solver_iter / solver_tol: mjOption.iterations / tolerance of the reference model (kp_model_load)
@@ -215,7 +215,7 @@ int job_schedule(int nsub, int spj, int taper, int* sizes) {
         int take = parts == 15 ? rem : std::min(rem, size);
         if (rem - take > 0 && rem - take < spj) take = rem;
         sizes[parts++] = take; rem -= take;
-        if (taper) size += 2;
+        size += taper;
     }
     std::reverse(sizes, sizes + parts);
     return parts;
@@ -337,7 +337,7 @@ int kp_model_set_option(kp_model* m, const char* name, double v) {
     else if (k == "planemesh_max") { if (v < 1 || v > 8) return fail("planemesh_max must be 1 .. 8"); m->planemesh_max = (int)v; }
     else if (k == "planemesh_tol") { if (v < 0) return fail("planemesh_tol must be >= 0"); m->planemesh_tol = v; }
     else if (k == "lpt_order") m->lpt_order = v < 0 ? -1 : (v != 0);
-    else if (k == "job_taper") m->job_taper = v != 0;
+    else if (k == "job_taper") m->job_taper = std::max(0, std::min(8, (int)v));
     else if (k == "queue_fence") m->queue_fence = v != 0;
     else if (k == "queue_slots") { if (v < 0) return fail("queue_slots must be >= 0 (0 = resident wave slots of the device)"); m->queue_slots = (int)v; }
     else if (k == "substeps_per_job") { if (v < 0 || v > 255) return fail("substeps_per_job must be 0 (whole control step per workgroup) .. 255"); m->substeps_per_job = (int)v; }

@@ -390,11 +390,11 @@ class KpSim:
         return self.L.kp_sim_last_step_seconds(self.h)
 
 
-def job_schedule(n_substeps: int, substeps_per_job: int = 3, taper: bool = True) -> list:
+def job_schedule(n_substeps: int, substeps_per_job: int = 4, taper: int = 1) -> list:
     """Job sizes of the queue-scheduled control step (kp_job_schedule; host arithmetic only)."""
     L = load_library()
     out = (C.c_int * 16)()
-    n = L.kp_job_schedule(int(n_substeps), int(substeps_per_job), int(bool(taper)), out)
+    n = L.kp_job_schedule(int(n_substeps), int(substeps_per_job), int(taper), out)
     if n < 0:
         raise KinPolyNativeError(f"kp_job_schedule: {L.kp_last_error().decode()}")
     return list(out[:n])

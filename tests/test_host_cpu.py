@@ -112,19 +112,20 @@ def test_job_schedule_host_logic():
     """kp_job_schedule (host arithmetic of the queue-scheduled control step): sizes sum to the control step, at most 16 jobs, the
     last job is substeps_per_job long unless the whole step is shorter, tapered sizes never grow towards the end."""
     from kinpoly_amd import sim as kpsim
-    assert kpsim.job_schedule(15, 3, True) == [7, 5, 3]
-    assert kpsim.job_schedule(15, 3, False) == [3, 3, 3, 3, 3]
-    assert kpsim.job_schedule(15, 16, True) == [15]
+    assert kpsim.job_schedule(15) == [6, 5, 4]            # the default schedule of a control step
+    assert kpsim.job_schedule(15, 3, 2) == [7, 5, 3]
+    assert kpsim.job_schedule(15, 3, 0) == [3, 3, 3, 3, 3]
+    assert kpsim.job_schedule(15, 16, 1) == [15]
     for nsub in (1, 2, 7, 15, 16, 30, 100, 255):
         for spj in (1, 2, 3, 5, 8):
-            for taper in (False, True):
+            for taper in (0, 1, 2):
                 sz = kpsim.job_schedule(nsub, spj, taper)
                 assert sum(sz) == nsub and 1 <= len(sz) <= 16 and min(sz) >= 1
                 assert sz[-1] == spj or len(sz) == 1 or len(sz) == 16
                 if taper and len(sz) > 2:
                     assert all(a >= b for a, b in zip(sz[1:], sz[2:]))
     with pytest.raises(kpsim.KinPolyNativeError):
-        kpsim.job_schedule(0, 3, True)
+        kpsim.job_schedule(0, 3, 1)
 
 
 # ------------------------------------------------------------------ the model compiler behind the C ABI (kp_model_compile; needs no GPU)
