@@ -205,10 +205,10 @@ bool build_tables(kp_sim* s) {
     return ok;
 }
 
-// Job sizes of kp_step_queue_kernel for a control step of nsub substeps: `spj` substeps for the last job and (taper) two more for each job
+// Job sizes of kp_step_queue_kernel for a control step of nsub substeps: `spj` substeps for the last job and `taper` more for each job
 // before it -- the FIFO runs all envs' first jobs, then all second jobs ...: long jobs first keep the hand-overs few, short jobs
 // last keep the end of the launch short -- what is left over becomes the first job (or joins it if shorter than spj); at most 16 jobs.
-// 15 = 7 + 5 + 3.
+// Default (spj 4, taper 1): 15 = 6 + 5 + 4.
 int job_schedule(int nsub, int spj, int taper, int* sizes) {
     int parts = 0, rem = nsub, size = spj;
     while (rem > 0 && parts < 16) {
