@@ -34,8 +34,8 @@ def patch(s):
         eval_rows<NT, false>(s, s.search, s.jv3, s.lim_jv, false, tid);           // aref''', '''        else aba_resolve(s, L8, s.x, nullptr, s.search);
         NP(2)
         eval_rows<NT, false>(s, s.search, s.jv3, s.lim_jv, false, tid);           // aref''')
-    rep("        const float alpha = line_search<NT>(s, P, g0, h0, tid, rownew);\n        if (!(alpha > 0.f)) { done = true; break; }\n        for (int i = tid; i < D_NV; i += NT) s.qacc[i] += alpha * s.search[i];\n        for (int i = tid; i < D_NB * 6; i += NT) sacc[i] += alpha * s.sv[i];\n        for (int k = tid",
-        "        NP(3)\n        const float alpha = line_search<NT>(s, P, g0, h0, tid, rownew);\n        NP(4)\n        if (!(alpha > 0.f)) { done = true; break; }\n        for (int i = tid; i < D_NV; i += NT) s.qacc[i] += alpha * s.search[i];\n        for (int i = tid; i < D_NB * 6; i += NT) sacc[i] += alpha * s.sv[i];\n        for (int k = tid")
+    rep("        const float alpha = line_search<NT>(s, P, g0, h0, tid, rownew, it == 0, rc0);\n        if (it == 0) rowcost = rc0;\n        if (!(alpha > 0.f)) { done = true; break; }\n        for (int i = tid; i < D_NV; i += NT) s.qacc[i] += alpha * s.search[i];\n        for (int i = tid; i < D_NB * 6; i += NT) sacc[i] += alpha * s.sv[i];\n        for (int k = tid",
+        "        NP(3)\n        const float alpha = line_search<NT>(s, P, g0, h0, tid, rownew, it == 0, rc0);\n        NP(4)\n        if (it == 0) rowcost = rc0;\n        if (!(alpha > 0.f)) { done = true; break; }\n        for (int i = tid; i < D_NV; i += NT) s.qacc[i] += alpha * s.search[i];\n        for (int i = tid; i < D_NB * 6; i += NT) sacc[i] += alpha * s.sv[i];\n        for (int k = tid")
     rep('''        rowcost = rownew;
         if (improvement < P.tol) { it++; done = true; break; }
     }

@@ -36,12 +36,14 @@ def patch(s):
         if (tid < no6) s.sv[6 * D_NB + tid] = s.osrch[tid];
         KP_SYNC();
         eval_rows<NT, true>(s, s.search, s.jv3, s.lim_jv, false, tid);''')
-    rep('''        const float alpha = line_search<NT>(s, P, g0, h0, tid, rownew);
+    rep('''        const float alpha = line_search<NT>(s, P, g0, h0, tid, rownew, it == 0, rc0);
+        if (it == 0) rowcost = rc0;
         if (!(alpha > 0.f)) { done = true; break; }
         for (int i = tid; i < D_NV; i += NT) s.qacc[i] += alpha * s.search[i];
         for (int i = tid; i < D_NB * 6; i += NT) sacc[i] += alpha * s.sv[i];
-        if (tid < no6)''', '''        const float alpha = line_search<NT>(s, P, g0, h0, tid, rownew);
+        if (tid < no6)''', '''        const float alpha = line_search<NT>(s, P, g0, h0, tid, rownew, it == 0, rc0);
         NP(5)
+        if (it == 0) rowcost = rc0;
         if (!(alpha > 0.f)) { done = true; break; }
         for (int i = tid; i < D_NV; i += NT) s.qacc[i] += alpha * s.search[i];
         for (int i = tid; i < D_NB * 6; i += NT) sacc[i] += alpha * s.sv[i];
