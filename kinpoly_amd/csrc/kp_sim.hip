@@ -47,6 +47,7 @@ struct kp_sim {
     int* diag = nullptr;
     int* order = nullptr; unsigned* cost = nullptr;   // launch order of the control-step kernel (k_lpt_order)
     unsigned *jobq = nullptr, *jobctr = nullptr;      // job FIFO of kp_step_queue_kernel
+    float* spd_next = nullptr;                        // [N, 80] torque hand-over between the jobs of a control step
     int jobq_cap = 0, wave_slots = 2048;
     unsigned long long* prof = nullptr;
     float* dbg_contacts = nullptr;
@@ -273,7 +274,7 @@ int launch_step(kp_sim* s, const float* action, int nsub, const uint8_t* mask, b
         }
     }
     const bool queue = nsub > 0 && parts > 1 && s->model->threads == 64 && s->n > slots && s->n <= 0xFFFFFF && !s->prof;   // env ids take 24 bits of a queue entry
-    A.jobq = s->jobq; A.jobctr = s->jobctr; A.n_parts = queue ? parts : 1; A.queue_fence = s->model->queue_fence;
+    A.jobq = s->jobq; A.jobctr = s->jobctr; A.spd_next = s->spd_next; A.n_parts = queue ? parts : 1; A.queue_fence = s->model->queue_fence;
     A.part_sub_lo = A.part_sub_hi = 0;
     for (int k = 0; queue && k < parts; k++) (k < 8 ? A.part_sub_lo : A.part_sub_hi) |= (unsigned long long)(sizes[k] & 255) << (8 * (k & 7));
     if (queue) {
@@ -390,7 +391,7 @@ kp_sim* kp_sim_create(const kp_model* m, int n_envs, int device_id, void* stream
     s->prev_bquat = dalloc(s, N * 96, &ok); s->prev_hpos = dalloc(s, N * 7, &ok);
     s->diag = (int*)dalloc(s, N * 4, &ok);
     s->order = (int*)dalloc(s, N, &ok); s->cost = (unsigned*)dalloc(s, N, &ok);
-    s->jobq_cap = (int)N * 16; s->jobq = (unsigned*)dalloc(s, (size_t)s->jobq_cap, &ok); s->jobctr = (unsigned*)dalloc(s, 4, &ok);
+    s->jobq_cap = (int)N * 16; s->jobq = (unsigned*)dalloc(s, (size_t)s->jobq_cap, &ok); s->jobctr = (unsigned*)dalloc(s, 4, &ok); s->spd_next = (float*)dalloc(s, N * 80, &ok);
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, s->device) == hipSuccess && prop.multiProcessorCount > 0) s->wave_slots = prop.multiProcessorCount * 8;

@@ -67,6 +67,7 @@ struct StepArgs {
     // wave through HBM.  jobq [n_envs * n_parts] entries (env | part << 24, 0xFFFFFFFF = not yet published), jobctr = {head, tail, stalled}
     unsigned* jobq;
     unsigned* jobctr;
+    float* spd_next;           // [N, 80]: qfrc_applied ++ qfrc_actuator (78 floats) of an env's NEXT substep, computed by the job that ran the substep before it
     int n_parts;
     int queue_fence;           // 1: the hand-over is a release (publish) / acquire (consume) pair at agent scope instead of relaxed sc1 accesses + s_waitcnt
     unsigned long long part_sub_lo, part_sub_hi;   // substeps of job 0 .. 15, one byte each (sum = n_substeps); packed so that no lookup indexes the kernel argument
@@ -1818,13 +1819,21 @@ __device__ __forceinline__ void step_body(StepArgs A, const int env_in, const in
     // ---- load: derived state first (the state the last forward pass ran on), then the real state
     const float* tq_row = A.target_qpos ? A.target_qpos + (size_t)env * D_NQ : nullptr;
     const float* act_row = A.action ? A.action + (size_t)env * D_NV : nullptr;
-    for (int i = tid; i < D_NQ; i += NT) s.qpos[i] = gld<Q>(A.qpos_d + (size_t)env * D_NQ + i);
+    // Torque hand-over between the jobs of a control step (stale mode): the stable-PD torque of substep k is a function of the kinematics of
+    // substep k - 1, which sit in the LDS of the job that ran k - 1.  That job therefore also computes the torque of k (it is the same
+    // solve its successor would start with) and hands over 78 floats; the successor then needs neither the derived state nor the forward
+    // pass on it (17.7 k cycles of a 49 k hand-over).  The first job of a control step still starts from the derived state the previous
+    // control step left.  Same code site, same operands: results do not depend on how the control step is cut.
+    const bool torque_in = Q && P.stale && P.actuation && part > 0 && A.spd_next != nullptr;
+    const bool torque_out = Q && P.stale && P.actuation && part >= 0 && part + 1 < A.n_parts && A.spd_next != nullptr;
+    for (int i = tid; i < D_NQ; i += NT) s.qpos[i] = gld<Q>((torque_in ? A.qpos : A.qpos_d) + (size_t)env * D_NQ + i);
     for (int i = tid; i < D_NV; i += NT) {
-        s.qvel[i] = gld<Q>(A.qvel_d + (size_t)env * D_NV + i);
+        s.qvel[i] = gld<Q>((torque_in ? A.qvel : A.qvel_d) + (size_t)env * D_NV + i);
         s.arm[i] = T.dof_armature[i]; s.dbody[i] = T.dof_body[i]; s.extra[i] = 0.f; s.qacc[i] = gld<Q>(A.warm + (size_t)env * D_NV + i);
     }
     if (tid < D_NB) { s.bpar[tid] = (unsigned char)(T.body_parent[tid] < 0 ? 0 : T.body_parent[tid]); s.bsub[tid] = T.body_subtree[tid]; s.bdep[tid] = T.body_depth[tid]; }
     if (tid < 6) s.applied[tid] = 0.f;
+    if (torque_in) for (int i = tid; i < 78; i += NT) s.applied[i] = gld<Q>(A.spd_next + (size_t)env * 80 + i);
     if (tid < 25) s.IAa[22 * tid + 21] = 0.f;
     if (tid < 22) s.IAa[22 * 24 + tid] = 0.f;
     if (tid < 6) s.pAa[6 * 24 + tid] = 0.f;
@@ -1860,8 +1869,8 @@ __device__ __forceinline__ void step_body(StepArgs A, const int env_in, const in
     // pass n is the forward pass on the final state.  Running the entry pass through the SAME code as a substep's forward pass is what
     // makes a control step cut into jobs bit-identical to an uncut one (two inlined copies need not contract their FMAs alike), and it
     // keeps the kernel's code a third shorter.
-    const int last_pass = (A.n_substeps > 0 && !P.stale) ? A.n_substeps : A.n_substeps - 1;
-    for (int sub = -1; sub <= last_pass; sub++) {
+    const int last_pass = (A.n_substeps > 0 && (!P.stale || torque_out)) ? A.n_substeps : A.n_substeps - 1;
+    for (int sub = torque_in ? 0 : -1; sub <= last_pass; sub++) {
         // per-lane invariants are re-derived from a laundered lane index every pass (see kp_launder): table addresses, the body's tree
         // level and offset, and -- at the top of each solve -- the Lane8 schedule
         const int tid = kp_launder(tid0);
@@ -1871,7 +1880,12 @@ __device__ __forceinline__ void step_body(StepArgs A, const int env_in, const in
         if (prof && sub == 0) tstart = __builtin_readcyclecounter();
         if (prof) t0 = __builtin_readcyclecounter();
         // stale mode: the controller sees M / bias of the previous forward pass (cinert, cdof, bias still in LDS)
-        if (substep && P.stale && P.actuation) { Lane8 La; La.init(kp_launder(tid), T.sched8); spd_torque_rfc<NT, OBJ>(s, T, P, La, tid, tq_row, act_row); }
+        const bool spd_pass = torque_out && sub == A.n_substeps;           // the extra pass of a job that is not the control step's last: the successor's first torque
+        if ((substep || spd_pass) && P.stale && P.actuation && !(torque_in && sub == 0)) { Lane8 La; La.init(kp_launder(tid), T.sched8); spd_torque_rfc<NT, OBJ>(s, T, P, La, tid, tq_row, act_row); }
+        if (spd_pass) {
+            for (int i = tid; i < 78; i += NT) gst<Q>(A.spd_next + (size_t)env * 80 + i, s.applied[i]);
+            break;
+        }
         if (substep && !P.actuation) {              // model option "actuation" = 0: ctrl = qfrc_applied = 0 (torque-free motion; tests)
             for (int i = tid; i < 78; i += NT) s.applied[i] = 0.f;          // applied[6] ++ ctrl[72]
             KP_SYNC();
