@@ -1967,10 +1967,12 @@ __device__ __forceinline__ void step_body(StepArgs A, const int env_in, const in
     bool bad = false;
     for (int i = tid; i < D_NQ; i += NT) { float v = s.qpos[i]; bad |= !(fabsf(v) < 1e10f); if (A.n_substeps > 0) gst<Q>(A.qpos + (size_t)env * D_NQ + i, v); }
     for (int i = tid; i < D_NV; i += NT) { float v = s.qvel[i]; bad |= !(fabsf(v) < 1e10f); if (A.n_substeps > 0) { gst<Q>(A.qvel + (size_t)env * D_NV + i, v); gst<Q>(A.warm + (size_t)env * D_NV + i, s.qacc[i]); } }
+    if (!torque_out) {       // the derived state is read by the control step's NEXT first job only (a job that hands its torque over has no reader for it)
 #pragma unroll
-    for (int n = 0; n < (D_NQ + NT - 1) / NT; n++) { int i = tid + n * NT; if (i < D_NQ) gst<Q>(A.qpos_d + (size_t)env * D_NQ + i, qd_save_q[n]); }
+        for (int n = 0; n < (D_NQ + NT - 1) / NT; n++) { int i = tid + n * NT; if (i < D_NQ) gst<Q>(A.qpos_d + (size_t)env * D_NQ + i, qd_save_q[n]); }
 #pragma unroll
-    for (int n = 0; n < (D_NV + NT - 1) / NT; n++) { int i = tid + n * NT; if (i < D_NV) gst<Q>(A.qvel_d + (size_t)env * D_NV + i, qd_save_v[n]); }
+        for (int n = 0; n < (D_NV + NT - 1) / NT; n++) { int i = tid + n * NT; if (i < D_NV) gst<Q>(A.qvel_d + (size_t)env * D_NV + i, qd_save_v[n]); }
+    }
     if (!Q || part == A.n_parts - 1) {      // read-outs: the last job of the control step only (earlier jobs' copies could land later from another L2)
         for (int i = tid; i < 72; i += NT) A.xpos[(size_t)env * 72 + i] = s.xpos[i];
         if (tid < D_NB) {                   // xipos = xpos + R ipos of the same forward pass
