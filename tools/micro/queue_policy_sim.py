@@ -7,7 +7,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-HAND = 49e3          # cycles per hand-over (forward pass + state in / out), DESIGN.md section 6
+HAND = float(__import__('os').environ.get('KP_HAND', 28e3))          # cycles per hand-over (state in / out + job set-up; 49e3 before round 3's torque hand-over), DESIGN.md section 6
 CLK = 2.38e3         # cycles per microsecond
 
 
@@ -41,7 +41,17 @@ def simulate(cost, sizes, slots, policy, prev=None, theta=1.25):
         while pending and pending[0][0] <= t:
             at, _, e, p, pr = heapq.heappop(pending)
             (prio if pr else fifo).append((e, p))
-        if phead < len(prio):
+        if policy == "prio_rem" and (head < len(fifo)):
+            # best visible job by remaining work (jobs of envs that have run at least one job: measured rate x substeps left; first jobs: FIFO order, lowest priority)
+            best, bi = None, -1
+            for i in range(head, len(fifo)):
+                e_, p_ = fifo[i]
+                if e_ < 0: continue
+                key = (cost[e_] * (1.0 - sum(frac[:p_]))) if p_ > 0 else -1.0 - i * 1e-9
+                if best is None or key > best: best, bi = key, i
+            e, p = fifo[bi]; fifo[bi] = (-1, 0)
+            while head < len(fifo) and fifo[head][0] < 0: head += 1
+        elif phead < len(prio):
             e, p = prio[phead]; phead += 1
         elif head < len(fifo):
             e, p = fifo[head]; head += 1
@@ -104,8 +114,8 @@ if __name__ == "__main__":
               f"corr with the previous launch {np.corrcoef(cost, prev)[0, 1]:.2f}")
         for theta in (1.1, 1.25, 1.4, 1.6, 2.0):
             print(f"   jobs (7, 5, 3): priority lane for jobs that ran > {theta} x the mean: makespan {simulate(cost, (7, 5, 3), 2048, 'prio', prev, theta) / CLK / 1e3:.3f} ms")
-        for sizes in ((7, 5, 3), (5, 4, 3, 2, 1), (15,)):
-            for pol in ("fifo", "lpt_prev", "lpt_true", "prio", "prio_lpt_prev", "continue_first"):
+        for sizes in ((6, 5, 4), (7, 5, 3), (5, 4, 3, 2, 1), (15,)):
+            for pol in ("fifo", "lpt_prev", "lpt_true", "prio", "prio_rem", "prio_lpt_prev", "continue_first"):
                 if len(sizes) == 1 and pol not in ("fifo", "lpt_prev", "lpt_true"):
                     continue
                 mk = simulate(cost, sizes, 2048, pol, prev)

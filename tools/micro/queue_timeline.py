@@ -19,7 +19,7 @@ def build():
         t = open(p).read()
         assert a in t, a
         open(p, "w").write(t.replace(a, b, 1))
-    edit("kp_sim.hip", "&& s->n <= 0xFFFFFF && !s->prof && !A.order;", "&& s->n <= 0xFFFFFF && !A.order;")
+    edit("kp_sim.hip", "&& s->n <= 0xFFFFFF && !s->prof;", "&& s->n <= 0xFFFFFF;")
     edit("kp_sim.hip", "    for (int k = 0; k < 8; k++) { double acc = 0; for (int e = 0; e < s->n; e++) acc += (double)h[(size_t)e * 8 + k]; out[k] = acc / s->n; }",
          "    for (int k = 0; k < 8; k++) out[k] = (double)h[k];")
     edit("kp_step_kernel.hpp", "    const bool prof = A.prof != nullptr;", "    const bool prof = false;")
@@ -34,10 +34,10 @@ def build():
     edit("kp_step_kernel.hpp", "        step_body<64, OBJ, false, true>(A, env, part);\n",
          "        const unsigned long long jb = __builtin_readcyclecounter();\n        step_body<64, OBJ, false, true>(A, env, part);\n"
          "        last_m = __builtin_readcyclecounter(); last_r = __builtin_amdgcn_s_memrealtime(); busy += last_m - jb; njobs++;\n")
-    edit("kp_step_kernel.hpp", "__global__ void k_queue_init(int n_envs, unsigned total, unsigned* __restrict__ jobq, unsigned* __restrict__ jobctr) {",
-         "__global__ void k_queue_init(int n_envs, unsigned total, unsigned* __restrict__ jobq, unsigned* __restrict__ jobctr, unsigned long long* prof) {\n"
+    edit("kp_step_kernel.hpp", "__global__ void k_queue_init(int n_envs, unsigned total, unsigned* __restrict__ jobq, unsigned* __restrict__ jobctr, const int* __restrict__ order) {",
+         "__global__ void k_queue_init(int n_envs, unsigned total, unsigned* __restrict__ jobq, unsigned* __restrict__ jobctr, const int* __restrict__ order, unsigned long long* prof) {\n"
          "    if (prof && blockIdx.x == 0 && threadIdx.x < 8) prof[threadIdx.x] = threadIdx.x == 3 ? ~0ull : 0ull;")
-    edit("kp_sim.hip", "s->stream, s->n, total, s->jobq, s->jobctr);", "s->stream, s->n, total, s->jobq, s->jobctr, s->prof);")
+    edit("kp_sim.hip", "s->stream, s->n, total, s->jobq, s->jobctr, A.order);", "s->stream, s->n, total, s->jobq, s->jobctr, A.order, s->prof);")
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
                            os.path.join(src, "kp_sim.hip"), "-o", LIB])
     shutil.rmtree(tmp)
