@@ -57,6 +57,9 @@ void kp_model_free(kp_model*);
  * "job_taper" substeps longer, default 1: 15 = 6 + 5 + 4; 0 = uniform) which resident waves pull from a FIFO, so that the
  * launch does not end on the tail of its longest envs; "queue_slots" (0 = CUs x 8, x 6 with objects); "queue_fence" (0/1, default 1: the job hand-over is an agent-scope
  * release / acquire fence pair around relaxed write-through accesses, correct by the HIP memory model; 0 = without the fences, +0.5 %);
+ * "queue_heavy" (default 160; 0 = off): a wave whose job ran at more than that percentage of the launch's mean time per substep keeps its env and runs the
+ * env's next job itself instead of queueing it -- the costliest envs are the ones a launch ends on, and with two envs per slot every trip through the
+ * FIFO costs them about one job's length of waiting (objects workload 6.49 -> 5.78 ms per launch; bit-identical results);
  * "lpt_order" (1 / 0 / -1 = default: on when free objects are simulated): longest-env-first order of the workgroups (plain launch) or of the
  * envs' first jobs in the FIFO, from the previous control step's per-env cycles. */
 int kp_model_set_option(kp_model*, const char* name, double value);

@@ -69,6 +69,7 @@ struct StepArgs {
     unsigned* jobctr;
     float* spd_next;           // [N, 80]: qfrc_applied ++ qfrc_actuator (78 floats) of an env's NEXT substep, computed by the job that ran the substep before it
     int n_parts;
+    int queue_heavy;           // > 0: a wave that finds its env heavy (this job's cycles per substep > queue_heavy % of the launch's running mean) runs the env's next job itself
     int queue_fence;           // 1: the hand-over is a release (publish) / acquire (consume) pair at agent scope instead of relaxed sc1 accesses + s_waitcnt
     unsigned long long part_sub_lo, part_sub_hi;   // substeps of job 0 .. 15, one byte each (sum = n_substeps); packed so that no lookup indexes the kernel argument
 };
@@ -2094,27 +2095,52 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 2 : 1)) void kp_forward_kernel(Step
 // the variant that is correct by construction is the default.
 template <bool OBJ>
 __global__ __launch_bounds__(64, 2) void kp_step_queue_kernel(StepArgs A) {
+    // jobctr: [0] head (claimed), [1] tail (published), [2] stalled flag, [3] jobs that were never queued because the finishing wave ran them itself,
+    //         [4] time (100 MHz ticks) and [5] substeps of the jobs finished so far in this launch (the running mean behind "heavy")
     const unsigned total = (unsigned)A.n_envs * (unsigned)A.n_parts;
     for (;;) {
         unsigned idx = 0;
         if (threadIdx.x == 0) idx = atomicAdd(&A.jobctr[0], 1u);
         idx = (unsigned)__builtin_amdgcn_readfirstlane((int)idx);
-        if (idx >= total) return;
+        // entries at and beyond total - jobctr[3] will never be published (jobctr[3] only grows): nothing left for this wave
+        if (idx >= total - __hip_atomic_load(&A.jobctr[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
         unsigned e, spins = 0;
         while ((e = __hip_atomic_load(&A.jobq[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0xFFFFFFFFu) {
             __builtin_amdgcn_s_sleep(32);
+            if (idx >= total - __hip_atomic_load(&A.jobctr[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
             if (++spins > (1u << 21)) { if (threadIdx.x == 0) atomicExch(&A.jobctr[2], 1u); return; }
         }
         asm volatile("" ::: "memory");                        // the job's (sc1) state loads stay behind the load that saw the entry
         if (A.queue_fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // memory-model variant: acquire side of the publish below
         e = (unsigned)__builtin_amdgcn_readfirstlane((int)e);
-        const int env = (int)(e & 0xFFFFFFu), part = (int)(e >> 24);
-        step_body<64, OBJ, false, true>(A, env, part);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // every lane's write-through state store has been acknowledged ...
-        if (A.queue_fence) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // memory-model variant: release all of this wave's stores at agent scope
-        if (part + 1 < A.n_parts && threadIdx.x == 0) {                // ... before the env's next job becomes visible
-            const unsigned pos = atomicAdd(&A.jobctr[1], 1u);
-            __hip_atomic_store(&A.jobq[pos], (unsigned)env | ((unsigned)(part + 1) << 24), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int env = (int)(e & 0xFFFFFFu);
+        int part = (int)(e >> 24);
+        for (;;) {
+            const unsigned long long tj = __builtin_amdgcn_s_memrealtime();          // 100 MHz ticks: only ratios of job times are used
+            step_body<64, OBJ, false, true>(A, env, part);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // every lane's write-through state store has been acknowledged ...
+            if (A.queue_fence) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // memory-model variant: release all of this wave's stores at agent scope
+            if (part + 1 >= A.n_parts) break;
+            // An env whose jobs run long is the one the launch will end on: with two envs per slot every hand-over through the FIFO costs it about one
+            // job's length of waiting.  The wave that finds its env heavy -- cycles per substep above queue_heavy % of the launch's running mean --
+            // keeps it: it runs the next job itself, at once, and the queue gets one entry fewer (jobctr[3]).  Who runs a job never changes its result.
+            int keep = 0;
+            if (A.queue_heavy > 0 && threadIdx.x == 0) {
+                const unsigned nsub = (unsigned)(((part < 8 ? A.part_sub_lo >> (8 * part) : A.part_sub_hi >> (8 * (part - 8)))) & 255ull);
+                const unsigned dt = (unsigned)((__builtin_amdgcn_s_memrealtime() - tj) >> 2);      // 40 ns units: the launch's sum stays far below 2^32
+                const unsigned tot = atomicAdd(&A.jobctr[4], dt) + dt, cnt = atomicAdd(&A.jobctr[5], nsub) + nsub;
+                keep = cnt >= 512u && (unsigned long long)dt * cnt * 100ull > (unsigned long long)tot * nsub * (unsigned)A.queue_heavy;
+            }
+            keep = __builtin_amdgcn_readfirstlane(keep);
+            if (!keep) {
+                if (threadIdx.x == 0) {                                    // ... before the env's next job becomes visible
+                    const unsigned pos = atomicAdd(&A.jobctr[1], 1u);
+                    __hip_atomic_store(&A.jobq[pos], (unsigned)env | ((unsigned)(part + 1) << 24), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                break;
+            }
+            if (threadIdx.x == 0) atomicAdd(&A.jobctr[3], 1u);
+            part++;
         }
     }
 }
@@ -2124,7 +2150,7 @@ __global__ __launch_bounds__(64, 2) void kp_step_queue_kernel(StepArgs A) {
 __global__ void k_queue_init(int n_envs, unsigned total, unsigned* __restrict__ jobq, unsigned* __restrict__ jobctr, const int* __restrict__ order) {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < total) jobq[i] = i < (unsigned)n_envs ? (order ? (unsigned)order[i] : i) : 0xFFFFFFFFu;
-    if (i == 0) { jobctr[0] = 0u; jobctr[1] = (unsigned)n_envs; }
+    if (i == 0) { jobctr[0] = 0u; jobctr[1] = (unsigned)n_envs; jobctr[3] = 0u; jobctr[4] = 0u; jobctr[5] = 0u; }
 }
 
 }  // namespace kp

@@ -244,10 +244,13 @@ def test_job_queue_schedule_is_bit_identical(kp):
     qpos, qvel = make_states(n, 43, lift=0.0, vel=0.5, noise=0.2)
     act = np.random.default_rng(44).normal(size=(n, 75)) * 0.2
     ref, dref = _run_sched(kp, kp.KpModel(substeps_per_job=0), n, qpos, qvel, act, steps=2)
-    got, dg = _run_sched(kp, kp.KpModel(substeps_per_job=5), n, qpos, qvel, act, steps=2)
-    for a_, b_ in zip(ref, got):
-        assert (a_ == b_).all()
-    assert (dref == dg).all() and dg[:, 2].max() == 0
+    # queue_heavy: a wave that finds its env heavy runs the env's next job itself instead of queueing it (0 = never, 105 = a third of the jobs,
+    # default 160): who runs a job must not change its result, and the shortened queue must still drain
+    for heavy in (None, 0, 105):
+        got, dg = _run_sched(kp, kp.KpModel(substeps_per_job=5, **({} if heavy is None else {"queue_heavy": heavy})), n, qpos, qvel, act, steps=2)
+        for a_, b_ in zip(ref, got):
+            assert (a_ == b_).all(), f"queue_heavy={heavy}"
+        assert (dref == dg).all() and dg[:, 2].max() == 0
     # objects (6 envs/CU kernel): push scene and standing on the step box, replicated
     from kinpoly_amd.model_compiler import STEP_KPM
     n = 200
