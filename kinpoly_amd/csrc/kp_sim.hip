@@ -393,7 +393,7 @@ kp_sim* kp_sim_create(const kp_model* m, int n_envs, int device_id, void* stream
     s->prev_bquat = dalloc(s, N * 96, &ok); s->prev_hpos = dalloc(s, N * 7, &ok);
     s->diag = (int*)dalloc(s, N * 4, &ok);
     s->order = (int*)dalloc(s, N, &ok); s->cost = (unsigned*)dalloc(s, N, &ok);
-    s->jobq_cap = (int)N * 16; s->jobq = (unsigned*)dalloc(s, (size_t)s->jobq_cap, &ok); s->jobctr = (unsigned*)dalloc(s, 8, &ok); s->spd_next = (float*)dalloc(s, N * 80, &ok);
+    s->jobq_cap = (int)N * 16; s->jobq = (unsigned*)dalloc(s, (size_t)s->jobq_cap, &ok); s->jobctr = (unsigned*)dalloc(s, 64, &ok); s->spd_next = (float*)dalloc(s, N * 80, &ok);
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, s->device) == hipSuccess && prop.multiProcessorCount > 0) s->wave_slots = prop.multiProcessorCount * 8;

@@ -2095,19 +2095,21 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 2 : 1)) void kp_forward_kernel(Step
 // the variant that is correct by construction is the default.
 template <bool OBJ>
 __global__ __launch_bounds__(64, 2) void kp_step_queue_kernel(StepArgs A) {
-    // jobctr: [0] head (claimed), [1] tail (published), [2] stalled flag, [3] jobs that were never queued because the finishing wave ran them itself,
-    //         [4] time (100 MHz ticks) and [5] substeps of the jobs finished so far in this launch (the running mean behind "heavy")
+    // jobctr: [0] head (claimed), [1] tail (published), [2] stalled flag; on cache lines of their own, away from the head / tail every claim and publish hits:
+    //         [16] jobs that were never queued because the finishing wave ran them itself; [32] time (40 ns units) and [33] substeps of the jobs finished so
+    //         far in this launch; [48], [49] the same sums of the previous launch (the mean behind "heavy": constant during the launch, read once per wave)
     const unsigned total = (unsigned)A.n_envs * (unsigned)A.n_parts;
+    const unsigned prev_tot = A.jobctr[48], prev_cnt = A.jobctr[49];
     for (;;) {
         unsigned idx = 0;
         if (threadIdx.x == 0) idx = atomicAdd(&A.jobctr[0], 1u);
         idx = (unsigned)__builtin_amdgcn_readfirstlane((int)idx);
-        // entries at and beyond total - jobctr[3] will never be published (jobctr[3] only grows): nothing left for this wave
-        if (idx >= total - __hip_atomic_load(&A.jobctr[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+        if (idx >= total) return;
         unsigned e, spins = 0;
         while ((e = __hip_atomic_load(&A.jobq[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0xFFFFFFFFu) {
             __builtin_amdgcn_s_sleep(32);
-            if (idx >= total - __hip_atomic_load(&A.jobctr[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+            // entries at and beyond total - jobctr[16] will never be published (the counter only grows): nothing left for this wave
+            if (idx >= total - __hip_atomic_load(&A.jobctr[16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
             if (++spins > (1u << 21)) { if (threadIdx.x == 0) atomicExch(&A.jobctr[2], 1u); return; }
         }
         asm volatile("" ::: "memory");                        // the job's (sc1) state loads stay behind the load that saw the entry
@@ -2128,8 +2130,11 @@ __global__ __launch_bounds__(64, 2) void kp_step_queue_kernel(StepArgs A) {
             if (A.queue_heavy > 0 && threadIdx.x == 0) {
                 const unsigned nsub = (unsigned)(((part < 8 ? A.part_sub_lo >> (8 * part) : A.part_sub_hi >> (8 * (part - 8)))) & 255ull);
                 const unsigned dt = (unsigned)((__builtin_amdgcn_s_memrealtime() - tj) >> 2);      // 40 ns units: the launch's sum stays far below 2^32
-                const unsigned tot = atomicAdd(&A.jobctr[4], dt) + dt, cnt = atomicAdd(&A.jobctr[5], nsub) + nsub;
-                keep = cnt >= 512u && (unsigned long long)dt * cnt * 100ull > (unsigned long long)tot * nsub * (unsigned)A.queue_heavy;
+                atomicAdd(&A.jobctr[32], dt); atomicAdd(&A.jobctr[33], nsub);
+                // the yardstick is the PREVIOUS launch's mean (k_queue_init moves it to jobctr[48..49]): this launch's own running mean is made of the jobs
+                // that finished first, i.e. of the light ones.  Jobs of fewer than four substeps are too noisy a sample of their env (one extra Newton
+                // iteration in one substep is + 25 %)
+                keep = prev_cnt >= 512u && nsub >= 4u && (unsigned long long)dt * prev_cnt * 100ull > (unsigned long long)prev_tot * nsub * (unsigned)A.queue_heavy;
             }
             keep = __builtin_amdgcn_readfirstlane(keep);
             if (!keep) {
@@ -2139,7 +2144,7 @@ __global__ __launch_bounds__(64, 2) void kp_step_queue_kernel(StepArgs A) {
                 }
                 break;
             }
-            if (threadIdx.x == 0) atomicAdd(&A.jobctr[3], 1u);
+            if (threadIdx.x == 0) atomicAdd(&A.jobctr[16], 1u);
             part++;
         }
     }
@@ -2150,7 +2155,7 @@ __global__ __launch_bounds__(64, 2) void kp_step_queue_kernel(StepArgs A) {
 __global__ void k_queue_init(int n_envs, unsigned total, unsigned* __restrict__ jobq, unsigned* __restrict__ jobctr, const int* __restrict__ order) {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < total) jobq[i] = i < (unsigned)n_envs ? (order ? (unsigned)order[i] : i) : 0xFFFFFFFFu;
-    if (i == 0) { jobctr[0] = 0u; jobctr[1] = (unsigned)n_envs; jobctr[3] = 0u; jobctr[4] = 0u; jobctr[5] = 0u; }
+    if (i == 0) { jobctr[0] = 0u; jobctr[1] = (unsigned)n_envs; jobctr[16] = 0u; jobctr[48] = jobctr[32]; jobctr[49] = jobctr[33]; jobctr[32] = 0u; jobctr[33] = 0u; }
 }
 
 }  // namespace kp

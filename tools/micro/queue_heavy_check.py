@@ -21,6 +21,12 @@ for e in range(n):
     qpos[e, 2] += lift
     for oi, pose in act.items():
         blk[e, 7 * oi: 7 * oi + 7] = pose
+def status64(sim):
+    ptr = sim.L.kp_sim_status_device(sim.h)
+    iface = {"shape": (64,), "typestr": "<u4", "data": (int(ptr), False), "version": 3, "strides": None}
+    return torch.as_tensor(type("_S", (), {"__cuda_array_interface__": iface})(), device="cuda").cpu().numpy()
+
+
 dev = lambda a: torch.tensor(a, dtype=torch.float32, device="cuda")   # noqa: E731
 qvel = rng.normal(size=(n, 75)) * 0.3
 acts = [dev(rng.normal(size=(n, 75)) * 0.3) for _ in range(5)]
@@ -36,8 +42,9 @@ for name, opts in (("queue off", dict(substeps_per_job=0)), ("queue_heavy 0", di
         for a in acts:
             sim.step_ctrl(a, 15); ts.append(sim.last_step_seconds() * 1e3)
         st = sim.status_tensor().cpu().numpy()
+        st16 = status64(sim)[16]
         out[(name, tag)] = (sim.get("qpos").cpu().numpy(), sim.get("qvel").cpu().numpy(), sim.get("obj_qpos").cpu().numpy() if kpm else None)
-        print(f"{name:16s} {tag:8s} launch {np.mean(ts[1:]):.3f} ms; jobs run by the finishing wave in the last launch: {int(st[3])} of {n * 3}; stalled {int(st[2])}", flush=True)
+        print(f"{name:16s} {tag:8s} launch {np.mean(ts[1:]):.3f} ms; jobs run by the finishing wave in the last launch: {int(st16)} of {n * 3}; stalled {int(st[2])}", flush=True)
         del sim
 for tag in ("floor", "objects"):
     ref = out[("queue off", tag)]
