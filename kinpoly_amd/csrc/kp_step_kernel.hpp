@@ -1160,21 +1160,26 @@ __device__ __forceinline__ int solve_constraints_direct(EnvLds& s, const Params&
     int it = 0, lev_hist = 1;
     bool done = false;          // left the loop through one of mj_solNewton's termination tests (not the iteration cap)
     const unsigned conlev = contact_levels(s, L8);
-    for (; it < P.max_iter; it++) {
-        wrench_project<NT, false>(s, P, sacc, s.qacc, nullptr, grad, true, true, tid, nullptr, s.fb, s.applied);
-        float g2 = 0.f, changed = 0.f, deep = 0.f;
+    // active set of the iterate: pyramid rows (con_act) and joint limits (their D as extra armature); changed = it differs from the set of the last call
+    float changed = 0.f, deep = 0.f;
+    auto active_set = [&]() {
+        changed = 0.f; deep = 0.f;
         for (int i = tid; i < D_NV; i += NT) {
-            const float g = grad[i];
-            g2 += g * g;
-            s.x[i] = -g;
             const float ex = (i >= 6 && s.lim_jar[i - 6] < 0.f) ? fabsf(s.lim_D[i - 6]) : 0.f;
             if (ex != s.extra[i]) changed = 1.f;
             s.extra[i] = ex;
             if (ex != 0.f) deep = fmaxf(deep, (float)s.bdep[s.dbody[i]]);     // active joint limit: its body's level is dirty
         }
         changed += active_set_changed<NT>(s, P, tid, deep);
-        g2 = block_sum<NT>(s, g2, tid);
         changed = (NT == 64) ? (__ballot(changed > 0.f) != 0ull ? 1.f : 0.f) : block_sum<NT>(s, changed, tid);
+        KP_SYNC();
+    };
+    active_set();
+    for (; it < P.max_iter; it++) {
+        wrench_project<NT, false>(s, P, sacc, s.qacc, nullptr, grad, true, true, tid, nullptr, s.fb, s.applied);
+        float g2 = 0.f;
+        for (int i = tid; i < D_NV; i += NT) { const float g = grad[i]; g2 += g * g; s.x[i] = -g; }
+        g2 = block_sum<NT>(s, g2, tid);
         KP_SYNC();
         if (P.scale * sqrtf(g2) < P.tol) { done = true; break; }
         if (it == 0 || changed > 0.f) {
@@ -1205,6 +1210,12 @@ __device__ __forceinline__ int solve_constraints_direct(EnvLds& s, const Params&
         const float improvement = P.scale * ((rowcost - rownew) - alpha * (g0 + 0.5f * alpha * h0));
         rowcost = rownew;
         if (improvement < P.tol) { it++; done = true; break; }
+        // The Newton step of a model that was exact: the search direction solved H search = -gradient for the active set of the old iterate and the new
+        // iterate has the same active set -- on a piecewise-quadratic cost its gradient is then (1 - alpha) x the old one, alpha = 1 up to the line
+        // search's rounding.  When that bound already passes mj_solNewton's |gradient| < tolerance test, the pass that would evaluate the gradient at
+        // the top of the next iteration (body wrenches, subtree sums, projection: a sixth of an iteration's work) is not run to confirm it.
+        active_set();
+        if (changed == 0.f && P.scale * fabsf(1.0f - alpha) * sqrtf(g2) < P.tol) { it++; done = true; break; }     // gradient(new) = (1 - alpha) gradient(old) on an unchanged active set
     }
     if (!done) ncap++;
     return it;
