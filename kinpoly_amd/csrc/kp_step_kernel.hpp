@@ -1700,29 +1700,34 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
     int it = 0, lev_hist = 1;
     bool done = false;          // left the loop through one of mj_solNewton's termination tests (not the iteration cap)
     const unsigned conlev = contact_levels(s, L8);
-    for (; it < P.max_iter; it++) {
-        // gradient: humanoid dofs (mres - J^T f) and object wrenches
-        con_prepare<NT>(s, P, tid);                  // lane = contact: M_c at this iterate (object rows of the Hessian AND the hulls' contact inertia in aba_solve) and the contact force
-        wrench_project<NT, true>(s, P, sacc, s.qacc, nullptr, grad, true, true, tid, s.jv3, s.fb, s.applied);
-        if (nobj > 0) obj_gradient(s, tid);
-        float g2 = 0.f, changed = 0.f, deep = 0.f;
+    // active set of the iterate (see solve_constraints_direct)
+    float changed = 0.f, deep = 0.f;
+    auto active_set = [&]() {
+        changed = 0.f; deep = 0.f;
         for (int i = tid; i < D_NV; i += NT) {
-            const float g = grad[i];
-            g2 += g * g;
-            s.x[i] = -g;
             const float ex = (i >= 6 && s.lim_jar[i - 6] < 0.f) ? fabsf(s.lim_D[i - 6]) : 0.f;
             if (ex != s.extra[i]) changed = 1.f;
             s.extra[i] = ex;
             if (ex != 0.f) deep = fmaxf(deep, (float)s.bdep[s.dbody[i]]);     // active joint limit: its body's level is dirty
         }
         changed += active_set_changed<NT>(s, P, tid, deep);
+        changed = (NT == 64) ? (__ballot(changed > 0.f) != 0ull ? 1.f : 0.f) : block_sum<NT>(s, changed, tid);     // one wave: a ballot is the whole reduction
+        KP_SYNC();
+    };
+    active_set();
+    for (; it < P.max_iter; it++) {
+        // gradient: humanoid dofs (mres - J^T f) and object wrenches
+        con_prepare<NT>(s, P, tid);                  // lane = contact: M_c at this iterate (object rows of the Hessian AND the hulls' contact inertia in aba_solve) and the contact force
+        wrench_project<NT, true>(s, P, sacc, s.qacc, nullptr, grad, true, true, tid, s.jv3, s.fb, s.applied);
+        if (nobj > 0) obj_gradient(s, tid);
+        float g2 = 0.f;
+        for (int i = tid; i < D_NV; i += NT) { const float g = grad[i]; g2 += g * g; s.x[i] = -g; }
         if (tid < nobj) {   // gradient in joint coordinates: [g_l ; R^T (g_a + r x g_l)], r = o - body origin
             const S6 g = lds6(s.ogr + 6 * tid);
             const V3 t = g.a + cross(ld3(s.xpos) - ld3(s.oq + 7 * tid), g.l);
             g2 += dot(g.l, g.l) + dot(t, t);
         }
         g2 = block_sum<NT>(s, g2, tid);
-        changed = (NT == 64) ? (__ballot(changed > 0.f) != 0ull ? 1.f : 0.f) : block_sum<NT>(s, changed, tid);     // one wave: a ballot is the whole reduction
         KP_SYNC();
         if (P.scale * sqrtf(g2) < P.tol) { done = true; break; }
         // search direction
@@ -1793,6 +1798,8 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
         const float improvement = P.scale * ((rowcost - rownew) - alpha * (g0 + 0.5f * alpha * h0));
         rowcost = rownew;
         if (improvement < P.tol) { it++; done = true; break; }
+        active_set();
+        if (changed == 0.f && P.scale * fabsf(1.0f - alpha) * sqrtf(g2) < P.tol) { it++; done = true; break; }     // gradient(new) = (1 - alpha) gradient(old): see solve_constraints_direct
     }
     if (!done) ncap++;          // the solver stopped at opt.iterations: counted per env in diag (flags >> 8)
     return it;
