@@ -22,10 +22,12 @@ def patch(s):
         wrench_project<NT, false>(s, P, sacc, s.qacc, nullptr, grad, true, true, tid, nullptr, s.fb, s.applied);''', '''    NP(0)
     for (; it < P.max_iter; it++) {
         wrench_project<NT, false>(s, P, sacc, s.qacc, nullptr, grad, true, true, tid, nullptr, s.fb, s.applied);''')
-    rep('''        KP_SYNC();
+    rep('''        g2 = block_sum<NT>(s, g2, tid);
+        KP_SYNC();
         if (P.scale * sqrtf(g2) < P.tol) { done = true; break; }
         if (it == 0 || changed > 0.f) {
-            const int clean''', '''        KP_SYNC();
+            const int clean''', '''        g2 = block_sum<NT>(s, g2, tid);
+        KP_SYNC();
         NP(1)
         if (P.scale * sqrtf(g2) < P.tol) { done = true; break; }
         if (it == 0 || changed > 0.f) {
@@ -38,14 +40,10 @@ def patch(s):
         "        NP(3)\n        const float alpha = line_search<NT>(s, P, g0, h0, tid, rownew, it == 0, rc0);\n        NP(4)\n        if (it == 0) rowcost = rc0;\n        if (!(alpha > 0.f)) { done = true; break; }\n        for (int i = tid; i < D_NV; i += NT) s.qacc[i] += alpha * s.search[i];\n        for (int i = tid; i < D_NB * 6; i += NT) sacc[i] += alpha * s.sv[i];\n        for (int k = tid")
     rep('''        rowcost = rownew;
         if (improvement < P.tol) { it++; done = true; break; }
-    }
-    if (!done) ncap++;
-    return it;''', '''        rowcost = rownew;
+        // The Newton step of a model that was exact''', '''        rowcost = rownew;
         NP(5)
         if (improvement < P.tol) { it++; done = true; break; }
-    }
-    if (!done) ncap++;
-    return it;''')
+        // The Newton step of a model that was exact''')
     rep("#define KP_T(i) if (prof) { t1 = __builtin_readcyclecounter(); pc[i] += t1 - t0; t0 = t1; }", "#define KP_T(i)")
     rep("niter_total += solve_constraints_direct<NT>(s, P, L8, depth, tid, nfact_total, ncap_total);",
         "niter_total += solve_constraints_direct<NT>(s, P, L8, depth, tid, nfact_total, ncap_total, pc);")

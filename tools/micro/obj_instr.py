@@ -50,20 +50,12 @@ def patch(s):
         if (tid < no6)''')
     rep('''        rowcost = rownew;
         if (improvement < P.tol) { it++; done = true; break; }
-    }
-    if (!done) ncap++;          // the solver stopped at opt.iterations: counted per env in diag (flags >> 8)
-    return it;
-}
-
-// ---------------------------------------------------------------- the kernel''', '''        rowcost = rownew;
+        active_set();
+        if (changed == 0.f && P.scale * fabsf(1.0f - alpha) * sqrtf(g2) < P.tol) { it++; done = true; break; }     // gradient(new) = (1 - alpha) gradient(old): see solve_constraints_direct''', '''        rowcost = rownew;
         NP(6)
         if (improvement < P.tol) { it++; done = true; break; }
-    }
-    if (!done) ncap++;          // the solver stopped at opt.iterations: counted per env in diag (flags >> 8)
-    return it;
-}
-
-// ---------------------------------------------------------------- the kernel''')
+        active_set();
+        if (changed == 0.f && P.scale * fabsf(1.0f - alpha) * sqrtf(g2) < P.tol) { it++; done = true; break; }''')
     rep("#define KP_T(i) if (prof) { t1 = __builtin_readcyclecounter(); pc[i] += t1 - t0; t0 = t1; }", "#define KP_T(i)")
     rep("niter_total += solve_constraints_obj<NT>(s, P, L8, depth, tid, nfact_total, ncap_total);",
         "niter_total += solve_constraints_obj<NT>(s, P, L8, depth, tid, nfact_total, ncap_total, pc);")
