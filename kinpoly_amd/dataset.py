@@ -135,42 +135,63 @@ class StateARDataset:
         return {k: v[ind][start:end] for k, v in self.data.items()}
 
     def take_probs(self, freq_dict, sampling_temp=0.5):
-        """:281-286: exp(-ewma(success history) / T), normalised; takes without history get ewma 0."""
-        def ewma(x, alpha=0.05):
-            avg = x[0]
-            for v in x[1:]:
-                avg = alpha * v + (1 - alpha) * avg
-            return avg
-        p = np.exp(-np.array([ewma((np.array(freq_dict[k])[:, 0] == 1).astype(float)) if len(freq_dict[k]) > 0 else 0.0 for k in freq_dict]) / sampling_temp)
+        """:281-286: exp(-ewma(success history) / T), normalised; takes without history get ewma 0.  The reference's recursion
+        avg <- alpha x_i + (1 - alpha) avg from avg = x_0 in closed form: (1 - alpha)^(n-1) x_0 + sum_i>0 alpha (1 - alpha)^(n-1-i) x_i."""
+        alpha = 0.05
+        e = np.zeros(len(freq_dict))
+        for j, k in enumerate(freq_dict):
+            h = freq_dict[k]
+            if len(h) > 0:
+                x = (np.asarray(h, np.float64)[:, 0] == 1).astype(np.float64)
+                w = alpha * (1.0 - alpha) ** np.arange(len(x) - 1, -1, -1.0)
+                w[0] = (1.0 - alpha) ** (len(x) - 1)
+                e[j] = float(w @ x)
+        p = np.exp(-e / sampling_temp)
         return p / p.sum()
 
     def sample_batch(self, n, freq_dict=None, use_freq=True, full_sample=False, sampling_temp=0.5, sampling_freq=0.9):
-        """n independent `sample_seq` draws (:264-327) -> dict of [n, fr_num, .] tensors (+ 'take_ind', 'fr_start')."""
-        inds, starts = np.zeros(n, np.int64), np.zeros(n, np.int64)
-        probs = None if freq_dict is None else self.take_probs(freq_dict, sampling_temp)
-        for i in range(n):
-            if use_freq and freq_dict is None:
-                inds[i] = self.rng.choice(self.freq_indices)
-            elif use_freq:
-                inds[i] = self.rng.choice(self.all_indices, p=probs) if self.rng.binomial(1, sampling_freq) else self.rng.choice(self.all_indices)
-                starts[i] = 0 if full_sample else self.rng.randint(0, max(self.get_seq_len(inds[i]) - self.fr_num, 1))
-            else:
-                inds[i] = self.rng.choice(self.all_indices)
-        return self.batch(inds, starts, None if full_sample else self.fr_num)
+        """n independent `sample_seq` draws (:264-327) -> dict of [n, fr_num, .] tensors (+ 'take_ind', 'fr_start').  The draws are made as
+        arrays (one rng call per quantity, not per row): the same distributions as n sequential sample_seq calls."""
+        starts = np.zeros(n, np.int64)
+        if use_freq and freq_dict is None:
+            inds = self.rng.choice(self.freq_indices, size=n)
+        elif use_freq:
+            probs = self.take_probs(freq_dict, sampling_temp)
+            coin = self.rng.binomial(1, sampling_freq, size=n).astype(bool)
+            inds = np.where(coin, self.rng.choice(self.all_indices, size=n, p=probs), self.rng.choice(self.all_indices, size=n))
+            if not full_sample:
+                hi = np.maximum(self._seq_lens()[inds] - self.fr_num, 1)
+                starts = np.minimum((self.rng.random_sample(n) * hi).astype(np.int64), hi - 1)
+        else:
+            inds = self.rng.choice(self.all_indices, size=n)
+        return self.batch(np.asarray(inds, np.int64), starts, None if full_sample else self.fr_num)
+
+    def _seq_lens(self):
+        if getattr(self, "_lens_np", None) is None or len(self._lens_np) != len(self.takes):
+            self._lens_np = np.array([q.shape[0] for q in self.data["qpos"]], np.int64)
+        return self._lens_np
+
+    def _flat_store(self):
+        """every take's rows back to back on self.device, per key [sum T, dim], + the takes' offsets: a batch is one gather per key"""
+        if getattr(self, "_flat", None) is None or self._flat_n != len(self.takes):
+            lens = self._seq_lens()
+            self._flat_off = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64) if len(lens) else np.zeros(0, np.int64)
+            self._flat = {k: torch.cat(v, 0).to(self.device) for k, v in self.data.items()} if len(lens) else {}
+            self._flat_n = len(self.takes)
+        return self._flat, self._flat_off
 
     def batch(self, inds, starts=None, length=None):
-        """Rows (take, start) as one padded batch; `len` holds each row's valid frame count (ragged when length is None)."""
-        inds = np.asarray(inds); starts = np.zeros(len(inds), np.int64) if starts is None else np.asarray(starts)
-        lens = [min(length, self.get_seq_len(i) - s) if length else self.get_seq_len(i) - s for i, s in zip(inds, starts)]
-        T = max(lens)
-        out = {}
-        for k, v in self.data.items():
-            rows = []
-            for i, s, L in zip(inds, starts, lens):
-                r = v[i][s:s + L]
-                rows.append(r if L == T else torch.cat([r, r[-1:].expand(T - L, -1)], 0))       # pad with the last frame
-            out[k] = torch.stack(rows, 0).to(self.device)
-        out["len"] = torch.tensor(lens, dtype=torch.int32, device=self.device)
+        """Rows (take, start) as one padded batch; `len` holds each row's valid frame count (ragged when length is None).  Rows shorter than
+        the batch's longest are padded with their last frame."""
+        inds = np.asarray(inds, np.int64); starts = np.zeros(len(inds), np.int64) if starts is None else np.asarray(starts, np.int64)
+        avail = self._seq_lens()[inds] - starts
+        lens = np.minimum(avail, length) if length else avail
+        T = int(lens.max())
+        flat, off = self._flat_store()
+        idx = (off[inds] + starts)[:, None] + np.minimum(np.arange(T)[None, :], (lens - 1)[:, None])             # [n, T] rows of the flat store
+        idx_t = torch.as_tensor(idx, device=self.device)
+        out = {k: v[idx_t] for k, v in flat.items()}
+        out["len"] = torch.as_tensor(lens.astype(np.int32), device=self.device)
         out["take_ind"], out["fr_start"] = torch.as_tensor(inds), torch.as_tensor(starts)
         return out
 

@@ -174,6 +174,14 @@ def test_dataset_features_and_sampling(golden):
     freq = {k: [[1, 0]] * 8 if k == "sit-1" else [[0, 5]] * 8 for k in ds.takes}
     p = ds.take_probs(freq)
     assert p[1] < p[0] and abs(p.sum() - 1) < 1e-12                                # often-succeeding takes are sampled less
+    hist = {k: [[float(v), 0] for v in np.random.RandomState(j).randint(0, 2, size=1 + 37 * j)] for j, k in enumerate(ds.takes)}      # the reference's recursion, literally
+    def ewma(x, alpha=0.05):
+        avg = x[0]
+        for v in x[1:]:
+            avg = alpha * v + (1 - alpha) * avg
+        return avg
+    want = np.exp(-np.array([ewma((np.array(hist[k])[:, 0] == 1).astype(float)) for k in hist]) / 0.5)
+    np.testing.assert_allclose(ds.take_probs(hist, 0.5), want / want.sum(), rtol=1e-12)
     b = ds.sample_batch(64, freq_dict=freq)
     assert b["qpos"].shape == (64, 10, 76) and b["target"].shape == (64, 10, 80) and b["obj_head_relative_poses"].shape == (64, 10, 7)
     for r in range(64):
