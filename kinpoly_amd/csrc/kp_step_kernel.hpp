@@ -9,8 +9,9 @@
 //   * every spatial quantity is expressed in ONE world-aligned frame at the root body origin, so tree
 //     recursions need no coordinate transforms: parents and children simply add;
 //   * kinematics, velocities and bias forces (RNE) come out of one level-synchronous pass (9 levels);
-//   * every linear solve -- (M + K_d h) for the stable-PD controller, M for the smooth acceleration,
-//     M + J^T D J for the Newton step of the contact solver -- is an articulated-body (ABA) pass:
+//   * every linear solve -- (M + K_d h) for the stable-PD controller, M + J^T D J for the Newton steps of the
+//     contact solver (M alone when no constraint row exists; qacc_smooth is never formed otherwise, see
+//     solve_constraints_direct) -- is an articulated-body (ABA) pass:
 //     leaves->root articulated inertia + bias, root->leaves accelerations.  K_d h and joint-limit terms
 //     enter as extra joint armature, active contact rows as a per-body 6x6 "contact inertia" D w w^T.
 //     The joint-space mass matrix is never formed or factorised (the reference materialises a dense
@@ -18,11 +19,12 @@
 //   * J v is read off the spatial accelerations the ABA forward pass leaves behind, J^T f and M v are a
 //     body-wrench subtree sum projected on the dofs; the solver's Gauss term lives in body form (spatial
 //     accelerations), so one projection per Newton iteration suffices;
-//   * Newton factorisations reuse the smooth solve's factors on the tree levels no active constraint reaches;
+//   * the first Newton factorisation of a substep walks every tree level; the later ones reuse its factors on the levels no active constraint reaches;
 //   * the RNE bias forces are never projected on the dofs: they stay body wrenches and enter the passes as articulated bias force.
 // Launch forms: kp_step_kernel (one workgroup = one wavefront per env and control step), kp_forward_kernel (sim.forward() only) and
 // kp_step_queue_kernel (the same step_body run by resident wavefronts that pull (env, few substeps) jobs from a FIFO in HBM, used
-// when there are more envs than wavefront slots; bit-identical results).
+// when there are more envs than wavefront slots; bit-identical results; the finishing job hands its successor the next stable-PD torque, and a wave
+// keeps an env it finds heavy).
 #pragma once
 #include <type_traits>
 
