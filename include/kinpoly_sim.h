@@ -201,6 +201,11 @@ int kp_gae_bootstrap(int n_envs, int T, const float* rewards, const float* masks
  * All device float32; logits are the composer MLP's output BEFORE its softmax. */
 int kp_mcp_compose(int n, int K, int A, const float* logits, const float* prim, const float* noise, int noise_stride, const float* stdv, float* out, void* hip_stream);
 
+/* One frame of the kinematic roll-out behind PolicyAR.init_context (TrajARNet.step, kin_poly/models/traj_ar_smpl_net.py:292-330): next_qpos [n,76] =
+ * step_ar(qpos, kin_action [n,80]) with the root quaternion normalised, qvel_fd [n,75] = get_qvel_fd_batch(qpos, next_qpos, dt)
+ * (kin_poly/utils/torch_utils.py:315-331).  A pure function of its device rows (no simulator handle). */
+int kp_kin_advance(int n, const float* qpos, const float* kin_action, float dt, float* next_qpos, float* qvel_fd, void* hip_stream);
+
 /* PolicyMCP's last layer AND its mixing stage in one fp32 MFMA kernel (same reference lines): with h2 [K, n, J] the raw output of the second
  * batched GEMM (no bias, no activation), b2 [K, J], w3 [K, J, ldw >= A] (= nets[k][1].weight^T stacked, rows ldw floats apart; with ldw >= 80,
  * ldw % 4 == 0 and a 16-byte aligned base the kernel reads it with 16-byte loads: pad the rows to 80), b3 [K, A]:

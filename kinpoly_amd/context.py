@@ -128,24 +128,22 @@ class TrajARNet(KinPolicy):
         obj = torch.empty((N, 7), device=dev)
         ctx = kin_sim.make_ctx(T, data["head_pose"].contiguous(), data["head_vels"].contiguous(), data["obj_head_relative_poses"].contiguous(),
                                one_hot.contiguous(), z96, z72, cur_t, obj_qpos=obj)
-        qpos, qvel = init_qpos.contiguous().clone(), init_qvel.contiguous().clone()
+        # time-major records: frame t + 1 of Q / V is written in place by the fused step (kp_kin_advance), so the loop carries views, not copies
+        Qb = torch.empty((T, N, 76), device=dev); Vb = torch.empty((T, N, 75), device=dev); Ab = torch.empty((T, N, 80), device=dev)
+        Qb[0].copy_(init_qpos); Vb[0].copy_(init_qvel)
         hx = self.init_hidden(N, dev)
-        Q, V, A = [], [], []
         for t in range(T):
             cur_t.fill_(t)
             obj.copy_(data["obj_pose"][:, t, :7])
-            kin_sim.set_state(qpos, qvel)                      # forward kinematics of the kinematic state
+            kin_sim.set_state(Qb[t], Vb[t])                    # forward kinematics of the kinematic state
             state = kin_sim.obs_ar(ctx)
-            Q.append(qpos.clone()); V.append(qvel.clone())
             action, hx = self.get_action(state, hx)
-            A.append(action)
+            Ab[t].copy_(action)
             if t == T - 1:
                 break
-            nxt = kin_sim.step_kin(action.contiguous())
-            nxt[:, 3:7] = nxt[:, 3:7] / nxt[:, 3:7].norm(dim=1, keepdim=True)   # TrajARNet.step normalises (:323-327)
-            qvel = get_qvel_fd_batch(qpos, nxt, dt).contiguous()
-            qpos = nxt.contiguous()
-        Q, V, A = torch.stack(Q, 1), torch.stack(V, 1), torch.stack(A, 1)
+            # next pose (root quaternion normalised, TrajARNet.step :323-327) and finite-difference velocity in one launch
+            kpsim.kin_advance(Qb[t], Ab[t], dt, Qb[t + 1], Vb[t + 1])
+        Q, V, A = Qb.transpose(0, 1), Vb.transpose(0, 1), Ab.transpose(0, 1)
         V = torch.cat([V[:, 1:], V[:, -2:-1]], 1)              # fix_qvel (:385-388)
         return Q, V, A
 

@@ -78,6 +78,50 @@ __global__ void k_step_kin(int n, const float* __restrict__ qpos, const float* _
     for (int j = 0; j < D_NU; j++) o[7 + j] = a[5 + j];
 }
 
+// One frame of TrajARNet's kinematic roll-out (kin_poly/models/traj_ar_smpl_net.py:292-330): next_qpos = step(action) with the root quaternion
+// normalised (:323-327) and qvel = get_qvel_fd_batch(qpos, next_qpos, dt) (kin_poly/utils/torch_utils.py:315-331: linear part, rotation vector of
+// next (x) cur^-1 through rotation_from_quaternion's sqrt(1 - w^2) form, wrapped to (-pi, pi], expressed in the current root frame, joint part).
+// One thread per env; replaces ~30 elementwise launches per frame of the batched init_context.
+__global__ void k_kin_advance(int n, const float* __restrict__ qpos, const float* __restrict__ act, float dt, float* __restrict__ next_qpos, float* __restrict__ qvel) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const float* q = qpos + (size_t)e * D_NQ;
+    const float* a = act + (size_t)e * 80;
+    float* o = next_qpos + (size_t)e * D_NQ;
+    float* v = qvel + (size_t)e * D_NV;
+    const Q4 rot = Q4{q[3], q[4], q[5], q[6]};
+    const Q4 hq = q_heading(rot);
+    const V3 linv = q_mul_vec(hq, v3(a[74], a[75], a[76]));
+    const float nx = q[0] + linv.x * dt, ny = q[1] + linv.y * dt, nz = a[0];
+    const V3 angv = q_mul_vec(rot, v3(a[77], a[78], a[79]));
+    Q4 nr = qmul(q_from_expmap(dt * angv), rot);
+    const float nn = sqrtf(nr.w * nr.w + nr.x * nr.x + nr.y * nr.y + nr.z * nr.z);
+    nr = Q4{nr.w / nn, nr.x / nn, nr.y / nn, nr.z / nn};
+    o[0] = nx; o[1] = ny; o[2] = nz; o[3] = nr.w; o[4] = nr.x; o[5] = nr.y; o[6] = nr.z;
+    const float idt = 1.0f / dt;
+    v[0] = (nx - q[0]) * idt; v[1] = (ny - q[1]) * idt; v[2] = (nz - q[2]) * idt;
+    // qrel = next (x) inverse(cur), inverse = conjugate / |cur|^2
+    const float c2 = rot.w * rot.w + rot.x * rot.x + rot.y * rot.y + rot.z * rot.z;
+    const Q4 qrel = qmul(nr, Q4{rot.w / c2, -rot.x / c2, -rot.y / c2, -rot.z / c2});
+    const float w = fminf(1.0f, fmaxf(-1.0f, qrel.w));
+    float sn = sqrtf(fmaxf(1.0f - w * w, 0.0f));
+    const bool small = sn < 1e-5f;
+    sn = fmaxf(sn, 1e-30f);
+    const V3 axis = small ? v3(1.f, 0.f, 0.f) : v3(qrel.x / sn, qrel.y / sn, qrel.z / sn);
+    float angle = small ? 0.0f : 2.0f * acosf(w);
+    if (angle > 3.14159265358979f) angle -= 6.28318530717959f;
+    if (angle < -3.14159265358979f) angle += 6.28318530717959f;
+    const V3 rv = (angle * idt) * axis;
+    // transform_vec_batch(rv, cur, 'root'): R(cur / |cur|)^T rv
+    const float cn = sqrtf(c2);
+    const float qw = rot.w / cn;
+    const V3 u = v3(-rot.x / cn, -rot.y / cn, -rot.z / cn);
+    const V3 t = 2.0f * cross(u, rv);
+    const V3 wv = rv + qw * t + cross(u, t);
+    v[3] = wv.x; v[4] = wv.y; v[5] = wv.z;
+    for (int j = 0; j < D_NU; j++) { const float nj = a[5 + j]; o[7 + j] = nj; v[6 + j] = (nj - q[7 + j]) * idt; }
+}
+
 // ---------------------------------------------------------------- target FK: one wavefront per row, lane = body, level-synchronous chain in LDS
 // (256-thread blocks = 4 rows).  Row loads and stores are coalesced; the 9-level parent chain goes through LDS.
 struct TargetBufs { float *qpos, *wbpos, *wbquat, *bquat, *com; };

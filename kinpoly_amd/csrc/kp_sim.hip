@@ -752,6 +752,13 @@ int kp_mcp_compose(int n, int K, int A, const float* logits, const float* prim, 
     return 0;
 }
 
+int kp_kin_advance(int n, const float* qpos, const float* kin_action, float dt, float* next_qpos, float* qvel_fd, void* stream) {
+    if (n <= 0 || !qpos || !kin_action || !next_qpos || !qvel_fd || !(dt > 0.f)) return fail("kp_kin_advance: bad arguments");
+    hipLaunchKernelGGL(kp::k_kin_advance, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, n, qpos, kin_action, dt, next_qpos, qvel_fd);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
 int kp_mcp_tail(int n, int K, int J, int A, const float* h2, const float* b2, const float* w3, int ldw, const float* b3, const float* logits, const float* noise,
                 int noise_stride, const float* stdv, float* out, void* stream) {
     if (n <= 0 || K <= 0 || K > 16 || J <= 0 || J % kp::MCP_CHUNK || A <= 0 || A > 80 || ldw < A || !h2 || !b2 || !w3 || !b3 || !logits || !out || (noise && !stdv))

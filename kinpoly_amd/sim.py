@@ -36,7 +36,7 @@ ABI_SYMBOLS = [
     "kp_sim_launch_cost", "kp_job_schedule", "kp_sim_fk_backward", "kp_sim_set_stream", "kp_sim_status_device", "kp_sim_mass_matrix",
     "kp_sim_contacts", "kp_gae_bootstrap", "kp_gru_gates_forward", "kp_gru_gates_backward", "kp_sim_phase_cycles_env",
     "kp_sim_post_step", "kp_sim_reset_rows", "kp_mcp_compose", "kp_sim_step_head", "kp_model_compile", "kp_model_load_xml",
-    "kp_mcp_tail", "kp_gru_cell_step",
+    "kp_mcp_tail", "kp_gru_cell_step", "kp_kin_advance",
 ]
 
 
@@ -97,6 +97,7 @@ def load_library(path: str | None = None):
     L.kp_sim_post_step.argtypes = [P, C.POINTER(KpCtx), C.POINTER(KpRewardCfg), C.c_void_p, C.c_void_p, C.c_int, F, F, U8, F, U8, U8, F, C.c_void_p]; L.kp_sim_post_step.restype = C.c_int
     L.kp_sim_reset_rows.argtypes = [P, F, F, C.c_void_p, U8, C.c_void_p, C.c_int, F, C.c_int]; L.kp_sim_reset_rows.restype = C.c_int
     L.kp_mcp_tail.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, F, F, F, C.c_int, F, F, F, C.c_int, F, F, C.c_void_p]; L.kp_mcp_tail.restype = C.c_int
+    L.kp_kin_advance.argtypes = [C.c_int, F, F, C.c_float, F, F, C.c_void_p]; L.kp_kin_advance.restype = C.c_int
     L.kp_gru_cell_step.argtypes = [C.c_int, C.c_int, C.c_int, F, F, F, F, F, F, F, F, C.c_void_p]; L.kp_gru_cell_step.restype = C.c_int
     L.kp_mcp_compose.argtypes = [C.c_int, C.c_int, C.c_int, F, F, F, C.c_int, F, F, C.c_void_p]; L.kp_mcp_compose.restype = C.c_int
     L.kp_gae.argtypes = [C.c_int, C.c_int, F, F, F, C.c_float, C.c_float, F, F, C.c_void_p]; L.kp_gae.restype = C.c_int
@@ -441,6 +442,22 @@ def mcp_tail(h2: torch.Tensor, b2: torch.Tensor, w3: torch.Tensor, b3: torch.Ten
                          C.c_void_p(logits.data_ptr()), nz, stride,
                          None if std is None else C.c_void_p(std.data_ptr()), C.c_void_p(out.data_ptr()), C.c_void_p(stream)), "kp_mcp_tail")
     return out
+
+
+def kin_advance(qpos: torch.Tensor, action: torch.Tensor, dt: float = 1.0 / 30.0, next_qpos: torch.Tensor | None = None, qvel: torch.Tensor | None = None):
+    """One frame of TrajARNet's kinematic roll-out (kp_kin_advance): (next_qpos [N,76] with a unit root quaternion, finite-difference qvel [N,75])."""
+    L = load_library()
+    n = qpos.shape[0]
+    if not all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in (qpos, action)) or tuple(qpos.shape) != (n, NQ) or tuple(action.shape) != (n, 80):
+        raise ValueError("kin_advance: qpos [N,76] and action [N,80] must be contiguous float32 device tensors")
+    next_qpos = torch.empty((n, NQ), device=qpos.device) if next_qpos is None else next_qpos
+    qvel = torch.empty((n, NV), device=qpos.device) if qvel is None else qvel
+    if not (next_qpos.is_contiguous() and qvel.is_contiguous()):
+        raise ValueError("kin_advance: outputs must be contiguous")
+    stream = torch.cuda.current_stream(qpos.device).cuda_stream
+    _check(L.kp_kin_advance(n, C.c_void_p(qpos.data_ptr()), C.c_void_p(action.data_ptr()), float(dt), C.c_void_p(next_qpos.data_ptr()), C.c_void_p(qvel.data_ptr()),
+                            C.c_void_p(stream)), "kp_kin_advance")
+    return next_qpos, qvel
 
 
 def gru_cell_step(gi: torch.Tensor, gh: torch.Tensor, b_ih: torch.Tensor, b_hh: torch.Tensor, h: torch.Tensor, state: torch.Tensor | None = None,

@@ -110,3 +110,38 @@ def test_reset_rows_zeroes_the_policy_state_of_the_reset_envs_only():
     torch.cuda.synchronize()
     assert torch.equal(hx.sum(1).cpu(), torch.tensor([0, 1024, 1024, 0, 1024, 1024, 1024, 1024, 0.0]))
     assert cur_t.cpu().tolist() == [0, 7, 7, 0, 7, 7, 7, 7, 0]
+
+
+def test_kin_advance_is_step_ar_plus_finite_difference_velocity():
+    """kp_kin_advance against the fp64 oracle: HumanoidAREnv.step_ar (kin_poly/envs/humanoid_ar_v1.py:216-241), the root-quaternion
+    normalisation of TrajARNet.step (traj_ar_smpl_net.py:323-327) and get_qvel_fd_batch (torch_utils.py:315-331) in one launch."""
+    import sys
+    sys.path.insert(0, ROOT)
+    from kinpoly_amd import sim as kpsim
+    from kinpoly_amd.context import get_qvel_fd_batch
+    from oracle import np_oracle as O
+    rng = np.random.default_rng(5)
+    n, dt = 300, 1.0 / 30.0
+    qpos = rng.normal(0, 0.4, (n, 76)); qpos[:, 2] += 0.9
+    qpos[:, 3:7] = rng.normal(0, 1, (n, 4)); qpos[:, 3:7] /= np.linalg.norm(qpos[:, 3:7], axis=1, keepdims=True)
+    qpos[:40, 3:7] *= 1.0 + rng.normal(0, 1e-3, (40, 1))               # not exactly unit: the inverse and the frame change both normalise
+    act = rng.normal(0, 0.5, (n, 80))
+    w = act[:, 77:80]; nw = np.linalg.norm(w, axis=1, keepdims=True)
+    act[:, 77:80] = w / nw * np.maximum(nw, 0.5)                          # acos(w) of a near-identity rotation is fp32 noise in the reference too
+    act[-1, 77:80] = 0.0                                                 # the 'small' branch: exactly no rotation
+    nxt, qv = kpsim.kin_advance(torch.tensor(qpos, dtype=torch.float32, device="cuda"), torch.tensor(act, dtype=torch.float32, device="cuda"), dt)
+    torch.cuda.synchronize()
+    q32 = torch.tensor(qpos, dtype=torch.float32).double().numpy(); a32 = torch.tensor(act, dtype=torch.float32).double().numpy()
+    want = np.stack([O.step_ar(q32[i], a32[i], dt) for i in range(n)])
+    want[:, 3:7] /= np.linalg.norm(want[:, 3:7], axis=1, keepdims=True)
+    wantv = get_qvel_fd_batch(torch.tensor(q32), torch.tensor(want), dt).numpy()
+    assert np.abs(nxt.cpu().numpy() - want).max() < 2e-6
+    got = qv.cpu().numpy()
+    assert np.abs(got[:, :3] - wantv[:, :3]).max() < 1e-4 and np.abs(got[:, 6:] - wantv[:, 6:]).max() < 1e-4
+    assert np.abs(got[:-1, 3:6] - wantv[:-1, 3:6]).max() < 2e-3         # rotation vector / dt through acos in fp32
+    assert np.all(got[-1, 3:6] == 0.0)
+    # in-place record layout of the roll-out: outputs are rows of time-major buffers
+    Q = torch.zeros((2, n, 76), device="cuda"); V = torch.zeros((2, n, 75), device="cuda")
+    Q[0].copy_(torch.tensor(qpos, dtype=torch.float32))
+    kpsim.kin_advance(Q[0], torch.tensor(act, dtype=torch.float32, device="cuda"), dt, Q[1], V[1])
+    assert torch.equal(Q[1], nxt) and torch.equal(V[1], qv)
