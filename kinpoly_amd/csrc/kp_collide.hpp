@@ -263,7 +263,10 @@ __device__ __forceinline__ int plane_cylinder(const float* g, float margin, floa
     float prjaxis = axis.z;
     if (prjaxis > 0.f) { axis = v3(-axis.x, -axis.y, -axis.z); prjaxis = -prjaxis; }
     const float dist0 = pos.z;
-    V3 vec = prjaxis * axis - normal;
+    // -normal with its axial component removed, (n . a) a - n.  Its z component a_z^2 - 1 is a difference of two numbers next to 1 for an
+    // upright cylinder (tilt 1e-3 rad: 1e-6 known to 1e-7 in fp32, i.e. the rim height r sin(tilt) off by tens of per cent); for a unit axis
+    // it equals -(a_x^2 + a_y^2), which has no cancellation
+    V3 vec = v3(prjaxis * axis.x, prjaxis * axis.y, -(axis.x * axis.x + axis.y * axis.y));
     const float len2 = dot(vec, vec);
     if (len2 >= 1e-12f) vec = (g[1] / sqrtf(len2)) * vec;
     else vec = v3(R[0] * g[1], R[3] * g[1], R[6] * g[1]);
@@ -317,7 +320,8 @@ __device__ inline int box_box(const float* ga, const float* gb, float margin, fl
         for (int a = 0; a < 3; a++) if (a != bi) qa = qa + ((dot(bn, Ra[a]) > 0.f ? 1.f : -1.f) * sa[a]) * Ra[a];
         for (int a = 0; a < 3; a++) if (a != bj) qb = qb + ((dot(bn, Rb[a]) > 0.f ? -1.f : 1.f) * sb[a]) * Rb[a];
         const V3 ua = Ra[bi], ub = Rb[bj], w = qa - qb;
-        const float b = dot(ua, ub), dd = dot(ua, w), e = dot(ub, w), den = 1.f - b * b;
+        const V3 uxu = cross(ua, ub);                                   // 1 - (ua . ub)^2 without the cancellation
+        const float b = dot(ua, ub), dd = dot(ua, w), e = dot(ub, w), den = dot(uxu, uxu);
         float ta = den > 1e-12f ? (b * e - dd) / den : 0.f, tb = den > 1e-12f ? (e - b * dd) / den : 0.f;
         ta = fmaxf(-sa[bi], fminf(sa[bi], ta)); tb = fmaxf(-sb[bj], fminf(sb[bj], tb));
         put_rec(rec, 0, best, 0.5f * ((qa + ta * ua) + (qb + tb * ub)), bn);

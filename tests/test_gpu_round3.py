@@ -212,3 +212,47 @@ def test_constraint_solve_does_not_depend_on_its_starting_point():
     dq = (a.get("qpos") - b.get("qpos")).abs().max().item()
     dv = (a.get("qvel") - b.get("qvel")).abs().max().item()
     assert dq < 2e-6 and dv < 3e-4, (dq, dv)          # measured 3.5e-7 / 4e-5; the zeroed start costs 0.7 Newton iterations more over the control step
+
+
+def test_upright_cylinder_with_a_tiny_tilt_has_the_oracles_contact_distances():
+    """mjc_PlaneCylinder's rim direction is (n . a) a - n: for a cylinder standing on the floor its z component a_z^2 - 1 cancels to nothing in fp32
+    (tilt 1e-3 rad: contact distances off by 1e-4, found by tools/obj_fuzz_trace.py on the 'avoid' scenes).  The kernel evaluates it as -(a_x^2 + a_y^2);
+    the contact set of the Can against the floor must equal the fp64 oracle's at tilts from 1e-5 to 1e-2 rad."""
+    sys.path.insert(0, ROOT)
+    from kinpoly_amd.model_compiler import read_kpm
+    from kinpoly_amd.sim import STEP_KPM, KpModel, KpSim
+    from oracle.kpo import OracleSim
+    kpm = read_kpm(STEP_KPM)
+    std = np.load(os.path.join(ROOT, "tests", "golden", "standing_neutral.npz"))
+    rng = np.random.default_rng(11)
+    n = 24
+    blk = np.zeros((n, 35))
+    for i in range(5):
+        blk[:, 7 * i: 7 * i + 3] = [(i + 1) * 100, 100, 0]
+    tilts = 10.0 ** rng.uniform(-5, -2, n)
+    for e in range(n):
+        ax = np.append(rng.normal(size=2), 0.0); ax /= np.linalg.norm(ax)
+        yaw = rng.uniform(-np.pi, np.pi)
+        qt = np.concatenate([[np.cos(tilts[e] / 2)], np.sin(tilts[e] / 2) * ax]); qy = np.array([np.cos(yaw / 2), 0, 0, np.sin(yaw / 2)])
+        w1, x1, y1, z1 = qt; w2, x2, y2, z2 = qy
+        q = np.array([w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2, w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2])
+        blk[e, 21:28] = [std["qpos"][0] + 1.5, std["qpos"][1] + 1.5, 0.69 + 0.0004, *q]          # the Can, out of the humanoid's reach
+    blk = np.asarray(blk, np.float32).astype(np.float64)
+    qpos = np.tile(np.asarray(std["qpos"], np.float32).astype(np.float64), (n, 1)); qvel = np.zeros((n, 75))
+    dev = lambda x: torch.tensor(x, dtype=torch.float32, device="cuda")  # noqa: E731
+    sim = KpSim(KpModel(STEP_KPM), n)
+    sim.record_contacts()
+    sim.set_objects(dev(blk)); sim.set_state(dev(qpos), dev(qvel)); sim.set_target(dev(qpos))
+    sim.step_ctrl(dev(np.zeros((n, 75))), 1)
+    hip = sim.contacts()
+    seen = 0
+    for e in range(n):
+        o = OracleSim(kpm=STEP_KPM)
+        o.set_object(0, kpm, 3, blk[e, 21:28])
+        o.reset(qpos[e], qvel[e])
+        c = o.contacts_full(); h = hip[e]
+        co = np.sort(c["dist"][(c["body"] == 24) & (c["b2"] == -1)]); ch = np.sort(h["dist"][(h["body"] == 24) & (h["b2"] == -1)])
+        assert len(co) == len(ch) and len(co) >= 1, (e, tilts[e], co, ch)
+        assert np.abs(co - ch).max() < 1e-6, (e, tilts[e], co, ch)
+        seen += len(co)
+    assert seen >= 2 * n
