@@ -1,0 +1,103 @@
+"""One-substep parity from common states.  Trajectory sweeps (floor_fuzz.py, obj_fuzz.py) measure the distance between two free-running trajectories,
+which mixes what the arithmetic disagrees on with how fast the scene amplifies it.  Here every scene follows the fp64 oracle's trajectory and, at EVERY
+substep, both sides start from the same fp32-rounded state (humanoid and objects, positions and velocities) and advance ONE substep: the error is the
+disagreement of one substep's arithmetic, and the contact sets are compared at the same state.
+
+    python tools/substep_parity.py floor|objects [n_scenes=64] [seed] [substeps=45]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
+import _scenes  # noqa: E402
+from kinpoly_amd.model_compiler import read_kpm  # noqa: E402
+from kinpoly_amd.sim import STEP_KPM, KpModel, KpSim  # noqa: E402
+from oracle.kpo import OracleSim  # noqa: E402
+
+LS_EXACT = bool(int(os.environ.get("KP_ORACLE_LS_EXACT", "0")))     # 1: the oracle's line search returns the exact minimiser (as the kernel's does) instead of MuJoCo's PrimalSearch
+
+DUMP = tuple(int(x) for x in os.environ["KP_DUMP"].split(",")) if "KP_DUMP" in os.environ else None
+
+
+def run(mode="floor", n=64, seed=None, nsub=45):
+    """-> dict(eq, ev, eo [nsub, n], differ [nsub, n] bool, ncon, scenes)"""
+    seed = (2024 if mode == "floor" else 0) if seed is None else seed
+    obj = mode == "objects"
+    S = _scenes.object_scenes(n, seed) if obj else _scenes.floor_scenes(n, seed)
+    kpm = read_kpm(STEP_KPM) if obj else None
+    r32 = _scenes.r32
+    dev = lambda x: torch.tensor(np.ascontiguousarray(x), dtype=torch.float32, device="cuda")  # noqa: E731
+    sim = KpSim(KpModel(STEP_KPM) if obj else KpModel(), n)
+    sim.record_contacts()
+    if obj:
+        sim.set_objects(dev(S["blk"]))
+    sim.set_state(dev(S["qpos"]), dev(S["qvel"])); sim.set_target(dev(S["target"]))
+    a_t = dev(S["action"])
+    oracles = []
+    for e in range(n):
+        o = OracleSim(kpm=STEP_KPM, ls_exact=LS_EXACT) if obj else OracleSim(ls_exact=LS_EXACT)
+        for slot, oi in enumerate(sorted(S["objects"][e])):
+            o.set_object(slot, kpm, oi, S["objects"][e][oi])
+        o.reset(S["qpos"][e], S["qvel"][e])
+        oracles.append(o)
+    eq = np.zeros((nsub, n)); ev = np.zeros((nsub, n)); eo = np.zeros((nsub, n)); differ = np.zeros((nsub, n), bool); ncon = np.zeros((nsub, n), int)
+    nit_o = np.zeros((nsub, n), int); nit_h = np.zeros((nsub, n), int)
+    for k in range(nsub):
+        q = np.stack([r32(o.get("qpos")) for o in oracles]); v = np.stack([r32(o.get("qvel")) for o in oracles])
+        if obj:
+            b = S["blk"].copy(); bv = np.zeros((n, 30))
+            for e, o in enumerate(oracles):
+                for slot, oi in enumerate(sorted(S["objects"][e])):
+                    oq, ov = o.get_object(slot)
+                    b[e, 7 * oi: 7 * oi + 7] = r32(oq); bv[e, 6 * oi: 6 * oi + 6] = r32(ov)
+                    o.set_object(slot, kpm, oi, b[e, 7 * oi: 7 * oi + 7], bv[e, 6 * oi: 6 * oi + 6])
+            sim.set_obj_state(dev(b), dev(bv))
+        sim.set_state(dev(q), dev(v))
+        if DUMP and DUMP[0] == k:               # KP_DUMP=substep,scene: the common state of that substep, for a closer look (tools/micro/substep_state.py)
+            e = DUMP[1]
+            np.savez(os.path.join(ROOT, "gpurun_out", f"substep_state_{mode}_{seed}_{k}_{e}.npz"), qpos=q[e], qvel=v[e], action=S["action"][e], target=S["target"][e],
+                     blk=b[e] if obj else np.zeros(35), bv=bv[e] if obj else np.zeros(30), objects=np.asarray(sorted(S["objects"][e]), int))
+        sim.step_ctrl(a_t, 1)
+        hq = sim.get("qpos").double().cpu().numpy(); hv = sim.get("qvel").double().cpu().numpy()
+        hob = sim.get("obj_qpos").double().cpu().numpy() if obj else None
+        hc = sim.contacts()
+        dg = sim.diag()
+        assert dg[:, 2].max() == 0, "non-finite state"
+        nit_h[k] = dg[:, 1]
+        for e, o in enumerate(oracles):
+            o.reset(q[e], v[e])
+            o.do_simulation(S["action"][e], S["target"][e], 1)
+            wv = o.get("qvel"); nit_o[k, e] = o.niter
+            eq[k, e] = np.abs(o.get("qpos") - hq[e]).max(); ev[k, e] = np.abs(wv - hv[e]).max() / max(1.0, np.abs(wv).max())
+            if obj:
+                eo[k, e] = max(np.abs(o.get_object(slot)[0] - hob[e, 7 * oi: 7 * oi + 7]).max() for slot, oi in enumerate(sorted(S["objects"][e])))
+            if obj:
+                c = o.contacts_full()
+                so, sh = sorted(zip(c["body"].tolist(), c["b2"].tolist())), sorted(zip(hc[e]["body"].tolist(), hc[e]["b2"].tolist()))
+            else:
+                so, sh = sorted(o.contacts()[0].tolist()), sorted(hc[e]["body"].tolist())
+            differ[k, e] = so != sh; ncon[k, e] = len(so)
+    return dict(eq=eq, ev=ev, eo=eo, differ=differ, ncon=ncon, scenes=S, seed=seed, nit_o=nit_o, nit_h=nit_h)
+
+
+if __name__ == "__main__":
+    mode = sys.argv[1] if len(sys.argv) > 1 else "floor"
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+    seed = int(sys.argv[3]) if len(sys.argv) > 3 else None
+    nsub = int(sys.argv[4]) if len(sys.argv) > 4 else 45
+    R = run(mode, n, seed, nsub)
+    eq, ev, eo, differ, ncon, S, seed = (R[k] for k in ("eq", "ev", "eo", "differ", "ncon", "scenes", "seed"))
+    err = np.maximum(eq, eo)
+    same = ~differ
+    print(f"{mode}{' [oracle with the exact line search]' if LS_EXACT else ''}: {n} scenes (seed {seed}) x {nsub} substeps, every substep from a common fp32-rounded state: one-substep |dqpos| median {np.median(err):.1e} p99 {np.quantile(err, .99):.1e} "
+          f"max {err.max():.1e}; rel |dqvel| max {ev.max():.1e}; contacts mean {ncon.mean():.1f} max {ncon.max()}")
+    print(f"   substeps whose contact sets differ between the two sides at the same state: {int(differ.sum())} of {differ.size}"
+          + (f" (their one-substep |dqpos| max {err[differ].max():.1e})" if differ.any() else "")
+          + f"; with equal contact sets: max |dqpos| {err[same].max():.1e}, above 1e-6: {int((err[same] > 1e-6).sum())}, above 1e-5: {int((err[same] > 1e-5).sum())}")
+    order = np.dstack(np.unravel_index(np.argsort(-err, axis=None)[:6], err.shape))[0]
+    for k, e in order:
+        print(f"   substep {k:2d} scene {e:3d} (kind {S['kind'][e]}, objects {sorted(S['objects'][e])}): |dqpos| {eq[k, e]:.1e} object {eo[k, e]:.1e} rel |dqvel| {ev[k, e]:.1e} contacts {ncon[k, e]} Newton iterations oracle {R['nit_o'][k, e]} hip {R['nit_h'][k, e]}"
+              f"{'  contact sets differ' if differ[k, e] else ''}")
