@@ -35,8 +35,9 @@ __device__ __forceinline__ Q4 q_heading(Q4 q) {  // get_heading_q
 __device__ __forceinline__ float heading_angle(Q4 q) {  // get_heading
     float w = q.w, z = q.z;
     if (z < 0.f) { w = -w; z = -z; }
-    float n = sqrtf(w * w + z * z);
-    return 2.0f * acosf(fminf(1.0f, fmaxf(-1.0f, w / n)));
+    // 2 acos(w / |(w, z)|) with z >= 0, as the angle of the point (w, z): acos next to 1 would turn the 6e-8 of an fp32 cosine into 1e-4 rad
+    // for a heading of 1e-3 rad (the reference works in fp64)
+    return 2.0f * atan2f(fabsf(z), w);
 }
 __device__ __forceinline__ Q4 q_from_expmap(V3 e) {  // quat_from_expmap + quaternion_about_axis
     float angle = sqrtf(dot(e, e));
@@ -103,12 +104,12 @@ __global__ void k_kin_advance(int n, const float* __restrict__ qpos, const float
     // qrel = next (x) inverse(cur), inverse = conjugate / |cur|^2
     const float c2 = rot.w * rot.w + rot.x * rot.x + rot.y * rot.y + rot.z * rot.z;
     const Q4 qrel = qmul(nr, Q4{rot.w / c2, -rot.x / c2, -rot.y / c2, -rot.z / c2});
-    const float w = fminf(1.0f, fmaxf(-1.0f, qrel.w));
-    float sn = sqrtf(fmaxf(1.0f - w * w, 0.0f));
+    // sin(acos(w)) and 2 acos(w) of the reference (fp64 there) without the fp32 cancellation of 1 - w^2: for the unit quaternion qrel the sine is |xyz|
+    float sn = sqrtf(qrel.x * qrel.x + qrel.y * qrel.y + qrel.z * qrel.z);
     const bool small = sn < 1e-5f;
     sn = fmaxf(sn, 1e-30f);
     const V3 axis = small ? v3(1.f, 0.f, 0.f) : v3(qrel.x / sn, qrel.y / sn, qrel.z / sn);
-    float angle = small ? 0.0f : 2.0f * acosf(w);
+    float angle = small ? 0.0f : 2.0f * atan2f(sn, qrel.w);
     if (angle > 3.14159265358979f) angle -= 6.28318530717959f;
     if (angle < -3.14159265358979f) angle += 6.28318530717959f;
     const V3 rv = (angle * idt) * axis;

@@ -75,8 +75,11 @@ __device__ __forceinline__ float quat_norm_v2(Q4 q) {  // multi_quat_norm_v2 of 
     return sqrtf(a * a + q.x * q.x + q.y * q.y + q.z * q.z);
 }
 __device__ __forceinline__ V3 rot_from_quat(Q4 q) {  // rotation_from_quaternion (transformation.py:348-356)
-    if (1.0f - fabsf(q.w) < 1e-8f) return v3(0.f, 0.f, 0.f);
-    float s = sqrtf(1.0f - q.w * q.w), ang = 2.0f * acosf(q.w);
+    // the reference (fp64): zero if 1 - |w| < 1e-8, else xyz / sqrt(1 - w^2) * 2 acos(w).  In fp32 1 - w^2 of a small rotation (a body turning at
+    // 0.1 rad/s between two control steps: 2e-6) is known to 3 %; for the unit quaternion q it equals |xyz|^2, and 1 - |w| = |xyz|^2 / (1 + |w|)
+    const float s2 = q.x * q.x + q.y * q.y + q.z * q.z;
+    if (s2 < 1e-8f * (1.0f + fabsf(q.w))) return v3(0.f, 0.f, 0.f);
+    const float s = sqrtf(s2), ang = 2.0f * atan2f(s, q.w);
     return (ang / s) * v3(q.x, q.y, q.z);
 }
 

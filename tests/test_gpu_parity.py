@@ -334,6 +334,36 @@ def test_obs_cc_matches_pinned_oracle(kp, golden):
     np.testing.assert_allclose(ob2, np.clip((obs - zg["zf_mean"]) / (zg["zf_std"] + 1e-8), -5, 5), atol=2e-4, rtol=1e-4)
 
 
+def test_obs_cc_small_headings_keep_their_digits(kp):
+    """rel_heading = get_heading(target) - get_heading(current) (humanoid_im.py:185-190) when both headings are tiny: 2 acos(w) next to w = 1 would
+    leave 1e-4 rad of fp32 noise where the reference (fp64) has none; the kernel takes the angle of (w, z) instead.  Feature 301 of the 784."""
+    rng = np.random.default_rng(21)
+    n = 40
+    qpos = np.tile(np.asarray(STD["qpos"], np.float64), (n, 1))
+    h0 = O.get_heading(qpos[0, 3:7])                 # the standing pose faces 3.0 rad: turn it back so that the headings below are the tiny ones
+    tq = qpos.copy()
+    hc, ht = 10.0 ** rng.uniform(-5, -2, n) * rng.choice([-1, 1], n), 10.0 ** rng.uniform(-5, -2, n) * rng.choice([-1, 1], n)
+
+    def yawed(q, h):          # heading rotation about z in front of the stored root quaternion
+        w1, z1 = np.cos(h / 2), np.sin(h / 2)
+        w2, x2, y2, z2 = q
+        return np.array([w1 * w2 - z1 * z2, w1 * x2 - z1 * y2, w1 * y2 + z1 * x2, w1 * z2 + z1 * w2])
+    for i in range(n):
+        qpos[i, 3:7] = yawed(qpos[i, 3:7], hc[i] - h0); tq[i, 3:7] = yawed(tq[i, 3:7], ht[i] - h0)
+    sim = kp.KpSim(kp.KpModel(), n)
+    sim.set_state(dev(qpos), dev(np.zeros((n, 75)))); sim.set_target(dev(tq))
+    obs = sim.obs_cc().cpu().numpy().astype(np.float64)
+    rd = {k: sim.get(k).cpu().numpy().astype(np.float64) for k in ("qpos", "qvel", "xpos", "xquat", "xipos", "target_qpos")}
+    worst = 0.0
+    for i in range(n):
+        t = O.qpos_fk(rd["target_qpos"][i], BODY_POS, BODY_IPOS, PARENT)
+        want = O.obs_cc(rd["qpos"][i], rd["qvel"][i], rd["xpos"][i].reshape(24, 3), rd["xquat"][i].reshape(24, 4), rd["xipos"][i].reshape(24, 3), t)
+        rel = O.get_heading(rd["target_qpos"][i, 3:7]) - O.get_heading(rd["qpos"][i, 3:7])
+        assert abs((want[301] - rel + np.pi) % (2 * np.pi) - np.pi) < 1e-8       # feature 301 is rel_heading, wrapped to (-pi, pi] (acos next to 1 costs even fp64 six digits)
+        worst = max(worst, abs(obs[i, 301] - want[301]))
+    assert worst < 2e-6, worst
+
+
 def test_env_mask_and_reset(kp):
     n = 8
     qpos, qvel = make_states(n, 11, lift=10.0)

@@ -124,21 +124,22 @@ def test_kin_advance_is_step_ar_plus_finite_difference_velocity():
     n, dt = 300, 1.0 / 30.0
     qpos = rng.normal(0, 0.4, (n, 76)); qpos[:, 2] += 0.9
     qpos[:, 3:7] = rng.normal(0, 1, (n, 4)); qpos[:, 3:7] /= np.linalg.norm(qpos[:, 3:7], axis=1, keepdims=True)
-    qpos[:40, 3:7] *= 1.0 + rng.normal(0, 1e-3, (40, 1))               # not exactly unit: the inverse and the frame change both normalise
     act = rng.normal(0, 0.5, (n, 80))
-    w = act[:, 77:80]; nw = np.linalg.norm(w, axis=1, keepdims=True)
-    act[:, 77:80] = w / nw * np.maximum(nw, 0.5)                          # acos(w) of a near-identity rotation is fp32 noise in the reference too
+    act[:100, 77:80] *= 10.0 ** rng.uniform(-3, -1, (100, 1))             # slow turns: the kernel takes sin / angle from |xyz| and atan2, not from 1 - w^2 and acos
     act[-1, 77:80] = 0.0                                                 # the 'small' branch: exactly no rotation
     nxt, qv = kpsim.kin_advance(torch.tensor(qpos, dtype=torch.float32, device="cuda"), torch.tensor(act, dtype=torch.float32, device="cuda"), dt)
     torch.cuda.synchronize()
     q32 = torch.tensor(qpos, dtype=torch.float32).double().numpy(); a32 = torch.tensor(act, dtype=torch.float32).double().numpy()
     want = np.stack([O.step_ar(q32[i], a32[i], dt) for i in range(n)])
     want[:, 3:7] /= np.linalg.norm(want[:, 3:7], axis=1, keepdims=True)
-    wantv = get_qvel_fd_batch(torch.tensor(q32), torch.tensor(want), dt).numpy()
+    # the reference holds unit quaternions to 1e-16; the fp32 rows are unit to 3e-8, which is enough to push w of a 1e-4 rad turn past 1 in ITS formula
+    # (clamped: zero velocity).  Give the fp64 evaluation the renormalised rows.
+    q32n = q32.copy(); q32n[:, 3:7] /= np.linalg.norm(q32n[:, 3:7], axis=1, keepdims=True)
+    wantv = get_qvel_fd_batch(torch.tensor(q32n), torch.tensor(want), dt).numpy()
     assert np.abs(nxt.cpu().numpy() - want).max() < 2e-6
     got = qv.cpu().numpy()
     assert np.abs(got[:, :3] - wantv[:, :3]).max() < 1e-4 and np.abs(got[:, 6:] - wantv[:, 6:]).max() < 1e-4
-    assert np.abs(got[:-1, 3:6] - wantv[:-1, 3:6]).max() < 2e-3         # rotation vector / dt through acos in fp32
+    assert np.abs(got[:-1, 3:6] - wantv[:-1, 3:6]).max() < 3e-5         # rotation vector / dt: 1e-7 of the quaternion product x 2 / dt
     assert np.all(got[-1, 3:6] == 0.0)
     # in-place record layout of the roll-out: outputs are rows of time-major buffers
     Q = torch.zeros((2, n, 76), device="cuda"); V = torch.zeros((2, n, 75), device="cuda")
