@@ -263,13 +263,13 @@ def test_every_substep_agrees_with_the_oracle_from_a_common_state(mode, n, nsub)
     """tools/substep_parity.py: the randomised scenes of the trajectory sweeps, but both sides restart from the oracle's fp32-rounded state at EVERY
     substep, so the error is one substep's arithmetic and not what the scene makes of it (this is the test that exposed the floor - cylinder
     cancellation).  Bound: 1e-5 in qpos / object pose per substep wherever the two sides hold the same contacts; contact sets may differ only on
-    the knife edge dist == margin, in at most 0.5 % of the substeps."""
+    the knife edges (dist == margin; two hull vertices level to 1e-7), in at most 0.5 % of the substeps."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import substep_parity
     R = substep_parity.run(mode, n, None, nsub)
     err = np.maximum(R["eq"], R["eo"])
-    same = ~R["differ"]
-    assert R["differ"].mean() <= 0.005, int(R["differ"].sum())
+    same = ~R["differ"] & ~R["vertex"]
+    assert (~same).mean() <= 0.005, int((~same).sum())
     assert err[same].max() < 1e-5, (err[same].max(), np.unravel_index(np.argmax(np.where(same, err, 0)), err.shape))
     assert np.median(err) < 5e-7 and R["ev"][same].max() < 1e-3
     assert R["ncon"].max() >= 10                     # the sweep does reach the many-contact states

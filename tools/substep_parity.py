@@ -3,7 +3,7 @@ which mixes what the arithmetic disagrees on with how fast the scene amplifies i
 substep, both sides start from the same fp32-rounded state (humanoid and objects, positions and velocities) and advance ONE substep: the error is the
 disagreement of one substep's arithmetic, and the contact sets are compared at the same state.
 
-    python tools/substep_parity.py floor|objects [n_scenes=64] [seed] [substeps=45]"""
+    python tools/substep_parity.py floor|objects|bench:tracked|bench:random_init|bench:objects [n_scenes=64] [seed] [substeps=45]"""
 import os
 import sys
 
@@ -22,11 +22,52 @@ LS_EXACT = bool(int(os.environ.get("KP_ORACLE_LS_EXACT", "0")))     # 1: the ora
 DUMP = tuple(int(x) for x in os.environ["KP_DUMP"].split(",")) if "KP_DUMP" in os.environ else None
 
 
+def bench_states(workload, n, seed):
+    """States of bench.py's own workloads ('tracked', 'random_init', 'objects'): the engine of that workload is built and stepped as the bench does
+    (warm-up + 25 env-steps), then n envs' states after the last step, with that step's UHC action and target, become the scenes."""
+    import bench
+    rec, env, policy, sampler, std = bench.run_workload(workload, 0, 4 if seed is None else seed, 64, 24, 5)
+    keep = {}
+    orig = env.step
+
+    def recording_step(*a, **k):
+        out = orig(*a, **k); keep["info"] = out[3]; return out
+    env.step = recording_step
+    a_track = bench.tracking_action(env) if workload == "tracked" else None
+    if workload == "tracked":
+        sampler.start(); bench.stagger_episodes(env, sampler, 4, False)
+        bench.rollout_steps(sampler, 10, a_track, False, False)
+    else:
+        bench.rollout_steps(sampler, 1, None, False, workload == "objects")
+    sim = env.sim
+    pick = np.linspace(0, env.n - 1, n).astype(int)
+    g = lambda k: sim.get(k).double().cpu().numpy()[pick]  # noqa: E731
+    qpos, qvel, target = g("qpos"), g("qvel"), g("target_qpos")
+    action = keep["info"]["cc_action"].double().cpu().numpy()[pick]
+    blk = np.zeros((n, 35)); bv = np.zeros((n, 30))
+    for i in range(5):
+        blk[:, 7 * i: 7 * i + 3] = [(i + 1) * 100, 100, 0]
+    objects = [{} for _ in range(n)]
+    if workload == "objects":
+        blk, bv = g("obj_qpos"), g("obj_qvel")
+        for e in range(n):
+            for oi in range(5):
+                if abs(blk[e, 7 * oi]) < 50 and abs(blk[e, 7 * oi + 1]) < 50:            # not parked (convert_obj_qpos parks the inactive ones 100+ m away)
+                    objects[e][oi] = blk[e, 7 * oi: 7 * oi + 7].copy()
+            objects[e] = dict(list(objects[e].items())[:2])
+    del env, sampler, policy
+    torch.cuda.empty_cache()
+    return dict(qpos=qpos, qvel=qvel, action=action, target=target, kind=np.zeros(n, int), objects=objects, blk=blk, bv=bv)
+
+
 def run(mode="floor", n=64, seed=None, nsub=45):
     """-> dict(eq, ev, eo [nsub, n], differ [nsub, n] bool, ncon, scenes)"""
     seed = (2024 if mode == "floor" else 0) if seed is None else seed
-    obj = mode == "objects"
-    S = _scenes.object_scenes(n, seed) if obj else _scenes.floor_scenes(n, seed)
+    obj = mode != "floor"
+    if mode.startswith("bench:"):
+        S = bench_states(mode.split(":")[1], n, seed)
+    else:
+        S = _scenes.object_scenes(n, seed) if obj else _scenes.floor_scenes(n, seed)
     kpm = read_kpm(STEP_KPM) if obj else None
     r32 = _scenes.r32
     dev = lambda x: torch.tensor(np.ascontiguousarray(x), dtype=torch.float32, device="cuda")  # noqa: E731
@@ -34,17 +75,19 @@ def run(mode="floor", n=64, seed=None, nsub=45):
     sim.record_contacts()
     if obj:
         sim.set_objects(dev(S["blk"]))
+        if "bv" in S:
+            sim.set_obj_state(dev(S["blk"]), dev(S["bv"]))
     sim.set_state(dev(S["qpos"]), dev(S["qvel"])); sim.set_target(dev(S["target"]))
     a_t = dev(S["action"])
     oracles = []
     for e in range(n):
         o = OracleSim(kpm=STEP_KPM, ls_exact=LS_EXACT) if obj else OracleSim(ls_exact=LS_EXACT)
         for slot, oi in enumerate(sorted(S["objects"][e])):
-            o.set_object(slot, kpm, oi, S["objects"][e][oi])
+            o.set_object(slot, kpm, oi, S["objects"][e][oi], S["bv"][e, 6 * oi: 6 * oi + 6] if "bv" in S else None)
         o.reset(S["qpos"][e], S["qvel"][e])
         oracles.append(o)
     eq = np.zeros((nsub, n)); ev = np.zeros((nsub, n)); eo = np.zeros((nsub, n)); differ = np.zeros((nsub, n), bool); ncon = np.zeros((nsub, n), int)
-    nit_o = np.zeros((nsub, n), int); nit_h = np.zeros((nsub, n), int)
+    nit_o = np.zeros((nsub, n), int); nit_h = np.zeros((nsub, n), int); vertex = np.zeros((nsub, n), bool)
     for k in range(nsub):
         q = np.stack([r32(o.get("qpos")) for o in oracles]); v = np.stack([r32(o.get("qvel")) for o in oracles])
         if obj:
@@ -73,14 +116,26 @@ def run(mode="floor", n=64, seed=None, nsub=45):
             wv = o.get("qvel"); nit_o[k, e] = o.niter
             eq[k, e] = np.abs(o.get("qpos") - hq[e]).max(); ev[k, e] = np.abs(wv - hv[e]).max() / max(1.0, np.abs(wv).max())
             if obj:
-                eo[k, e] = max(np.abs(o.get_object(slot)[0] - hob[e, 7 * oi: 7 * oi + 7]).max() for slot, oi in enumerate(sorted(S["objects"][e])))
+                eo[k, e] = max(np.abs(o.get_object(slot)[0] - hob[e, 7 * oi: 7 * oi + 7]).max() for slot, oi in enumerate(sorted(S["objects"][e]))) if S["objects"][e] else 0.0
             if obj:
                 c = o.contacts_full()
                 so, sh = sorted(zip(c["body"].tolist(), c["b2"].tolist())), sorted(zip(hc[e]["body"].tolist(), hc[e]["b2"].tolist()))
+                cb, cp, hk = list(zip(c["body"].tolist(), c["b2"].tolist())), c["pos"], list(zip(hc[e]["body"].tolist(), hc[e]["b2"].tolist()))
             else:
-                so, sh = sorted(o.contacts()[0].tolist()), sorted(hc[e]["body"].tolist())
+                ob, op, _ = o.contacts()
+                so, sh = sorted(ob.tolist()), sorted(hc[e]["body"].tolist())
+                cb, cp, hk = ob.tolist(), op, hc[e]["body"].tolist()
             differ[k, e] = so != sh; ncon[k, e] = len(so)
-    return dict(eq=eq, ev=ev, eo=eo, differ=differ, ncon=ncon, scenes=S, seed=seed, nit_o=nit_o, nit_h=nit_h)
+            if so == sh and len(so):
+                # the same entities on both sides: are they the same POINTS?  (two hull vertices level to 1e-8 -- a flat sole -- are one contact with two
+                # possible positions centimetres apart; which one is "the support vertex" is decided by the last bit of the kinematics)
+                used = set()
+                for i in range(len(cb)):
+                    cand = [j for j in range(len(hk)) if j not in used and hk[j] == cb[i]]
+                    j = min(cand, key=lambda jj: np.abs(hc[e]["pos"][jj] - cp[i]).max()); used.add(j)
+                    if np.abs(hc[e]["pos"][j] - cp[i]).max() > 1e-4:
+                        vertex[k, e] = True
+    return dict(eq=eq, ev=ev, eo=eo, differ=differ, ncon=ncon, scenes=S, seed=seed, nit_o=nit_o, nit_h=nit_h, vertex=vertex)
 
 
 if __name__ == "__main__":
@@ -91,13 +146,15 @@ if __name__ == "__main__":
     R = run(mode, n, seed, nsub)
     eq, ev, eo, differ, ncon, S, seed = (R[k] for k in ("eq", "ev", "eo", "differ", "ncon", "scenes", "seed"))
     err = np.maximum(eq, eo)
-    same = ~differ
+    vertex = R["vertex"]
+    same = ~differ & ~vertex
     print(f"{mode}{' [oracle with the exact line search]' if LS_EXACT else ''}: {n} scenes (seed {seed}) x {nsub} substeps, every substep from a common fp32-rounded state: one-substep |dqpos| median {np.median(err):.1e} p99 {np.quantile(err, .99):.1e} "
           f"max {err.max():.1e}; rel |dqvel| max {ev.max():.1e}; contacts mean {ncon.mean():.1f} max {ncon.max()}")
     print(f"   substeps whose contact sets differ between the two sides at the same state: {int(differ.sum())} of {differ.size}"
           + (f" (their one-substep |dqpos| max {err[differ].max():.1e})" if differ.any() else "")
-          + f"; with equal contact sets: max |dqpos| {err[same].max():.1e}, above 1e-6: {int((err[same] > 1e-6).sum())}, above 1e-5: {int((err[same] > 1e-5).sum())}")
+          + f"; same entities but another vertex of a hull at the same height (to 1e-7): {int(vertex.sum())}" + (f" (|dqpos| max {err[vertex].max():.1e})" if vertex.any() else "")
+          + f"; with the same contact points: max |dqpos| {err[same].max():.1e}, above 1e-6: {int((err[same] > 1e-6).sum())}, above 1e-5: {int((err[same] > 1e-5).sum())}")
     order = np.dstack(np.unravel_index(np.argsort(-err, axis=None)[:6], err.shape))[0]
     for k, e in order:
         print(f"   substep {k:2d} scene {e:3d} (kind {S['kind'][e]}, objects {sorted(S['objects'][e])}): |dqpos| {eq[k, e]:.1e} object {eo[k, e]:.1e} rel |dqvel| {ev[k, e]:.1e} contacts {ncon[k, e]} Newton iterations oracle {R['nit_o'][k, e]} hip {R['nit_h'][k, e]}"
-              f"{'  contact sets differ' if differ[k, e] else ''}")
+              f"{'  contact sets differ' if differ[k, e] else ('  another vertex at the same height' if vertex[k, e] else '')}")
