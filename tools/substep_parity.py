@@ -21,6 +21,8 @@ LS_EXACT = bool(int(os.environ.get("KP_ORACLE_LS_EXACT", "0")))     # 1: the ora
 
 DUMP = tuple(int(x) for x in os.environ["KP_DUMP"].split(",")) if "KP_DUMP" in os.environ else None
 
+MARGIN = 0.001        # geom margin of the compiled models (the blob's `opt`)
+
 
 def bench_states(workload, n, seed):
     """States of bench.py's own workloads ('tracked', 'random_init', 'objects'): the engine of that workload is built and stepped as the bench does
@@ -87,7 +89,7 @@ def run(mode="floor", n=64, seed=None, nsub=45):
         o.reset(S["qpos"][e], S["qvel"][e])
         oracles.append(o)
     eq = np.zeros((nsub, n)); ev = np.zeros((nsub, n)); eo = np.zeros((nsub, n)); differ = np.zeros((nsub, n), bool); ncon = np.zeros((nsub, n), int)
-    nit_o = np.zeros((nsub, n), int); nit_h = np.zeros((nsub, n), int); vertex = np.zeros((nsub, n), bool)
+    nit_o = np.zeros((nsub, n), int); nit_h = np.zeros((nsub, n), int); vertex = np.zeros((nsub, n), bool); edge = np.full((nsub, n), np.nan)
     for k in range(nsub):
         q = np.stack([r32(o.get("qpos")) for o in oracles]); v = np.stack([r32(o.get("qvel")) for o in oracles])
         if obj:
@@ -126,6 +128,13 @@ def run(mode="floor", n=64, seed=None, nsub=45):
                 so, sh = sorted(ob.tolist()), sorted(hc[e]["body"].tolist())
                 cb, cp, hk = ob.tolist(), op, hc[e]["body"].tolist()
             differ[k, e] = so != sh; ncon[k, e] = len(so)
+            if so != sh:
+                # how far from a rule's threshold is the contact only one side has?  Its distance against the margin; when it is not there, the contact
+                # is one of mjc_PlaneConvex's neighbour vertices and the threshold is the 0.3 rbound separation from the first contact
+                od = (c["dist"] if obj else o.contacts()[2]); ol = (cb if obj else ob.tolist())
+                only_o = [od[i] for i, key in enumerate(ol) if ol[:i + 1].count(key) > hk.count(key)]
+                only_h = [hc[e]["dist"][j] for j, key in enumerate(hk) if hk[:j + 1].count(key) > ol.count(key)]
+                edge[k, e] = min([abs(d - MARGIN) for d in only_o + only_h] or [np.nan])
             if so == sh and len(so):
                 # the same entities on both sides: are they the same POINTS?  (two hull vertices level to 1e-8 -- a flat sole -- are one contact with two
                 # possible positions centimetres apart; which one is "the support vertex" is decided by the last bit of the kinematics)
@@ -135,7 +144,7 @@ def run(mode="floor", n=64, seed=None, nsub=45):
                     j = min(cand, key=lambda jj: np.abs(hc[e]["pos"][jj] - cp[i]).max()); used.add(j)
                     if np.abs(hc[e]["pos"][j] - cp[i]).max() > 1e-4:
                         vertex[k, e] = True
-    return dict(eq=eq, ev=ev, eo=eo, differ=differ, ncon=ncon, scenes=S, seed=seed, nit_o=nit_o, nit_h=nit_h, vertex=vertex)
+    return dict(eq=eq, ev=ev, eo=eo, differ=differ, ncon=ncon, scenes=S, seed=seed, nit_o=nit_o, nit_h=nit_h, vertex=vertex, edge=edge)
 
 
 if __name__ == "__main__":
@@ -152,6 +161,7 @@ if __name__ == "__main__":
           f"max {err.max():.1e}; rel |dqvel| max {ev.max():.1e}; contacts mean {ncon.mean():.1f} max {ncon.max()}")
     print(f"   substeps whose contact sets differ between the two sides at the same state: {int(differ.sum())} of {differ.size}"
           + (f" (their one-substep |dqpos| max {err[differ].max():.1e})" if differ.any() else "")
+          + (f"; the one-sided contact's |dist - margin|: max {np.nanmax(R['edge']):.1e}" if differ.any() else "")
           + f"; same entities but another vertex of a hull at the same height (to 1e-7): {int(vertex.sum())}" + (f" (|dqpos| max {err[vertex].max():.1e})" if vertex.any() else "")
           + f"; with the same contact points: max |dqpos| {err[same].max():.1e}, above 1e-6: {int((err[same] > 1e-6).sum())}, above 1e-5: {int((err[same] > 1e-5).sum())}")
     order = np.dstack(np.unravel_index(np.argsort(-err, axis=None)[:6], err.shape))[0]
