@@ -12,7 +12,7 @@ for s in 0 1 2; do python tools/obj_fuzz.py 64 3 $s; done > $E/obj_fuzz.log 2>&1
 for s in 3 4 5 6 7 8; do python tools/obj_fuzz.py 64 3 $s; done 2>&1 | grep "scenes x" > $E/obj_fuzz_seeds3to8.log
 ( python tools/obj_fuzz_trace.py 2 59; python tools/obj_fuzz_trace.py 2 40 ) > $E/obj_fuzz_trace.log 2>&1      # the one scene left above 1e-4: growth of rounding, every substep agrees from a common state
 ( python tools/substep_parity.py floor 640; for s in 0 1 2 3 4 5 6 7 8; do python tools/substep_parity.py objects 64 $s; done ) 2>&1 | grep -v amdgpu.ids > $E/substep_parity.log
-( python tools/substep_parity.py bench:tracked 512; python tools/substep_parity.py bench:random_init 512; python tools/substep_parity.py bench:objects 256 ) 2>&1 | grep -v amdgpu.ids > $E/substep_parity_bench.log
+( python tools/substep_parity.py bench:tracked 2048; python tools/substep_parity.py bench:random_init 2048; python tools/substep_parity.py bench:objects 1024 ) 2>&1 | grep -v amdgpu.ids > $E/substep_parity_bench.log
 python tools/obs_reward_errors.py 2>&1 | grep -v amdgpu.ids > $E/obs_reward_errors.log
 for s in 0 2; do KP_PLANEMESH=4,0.001 python tools/obj_fuzz.py 64 3 $s; done > $E/obj_fuzz_round2_rule.log 2>&1
 for s in 0 1; do python tools/contact_compare.py 64 $s; done > $E/contact_compare.log 2>&1

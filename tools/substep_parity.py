@@ -22,6 +22,8 @@ LS_EXACT = bool(int(os.environ.get("KP_ORACLE_LS_EXACT", "0")))     # 1: the ora
 DUMP = tuple(int(x) for x in os.environ["KP_DUMP"].split(",")) if "KP_DUMP" in os.environ else None
 
 MARGIN = 0.001        # geom margin of the compiled models (the blob's `opt`)
+_K = read_kpm(STEP_KPM)
+RBOUND, PM_TOL = _K["mesh_rbound"], float(_K["planemesh"][1])
 
 
 def bench_states(workload, n, seed):
@@ -89,7 +91,7 @@ def run(mode="floor", n=64, seed=None, nsub=45):
         o.reset(S["qpos"][e], S["qvel"][e])
         oracles.append(o)
     eq = np.zeros((nsub, n)); ev = np.zeros((nsub, n)); eo = np.zeros((nsub, n)); differ = np.zeros((nsub, n), bool); ncon = np.zeros((nsub, n), int)
-    nit_o = np.zeros((nsub, n), int); nit_h = np.zeros((nsub, n), int); vertex = np.zeros((nsub, n), bool); edge = np.full((nsub, n), np.nan)
+    nit_o = np.zeros((nsub, n), int); nit_h = np.zeros((nsub, n), int); vertex = np.zeros((nsub, n), bool); klass = np.full((nsub, n), "", dtype=object)
     for k in range(nsub):
         q = np.stack([r32(o.get("qpos")) for o in oracles]); v = np.stack([r32(o.get("qvel")) for o in oracles])
         if obj:
@@ -129,12 +131,30 @@ def run(mode="floor", n=64, seed=None, nsub=45):
                 cb, cp, hk = ob.tolist(), op, hc[e]["body"].tolist()
             differ[k, e] = so != sh; ncon[k, e] = len(so)
             if so != sh:
-                # how far from a rule's threshold is the contact only one side has?  Its distance against the margin; when it is not there, the contact
-                # is one of mjc_PlaneConvex's neighbour vertices and the threshold is the 0.3 rbound separation from the first contact
+                # which rule's threshold does the difference sit on?  'margin': a one-sided contact within 1e-6 of dist == margin; 'support': the hull's first
+                # contact (mjc_PlaneConvex's support vertex) is another vertex at the same height, which also changes the neighbours that follow it;
+                # 'separation': a one-sided neighbour vertex within 1e-5 of the tolplanemesh x rbound distance from the first contact; 'other': none of these
                 od = (c["dist"] if obj else o.contacts()[2]); ol = (cb if obj else ob.tolist())
-                only_o = [od[i] for i, key in enumerate(ol) if ol[:i + 1].count(key) > hk.count(key)]
-                only_h = [hc[e]["dist"][j] for j, key in enumerate(hk) if hk[:j + 1].count(key) > ol.count(key)]
-                edge[k, e] = min([abs(d - MARGIN) for d in only_o + only_h] or [np.nan])
+                hd, hp = hc[e]["dist"], hc[e]["pos"]
+                kinds = set()
+                for key in set(ol) | set(hk):
+                    O = [(od[i], cp[i]) for i in range(len(ol)) if ol[i] == key]; H = [(hd[j], hp[j]) for j in range(len(hk)) if hk[j] == key]
+                    if len(O) == len(H):
+                        continue
+                    floor_pair = (not obj) or key[1] == -1
+                    body = key[0] if obj else key
+                    if floor_pair and body < 24 and O and H and np.abs(O[0][1] - H[0][1]).max() > 1e-4 and abs(O[0][0] - H[0][0]) < 1e-6:
+                        kinds.add("support"); continue
+                    long_, short_ = (O, H) if len(O) > len(H) else (H, O)
+                    lone = [x for x in long_ if not any(np.abs(x[1] - y[1]).max() < 1e-4 for y in short_)] or long_[len(short_):]
+                    for d, pp in lone:
+                        if abs(d - MARGIN) < 1e-6:
+                            kinds.add("margin")
+                        elif floor_pair and body < 24 and long_ and abs(np.linalg.norm(np.array([pp[0], pp[1], d]) - long_[0][1]) - PM_TOL * RBOUND[body]) < 1e-5:
+                            kinds.add("separation")
+                        else:
+                            kinds.add("other")
+                klass[k, e] = "+".join(sorted(kinds)) or "other"
             if so == sh and len(so):
                 # the same entities on both sides: are they the same POINTS?  (two hull vertices level to 1e-8 -- a flat sole -- are one contact with two
                 # possible positions centimetres apart; which one is "the support vertex" is decided by the last bit of the kinematics)
@@ -144,7 +164,7 @@ def run(mode="floor", n=64, seed=None, nsub=45):
                     j = min(cand, key=lambda jj: np.abs(hc[e]["pos"][jj] - cp[i]).max()); used.add(j)
                     if np.abs(hc[e]["pos"][j] - cp[i]).max() > 1e-4:
                         vertex[k, e] = True
-    return dict(eq=eq, ev=ev, eo=eo, differ=differ, ncon=ncon, scenes=S, seed=seed, nit_o=nit_o, nit_h=nit_h, vertex=vertex, edge=edge)
+    return dict(eq=eq, ev=ev, eo=eo, differ=differ, ncon=ncon, scenes=S, seed=seed, nit_o=nit_o, nit_h=nit_h, vertex=vertex, klass=klass)
 
 
 if __name__ == "__main__":
@@ -161,7 +181,7 @@ if __name__ == "__main__":
           f"max {err.max():.1e}; rel |dqvel| max {ev.max():.1e}; contacts mean {ncon.mean():.1f} max {ncon.max()}")
     print(f"   substeps whose contact sets differ between the two sides at the same state: {int(differ.sum())} of {differ.size}"
           + (f" (their one-substep |dqpos| max {err[differ].max():.1e})" if differ.any() else "")
-          + (f"; the one-sided contact's |dist - margin|: max {np.nanmax(R['edge']):.1e}" if differ.any() else "")
+          + (" [" + ", ".join(f"{nm}: {int((R['klass'] == nm).sum())}" for nm in sorted(set(R['klass'][differ].tolist()))) + "]" if differ.any() else "")
           + f"; same entities but another vertex of a hull at the same height (to 1e-7): {int(vertex.sum())}" + (f" (|dqpos| max {err[vertex].max():.1e})" if vertex.any() else "")
           + f"; with the same contact points: max |dqpos| {err[same].max():.1e}, above 1e-6: {int((err[same] > 1e-6).sum())}, above 1e-5: {int((err[same] > 1e-5).sum())}")
     order = np.dstack(np.unravel_index(np.argsort(-err, axis=None)[:6], err.shape))[0]
