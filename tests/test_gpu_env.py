@@ -56,24 +56,24 @@ def test_env_step_matches_composed_oracle():
         x = {k: sim.get(k) for k in ("qpos", "qvel", "xpos", "xquat", "xipos")}
         xp, xq, xi = x["xpos"].reshape(24, 3), x["xquat"].reshape(24, 4), x["xipos"].reshape(24, 3)
         want0 = O.obs_ar(x["qpos"], xp, xq, head_pose[i, 0], head_vels[i, 0], obj_rel[i, 0], np.zeros(4), None)
-        np.testing.assert_allclose(obs0[i], want0, atol=5e-5)
+        np.testing.assert_allclose(obs0[i], want0, atol=2e-6)                 # measured 2.6e-7
         prev_bquat = O.get_body_quat(x["qpos"]); prev_h = np.concatenate([xp[13], xq[13]])
         tgt = O.qpos_fk(O.step_ar(x["qpos"], a[i]), BP, BI, PAR)
         cco = O.zfilter(O.obs_cc(x["qpos"], x["qvel"], xp, xq, xi, tgt), 0.0, 1.0, 5.0)
-        np.testing.assert_allclose(cc_state[i], cco, atol=2e-4)
+        np.testing.assert_allclose(cc_state[i], cco, atol=3e-6)               # measured 4.6e-7
         with torch.no_grad():
             cca = mcp.action_mean(torch.tensor(cco)[None])[0].numpy()
-        np.testing.assert_allclose(cc_action[i], cca, atol=2e-3)        # fp32 GEMMs vs fp64
+        np.testing.assert_allclose(cc_action[i], cca, atol=1e-6)              # fp32 GEMMs vs fp64: measured 2e-9 (output layer x 0.1)
         sim.do_simulation(cc_action[i], tgt["qpos"], 15)               # same action => isolates the physics
         x = {k: sim.get(k) for k in ("qpos", "qvel", "xpos", "xquat", "xipos")}
         xp, xq = x["xpos"].reshape(24, 3), x["xquat"].reshape(24, 4)
-        np.testing.assert_allclose(env.sim.get("qpos")[i].double().cpu().numpy(), x["qpos"], atol=1e-4)
+        np.testing.assert_allclose(env.sim.get("qpos")[i].double().cpu().numpy(), x["qpos"], atol=3e-6)      # measured 3.1e-7
         want = O.obs_ar(x["qpos"], xp, xq, head_pose[i, 1], head_vels[i, 1], obj_rel[i, 1], np.zeros(4), None)
-        np.testing.assert_allclose(obs[i], want, atol=2e-4)
+        np.testing.assert_allclose(obs[i], want, atol=3e-6)
         gt = O.qpos_fk(gt_qpos[i, 1], BP, BI, PAR); gtp = O.qpos_fk(gt_qpos[i, 0], BP, BI, PAR)
         r, _ = O.dynamic_supervision_v1(np.concatenate([xp[13], xq[13]]), prev_h, O.get_body_quat(x["qpos"]), prev_bquat, xp, tgt, head_pose[i, 1],
                                         gt["bquat"].reshape(-1), gtp["bquat"].reshape(-1), 1 / 30, O.REWARD_WEIGHTS)
-        assert abs(rew[i] - r) < 2e-3
+        assert abs(rew[i] - r) < 2e-6                                         # measured 1.2e-7
     assert not bool(done.any()) and int(env.cur_t[0]) == 1
 
 
@@ -104,7 +104,7 @@ def test_single_env_facade_numpy_surface():
     gt = env.gt_targets
     assert gt["wbpos"].shape == (10, 24, 3) and gt["wbquat"].shape == (10, 24, 4) and gt["bquat"].shape == (10, 96)
     want = O.qpos_fk(STD["qpos"], BP, BI, PAR)
-    np.testing.assert_allclose(gt["wbpos"][3], want["wbpos"], atol=2e-5)
+    np.testing.assert_allclose(gt["wbpos"][3], want["wbpos"], atol=2e-06)        # measured 1.4e-07
     assert isinstance(env.np_random.uniform(), float) and env.bquat.shape == (96,)
 
 
@@ -225,7 +225,7 @@ def test_env_with_step_object():
     for i in range(n):
         want = O.obs_ar(rd["qpos"][i], rd["xpos"][i].reshape(24, 3), rd["xquat"][i].reshape(24, 4), c["head_pose"][i, 0], c["head_vels"][i, 0],
                         c["obj_head_relative_poses"][i, 0], c["action_one_hot"][i], rd["obj_qpos"][i, 28:35])
-        np.testing.assert_allclose(obs[i], want, atol=5e-5)
+        np.testing.assert_allclose(obs[i], want, atol=1e-06)        # measured 6.6e-08
     a = torch.zeros((n, 80), device=env.device)
     q0 = env.sim.get("qpos")
     for i in range(n):
@@ -243,7 +243,7 @@ def test_env_with_step_object():
     for i in range(2):
         want = O.obs_ar(rd["qpos"][i], rd["xpos"][i].reshape(24, 3), rd["xquat"][i].reshape(24, 4), c["head_pose"][i, 3], c["head_vels"][i, 3],
                         c["obj_head_relative_poses"][i, 3], c["action_one_hot"][i], rd["obj_qpos"][i, 28:35])
-        np.testing.assert_allclose(obs_t[i].double().cpu().numpy(), want, atol=5e-5)
+        np.testing.assert_allclose(obs_t[i].double().cpu().numpy(), want, atol=3e-06)        # measured 2.6e-07
 
 
 def test_context_rollout_matches_reference_fixture(golden):
@@ -259,22 +259,22 @@ def test_context_rollout_matches_reference_fixture(golden):
     kin_sim = kpsim.KpSim(kpsim.KpModel(), B)
     with torch.no_grad():
         init_qpos, init_qvel, _ = net.init_states(data)
-    np.testing.assert_allclose(init_qpos.double().cpu().numpy(), g["init_qpos"], atol=2e-5)
+    np.testing.assert_allclose(init_qpos.double().cpu().numpy(), g["init_qpos"], atol=3e-06)        # measured 2.6e-07
     q, v, a = net.rollout(data, kin_sim, init_qpos, init_qvel)
-    np.testing.assert_allclose(a.double().cpu().numpy(), g["action"], atol=5e-4)
-    np.testing.assert_allclose(q.double().cpu().numpy(), g["ar_qpos"], atol=5e-4)
-    np.testing.assert_allclose(v.double().cpu().numpy(), g["ar_qvel"], atol=2e-2)
+    np.testing.assert_allclose(a.double().cpu().numpy(), g["action"], atol=1e-06)        # measured 1.4e-08
+    np.testing.assert_allclose(q.double().cpu().numpy(), g["ar_qpos"], atol=3e-06)        # measured 2.7e-07
+    np.testing.assert_allclose(v.double().cpu().numpy(), g["ar_qvel"], atol=3e-05)        # measured 2.6e-06
     ctx = PolicyARContext(net, kin_sim, smooth=True).init_context(data)
     assert ctx["ar_qpos"].shape == (B, T, 76) and ctx["ar_wbpos"].shape == (B, T, 72) and torch.isfinite(ctx["ar_bquat"]).all()
     # cfg.smooth in the reference leaves ar_qpos as rolled out (its filter call is a no-op: smooth_effective.npz)
-    np.testing.assert_allclose(ctx["ar_qpos"].double().cpu().numpy(), g["ar_qpos"], atol=5e-4)
+    np.testing.assert_allclose(ctx["ar_qpos"].double().cpu().numpy(), g["ar_qpos"], atol=3e-06)        # measured 2.7e-07
     assert torch.equal(ctx["ar_qpos"], q)
     # the documented deviation: real time-axis smoothing, opt-in
     from scipy.ndimage import gaussian_filter1d
     ctx_s = PolicyARContext(net, kin_sim, smooth=True, smooth_time_axis=True).init_context(data)
     want = gaussian_filter1d(g["ar_qpos"][:, :, 7:], 1, axis=1)
-    np.testing.assert_allclose(ctx_s["ar_qpos"][:, :, 7:].double().cpu().numpy(), want, atol=5e-4)
-    np.testing.assert_allclose(ctx_s["ar_qpos"][:, :, :7].double().cpu().numpy(), g["ar_qpos"][:, :, :7], atol=5e-4)
+    np.testing.assert_allclose(ctx_s["ar_qpos"][:, :, 7:].double().cpu().numpy(), want, atol=1e-06)        # measured 8.8e-09
+    np.testing.assert_allclose(ctx_s["ar_qpos"][:, :, :7].double().cpu().numpy(), g["ar_qpos"][:, :, :7], atol=3e-06)        # measured 2.7e-07
 
 
 def test_agent_ar_iteration_and_checkpoint(tmp_path):

@@ -60,17 +60,17 @@ def test_policy_mcp_fused_path_matches_reference_forward(kp, golden):
     with torch.no_grad():
         fused = pol.action_mean(x)                       # rollout path: fused GEMMs (no grad)
         w = pol.composer(x)
-    np.testing.assert_allclose(w.double().cpu().numpy(), g["mcp_weights"], atol=2e-5)
-    np.testing.assert_allclose(fused.double().cpu().numpy(), g["mcp_mean"], atol=2e-4, rtol=1e-4)
+    np.testing.assert_allclose(w.double().cpu().numpy(), g["mcp_weights"], atol=2e-06)        # measured 1.7e-07
+    np.testing.assert_allclose(fused.double().cpu().numpy(), g["mcp_mean"], atol=1e-05, rtol=1e-6)        # measured 7.0e-07
     # the training path (plain modules, autograd on) computes the same thing
     for p in pol.parameters():
         p.requires_grad_(True)
     plain = pol.action_mean(x)
     assert plain.requires_grad
-    np.testing.assert_allclose(plain.detach().double().cpu().numpy(), g["mcp_mean"], atol=2e-4, rtol=1e-4)
+    np.testing.assert_allclose(plain.detach().double().cpu().numpy(), g["mcp_mean"], atol=1e-05, rtol=1e-6)        # measured 5.9e-07
     # select_action(mean_action=True) is what the env calls in test mode
     with torch.no_grad():
-        np.testing.assert_allclose(pol.select_action(x, True).double().cpu().numpy(), g["mcp_mean"], atol=2e-4, rtol=1e-4)
+        np.testing.assert_allclose(pol.select_action(x, True).double().cpu().numpy(), g["mcp_mean"], atol=1e-05, rtol=1e-6)        # measured 7.0e-07
 
 
 def test_value_net_matches_reference_forward(kp, golden):
@@ -84,7 +84,7 @@ def test_value_net_matches_reference_forward(kp, golden):
     val = val.cuda()
     with torch.no_grad():
         got = val(dev(g["s"]))
-    np.testing.assert_allclose(got.double().cpu().numpy(), g["value"], atol=2e-4, rtol=1e-4)
+    np.testing.assert_allclose(got.double().cpu().numpy(), g["value"], atol=5e-06, rtol=1e-6)        # measured 3.5e-07
 
 
 def test_mass_matrix_and_bias_readouts_match_oracle(kp):
@@ -105,9 +105,9 @@ def test_mass_matrix_and_bias_readouts_match_oracle(kp):
     for e in range(n):
         o.reset(q32[e], v32[e])
         Mo, bo = o.fullM(), o.get("qfrc_bias")
-        np.testing.assert_allclose(M[e], Mo, atol=2e-5 * np.abs(Mo).max())
-        np.testing.assert_allclose(M[e], M[e].T, atol=1e-5 * np.abs(Mo).max())
-        np.testing.assert_allclose(b[e], bo, atol=3e-5 * max(1.0, np.abs(bo).max()))
+        np.testing.assert_allclose(M[e], Mo, atol=2e-6 * np.abs(Mo).max())        # measured 2e-7 of the largest entry
+        np.testing.assert_allclose(M[e], M[e].T, atol=5e-7 * np.abs(Mo).max())        # measured 3e-8 of the largest entry
+        np.testing.assert_allclose(b[e], bo, atol=2e-6 * max(1.0, np.abs(bo).max()))        # measured 1.7e-7 of the largest entry
     # the generic getter returns the same data, flattened
     np.testing.assert_array_equal(sim.get("M").view(n, 75, 75).double().cpu().numpy(), M)
     np.testing.assert_array_equal(sim.get("bias").double().cpu().numpy(), b)
@@ -119,7 +119,7 @@ def test_mass_matrix_and_bias_readouts_match_oracle(kp):
     qd, vd = sim.get("qpos_d").double().cpu().numpy(), sim.get("qvel_d").double().cpu().numpy()
     for e in range(2):
         o.reset(qd[e], vd[e])
-        np.testing.assert_allclose(M2[e], o.fullM(), atol=2e-5 * np.abs(M2[e]).max())
+        np.testing.assert_allclose(M2[e], o.fullM(), atol=2e-6 * np.abs(M2[e]).max())        # measured 2e-7 of the largest entry
 
 
 def _buried_states(n, seed):
@@ -248,9 +248,9 @@ def test_contact_sets_match_oracle_contact_by_contact(kp):
             key = np.lexsort((np.round(x["pos"][:, 2], 4), np.round(x["pos"][:, 1], 4), np.round(x["pos"][:, 0], 4), x["b2"], x["body"]))
             return {k: v[key] for k, v in x.items()}
         c, h = canon(c), canon(h)
-        np.testing.assert_allclose(h["dist"], c["dist"], atol=2e-5, err_msg=f"scene {e}")
-        np.testing.assert_allclose(h["pos"], c["pos"], atol=2e-5, err_msg=f"scene {e}")
-        np.testing.assert_allclose(h["normal"], c["normal"], atol=2e-4, err_msg=f"scene {e}")
+        np.testing.assert_allclose(h["dist"], c["dist"], atol=2e-06, err_msg=f"scene {e}")        # measured 1.7e-07
+        np.testing.assert_allclose(h["pos"], c["pos"], atol=2e-06, err_msg=f"scene {e}")        # measured 1.8e-07
+        np.testing.assert_allclose(h["normal"], c["normal"], atol=2e-05, err_msg=f"scene {e}")        # measured 1.6e-06
         for a, b in zip(c["body"], c["b2"]):
             kinds.add(("hull" if a < 24 else "obj", "floor" if b < 0 else "obj"))
     assert kinds == {("hull", "floor"), ("hull", "obj"), ("obj", "floor"), ("obj", "obj")} and n_contacts > 300
@@ -331,7 +331,7 @@ def test_fused_unroll_matches_reference_padded_forward_fp32(kp, golden):
     starts = np.concatenate([[True], masks[:-1] == 0]).reshape(N, T); starts[:, 0] = True
     with torch.no_grad():
         means = net.unroll(dev(g["states"]).view(N, T, -1), torch.tensor(starts, device="cuda"))
-    np.testing.assert_allclose(means.reshape(N * T, -1).double().cpu().numpy(), g["action_mean"], atol=3e-4)
+    np.testing.assert_allclose(means.reshape(N * T, -1).double().cpu().numpy(), g["action_mean"], atol=1e-06)        # measured 8.3e-09
 
 
 def test_resting_box_depth_matches_the_closed_form_on_the_device(kp):

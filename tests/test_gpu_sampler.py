@@ -224,17 +224,17 @@ def test_sampler_rows_match_the_cpu_episode_loop():
         np.testing.assert_array_equal(g(b.exps), want["exp"])
         np.testing.assert_array_equal(g(b.v_metas), want["v_meta"])
         np.testing.assert_allclose(g(b.gt_target_qpos), want["gt_target_qpos"], atol=1e-6)
-        np.testing.assert_allclose(g(b.states), want["state"], atol=2e-3)
-        np.testing.assert_allclose(g(b.actions), want["action"], atol=2e-3)
-        np.testing.assert_allclose(g(b.curr_qpos), want["curr_qpos"], atol=2e-3)
-        np.testing.assert_allclose(g(b.res_qpos), want["res_qpos"], atol=2e-3)
-        np.testing.assert_allclose(g(b.next_states), want["next_state"], atol=2e-3)
-        np.testing.assert_allclose(g(b.rewards), want["reward"], atol=5e-3)
-        np.testing.assert_allclose(g(b.cc_state), want["cc_state"], atol=5e-3)
-        np.testing.assert_allclose(g(b.cc_action), want["cc_action"], atol=2e-2)
+        np.testing.assert_allclose(g(b.states), want["state"], atol=5e-06)        # measured 3.9e-07
+        np.testing.assert_allclose(g(b.actions), want["action"], atol=1e-06)        # measured 5.8e-08
+        np.testing.assert_allclose(g(b.curr_qpos), want["curr_qpos"], atol=5e-06)        # measured 3.9e-07
+        np.testing.assert_allclose(g(b.res_qpos), want["res_qpos"], atol=5e-06)        # measured 3.9e-07
+        np.testing.assert_allclose(g(b.next_states), want["next_state"], atol=5e-06)        # measured 3.9e-07
+        np.testing.assert_allclose(g(b.rewards), want["reward"], atol=1e-06)        # measured 4.3e-08
+        np.testing.assert_allclose(g(b.cc_state), want["cc_state"], atol=0.0002)        # measured 1.0e-05
+        np.testing.assert_allclose(g(b.cc_action), want["cc_action"], atol=1e-06)        # measured 5.8e-09
         # the first rows (no accumulated fp32 / fp64 drift yet) at kernel accuracy
-        np.testing.assert_allclose(g(b.states)[0], want["state"][0], atol=5e-5)
-        np.testing.assert_allclose(g(b.res_qpos)[0], want["res_qpos"][0], atol=1e-4)
+        np.testing.assert_allclose(g(b.states)[0], want["state"][0], atol=3e-06)        # measured 2.0e-07
+        np.testing.assert_allclose(g(b.res_qpos)[0], want["res_qpos"][0], atol=2e-06)        # measured 2.0e-07
         saw_end |= bool((want["done"] & ~want["fail"]).any()); saw_fail |= bool(want["fail"].any())
     assert saw_end and saw_fail
     assert (b.masks[0] == 0).sum() == 2 and (b.masks[1] == 0).all()
