@@ -51,16 +51,41 @@ def quat_rotate_t(q, v):
     return v + qc[..., :1] * t + torch.cross(u, t, dim=-1)
 
 
+# The reference evaluates sqrt(1 - w^2), acos(w) and 1 - |w| in fp64, where they are harmless.  In fp32 they lose a small rotation's digits (1 - w^2 of a
+# 1e-3 rad turn is 2.5e-7, known to 6e-8), so below fp64 the same quantities are taken from |xyz| of the unit quaternion; in fp64 the reference's own
+# expressions are kept, so that the fixtures generated from it (whose quaternions are unit to 1e-7 only) are met to the last digit.
+def quat_sin_half(q):
+    """sin(angle / 2) >= 0 of a unit quaternion [..., 4]: sqrt(1 - w^2) (fp64) / |xyz| (fp32)."""
+    if q.dtype == torch.float64:
+        return torch.sqrt((1 - q[..., 0] * q[..., 0]).clamp_min(0.0))
+    return q[..., 1:].norm(dim=-1)
+
+
+def quat_acos_w(q):
+    """acos(w) of a unit quaternion [..., 4]: as written (fp64) / atan2(|xyz|, w) (fp32)."""
+    if q.dtype == torch.float64:
+        return torch.acos(q[..., 0].clamp(-1.0, 1.0))
+    return torch.atan2(q[..., 1:].norm(dim=-1), q[..., 0])
+
+
+def quat_small(q, eps=1e-8):
+    """the reference's `1 - |w| < eps` (uhc/khrylib/utils/transformation.py:349): as written (fp64) / |xyz|^2 < eps (1 + |w|) (fp32)."""
+    if q.dtype == torch.float64:
+        return (1 - q[..., 0].abs()) < eps
+    return (q[..., 1:] ** 2).sum(-1) < eps * (1 + q[..., 0].abs())
+
+
 def get_qvel_fd_batch(cur_qpos, next_qpos, dt):
     """kin_poly/utils/torch_utils.py:315-331 (transform=None)."""
     v = (next_qpos[:, :3] - cur_qpos[:, :3]) / dt
     qrel = quat_mul(next_qpos[:, 3:7], quat_inv(cur_qpos[:, 3:7]))
     w = qrel[:, 0].clamp(-1.0, 1.0)
-    s = torch.sqrt((1 - w * w).clamp_min(0.0))                  # sin(acos(w)); rotation_from_quaternion_batch (:109-130)
+    # sin(acos(w)) and 2 acos(w) of rotation_from_quaternion_batch (:109-130)
+    s = quat_sin_half(qrel)
     small = s < 1e-5
     s = s.clamp_min(1e-30)
     axis = torch.where(small[:, None], torch.tensor([1.0, 0.0, 0.0], device=w.device, dtype=w.dtype).expand_as(qrel[:, 1:]), qrel[:, 1:] / s[:, None])
-    angle = torch.where(small, torch.zeros_like(w), 2 * torch.acos(w))
+    angle = torch.where(small, torch.zeros_like(w), 2 * quat_acos_w(qrel))
     angle = torch.where(angle > math.pi, angle - 2 * math.pi, angle)
     angle = torch.where(angle < -math.pi, angle + 2 * math.pi, angle)
     rv = quat_rotate_t(cur_qpos[:, 3:7], axis * angle[:, None] / dt)

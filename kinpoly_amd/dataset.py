@@ -17,7 +17,7 @@ import os
 import numpy as np
 import torch
 
-from .context import heading_q, quat_inv, quat_mul, quat_rotate_t
+from .context import heading_q, quat_acos_w, quat_inv, quat_mul, quat_rotate_t, quat_sin_half, quat_small
 
 ACTIONS = ("sit", "push", "avoid", "step")             # cfg.all_actions order = action_one_hot columns
 TRAIN_KEYS = ("wbpos", "wbquat", "bquat")
@@ -30,9 +30,9 @@ def _fd_vel(cur7, nxt7, dt):
     v = quat_rotate_t(heading_q(cur7[:, 3:7]), (nxt7[:, :3] - cur7[:, :3]) / dt)
     qrel = quat_mul(nxt7[:, 3:7], quat_inv(cur7[:, 3:7]))
     w = qrel[:, 0]
-    small = (1 - w.abs()) < 1e-8
-    s = torch.sqrt((1 - w * w).clamp_min(1e-30))
-    angle = torch.where(small, torch.zeros_like(w), 2 * torch.acos(w.clamp(-1.0, 1.0)))
+    small = quat_small(qrel)                          # 1 - |w| < 1e-8, sqrt(1 - w^2), acos(w): in the forms that keep a slow turn's digits in fp32
+    s = quat_sin_half(qrel).clamp_min(1e-30)
+    angle = torch.where(small, torch.zeros_like(w), 2 * quat_acos_w(qrel))
     axis = torch.where(small[:, None], torch.tensor([1.0, 0.0, 0.0], device=w.device, dtype=w.dtype).expand_as(qrel[:, 1:]), qrel[:, 1:] / s[:, None])
     angle = torch.where(angle > math.pi, angle - 2 * math.pi, angle)
     rv = quat_rotate_t(cur7[:, 3:7], axis * angle[:, None] / dt)

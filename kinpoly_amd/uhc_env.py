@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import sim as kpsim
-from .context import quat_inv, quat_mul, quat_rotate_t
+from .context import quat_acos_w, quat_inv, quat_mul, quat_rotate_t, quat_sin_half, quat_small
 from .env import RunningState
 from .model_compiler import read_kpm
 from .nets import PolicyMCP
@@ -25,10 +25,9 @@ UHC_REWARD_WEIGHTS = dict(w_p=0.3, w_v=0.1, w_e=0.45, w_c=0.1, w_vf=0.05, k_p=2.
 
 def rotation_from_quaternion_t(q):
     """uhc/khrylib/utils/transformation.py:348-356 on [..., 4]: axis * angle, no wrap; exactly 0 when 1 - |w| < 1e-8."""
-    w = q[..., 0]
-    small = (1 - w.abs()) < 1e-8
-    s = torch.sqrt((1 - w * w).clamp_min(1e-30))
-    out = q[..., 1:] / s[..., None] * (2 * torch.acos(w.clamp(-1.0, 1.0)))[..., None]
+    small = quat_small(q)
+    s = quat_sin_half(q).clamp_min(1e-30)
+    out = q[..., 1:] / s[..., None] * (2 * quat_acos_w(q))[..., None]
     return torch.where(small[..., None], torch.zeros_like(out), out)
 
 
@@ -43,9 +42,9 @@ def get_qvel_fd_new_t(cur_qpos, next_qpos, dt):
     v = (next_qpos[..., :3] - cur_qpos[..., :3]) / dt
     qrel = quat_mul(next_qpos[..., 3:7], quat_inv(cur_qpos[..., 3:7]))
     w = qrel[..., 0]
-    small = (1 - w.abs()) < 1e-8
-    s = torch.sqrt((1 - w * w).clamp_min(1e-30))
-    angle = torch.where(small, torch.zeros_like(w), 2 * torch.acos(w.clamp(-1.0, 1.0)))
+    small = quat_small(qrel)
+    s = quat_sin_half(qrel).clamp_min(1e-30)
+    angle = torch.where(small, torch.zeros_like(w), 2 * quat_acos_w(qrel))
     axis = torch.where(small[..., None], torch.tensor([1.0, 0.0, 0.0], device=w.device, dtype=w.dtype).expand_as(qrel[..., 1:]), qrel[..., 1:] / s[..., None])
     angle = torch.where(angle > math.pi, angle - 2 * math.pi, angle)
     rv = quat_rotate_t(cur_qpos[..., 3:7], axis * angle[..., None] / dt)
@@ -90,7 +89,7 @@ def world_rfc_implicit_reward_t(xpos, bquat, prev_bquat, com, action, e_bquat, e
     cur_ee = xpos.view(N, 24, 3)[:, list(EE_BODIES)].reshape(N, 15)
     cur_bangvel = get_angvel_fd_t(prev_bquat, bquat, dt)
     qd = quat_mul(bquat.view(N, 24, 4), quat_inv(e_bquat.view(N, 24, 4)))
-    pose_diff = torch.acos(qd[..., 0].abs().clamp(-1.0, 1.0)) * b_diffw[None]
+    pose_diff = (torch.acos(qd[..., 0].abs().clamp(-1.0, 1.0)) if qd.dtype == torch.float64 else torch.atan2(quat_sin_half(qd), qd[..., 0].abs())) * b_diffw[None]   # acos(|w|)
     pose_r = torch.exp(-ws["k_p"] * (pose_diff ** 2).sum(1))
     vel_r = torch.exp(-ws["k_v"] * ((cur_bangvel - e_bangvel) ** 2).sum(1))
     ee_r = torch.exp(-ws["k_e"] * ((cur_ee - e_ee_wpos) ** 2).sum(1))

@@ -24,8 +24,8 @@ def test_expert_features_match_reference_fixture(golden):
     clip = torch.tensor(g["clip"], dtype=torch.float32)[None].repeat(2, 1, 1)
     env.load_expert(clip)
     ex = env.expert
-    tol = dict(qvel=2e-3, rlinv=2e-4, rlinv_local=2e-4, rangv=2e-3, rq_rmh=2e-6, com=2e-6, body_com=2e-6, head_pose=2e-6, ee_pos=2e-6, ee_wpos=2e-6,
-               bquat=2e-6, bangvel=2e-3, wbpos=2e-6, wbquat=2e-6)      # finite differences divide fp32 round-off by dt = 1/30
+    tol = dict(qvel=5e-4, rlinv=2e-5, rlinv_local=2e-5, rangv=5e-4, rq_rmh=2e-6, com=2e-6, body_com=2e-6, head_pose=2e-6, ee_pos=2e-6, ee_wpos=2e-6,
+               bquat=2e-6, bangvel=5e-4, wbpos=2e-6, wbquat=2e-6)      # finite differences divide fp32 round-off by dt = 1/30: measured <= 7.5e-5 on values up to 126 (velocities), 1.4e-6 (root linear)
     for k, a in tol.items():
         np.testing.assert_allclose(ex[k][1].double().cpu().numpy(), g["e_" + k], atol=a, rtol=1e-5, err_msg=k)
     assert abs(float(ex["height_lb"][0]) - float(g["e_height_lb"])) < 1e-6
