@@ -10,7 +10,8 @@ import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
+import _scenes  # noqa: E402
 from kinpoly_amd.model_compiler import read_kpm  # noqa: E402
 from kinpoly_amd.sim import STEP_KPM, KpModel, KpSim  # noqa: E402
 from oracle.kpo import OracleSim  # noqa: E402
@@ -19,42 +20,10 @@ seed = int(sys.argv[1]); scene = int(sys.argv[2])
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 nsub = int(sys.argv[4]) if len(sys.argv) > 4 else 45
 kpm = read_kpm(STEP_KPM)
-std = np.load(os.path.join(ROOT, "tests/golden/standing_neutral.npz"))
-rng = np.random.default_rng(seed)
-x0, y0 = std["qpos"][0], std["qpos"][1]
-nominal = {0: [[0.0, -0.45, 0.3805]], 1: [[0.0, 0.55, 0.921], [0.0, 0.55, 0.7905]], 2: [[0.0, 0.45, 0.69]], 3: [[0.0, 0.0, 0.3705]]}
-obj_of_action = {0: [0], 1: [1, 2], 2: [3], 3: [4]}
-
-
-def rquat(scale):
-    ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
-    a = rng.normal() * scale
-    return np.concatenate([[np.cos(a / 2)], np.sin(a / 2) * ax])
-
-
-# the generator of obj_fuzz.py, draw for draw
-blk = np.zeros((n, 35))
-for i in range(5):
-    blk[:, 7 * i: 7 * i + 3] = [(i + 1) * 100, 100, 0]
-qpos = np.tile(std["qpos"], (n, 1)); qvel = rng.normal(size=(n, 75)) * 0.2
-scenes = []
-for e in range(n):
-    a = int(rng.integers(0, 4))
-    objs = {}
-    shift = rng.normal(size=2) * 0.15
-    lift = rng.uniform(0, 0.25) if rng.uniform() < 0.5 else 0.0
-    tilt = rquat(0.25 if rng.uniform() < 0.5 else 0.0)
-    for oi, (lx, ly, lz) in zip(obj_of_action[a], nominal[a]):
-        objs[oi] = [x0 + lx + shift[0], y0 + ly + shift[1], lz + lift + 0.0003, *tilt]
-        blk[e, 7 * oi: 7 * oi + 7] = objs[oi]
-    if a == 3:
-        qpos[e, 2] += 0.341 + lift + 0.02
-    qpos[e, 7:] += rng.normal(size=69) * 0.1
-    scenes.append(objs)
-action = rng.normal(size=(n, 75)) * 0.2
-r32 = lambda x: np.asarray(x, np.float32).astype(np.float64)  # noqa: E731
+S = _scenes.object_scenes(n, seed)                  # the generator of obj_fuzz.py, draw for draw
+blk, qpos, qvel, action, scenes = S["blk"], S["qpos"], S["qvel"], S["action"], S["objects"]
+r32 = _scenes.r32
 dev = lambda x: torch.tensor(np.asarray(x), dtype=torch.float32, device="cuda")  # noqa: E731
-blk, qpos, qvel, action = r32(blk), r32(qpos), r32(qvel), r32(action)
 e = scene
 ois = sorted(scenes[e])
 print(f"seed {seed} scene {e}: objects {ois}", flush=True)
