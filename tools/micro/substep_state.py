@@ -32,5 +32,5 @@ dv = hv - wv
 print("efc force (oracle)", o.efc()[0])
 print(f"|dqvel| max {np.abs(dv).max():.2e} at dof {int(np.abs(dv).argmax())}; qacc of the constraint (oracle) there {((o.qacc_full() - o.qacc_smooth_full())[int(np.abs(dv).argmax())]):.3f}; Newton iterations oracle {o.niter} hip {sim.diag()[0, 1]}")
 if len(c["body"]) == len(h["body"]) and len(c["body"]):
-    ang = [float(np.arccos(np.clip(np.dot(c["normal"][i], h["normal"][i]), -1, 1))) for i in range(len(c["body"]))]
+    ang = [float(np.arctan2(np.linalg.norm(np.cross(c["normal"][i], h["normal"][i])), np.dot(c["normal"][i], h["normal"][i]))) for i in range(len(c["body"]))]
     print("angle between the normals (rad):", np.round(ang, 6), "  |ddist|:", np.abs(c["dist"] - h["dist"]))

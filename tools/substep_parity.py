@@ -92,6 +92,7 @@ def run(mode="floor", n=64, seed=None, nsub=45):
         oracles.append(o)
     eq = np.zeros((nsub, n)); ev = np.zeros((nsub, n)); eo = np.zeros((nsub, n)); differ = np.zeros((nsub, n), bool); ncon = np.zeros((nsub, n), int)
     nit_o = np.zeros((nsub, n), int); nit_h = np.zeros((nsub, n), int); vertex = np.zeros((nsub, n), bool); klass = np.full((nsub, n), "", dtype=object)
+    nang = np.zeros((nsub, n)); ddist = np.zeros((nsub, n))
     for k in range(nsub):
         q = np.stack([r32(o.get("qpos")) for o in oracles]); v = np.stack([r32(o.get("qvel")) for o in oracles])
         if obj:
@@ -164,7 +165,10 @@ def run(mode="floor", n=64, seed=None, nsub=45):
                     j = min(cand, key=lambda jj: np.abs(hc[e]["pos"][jj] - cp[i]).max()); used.add(j)
                     if np.abs(hc[e]["pos"][j] - cp[i]).max() > 1e-4:
                         vertex[k, e] = True
-    return dict(eq=eq, ev=ev, eo=eo, differ=differ, ncon=ncon, scenes=S, seed=seed, nit_o=nit_o, nit_h=nit_h, vertex=vertex, klass=klass)
+                    elif obj:            # the same point: how far apart are the two normals (MPR's direction for the hull - primitive pairs) and distances?
+                        nang[k, e] = max(nang[k, e], float(np.arctan2(np.linalg.norm(np.cross(c["normal"][i], hc[e]["normal"][j])), np.dot(c["normal"][i], hc[e]["normal"][j]))))     # not acos(dot): the hip normal is unit to 1e-7 only
+                        ddist[k, e] = max(ddist[k, e], abs(c["dist"][i] - hc[e]["dist"][j]))
+    return dict(eq=eq, ev=ev, eo=eo, differ=differ, ncon=ncon, scenes=S, seed=seed, nit_o=nit_o, nit_h=nit_h, vertex=vertex, klass=klass, nang=nang, ddist=ddist)
 
 
 if __name__ == "__main__":
@@ -184,6 +188,8 @@ if __name__ == "__main__":
           + (" [" + ", ".join(f"{nm}: {int((R['klass'] == nm).sum())}" for nm in sorted(set(R['klass'][differ].tolist()))) + "]" if differ.any() else "")
           + f"; same entities but another vertex of a hull at the same height (to 1e-7): {int(vertex.sum())}" + (f" (|dqpos| max {err[vertex].max():.1e})" if vertex.any() else "")
           + f"; with the same contact points: max |dqpos| {err[same].max():.1e}, above 1e-6: {int((err[same] > 1e-6).sum())}, above 1e-5: {int((err[same] > 1e-5).sum())}")
+    if R["nang"].any():
+        print(f"   matched contacts of the same point: |d dist| max {R['ddist'].max():.1e}; angle between the two normals max {R['nang'].max():.1e} rad, above 1e-4 rad in {int((R['nang'] > 1e-4).sum())} substeps, above 1e-3 in {int((R['nang'] > 1e-3).sum())}")
     order = np.dstack(np.unravel_index(np.argsort(-err, axis=None)[:6], err.shape))[0]
     for k, e in order:
         print(f"   substep {k:2d} scene {e:3d} (kind {S['kind'][e]}, objects {sorted(S['objects'][e])}): |dqpos| {eq[k, e]:.1e} object {eo[k, e]:.1e} rel |dqvel| {ev[k, e]:.1e} contacts {ncon[k, e]} Newton iterations oracle {R['nit_o'][k, e]} hip {R['nit_h'][k, e]}"
