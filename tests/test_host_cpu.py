@@ -228,3 +228,24 @@ def test_python_model_compiler_and_hull_graph_against_qhull():
         qh = mc.hull_graph_qhull(v)
         assert mine == {(i, j) for i in range(len(v)) for j in qh[i]}, f"hull {b}"
         assert len(mine) == 2 * (3 * len(v) - 6)          # a triangulated convex polyhedron: E = 3 V - 6
+
+
+def test_parity_tool_scene_generators_are_deterministic_and_fp32_valued():
+    """tools/_scenes.py feeds the parity sweeps (substep_parity.py, obj_fuzz_trace.py): same seed -> same scenes, every number already an fp32 value
+    (both sides of a sweep must get identical inputs), unit root quaternions, objects only where the scene's action class puts them."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import _scenes
+    a, b = _scenes.object_scenes(16, 3), _scenes.object_scenes(16, 3)
+    for k in ("qpos", "qvel", "action", "blk"):
+        assert np.array_equal(a[k], b[k]) and np.array_equal(a[k], a[k].astype(np.float32).astype(np.float64)), k
+    assert not np.array_equal(a["qpos"], _scenes.object_scenes(16, 4)["qpos"])
+    for e, objs in enumerate(a["objects"]):
+        assert sorted(objs) == _scenes.OBJ_OF_ACTION[int(a["kind"][e])]
+        for oi, pose in objs.items():
+            assert np.array_equal(pose, a["blk"][e, 7 * oi: 7 * oi + 7]) and abs(np.linalg.norm(pose[3:7]) - 1) < 1e-6
+        parked = [oi for oi in range(5) if oi not in objs]
+        assert all(a["blk"][e, 7 * oi] >= 100 for oi in parked)
+    f = _scenes.floor_scenes(20)
+    assert f["qpos"].shape == (20, 76) and f["target"].shape == (20, 76) and set(f["kind"]) == {0, 1, 2, 3, 4}
+    assert np.abs(np.linalg.norm(f["qpos"][:, 3:7], axis=1) - 1).max() < 1e-6 and f["blk"] is None and all(o == {} for o in f["objects"])
