@@ -16,6 +16,13 @@ HEADERS = ["kp_model.hpp", "kp_device.hpp", "kp_step_kernel.hpp", "kp_obs_kernel
            "../../include/kinpoly_sim.h"]
 
 
+# Optimisation flags of the product build (tools that compile instrumented variants of the library use the same list).  -O2 without the loop and SLP
+# vectorisers: on the one-wavefront-per-env kernels their packed fp32 operations (v_pk_fma_f32 and friends need even-aligned register pairs) cost more
+# in moves and register pressure than they save -- control-step launch 2.785 -> 2.695 ms (floor), 5.16 -> 5.03 ms (objects) against -O3 with both on
+# (measured on the final kernels of round 3; -fno-unroll-loops on top loses 3 % on the object kernel).
+OPT_FLAGS = ["-O2", "-fno-vectorize", "-fno-slp-vectorize"]
+
+
 def _hipcc() -> str:
     for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if c and os.path.exists(c):
@@ -38,7 +45,7 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
     extra = os.environ.get("KP_HIPCC_FLAGS", "").split()
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", *extra,
+    cmd = [_hipcc(), "--offload-arch=gfx950", *OPT_FLAGS, "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", *extra,
            *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB]
     if verbose:
         print(" ".join(cmd))

@@ -7,6 +7,8 @@ The patched sources live in a temp dir; the tree is not touched."""
 import os, shutil, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from kinpoly_amd.build import OPT_FLAGS  # noqa: E402  (the product build's optimisation flags)
 
 
 def patch(s):
@@ -70,7 +72,7 @@ def main(out):
     p = os.path.join(src, "kp_step_kernel.hpp")
     text = patch(open(p).read())
     open(p, "w").write(text)
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", *OPT_FLAGS, "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
                            os.path.join(src, "kp_sim.hip"), "-o", out])
     shutil.rmtree(tmp)
     print("built", out)

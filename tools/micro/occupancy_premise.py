@@ -5,6 +5,8 @@
 import os, shutil, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from kinpoly_amd.build import OPT_FLAGS  # noqa: E402  (the product build's optimisation flags)
 LIB = os.path.join(ROOT, "tools", "micro", "bin", "libkinpoly_sim_premise.so")
 
 
@@ -23,7 +25,7 @@ def build():
     edit("kp_step_kernel.hpp", "__global__ __launch_bounds__(64, 2) void kp_step_queue_kernel", "__global__ __launch_bounds__(64, 3) void kp_step_queue_kernel")
     edit("kp_sim.hip", "    const int spj = s->model->substeps_per_job;",
          "    if (const char* e = std::getenv(\"KP_LDS_PAD\")) lds = std::max<size_t>(lds, (size_t)std::atoi(e));\n    const int spj = s->model->substeps_per_job;")
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", *OPT_FLAGS, "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
                            os.path.join(src, "kp_sim.hip"), "-o", LIB])
     shutil.rmtree(tmp)
     print("built", LIB)

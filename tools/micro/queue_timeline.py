@@ -5,6 +5,8 @@ Prints the real shader clock under this load, the mean busy fraction of a wave, 
 import os, shutil, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from kinpoly_amd.build import OPT_FLAGS  # noqa: E402  (the product build's optimisation flags)
 LIB = os.path.join(ROOT, "tools", "micro", "bin", "libkinpoly_sim_timeline.so")
 
 
@@ -38,7 +40,7 @@ def build():
          "__global__ void k_queue_init(int n_envs, unsigned total, unsigned* __restrict__ jobq, unsigned* __restrict__ jobctr, const int* __restrict__ order, unsigned long long* prof) {\n"
          "    if (prof && blockIdx.x == 0 && threadIdx.x < 8) prof[threadIdx.x] = threadIdx.x == 3 ? ~0ull : 0ull;")
     edit("kp_sim.hip", "s->stream, s->n, total, s->jobq, s->jobctr, A.order);", "s->stream, s->n, total, s->jobq, s->jobctr, A.order, s->prof);")
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", *OPT_FLAGS, "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
                            os.path.join(src, "kp_sim.hip"), "-o", LIB])
     shutil.rmtree(tmp)
     print("built", LIB)

@@ -5,9 +5,11 @@ articulated-body loops (stable-PD / smooth phases) -- check this after touching 
 import os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from kinpoly_amd.build import OPT_FLAGS  # noqa: E402  (the product build's optimisation flags)
 with tempfile.TemporaryDirectory() as tmp:
     asm = os.path.join(tmp, "k.s")
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", "-Wno-unused-value",
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", *OPT_FLAGS, "-std=c++17", "--cuda-device-only", "-S", "-Wno-unused-value",
                            os.path.join(ROOT, "kinpoly_amd", "csrc", "kp_sim.hip"), "-o", asm])
     text = open(asm).read().split("\n")
 starts = {i: m.group(1) for i, l in enumerate(text) if (m := re.match(r"^(_ZN2kp\w+):", l))}
