@@ -413,7 +413,7 @@ def test_obs_ar_and_reward_match_pinned_oracle(kp, golden):
         t = c["t"][i]
         xpos, xquat = rd["xpos"][i].reshape(24, 3), rd["xquat"][i].reshape(24, 4)
         want = O.obs_ar(rd["qpos"][i], xpos, xquat, c["head_pose"][i, t], c["head_vels"][i, t], c["obj_rel"][i, t], g["action_one_hot"][i], g["obj_qpos"][i][:7])
-        np.testing.assert_allclose(obs[i], want, atol=2e-6, rtol=0)        # measured 3e-7
+        np.testing.assert_allclose(obs[i], want, atol=5e-6, rtol=0)        # measured 3e-7 .. 7e-7 (build flags move the last bit)
         tgt = O.qpos_fk(rd["target_qpos"][i], BODY_POS, BODY_IPOS, PARENT)
         head = np.concatenate([xpos[13], xquat[13]])
         r, inf = O.dynamic_supervision_v1(head, rd["prev_hpos"][i], O.get_body_quat(rd["qpos"][i]), rd["prev_bquat"][i], xpos, tgt, c["head_pose"][i, t],
