@@ -244,10 +244,13 @@ WORKLOAD_DESC = {
                  "termination, fail-safe on), batched inference, standing clip",
     "objects": "BASELINE configs[3] on one GPU: same env-step with the scene's free objects simulated (sit: chair, push: box on table, avoid: Can, step: step box; "
                "SURVEY 8(d) config 4 synthetic takes, four action classes evenly over the envs), kinematic policy's output replaced by the clip's next pose + noise",
-    "train_iter": "one AgentAR.optimize_policy per step: sample 4096 x 24 env-steps of the configs[2] rollout (random-init TrajARNet, standing clips), GAE, all-gather of "
+    "train_iter": "one AgentAR.optimize_policy per step: sample 4096 x 24 env-steps of the configs[2] rollout (random-init TrajARNet; every episode on a clip drawn from a "
+                  "StateARDataset of synthetic takes and run through init_context, as scripts/train_ar_policy.py does), GAE, all-gather of "
                   "advantages / returns, 10 PPO epochs + 20 supervised step updates, gradients all-reduced (kin_poly.yml:36-71)",
 }
 ROLLOUT_WORKLOADS = ("tracked", "random_init", "wild_eval", "objects")
+TRAIN_KEYS = ("T_sample", "T_update", "samples_per_s_per_gpu", "samples_per_iter_per_gpu", "iters", "avg_reward", "fail_rate", "episodes_per_iter",
+              "clips_through_init_context_per_iter", "pool_exhausted", "update_tflops", "update_mfma_frac", "update_flops_per_iter", "episode_source")
 
 
 def run_workload(workload, device_index, seed, threads, steps, warmup, barrier=None):
@@ -326,39 +329,68 @@ def object_scene_launches(device_index, threads):
     return out
 
 
-def train_iteration(device_index, seed, horizon, iters, warm, barrier=None, threads=64):
-    """`iters` timed AgentAR.optimize_policy calls (after `warm` untimed) at ENVS_PER_GPU x horizon env-steps per rank."""
+def train_iteration(device_index, seed, horizon, iters, warm, barrier=None, threads=64, objects=False, rank=0):
+    """`iters` timed AgentAR.optimize_policy calls (after `warm` untimed) at ENVS_PER_GPU x horizon env-steps per rank, the way
+    scripts/train_ar_policy.py runs them: every episode draws its clip from a StateARDataset (adaptive take sampling, freq_dict feedback) and goes
+    through init_context (context GRU over the 100-frame clip -> init_qpos / init_qvel) -- inside the timed region, at whatever failure rate the
+    random-init networks produce.  objects=False: BASELINE configs[2] (object-free takes); True: configs[3]'s four action classes with free objects."""
     from kinpoly_amd.agent import AgentAR
-    from kinpoly_amd.env import standing_context
+    from kinpoly_amd import dataset as D
     from kinpoly_amd import sim as kpsim
+    from kinpoly_amd.model_compiler import read_kpm
     std = np.load(os.path.join(ROOT, "tests", "golden", "standing_neutral.npz"))
-    fk_sim = kpsim.KpSim(kpsim.KpModel(), ENVS_PER_GPU, device_index)
-    g = torch.Generator().manual_seed(seed)
-
-    def context_fn(m):
-        h = (torch.rand(m, generator=g) * 2 - 1) * np.pi
-        ctx = standing_context(m, CLIP_LEN, std["qpos"], std["qvel"], fk_sim, h)
-        ctx["obj_pose"] = torch.tensor([0.0, 0, 0, 1, 0, 0, 0], device=ctx["qpos"].device).repeat(m, CLIP_LEN, 1)
-        return ctx
-    agent = AgentAR(ENVS_PER_GPU, context_fn, device=device_index, horizon=horizon, seed=seed, use_init_context=False, pool_depth=2,
-                    model_options={"threads_per_env": threads})
+    fk_sim = kpsim.KpSim(kpsim.KpModel(kpsim.STEP_KPM), ENVS_PER_GPU, device_index)
+    # one data set for the whole job (take seed independent of the rank), one draw stream per rank
+    takes = D.synthetic_takes(fk_sim, std["qpos"], n_per_action=8, T_range=(CLIP_LEN + 10, CLIP_LEN + 60), body_mass=read_kpm(kpsim.STEP_KPM)["body_mass"],
+                              seed=seed, with_objects=objects)
+    ds = D.StateARDataset(takes, fr_num=CLIP_LEN, seed=seed + rank, device=fk_sim.device)
+    agent = AgentAR(ENVS_PER_GPU, dataset=ds, device=device_index, horizon=horizon, seed=seed, use_init_context=True, pool_depth=4,
+                    model_options={"threads_per_env": threads}, sampling_temp=0.3, sampling_freq=0.5)
     for i in range(warm):
         agent.optimize_policy(i)
     (barrier or torch.cuda.synchronize)()
     t0 = time.perf_counter()
     ts = tu = 0.0
     info = {}
+    drawn0, eps, fails = agent.source.n_drawn, 0, 0.0
     for i in range(iters):
         info = agent.optimize_policy(warm + i)
-        ts += info["T_sample"]; tu += info["T_update"]
+        ts += info["T_sample"]; tu += info["T_update"]; eps += info["episodes"]; fails += info["fail_rate"]
     (barrier or torch.cuda.synchronize)()
     el = time.perf_counter() - t0
-    rec = {"elapsed": el, "T_sample": ts / iters, "T_update": tu / iters, "samples_per_iter_per_gpu": ENVS_PER_GPU * horizon, "horizon": horizon,
-           "iters": iters, "warmup": warm, "samples_per_s_per_gpu": ENVS_PER_GPU * horizon * iters / el, "avg_reward": info.get("avg_reward"),
-           "pool_exhausted": info.get("pool_exhausted")}
+    n_s = ENVS_PER_GPU * horizon
+    # FLOPs of the update, counted from its GEMM shapes (2 x MACs; backward = 2 x forward): the policy = GRU re-unroll (105 -> 3 x 1024 input gates,
+    # 1024 -> 3 x 1024 recurrent gates) + MLP 1129-1024-512-256-80 per sample, the value net 105-512-256-1
+    pol_macs = 105 * 3072 + 1024 * 3072 + 1129 * 1024 + 1024 * 512 + 512 * 256 + 256 * 80
+    val_macs = 105 * 512 + 512 * 256 + 256
+    ne, ns = agent.trainer.num_optim_epoch, agent.num_step_update
+    # policy: (forward + backward = 3 forward-equivalents) x (PPO epochs + supervised steps); fixed_log_probs is epoch 0's own forward
+    # (PPOTrainer.update), so no extra pass.  value: one forward for GAE + 3 x the regression steps
+    upd_flops = 2.0 * n_s * (pol_macs * 3 * (ne + ns) + val_macs * (1 + 3 * ne * agent.trainer.value_opt_niter))
+    rec = {"elapsed": el, "T_sample": ts / iters, "T_update": tu / iters, "samples_per_iter_per_gpu": n_s, "horizon": horizon,
+           "iters": iters, "warmup": warm, "samples_per_s_per_gpu": n_s * iters / el, "avg_reward": info.get("avg_reward"),
+           "pool_exhausted": info.get("pool_exhausted"), "episodes_per_iter": eps / iters, "clips_through_init_context_per_iter": (agent.source.n_drawn - drawn0) / iters,
+           "fail_rate": fails / iters, "episode_source": f"StateARDataset of {ds.get_len()} synthetic takes ({'four action classes with free objects' if objects else 'no objects'}), "
+                                                         "adaptive take sampling + init_context per episode, pool_depth 4",
+           "update_tflops": upd_flops / (tu / iters) / 1e12, "update_mfma_frac": upd_flops / (tu / iters) / 1e12 / MFMA_FP32_PEAK_TFLOPS,
+           "update_flops_per_iter": upd_flops}
     del agent, fk_sim
     torch.cuda.empty_cache()
     return rec
+
+
+def relaunch_under_torchrun(n_gpus):
+    """`python bench.py --gpus N` without a launcher (the form the driver's scaling run may use): start N ranks of this same command under
+    torch.distributed.run on this node (the reference forks its own workers too, agent_ar.py:651-663) and hand its exit code back."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ, KP_BENCH_CHILD="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -383,6 +415,8 @@ def main():
     if args.warmup is None:
         args.warmup = 1 if train else 20
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:        # no launcher around us: become one
+        raise SystemExit(relaunch_under_torchrun(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -417,7 +451,7 @@ def main():
         ranks_seen = int(one.item())
 
     if train:
-        rec = train_iteration(local_rank, 4, TRAIN_HORIZON, args.steps, args.warmup, barrier, args.threads_per_env)
+        rec = train_iteration(local_rank, 4, TRAIN_HORIZON, args.steps, args.warmup, barrier, args.threads_per_env, rank=rank)
         env = policy = sampler = None
         std = np.load(os.path.join(ROOT, "tests", "golden", "standing_neutral.npz"))
     else:
@@ -440,7 +474,7 @@ def main():
                "config": {"workload": WORKLOAD_DESC["train_iter"], "workload_id": "train_iter", "envs_per_gpu": ENVS_PER_GPU, "horizon": TRAIN_HORIZON,
                           "samples_per_step": per_step * world, "parallelism": f"env-sharded x{world}, data-parallel update"},
                "ranks_seen": ranks_seen, "ms_per_step_per_rank": per_rank_ms, "collective_backend": (dist.get_backend() if in_group else None),
-               "train_iteration": {k: rec[k] for k in ("T_sample", "T_update", "samples_per_iter_per_gpu", "avg_reward", "pool_exhausted")}}
+               "train_iteration": {k: rec[k] for k in TRAIN_KEYS}}
         print(json.dumps(out), flush=True)
     elif rank == 0:
         kern_s, n_launch, diag = rec["kern_s"], rec["n_launch"], rec["diag"]
@@ -530,9 +564,9 @@ def main():
                 out["object_scenes"] = {"error": f"{type(ex).__name__}: {ex}"[:200]}
             try:        # a whole training iteration: the update is its larger part
                 out["train_iteration"] = {}
-                for hz, it in ((TRAIN_HORIZON, 2), (CLIP_LEN - 1, 1)):
-                    r3 = train_iteration(local_rank, 4, hz, it, 1)
-                    out["train_iteration"][f"4096x{hz}"] = {k: r3[k] for k in ("T_sample", "T_update", "samples_per_s_per_gpu", "samples_per_iter_per_gpu", "iters", "avg_reward")}
+                for name, hz, it, obj in ((f"4096x{TRAIN_HORIZON}", TRAIN_HORIZON, 2, False), (f"4096x{TRAIN_HORIZON}_objects", TRAIN_HORIZON, 1, True)):
+                    r3 = train_iteration(local_rank, 4, hz, it, 1, objects=obj)
+                    out["train_iteration"][name] = {k: r3[k] for k in TRAIN_KEYS}
             except Exception as ex:
                 out["train_iteration"] = {"error": f"{type(ex).__name__}: {ex}"[:200]}
         else:

@@ -173,18 +173,31 @@ int kp_sim_term_reward(kp_sim*, const kp_ctx* ctx, const kp_reward_cfg* cfg, flo
 /* The tail of HumanoidAREnv.step in one launch (humanoid_ar_v1.py:288-316): cur_t += 1 (in place; cur_t must be ctx->cur_t), termination and
  * reward as kp_sim_term_reward with the incremented cur_t, then end = cur_t >= min(env_episode_len, ar_context['len']), done = fail || end,
  * percent = cur_t / ar_context['len'].  row_len: int32 [R] = ar_context['len'] of every context row (env e reads row_len[ctx->row[e]]).
- * done / end: uint8 [N]; percent: float [N]; done_count (optional, may be NULL): int32 device counter incremented by the number of done envs. */
+ * done / end: uint8 [N]; percent: float [N]; done_count (optional, may be NULL): int32 device counter incremented by the number of done envs.
+ * obj7 (optional, may be NULL): float [N,7] <- get_obj_qpos(ar_context['action_one_hot'][0]) of the state after the step (humanoid_ar_v1.py:171-172,
+ * 466-477): the simulated pose of the action's first object, data.qpos[76 + action_index_map[a] : +7]; rows whose clip has no action are left
+ * alone.  It is the buffer kp_ctx.obj_qpos points to, so the next kp_sim_obs_ar reads the objects where the physics left them. */
 int kp_sim_post_step(kp_sim*, const kp_ctx* ctx, const kp_reward_cfg* cfg, int32_t* cur_t, const int32_t* row_len, int env_episode_len,
-                     float* reward, float* info, uint8_t* fail, float* diffs, uint8_t* done, uint8_t* end, float* percent, int32_t* done_count);
+                     float* reward, float* info, uint8_t* fail, float* diffs, uint8_t* done, uint8_t* end, float* percent, int32_t* done_count, float* obj7);
 
 /* Masked reset in one gather + sim.forward() (mujoco_env.py:86-103, humanoid_ar_v1.py:334-387): for the envs with env_mask != 0 (NULL: all)
  * qpos / qvel <- init_qpos / init_qvel [R, 76] / [R, 75] of context row row[e] (NULL: row e), cur_t[e] = 0 (cur_t may be NULL), warm start
  * zeroed, derived quantities recomputed; set_target != 0: target = qpos_fk(init_qpos) for those envs as reset_model does (:384-386).
  * aux_rows (optional, may be NULL): caller-owned float [N, aux_cols] device rows zeroed for the same envs -- per-episode state that lives
  * outside the simulator, i.e. the kinematic policy's GRU hidden state (PolicyAR.reset / action_rnn.initialize at every episode start,
- * kin_poly/models/policy_ar.py:124-131). */
+ * kin_poly/models/policy_ar.py:124-131).
+ * row_obj_qpos (optional, may be NULL): float [R,35] = convert_obj_qpos(action_one_hot, obj_pose[0]) of every context row (humanoid_ar_v1.py:377,
+ * 479-496); the masked envs' object block is set from their row exactly as kp_sim_set_objects sets it (velocities zero, :382) before sim.forward().
+ * row_action_one_hot [R,4] + obj7 [N,7] (optional, both or neither): obj7 <- get_obj_qpos(action_one_hot) of the fresh block for those envs
+ * ([0,0,0,1,0,0,0] for a clip without action, :465-466). */
 int kp_sim_reset_rows(kp_sim*, const float* init_qpos, const float* init_qvel, const int32_t* row, const uint8_t* env_mask, int32_t* cur_t, int set_target,
-                      float* aux_rows, int aux_cols);
+                      float* aux_rows, int aux_cols, const float* row_obj_qpos, const float* row_action_one_hot, float* obj7);
+
+/* Episode turnover of a sampler that keeps the NEXT clips of every env resident (the per-episode sample_seq -> init_context -> load_context of
+ * sample_worker, kin_poly/core/agent_ar.py:518-535, made ahead of time and batched): the context table holds n_slots rows per env, row = slot * n + env;
+ * for every env with done != 0: head <- (head + 1) mod n_slots, ahead <- ahead - 1 (clips still queued behind the current one), row <- head * n + env
+ * (the int32 [n] buffer kp_ctx.row points to).  A pure function of its device arrays (no simulator handle); follow with kp_sim_reset_rows(done). */
+int kp_pool_advance(int n, int n_slots, const uint8_t* done, int32_t* head, int32_t* ahead, int32_t* row, void* hip_stream);
 
 /* estimate_advantages before normalisation (uhc/khrylib/rl/core/common.py:5-20) on an env-major
  * [N,T] layout (each env's T rows contiguous, time increasing).  All pointers device, float32. */

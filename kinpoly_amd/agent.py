@@ -2,8 +2,8 @@
 (`optimize_policy` :271-297 = per_epoch_update + sample :651-680 + update_params :682-752), one process per GPU.
 
     per_epoch_update  LambdaLR schedules of the policy / value optimisers (:215-225, 268-269)
-    sample            VectorSampler over N envs: device SoA, every episode on a freshly drawn clip (EpisodeSource: batched
-                      sample_seq + init_context ahead of the rollout, freq_dict feedback, :518-606)
+    sample            VectorSampler over N envs: device SoA, every episode on a freshly drawn clip at any failure rate (a ring of pool_depth + 1
+                      context rows per env, topped up on demand by EpisodeSource: batched sample_seq + init_context, freq_dict feedback, :518-606)
     rl_update         GAE (k_gae) + global advantage normalisation (RCCL all-gather) + PPO epochs (:756-772); with
                       joint_controller also update_controller (:774-794), which -- as in the reference, whose optimiser holds
                       policy_net only -- leaves the UHC weights alone unless `train_uhc` is set (PPOTrainer)
@@ -34,7 +34,7 @@ class AgentAR:
     def __init__(self, n_envs, context_fn=None, device=0, horizon=99, seed=4, wild=False, use_init_context=True,
                  policy_lr=1e-5, value_lr=3e-4, supervised_lr=5e-4, num_optim_epoch=10, num_step_update=20, gamma=0.95, tau=0.95,
                  clip_epsilon=0.2, rl_update=True, step_update=True, model_options=None, dataset=None, sampling_temp=0.3, sampling_freq=0.5,
-                 pool_depth=2, num_epoch_fix=100, num_epoch=10000, joint_controller=False, grad_joint=False, grad_alternate=False, train_uhc=False):
+                 pool_depth=4, num_epoch_fix=100, num_epoch=10000, joint_controller=False, grad_joint=False, grad_alternate=False, train_uhc=False):
         rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
         enable_tuned_gemms()          # library GEMM solution per shape (rollout and update shapes at 4096 envs); selection only
         torch.manual_seed(seed + rank)
@@ -45,7 +45,9 @@ class AgentAR:
         self.value_net = Value(MLP(105, (512, 256), "relu")).to(self.device)
         self._sync_params()
         self.kin_sim = kpsim.KpSim(self.env.model, n_envs, self.device.index)      # physics-free twin for the kinematic roll-out
-        self.ctx_builder = PolicyARContext(self.policy_net, self.kin_sim, smooth=True)
+        # a training episode reads init_qpos / init_qvel of its context only: the whole-clip kinematic roll-out and the [N, T, 1024] context
+        # feature sequence of init_context are not computed (PolicyARContext; evaluate.py builds its own with need_rollout=True)
+        self.ctx_builder = PolicyARContext(self.policy_net, self.kin_sim, smooth=True, need_rollout=False, keep_context_feat=False)
         # sampling_temp / sampling_freq: kin_poly.yml:67-68; freq_dict lives in the source (agent_ar.py:228-234)
         self.source = EpisodeSource(dataset=dataset, context_fn=context_fn if dataset is None else None,
                                     ctx_builder=self.ctx_builder if use_init_context else None,
@@ -93,7 +95,7 @@ class AgentAR:
         n = batch.rewards.numel()
         info.update(T_sample=t1 - t0, T_update=t2 - t1, T_total=time.time() - t0, num_steps=n, avg_reward=float(batch.rewards.mean()),
                     fail_rate=float(batch.fails.float().mean()), env_steps_per_s=n / (t1 - t0), episodes=len(batch.episodes.get("percent", ())),
-                    pool_exhausted=self.sampler.pool_exhausted, policy_lr=self.trainer.opt_p.param_groups[0]["lr"])
+                    pool_exhausted=self.sampler.pool_exhausted, clips_drawn=self.source.n_drawn, top_ups=self.sampler.top_ups, policy_lr=self.trainer.opt_p.param_groups[0]["lr"])
         return info
 
     def save_checkpoint(self, path):

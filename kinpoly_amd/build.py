@@ -12,8 +12,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "libkinpoly_sim.so")
 SOURCES = ["kp_sim.hip"]
-HEADERS = ["kp_model.hpp", "kp_device.hpp", "kp_step_kernel.hpp", "kp_obs_kernels.hpp", "kp_rollout_kernels.hpp",
-           "../../include/kinpoly_sim.h"]
+STAMP = LIB + ".flags"          # the flag list the library was built with (a change of flags rebuilds, like a change of a source)
+
+
+def _dependencies():
+    """every file the library is compiled from: csrc/*.hip|*.hpp and include/*.h (globbed, so that a new header is a dependency the day it appears)"""
+    import glob
+    inc = os.path.join(os.path.dirname(_HERE), "include")
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(inc, "*.h")))
 
 
 # Optimisation flags of the product build (tools that compile instrumented variants of the library use the same list).  -O2 without the loop and SLP
@@ -30,15 +36,20 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (ROCm toolchain required to build libkinpoly_sim.so)")
 
 
+def _flags():
+    return [*OPT_FLAGS, *os.environ.get("KP_HIPCC_FLAGS", "").split()]
+
+
 def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    for f in SOURCES + HEADERS:
-        p = os.path.join(CSRC, f)
-        if os.path.exists(p) and os.path.getmtime(p) > t:
-            return True
-    return False
+    if any(os.path.getmtime(p) > t for p in _dependencies()):
+        return True
+    try:
+        return open(STAMP).read() != " ".join(_flags())
+    except OSError:
+        return True
 
 
 def build_native(force: bool = False, verbose: bool = False) -> str:
@@ -50,6 +61,8 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    with open(STAMP, "w") as f:
+        f.write(" ".join(_flags()))
     return LIB
 
 

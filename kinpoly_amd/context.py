@@ -116,24 +116,52 @@ class TrajARNet(KinPolicy):
         self.context_mlp = MLP(rnn_hdim, mlp_hsize, htype)
         self.context_fc = nn.Linear(mlp_hsize[-1], self.init_dim)
 
-    def get_context_feat(self, data):
-        """get_context_feat (:138-167): GRU over [obj_head_relative_poses, head_vels, action_one_hot] -> [N, T, rnn_hdim]."""
+    def _context_input(self, data):
         one_hot = data["action_one_hot"]
         T = data["head_vels"].shape[1]
         if one_hot.dim() == 2:
             one_hot = one_hot[:, None].expand(-1, T, -1)
-        feat = torch.cat([data["obj_head_relative_poses"], data["head_vels"], one_hot], 2)
+        return torch.cat([data["obj_head_relative_poses"], data["head_vels"], one_hot], 2)
+
+    def get_context_feat(self, data):
+        """get_context_feat (:138-167): GRU over [obj_head_relative_poses, head_vels, action_one_hot] -> [N, T, rnn_hdim]."""
+        feat = self._context_input(data)
         hx = torch.zeros((feat.shape[0], self.rnn_hdim), device=feat.device, dtype=feat.dtype)
         outs = []
-        for t in range(T):
+        for t in range(feat.shape[1]):
             hx = self.context_rnn.rnn_f(feat[:, t], hx)
             outs.append(hx)
         return torch.stack(outs, 1)
 
-    def init_states(self, data):
-        """init_states (:180-201) + init_pred_qpos (:169-178): -> (init_qpos [N,76], init_qvel [N,75], context_feat_rnn)."""
-        ctx = self.get_context_feat(data)
-        init = self.context_fc(self.context_mlp(ctx.mean(1)))
+    def get_context_mean(self, data):
+        """context_feat_rnn.mean(dim=1) of init_states (:185-186) without keeping the [N, T, rnn_hdim] sequence: the only consumer of the
+        sequence itself is the `use_context` / `use_of` observation block (humanoid_ar_v1.py:151-155), off in kin_poly.yml, and 4096 clips of 100
+        frames would be 1.7 GB of it per draw.  On the device every step is the two gate GEMMs + kp_gru_cell_step (as the rollout's GRU step)."""
+        feat = self._context_input(data)
+        N, T = feat.shape[:2]
+        cell = self.context_rnn.rnn_f
+        hx = torch.zeros((N, self.rnn_hdim), device=feat.device, dtype=feat.dtype)
+        acc = torch.zeros_like(hx)
+        fast = feat.is_cuda and feat.dtype == torch.float32 and not torch.is_grad_enabled()
+        ft = feat.transpose(0, 1).contiguous()                     # time-major: every step's input rows are contiguous
+        for t in range(T):
+            if fast:
+                gi = torch.nn.functional.linear(ft[t], cell.weight_ih)
+                gh = torch.nn.functional.linear(hx, cell.weight_hh)
+                hx = kpsim.gru_cell_step(gi, gh, cell.bias_ih, cell.bias_hh, hx)
+            else:
+                hx = cell(ft[t], hx)
+            acc = acc + hx
+        return acc / T
+
+    def init_states(self, data, keep_feat: bool = True):
+        """init_states (:180-201) + init_pred_qpos (:169-178): -> (init_qpos [N,76], init_qvel [N,75], context_feat_rnn or None)."""
+        if keep_feat:
+            ctx = self.get_context_feat(data)
+            mean = ctx.mean(1)
+        else:
+            ctx, mean = None, self.get_context_mean(data)
+        init = self.context_fc(self.context_mlp(mean))
         pred, vel = init[:, :self.action_dim], init[:, self.action_dim:]
         q0 = data["qpos"][:, 0]
         pred_qpos = torch.cat([q0[:, :2], pred[:, :74]], 1)
@@ -174,26 +202,57 @@ class TrajARNet(KinPolicy):
 
 
 class PolicyARContext:
-    """`PolicyAR.init_context` for N episodes at once -> the `ar_context` tensors the env consumes."""
+    """`PolicyAR.init_context` for N episodes at once -> the `ar_context` tensors the env consumes.
 
-    def __init__(self, net: TrajARNet, kin_sim: kpsim.KpSim, smooth: bool = True, smooth_time_axis: bool = False):
+    need_rollout (constructor default, per-call override): the kinematic roll-out of the whole clip (`ar_qpos`, `ar_qvel`, `ar_wbpos`, ...) is
+    read by `ar_mode` (humanoid_ar_v1.py:263, 339-341), `ar_fail_safe` (:327-331), the legacy `policy_v == 2` observation (:209-210) and
+    the evaluation scripts; a TRAINING episode consumes `init_qpos` / `init_qvel` only (reset_model :342-343 -- load_context's
+    `target = qpos_fk(ar_qpos[0])`, :88, is overwritten by the reset that always follows, :384).  With need_rollout=False the T GRU + MLP +
+    FK steps of the roll-out are skipped and the context keys they would fill are absent; everything a training episode reads is unchanged."""
+
+    def __init__(self, net: TrajARNet, kin_sim: kpsim.KpSim, smooth: bool = True, smooth_time_axis: bool = False, need_rollout: bool = True,
+                 keep_context_feat: bool = True):
         # smooth = cfg.smooth (kin_poly.yml:19): selects the branch of init_context (fix_height + FK of ar_qpos);
         # smooth_time_axis: deviation from the reference, see the module docstring
         self.net, self.kin_sim, self.smooth, self.smooth_time_axis = net, kin_sim, smooth, smooth_time_axis
+        self.need_rollout, self.keep_context_feat = need_rollout, keep_context_feat
+
+    def _rollout_any(self, data, init_qpos, init_qvel):
+        """TrajARNet.rollout for any number of clips: the kinematic twin simulator holds kin_sim.n rows, so other batch sizes go through it in
+        chunks of that many (the last one padded with copies of its last clip)."""
+        m, n = init_qpos.shape[0], self.kin_sim.n
+        if m == n:
+            q, v, _ = self.net.rollout(data, self.kin_sim, init_qpos, init_qvel)
+            return q, v
+        keys = ("qpos", "head_pose", "head_vels", "obj_head_relative_poses", "action_one_hot", "obj_pose")
+        qs, vs = [], []
+        for i in range(0, m, n):
+            k = min(n, m - i)
+            idx = torch.arange(i, i + n, device=init_qpos.device).clamp_(max=m - 1)
+            part = {key: data[key][idx].contiguous() for key in keys}
+            q, v, _ = self.net.rollout(part, self.kin_sim, init_qpos[idx].contiguous(), init_qvel[idx].contiguous())
+            qs.append(q[:k]); vs.append(v[:k])
+        return torch.cat(qs, 0), torch.cat(vs, 0)
 
     @torch.no_grad()
-    def init_context(self, data: dict, fix_height: bool = False) -> dict:
+    def init_context(self, data: dict, fix_height: bool = False, need_rollout: bool | None = None) -> dict:
         out = dict(data)
-        init_qpos, init_qvel, ctx_feat = self.net.init_states(data)
-        out["init_qpos"], out["init_qvel"], out["context_feat_rnn"] = init_qpos.contiguous(), init_qvel.contiguous(), ctx_feat
-        ar_qpos, ar_qvel, _ = self.net.rollout(data, self.kin_sim, init_qpos, init_qvel)
+        need_rollout = self.need_rollout if need_rollout is None else need_rollout
+        init_qpos, init_qvel, ctx_feat = self.net.init_states(data, keep_feat=self.keep_context_feat)
+        out["init_qpos"], out["init_qvel"] = init_qpos.contiguous(), init_qvel.contiguous()
+        if ctx_feat is not None:
+            out["context_feat_rnn"] = ctx_feat
         begin_feet_offset = 0.01
+        if self.smooth and fix_height:
+            fk = self.kin_sim.fk(out["init_qpos"])
+            N0 = init_qpos.shape[0]
+            feet = torch.minimum(fk["wbpos"].view(N0, 24, 3)[:, 4, 2], fk["wbpos"].view(N0, 24, 3)[:, 8, 2]) - begin_feet_offset
+            out["init_qpos"] = torch.cat([out["init_qpos"][:, :2], (out["init_qpos"][:, 2] - feet)[:, None], out["init_qpos"][:, 3:]], 1).contiguous()
+        if not need_rollout:
+            return out
+        ar_qpos, ar_qvel = self._rollout_any(data, init_qpos, init_qvel)
         N, T = ar_qpos.shape[:2]
         if self.smooth:
-            if fix_height:
-                fk = self.kin_sim.fk(out["init_qpos"])
-                feet = torch.minimum(fk["wbpos"].view(N, 24, 3)[:, 4, 2], fk["wbpos"].view(N, 24, 3)[:, 8, 2]) - begin_feet_offset
-                out["init_qpos"] = torch.cat([out["init_qpos"][:, :2], (out["init_qpos"][:, 2] - feet)[:, None], out["init_qpos"][:, 3:]], 1).contiguous()
             if self.smooth_time_axis:      # NOT what the reference computes (its filter call is a no-op, module docstring)
                 ar_qpos = torch.cat([ar_qpos[:, :, :7], gaussian_filter1d_time(ar_qpos[:, :, 7:], 1.0)], 2)
             if fix_height:

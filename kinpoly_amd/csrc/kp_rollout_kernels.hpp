@@ -18,6 +18,15 @@ struct CtxDev {  // mirrors kp_ctx in include/kinpoly_sim.h
     __device__ __forceinline__ size_t r(int e) const { return row ? (size_t)row[e] : (size_t)e; }
 };
 
+// action_index_map of HumanoidAREnv (humanoid_ar_v1.py:37-39): first column of the action's object(s) inside data.qpos[76:111]
+// (sit -> chair 0, push -> box 7 (+ table 14), avoid -> Can 21, step -> step 28); -1 when the one-hot is all zero (no object, :465-466)
+__device__ __forceinline__ int obj_action_start(const float* one_hot) {
+    if (!one_hot) return -1;
+    int a = -1;
+    for (int k = 0; k < 4; k++) if (a < 0 && one_hot[k] != 0.f) a = k;
+    return a < 0 ? -1 : (a == 0 ? 0 : (a == 1 ? 7 : (a == 2 ? 21 : 28)));
+}
+
 __device__ __forceinline__ V3 tv_heading(V3 v, Q4 q) { return q_tmul_vec(q_heading(q), v); }  // transform_vec(v, q, 'heading')
 
 __global__ void k_obs_ar(int n, CtxDev C, const float* __restrict__ qpos, const float* __restrict__ xpos, const float* __restrict__ xquat,
@@ -97,6 +106,8 @@ struct PostStep {
     uint8_t *done, *end;        // [N]
     float* percent;             // [N]
     int* done_count;            // optional: += number of done envs (a rollout loop's episode counter, no extra reduction launch)
+    float* obj7;                // optional [N,7]: get_obj_qpos(action_one_hot) after the step = the simulated pose of the action's (first) object,
+    const float* sim_obj_qpos;  //   read from the simulator's data.qpos[76:111] rows [N,35]; envs whose clip has no action keep their obj7
 };
 template <bool POST>
 __global__ __launch_bounds__(256) void k_term_reward(int n, CtxDev C, RewardW W, const float* __restrict__ qpos, const float* __restrict__ xpos,
@@ -164,6 +175,10 @@ __global__ __launch_bounds__(256) void k_term_reward(int n, CtxDev C, RewardW W,
         PS.end[e] = ended; PS.done[e] = failed || ended;
         PS.percent[e] = (float)t_now / (float)clen;
         if (PS.done_count && (failed || ended)) atomicAdd(PS.done_count, 1);
+        if (PS.obj7) {
+            const int st = obj_action_start(C.action_one_hot + C.r(e) * 4);
+            if (st >= 0) for (int k = 0; k < 7; k++) PS.obj7[(size_t)e * 7 + k] = PS.sim_obj_qpos[(size_t)e * 35 + st + k];
+        }
     }
 }
 
@@ -180,6 +195,18 @@ __global__ void k_reset_rows(int n, const float* __restrict__ init_qpos, const f
     if (i < D_NQ) { const float v = init_qpos[r * D_NQ + i]; qpos[(size_t)e * D_NQ + i] = v; qpos_d[(size_t)e * D_NQ + i] = v; }
     if (i < D_NV) { const float v = init_qvel[r * D_NV + i]; qvel[(size_t)e * D_NV + i] = v; qvel_d[(size_t)e * D_NV + i] = v; warm[(size_t)e * D_NV + i] = 0.f; }
     if (i == 0 && cur_t) cur_t[e] = 0;
+}
+
+// Episode turnover of a sampler that keeps every env's NEXT clips resident as a ring of n_slots context rows per env (row = slot * n + env):
+// a finished env moves to the next slot of its ring and has one queued clip less (sample_seq -> init_context -> load_context of the next
+// episode, agent_ar.py:518-535, made ahead of time).  One launch instead of an add, a remainder, a subtract, a multiply-add, a cast and two masked copies.
+__global__ void k_pool_advance(int n, int n_slots, const uint8_t* __restrict__ done, int* __restrict__ head, int* __restrict__ ahead, int* __restrict__ row) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n || !done[e]) return;
+    int h = head[e] + 1;
+    if (h >= n_slots) h = 0;
+    head[e] = h; ahead[e] -= 1;
+    row[e] = h * n + e;
 }
 
 // reverse scan per env over an env-major [N, T] layout (time contiguous per env), masks cut episodes

@@ -495,20 +495,30 @@ int kp_sim_set_target(kp_sim* s, const float* tq, const uint8_t* mask) {
 
 // objects that are not parked (convert_obj_qpos parks the inactive ones 100+ m away): dynamic mode -> they become the env's
 // free bodies (slots in object order, velocities zeroed as reset_model does); static mode -> their world-frame geoms are frozen
-__global__ void k_set_objects(int n, const float* __restrict__ obj_qpos_in, const uint8_t* __restrict__ mask, float* __restrict__ obj_qpos,
+// row (optional): env e takes row row[e] of obj_qpos_in (a table of context rows, kp_sim_reset_rows) instead of row e; obj7 / one_hot (optional):
+// obj7[e] <- get_obj_qpos(action_one_hot) of the fresh block, i.e. the 7 floats at the action's slot, untouched when the row has no action
+__global__ void k_set_objects(int n, const float* __restrict__ obj_qpos_all, const uint8_t* __restrict__ mask, float* __restrict__ obj_qpos,
                               float* __restrict__ geoms, int* __restrict__ ngeom, const float* __restrict__ og, const float* __restrict__ omass,
-                              int n_og, int n_obj, int dynamic, signed char* __restrict__ slot, float* __restrict__ obj_qvel, float* __restrict__ obj_warm) {
+                              int n_og, int n_obj, int dynamic, signed char* __restrict__ slot, float* __restrict__ obj_qvel, float* __restrict__ obj_warm,
+                              const int* __restrict__ row, const float* __restrict__ one_hot, float* __restrict__ obj7) {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
     if (mask && !mask[e]) return;
     int ng = 0, ns = 0;
-    for (int i = 0; i < 35; i++) obj_qpos[(size_t)e * 35 + i] = obj_qpos_in[(size_t)e * 35 + i];
+    const size_t r = row ? (size_t)row[e] : (size_t)e;
+    const float* src = obj_qpos_all + r * 35;
+    if (obj7) {
+        const int st = kp::obj_action_start(one_hot ? one_hot + r * 4 : nullptr);
+        if (st >= 0) for (int i = 0; i < 7; i++) obj7[(size_t)e * 7 + i] = obj_qpos_all[r * 35 + st + i];
+        else { for (int i = 0; i < 7; i++) obj7[(size_t)e * 7 + i] = 0.f; obj7[(size_t)e * 7 + 3] = 1.f; }
+    }
+    for (int i = 0; i < 35; i++) obj_qpos[(size_t)e * 35 + i] = src[i];
     for (int i = 0; i < 30; i++) obj_qvel[(size_t)e * 30 + i] = 0.f;
     for (int i = 0; i < 6 * kp::D_MAXOBJ; i++) obj_warm[(size_t)e * 6 * kp::D_MAXOBJ + i] = 0.f;
     for (int k = 0; k < kp::D_MAXOBJ; k++) slot[(size_t)e * kp::D_MAXOBJ + k] = -1;
     if (dynamic) {
         for (int oi = 0; oi < n_obj && oi < 5 && ns < kp::D_MAXOBJ; oi++) {
-            const float* pose = obj_qpos_in + (size_t)e * 35 + 7 * oi;
+            const float* pose = src + 7 * oi;
             if (sqrtf(pose[0] * pose[0] + pose[1] * pose[1] + pose[2] * pose[2]) > 50.0f) continue;
             slot[(size_t)e * kp::D_MAXOBJ + ns++] = (signed char)oi;
         }
@@ -519,7 +529,7 @@ __global__ void k_set_objects(int n, const float* __restrict__ obj_qpos_in, cons
         const float* g = og + 18 * gi;
         const int oi = (int)g[0];
         if (oi >= n_obj || oi >= 5) continue;
-        const float* pose = obj_qpos_in + (size_t)e * 35 + 7 * oi;
+        const float* pose = src + 7 * oi;
         if (sqrtf(pose[0] * pose[0] + pose[1] * pose[1] + pose[2] * pose[2]) > 50.0f) continue;
         kp::Q4 q = kp::qnormalize(kp::Q4{pose[3], pose[4], pose[5], pose[6]});
         float R[9], Rg[9];
@@ -542,7 +552,8 @@ int kp_sim_set_objects(kp_sim* s, const float* obj_qpos, const uint8_t* mask) {
     const int dynamic = s->model->dynamic_objects && s->T.obj_inertial != nullptr;
     HIP_OK(hipSetDevice(s->device));
     hipLaunchKernelGGL(k_set_objects, dim3((s->n + 63) / 64), dim3(64), 0, s->stream, s->n, obj_qpos, mask, s->obj_qpos, s->geoms, s->ngeom,
-                       s->d_obj_geoms, s->d_obj_mass, s->n_obj_geoms, s->n_obj, dynamic, s->obj_slot, s->obj_qvel, s->obj_warm);
+                       s->d_obj_geoms, s->d_obj_mass, s->n_obj_geoms, s->n_obj, dynamic, s->obj_slot, s->obj_qvel, s->obj_warm,
+                       (const int*)nullptr, (const float*)nullptr, (float*)nullptr);
     HIP_OK(hipGetLastError());
     s->has_objects = true;
     return 0;
@@ -703,14 +714,14 @@ int kp_sim_term_reward(kp_sim* s, const kp_ctx* c, const kp_reward_cfg* w, float
 }
 
 int kp_sim_post_step(kp_sim* s, const kp_ctx* c, const kp_reward_cfg* w, int32_t* cur_t, const int32_t* row_len, int env_episode_len,
-                     float* reward, float* info, uint8_t* failp, float* diffs, uint8_t* done, uint8_t* end, float* percent, int32_t* done_count) {
+                     float* reward, float* info, uint8_t* failp, float* diffs, uint8_t* done, uint8_t* end, float* percent, int32_t* done_count, float* obj7) {
     if (!s || !c || !w || !cur_t || !row_len || !reward || !info || !failp || !diffs || !done || !end || !percent || !c->head_pose || !c->gt_bquat || !c->gt_wbpos || c->T < 2)
         return fail("kp_sim_post_step: bad arguments");
     if (c->cur_t != cur_t) return fail("kp_sim_post_step: cur_t must be the buffer the context reads (kp_ctx.cur_t)");
     HIP_OK(hipSetDevice(s->device));
     kp::RewardW W{w->w_hp, w->w_hq, w->w_p, w->w_jp, w->w_act_p, w->w_act_v, w->k_hp, w->k_hq, w->k_p, w->k_jp, w->k_act_p, w->k_act_v,
                   w->dt, w->body_diff_thresh, w->body_diff_gt_thresh, w->use_gt_term};
-    kp::PostStep PS{cur_t, row_len, env_episode_len, done, end, percent, done_count};
+    kp::PostStep PS{cur_t, row_len, env_episode_len, done, end, percent, done_count, obj7, obj7 ? s->obj_qpos : nullptr};
     hipLaunchKernelGGL(kp::k_term_reward<true>, dim3((s->n + 7) / 8), dim3(256), 0, s->stream, s->n, to_dev(c), W, s->qpos, s->xpos, s->xquat,
                        s->t_wbpos, s->t_bquat, s->prev_bquat, s->prev_hpos, s->diffw, reward, info, failp, diffs, PS);
     HIP_OK(hipGetLastError());
@@ -718,9 +729,18 @@ int kp_sim_post_step(kp_sim* s, const kp_ctx* c, const kp_reward_cfg* w, int32_t
 }
 
 int kp_sim_reset_rows(kp_sim* s, const float* init_qpos, const float* init_qvel, const int32_t* row, const uint8_t* mask, int32_t* cur_t, int set_target,
-                      float* aux_rows, int aux_cols) {
+                      float* aux_rows, int aux_cols, const float* row_obj_qpos, const float* row_action_one_hot, float* obj7) {
     if (!s || !init_qpos || !init_qvel || (aux_rows && aux_cols <= 0)) return fail("kp_sim_reset_rows: null argument");
+    if (obj7 && !row_obj_qpos) return fail("kp_sim_reset_rows: obj7 needs row_obj_qpos");
     HIP_OK(hipSetDevice(s->device));
+    if (row_obj_qpos) {       // the object block of reset_model (humanoid_ar_v1.py:377-382) from the env's context row, before sim.forward()
+        if (!s->d_obj_geoms) return fail("kp_sim_reset_rows: the model blob has no object geoms");
+        const int dynamic = s->model->dynamic_objects && s->T.obj_inertial != nullptr;
+        hipLaunchKernelGGL(k_set_objects, dim3((s->n + 63) / 64), dim3(64), 0, s->stream, s->n, row_obj_qpos, mask, s->obj_qpos, s->geoms, s->ngeom,
+                           s->d_obj_geoms, s->d_obj_mass, s->n_obj_geoms, s->n_obj, dynamic, s->obj_slot, s->obj_qvel, s->obj_warm, row, row_action_one_hot, obj7);
+        HIP_OK(hipGetLastError());
+        s->has_objects = true;
+    }
     hipLaunchKernelGGL(kp::k_reset_rows, dim3(s->n), dim3(128), 0, s->stream, s->n, init_qpos, init_qvel, row, mask, cur_t, s->qpos, s->qvel, s->qpos_d, s->qvel_d, s->warm,
                        aux_rows, aux_rows ? aux_cols : 0);
     HIP_OK(hipGetLastError());
@@ -742,6 +762,13 @@ int kp_gae_bootstrap(int n, int T, const float* rewards, const float* masks, con
 }
 int kp_gae(int n, int T, const float* rewards, const float* masks, const float* values, float gamma, float tau, float* adv, float* ret, void* stream) {
     return kp_gae_bootstrap(n, T, rewards, masks, values, nullptr, gamma, tau, adv, ret, stream);
+}
+
+int kp_pool_advance(int n, int n_slots, const uint8_t* done, int32_t* head, int32_t* ahead, int32_t* row, void* stream) {
+    if (n <= 0 || n_slots <= 0 || !done || !head || !ahead || !row) return fail("kp_pool_advance: bad arguments");
+    hipLaunchKernelGGL(kp::k_pool_advance, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, n_slots, done, head, ahead, row);
+    HIP_OK(hipGetLastError());
+    return 0;
 }
 
 int kp_mcp_compose(int n, int K, int A, const float* logits, const float* prim, const float* noise, int noise_stride, const float* stdv, float* out, void* stream) {

@@ -149,14 +149,21 @@ class StateARDataset:
         p = np.exp(-e / sampling_temp)
         return p / p.sum()
 
-    def sample_batch(self, n, freq_dict=None, use_freq=True, full_sample=False, sampling_temp=0.5, sampling_freq=0.9):
+    @property
+    def has_objects(self):
+        """does any take carry an action object (action_one_hot != 0)?  host-side, evaluated once"""
+        if getattr(self, "_has_obj", None) is None:
+            self._has_obj = any(bool((a.abs().sum() > 0).item()) for a in self.data["action_one_hot"])
+        return self._has_obj
+
+    def sample_batch(self, n, freq_dict=None, use_freq=True, full_sample=False, sampling_temp=0.5, sampling_freq=0.9, probs=None):
         """n independent `sample_seq` draws (:264-327) -> dict of [n, fr_num, .] tensors (+ 'take_ind', 'fr_start').  The draws are made as
         arrays (one rng call per quantity, not per row): the same distributions as n sequential sample_seq calls."""
         starts = np.zeros(n, np.int64)
         if use_freq and freq_dict is None:
             inds = self.rng.choice(self.freq_indices, size=n)
         elif use_freq:
-            probs = self.take_probs(freq_dict, sampling_temp)
+            probs = self.take_probs(freq_dict, sampling_temp) if probs is None else probs      # probs: the caller's cached take_probs(freq_dict)
             coin = self.rng.binomial(1, sampling_freq, size=n).astype(bool)
             inds = np.where(coin, self.rng.choice(self.all_indices, size=n, p=probs), self.rng.choice(self.all_indices, size=n))
             if not full_sample:
@@ -209,9 +216,11 @@ class StateARDataset:
 
 
 # ------------------------------------------------------------------ synthetic stand-in for the absent MoCap set
-def synthetic_takes(sim, std_qpos, n_per_action=2, T_range=(110, 160), body_mass=None, seed=0):
+def synthetic_takes(sim, std_qpos, n_per_action=2, T_range=(110, 160), body_mass=None, seed=0, with_objects=True):
     """standing -> seeded smooth joint-space sinusoids (amplitude <= 0.3 rad, <= 1 Hz), four action
-    classes with their object(s) at constant poses in front of / behind the humanoid, yaw U(-pi, pi)."""
+    classes with their object(s) at constant poses in front of / behind the humanoid, yaw U(-pi, pi).  with_objects=False: the same
+    motions as takes without an action (obj_pose = [0,0,0,1,0,0,0], action_one_hot = 0; process_smpl.py:223-225) -- config 3's
+    object-free MoCap clips."""
     rng = np.random.default_rng(seed)
     std_qpos = np.asarray(std_qpos, np.float64)
     obj_local = {"sit": [[0.0, -0.6, 0.3805]], "push": [[0.0, 0.8, 0.921], [0.0, 0.8, 0.7905]], "avoid": [[0.0, 1.0, 0.69]], "step": [[0.0, 0.8, 0.3705]]}
@@ -231,5 +240,8 @@ def synthetic_takes(sim, std_qpos, n_per_action=2, T_range=(110, 160), body_mass
             obj = []
             for lx, ly, lz in obj_local[a]:
                 obj += [std_qpos[0] + c * lx - s_ * ly, std_qpos[1] + s_ * lx + c * ly, lz, *qz]
-            takes[f"{a}-synthetic-{j:02d}"] = build_take_features(sim, q, np.tile(np.array(obj), (T, 1)), a, body_mass)
+            if with_objects:
+                takes[f"{a}-synthetic-{j:02d}"] = build_take_features(sim, q, np.tile(np.array(obj), (T, 1)), a, body_mass)
+            else:
+                takes[f"none-synthetic-{a}-{j:02d}"] = build_take_features(sim, q, None, None, body_mass)
     return takes

@@ -67,8 +67,9 @@ class BatchedHumanoidAREnv:
         self.row = None           # int32 [N]: context row every env reads (load_context / set_rows)
         self.row_len = None       # int32 [R]: ar_context['len'] of every row
         self.row_meta = None      # [R, 2]: take index, first frame of every row (v_meta of the reference's memory rows)
-        self.obj_qpos = None      # [N,35] = data.qpos[76:111] (convert_obj_qpos)
-        self.obj7 = None          # [N,7]  = get_obj_qpos(action_one_hot)
+        self.obj_qpos = None      # not None: the clips carry action objects and the simulator holds data.qpos[76:111] (sim.get('obj_qpos'))
+        self.obj7 = None          # [N,7]  = get_obj_qpos(action_one_hot), kept by kp_sim_reset_rows / kp_sim_post_step
+        self._row_obj_qpos = None  # [R,35] = convert_obj_qpos(action_one_hot, obj_pose[0]) of every context row
         self._ctx_struct = None
         self.end_reward = 0.0
         self.action_dim, self.obs_dim, self.cc_action_dim = 80, kpsim.AR_OBS_DIM, kpsim.CC_ACTION_DIM
@@ -92,6 +93,95 @@ class BatchedHumanoidAREnv:
         self.mode = mode
         self.reward_cfg.use_gt_term = int(mode == "train" and not self.wild)
 
+    def alloc_context(self, R: int, T: int, objects: bool = False, with_ar: bool = False, obj_width: int = 14):
+        """Empty context tables [R, T, .] (R a multiple of n_envs) that `write_context_rows` fills in place: what a sampler that keeps the next
+        episodes' clips resident allocates once (VectorSampler's ring of pool_depth + 1 rows per env).  objects: the clips carry action objects
+        (the per-row object block of reset_model is kept next to them); with_ar: room for the kinematic roll-out (ar_qpos / ar_qvel: ar_mode,
+        ar_fail_safe, evaluation)."""
+        if R % self.n != 0:
+            raise ValueError(f"context rows ({R}) must be a multiple of n_envs ({self.n})")
+        dev = self.device
+        z = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)  # noqa: E731
+        self.ctx = {"qpos": z(R, T, 76), "head_pose": z(R, T, 7), "head_vels": z(R, T, 6), "obj_head_relative_poses": z(R, T, 7), "action_one_hot": z(R, 4),
+                    "init_qpos": z(R, 76), "init_qvel": z(R, 75), "gt_bquat": z(R, T, 96), "gt_wbpos": z(R, T, 72)}
+        if objects:
+            self.ctx["obj_pose"] = z(R, T, obj_width)
+        if with_ar or self.ar_mode:
+            self.ctx["ar_qpos"], self.ctx["ar_qvel"] = z(R, T, 76), z(R, T, 75)
+        self.row_len = torch.full((R,), T - 1, dtype=torch.int32, device=dev)
+        self.row_meta = z(R, 2)
+        self.row = torch.arange(self.n, device=dev, dtype=torch.int32)
+        self._row_obj_qpos = self.obj7 = self.obj_qpos = None
+        if objects:
+            self._alloc_objects(R)
+        self._bind_context()
+
+    def _alloc_objects(self, R):
+        # data.qpos[76:111] of every row as reset_model builds it (convert_obj_qpos); obj7 [N,7] = get_obj_qpos(action_one_hot) per env, kept by
+        # kp_sim_reset_rows / kp_sim_post_step; obj_qpos: the flag "this env simulates objects" for callers (the poses live in the simulator: sim.get('obj_qpos'))
+        self._row_obj_qpos = convert_obj_qpos(torch.zeros((R, 4), device=self.device), torch.zeros((R, 7), device=self.device))[0]
+        self.obj7 = torch.tensor([0.0, 0, 0, 1, 0, 0, 0], device=self.device).repeat(self.n, 1).contiguous()
+        self.obj_qpos = True
+
+    def _bind_context(self):
+        c = self.ctx
+        T = c["qpos"].shape[1]
+        self._ctx_struct = self.sim.make_ctx(T, c["head_pose"], c["head_vels"], c["obj_head_relative_poses"], c["action_one_hot"],
+                                             c["gt_bquat"], c["gt_wbpos"], self.cur_t, obj_qpos=self.obj7, row=self.row)
+        # rows a reset starts from (reset_model, humanoid_ar_v1.py:339-341): the kinematic roll-out's first frame in ar_mode, else init_qpos / init_qvel
+        if self.ar_mode:
+            self._init_q, self._init_v = c["ar_qpos"][:, 0].contiguous(), c["ar_qvel"][:, 0].contiguous()
+        else:
+            self._init_q, self._init_v = c["init_qpos"], c["init_qvel"]
+
+    def write_context_rows(self, rows: torch.Tensor, data: dict):
+        """Overwrite the context rows `rows` (int64 [m]) in place with m freshly drawn clips: data[k] is [m, T', .] with T' <= the tables' T (shorter
+        clips are padded with their last frame, as StateARDataset.batch pads), action_one_hot [m, T', 4] or [m, 4], init_qpos / init_qvel [m, .],
+        optional len [m], take_ind / fr_start [m], obj_pose, ar_qpos / ar_qvel.  The GT clip's FK (load_context's gt_targets, humanoid_ar_v1.py:87)
+        is computed for those rows only.  Envs that are playing one of these rows must be reset afterwards."""
+        c, dev = self.ctx, self.device
+        rows = rows.to(dev, torch.int64)
+        m, T = rows.numel(), c["qpos"].shape[1]
+        if m == 0:
+            return
+
+        def fit(v):                                  # [m, T', .] -> [m, T, .]
+            v = v.to(dev, torch.float32)
+            if v.dim() == 3 and v.shape[1] < T:
+                v = torch.cat([v, v[:, -1:].expand(-1, T - v.shape[1], -1)], 1)
+            return v
+        if data["qpos"].shape[1] > T:
+            raise ValueError(f"clips of {data['qpos'].shape[1]} frames do not fit context tables of {T}")
+        one_hot = data["action_one_hot"].to(dev, torch.float32)
+        if one_hot.dim() == 3:
+            one_hot = one_hot[:, 0]
+        for k in ("qpos", "head_pose", "head_vels", "obj_head_relative_poses", "init_qpos", "init_qvel"):
+            c[k].index_copy_(0, rows, fit(data[k]))
+        c["action_one_hot"].index_copy_(0, rows, one_hot)
+        for k in ("ar_qpos", "ar_qvel"):
+            if k in c:
+                if k not in data:
+                    raise ValueError(f"this env needs ctx['{k}'] (ar_mode / tables allocated with_ar)")
+                c[k].index_copy_(0, rows, fit(data[k]))
+        gt = self.sim.fk(fit(data["qpos"]).reshape(-1, 76).contiguous())
+        c["gt_bquat"].index_copy_(0, rows, gt["bquat"].view(m, T, 96))
+        c["gt_wbpos"].index_copy_(0, rows, gt["wbpos"].view(m, T, 72))
+        lens = data.get("len")
+        new_len = torch.full((m,), T - 1, dtype=torch.int32, device=dev) if lens is None else torch.as_tensor(lens, device=dev).to(torch.int32) - 1
+        self.row_len.index_copy_(0, rows, new_len)
+        meta = torch.stack([torch.as_tensor(data[k]).to(dev, torch.float32) if k in data else torch.zeros(m, device=dev) for k in ("take_ind", "fr_start")], 1)
+        self.row_meta.index_copy_(0, rows, meta)
+        if self._row_obj_qpos is not None:
+            if "obj_pose" in data:
+                op = fit(data["obj_pose"])
+                if "obj_pose" in c and op.shape[2] == c["obj_pose"].shape[2]:
+                    c["obj_pose"].index_copy_(0, rows, op)
+                self._row_obj_qpos.index_copy_(0, rows, convert_obj_qpos(one_hot, op[:, 0])[0])
+            else:
+                self._row_obj_qpos.index_copy_(0, rows, convert_obj_qpos(torch.zeros_like(one_hot), torch.zeros((m, 7), device=dev))[0])
+        if self.ar_mode:
+            self._init_q.index_copy_(0, rows, c["ar_qpos"][rows, 0]); self._init_v.index_copy_(0, rows, c["ar_qvel"][rows, 0])
+
     def load_context(self, ctx: dict, env_mask: torch.Tensor | None = None, row: torch.Tensor | None = None, keep_state: bool = False):
         """ctx tensors are [R, T, .] (action_one_hot [R, T, 4] or [R, 4]; init_qpos/init_qvel [R, .]) with R = n_envs context rows,
         or -- for a sampler that keeps the next episodes' clips resident -- R = k * n_envs rows with `row` (int32 [N]) naming the
@@ -106,78 +196,41 @@ class BatchedHumanoidAREnv:
             raise ValueError(f"context rows ({R}) must be a multiple of n_envs ({self.n})")
         if env_mask is not None and (R != self.n or row is not None):
             raise ValueError("masked load_context works on one row per env")
-        new = {k: ctx[k].to(self.device, torch.float32) for k in CTX_KEYS}
-        if new["action_one_hot"].dim() == 3:
-            new["action_one_hot"] = new["action_one_hot"][:, 0]
-        for k in ("obj_pose", "ar_qpos", "ar_qvel"):
-            if k in ctx:
-                new[k] = ctx[k].to(self.device, torch.float32)
+        lens = ctx.get("len")
+        if lens is not None:
+            lt = torch.as_tensor(lens)
+            if int(lt.max()) > T or int(lt.min()) < 2:
+                raise ValueError("ctx['len'] must lie in [2, T]")
+        one_hot = ctx["action_one_hot"] if ctx["action_one_hot"].dim() == 2 else ctx["action_one_hot"][:, 0]
+        has_obj = "obj_pose" in ctx and bool((one_hot.sum(1) > 0).any())
         fresh = self.ctx is None or env_mask is None or self.ctx["qpos"].shape[:2] != (R, T)
         if fresh:
             if env_mask is not None and self.ctx is not None:
                 raise ValueError("masked load_context needs the same clip length T")
-            self.ctx = {k: v.contiguous().clone() for k, v in new.items()}
-            rows = self.ctx["qpos"].reshape(-1, 76).contiguous()
-            gt = self.sim.fk(rows)
-            self.ctx["gt_bquat"] = gt["bquat"].view(R, T, 96).contiguous()
-            self.ctx["gt_wbpos"] = gt["wbpos"].view(R, T, 72).contiguous()
+            obj7_before = self.obj7 if keep_state else None
+            self.alloc_context(R, T, objects=has_obj, with_ar="ar_qpos" in ctx, obj_width=ctx["obj_pose"].shape[2] if "obj_pose" in ctx else 14)
+            if row is not None:
+                self.row.copy_(row.to(self.device, torch.int32))
+            self.write_context_rows(torch.arange(R, device=self.device), ctx)
+            if self.obj7 is not None:
+                if obj7_before is not None:
+                    self.obj7.copy_(obj7_before)       # the simulated objects stay where they are
+                else:                                  # before the first reset: the clip's own object pose
+                    r = self.row.long()
+                    start = torch.tensor(ACTION_INDEX_MAP, device=self.device)[self.ctx["action_one_hot"][r].argmax(1)]
+                    got = torch.gather(self._row_obj_qpos[r], 1, start[:, None] + torch.arange(7, device=self.device)[None])
+                    self.obj7.copy_(torch.where(self.ctx["action_one_hot"][r].sum(1, keepdim=True) > 0, got, self.obj7))
         else:
-            m = env_mask.to(self.device, torch.bool)
-            idx = m.nonzero(as_tuple=True)[0]
-            if idx.numel():
-                for k, v in new.items():
-                    self.ctx[k][idx] = v[idx]
-                rows = self.ctx["qpos"][idx].reshape(-1, 76).contiguous()
-                gt = self.sim.fk(rows)
-                self.ctx["gt_bquat"][idx] = gt["bquat"].view(-1, T, 96)
-                self.ctx["gt_wbpos"][idx] = gt["wbpos"].view(-1, T, 72)
-        lens = ctx.get("len")
-        if lens is None:
-            new_len = torch.full((R,), T - 1, dtype=torch.int32, device=self.device)
-        else:
-            new_len = torch.as_tensor(lens, device=self.device).to(torch.int32) - 1
-            if int(new_len.max()) > T - 1 or int(new_len.min()) < 1:
-                raise ValueError("ctx['len'] must lie in [2, T]")
-        if fresh or self.row_len is None:
-            self.row_len = new_len
-        else:
-            self.row_len = torch.where(env_mask.to(self.device, torch.bool), new_len, self.row_len)
-        # per-row episode meta (v_meta of push_memory, agent_ar.py:627-631): take index, first frame; optional
-        self.row_meta = torch.stack([torch.as_tensor(ctx[k]).to(self.device, torch.float32) if k in ctx else torch.zeros(R, device=self.device)
-                                     for k in ("take_ind", "fr_start")], 1) if fresh or self.row_meta is None else self.row_meta
-        if fresh:
-            self.row = (torch.arange(self.n, device=self.device, dtype=torch.int32) if row is None else row.to(self.device, torch.int32).contiguous().clone())
-        c = self.ctx
-        if "obj_pose" in c and bool((c["action_one_hot"].sum(1) > 0).any()):
-            # data.qpos[76:111] of every row as reset_model builds it (convert_obj_qpos) + which 7 columns get_obj_qpos(action_one_hot) reads
-            self._row_obj_qpos, self._row_obj7 = convert_obj_qpos(c["action_one_hot"], c["obj_pose"][:, 0])
-            a_idx = c["action_one_hot"].argmax(1)
-            self._row_obj_has = c["action_one_hot"].sum(1) > 0
-            start = torch.tensor(ACTION_INDEX_MAP, device=self.device)[a_idx]
-            self._row_obj_cols = start[:, None] + torch.arange(7, device=self.device)[None]
-            r = self.row.long()
-            if not (keep_state and self.obj7 is not None):
-                self.obj_qpos, self.obj7 = self._row_obj_qpos[r].contiguous(), self._row_obj7[r].contiguous()
-                self._obj_has, self._obj_cols = self._row_obj_has[r].contiguous(), self._row_obj_cols[r].contiguous()
-                self._obj35 = torch.empty((self.n, 35), dtype=torch.float32, device=self.device)
-        else:
-            self.obj_qpos = self.obj7 = None
-        self._ctx_struct = self.sim.make_ctx(T, c["head_pose"], c["head_vels"], c["obj_head_relative_poses"], c["action_one_hot"],
-                                             c["gt_bquat"], c["gt_wbpos"], self.cur_t, obj_qpos=self.obj7, row=self.row)
-        # rows a reset starts from (reset_model, humanoid_ar_v1.py:339-341): the kinematic roll-out's first frame in ar_mode, else init_qpos / init_qvel
-        if self.ar_mode:
-            self._init_q, self._init_v = c["ar_qpos"][:, 0].contiguous(), c["ar_qvel"][:, 0].contiguous()
-        else:
-            self._init_q, self._init_v = c["init_qpos"].contiguous(), c["init_qvel"].contiguous()
-        self._refresh_len()
+            idx = env_mask.to(self.device, torch.bool).nonzero(as_tuple=True)[0]
+            if has_obj and self._row_obj_qpos is None:             # the first clips with objects arrive through a masked load
+                self._alloc_objects(R)
+                self._bind_context()
+            self.write_context_rows(idx, {k: (v.to(self.device)[idx] if torch.is_tensor(v) and v.shape[:1] == (R,) else v) for k, v in ctx.items()})
 
     @property
     def ctx_len(self):
-        """ar_context['len'] of every env's current clip (int32 [N]); cached, refreshed when rows or lengths change."""
-        return self._clen
-
-    def _refresh_len(self):
-        self._clen = self.row_len[self.row.long()]
+        """ar_context['len'] of every env's current clip (int32 [N])."""
+        return self.row_len[self.row.long()]
 
     def set_rows(self, new_row: torch.Tensor, env_mask: torch.Tensor | None = None):
         """Put the masked envs on other context rows (device op, no copy): the new episode's clip of agent_ar.py:519-535.
@@ -187,7 +240,6 @@ class BatchedHumanoidAREnv:
             self.row.copy_(nr)
         else:
             self.row.copy_(torch.where(env_mask.to(self.device, torch.bool), nr, self.row))
-        self._refresh_len()
 
     def ctx_rows(self, key):
         """ctx[key] gathered to the envs' current rows: [N, ...]."""
@@ -202,23 +254,13 @@ class BatchedHumanoidAREnv:
         return (m.view(torch.uint8) if m.dtype == torch.bool else m.to(torch.uint8)).contiguous()
 
     def reset(self, env_mask: torch.Tensor | None = None, policy_state: torch.Tensor | None = None):
-        """sim.reset(); cur_t = 0; reset_model(): state <- ar_context init_qpos/init_qvel, target = FK(init) (:334-387).  The humanoid's part is
-        one gather launch + sim.forward() + the target FK (kp_sim_reset_rows).  policy_state [N, H] (optional): the caller's recurrent policy
-        state, zeroed in place for the same envs by that launch (PolicyAR.reset at every episode start, policy_ar.py:124-131)."""
+        """sim.reset(); cur_t = 0; reset_model(): state <- ar_context init_qpos/init_qvel (+ the clip's object block, convert_obj_qpos), target =
+        FK(init) (:334-387): one gather launch for the humanoid, one for the objects, sim.forward() and the target FK (kp_sim_reset_rows).
+        policy_state [N, H] (optional): the caller's recurrent policy state, zeroed in place for the same envs by that launch (PolicyAR.reset at
+        every episode start, policy_ar.py:124-131)."""
         m8 = self._mask8(env_mask, self.device)
-        if self.obj_qpos is not None:
-            mb = None if m8 is None else m8.view(torch.bool)
-            r = self.row.long()
-            if mb is None:
-                self.obj_qpos.copy_(self._row_obj_qpos[r]); self._obj_has.copy_(self._row_obj_has[r]); self._obj_cols.copy_(self._row_obj_cols[r])
-            else:
-                self.obj_qpos.copy_(torch.where(mb[:, None], self._row_obj_qpos[r], self.obj_qpos))
-                self._obj_has.copy_(torch.where(mb, self._row_obj_has[r], self._obj_has))
-                self._obj_cols.copy_(torch.where(mb[:, None], self._row_obj_cols[r], self._obj_cols))
-            self.sim.set_objects(self.obj_qpos, m8)
-            fresh = torch.where(self._obj_has[:, None], torch.gather(self.obj_qpos, 1, self._obj_cols), self._row_obj7[r])
-            self.obj7.copy_(fresh if mb is None else torch.where(mb[:, None], fresh, self.obj7))
-        self.sim.reset_rows(self._init_q, self._init_v, self.row, m8, self.cur_t, set_target=True, aux_rows=policy_state)
+        self.sim.reset_rows(self._init_q, self._init_v, self.row, m8, self.cur_t, set_target=True, aux_rows=policy_state,
+                            row_obj_qpos=self._row_obj_qpos, row_one_hot=None if self._row_obj_qpos is None else self.ctx["action_one_hot"], obj7=self.obj7)
         return self.sim.obs_ar(self._ctx_struct, self._obs)
 
     def _ar_frame(self, key):
@@ -246,14 +288,11 @@ class BatchedHumanoidAREnv:
         with torch.no_grad():
             cc_action = self.cc_policy.select_action(cc_obs, mean_action, self.gen, cc_noise).contiguous()
         sim.step_ctrl(cc_action, self.frame_skip)
-        if self.obj7 is not None:
-            sim.get("obj_qpos", self._obj35)
-            self.obj7.copy_(torch.where(self._obj_has[:, None], torch.gather(self._obj35, 1, self._obj_cols), self.obj7))
-        # cur_t += 1; fail (body diffs), reward, end / done / percent in one launch (:288-316)
+        # cur_t += 1; fail (body diffs), reward, end / done / percent, and the action object's simulated pose for the next observation, in one launch (:288-316)
         self._flip ^= 1
         o = self._outs[self._flip]
         sim.post_step(self._ctx_struct, self.reward_cfg, self.cur_t, self.row_len, int(min(self.env_episode_len, 2 ** 31 - 1)),
-                      o["reward"], o["info"], o["fail"], o["diffs"], o["done"], o["end"], o["percent"], self.done_count)
+                      o["reward"], o["info"], o["fail"], o["diffs"], o["done"], o["end"], o["percent"], self.done_count, self.obj7)
         obs = sim.obs_ar(self._ctx_struct, self._obs_next) if need_obs else None
         info = {"fail": o["fail"].view(torch.bool), "end": o["end"].view(torch.bool), "percent": o["percent"], "cc_action": cc_action, "cc_state": cc_obs,
                 "custom_reward": o["reward"], "custom_info": o["info"], "body_diff": o["diffs"]}

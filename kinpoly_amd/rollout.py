@@ -12,7 +12,8 @@ Episode semantics follow sample_worker (agent_ar.py:518-606): every episode draw
 (`sample_seq` -> `init_context` -> `load_context` -> `reset`), runs until `done`, and leaves `[percent, fr_start]` in the
 take's `freq_dict` entry, which steers the next draws.  The draws of the NEXT episodes are made ahead of the rollout, batched
 (`EpisodeSource`: N clips + one batched init_context per pool level), and kept resident as extra context rows; a finished env
-moves to its next row on the device (no host sync inside the loop).  What differs, by construction of a lock-step sampler: the
+moves to its next row on the device; one host read every `pool_depth` steps tells the sampler how many queued clips were used up, and
+exactly that many are drawn and written in place, so the pool never runs dry and no clip is played twice.  What differs, by construction of a lock-step sampler: the
 horizon T is fixed, so an episode can straddle two sample() calls -- its hidden state is carried over (`RolloutBatch.hx0`) and
 the cut is bootstrapped with V (kp_gae_bootstrap) instead of being forced terminal.
 """
@@ -51,24 +52,41 @@ class RolloutBatch:
     episodes: dict = field(default_factory=dict)   # finished episodes: take_ind, fr_start, percent (numpy), for freq_dict
 
 
+def _agree_status(status: int, device, group=None) -> int:
+    """max of a per-rank status word over the job (one tiny all-reduce), so that every rank raises -- or none does -- and no rank is left
+    waiting in the next collective for one that threw."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        t = torch.tensor([int(status)], dtype=torch.int32, device=device if dist.get_backend(group) == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        return int(t.item())
+    return int(status)
+
+
 class EpisodeSource:
     """`sample_seq` + `init_context` for n episodes at once (agent_ar.py:519-533).
 
     dataset: kinpoly_amd.dataset.StateARDataset (or None with `context_fn(n) -> dict`); ctx_builder: PolicyARContext or None
     (contexts already carry init_qpos / init_qvel).  Keeps the reference's `freq_dict` (take -> list of [percent, fr_start],
-    last 5000 kept, agent_ar.py:668-676) and passes it with sampling_temp / sampling_freq to every draw."""
+    last 5000 kept, agent_ar.py:668-676) and passes it with sampling_temp / sampling_freq to every draw.  As in the reference, the
+    dict changes only BETWEEN sample() calls (the forked workers draw from the copy they were started with and the agent merges their
+    lists afterwards, agent_ar.py:664-673): the take probabilities are evaluated once per version of the dict."""
 
     def __init__(self, dataset=None, ctx_builder=None, context_fn=None, sampling_temp=0.5, sampling_freq=0.9, fix_height=False):
         assert (dataset is None) != (context_fn is None), "give a dataset or a context_fn"
         self.dataset, self.ctx_builder, self.context_fn = dataset, ctx_builder, context_fn
         self.sampling_temp, self.sampling_freq, self.fix_height = sampling_temp, sampling_freq, fix_height
         self.freq_dict = {k: [] for k in dataset.takes} if dataset is not None else {}
+        self._probs = None
+        self.n_drawn = 0          # clips drawn so far (every one of them went through init_context when there is a ctx_builder)
 
     def draw(self, n: int, device) -> dict:
         if self.dataset is not None:
-            data = self.dataset.sample_batch(n, freq_dict=self.freq_dict, sampling_temp=self.sampling_temp, sampling_freq=self.sampling_freq)
+            if self._probs is None:
+                self._probs = self.dataset.take_probs(self.freq_dict, self.sampling_temp)
+            data = self.dataset.sample_batch(n, freq_dict=self.freq_dict, sampling_temp=self.sampling_temp, sampling_freq=self.sampling_freq, probs=self._probs)
         else:
             data = self.context_fn(n)
+        self.n_drawn += n
         data = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in data.items()}
         if self.ctx_builder is not None:
             data = self.ctx_builder.init_context(data, fix_height=self.fix_height)
@@ -96,6 +114,7 @@ class EpisodeSource:
             for ti, fs, pc in part:
                 self.freq_dict[self.dataset.takes[ti]].append([pc, fs])
         self.freq_dict = {k: (v if len(v) < 5000 else v[-5000:]) for k, v in self.freq_dict.items()}
+        self._probs = None
 
     def save_freq_dict(self, path):
         """joblib.dump(self.freq_dict, 'freq_dict.pt') of the reference (agent_ar.py:297): a pickle of {take: [[percent, fr_start], ...]}."""
@@ -104,70 +123,88 @@ class EpisodeSource:
             pickle.dump(self.freq_dict, f)
 
 
-_ROW_KEYS = ("qpos", "head_pose", "head_vels", "obj_head_relative_poses", "action_one_hot", "init_qpos", "init_qvel", "obj_pose", "ar_qpos", "ar_qvel")
+def ring_refill_plan(head: torch.Tensor, ahead: torch.Tensor, n_slots: int, total: int):
+    """Which ring rows a top-up writes.  head / ahead: int [N] (slot every env is playing, clips queued behind it); every env is brought back to
+    n_slots - 1 queued clips.  total = sum of the deficits (the caller's one host read).  Returns (env [total], row [total]) int64: env e's
+    j-th new clip goes to slot (head + ahead + 1 + j) mod n_slots, row = slot * N + e -- never the slot the env is playing.  Pure torch (CPU-testable)."""
+    N = head.shape[0]
+    dev = head.device
+    deficit = (n_slots - 1) - ahead.long()
+    ar = torch.arange(N, device=dev)
+    env_idx = torch.repeat_interleave(ar, deficit, output_size=total)
+    first = torch.cumsum(deficit, 0) - deficit                       # index of every env's first new clip in the flat list
+    j = torch.arange(total, device=dev) - first[env_idx]
+    slot = (head.long()[env_idx] + ahead.long()[env_idx] + 1 + j) % n_slots
+    return env_idx, slot * N + env_idx
 
 
 class VectorSampler:
     """Fixed-horizon lock-step sampler with device-side auto-reset (no host sync inside the loop).
 
-    Without a `source` a finished env restarts on its own clip (the synthetic single-clip configs of SURVEY 8d).  With one, every
-    episode gets a freshly drawn clip: `pool_depth` levels of N pre-drawn contexts sit behind the current ones as extra context
-    rows, `done` moves an env one level down.  An env that exhausts the pool inside one call restarts on its last clip and is
-    counted in `pool_exhausted` (size pool_depth for the shortest episodes you expect: T / mean episode length)."""
+    Without a `source` a finished env restarts on its own clip (the synthetic single-clip configs of SURVEY 8d).  With one, EVERY episode runs
+    on a freshly drawn clip, whatever the failure rate (agent_ar.py:518-535: sample_seq -> init_context -> load_context -> reset per episode):
+    every env owns a ring of `pool_depth + 1` context rows -- the clip it is on and up to pool_depth clips drawn ahead.  `done` moves the env one
+    slot on (kp_pool_advance, on the device); every pool_depth steps the sampler reads ONE number from the device -- how many queued clips
+    were used up -- draws exactly that many (one batched sample_seq + init_context), and writes them into the used-up slots in place.  An env
+    ends at most one episode per step, so between two top-ups it cannot use more than the pool_depth clips it had: the pool cannot run dry,
+    and clips that were not used stay queued across sample() calls instead of being drawn again."""
+
+    NOISE_CHUNK = 16          # exploration noise is drawn for this many steps at a time (memory does not grow with the horizon)
 
     def __init__(self, env: BatchedHumanoidAREnv, policy: KinPolicy, record_qpos: bool = False, mean_action: bool = False,
-                 source: EpisodeSource | None = None, pool_depth: int = 2, record_full: bool = False):
+                 source: EpisodeSource | None = None, pool_depth: int = 4, record_full: bool = False):
         self.env, self.policy, self.record_qpos, self.mean_action = env, policy, record_qpos or record_full, mean_action
-        self.source, self.pool_depth, self.record_full = source, int(pool_depth), record_full
+        self.source, self.pool_depth, self.record_full = source, max(1, int(pool_depth)), record_full
         self.obs = self.hx = self.fresh = None
-        self.level = None
-        self.pool_exhausted = 0
-        self._replay = None       # bool [N]: the env is re-running a clip it already finished (pool exhausted): not evidence for freq_dict
-        self.group = None         # process group of the job-wide freq_dict exchange (None = the default group)
+        self.head = self.ahead = None      # int32 [N]: ring slot every env is playing / fresh clips queued behind it
+        self._since = 0                    # steps since the last top-up
+        self.pool_exhausted = 0            # 0 by construction; kept as the counter callers report
+        self.top_ups = 0                   # host reads of the ring state so far (one per pool_depth steps)
+        self.group = None                  # process group of the job-wide freq_dict exchange (None = the default group)
 
     # ------------------------------------------------------------------ episode pool
-    def _refill(self):
-        """Row table of this call: level 0 = the clips the envs are on now, levels 1..D = freshly drawn next episodes."""
-        env, N, dev = self.env, self.env.n, self.env.device
-        levels = []
-        if env.ctx is not None and self.obs is not None:
-            r = env.row.long()
-            cur = {k: env.ctx[k][r] for k in _ROW_KEYS if k in env.ctx}
-            cur["len"] = env.row_len[r] + 1
-            cur["take_ind"], cur["fr_start"] = env.row_meta[r, 0], env.row_meta[r, 1]
-            levels.append(cur)
-        n_new = self.pool_depth + (0 if levels else 1)
-        for _ in range(n_new):
-            d = self.source.draw(N, dev)
-            T = d["qpos"].shape[1]
-            lv = {k: d[k] for k in _ROW_KEYS if k in d}
-            if lv["action_one_hot"].dim() == 3:
-                lv["action_one_hot"] = lv["action_one_hot"][:, 0]
-            lv["len"] = torch.as_tensor(d["len"], device=dev).to(torch.int32) if "len" in d else torch.full((N,), T, dtype=torch.int32, device=dev)
-            for k in ("take_ind", "fr_start"):
-                lv[k] = torch.as_tensor(d[k]).to(dev, torch.float32) if k in d else torch.zeros(N, device=dev)
-            levels.append(lv)
-        keys = [k for k in levels[0] if all(k in lv for lv in levels)]
-        # draws can come back with different clip lengths (batch() pads to the longest take of THAT draw): bring every level to the
-        # common T by repeating its last frame, as StateARDataset.batch pads, so the row table is one [R, T, .] block
-        T_all = max(lv["qpos"].shape[1] for lv in levels)
-        for lv in levels:
-            T_lv = lv["qpos"].shape[1]
-            if T_lv < T_all:
-                for k in keys:
-                    v = lv[k]
-                    if torch.is_tensor(v) and v.dim() == 3 and v.shape[1] == T_lv:
-                        lv[k] = torch.cat([v, v[:, -1:].expand(-1, T_all - T_lv, -1)], 1)
-        table = {k: torch.cat([lv[k].to(dev) for lv in levels], 0) for k in keys}
-        first = self.obs is None
-        env.load_context(table, row=torch.arange(N, device=dev, dtype=torch.int32), keep_state=not first)
-        self.level = torch.zeros(N, dtype=torch.int64, device=dev)
-        self._n_levels = len(levels)
+    @property
+    def n_slots(self):
+        return self.pool_depth + 1
+
+    def _pool_init(self):
+        """The ring: slot 0 = the clips the first episodes run on, slots 1 .. pool_depth = their successors, all freshly drawn."""
+        env, N, dev, D = self.env, self.env.n, self.env.device, self.n_slots
+        first = self.source.draw(N, dev)
+        T = first["qpos"].shape[1]
+        if self.source.dataset is not None:
+            T = max(T, int(self.source.dataset.fr_num))
+        one_hot = first["action_one_hot"]
+        objects = "obj_pose" in first and (self.source.dataset.has_objects if self.source.dataset is not None and hasattr(self.source.dataset, "has_objects")
+                                           else bool((one_hot.reshape(-1, 4).sum(1) > 0).any()))
+        env.alloc_context(D * N, T, objects=objects, with_ar="ar_qpos" in first, obj_width=first["obj_pose"].shape[2] if "obj_pose" in first else 14)
+        ar = torch.arange(N, device=dev)
+        env.write_context_rows(ar, first)
+        for s in range(1, D):
+            env.write_context_rows(ar + s * N, self.source.draw(N, dev))
+        self.head = torch.zeros(N, dtype=torch.int32, device=dev)
+        self.ahead = torch.full((N,), D - 1, dtype=torch.int32, device=dev)
+        self._since = 0
+
+    def _top_up(self):
+        """Replace the queued clips the envs used up since the last call: one host read (how many), one batched draw, in-place row writes."""
+        env, D = self.env, self.n_slots
+        self._since = 0
+        self.top_ups += 1
+        deficit = (D - 1) - self.ahead
+        total, low = torch.stack([deficit.sum(), self.ahead.min()]).tolist()
+        if low < 0:            # cannot happen: an env ends at most one episode per step and had pool_depth clips pool_depth steps ago
+            self.pool_exhausted += 1
+            raise kpsim.KinPolyNativeError("episode pool underflow: an env finished more episodes than steps since the last top-up")
+        if total == 0:
+            return
+        env_idx, rows = ring_refill_plan(self.head, self.ahead, D, int(total))
+        env.write_context_rows(rows, self.source.draw(int(total), env.device))
+        self.ahead.add_(deficit)
 
     def start(self):
         if self.source is not None:
-            self.obs = None
-            self._refill()
+            self._pool_init()
         self.obs = self.env.reset().clone()
         self.hx = self.policy.init_hidden(self.env.n, self.env.device)
         self.fresh = torch.ones(self.env.n, dtype=torch.bool, device=self.env.device)
@@ -177,8 +214,6 @@ class VectorSampler:
         env, pol, N, dev = self.env, self.policy, self.env.n, self.env.device
         if self.obs is None:
             self.start()
-        elif self.source is not None:
-            self._refill()
         f = lambda *s: torch.empty((N, T, *s), device=dev)  # noqa: E731
         S, A, R = f(105), f(80), f()
         E = torch.empty((N, T), dtype=torch.bool, device=dev); F = torch.empty((N, T), dtype=torch.bool, device=dev)
@@ -187,58 +222,55 @@ class VectorSampler:
         full = self.record_full
         NS, VM, RQ, CA, CS = (f(105), f(3), f(76), f(75), f(784)) if full else (None,) * 5
         D = torch.empty((N, T), dtype=torch.bool, device=dev); PC = f(); MT = f(2)
-        REC = torch.empty((N, T), dtype=torch.bool, device=dev)      # finished episodes that count for freq_dict (not the replays of an exhausted pool)
-        if self._replay is None:
-            self._replay = torch.zeros(N, dtype=torch.bool, device=dev)
-        ar = torch.arange(N, device=dev)
         hx0 = self.hx.clone()
         fr_num = float(env.ctx["qpos"].shape[1])
-        exhausted = torch.zeros((), dtype=torch.int64, device=dev)
-        # the exploration noise of both policies for the whole horizon in one launch: [T, N, 80 kinematic + 75 UHC]
+        # exploration noise of both policies, NOISE_CHUNK steps per launch, only the columns a sampling policy reads: [chunk, N, 80 kinematic | 75 UHC]
         cc_mean = env.mode == "test" or (env.mode == "train" and env.joint_controller)
-        noise = None if (self.mean_action and cc_mean) else torch.randn((T, N, 155), device=dev, generator=env.gen)
+        n_kin, n_cc = (0 if self.mean_action else 80), (0 if cc_mean else 75)
+        noise = None
         for t in range(T):
+            if (n_kin + n_cc) and t % self.NOISE_CHUNK == 0:
+                noise = torch.randn((min(self.NOISE_CHUNK, T - t), N, n_kin + n_cc), device=dev, generator=env.gen)
+            nz = None if noise is None else noise[t % self.NOISE_CHUNK]
             S[:, t] = self.obs
             E[:, t] = self.fresh
-            action, self.hx = pol.select_action(self.obs, self.hx, self.mean_action, env.gen, None if noise is None else noise[t, :, :80])
+            action, self.hx = pol.select_action(self.obs, self.hx, self.mean_action, env.gen, nz[:, :n_kin] if n_kin else None)
             action = action.contiguous()
             row = env.row.long()
             if self.record_qpos:
                 Q[:, t] = env.sim.get("qpos")
-                G[:, t] = env.ctx["qpos"][row, torch.minimum(env.cur_t.long() + 1, env.ctx_len.long())]
+                G[:, t] = env.ctx["qpos"][row, torch.minimum(env.cur_t.long() + 1, env.row_len[row].long())]
             meta = env.row_meta[row]
-            obs, _, done, info = env.step(action, need_obs=full, cc_noise=None if noise is None else noise[t, :, 80:])
+            obs, _, done, info = env.step(action, need_obs=full, cc_noise=nz[:, n_kin:] if n_cc else None)
             A[:, t] = action
             R[:, t] = info["custom_reward"]
             F[:, t] = info["fail"]
             D[:, t] = done; PC[:, t] = info["percent"]; MT[:, t] = meta
-            REC[:, t] = done & ~self._replay
             if full:
                 NS[:, t] = obs; RQ[:, t] = env.sim.get("qpos"); CA[:, t] = info["cc_action"]; CS[:, t] = info["cc_state"]
                 VM[:, t, :2] = meta; VM[:, t, 2] = fr_num
-            # device-side episode turnover: finished envs move to their next pre-drawn clip (masked row switch), then the masked reset
+            # device-side episode turnover: a finished env moves to the next clip of its ring (env.row in place), then the masked reset
             if self.source is not None:
-                nxt = self.level + done.long()
-                over = nxt >= self._n_levels
-                exhausted += (over & done).sum()
-                self._replay = torch.where(done, over, self._replay)     # a finished env that found no fresh clip replays its last one
-                self.level = torch.where(over, self.level, nxt)
-                env.set_rows((self.level * N + ar).to(torch.int32), done)
+                kpsim.pool_advance(done, self.head, self.ahead, env.row, self.n_slots)
             # env._obs: step() writes its own observation elsewhere, so this stays valid through the next step; the same launch zeroes the GRU state
             # of the finished envs in place (self.hx is this step's fresh output of select_action; hx0 above is a copy)
             self.obs = env.reset(done, policy_state=self.hx)
             self.fresh = D[:, t]                # `done` itself lives in a buffer the step after next reuses
+            if self.source is not None:
+                self._since += 1
+                if self._since >= self.pool_depth:
+                    self._top_up()
         M = (~D).float()
-        # one host transfer per call: finished episodes -> freq_dict, launch status
-        status = int(env.sim.status_tensor()[2])
-        if status:
-            raise kpsim.KinPolyNativeError("kp_step_queue_kernel reported a stalled job queue during the rollout (states are incomplete)")
-        self.pool_exhausted += int(exhausted)
-        dm = REC.cpu().numpy()
+        # one host transfer per call: finished episodes -> freq_dict, launch status.  Every rank takes part in the job-wide exchanges BEFORE
+        # any rank raises, so a stalled queue on one rank ends the job on all of them instead of leaving the others in a collective
+        status = _agree_status(int(env.sim.status_tensor()[2]), dev, self.group)
+        dm = D.cpu().numpy()
         eps = {"take_ind": MT[..., 0].cpu().numpy()[dm].astype(np.int64), "fr_start": MT[..., 1].cpu().numpy()[dm].astype(np.int64),
                "percent": PC.cpu().numpy()[dm].astype(np.float64)}
         if self.source is not None:
             self.source.record(eps["take_ind"], eps["fr_start"], eps["percent"], self.group)
+        if status:
+            raise kpsim.KinPolyNativeError("kp_step_queue_kernel reported a stalled job queue during the rollout on some rank (states are incomplete)")
         return RolloutBatch(S, A, R, M, E, F, Q, G, NS, torch.ones((N, T), device=dev) if full else None, VM, RQ, CA, CS, hx0, self.obs.clone(), eps)
 
 
@@ -324,6 +356,7 @@ class PPOTrainer:
         self.policy, self.value, self.group, self.cc_policy = policy, value, group, cc_policy
         self.gamma, self.tau, self.clip_epsilon, self.num_optim_epoch, self.policy_grad_clip = gamma, tau, clip_epsilon, num_optim_epoch, policy_grad_clip
         self.value_opt_niter = value_opt_niter
+        self.value_side_stream = True      # run the value net's steps on a side stream under the policy epochs (single-process device runs)
         self.opt_p = torch.optim.Adam([p for p in policy.parameters() if p.requires_grad], lr=policy_lr, weight_decay=policy_weightdecay)
         self.opt_v = torch.optim.Adam(value.parameters(), lr=value_lr, weight_decay=value_weightdecay)
         self.sched_p = lambda_lr(self.opt_p, num_epoch_fix, num_epoch)
@@ -347,9 +380,19 @@ class PPOTrainer:
         _allreduce_grads(params, self.group)
         torch.nn.utils.clip_grad_norm_(params, self.policy_grad_clip)
 
+    def _value_epochs(self, flat_states, ret, n_steps):
+        """the value net's regression steps of all epochs: `update_value` (agent_ppo.py:53-56) x n_steps.  They share nothing with the policy
+        passes (fixed targets `ret`, own optimiser), so update() runs them on a side stream underneath the policy epochs."""
+        vloss = None
+        for _ in range(n_steps):
+            vloss = (self.value(flat_states) - ret).pow(2).mean()
+            self.opt_v.zero_grad(); vloss.backward(); _allreduce_grads(list(self.value.parameters()), self.group); self.opt_v.step()
+        return vloss
+
     def update(self, batch: RolloutBatch, bootstrap: bool = True):
         N, T, _ = batch.states.shape
         flat_states = batch.states.reshape(N * T, -1)
+        flat_actions = batch.actions.reshape(N * T, -1)
         ind = None
         if batch.exps is not None:                # `ind = exps.nonzero()` (agent_ar.py:763): the rows the surrogate is taken over
             ind = batch.exps.reshape(-1).nonzero(as_tuple=False).squeeze(1)
@@ -358,22 +401,32 @@ class PPOTrainer:
         with torch.no_grad():
             values = self.value(flat_states).view(N, T)
             last_v = self.value(batch.last_states).view(N) if (bootstrap and batch.last_states is not None) else None
-            means = self.policy.unroll(batch.states, batch.episode_start, batch.hx0)
-            fixed_log_probs = self.policy.log_prob(means.reshape(N * T, -1), batch.actions.reshape(N * T, -1))
         adv, ret = estimate_advantages(batch.rewards, batch.masks, values, self.gamma, self.tau, self.group, last_v)
         adv, ret = adv.reshape(-1, 1), ret.reshape(-1, 1)
-        stats = {}
+        # value steps of all epochs on a side stream (device tensors only), policy epochs on the current one
+        side = None
+        if flat_states.is_cuda and self.value_side_stream:
+            side = torch.cuda.Stream(device=flat_states.device)
+            side.wait_stream(torch.cuda.current_stream(flat_states.device))
+            with torch.cuda.stream(side):
+                vloss = self._value_epochs(flat_states, ret, self.num_optim_epoch * self.value_opt_niter)
+        else:
+            vloss = self._value_epochs(flat_states, ret, self.num_optim_epoch * self.value_opt_niter)
+        # fixed_log_probs (agent_ar.py:758-759) is the policy's forward at the parameters the update starts from: epoch 0's own forward, reused
+        # (the reference evaluates it twice; one of its 11 policy forwards is redundant), so epoch 0's ratio is exactly 1 as it is there
+        fixed_log_probs, surr = None, None
         for _ in range(self.num_optim_epoch):
-            for _ in range(self.value_opt_niter):
-                vloss = (self.value(flat_states) - ret).pow(2).mean()
-                self.opt_v.zero_grad(); vloss.backward(); _allreduce_grads(list(self.value.parameters()), self.group); self.opt_v.step()
             means = self.policy.unroll(batch.states, batch.episode_start, batch.hx0)
-            log_probs = self.policy.log_prob(means.reshape(N * T, -1), batch.actions.reshape(N * T, -1))
+            log_probs = self.policy.log_prob(means.reshape(N * T, -1), flat_actions)
+            if fixed_log_probs is None:
+                fixed_log_probs = log_probs.detach()
             surr = ppo_surrogate(log_probs, fixed_log_probs, adv, self.clip_epsilon, ind)
             self.opt_p.zero_grad(); surr.backward()
             self._clip()
             self.opt_p.step()
-            stats = {"value_loss": float(vloss.detach()), "surr_loss": float(surr.detach())}
+        if side is not None:
+            torch.cuda.current_stream(flat_states.device).wait_stream(side)
+        stats = {"value_loss": float(vloss.detach()), "surr_loss": float(surr.detach())} if surr is not None else {}
         if self.cc_policy is not None and batch.cc_state is not None:
             stats["cc_surr_loss"] = self.update_controller(batch, adv, ind)
         return stats
@@ -396,17 +449,18 @@ class PPOTrainer:
         with torch.no_grad():
             values = self.value(flat_states).view(N, T)
             last_v = self.value(batch.last_states).view(N) if (bootstrap and batch.last_states is not None) else None
-            means = self.policy.unroll(batch.states, batch.episode_start, batch.hx0)
-            fixed_log_probs = self.policy.log_prob(means.reshape(N * T, -1), batch.actions.reshape(N * T, -1))
             tgt_wbpos = fk.wbpos(tgt)
         adv, ret = estimate_advantages(batch.rewards, batch.masks, values, self.gamma, self.tau, self.group, last_v)
         adv, ret = adv.reshape(-1, 1), ret.reshape(-1, 1)
-        stats = {}
+        stats, fixed_log_probs = {}, None
         for _ in range(self.num_optim_epoch):
             vloss = (self.value(flat_states) - ret).pow(2).mean()
             self.opt_v.zero_grad(); vloss.backward(); _allreduce_grads(list(self.value.parameters()), self.group); self.opt_v.step()
             means = self.policy.unroll(batch.states, batch.episode_start, batch.hx0).reshape(N * T, -1)
-            surr = ppo_surrogate(self.policy.log_prob(means, batch.actions.reshape(N * T, -1)), fixed_log_probs, adv, self.clip_epsilon, ind)
+            log_probs = self.policy.log_prob(means, batch.actions.reshape(N * T, -1))
+            if fixed_log_probs is None:            # the forward at the starting parameters is epoch 0's own (see update())
+                fixed_log_probs = log_probs.detach()
+            surr = ppo_surrogate(log_probs, fixed_log_probs, adv, self.clip_epsilon, ind)
             loss_step, _ = compute_loss_lite(fk, kinematic_step(curr, means), tgt, gt_wbpos=tgt_wbpos)
             if grad_alternate:
                 if epoch % 2 == 1:

@@ -36,7 +36,7 @@ ABI_SYMBOLS = [
     "kp_sim_launch_cost", "kp_job_schedule", "kp_sim_fk_backward", "kp_sim_set_stream", "kp_sim_status_device", "kp_sim_mass_matrix",
     "kp_sim_contacts", "kp_gae_bootstrap", "kp_gru_gates_forward", "kp_gru_gates_backward", "kp_sim_phase_cycles_env",
     "kp_sim_post_step", "kp_sim_reset_rows", "kp_mcp_compose", "kp_sim_step_head", "kp_model_compile", "kp_model_load_xml",
-    "kp_mcp_tail", "kp_gru_cell_step", "kp_kin_advance",
+    "kp_mcp_tail", "kp_gru_cell_step", "kp_kin_advance", "kp_pool_advance",
 ]
 
 
@@ -94,8 +94,9 @@ def load_library(path: str | None = None):
     L.kp_sim_step_begin.argtypes = [P]; L.kp_sim_step_begin.restype = C.c_int
     L.kp_sim_obs_ar.argtypes = [P, C.POINTER(KpCtx), F]; L.kp_sim_obs_ar.restype = C.c_int
     L.kp_sim_term_reward.argtypes = [P, C.POINTER(KpCtx), C.POINTER(KpRewardCfg), F, F, U8, F]; L.kp_sim_term_reward.restype = C.c_int
-    L.kp_sim_post_step.argtypes = [P, C.POINTER(KpCtx), C.POINTER(KpRewardCfg), C.c_void_p, C.c_void_p, C.c_int, F, F, U8, F, U8, U8, F, C.c_void_p]; L.kp_sim_post_step.restype = C.c_int
-    L.kp_sim_reset_rows.argtypes = [P, F, F, C.c_void_p, U8, C.c_void_p, C.c_int, F, C.c_int]; L.kp_sim_reset_rows.restype = C.c_int
+    L.kp_sim_post_step.argtypes = [P, C.POINTER(KpCtx), C.POINTER(KpRewardCfg), C.c_void_p, C.c_void_p, C.c_int, F, F, U8, F, U8, U8, F, C.c_void_p, F]; L.kp_sim_post_step.restype = C.c_int
+    L.kp_sim_reset_rows.argtypes = [P, F, F, C.c_void_p, U8, C.c_void_p, C.c_int, F, C.c_int, F, F, F]; L.kp_sim_reset_rows.restype = C.c_int
+    L.kp_pool_advance.argtypes = [C.c_int, C.c_int, U8, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]; L.kp_pool_advance.restype = C.c_int
     L.kp_mcp_tail.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, F, F, F, C.c_int, F, F, F, C.c_int, F, F, C.c_void_p]; L.kp_mcp_tail.restype = C.c_int
     L.kp_kin_advance.argtypes = [C.c_int, F, F, C.c_float, F, F, C.c_void_p]; L.kp_kin_advance.restype = C.c_int
     L.kp_gru_cell_step.argtypes = [C.c_int, C.c_int, C.c_int, F, F, F, F, F, F, F, F, C.c_void_p]; L.kp_gru_cell_step.restype = C.c_int
@@ -336,16 +337,22 @@ class KpSim:
                                          C.c_void_p(fail.data_ptr()), _ptr(diffs, self.n, 2)), "kp_sim_term_reward")
         return reward, info, fail, diffs
 
-    def post_step(self, ctx: "KpCtx", cfg: "KpRewardCfg", cur_t, row_len, episode_len, reward, info, fail, diffs, done, end, percent, done_count=None):
-        """cur_t += 1; termination + reward; end / done / percent -- the tail of HumanoidAREnv.step in one launch (kp_sim_post_step)."""
+    def post_step(self, ctx: "KpCtx", cfg: "KpRewardCfg", cur_t, row_len, episode_len, reward, info, fail, diffs, done, end, percent, done_count=None, obj7=None):
+        """cur_t += 1; termination + reward; end / done / percent -- the tail of HumanoidAREnv.step in one launch (kp_sim_post_step).
+        obj7 [N,7]: refreshed with the simulated pose of every env's action object (get_obj_qpos(action_one_hot))."""
         _check(self.L.kp_sim_post_step(self.h, C.byref(ctx), C.byref(cfg), C.c_void_p(cur_t.data_ptr()), C.c_void_p(row_len.data_ptr()), int(episode_len),
                                        C.c_void_p(reward.data_ptr()), _ptr(info, self.n, 6), C.c_void_p(fail.data_ptr()), _ptr(diffs, self.n, 2),
                                        C.c_void_p(done.data_ptr()), C.c_void_p(end.data_ptr()), C.c_void_p(percent.data_ptr()),
-                                       None if done_count is None else C.c_void_p(done_count.data_ptr())), "kp_sim_post_step")
+                                       None if done_count is None else C.c_void_p(done_count.data_ptr()), _ptr(obj7, self.n, 7)), "kp_sim_post_step")
 
-    def reset_rows(self, init_qpos, init_qvel, row=None, env_mask=None, cur_t=None, set_target=True, aux_rows=None):
+    def reset_rows(self, init_qpos, init_qvel, row=None, env_mask=None, cur_t=None, set_target=True, aux_rows=None, row_obj_qpos=None, row_one_hot=None, obj7=None):
         """masked reset from context rows: state <- init rows, cur_t = 0, sim.forward(), target = FK(init) (kp_sim_reset_rows).
-        aux_rows [N, C]: caller-owned per-env rows zeroed for the same envs (the policy's GRU state)."""
+        aux_rows [N, C]: caller-owned per-env rows zeroed for the same envs (the policy's GRU state).  row_obj_qpos [R, 35] (+ row_one_hot [R, 4],
+        obj7 [N, 7]): the object block of reset_model from the env's context row, and get_obj_qpos(action_one_hot) of it."""
+        R = init_qpos.shape[0]
+        for t, d in ((row_obj_qpos, 35), (row_one_hot, 4)):
+            if t is not None and not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == (R, d)):
+                raise ValueError(f"object row tables must be contiguous float32 device tensors [R, {d}]")
         if aux_rows is not None and not (aux_rows.is_cuda and aux_rows.dtype == torch.float32 and aux_rows.is_contiguous() and aux_rows.dim() == 2 and aux_rows.shape[0] == self.n):
             raise ValueError("aux_rows must be a contiguous float32 device tensor [N, C]")
         for t, d in ((init_qpos, NQ), (init_qvel, NV)):
@@ -353,7 +360,9 @@ class KpSim:
                 raise ValueError("init rows must be contiguous float32 device tensors [R, dim]")
         _check(self.L.kp_sim_reset_rows(self.h, C.c_void_p(init_qpos.data_ptr()), C.c_void_p(init_qvel.data_ptr()), None if row is None else C.c_void_p(row.data_ptr()),
                                         _mask_ptr(env_mask, self.n), None if cur_t is None else C.c_void_p(cur_t.data_ptr()), int(bool(set_target)),
-                                        None if aux_rows is None else C.c_void_p(aux_rows.data_ptr()), 0 if aux_rows is None else int(aux_rows.shape[1])), "kp_sim_reset_rows")
+                                        None if aux_rows is None else C.c_void_p(aux_rows.data_ptr()), 0 if aux_rows is None else int(aux_rows.shape[1]),
+                                        None if row_obj_qpos is None else C.c_void_p(row_obj_qpos.data_ptr()), None if row_one_hot is None else C.c_void_p(row_one_hot.data_ptr()),
+                                        _ptr(obj7, self.n, 7)), "kp_sim_reset_rows")
 
     def diag(self) -> np.ndarray:
         out = np.zeros((self.n, 4), np.int32)
@@ -399,6 +408,22 @@ def job_schedule(n_substeps: int, substeps_per_job: int = 4, taper: int = 1) -> 
     if n < 0:
         raise KinPolyNativeError(f"kp_job_schedule: {L.kp_last_error().decode()}")
     return list(out[:n])
+
+
+def pool_advance(done: torch.Tensor, head: torch.Tensor, ahead: torch.Tensor, row: torch.Tensor, n_slots: int):
+    """Episode turnover on a ring of n_slots context rows per env (kp_pool_advance): done uint8 / bool [N]; head, ahead, row int32 [N], in place."""
+    L = load_library()
+    n = done.shape[0]
+    if done.dtype == torch.bool:
+        done = done.view(torch.uint8)
+    for t in (head, ahead, row):
+        if not (t.is_cuda and t.dtype == torch.int32 and t.is_contiguous() and tuple(t.shape) == (n,)):
+            raise ValueError("pool_advance: head / ahead / row must be contiguous int32 device tensors [N]")
+    if not (done.is_cuda and done.dtype == torch.uint8 and done.is_contiguous()):
+        raise ValueError("pool_advance: done must be a contiguous uint8 / bool device tensor [N]")
+    stream = torch.cuda.current_stream(done.device).cuda_stream
+    _check(L.kp_pool_advance(n, int(n_slots), C.c_void_p(done.data_ptr()), C.c_void_p(head.data_ptr()), C.c_void_p(ahead.data_ptr()), C.c_void_p(row.data_ptr()),
+                             C.c_void_p(stream)), "kp_pool_advance")
 
 
 def mcp_compose(logits: torch.Tensor, prim: torch.Tensor, noise: torch.Tensor | None = None, std: torch.Tensor | None = None, out: torch.Tensor | None = None):

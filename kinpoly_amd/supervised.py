@@ -133,5 +133,5 @@ def update_supervised_step(policy, optimizer, fk: TorchFK, batch, num_epoch=20, 
         if grad_allreduce is not None:
             grad_allreduce([p for p in policy.parameters() if p.requires_grad])
         optimizer.step()
-        loss_val = float(loss.detach())
-    return loss_val
+        loss_val = loss.detach()
+    return None if loss_val is None else float(loss_val)      # one host read per call, not one per epoch

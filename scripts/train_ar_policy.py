@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--clip_len", type=int, default=100)
     ap.add_argument("--num_optim_epoch", type=int, default=10)
     ap.add_argument("--num_step_update", type=int, default=20)
+    ap.add_argument("--pool_depth", type=int, default=4, help="clips kept queued behind every env's current one (one host read per pool_depth steps)")
     ap.add_argument("--save", type=str, default="")
     ap.add_argument("--data", type=str, default="", help="feature file in the reference's schema (<data_dir>/features/<data_file>.p)")
     args = ap.parse_args()
@@ -46,9 +47,11 @@ def main():
     fk_sim = kpsim.KpSim(kpsim.KpModel(kpsim.STEP_KPM), args.num_envs, local)
     if args.data:
         ds = D.StateARDataset(args.data, fr_num=args.clip_len, seed=4 + rank, device=fk_sim.device)
-    else:       # the reference's MoCap features are not in its repository: same schema, synthetic takes
+    else:       # the reference's MoCap features are not in its repository: same schema, synthetic takes.  ONE
+        # data set for the whole job (take seed independent of the rank): the job-wide freq_dict is keyed by take name, so a name must
+        # mean the same motion on every rank; only the draw stream (dataset seed) differs per rank
         takes = D.synthetic_takes(fk_sim, std["qpos"], n_per_action=4, T_range=(args.clip_len + 10, args.clip_len + 60),
-                                  body_mass=read_kpm(kpsim.STEP_KPM)["body_mass"], seed=4 + rank)
+                                  body_mass=read_kpm(kpsim.STEP_KPM)["body_mass"], seed=4)
         ds = D.StateARDataset(takes, fr_num=args.clip_len, seed=4 + rank, device=fk_sim.device)
     if rank == 0:
         print(f"dataset: {ds.get_len()} takes, {len(ds.freq_indices)} windows of {args.clip_len} frames", flush=True)
@@ -56,7 +59,7 @@ def main():
     # every episode draws its clip through data_loader.sample_seq(freq_dict, sampling_temp, sampling_freq) (agent_ar.py:519-523): the
     # agent keeps the freq_dict and feeds each finished episode's [percent, fr_start] back (random window starts, adaptive takes)
     agent = AgentAR(args.num_envs, dataset=ds, device=local, horizon=args.horizon, num_optim_epoch=args.num_optim_epoch,
-                    num_step_update=args.num_step_update, sampling_temp=0.3, sampling_freq=0.5)
+                    num_step_update=args.num_step_update, sampling_temp=0.3, sampling_freq=0.5, pool_depth=args.pool_depth)
     for it in range(args.iters):
         info = agent.optimize_policy(it)
         if rank == 0:

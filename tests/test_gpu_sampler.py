@@ -84,6 +84,118 @@ def test_every_episode_draws_a_new_clip_and_feeds_freq_dict():
         np.testing.assert_allclose(b.curr_qpos[e, t].cpu().numpy()[7:], ds.data["qpos"][ti][fs].numpy()[7:], atol=1e-6)
 
 
+def test_every_episode_runs_on_a_fresh_clip_at_fail_rate_one():
+    """random-init networks fail (almost) every episode after one step; every one of those episodes must still run on its own
+    freshly drawn clip through init_context (agent_ar.py:518-535), the pool must not run dry (it cannot, by construction), every done flag is one
+    episode in freq_dict, and unused queued clips survive the sample() calls instead of being re-drawn."""
+    from kinpoly_amd import sim as kpsim
+    from kinpoly_amd.context import PolicyARContext, TrajARNet
+    from kinpoly_amd.env import BatchedHumanoidAREnv
+    from kinpoly_amd.rollout import EpisodeSource, VectorSampler
+    n, T, fr, depth = 64, 12, 12, 3
+    ds, fk_sim = _dataset(n, fr, seed=5)
+    assert ds.has_objects
+    torch.manual_seed(3)
+    env = BatchedHumanoidAREnv(n, 0, mode="train", seed=3)
+    net = TrajARNet().to(env.device)
+    src = EpisodeSource(dataset=ds, ctx_builder=PolicyARContext(net, fk_sim, need_rollout=False, keep_context_feat=False), sampling_temp=0.3, sampling_freq=0.5)
+    sampler = VectorSampler(env, net, source=src, pool_depth=depth, record_full=True)
+    sampler.start()
+    D = depth + 1
+    assert src.n_drawn == D * n and env.ctx["qpos"].shape[0] == D * n and "ar_qpos" not in env.ctx
+    n_done_total, pairs, first_meta = 0, [], None
+    for call in range(3):
+        b = sampler.sample(T)
+        dn = (b.masks == 0).cpu().numpy(); vm = b.v_metas.cpu().numpy()
+        n_done = int(dn.sum()); n_done_total += n_done
+        assert float(b.fails.float().mean()) > 0.9, "random-init networks should fail nearly every step"
+        assert sampler.pool_exhausted == 0 and int(sampler.ahead.min()) >= 0
+        assert len(b.episodes["percent"]) == n_done, "every done flag is one recorded episode (no replays to leave out)"
+        # T is a multiple of pool_depth: the last top-up of the call has replaced every clip used so far, and nothing more
+        assert src.n_drawn == D * n + n_done_total and int(sampler.ahead.min()) == depth
+        meta = vm[..., 0].astype(np.int64) * 100000 + vm[..., 1].astype(np.int64)          # (take, fr_start) of the clip every row ran on
+        if first_meta is not None:      # the envs' clips continue across calls (same episode unless the last row of the previous call ended it)
+            cont = ~last_done
+            assert (meta[cont, 0] == first_meta[cont]).all()
+        es = b.episode_start.cpu().numpy()
+        for e in range(n):
+            seq = [meta[e, 0]] + [meta[e, t] for t in range(1, T) if es[e, t]]
+            pairs += list(zip(seq[:-1], seq[1:]))
+        first_meta, last_done = meta[:, -1], dn[:, -1]
+    assert sum(len(v) for v in src.freq_dict.values()) == n_done_total
+    assert sampler.top_ups == 3 * T // depth
+    # consecutive episodes of an env share (take_ind, fr_start) no more often than independent draws do
+    allm = np.array([p[1] for p in pairs]); _, counts = np.unique(allm, return_counts=True)
+    chance = float(((counts / counts.sum()) ** 2).sum())
+    repeats = float(np.mean([a == b_ for a, b_ in pairs]))
+    assert len(pairs) > 1500 and repeats < 3 * chance + 0.01, (repeats, chance)
+
+
+def test_lazy_init_context_gives_the_training_episode_the_same_start():
+    """need_rollout=False / keep_context_feat=False skip work no training episode reads (humanoid_ar_v1.py:88, 339-343): init_qpos / init_qvel
+    must be what the full init_context computes."""
+    from kinpoly_amd.context import PolicyARContext, TrajARNet
+    n, fr = 24, 12
+    ds, fk_sim = _dataset(n, fr, seed=2)
+    torch.manual_seed(11)
+    net = TrajARNet().to(fk_sim.device)
+    data = {k: (v.to(fk_sim.device) if torch.is_tensor(v) else v) for k, v in ds.sample_batch(n, use_freq=False).items()}
+    full = PolicyARContext(net, fk_sim).init_context(data)
+    lazy = PolicyARContext(net, fk_sim, need_rollout=False, keep_context_feat=False).init_context(data)
+    assert "ar_qpos" in full and "ar_qpos" not in lazy and "context_feat_rnn" not in lazy
+    np.testing.assert_allclose(lazy["init_qpos"].cpu().numpy(), full["init_qpos"].cpu().numpy(), atol=2e-6)
+    np.testing.assert_allclose(lazy["init_qvel"].cpu().numpy(), full["init_qvel"].cpu().numpy(), atol=2e-6)
+    # any batch size goes through the kinematic twin in chunks
+    m = 2 * n + 5
+    data2 = {k: (v.to(fk_sim.device) if torch.is_tensor(v) else v) for k, v in ds.sample_batch(m, use_freq=False).items()}
+    big = PolicyARContext(net, fk_sim).init_context(data2)
+    assert big["ar_qpos"].shape == (m, fr, 76) and torch.isfinite(big["ar_qpos"]).all()
+    one = PolicyARContext(net, fk_sim).init_context({k: (v[n:2 * n] if torch.is_tensor(v) and v.shape[:1] == (m,) else v) for k, v in data2.items()})
+    np.testing.assert_allclose(big["ar_qpos"][n:2 * n].cpu().numpy(), one["ar_qpos"].cpu().numpy(), atol=1e-6)
+
+
+def test_object_pose_of_the_observation_follows_the_simulated_object():
+    """env.py's object bookkeeping lives behind the C ABI now (kp_sim_reset_rows / kp_sim_post_step): obj7 = get_obj_qpos(action_one_hot)
+    (humanoid_ar_v1.py:466-477) is the action's slice of the simulator's data.qpos[76:111] after every reset and step, [0,0,0,1,0,0,0] for a
+    clip without action, and the object block of a reset is convert_obj_qpos of the env's CURRENT row (:479-496)."""
+    from kinpoly_amd.env import ACTION_INDEX_MAP, BatchedHumanoidAREnv, convert_obj_qpos
+    n, fr = 32, 12
+    ds, _ = _dataset(n, fr, seed=9)
+    env = BatchedHumanoidAREnv(n, 0, mode="train", seed=9)
+    ctx = {k: (v.to(env.device) if torch.is_tensor(v) else v) for k, v in ds.sample_batch(2 * n, use_freq=False).items()}
+    ctx["action_one_hot"][:5] = 0                                   # a few clips without action
+    ctx["init_qpos"], ctx["init_qvel"] = ctx["qpos"][:, 0].contiguous(), ctx["qvel"][:, 0].contiguous()
+    env.load_context(ctx, row=torch.arange(n, dtype=torch.int32))   # 2 rows per env; start on the first n
+    one_hot = ctx["action_one_hot"][:, 0] if ctx["action_one_hot"].dim() == 3 else ctx["action_one_hot"]
+    blk_all, _ = convert_obj_qpos(one_hot, ctx["obj_pose"][:, 0])
+
+    def expect(rows):
+        sim35 = env.sim.get("obj_qpos")
+        st = torch.tensor(ACTION_INDEX_MAP, device=env.device)[one_hot[rows].argmax(1)]
+        got = torch.gather(sim35, 1, st[:, None] + torch.arange(7, device=env.device)[None])
+        none = torch.tensor([0.0, 0, 0, 1, 0, 0, 0], device=env.device).expand(n, 7)
+        return torch.where(one_hot[rows].sum(1, keepdim=True) > 0, got, none), sim35
+    env.reset()
+    rows = env.row.long()
+    want, sim35 = expect(rows)
+    assert torch.equal(env.obj7, want) and torch.equal(sim35, blk_all[rows])
+    a = torch.zeros((n, 80), device=env.device); a[:, :74] = torch.cat([ctx["qpos"][:n, 0, 2:3], env._obs[:, 1:5], ctx["qpos"][:n, 0, 7:]], 1)
+    for _ in range(2):
+        env.step(a.contiguous())
+        want, _ = expect(rows)
+        assert torch.equal(env.obj7[5:], want[5:])
+        assert torch.equal(env.obj7[:5], torch.tensor([0.0, 0, 0, 1, 0, 0, 0], device=env.device).expand(5, 7))
+    # half of the envs move to their second row and are reset: their objects are that row's, the others keep their simulated state
+    mask = torch.arange(n, device=env.device) % 2 == 0
+    before = env.sim.get("obj_qpos").clone()
+    env.set_rows(torch.arange(n, 2 * n, device=env.device), mask)
+    env.reset(mask)
+    rows2 = env.row.long()
+    want, sim35 = expect(rows2)
+    assert torch.equal(env.obj7, want)
+    assert torch.equal(sim35[mask], blk_all[rows2][mask]) and torch.equal(sim35[~mask], before[~mask])
+
+
 def test_hidden_state_carries_across_calls_and_ppo_ratio_starts_at_one():
     """episodes that continue from the previous sample() call keep their GRU state (RolloutBatch.hx0), so the means the
     update recomputes are the behaviour policy's: with mean actions the recorded actions ARE those means."""
