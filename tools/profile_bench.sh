@@ -1,11 +1,11 @@
 #!/bin/bash
 # rocprofv3 passes of the bench command itself (run ON the GPU box through gpurun, from the repo root):
 #   kernel trace + stats, then one --pmc pass per counter group (FETCH_SIZE and WRITE_SIZE do not fit one pass; no trace domains with --pmc).
-# Results land in gpurun_out/r03_prof/ ; tools/make_pmc_summary.py turns them into profiles/r03/pmc_bench_<workload>.json.
+# Results land in gpurun_out/${KP_ROUND:-r04}_prof/ ; tools/make_pmc_summary.py turns them into profiles/${KP_ROUND:-r04}/pmc_bench_<workload>.json.
 #   usage: tools/profile_bench.sh [workload]
 set -u
 WL=${1:-tracked}
-OUT=gpurun_out/r03_prof/$WL
+OUT=gpurun_out/${KP_ROUND:-r04}_prof/$WL
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 CMD="python bench.py --workload $WL --steps 30 --warmup 10 --no-cpu-baseline --no-secondary"
