@@ -356,7 +356,6 @@ class PPOTrainer:
         self.policy, self.value, self.group, self.cc_policy = policy, value, group, cc_policy
         self.gamma, self.tau, self.clip_epsilon, self.num_optim_epoch, self.policy_grad_clip = gamma, tau, clip_epsilon, num_optim_epoch, policy_grad_clip
         self.value_opt_niter = value_opt_niter
-        self.value_side_stream = True      # run the value net's steps on a side stream under the policy epochs (single-process device runs)
         self.opt_p = torch.optim.Adam([p for p in policy.parameters() if p.requires_grad], lr=policy_lr, weight_decay=policy_weightdecay)
         self.opt_v = torch.optim.Adam(value.parameters(), lr=value_lr, weight_decay=value_weightdecay)
         self.sched_p = lambda_lr(self.opt_p, num_epoch_fix, num_epoch)
@@ -382,7 +381,7 @@ class PPOTrainer:
 
     def _value_epochs(self, flat_states, ret, n_steps):
         """the value net's regression steps of all epochs: `update_value` (agent_ppo.py:53-56) x n_steps.  They share nothing with the policy
-        passes (fixed targets `ret`, own optimiser), so update() runs them on a side stream underneath the policy epochs."""
+        passes (fixed targets `ret`, own optimiser)."""
         vloss = None
         for _ in range(n_steps):
             vloss = (self.value(flat_states) - ret).pow(2).mean()
@@ -403,15 +402,11 @@ class PPOTrainer:
             last_v = self.value(batch.last_states).view(N) if (bootstrap and batch.last_states is not None) else None
         adv, ret = estimate_advantages(batch.rewards, batch.masks, values, self.gamma, self.tau, self.group, last_v)
         adv, ret = adv.reshape(-1, 1), ret.reshape(-1, 1)
-        # value steps of all epochs on a side stream (device tensors only), policy epochs on the current one
-        side = None
-        if flat_states.is_cuda and self.value_side_stream:
-            side = torch.cuda.Stream(device=flat_states.device)
-            side.wait_stream(torch.cuda.current_stream(flat_states.device))
-            with torch.cuda.stream(side):
-                vloss = self._value_epochs(flat_states, ret, self.num_optim_epoch * self.value_opt_niter)
-        else:
-            vloss = self._value_epochs(flat_states, ret, self.num_optim_epoch * self.value_opt_niter)
+        # the value net's steps of all epochs first: they share nothing with the policy passes (fixed targets, own optimiser).  Running them on a
+        # side stream underneath the policy epochs was tried in round 4 (at most 15 of 850 ms to gain) and DEADLOCKED in the second or third
+        # iteration on ROCm 7.2 / torch 2.10 (two autograd backward passes in flight on two streams; tools/micro/dbg_train_hang.py,
+        # profiles/r04/side_stream_hang.log) -- one stream.
+        vloss = self._value_epochs(flat_states, ret, self.num_optim_epoch * self.value_opt_niter)
         # fixed_log_probs (agent_ar.py:758-759) is the policy's forward at the parameters the update starts from: epoch 0's own forward, reused
         # (the reference evaluates it twice; one of its 11 policy forwards is redundant), so epoch 0's ratio is exactly 1 as it is there
         fixed_log_probs, surr = None, None
@@ -424,8 +419,6 @@ class PPOTrainer:
             self.opt_p.zero_grad(); surr.backward()
             self._clip()
             self.opt_p.step()
-        if side is not None:
-            torch.cuda.current_stream(flat_states.device).wait_stream(side)
         stats = {"value_loss": float(vloss.detach()), "surr_loss": float(surr.detach())} if surr is not None else {}
         if self.cc_policy is not None and batch.cc_state is not None:
             stats["cc_surr_loss"] = self.update_controller(batch, adv, ind)
