@@ -117,11 +117,15 @@ def rollout_steps(sampler, k, a_track=None, wild=False, follow_clip=False):
         a_noisy = None
         if a_track is not None and not wild and not follow_clip:        # the stand-in actions of the whole call in one launch, like the noise
             a_noisy = torch.add(a_track.unsqueeze(0), noise[:, :, 155:], alpha=0.04)
+        if follow_clip and getattr(env, "_clip_action", None) is None:
+            # step_ar's encoding of every clip frame (root height, [root quaternion: the env's own], 69 joint angles, zero velocities), one table per context
+            q = env.ctx["qpos"]
+            env._clip_action = torch.cat([q[..., 2:3], torch.zeros_like(q[..., :4]), q[..., 7:], torch.zeros_like(q[..., :6])], -1).contiguous()
         for t in range(k):
             action, sampler.hx = pol.select_action(sampler.obs, sampler.hx, wild, env.gen, None if wild else noise[t, :, :80])
             if follow_clip:                                      # moving clips (objects workload): the action that reproduces the clip's NEXT pose
-                qn = env._ar_frame("qpos")
-                a_track = torch.cat([qn[:, 2:3], sampler.obs[:, 1:5], qn[:, 7:], torch.zeros((env.n, 6), device=env.device)], 1)
+                a_track = env._clip_action[env.row, torch.clamp(env.cur_t + 1, max=env._clip_action.shape[1] - 1)]
+                a_track[:, 1:5] = sampler.obs[:, 1:5]
             if a_track is not None:                              # the policy's GEMMs ran; a trained policy's output stands in for theirs
                 action = a_track if wild else (a_noisy[t] if a_noisy is not None else torch.add(a_track, noise[t, :, 155:], alpha=0.04))
             obs, _, done, info = env.step(action.contiguous(), need_obs=False, cc_noise=None if wild else noise[t, :, 80:155])
@@ -466,6 +470,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    train_n = None
+    if world > 1 and not train and not args.no_secondary:
+        # the Amdahl term of a training job on N GPUs: one whole optimize_policy (sampling + all-gather of advantages / returns + data-parallel update with
+        # gradient all-reduces) timed on every rank, max over ranks
+        del sampler, env, policy
+        sampler = env = policy = None
+        torch.cuda.empty_cache()
+        r3 = train_iteration(local_rank, 4, TRAIN_HORIZON, 1, 1, barrier, args.threads_per_env, rank=rank)
+        t3 = torch.tensor([r3["elapsed"], r3["T_sample"], r3["T_update"]], device=cdev, dtype=torch.float64)
+        dist.all_reduce(t3, op=dist.ReduceOp.MAX)
+        train_n = {**{k: r3[k] for k in TRAIN_KEYS}, "T_iteration_max_over_ranks": float(t3[0]), "T_sample_max_over_ranks": float(t3[1]), "T_update_max_over_ranks": float(t3[2]),
+                   "samples_per_s_whole_job": ENVS_PER_GPU * TRAIN_HORIZON * world / float(t3[0]), "n_gpus": world}
     if rank == 0 and train:
         per_step = ENVS_PER_GPU * TRAIN_HORIZON
         out = {"metric": "env-steps/sec (whole node) at 4096 envs/GPU, 69-DoF SMPL", "value": per_step * world * args.steps / elapsed, "unit": "env-steps/s",
@@ -571,6 +587,8 @@ def main():
                 out["train_iteration"] = {"error": f"{type(ex).__name__}: {ex}"[:200]}
         else:
             del sampler, env, policy
+            if train_n is not None:
+                out["train_iteration"] = {f"4096x{TRAIN_HORIZON}_x{world}gpus": train_n}
         if world == 1 and not args.no_cpu_baseline:
             workers = min(35, os.cpu_count() or 1)
             try:

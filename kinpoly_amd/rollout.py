@@ -105,7 +105,7 @@ class EpisodeSource:
         if self.dataset is None:
             return
         mine = [[int(ti), int(fs), float(pc)] for ti, fs, pc in zip(take_ind, fr_start, percent)]
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if _collective_on(group):
             every = [None] * dist.get_world_size(group)
             dist.all_gather_object(every, mine, group=group)
         else:

@@ -44,7 +44,21 @@ def main():
     ar(one)
     torch.cuda.synchronize()
     ok3 = calls["all_gather"] == 1 and calls["all_reduce"] == 1 and float(one) == 1.0 and dist.get_backend() == "nccl"
-    print("NCCL_ONE_RANK_OK" if (ok1 and ok2 and ok3) else f"NCCL_ONE_RANK_FAIL {ok1} {ok2} {ok3} {calls}", flush=True)
+    # the job-wide freq_dict exchange (EpisodeSource.record: all_gather_object of the finished episodes, agent_ar.py:664-673) through RCCL
+    class _DS:
+        takes = ["a", "b"]
+    src = R.EpisodeSource.__new__(R.EpisodeSource)
+    src.dataset, src.freq_dict, src._probs = _DS(), {"a": [], "b": []}, None
+    ago, n_ago = dist.all_gather_object, [0]
+
+    def count_ago(*a, **k):
+        n_ago[0] += 1
+        return ago(*a, **k)
+    dist.all_gather_object = count_ago
+    src.record([0, 1, 1], [3, 5, 7], [1.0, 0.25, 0.5])
+    ok4 = n_ago[0] == 1 and src.freq_dict == {"a": [[1.0, 3]], "b": [[0.25, 5], [0.5, 7]]}
+    ok5 = R._agree_status(0, dev) == 0
+    print("NCCL_ONE_RANK_OK" if (ok1 and ok2 and ok3 and ok4 and ok5) else f"NCCL_ONE_RANK_FAIL {ok1} {ok2} {ok3} {ok4} {ok5} {calls}", flush=True)
     dist.destroy_process_group()
 
 

@@ -106,3 +106,150 @@ def pyramid_rows(n):
     """the four rows of a condim-3 pyramidal contact: n + mu t1, n - mu t1, n + mu t2, n - mu t2"""
     n, t1, t2 = make_frame(n)
     return np.stack([n + MU * t1, n - MU * t1, n + MU * t2, n - MU * t2])
+
+
+# ------------------------------------------------------------------ round 4: a box resting on the table (the data set's only box - box pair) and set0's constants
+def _obj(idx):
+    inert = KPM["obj_inertial"].reshape(-1, 13)[idx]
+    return float(inert[0]), float(inert[10]), float(inert[12])          # mass, translational invweight0, free-joint armature
+
+
+BOX_OBJ, TABLE_OBJ = 1, 2
+PUSH_BOX_MASS, PUSH_BOX_INVW, PUSH_BOX_ARM = _obj(BOX_OBJ)
+TABLE_MASS, TABLE_INVW, TABLE_ARM = _obj(TABLE_OBJ)
+_gb = _og[_og[:, 0].astype(int) == BOX_OBJ][0]
+_gt = _og[_og[:, 0].astype(int) == TABLE_OBJ]
+PUSH_BOX_BOTTOM = float(_gb[7]) - float(_gb[4])                         # z of the box's bottom face relative to its body origin (-0.22)
+TABLE_TOP = float(_gt[0][7]) + float(_gt[0][4])                         # top face of the table top (-0.09)
+TABLE_FEET = float(_gt[1][7]) - float(_gt[1][3])                        # bottom caps of the four upright leg cylinders (-0.79)
+N_LEG_CONTACTS = 12     # mjc_PlaneCylinder on an upright cylinder: the rim point along its x axis and the two points 120 degrees either side, x 4 legs
+N_BOX_CONTACTS = 4      # mjc_BoxBox, face on face: the four corners of the smaller face
+
+
+def stack_recurrence(zb0, zt0, n_steps):
+    """The push scene at rest, vertical motion only: the table on its four legs on the plane, the box lying flat on the table top.  Two unknown
+    accelerations (a_b, a_t); N_LEG_CONTACTS x 4 pyramid rows see a_t - aref(r_t, v_t) with the table's row weight (the plane has no weight),
+    N_BOX_CONTACTS x 4 rows see (a_b - a_t) - aref(r_bt, v_b - v_t) with the weight of invweight0(box) + invweight0(table)  (a contact's
+    regulariser uses the sum of the two bodies' invweight0).  The primal problem
+        min  1/2 M_b (a_b - a0_b)^2 + 1/2 M_t (a_t - a0_t)^2 + 1/2 n_t D_t min(0, a_t - ar_t)^2 + 1/2 n_bt D_bt min(0, a_b - a_t - ar_bt)^2
+    is strictly convex and piecewise quadratic: the minimiser is the solution of the one active-set case that is consistent with itself.
+    Returns (z_box, z_table) of the body origins after each substep."""
+    Mb, Mt = PUSH_BOX_MASS + PUSH_BOX_ARM, TABLE_MASS + TABLE_ARM
+    a0b, a0t = -G * PUSH_BOX_MASS / Mb, -G * TABLE_MASS / Mt
+    zb, vb, zt, vt, out = zb0, 0.0, zt0, 0.0, []
+    for _ in range(n_steps):
+        dist_t = zt + TABLE_FEET
+        dist_bt = (zb + PUSH_BOX_BOTTOM) - (zt + TABLE_TOP)
+        has_t, has_bt = dist_t <= MARGIN, dist_bt <= MARGIN
+        ct = cbt = art = arbt = 0.0
+        if has_t:
+            r = dist_t - MARGIN
+            ct, art = 4.0 * N_LEG_CONTACTS * row_weight(r, TABLE_INVW), aref(r, vt)
+        if has_bt:
+            r = dist_bt - MARGIN
+            cbt, arbt = 4.0 * N_BOX_CONTACTS * row_weight(r, PUSH_BOX_INVW + TABLE_INVW), aref(r, vb - vt)
+        sol = None
+        for act_t in ((True, False) if has_t else (False,)):
+            for act_bt in ((True, False) if has_bt else (False,)):
+                kt, kbt = (ct if act_t else 0.0), (cbt if act_bt else 0.0)
+                # gradient = 0:  Mb (ab - a0b) + kbt (ab - at - arbt) = 0 ;  Mt (at - a0t) + kt (at - art) - kbt (ab - at - arbt) = 0
+                A = np.array([[Mb + kbt, -kbt], [-kbt, Mt + kt + kbt]])
+                rhs = np.array([Mb * a0b + kbt * arbt, Mt * a0t + kt * art - kbt * arbt])
+                ab, at = np.linalg.solve(A, rhs)
+                if (not has_t or ((at - art < 0.0) == act_t)) and (not has_bt or ((ab - at - arbt < 0.0) == act_bt)):
+                    sol = (ab, at)
+        assert sol is not None
+        ab, at = sol
+        vb += H * ab; zb += H * vb
+        vt += H * at; zt += H * vt
+        out.append((zb, zt))
+    return np.array(out)
+
+
+def set0_constants(body_pos, body_ipos, parent, mass, inertia, armature, qpos_fk, quaternion_matrix3):
+    """mjModel.body_invweight0 / dof_invweight0 and the humanoid's share of stat.meaninertia as engine_setconst.c's set0 defines them, evaluated
+    from scratch at qpos0 (root at its XML position with the identity quaternion, every hinge at zero):  M = sum_b m_b Jv_b^T Jv_b +
+    Jw_b^T (R_b I_b R_b^T) Jw_b + diag(armature) with the explicit world-frame Jacobians of every body's centre of mass;
+    body_invweight0[b] = (tr(Jv M^-1 Jv^T) / 3, tr(Jw M^-1 Jw^T) / 3); dof_invweight0 = diag(M^-1), averaged over the three translational and
+    over the three rotational dofs of the free joint; meaninertia = mean of diag(M) (over ALL dofs of the scene: the caller adds the objects).
+    qpos_fk / quaternion_matrix3: the reference-pinned FK restatement (oracle/np_oracle.py)."""
+    nb = len(parent)
+    qpos0 = np.zeros(76); qpos0[:3] = body_pos[0]; qpos0[3] = 1.0
+    fk = qpos_fk(qpos0, body_pos, body_ipos, parent)
+    R = [quaternion_matrix3(q) for q in fk["wbquat"]]
+    axes, anchors, trans, body_of = [], [], [], []
+    for k in range(3):
+        axes.append(np.eye(3)[k]); anchors.append(np.zeros(3)); trans.append(True); body_of.append(0)
+    for k in range(3):
+        axes.append(R[0][:, k]); anchors.append(fk["wbpos"][0]); trans.append(False); body_of.append(0)
+    for b in range(1, nb):                                     # hinges z, y, x at the body origin; all angles are zero at qpos0
+        for k in (2, 1, 0):
+            axes.append(R[parent[b]][:, k]); anchors.append(fk["wbpos"][b]); trans.append(False); body_of.append(b)
+    nv = len(axes)
+    anc = np.zeros((nb, nb), bool)
+    for b in range(nb):
+        k = b
+        while k >= 0:
+            anc[b, k] = True; k = parent[k]
+    M = np.diag(np.asarray(armature, float).copy())
+    Js = []
+    for b in range(nb):
+        Jv, Jw = np.zeros((3, nv)), np.zeros((3, nv))
+        for d in range(nv):
+            if anc[b, body_of[d]]:
+                if trans[d]:
+                    Jv[:, d] = axes[d]
+                else:
+                    Jw[:, d] = axes[d]; Jv[:, d] = np.cross(axes[d], fk["body_com"][b] - anchors[d])
+        Ib = inertia[b]; I3 = np.array([[Ib[0], Ib[3], Ib[4]], [Ib[3], Ib[1], Ib[5]], [Ib[4], Ib[5], Ib[2]]])
+        M += mass[b] * Jv.T @ Jv + Jw.T @ (R[b] @ I3 @ R[b].T) @ Jw
+        Js.append((Jv, Jw))
+    Minv = np.linalg.inv(M)
+    body_invw = np.array([[np.trace(Jv @ Minv @ Jv.T) / 3.0, np.trace(Jw @ Minv @ Jw.T) / 3.0] for Jv, Jw in Js])
+    dof_invw = np.diag(Minv).copy()
+    dof_invw[0:3] = dof_invw[0:3].mean(); dof_invw[3:6] = dof_invw[3:6].mean()
+    return body_invw, dof_invw, np.diag(M).copy()
+
+
+def object_diag_inertia(obj_index):
+    """diag of qM for one free object at qpos0 from its XML geoms alone: 3 x (mass + armature) and the body-frame inertia about the BODY ORIGIN
+    (a free joint's rotational dofs are body-frame axes through the body origin) of the explicit-mass boxes / z-cylinders, + armature."""
+    gs = _og[_og[:, 0].astype(int) == obj_index]
+    arm = float(KPM["obj_inertial"].reshape(-1, 13)[obj_index][12])
+    m_tot, I = 0.0, np.zeros((3, 3))
+    for g in gs:
+        typ, size, pos, R, m = int(g[1]), g[2:5], g[5:8], g[8:17].reshape(3, 3), float(g[17])
+        if typ == 0:
+            a, b, c = size
+            Il = np.diag([m / 3.0 * (b * b + c * c), m / 3.0 * (a * a + c * c), m / 3.0 * (a * a + b * b)])
+        else:
+            r, hh = size[0], size[1]
+            Il = np.diag([m * (3 * r * r + 4 * hh * hh) / 12.0, m * (3 * r * r + 4 * hh * hh) / 12.0, m * r * r / 2.0])
+        I += R @ Il @ R.T + m * (pos @ pos * np.eye(3) - np.outer(pos, pos))
+        m_tot += m
+    return np.concatenate([np.full(3, m_tot + arm), np.diag(I) + arm])
+
+
+def object_invweight(obj_index):
+    """body_invweight0 (translational, rotational) of one free object by set0's definition: its 6 x 6 joint-space inertia at qpos0 (translation
+    of the BODY ORIGIN along world axes, rotation about body axes through the origin; the centre of mass sits at c, so the two couple through
+    m [c]x), + armature on the diagonal, and the centre-of-mass Jacobian Jv = [1, -[c]x], Jw = [0, 1]."""
+    gs = _og[_og[:, 0].astype(int) == obj_index]
+    arm = float(KPM["obj_inertial"].reshape(-1, 13)[obj_index][12])
+    m = float(gs[:, 17].sum())
+    c = (gs[:, 17:18] * gs[:, 5:8]).sum(0) / m
+    Io = np.zeros((3, 3))                      # inertia about the body origin
+    for g in gs:
+        typ, size, pos, R, mg = int(g[1]), g[2:5], g[5:8], g[8:17].reshape(3, 3), float(g[17])
+        if typ == 0:
+            a, b, cc = size
+            Il = np.diag([mg / 3.0 * (b * b + cc * cc), mg / 3.0 * (a * a + cc * cc), mg / 3.0 * (a * a + b * b)])
+        else:
+            r, hh = size[0], size[1]
+            Il = np.diag([mg * (3 * r * r + 4 * hh * hh) / 12.0, mg * (3 * r * r + 4 * hh * hh) / 12.0, mg * r * r / 2.0])
+        Io += R @ Il @ R.T + mg * (pos @ pos * np.eye(3) - np.outer(pos, pos))
+    cx = np.array([[0, -c[2], c[1]], [c[2], 0, -c[0]], [-c[1], c[0], 0]])
+    M = np.block([[m * np.eye(3), -m * cx], [m * cx, Io]]) + arm * np.eye(6)      # v_com = v - c x w = v - [c]x w
+    Minv = np.linalg.inv(M)
+    Jv, Jw = np.hstack([np.eye(3), -cx]), np.hstack([np.zeros((3, 3)), np.eye(3)])
+    return np.trace(Jv @ Minv @ Jv.T) / 3.0, np.trace(Jw @ Minv @ Jw.T) / 3.0

@@ -1,0 +1,72 @@
+"""GPU tests of round 4: the multi-GPU launcher path of bench.py on one device, the known answers added this round."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (VERDICT r3 missing #3; the reference forks its own workers, agent_ar.py:651-663):
+    bench.py re-executes itself under torch.distributed.run.  On this 1-GPU box both ranks share device 0 (KP_BENCH_SHARED_DEVICE: gloo), which
+    exercises everything but RCCL: the launcher, the rendezvous, the barrier / max-over-ranks timing, and the N > 1 line's training iteration
+    (all-gather of advantages / returns, gradient all-reduces, the job-wide freq_dict exchange)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(KP_BENCH_SHARED_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"],
+                         env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["ranks_seen"] == 2 and len(rec["ms_per_step_per_rank"]) == 2
+    assert rec["value"] > 0 and rec["config"]["parallelism"] == "env-sharded x2"
+    ti = rec["train_iteration"]["4096x24_x2gpus"]
+    assert ti["pool_exhausted"] == 0 and ti["n_gpus"] == 2 and ti["samples_per_s_whole_job"] > 0
+    assert ti["T_iteration_max_over_ranks"] >= max(ti["T_sample"], ti["T_update"])
+
+
+STD = np.load(os.path.join(ROOT, "tests", "golden", "standing_neutral.npz"))
+
+
+def test_known_answer_box_resting_on_the_table_on_the_device():
+    """(vi) the push scene's resting pair on the HIP kernel: the table on its four upright legs (3 contacts each, mjc_PlaneCylinder), the box flat on
+    the table top (4 contacts, mjc_BoxBox), both free bodies of the env, released 1 mm above their margins -- fp32 against the fp64 two-body
+    recurrence written from MuJoCo's documented soft-contact model (tests/known_answers.stack_recurrence; the oracle follows it to 1e-11)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import known_answers as K
+    from kinpoly_amd.sim import STEP_KPM, KpModel, KpSim
+    n = 2
+    zt0 = float(np.float32(-K.TABLE_FEET + K.MARGIN + 0.001))
+    zb0 = float(np.float32(zt0 + K.TABLE_TOP - K.PUSH_BOX_BOTTOM + K.MARGIN + 0.001))
+    sim = KpSim(KpModel(STEP_KPM), n, 0)
+    blk = np.zeros((n, 35))
+    for i in range(5):
+        blk[:, 7 * i: 7 * i + 3] = [(i + 1) * 100, 100, 0]
+    blk[:, 7:14] = [0.0, 0.0, zb0, 1, 0, 0, 0]
+    blk[:, 14:21] = [0.0, 0.0, zt0, 1, 0, 0, 0]
+    q = np.tile(STD["qpos"], (n, 1)); q[:, 0] += 30
+    dev = lambda a: torch.tensor(a, dtype=torch.float32, device=sim.device)      # noqa: E731
+    sim.set_objects(dev(blk)); sim.set_state(dev(q), dev(np.zeros((n, 75)))); sim.set_target(dev(q))
+    sim.record_contacts()
+    act = dev(np.zeros((n, 75)))
+    zs = []
+    for _ in range(500):
+        sim.step_ctrl(act, 1)
+        o = sim.get("obj_qpos")[0]
+        zs.append((float(o[9]), float(o[16])))
+    ref = K.stack_recurrence(zb0, zt0, 500)
+    assert np.abs(np.array(zs) - ref).max() < 3e-6                 # ulp of z = 1.0 in fp32 is 1.2e-7; the motion spans 2 mm
+    con = sim.contacts()[0]
+    obj_con = [(a, b) for a, b in zip(con["body"], con["b2"]) if a >= 24 or b >= 24]
+    assert len(obj_con) == K.N_LEG_CONTACTS + K.N_BOX_CONTACTS, obj_con
+    o = sim.get("obj_qpos")[0].double().cpu().numpy()
+    assert np.abs(o[7:9]).max() < 1e-5 and np.abs(o[14:16]).max() < 1e-5 and int(sim.diag()[:, 2].max()) == 0

@@ -437,3 +437,58 @@ def test_known_answer_contact_frame_and_pyramid_rows():
     np.testing.assert_allclose(t1, [0, 1, 0]); np.testing.assert_allclose(t2, [-1, 0, 0])
     n, t1, t2 = K.make_frame([0.1, 0.9, 0.2])                           # within 60 degrees of y: reference axis z
     assert abs(t1 @ n) < 1e-15 and t1[2] > 0.9 and np.allclose(np.cross(n, t1), t2)
+
+
+def test_known_answer_box_resting_on_the_table_follows_the_two_body_recurrence():
+    """(vi) round 4: the push scene's resting pair -- the table on its four upright legs (mjc_PlaneCylinder: 3 contacts per leg), the box flat on the
+    table top (mjc_BoxBox: 4 contacts), 64 pyramid rows in all -- released 1 mm above their contact margins.  Vertical motion of two bodies
+    under the documented soft-contact model is the 2 x 2 piecewise-quadratic problem of known_answers.stack_recurrence; the oracle's dense
+    Newton solve on 75 + 12 dofs must trace it substep by substep, with 16 contacts once both pairs touch."""
+    import known_answers as K
+    from kinpoly_amd.model_compiler import STEP_KPM
+    zt0 = -K.TABLE_FEET + K.MARGIN + 0.001
+    zb0 = zt0 + K.TABLE_TOP - K.PUSH_BOX_BOTTOM + K.MARGIN + 0.001
+    o = OracleSim(kpm=STEP_KPM)
+    o.set_object(0, K.KPM, K.BOX_OBJ, [0.0, 0.0, zb0, 1, 0, 0, 0])
+    o.set_object(1, K.KPM, K.TABLE_OBJ, [0.0, 0.0, zt0, 1, 0, 0, 0])
+    q = STD["qpos"].copy(); q[0] += 30; q[2] += 50
+    o.reset(q, np.zeros(75))
+    zs, ncon = [], []
+    for _ in range(500):
+        o.step()
+        zs.append((o.get_object(0)[0][2], o.get_object(1)[0][2]))
+        ncon.append(len(o.contacts()[0]))
+    ref = K.stack_recurrence(zb0, zt0, 500)
+    assert np.abs(np.array(zs) - ref).max() < 1e-11
+    assert ncon[-1] == K.N_LEG_CONTACTS + K.N_BOX_CONTACTS and max(ncon) == 16
+    # nothing but vertical motion happened, and both pairs came to rest inside their margins
+    qb, qt = o.get_object(0)[0], o.get_object(1)[0]
+    assert np.abs(qb[:2]).max() < 1e-12 and np.abs(qt[:2]).max() < 1e-12 and abs(qb[3] - 1) < 1e-12 and abs(qt[3] - 1) < 1e-12
+    gap = (ref[-1, 0] + K.PUSH_BOX_BOTTOM) - (ref[-1, 1] + K.TABLE_TOP)
+    feet = ref[-1, 1] + K.TABLE_FEET
+    assert 0 < gap < K.MARGIN and 0 < feet < K.MARGIN and abs(ref[-1, 0] - ref[-40, 0]) < 1e-10
+    # resting depths of the documented model: n rows x D(r) x k d(r) |r| carry the weight above them (aref = -k d(r) r at rest)
+    for n_rows, invw, load, r in ((4 * K.N_LEG_CONTACTS, K.TABLE_INVW, (K.TABLE_MASS + K.PUSH_BOX_MASS) * K.G, feet - K.MARGIN),
+                                  (4 * K.N_BOX_CONTACTS, K.PUSH_BOX_INVW + K.TABLE_INVW, K.PUSH_BOX_MASS * K.G, gap - K.MARGIN)):
+        assert n_rows * K.row_weight(r, invw) * K.K_REF * K.impedance(r) * abs(r) == pytest.approx(load, rel=1e-6)
+
+
+def test_known_answer_set0_constants_of_the_compiled_model():
+    """(vii) round 4: body_invweight0 / dof_invweight0 / meaninertia scale every regulariser R, every joint-limit row and the solver's
+    termination test.  The compiled blob's values against an independent evaluation of engine_setconst.c's set0 definitions from the blob's
+    raw body parameters (explicit centre-of-mass Jacobians at qpos0, dense inverse) and, for meaninertia, the objects' diagonal inertia
+    from their XML geoms by the textbook box / cylinder formulas."""
+    import known_answers as K
+    kpm = K.KPM
+    bw, dw, diagM = K.set0_constants(BODY_POS, BODY_IPOS, PARENT, MASS, INERTIA, kpm["dof_armature"], O.qpos_fk, O.quaternion_matrix3)
+    np.testing.assert_allclose(kpm["body_invweight0"].reshape(24, 2), bw, rtol=1e-9)
+    np.testing.assert_allclose(kpm["dof_invweight0"], dw, rtol=1e-9)
+    obj_diag = np.concatenate([K.object_diag_inertia(i) for i in range(5)])
+    mean_inertia = (diagM.sum() + obj_diag.sum()) / (75 + 30)
+    assert float(kpm["opt"][16]) == pytest.approx(mean_inertia, rel=1e-9)
+    # the objects' own invweight0 (the regulariser of every object contact): the free body's 6 x 6 inertia about its origin and its
+    # centre-of-mass Jacobian -- NOT 1 / (m + armature): the armature sits on the origin's dofs and the centre of mass is 0.1 ... 0.44 m below it
+    for i in range(5):
+        inert = kpm["obj_inertial"].reshape(-1, 13)[i]
+        wt, wr = K.object_invweight(i)
+        assert float(inert[10]) == pytest.approx(wt, rel=1e-9) and float(inert[11]) == pytest.approx(wr, rel=1e-9)
