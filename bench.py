@@ -471,6 +471,9 @@ def main():
         elapsed = float(t.item())
 
     train_n = None
+    if not train:       # read what the line needs from the engine before it is torn down
+        cost = env.sim.launch_cost().astype(np.float64)
+        spj = int(env.model.get_option("substeps_per_job"))
     if world > 1 and not train and not args.no_secondary:
         # the Amdahl term of a training job on N GPUs: one whole optimize_policy (sampling + all-gather of advantages / returns + data-parallel update with
         # gradient all-reduces) timed on every rank, max over ranks
@@ -494,12 +497,11 @@ def main():
         print(json.dumps(out), flush=True)
     elif rank == 0:
         kern_s, n_launch, diag = rec["kern_s"], rec["n_launch"], rec["diag"]
-        cost = env.sim.launch_cost().astype(np.float64)
         objects = args.workload == "objects"
         value = ENVS_PER_GPU * world * args.steps / elapsed
         algo_bytes = (ALGO_BYTES_PER_ENV_STEP_OBJ if objects else ALGO_BYTES_PER_ENV_STEP) * ENVS_PER_GPU
         achieved = algo_bytes / kern_s / 1e9
-        kernel_name = ("kp_step_queue_kernel" if int(env.model.get_option("substeps_per_job")) > 0 else "kp_step_kernel") + ("<true>" if objects else "<false>")
+        kernel_name = ("kp_step_queue_kernel" if spj > 0 else "kp_step_kernel") + ("<true>" if objects else "<false>")
         # HBM bytes / instruction counts: ONLY from a rocprofv3 --pmc pass of this same command and workload (tools/profile_bench.sh writes
         # profiles/r03/pmc_bench_<workload>.json); otherwise null -- nothing canned from another workload enters the line
         traffic, traffic_src, valu = None, None, None
@@ -545,7 +547,7 @@ def main():
             "episodes_ended_per_step_frac": rec["n_done"] / (ENVS_PER_GPU * args.steps),
             # per-env shader-clock cycles of the last launch (kp_sim_launch_cost): what the launch would take if its waves were perfectly
             # packed on the resident slots vs its longest env
-            "launch_balance": {"substeps_per_job": int(env.model.get_option("substeps_per_job")), "sum_env_cycles_over_2048_slots_ms": float(cost.sum() / 2048 / 2.38e6),
+            "launch_balance": {"substeps_per_job": spj, "sum_env_cycles_over_2048_slots_ms": float(cost.sum() / 2048 / 2.38e6),
                                "longest_env_ms": float(cost.max() / 2.38e6), "median_env_ms": float(np.median(cost) / 2.38e6)},
         }
         if world == 1 and not args.no_secondary:
