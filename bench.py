@@ -61,7 +61,8 @@ def build_engine(device_index, seed, threads, workload="tracked"):
     wild = workload == "wild_eval"
     opts = {"threads_per_env": threads, **({"substeps_per_job": int(os.environ["KP_SUBSTEPS_PER_JOB"])} if "KP_SUBSTEPS_PER_JOB" in os.environ else {}),
             **({"lpt_order": int(os.environ["KP_LPT_ORDER"])} if "KP_LPT_ORDER" in os.environ else {}),
-            **({"queue_heavy": int(os.environ["KP_QUEUE_HEAVY"])} if "KP_QUEUE_HEAVY" in os.environ else {})}
+            **({"queue_heavy": int(os.environ["KP_QUEUE_HEAVY"])} if "KP_QUEUE_HEAVY" in os.environ else {}),
+            **({"queue_prio": int(os.environ["KP_QUEUE_PRIO"])} if "KP_QUEUE_PRIO" in os.environ else {})}
     env = BatchedHumanoidAREnv(ENVS_PER_GPU, device_index, mode="test" if wild else "train", wild=wild, seed=seed, model_options=opts)
     policy = KinPolicy().to(env.device).float()
     g = torch.Generator().manual_seed(seed)
@@ -136,6 +137,29 @@ def rollout_steps(sampler, k, a_track=None, wild=False, follow_clip=False):
                 n_early += early.sum()
             sampler.obs = env.reset(done, policy_state=sampler.hx)        # finished envs: state, target, observation and the GRU state in one pass
     return n_early if wild else env.done_count.to(torch.int64)[0]       # episodes ended: counted inside kp_sim_post_step
+
+
+def parity_summary(workload):
+    """One-substep parity of THIS workload's own states against the fp64 oracle, as committed under profiles/ by tools/substep_parity.py
+    (both sides restarted from a common fp32-rounded state at every substep): not measured in this run, read from the log."""
+    import re
+    path = os.path.join(PROFILE_DIR, "substep_parity_bench.log")
+    if not os.path.exists(path):
+        return None
+    lines = open(path).read().splitlines()
+    for i, ln in enumerate(lines):
+        if ln.startswith(f"bench:{workload}:") and i + 1 < len(lines):
+            m = re.search(r"differ between the two sides at the same state: (\d+) of (\d+)", lines[i + 1])
+            v = re.search(r"another vertex of a hull at the same height \(to 1e-7\): (\d+)", lines[i + 1])
+            q = re.search(r"with the same contact points: max \|dqpos\| ([0-9.e+-]+)", lines[i + 1])
+            med = re.search(r"one-substep \|dqpos\| median ([0-9.e+-]+) p99 ([0-9.e+-]+)", ln)
+            if m and q:
+                return {"substeps": int(m.group(2)), "contact_set_diffs": int(m.group(1)), "same_entities_other_hull_vertex": int(v.group(1)) if v else None,
+                        "max_same_set_dqpos": float(q.group(1)), "median_dqpos": float(med.group(1)) if med else None, "p99_dqpos": float(med.group(2)) if med else None,
+                        "note": "HIP kernel vs fp64 oracle, ONE substep from a common state, on states of this workload; contact-set differences sit on the knife edges of "
+                                "MuJoCo's own contact rules (dist == margin, level hull vertices), where per-step agreement to 1e-3 rad does not hold on either side",
+                        "source": os.path.relpath(path, ROOT)}
+    return None
 
 
 def policy_gemm_probe(env, policy, iters=30):
@@ -545,6 +569,7 @@ def main():
             "hessian_factorisations_per_substep": float((diag[:, 3] >> 8).mean() / 15.0),
             "bad_envs": int(((diag[:, 2] & 255) != 0).sum()), "newton_cap_hits": int((diag[:, 2] >> 8).sum()),
             "episodes_ended_per_step_frac": rec["n_done"] / (ENVS_PER_GPU * args.steps),
+            "parity": parity_summary(args.workload),
             # per-env shader-clock cycles of the last launch (kp_sim_launch_cost): what the launch would take if its waves were perfectly
             # packed on the resident slots vs its longest env
             "launch_balance": {"substeps_per_job": spj, "sum_env_cycles_over_2048_slots_ms": float(cost.sum() / 2048 / 2.38e6),

@@ -27,7 +27,7 @@ int fail(const std::string& m) { g_err = m; return -1; }
 
 struct kp_model {
     kp::HostModel h;
-    int contact = 1, limits = 1, stale = 1, solver_iter = 100, threads = 64, dynamic_objects = 1, lpt_order = -1, substeps_per_job = 4, queue_slots = 0, job_taper = 1, queue_fence = 1, queue_heavy = 160;
+    int contact = 1, limits = 1, stale = 1, solver_iter = 100, threads = 64, dynamic_objects = 1, lpt_order = -1, substeps_per_job = 4, queue_slots = 0, job_taper = 1, queue_fence = 1, queue_heavy = 160, queue_prio = 0;
     int planemesh_max = 3; double planemesh_tol = 0.3;   // mjc_PlaneConvex's maxplanemesh / tolplanemesh (the blob's `planemesh`)
     int actuation = 1;            // 0: no stable-PD torque, no residual force (ctrl = qfrc_applied = 0): torque-free flight for the energy test
     double solver_tol = 1e-8, gravity_z = -9.81, gravity_x = 0.0, gravity_y = 0.0;   // solver_iter / solver_tol: mjOption.iterations / tolerance of the reference model (kp_model_load)
@@ -49,6 +49,7 @@ struct kp_sim {
     unsigned *jobq = nullptr, *jobctr = nullptr;      // job FIFO of kp_step_queue_kernel
     float* spd_next = nullptr;                        // [N, 80] torque hand-over between the jobs of a control step
     int jobq_cap = 0, wave_slots = 2048;
+    int q_nsub = -1, q_obj = -1;                      // what the queue's "heavy job" yardstick (jobctr[32..33] -> [48..49]) was measured on
     unsigned long long* prof = nullptr;
     float* dbg_contacts = nullptr;
     float *obj_qpos = nullptr, *geoms = nullptr;      // [N,35], [N,8,17]
@@ -274,10 +275,16 @@ int launch_step(kp_sim* s, const float* action, int nsub, const uint8_t* mask, b
         }
     }
     const bool queue = nsub > 0 && parts > 1 && s->model->threads == 64 && s->n > slots && s->n <= 0xFFFFFF && !s->prof;   // env ids take 24 bits of a queue entry
-    A.jobq = s->jobq; A.jobctr = s->jobctr; A.spd_next = s->spd_next; A.n_parts = queue ? parts : 1; A.queue_fence = s->model->queue_fence; A.queue_heavy = s->model->queue_heavy;
+    A.jobq = s->jobq; A.jobctr = s->jobctr; A.spd_next = s->spd_next; A.n_parts = queue ? parts : 1; A.queue_fence = s->model->queue_fence; A.queue_heavy = s->model->queue_heavy; A.queue_prio = s->model->queue_prio; A.order_valid = A.order != nullptr;
     A.part_sub_lo = A.part_sub_hi = 0;
     for (int k = 0; queue && k < parts; k++) (k < 8 ? A.part_sub_lo : A.part_sub_hi) |= (unsigned long long)(sizes[k] & 255) << (8 * (k & 7));
     if (queue) {
+        // the yardstick of queue_heavy is the previous launch's mean job time per substep: it only means something for the same kernel on the same
+        // schedule, so a change of the substep count or of the kernel instantiation starts it from nothing (that launch keeps no env)
+        if (nsub != s->q_nsub || (int)obj != s->q_obj) {
+            HIP_OK(hipMemsetAsync(s->jobctr + 32, 0, 2 * sizeof(unsigned), s->stream));
+            s->q_nsub = nsub; s->q_obj = (int)obj;
+        }
         const unsigned total = (unsigned)s->n * (unsigned)parts;
         hipLaunchKernelGGL(kp::k_queue_init, dim3((total + 255) / 256), dim3(256), 0, s->stream, s->n, total, s->jobq, s->jobctr, A.order);   // inside the timed bracket
         A.order = nullptr;                                              // the queue kernel addresses envs by their queue entry
@@ -341,6 +348,7 @@ int kp_model_set_option(kp_model* m, const char* name, double v) {
     else if (k == "job_taper") m->job_taper = std::max(0, std::min(8, (int)v));
     else if (k == "queue_fence") m->queue_fence = v != 0;
     else if (k == "queue_heavy") m->queue_heavy = std::max(0, (int)v);
+    else if (k == "queue_prio") m->queue_prio = v != 0;
     else if (k == "queue_slots") { if (v < 0) return fail("queue_slots must be >= 0 (0 = resident wave slots of the device)"); m->queue_slots = (int)v; }
     else if (k == "substeps_per_job") { if (v < 0 || v > 255) return fail("substeps_per_job must be 0 (whole control step per workgroup) .. 255"); m->substeps_per_job = (int)v; }
     else if (k == "threads_per_env") { if (v != 64 && v != 128 && v != 256) return fail("threads_per_env must be 64, 128 or 256"); m->threads = (int)v; }
@@ -368,6 +376,7 @@ double kp_model_get_option(const kp_model* m, const char* name) {
     if (k == "job_taper") return m->job_taper;
     if (k == "queue_fence") return m->queue_fence;
     if (k == "queue_heavy") return m->queue_heavy;
+    if (k == "queue_prio") return m->queue_prio;
     if (k == "threads_per_env") return m->threads;
     if (k == "timestep") return m->h.opt[kp::OPT_TIMESTEP];
     if (k == "lds_bytes_per_env") return (double)sizeof(kp::EnvLds);

@@ -73,6 +73,8 @@ struct StepArgs {
     int n_parts;
     int queue_heavy;           // > 0: a wave that finds its env heavy (this job's cycles per substep > queue_heavy % of the launch's running mean) runs the env's next job itself
     int queue_fence;           // 1: the hand-over is a release (publish) / acquire (consume) pair at agent scope instead of relaxed sc1 accesses + s_waitcnt
+    int queue_prio;            // > 0: waves running jobs of envs known to be heavy raise their issue priority (s_setprio)
+    int order_valid;           // the first jobs were queued longest-env-first
     unsigned long long part_sub_lo, part_sub_hi;   // substeps of job 0 .. 15, one byte each (sum = n_substeps); packed so that no lookup indexes the kernel argument
 };
 
@@ -2137,6 +2139,11 @@ __global__ __launch_bounds__(64, 2) void kp_step_queue_kernel(StepArgs A) {
         e = (unsigned)__builtin_amdgcn_readfirstlane((int)e);
         const int env = (int)(e & 0xFFFFFFu);
         int part = (int)(e >> 24);
+        // Issue priority: the launch ends on its costliest envs' serial chains, and a wave shares its SIMD's issue slots with one other wave.  A wave that
+        // runs a job of an env known to be heavy -- one of the first queue entries when the first jobs were queued longest-env-first (k_lpt_order), or an
+        // env it kept because its last job ran long (below) -- raises its own priority, so the SIMD's arbiter prefers it over its neighbour
+        // (s_setprio: scheduling only, results do not depend on it); every other job runs at the default priority.
+        if (A.queue_prio > 0) { if (A.order_valid && part == 0 && idx < (unsigned)A.n_envs / 16u) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); }
         for (;;) {
             const unsigned long long tj = __builtin_amdgcn_s_memrealtime();          // 100 MHz ticks: only ratios of job times are used
             step_body<64, OBJ, false, true>(A, env, part);
@@ -2165,6 +2172,7 @@ __global__ __launch_bounds__(64, 2) void kp_step_queue_kernel(StepArgs A) {
                 break;
             }
             if (threadIdx.x == 0) atomicAdd(&A.jobctr[16], 1u);
+            if (A.queue_prio > 0) __builtin_amdgcn_s_setprio(3);
             part++;
         }
     }

@@ -275,7 +275,11 @@ class BatchedHumanoidAREnv:
     def step(self, a: torch.Tensor, need_obs: bool = True, cc_noise: torch.Tensor | None = None):
         """One batched HumanoidAREnv.step.  need_obs=False skips get_ar_obs_v1 (a sampler that resets finished envs right after the step and
         does not record next_states gets its observation from reset()); cc_noise [N, 75]: standard-normal draws for the UHC's exploration
-        made ahead by the caller.  The returned tensors live in two alternating buffer sets: valid until the next-but-one step()."""
+        made ahead by the caller.  Lifetime of what is returned (no per-step allocation): done / fail / end / percent / the rewards live in two
+        alternating buffer sets and stay valid until the next-but-one step(); `obs` and info['cc_state'] live in single
+        buffers and are overwritten by the NEXT step() (reset() likewise returns its one observation buffer, which the next reset() rewrites):
+        a caller that keeps any of them longer clones them (VectorSampler copies each step's values into its [N, T, .] rollout rows; the
+        numpy facade HumanoidAREnv copies on conversion)."""
         sim = self.sim
         if self.ar_mode:                 # the UHC tracks the kinematic roll-out (:263-264)
             sim.step_begin()

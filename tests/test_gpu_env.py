@@ -490,3 +490,27 @@ def test_fk_backward_kernel_matches_autograd():
     ga, gb = qa.grad.double(), qb.grad
     assert float((ga - gb).abs().max()) < 2e-4 * float(gb.abs().max())
     assert float((ga[:, 3:7] - gb[:, 3:7]).abs().max()) < 2e-4 * float(gb[:, 3:7].abs().max())
+
+
+def test_step_outputs_live_as_long_as_the_docstring_says():
+    """step() returns views into reused buffers.  done / fail / end / percent / rewards alternate between two sets (valid until the
+    next-but-one step), obs and cc_state are single buffers (valid until the next step).  A caller holding them longer must clone."""
+    from kinpoly_amd.env import BatchedHumanoidAREnv, standing_context
+    n = 8
+    env = BatchedHumanoidAREnv(n, 0, mode="train", seed=0)
+    env.load_context(standing_context(n, 30, STD["qpos"], STD["qvel"], env.sim))
+    obs = env.reset()
+    a = torch.zeros((n, 80), device=env.device); a[:, :74] = torch.cat([env.sim.get("qpos")[:, 2:3], obs[:, 1:5], env.sim.get("qpos")[:, 7:]], 1)
+    held = []
+    for k in range(3):
+        o, _, done, info = env.step(a.contiguous())
+        held.append(dict(obs=o, done=done, reward=info["custom_reward"], percent=info["percent"], cc_state=info["cc_state"],
+                         reward_copy=info["custom_reward"].clone(), percent_copy=info["percent"].clone()))
+    # step 1's alternating outputs survived step 2 and were reused by step 3; step 2's are intact
+    assert held[0]["reward"].data_ptr() == held[2]["reward"].data_ptr() != held[1]["reward"].data_ptr()
+    assert held[0]["done"].data_ptr() == held[2]["done"].data_ptr() != held[1]["done"].data_ptr()
+    assert torch.equal(held[1]["reward"], held[1]["reward_copy"]) and torch.equal(held[1]["percent"], held[1]["percent_copy"])
+    assert not torch.equal(held[0]["percent"], held[0]["percent_copy"])          # cur_t / len moved on: the view shows step 3's values
+    # single buffers
+    assert held[0]["obs"].data_ptr() == held[1]["obs"].data_ptr() == held[2]["obs"].data_ptr()
+    assert held[0]["cc_state"].data_ptr() == held[2]["cc_state"].data_ptr()
