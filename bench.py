@@ -278,7 +278,7 @@ WORKLOAD_DESC = {
 }
 ROLLOUT_WORKLOADS = ("tracked", "random_init", "wild_eval", "objects")
 TRAIN_KEYS = ("T_sample", "T_update", "samples_per_s_per_gpu", "samples_per_iter_per_gpu", "iters", "avg_reward", "fail_rate", "episodes_per_iter",
-              "clips_through_init_context_per_iter", "pool_exhausted", "update_tflops", "update_mfma_frac", "update_flops_per_iter", "episode_source")
+              "clips_drawn_per_iter", "clips_through_init_context_per_iter", "pool_exhausted", "update_tflops", "update_mfma_frac", "update_flops_per_iter", "episode_source")
 
 
 def run_workload(workload, device_index, seed, threads, steps, warmup, barrier=None):
@@ -357,7 +357,7 @@ def object_scene_launches(device_index, threads):
     return out
 
 
-def train_iteration(device_index, seed, horizon, iters, warm, barrier=None, threads=64, objects=False, rank=0):
+def train_iteration(device_index, seed, horizon, iters, warm, barrier=None, threads=64, objects=False, rank=0, cache_init_context=False):
     """`iters` timed AgentAR.optimize_policy calls (after `warm` untimed) at ENVS_PER_GPU x horizon env-steps per rank, the way
     scripts/train_ar_policy.py runs them: every episode draws its clip from a StateARDataset (adaptive take sampling, freq_dict feedback) and goes
     through init_context (context GRU over the 100-frame clip -> init_qpos / init_qvel) -- inside the timed region, at whatever failure rate the
@@ -373,14 +373,14 @@ def train_iteration(device_index, seed, horizon, iters, warm, barrier=None, thre
                               seed=seed, with_objects=objects)
     ds = D.StateARDataset(takes, fr_num=CLIP_LEN, seed=seed + rank, device=fk_sim.device)
     agent = AgentAR(ENVS_PER_GPU, dataset=ds, device=device_index, horizon=horizon, seed=seed, use_init_context=True, pool_depth=4,
-                    model_options={"threads_per_env": threads}, sampling_temp=0.3, sampling_freq=0.5)
+                    model_options={"threads_per_env": threads}, sampling_temp=0.3, sampling_freq=0.5, cache_init_context=cache_init_context)
     for i in range(warm):
         agent.optimize_policy(i)
     (barrier or torch.cuda.synchronize)()
     t0 = time.perf_counter()
     ts = tu = 0.0
     info = {}
-    drawn0, eps, fails = agent.source.n_drawn, 0, 0.0
+    drawn0, hits0, eps, fails = agent.source.n_drawn, agent.source.n_memo_hits, 0, 0.0
     for i in range(iters):
         info = agent.optimize_policy(warm + i)
         ts += info["T_sample"]; tu += info["T_update"]; eps += info["episodes"]; fails += info["fail_rate"]
@@ -397,7 +397,8 @@ def train_iteration(device_index, seed, horizon, iters, warm, barrier=None, thre
     upd_flops = 2.0 * n_s * (pol_macs * 3 * (ne + ns) + val_macs * (1 + 3 * ne * agent.trainer.value_opt_niter))
     rec = {"elapsed": el, "T_sample": ts / iters, "T_update": tu / iters, "samples_per_iter_per_gpu": n_s, "horizon": horizon,
            "iters": iters, "warmup": warm, "samples_per_s_per_gpu": n_s * iters / el, "avg_reward": info.get("avg_reward"),
-           "pool_exhausted": info.get("pool_exhausted"), "episodes_per_iter": eps / iters, "clips_through_init_context_per_iter": (agent.source.n_drawn - drawn0) / iters,
+           "pool_exhausted": info.get("pool_exhausted"), "episodes_per_iter": eps / iters,
+           "clips_through_init_context_per_iter": ((agent.source.n_drawn - drawn0) - (agent.source.n_memo_hits - hits0)) / iters, "clips_drawn_per_iter": (agent.source.n_drawn - drawn0) / iters,
            "fail_rate": fails / iters, "episode_source": f"StateARDataset of {ds.get_len()} synthetic takes ({'four action classes with free objects' if objects else 'no objects'}), "
                                                          "adaptive take sampling + init_context per episode, pool_depth 4",
            "update_tflops": upd_flops / (tu / iters) / 1e12, "update_mfma_frac": upd_flops / (tu / iters) / 1e12 / MFMA_FP32_PEAK_TFLOPS,
@@ -607,9 +608,13 @@ def main():
                 out["object_scenes"] = {"error": f"{type(ex).__name__}: {ex}"[:200]}
             try:        # a whole training iteration: the update is its larger part
                 out["train_iteration"] = {}
-                for name, hz, it, obj in ((f"4096x{TRAIN_HORIZON}", TRAIN_HORIZON, 2, False), (f"4096x{TRAIN_HORIZON}_objects", TRAIN_HORIZON, 1, True)):
-                    r3 = train_iteration(local_rank, 4, hz, it, 1, objects=obj)
+                for name, hz, it, obj, memo in ((f"4096x{TRAIN_HORIZON}", TRAIN_HORIZON, 2, False, False), (f"4096x{TRAIN_HORIZON}_objects", TRAIN_HORIZON, 1, True, False),
+                                                (f"4096x{TRAIN_HORIZON}_init_context_memo", TRAIN_HORIZON, 2, False, True)):
+                    r3 = train_iteration(local_rank, 4, hz, it, 1, objects=obj, cache_init_context=memo)
                     out["train_iteration"][name] = {k: r3[k] for k in TRAIN_KEYS}
+                out["train_iteration"]["note"] = ("random-init networks: (almost) every episode fails after one step, so every env-step draws a clip and runs it through init_context "
+                                                  "(context GRU over its 100 frames) -- the worst case of the episode source; `_init_context_memo` is the opt-in lookup of windows "
+                                                  "already computed under the same context-network parameters (EpisodeSource.cache_init_context; the synthetic set has few windows, a MoCap set has ~1e5)")
             except Exception as ex:
                 out["train_iteration"] = {"error": f"{type(ex).__name__}: {ex}"[:200]}
         else:

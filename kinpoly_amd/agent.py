@@ -34,7 +34,8 @@ class AgentAR:
     def __init__(self, n_envs, context_fn=None, device=0, horizon=99, seed=4, wild=False, use_init_context=True,
                  policy_lr=1e-5, value_lr=3e-4, supervised_lr=5e-4, num_optim_epoch=10, num_step_update=20, gamma=0.95, tau=0.95,
                  clip_epsilon=0.2, rl_update=True, step_update=True, model_options=None, dataset=None, sampling_temp=0.3, sampling_freq=0.5,
-                 pool_depth=4, num_epoch_fix=100, num_epoch=10000, joint_controller=False, grad_joint=False, grad_alternate=False, train_uhc=False):
+                 pool_depth=4, num_epoch_fix=100, num_epoch=10000, joint_controller=False, grad_joint=False, grad_alternate=False, train_uhc=False,
+                 cache_init_context=False):
         rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
         enable_tuned_gemms()          # library GEMM solution per shape (rollout and update shapes at 4096 envs); selection only
         torch.manual_seed(seed + rank)
@@ -51,7 +52,7 @@ class AgentAR:
         # sampling_temp / sampling_freq: kin_poly.yml:67-68; freq_dict lives in the source (agent_ar.py:228-234)
         self.source = EpisodeSource(dataset=dataset, context_fn=context_fn if dataset is None else None,
                                     ctx_builder=self.ctx_builder if use_init_context else None,
-                                    sampling_temp=sampling_temp, sampling_freq=sampling_freq, fix_height=False)
+                                    sampling_temp=sampling_temp, sampling_freq=sampling_freq, fix_height=False, cache_init_context=cache_init_context)
         self.horizon, self.rl_update, self.step_update, self.num_step_update = horizon, rl_update, step_update, num_step_update
         self.grad_joint, self.grad_alternate = grad_joint, grad_alternate       # policy_specs.grad_joint / grad_alternate (agent_ar.py:703, 746-747)
         self.trainer = PPOTrainer(self.policy_net, self.value_net, gamma, tau, clip_epsilon, policy_lr, value_lr, num_optim_epoch,
@@ -95,7 +96,7 @@ class AgentAR:
         n = batch.rewards.numel()
         info.update(T_sample=t1 - t0, T_update=t2 - t1, T_total=time.time() - t0, num_steps=n, avg_reward=float(batch.rewards.mean()),
                     fail_rate=float(batch.fails.float().mean()), env_steps_per_s=n / (t1 - t0), episodes=len(batch.episodes.get("percent", ())),
-                    pool_exhausted=self.sampler.pool_exhausted, clips_drawn=self.source.n_drawn, top_ups=self.sampler.top_ups, policy_lr=self.trainer.opt_p.param_groups[0]["lr"])
+                    pool_exhausted=self.sampler.pool_exhausted, clips_drawn=self.source.n_drawn, init_context_memo_hits=self.source.n_memo_hits, top_ups=self.sampler.top_ups, policy_lr=self.trainer.opt_p.param_groups[0]["lr"])
         return info
 
     def save_checkpoint(self, path):

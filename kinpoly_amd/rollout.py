@@ -71,13 +71,22 @@ class EpisodeSource:
     dict changes only BETWEEN sample() calls (the forked workers draw from the copy they were started with and the agent merges their
     lists afterwards, agent_ar.py:664-673): the take probabilities are evaluated once per version of the dict."""
 
-    def __init__(self, dataset=None, ctx_builder=None, context_fn=None, sampling_temp=0.5, sampling_freq=0.9, fix_height=False):
+    def __init__(self, dataset=None, ctx_builder=None, context_fn=None, sampling_temp=0.5, sampling_freq=0.9, fix_height=False, cache_init_context=False):
         assert (dataset is None) != (context_fn is None), "give a dataset or a context_fn"
         self.dataset, self.ctx_builder, self.context_fn = dataset, ctx_builder, context_fn
         self.sampling_temp, self.sampling_freq, self.fix_height = sampling_temp, sampling_freq, fix_height
         self.freq_dict = {k: [] for k in dataset.takes} if dataset is not None else {}
         self._probs = None
         self.n_drawn = 0          # clips drawn so far (every one of them went through init_context when there is a ctx_builder)
+        # Opt-in memo of init_context (off by default: then every drawn clip runs through the context network, as in the reference).  What a training
+        # episode takes from init_context -- init_qpos / init_qvel -- is a pure function of the window (take, fr_start) and of the context
+        # network's parameters, which no update of the RL phase touches (neither the PPO surrogate nor the supervised step loss reaches
+        # context_rnn / context_mlp / context_fc; they get no gradient and Adam skips them): a window that was seen under the same parameter
+        # version is looked up instead of recomputed.  Needs a ctx_builder with need_rollout=False; any change of the parameters' versions
+        # (load_state_dict, an optimiser that does train them) empties the memo.
+        self.cache_init_context = bool(cache_init_context) and dataset is not None and ctx_builder is not None and not ctx_builder.need_rollout
+        self._memo = None
+        self.n_memo_hits = 0
 
     def draw(self, n: int, device) -> dict:
         if self.dataset is not None:
@@ -87,12 +96,42 @@ class EpisodeSource:
         else:
             data = self.context_fn(n)
         self.n_drawn += n
+        keys = (data["take_ind"].numpy().astype(np.int64), data["fr_start"].numpy().astype(np.int64)) if self.cache_init_context else None
         data = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in data.items()}
-        if self.ctx_builder is not None:
+        if self.cache_init_context:
+            data = self._init_context_memo(data, keys, device)
+        elif self.ctx_builder is not None:
             data = self.ctx_builder.init_context(data, fix_height=self.fix_height)
         elif "init_qpos" not in data:         # no context network: the episode starts on the clip's first frame
             data["init_qpos"] = data["qpos"][:, 0].contiguous()
             data["init_qvel"] = data["qvel"][:, 0].contiguous() if "qvel" in data else torch.zeros((n, 75), device=device)
+        return data
+
+    def _init_context_memo(self, data, keys, device):
+        net = self.ctx_builder.net
+        params = list(net.context_rnn.parameters()) + list(net.context_mlp.parameters()) + list(net.context_fc.parameters())
+        ver = tuple((p._version, p.data_ptr()) for p in params)
+        lens = self.dataset._seq_lens()
+        if self._memo is None or self._memo["ver"] != ver or self._memo["n_takes"] != len(lens):
+            per_take = np.maximum(lens - self.dataset.fr_num, 1)                  # window starts a take offers (sample_batch)
+            off = np.concatenate([[0], np.cumsum(per_take)]).astype(np.int64)
+            self._memo = {"ver": ver, "n_takes": len(lens), "off": off, "have": np.zeros(int(off[-1]), bool),
+                          "q": torch.zeros((int(off[-1]), 76), device=device), "v": torch.zeros((int(off[-1]), 75), device=device)}
+        m = self._memo
+        wid = m["off"][keys[0]] + keys[1]
+        miss_w, first = np.unique(wid[~m["have"][wid]], return_index=True)
+        if len(miss_w):
+            rows = np.nonzero(~m["have"][wid])[0][first]                          # one drawn row per missing window
+            idx = torch.as_tensor(rows, device=device)
+            n = len(wid)
+            part = {k: (v[idx] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == n else v) for k, v in data.items()}
+            out = self.ctx_builder.init_context(part, fix_height=self.fix_height)
+            w_t = torch.as_tensor(miss_w, device=device)
+            m["q"].index_copy_(0, w_t, out["init_qpos"]); m["v"].index_copy_(0, w_t, out["init_qvel"])
+            m["have"][miss_w] = True
+        self.n_memo_hits += len(wid) - len(miss_w)
+        w_all = torch.as_tensor(wid, device=device)
+        data["init_qpos"], data["init_qvel"] = m["q"][w_all].contiguous(), m["v"][w_all].contiguous()
         return data
 
     def record(self, take_ind, fr_start, percent, group=None):

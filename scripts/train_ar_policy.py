@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--num_optim_epoch", type=int, default=10)
     ap.add_argument("--num_step_update", type=int, default=20)
     ap.add_argument("--pool_depth", type=int, default=4, help="clips kept queued behind every env's current one (one host read per pool_depth steps)")
+    ap.add_argument("--cache_init_context", action="store_true", help="look init_qpos / init_qvel of a window up once it has been computed under the same context-network parameters")
     ap.add_argument("--save", type=str, default="")
     ap.add_argument("--data", type=str, default="", help="feature file in the reference's schema (<data_dir>/features/<data_file>.p)")
     args = ap.parse_args()
@@ -59,7 +60,7 @@ def main():
     # every episode draws its clip through data_loader.sample_seq(freq_dict, sampling_temp, sampling_freq) (agent_ar.py:519-523): the
     # agent keeps the freq_dict and feeds each finished episode's [percent, fr_start] back (random window starts, adaptive takes)
     agent = AgentAR(args.num_envs, dataset=ds, device=local, horizon=args.horizon, num_optim_epoch=args.num_optim_epoch,
-                    num_step_update=args.num_step_update, sampling_temp=0.3, sampling_freq=0.5, pool_depth=args.pool_depth)
+                    num_step_update=args.num_step_update, sampling_temp=0.3, sampling_freq=0.5, pool_depth=args.pool_depth, cache_init_context=args.cache_init_context)
     for it in range(args.iters):
         info = agent.optimize_policy(it)
         if rank == 0:

@@ -154,6 +154,34 @@ def test_lazy_init_context_gives_the_training_episode_the_same_start():
     np.testing.assert_allclose(big["ar_qpos"][n:2 * n].cpu().numpy(), one["ar_qpos"].cpu().numpy(), atol=1e-6)
 
 
+def test_init_context_memo_returns_what_init_context_computes():
+    """EpisodeSource(cache_init_context=True): init_qpos / init_qvel of a window (take, fr_start) are looked up once they have been computed under
+    the same context-network parameters; the values are those of a plain init_context call, the memo is emptied when the parameters change."""
+    from kinpoly_amd.context import PolicyARContext, TrajARNet
+    from kinpoly_amd.rollout import EpisodeSource
+    n, fr = 48, 12
+    ds, fk_sim = _dataset(n, fr, seed=6)
+    ds2, _ = _dataset(n, fr, seed=6)
+    torch.manual_seed(5)
+    net = TrajARNet().to(fk_sim.device)
+    builder = PolicyARContext(net, fk_sim, need_rollout=False, keep_context_feat=False)
+    plain = EpisodeSource(dataset=ds, ctx_builder=builder)
+    memo = EpisodeSource(dataset=ds2, ctx_builder=builder, cache_init_context=True)
+    assert memo.cache_init_context
+    for _ in range(3):                              # the same draw stream on both sides (same dataset seed)
+        a, b = plain.draw(n, fk_sim.device), memo.draw(n, fk_sim.device)
+        assert torch.equal(a["take_ind"], b["take_ind"]) and torch.equal(a["fr_start"], b["fr_start"])
+        np.testing.assert_allclose(b["init_qpos"].cpu().numpy(), a["init_qpos"].cpu().numpy(), atol=2e-6)
+        np.testing.assert_allclose(b["init_qvel"].cpu().numpy(), a["init_qvel"].cpu().numpy(), atol=2e-6)
+    assert memo.n_memo_hits > n, "4 takes x a handful of window starts: most of 3 x 48 draws repeat a window"
+    with torch.no_grad():
+        net.context_fc.bias.add_(0.01)              # the parameters moved: everything is recomputed
+    hits = memo.n_memo_hits
+    a, b = plain.draw(n, fk_sim.device), memo.draw(n, fk_sim.device)
+    np.testing.assert_allclose(b["init_qpos"].cpu().numpy(), a["init_qpos"].cpu().numpy(), atol=2e-6)
+    assert memo.n_memo_hits - hits < n and int(memo._memo["have"].sum()) <= n
+
+
 def test_object_pose_of_the_observation_follows_the_simulated_object():
     """env.py's object bookkeeping lives behind the C ABI now (kp_sim_reset_rows / kp_sim_post_step): obj7 = get_obj_qpos(action_one_hot)
     (humanoid_ar_v1.py:466-477) is the action's slice of the simulator's data.qpos[76:111] after every reset and step, [0,0,0,1,0,0,0] for a
