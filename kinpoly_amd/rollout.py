@@ -143,15 +143,18 @@ class EpisodeSource:
         same dict and draws its next clips from the same take probabilities."""
         if self.dataset is None:
             return
-        mine = [[int(ti), int(fs), float(pc)] for ti, fs, pc in zip(take_ind, fr_start, percent)]
+        # arrays, not Python rows: with random-init networks every env-step ends an episode (98 304 of them per 4096 x 24 sample() call)
+        mine = (np.asarray(take_ind, np.int64), np.asarray(fr_start, np.int64), np.asarray(percent, np.float64))
         if _collective_on(group):
             every = [None] * dist.get_world_size(group)
             dist.all_gather_object(every, mine, group=group)
         else:
             every = [mine]
-        for part in every:
-            for ti, fs, pc in part:
-                self.freq_dict[self.dataset.takes[ti]].append([pc, fs])
+        for ti, fs, pc in every:
+            for t in np.unique(ti):
+                m = ti == t
+                pcs, fss = pc[m][-5000:].tolist(), fs[m][-5000:].tolist()          # only the last 5000 entries of a take are kept (agent_ar.py:674-676)
+                self.freq_dict[self.dataset.takes[int(t)]].extend(map(list, zip(pcs, fss)))
         self.freq_dict = {k: (v if len(v) < 5000 else v[-5000:]) for k, v in self.freq_dict.items()}
         self._probs = None
 
