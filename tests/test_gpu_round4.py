@@ -70,3 +70,47 @@ def test_known_answer_box_resting_on_the_table_on_the_device():
     assert len(obj_con) == K.N_LEG_CONTACTS + K.N_BOX_CONTACTS, obj_con
     o = sim.get("obj_qpos")[0].double().cpu().numpy()
     assert np.abs(o[7:9]).max() < 1e-5 and np.abs(o[14:16]).max() < 1e-5 and int(sim.diag()[:, 2].max()) == 0
+
+
+@pytest.mark.timeout(300, method="thread")
+def test_default_queue_schedule_is_bit_identical_over_many_steps_with_objects():
+    """the schedule of kp_step_queue_kernel depends on wall-clock job times (queue_heavy keeps an env whose job ran long; with objects the
+    first jobs are queued longest-env-first from the previous step's cycles) -- who runs a job, and when, must never change a result.  4096 envs
+    of mixed scenes (floor only / standing on the step box / push scene / Can at the legs) with the DEFAULT options over 8 control steps, actions
+    redrawn every step, the substep count changed on the way (15, 15, 5, 15, ...: the queue's yardstick starts from nothing after a change),
+    against the plain one-workgroup-per-env launch: every state and diagnostic bit for bit, no stall."""
+    from kinpoly_amd.sim import STEP_KPM, KpModel, KpSim
+    n = 4096
+    rng = np.random.default_rng(21)
+    x0, y0 = STD["qpos"][0], STD["qpos"][1]
+    scenes = [({}, 0.0), ({4: [x0, y0, 0.3705, 1, 0, 0, 0]}, 0.341), ({1: [x0 + 0.75, y0, 0.921, 1, 0, 0, 0], 2: [x0 + 0.75, y0, 0.7905, 1, 0, 0, 0]}, 0.0),
+              ({3: [x0 + 0.36, y0 + 0.05, 0.69, 1, 0, 0, 0]}, 0.0)]
+    blk = np.zeros((n, 35))
+    for i in range(5):
+        blk[:, 7 * i: 7 * i + 3] = [(i + 1) * 100, 100, 0]
+    qpos = np.tile(STD["qpos"], (n, 1)); qpos[:, 7:] += rng.normal(size=(n, 69)) * 0.1
+    for e in range(n):
+        act_objs, lift = scenes[e % 4]
+        qpos[e, 2] += lift
+        for oi, pose in act_objs.items():
+            blk[e, 7 * oi: 7 * oi + 7] = pose
+    qvel = rng.normal(size=(n, 75)) * 0.3
+    acts = [rng.normal(size=(n, 75)) * 0.3 for _ in range(8)]
+    nsubs = [15, 15, 5, 15, 15, 3, 15, 15]
+    dev = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device="cuda")      # noqa: E731
+
+    def run(**opts):
+        sim = KpSim(KpModel(STEP_KPM, **opts), n, 0)
+        sim.set_objects(dev(blk)); sim.set_state(dev(qpos), dev(qvel)); sim.set_target(dev(np.tile(STD["qpos"], (n, 1))))
+        outs = []
+        for a, ns in zip(acts, nsubs):
+            sim.step_ctrl(dev(a), ns)
+            outs.append([sim.get(k).cpu().numpy() for k in ("qpos", "qvel", "xpos", "obj_qpos", "obj_qvel")] + [sim.diag().copy()])
+        return outs
+    ref = run(substeps_per_job=0)
+    got = run()                                                     # defaults: job queue, queue_heavy 160, lpt_order on (objects)
+    assert KpModel(STEP_KPM).get_option("queue_heavy") == 160 and KpModel(STEP_KPM).get_option("substeps_per_job") > 0
+    for step, (r, g) in enumerate(zip(ref, got)):
+        for k, (a_, b_) in enumerate(zip(r, g)):
+            assert (a_ == b_).all() or (np.isnan(a_) == np.isnan(b_)).all() and (a_[~np.isnan(a_)] == b_[~np.isnan(b_)]).all(), (step, k)
+    assert int((got[-1][5][:, 2] & 255).max()) == 0
