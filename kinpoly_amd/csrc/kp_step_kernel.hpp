@@ -768,6 +768,35 @@ __device__ __forceinline__ void collide(EnvLds& s, const DevTables& T, const Par
                     // mjc_Convex (libccd MPR): geom 1 = the box / cylinder, geom 2 = the hull; one contact, normal into the hull
                     EnvLdsObj& so = static_cast<EnvLdsObj&>(s);
                     const float* g = so.geom + 17 * gi;
+                    // Third, exact-safe cull before the MPR query (round 4: on the envs that end the `objects` launch 13 of 15 queries per substep
+                    // found nothing and cost 5 - 6 k cycles each): a separating PLANE.  lane = hull vertex (xw, already in registers); if every
+                    // vertex lies beyond one face plane of the box -- or beyond a cap plane / a tangent plane of the cylinder -- by more than the
+                    // margin, the hull is farther than the margin from the primitive and libccd would return "no intersection" for the shapes
+                    // inflated by margin / 2 each.  The 0.1 mm slack keeps the fp32 evaluation of the test away from the margin (the query itself
+                    // runs in fp64 on the same fp32 poses); a pair that is not separated by one of these planes goes to the query as before.
+                    {
+                        const float* Rg = g + 7;
+                        const V3 dv = xw - ld3(g + 4);
+                        const float px = Rg[0] * dv.x + Rg[3] * dv.y + Rg[6] * dv.z, py = Rg[1] * dv.x + Rg[4] * dv.y + Rg[7] * dv.z, pz = Rg[2] * dv.x + Rg[5] * dv.y + Rg[8] * dv.z;
+                        const bool has = tid < nvb;
+                        const float lim = P.margin + 1e-4f;
+                        bool sep;
+                        if (g[0] == 0.f) {
+                            const float hx = g[1] + lim, hy = g[2] + lim, hz = g[3] + lim;
+                            sep = __ballot(has && !(px > hx)) == 0ull || __ballot(has && !(px < -hx)) == 0ull || __ballot(has && !(py > hy)) == 0ull ||
+                                  __ballot(has && !(py < -hy)) == 0ull || __ballot(has && !(pz > hz)) == 0ull || __ballot(has && !(pz < -hz)) == 0ull;
+                        } else {
+                            const float hz = g[2] + lim;
+                            sep = __ballot(has && !(pz > hz)) == 0ull || __ballot(has && !(pz < -hz)) == 0ull;
+                            if (!sep) {          // tangent plane facing the hull: the unit radial direction u from the cylinder's axis towards the body origin
+                                const V3 cb = xb - ld3(g + 4);
+                                const float ux = Rg[0] * cb.x + Rg[3] * cb.y + Rg[6] * cb.z, uy = Rg[1] * cb.x + Rg[4] * cb.y + Rg[7] * cb.z;
+                                const float un = sqrtf(ux * ux + uy * uy);
+                                if (un > 1e-6f) sep = __ballot(has && !((px * ux + py * uy) > (g[1] + lim) * un)) == 0ull;
+                            }
+                        }
+                        if (sep) continue;
+                    }
                     const GeomSupport ga(g);
                     float* hrec = s.U + 232;                              // hull record of the support functor (LDS scratch: s.U is free outside the ABA passes)
                     hull_support_store(hrec, xb, xb + mulmat(R, ld3(T.body_ipos + 3 * b)), R);       // centre = the body's COM (xipos)
@@ -1569,10 +1598,19 @@ __device__ __forceinline__ void schur_columns(EnvLdsObj& s, const Params& P, uns
     const unsigned path = (unsigned)__ballot((touch & subtree) != 0u);
     if (path == 0u) return;
     const int npd = 3 * __popc(path) + 3;                       // dofs on the path (the root has six)
-    const int ncmax = min(8, D_SCHUR_SCRATCH / (54 + npd));     // >= 4
     const int ncols = 6 * __popc(cmask);
+    // columns per round: the accumulators [9][nc][6] and the first s0 rows of the right-hand sides [npd][nc] share the 552 floats of jv3 | lim_jv | sa | sw,
+    // the remaining rows go to sv[0, 144) (the hulls' spatial accelerations of y0: read by obj_coupling_u before this call, rewritten by the
+    // back-substitution pass after it).  Round 4: with the 552 floats alone a humanoid lying on the table (14 - 20 bodies on the path) got 4 - 5
+    // columns per round, i.e. three rounds for the push scene's twelve columns; now six, i.e. two.
+    int ncmax = min(8, ncols);
+    while (ncmax > 1 && (54 * ncmax > D_SCHUR_SCRATCH || (npd - (D_SCHUR_SCRATCH - 54 * ncmax) / ncmax) * ncmax > 144)) ncmax--;
+    if (ncols > ncmax) ncmax = min(ncmax, (ncols + ((ncols + ncmax - 1) / ncmax) - 1) / ((ncols + ncmax - 1) / ncmax));      // same number of rounds, evenly filled
     float* ACC = s.jv3;                                          // [9 levels][ncmax][6]
-    float* UU = ACC + 54 * ncmax;                                // [npd][ncmax]
+    float* UUa = ACC + 54 * ncmax;                               // rows [0, s0) of [npd][ncmax]
+    float* UUb = s.sv;                                           // rows [s0, npd)
+    const int s0 = (D_SCHUR_SCRATCH - 54 * ncmax) / ncmax;
+#define KP_UU(slot) ((slot) < s0 ? UUa + (slot) * ncmax : UUb + ((slot) - s0) * ncmax)
     const int nobj = s.nobj;
     for (int c0 = 0; c0 < ncols; c0 += ncmax) {
         const int nc = min(ncmax, ncols - c0);
@@ -1612,7 +1650,7 @@ __device__ __forceinline__ void schur_columns(EnvLdsObj& s, const Params& P, uns
                     const int dd = d0 + j;
                     const float u = -sum8(rmask * s.cdof[6 * dd + rc] * pA);
                     pA += rmask * s.U[6 * dd + rc] * (u * s.Dinv[dd]);
-                    if (colok && r == 0) UU[(sl + j) * ncmax + jc] = u;
+                    if (colok && r == 0) KP_UU(sl + j)[jc] = u;
                 }
             }
             if (colok && rowok) {
@@ -1635,7 +1673,7 @@ __device__ __forceinline__ void schur_columns(EnvLdsObj& s, const Params& P, uns
 #pragma unroll
                 for (int j = 0; j < 3; j++) {
                     const int dd = d0 + j;
-                    const float qdd = (UU[(sl + j) * ncmax + jc] - sum8(rmask * s.U[6 * dd + rc] * a)) * s.Dinv[dd];
+                    const float qdd = (KP_UU(sl + j)[jc] - sum8(rmask * s.U[6 * dd + rc] * a)) * s.Dinv[dd];
                     a += qdd * s.cdof[6 * dd + rc];
                 }
             }
@@ -1658,6 +1696,7 @@ __device__ __forceinline__ void schur_columns(EnvLdsObj& s, const Params& P, uns
         }
         KP_SYNC();
     }
+#undef KP_UU
 }
 
 // the constraint solve with free objects in the scene: same Newton iteration as solve_constraints on the joint unknowns
