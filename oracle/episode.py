@@ -25,14 +25,32 @@ from .kpo import OracleSim
 
 
 class EpisodeOracle:
-    def __init__(self, kpm, kin_policy, cc_policy, body_diff_thresh=10.0, body_diff_gt_thresh=12.0, dt=1.0 / 30.0):
+    ACTION_OBJECTS = ((0,), (1, 2), (3,), (4,))      # sit -> chair, push -> box + table, avoid -> Can, step -> step (humanoid_ar_v1.py:37-39, XML body order)
+
+    def __init__(self, kpm, kin_policy, cc_policy, body_diff_thresh=10.0, body_diff_gt_thresh=12.0, dt=1.0 / 30.0, kpm_path=None):
         """kin_policy / cc_policy: fp64 CPU copies of kinpoly_amd.nets.KinPolicy / PolicyMCP (the networks under test are not the subject
         here; their forward is pinned by tests/golden/policies.npz and traj_ar_net.npz)."""
         self.bp, self.bi, self.par = kpm["body_pos"].reshape(24, 3), kpm["body_ipos"].reshape(24, 3), kpm["body_parent"]
         self.diffw = kpm["body_diffw"]
         self.kin, self.mcp = kin_policy, cc_policy
         self.th, self.th_gt, self.dt = body_diff_thresh, body_diff_gt_thresh, dt
-        self.sim = OracleSim()
+        self.kpm = kpm
+        self.sim = OracleSim() if kpm_path is None else OracleSim(kpm=kpm_path)      # kpm_path: the scene the objects come from (mocap training: ..._all_step.xml)
+
+    def _place_objects(self, ctx):
+        """reset_model's object block (humanoid_ar_v1.py:377-382, convert_obj_qpos :479-496): the action's objects at obj_pose[0], velocities zero,
+        everything else parked (not simulated).  Returns whether the clip has an action object."""
+        self.sim.clear_objects()
+        if "obj_pose" not in ctx or ctx["action_one_hot"].sum() == 0:
+            return False
+        a = int(np.nonzero(ctx["action_one_hot"])[0][0])
+        for slot, oi in enumerate(self.ACTION_OBJECTS[a]):
+            self.sim.set_object(slot, self.kpm, oi, ctx["obj_pose"][0][7 * slot: 7 * slot + 7])
+        return True
+
+    def _obj7(self, has):
+        """get_obj_qpos(action_one_hot) (:466-477): the simulated pose of the action's first object"""
+        return self.sim.get_object(0)[0].copy() if has else None
 
     def _x(self):
         x = {k: self.sim.get(k) for k in ("qpos", "qvel", "xpos", "xquat", "xipos")}
@@ -40,7 +58,7 @@ class EpisodeOracle:
 
     def rollout(self, ctx, T, v_meta=(0.0, 0.0)):
         """ctx: numpy dict of ONE clip (qpos [L, 76], head_pose [L, 7], head_vels [L, 6], obj_head_relative_poses [L, 7], action_one_hot [4],
-        init_qpos [76], init_qvel [75]).  Runs T env-steps, starting a new episode on the same clip after every `done`.  Returns the
+        init_qpos [76], init_qvel [75]; optional obj_pose [L, 7 k]: with a non-zero action_one_hot the action's objects are free bodies of the scene).  Runs T env-steps, starting a new episode on the same clip after every `done`.  Returns the
         memory fields as arrays [T, .] plus 'done' / 'fail' / 'percent'."""
         L = ctx["qpos"].shape[0]
         clip_len = L - 1                                            # ar_context['len'] (humanoid_ar_v1.py:84-88)
@@ -51,11 +69,12 @@ class EpisodeOracle:
         for _ in range(T):
             fresh = state is None
             if fresh:                                              # load_context + reset
+                has_obj = self._place_objects(ctx)
                 self.sim.reset(ctx["init_qpos"], ctx["init_qvel"])
                 cur_t = 0
                 hx = torch.zeros((1, self.kin.rnn_hdim), dtype=torch.float64)
                 qpos, qvel, xp, xq, xi = self._x()
-                state = O.obs_ar(qpos, xp, xq, ctx["head_pose"][0], ctx["head_vels"][0], ctx["obj_head_relative_poses"][0], ctx["action_one_hot"], None)
+                state = O.obs_ar(qpos, xp, xq, ctx["head_pose"][0], ctx["head_vels"][0], ctx["obj_head_relative_poses"][0], ctx["action_one_hot"], self._obj7(has_obj))
             with torch.no_grad():
                 a, hx = self.kin.select_action(torch.from_numpy(state)[None], hx, True)
             a = a[0].numpy()
@@ -75,7 +94,7 @@ class EpisodeOracle:
             end = cur_t >= clip_len
             done = fail or end
             t_ctx = min(cur_t, L - 1)
-            next_state = O.obs_ar(qpos, xp, xq, ctx["head_pose"][t_ctx], ctx["head_vels"][t_ctx], ctx["obj_head_relative_poses"][t_ctx], ctx["action_one_hot"], None)
+            next_state = O.obs_ar(qpos, xp, xq, ctx["head_pose"][t_ctx], ctx["head_vels"][t_ctx], ctx["obj_head_relative_poses"][t_ctx], ctx["action_one_hot"], self._obj7(has_obj))
             r, _ = O.dynamic_supervision_v1(np.concatenate([xp[13], xq[13]]), prev_hpos, O.get_body_quat(qpos), prev_bquat, xp, tgt, ctx["head_pose"][t_ctx],
                                             gt[t_ctx]["bquat"].reshape(-1), gt[t_ctx - 1]["bquat"].reshape(-1), self.dt, O.REWARD_WEIGHTS)
             for k, v in (("state", state), ("action", a), ("mask", 0.0 if done else 1.0), ("next_state", next_state), ("reward", r), ("exp", 1.0),

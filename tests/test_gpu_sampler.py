@@ -378,3 +378,55 @@ def test_sampler_rows_match_the_cpu_episode_loop():
         saw_end |= bool((want["done"] & ~want["fail"]).any()); saw_fail |= bool(want["fail"].any())
     assert saw_end and saw_fail
     assert (b.masks[0] == 0).sum() == 2 and (b.masks[1] == 0).all()
+
+
+def test_sampler_rows_match_the_cpu_episode_loop_with_action_objects():
+    """a1 parity with the scene's free objects (round 4): two envs whose clips carry an action -- `step` (the step box 0.55 m ahead of the humanoid)
+    and `push` (the box on the table, table 0.75 m ahead) -- against oracle/episode.py, which places the objects by convert_obj_qpos at every
+    episode start, simulates them as free bodies of the fp64 C physics and feeds get_obj_qpos(action_one_hot) (the SIMULATED pose of the
+    action's first object) into get_ar_obs_v1.  On the device that pose reaches the observation through kp_sim_reset_rows / kp_sim_post_step
+    (no torch bookkeeping any more): states and next_states carry it in columns 81:88."""
+    import copy
+    from kinpoly_amd.env import BatchedHumanoidAREnv, standing_context
+    from kinpoly_amd.model_compiler import STEP_KPM, read_kpm
+    from kinpoly_amd.nets import KinPolicy
+    from kinpoly_amd.rollout import VectorSampler
+    from oracle.episode import EpisodeOracle
+    n, L, T = 2, 6, 11
+    torch.manual_seed(9)
+    env = BatchedHumanoidAREnv(n, 0, mode="train", joint_controller=True, seed=9)
+    ctx = standing_context(n, L, STD["qpos"], STD["qvel"], env.sim, torch.tensor([0.0, 0.0]))
+    x0, y0 = float(STD["qpos"][0]), float(STD["qpos"][1])
+    obj = torch.zeros((n, L, 14), device=env.device)
+    obj[0, :, :7] = torch.tensor([x0, y0 + 0.95, 0.3705, 1, 0, 0, 0.0], device=env.device)                    # step box ahead (+y is forward)
+    obj[1, :, :7] = torch.tensor([x0, y0 + 0.9, 0.921, 1, 0, 0, 0.0], device=env.device)                      # box on ...
+    obj[1, :, 7:] = torch.tensor([x0, y0 + 0.9, 0.7905, 1, 0, 0, 0.0], device=env.device)                     # ... the table
+    ctx["obj_pose"] = obj
+    ctx["action_one_hot"] = torch.tensor([[0.0, 0, 0, 1], [0.0, 1, 0, 0]], device=env.device)
+    env.load_context(ctx)
+    assert env.obj7 is not None
+    pol = KinPolicy().to(env.device)
+    env.reset()
+    with torch.no_grad():
+        pol.action_fc.weight.mul_(0.02); pol.action_fc.bias.zero_()
+        q0 = ctx["init_qpos"]
+        pol.action_fc.bias[:74] = torch.cat([q0[0, 2:3], torch.tensor([1.0, 0, 0, 0], device=env.device), q0[0, 7:]])
+    sampler = VectorSampler(env, pol, mean_action=True, record_full=True)
+    b = sampler.sample(T)
+    kpm = read_kpm(STEP_KPM)
+    ep = EpisodeOracle(kpm, copy.deepcopy(pol).double().cpu(), copy.deepcopy(env.cc_policy).double().cpu(), kpm_path=STEP_KPM)
+    c = {k: v.double().cpu().numpy() for k, v in ctx.items()}
+    for e in range(n):
+        one = {k: (c[k][e] if c[k].ndim > 1 else c[k]) for k in ("qpos", "head_pose", "head_vels", "obj_head_relative_poses", "action_one_hot", "init_qpos", "init_qvel", "obj_pose")}
+        want = ep.rollout(one, T)
+        g = lambda x: x[e].double().cpu().numpy()      # noqa: E731
+        np.testing.assert_array_equal(g(b.masks), want["mask"])
+        np.testing.assert_array_equal(g(b.fails).astype(bool), want["fail"].astype(bool))
+        np.testing.assert_allclose(g(b.states), want["state"], atol=5e-6)
+        np.testing.assert_allclose(g(b.next_states), want["next_state"], atol=5e-6)
+        np.testing.assert_allclose(g(b.res_qpos), want["res_qpos"], atol=5e-6)
+        np.testing.assert_allclose(g(b.rewards), want["reward"], atol=1e-6)
+        np.testing.assert_allclose(g(b.cc_action), want["cc_action"], atol=1e-6)
+        # the object block of the observation moves with the simulated object (it settles on the floor / the table by ~0.1 mm): not the clip's constant pose
+        assert np.abs(want["next_state"][:, 81:84] - want["state"][0, 81:84]).max() > 1e-5
+        assert (want["mask"] == 0).sum() >= 1, "the clip must end (and the objects be re-placed) inside the window"
