@@ -62,7 +62,8 @@ def build_engine(device_index, seed, threads, workload="tracked"):
     opts = {"threads_per_env": threads, **({"substeps_per_job": int(os.environ["KP_SUBSTEPS_PER_JOB"])} if "KP_SUBSTEPS_PER_JOB" in os.environ else {}),
             **({"lpt_order": int(os.environ["KP_LPT_ORDER"])} if "KP_LPT_ORDER" in os.environ else {}),
             **({"queue_heavy": int(os.environ["KP_QUEUE_HEAVY"])} if "KP_QUEUE_HEAVY" in os.environ else {}),
-            **({"queue_prio": int(os.environ["KP_QUEUE_PRIO"])} if "KP_QUEUE_PRIO" in os.environ else {})}
+            **({"queue_prio": int(os.environ["KP_QUEUE_PRIO"])} if "KP_QUEUE_PRIO" in os.environ else {}),
+            **({"queue_fence": int(os.environ["KP_QUEUE_FENCE"])} if "KP_QUEUE_FENCE" in os.environ else {})}
     env = BatchedHumanoidAREnv(ENVS_PER_GPU, device_index, mode="test" if wild else "train", wild=wild, seed=seed, model_options=opts)
     policy = KinPolicy().to(env.device).float()
     g = torch.Generator().manual_seed(seed)

@@ -42,6 +42,7 @@ namespace kp {
 // tools/micro/spill_report.py).  Re-deriving them from a laundered index per substep / per solve costs a few address adds and keeps
 // their live ranges inside the phase that uses them.
 __device__ __forceinline__ int kp_launder(int x) { asm volatile("" : "+v"(x)); return x; }
+__device__ __forceinline__ int kp_launder_uniform(int x) { asm volatile("" : "+s"(x)); return x; }      // the same for a wave-uniform value (stays in an SGPR)
 
 struct StepArgs {
     DevTables T;
@@ -1864,13 +1865,18 @@ template <bool Q, typename V> __device__ __forceinline__ void gst(V* p, V v) {
 }
 
 template <int NT, bool OBJ, bool FWD, bool Q = false>
-__device__ __forceinline__ void step_body(StepArgs A, const int env_in, const int part) {
-    if (FWD) A.n_substeps = 0;
-    else if (part >= 0) A.n_substeps = (int)(((part < 8 ? A.part_sub_lo >> (8 * part) : A.part_sub_hi >> (8 * (part - 8)))) & 255ull);   // this job's share of the control step
+__device__ __forceinline__ void step_body(const StepArgs& A, const int env_in, const int part) {
+    // this job's share of the control step; A stays the kernel's read-only argument block (a by-value copy that the job modifies is a private copy per job)
+    const int n_substeps = FWD ? 0 : (part >= 0 ? (int)(((part < 8 ? A.part_sub_lo >> (8 * part) : A.part_sub_hi >> (8 * (part - 8)))) & 255ull) : A.n_substeps);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     typename std::conditional<OBJ, EnvLdsObj, EnvLds>::type& s = *reinterpret_cast<typename std::conditional<OBJ, EnvLdsObj, EnvLds>::type*>(smem_raw);
     const int tid0 = threadIdx.x;
-    const int tid = tid0;
+    // laundered per job: the per-lane table addresses of the load section below are invariant over the queue kernel's job loop, so LLVM formed them all at
+    // kernel entry and kept ~20 of them (64-bit, per lane) in scratch for the whole launch, reloading them in every job.  With the store section's
+    // addresses (below) that made the object queue kernel's scratch 464 B per lane = 6.6 MB per XCD on 224 resident waves, more than the 4 MB of L2
+    // behind them: every job's spills and reloads went to HBM (298 MB per launch, 22 x the algorithmic bytes; one workgroup per env: 176 B per lane,
+    // 45 MB).  Now 176 B per lane and 101 MB per launch (profiles/r04/traffic_with_and_without_queue.log).
+    const int tid = kp_launder(tid0);
     const int env = env_in;
     if (env >= A.n_envs) return;
     if (A.env_mask && !A.env_mask[env]) return;
@@ -1888,21 +1894,21 @@ __device__ __forceinline__ void step_body(StepArgs A, const int env_in, const in
     // control step left.  Same code site, same operands: results do not depend on how the control step is cut.
     const bool torque_in = Q && P.stale && P.actuation && part > 0 && A.spd_next != nullptr;
     const bool torque_out = Q && P.stale && P.actuation && part >= 0 && part + 1 < A.n_parts && A.spd_next != nullptr;
-    for (int i = tid; i < D_NQ; i += NT) s.qpos[i] = gld<Q>((torque_in ? A.qpos : A.qpos_d) + (size_t)env * D_NQ + i);
+    for (int i = tid; i < D_NQ; i += NT) s.qpos[i] = gld<Q>((torque_in ? A.qpos : A.qpos_d) + (size_t)env * D_NQ + (unsigned)(i));
     for (int i = tid; i < D_NV; i += NT) {
-        s.qvel[i] = gld<Q>((torque_in ? A.qvel : A.qvel_d) + (size_t)env * D_NV + i);
-        s.arm[i] = T.dof_armature[i]; s.dbody[i] = T.dof_body[i]; s.extra[i] = 0.f; s.qacc[i] = gld<Q>(A.warm + (size_t)env * D_NV + i);
+        s.qvel[i] = gld<Q>((torque_in ? A.qvel : A.qvel_d) + (size_t)env * D_NV + (unsigned)(i));
+        s.arm[i] = T.dof_armature[i]; s.dbody[i] = T.dof_body[i]; s.extra[i] = 0.f; s.qacc[i] = gld<Q>(A.warm + (size_t)env * D_NV + (unsigned)(i));
     }
     if (tid < D_NB) { s.bpar[tid] = (unsigned char)(T.body_parent[tid] < 0 ? 0 : T.body_parent[tid]); s.bsub[tid] = T.body_subtree[tid]; s.bdep[tid] = T.body_depth[tid]; }
     if (tid < 6) s.applied[tid] = 0.f;
-    if (torque_in) for (int i = tid; i < 78; i += NT) s.applied[i] = gld<Q>(A.spd_next + (size_t)env * 80 + i);
+    if (torque_in) for (int i = tid; i < 78; i += NT) s.applied[i] = gld<Q>(A.spd_next + (size_t)env * 80 + (unsigned)(i));
     if (tid < 25) s.IAa[22 * tid + 21] = 0.f;
     if (tid < 22) s.IAa[22 * 24 + tid] = 0.f;
     if (tid < 6) s.pAa[6 * 24 + tid] = 0.f;
     if (tid == 0) { s.ncon = 0; s.nlim = 0; s.flag = 0; }
     if constexpr (OBJ) {
         static_assert(NT == 64, "the object kernel runs one wavefront per environment");
-        for (int i = tid; i < D_MAXGEOM * 17; i += NT) s.geom[i] = A.geoms[(size_t)env * D_MAXGEOM * 17 + i];
+        for (int i = tid; i < D_MAXGEOM * 17; i += NT) s.geom[i] = A.geoms[(size_t)env * D_MAXGEOM * 17 + (unsigned)(i)];
         const int ngs = A.ngeom[env];
         int nobj = 0, ng = ngs;
         if (tid < D_MAXGEOM) s.gobj[tid] = -1;
@@ -1910,8 +1916,8 @@ __device__ __forceinline__ void step_body(StepArgs A, const int env_in, const in
             const int oi = A.obj_slot ? A.obj_slot[(size_t)env * D_MAXOBJ + k] : -1;
             if (oi < 0 || oi >= T.n_obj) break;
             nobj = k + 1;
-            if (tid < 7) s.oq[7 * k + tid] = gld<Q>(A.obj_qpos + (size_t)env * 35 + 7 * oi + tid);
-            if (tid < 6) { s.ov[6 * k + tid] = gld<Q>(A.obj_qvel + (size_t)env * 30 + 6 * oi + tid); s.oqa[6 * k + tid] = gld<Q>(A.obj_warm + (size_t)env * 6 * D_MAXOBJ + 6 * k + tid); }
+            if (tid < 7) s.oq[7 * k + tid] = gld<Q>(A.obj_qpos + (size_t)env * 35 + (unsigned)(7 * oi + tid));
+            if (tid < 6) { s.ov[6 * k + tid] = gld<Q>(A.obj_qvel + (size_t)env * 30 + (unsigned)(6 * oi + tid)); s.oqa[6 * k + tid] = gld<Q>(A.obj_warm + (size_t)env * 6 * D_MAXOBJ + (unsigned)(6 * k + tid)); }
             if (tid < 13) s.oc[13 * k + tid] = T.obj_inertial[13 * oi + tid];
             for (int gi = T.obj_geom_adr[oi]; gi < T.obj_geom_adr[oi + 1] && ng < D_MAXGEOM; gi++, ng++) {
                 if (tid == 0) { s.gobj[ng] = (signed char)k; s.ggi[ng] = (unsigned char)gi; }
@@ -1931,21 +1937,21 @@ __device__ __forceinline__ void step_body(StepArgs A, const int env_in, const in
     // pass n is the forward pass on the final state.  Running the entry pass through the SAME code as a substep's forward pass is what
     // makes a control step cut into jobs bit-identical to an uncut one (two inlined copies need not contract their FMAs alike), and it
     // keeps the kernel's code a third shorter.
-    const int last_pass = (A.n_substeps > 0 && (!P.stale || torque_out)) ? A.n_substeps : A.n_substeps - 1;
+    const int last_pass = (n_substeps > 0 && (!P.stale || torque_out)) ? n_substeps : n_substeps - 1;
     for (int sub = torque_in ? 0 : -1; sub <= last_pass; sub++) {
         // per-lane invariants are re-derived from a laundered lane index every pass (see kp_launder): table addresses, the body's tree
         // level and offset, and -- at the top of each solve -- the Lane8 schedule
         const int tid = kp_launder(tid0);
         const int depth = tid < D_NB ? (int)s.bdep[tid] : -1;
         const V3 bpos = tid < D_NB ? ld3(T.body_pos + 3 * tid) : v3(0.f, 0.f, 0.f);
-        const bool substep = sub >= 0 && sub < A.n_substeps;
+        const bool substep = sub >= 0 && sub < n_substeps;
         if (prof && sub == 0) tstart = __builtin_readcyclecounter();
         if (prof) t0 = __builtin_readcyclecounter();
         // stale mode: the controller sees M / bias of the previous forward pass (cinert, cdof, bias still in LDS)
-        const bool spd_pass = torque_out && sub == A.n_substeps;           // the extra pass of a job that is not the control step's last: the successor's first torque
+        const bool spd_pass = torque_out && sub == n_substeps;           // the extra pass of a job that is not the control step's last: the successor's first torque
         if ((substep || spd_pass) && P.stale && P.actuation && !(torque_in && sub == 0)) { Lane8 La; La.init(kp_launder(tid), T.sched8); spd_torque_rfc<NT, OBJ>(s, T, P, La, tid, tq_row, act_row); }
         if (spd_pass) {
-            for (int i = tid; i < 78; i += NT) gst<Q>(A.spd_next + (size_t)env * 80 + i, s.applied[i]);
+            for (int i = tid; i < 78; i += NT) gst<Q>(A.spd_next + (size_t)env * 80 + (unsigned)(i), s.applied[i]);
             break;
         }
         if (substep && !P.actuation) {              // model option "actuation" = 0: ctrl = qfrc_applied = 0 (torque-free motion; tests)
@@ -1967,9 +1973,9 @@ __device__ __forceinline__ void step_body(StepArgs A, const int env_in, const in
 #pragma unroll
             for (int n = 0; n < (D_NV + NT - 1) / NT; n++) { int i = tid + n * NT; qd_save_v[n] = i < D_NV ? s.qvel[i] : 0.f; }
             KP_SYNC();
-            if (A.n_substeps > 0) {
-                for (int i = tid; i < D_NQ; i += NT) s.qpos[i] = gld<Q>(A.qpos + (size_t)env * D_NQ + i);
-                for (int i = tid; i < D_NV; i += NT) s.qvel[i] = gld<Q>(A.qvel + (size_t)env * D_NV + i);
+            if (n_substeps > 0) {
+                for (int i = tid; i < D_NQ; i += NT) s.qpos[i] = gld<Q>(A.qpos + (size_t)env * D_NQ + (unsigned)(i));
+                for (int i = tid; i < D_NV; i += NT) s.qvel[i] = gld<Q>(A.qvel + (size_t)env * D_NV + (unsigned)(i));
                 KP_SYNC();
             }
             continue;
@@ -1978,7 +1984,7 @@ __device__ __forceinline__ void step_body(StepArgs A, const int env_in, const in
         if constexpr (OBJ) obj_forward(s, T, P, tid);
         KP_T(1)
         collide<NT, OBJ>(s, T, P, tid);
-        if (A.dbg_contacts && sub == A.n_substeps - 1) {      // test hook: the contact set of the last collision pass (con_D still holds the distance)
+        if (A.dbg_contacts && sub == n_substeps - 1) {      // test hook: the contact set of the last collision pass (con_D still holds the distance)
             float* o = A.dbg_contacts + (size_t)env * (1 + D_MAXCON * 9);
             if (tid == 0) o[0] = (float)s.ncon;
             for (int c = tid; c < s.ncon; c += NT) {
@@ -2021,41 +2027,44 @@ __device__ __forceinline__ void step_body(StepArgs A, const int env_in, const in
         KP_SYNC();
         KP_T(6)
     }
-    if (prof && tid == 0 && A.n_substeps > 0) {
+    if (prof && tid == 0 && n_substeps > 0) {
         pc[7] = __builtin_readcyclecounter() - tstart;
         for (int k = 0; k < 8; k++) A.prof[8 * (size_t)env + k] = pc[k];
     }
-    // ---- store
+    // ---- store.  The row addresses are re-derived from laundered copies of the env and lane indices: the ones the load section formed at the top of the job
+    // would otherwise stay live through the whole job (37 spilled 64-bit addresses per lane in the object queue kernel)
+    const int tidS = kp_launder(tid0);
+    const int envS = kp_launder_uniform(env);
     bool bad = false;
-    for (int i = tid; i < D_NQ; i += NT) { float v = s.qpos[i]; bad |= !(fabsf(v) < 1e10f); if (A.n_substeps > 0) gst<Q>(A.qpos + (size_t)env * D_NQ + i, v); }
-    for (int i = tid; i < D_NV; i += NT) { float v = s.qvel[i]; bad |= !(fabsf(v) < 1e10f); if (A.n_substeps > 0) { gst<Q>(A.qvel + (size_t)env * D_NV + i, v); gst<Q>(A.warm + (size_t)env * D_NV + i, s.qacc[i]); } }
+    for (int i = tidS; i < D_NQ; i += NT) { float v = s.qpos[i]; bad |= !(fabsf(v) < 1e10f); if (n_substeps > 0) gst<Q>(A.qpos + (size_t)envS * D_NQ + (unsigned)(i), v); }
+    for (int i = tidS; i < D_NV; i += NT) { float v = s.qvel[i]; bad |= !(fabsf(v) < 1e10f); if (n_substeps > 0) { gst<Q>(A.qvel + (size_t)envS * D_NV + (unsigned)(i), v); gst<Q>(A.warm + (size_t)envS * D_NV + (unsigned)(i), s.qacc[i]); } }
     if (!torque_out) {       // the derived state is read by the control step's NEXT first job only (a job that hands its torque over has no reader for it)
 #pragma unroll
-        for (int n = 0; n < (D_NQ + NT - 1) / NT; n++) { int i = tid + n * NT; if (i < D_NQ) gst<Q>(A.qpos_d + (size_t)env * D_NQ + i, qd_save_q[n]); }
+        for (int n = 0; n < (D_NQ + NT - 1) / NT; n++) { int i = tidS + n * NT; if (i < D_NQ) gst<Q>(A.qpos_d + (size_t)envS * D_NQ + (unsigned)(i), qd_save_q[n]); }
 #pragma unroll
-        for (int n = 0; n < (D_NV + NT - 1) / NT; n++) { int i = tid + n * NT; if (i < D_NV) gst<Q>(A.qvel_d + (size_t)env * D_NV + i, qd_save_v[n]); }
+        for (int n = 0; n < (D_NV + NT - 1) / NT; n++) { int i = tidS + n * NT; if (i < D_NV) gst<Q>(A.qvel_d + (size_t)envS * D_NV + (unsigned)(i), qd_save_v[n]); }
     }
     if (!Q || part == A.n_parts - 1) {      // read-outs: the last job of the control step only (earlier jobs' copies could land later from another L2)
-        for (int i = tid; i < 72; i += NT) A.xpos[(size_t)env * 72 + i] = s.xpos[i];
-        if (tid < D_NB) {                   // xipos = xpos + R ipos of the same forward pass
-            const V3 xi = ld3(s.xpos + 3 * tid) + qrot(Q4{s.xquat[4 * tid], s.xquat[4 * tid + 1], s.xquat[4 * tid + 2], s.xquat[4 * tid + 3]}, ld3(T.body_ipos + 3 * tid));
-            st3(A.xipos + (size_t)env * 72 + 3 * tid, xi);
+        for (int i = tidS; i < 72; i += NT) A.xpos[(size_t)envS * 72 + (unsigned)(i)] = s.xpos[i];
+        if (tidS < D_NB) {                   // xipos = xpos + R ipos of the same forward pass
+            const V3 xi = ld3(s.xpos + 3 * tidS) + qrot(Q4{s.xquat[4 * tidS], s.xquat[4 * tidS + 1], s.xquat[4 * tidS + 2], s.xquat[4 * tidS + 3]}, ld3(T.body_ipos + 3 * tidS));
+            st3(A.xipos + (size_t)envS * 72 + (unsigned)(3 * tidS), xi);
         }
-        for (int i = tid; i < 96; i += NT) A.xquat[(size_t)env * 96 + i] = s.xquat[i];
+        for (int i = tidS; i < 96; i += NT) A.xquat[(size_t)envS * 96 + (unsigned)(i)] = s.xquat[i];
     }
     if constexpr (OBJ) {
-        if (A.n_substeps > 0) {
+        if (n_substeps > 0) {
             for (int k = 0; k < s.nobj; k++) {
-                const int oi = A.obj_slot[(size_t)env * D_MAXOBJ + k];
-                if (tid < 7) { const float v = s.oq[7 * k + tid]; bad |= !(fabsf(v) < 1e10f); gst<Q>(A.obj_qpos + (size_t)env * 35 + 7 * oi + tid, v); }
-                if (tid < 6) { gst<Q>(A.obj_qvel + (size_t)env * 30 + 6 * oi + tid, s.ov[6 * k + tid]); gst<Q>(A.obj_warm + (size_t)env * 6 * D_MAXOBJ + 6 * k + tid, s.oqa[6 * k + tid]); }
+                const int oi = A.obj_slot[(size_t)envS * D_MAXOBJ + k];
+                if (tidS < 7) { const float v = s.oq[7 * k + tidS]; bad |= !(fabsf(v) < 1e10f); gst<Q>(A.obj_qpos + (size_t)envS * 35 + (unsigned)(7 * oi + tidS), v); }
+                if (tidS < 6) { gst<Q>(A.obj_qvel + (size_t)envS * 30 + (unsigned)(6 * oi + tidS), s.ov[6 * k + tidS]); gst<Q>(A.obj_warm + (size_t)envS * 6 * D_MAXOBJ + (unsigned)(6 * k + tidS), s.oqa[6 * k + tidS]); }
             }
         }
     }
     if (bad) atomicOr(&s.flag, 1);
     KP_SYNC();
-    if (tid == 0 && A.diag && A.n_substeps > 0) {
-        int* dg = A.diag + 4 * (size_t)env;
+    if (tidS == 0 && A.diag && n_substeps > 0) {
+        int* dg = A.diag + 4 * (size_t)envS;
         if (part > 0) {      // later job of the same control step: accumulate
             const int d3 = gld<Q>(dg + 3), d2 = gld<Q>(dg + 2);
             niter_total += gld<Q>(dg + 1); s.flag |= d2 & 255; ncap_total += d2 >> 8;
@@ -2063,8 +2072,8 @@ __device__ __forceinline__ void step_body(StepArgs A, const int env_in, const in
         }
         gst<Q>(dg + 0, s.ncon); gst<Q>(dg + 1, niter_total); gst<Q>(dg + 2, (s.flag & 255) | (ncap_total << 8)); gst<Q>(dg + 3, maxcon | (nfact_total << 8));
     }
-    if (tid == 0 && A.cost && A.n_substeps > 0)
-        gst<Q>(A.cost + env, (part > 0 ? gld<Q>(A.cost + env) : 0u) + (unsigned)((__builtin_readcyclecounter() - t_launch) >> 10));
+    if (tidS == 0 && A.cost && n_substeps > 0)
+        gst<Q>(A.cost + envS, (part > 0 ? gld<Q>(A.cost + envS) : 0u) + (unsigned)((__builtin_readcyclecounter() - t_launch) >> 10));
 }
 
 // mj_fullM(model, M, data.qM)[:75, :75] and data.qfrc_bias[:75] as the reference's compute_desired_accel reads them
@@ -2143,7 +2152,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 2 : 1)) void kp_forward_kernel(Step
 // publishes the env's next part at the tail.  An env therefore migrates between waves (its state already round-trips through HBM at
 // job boundaries exactly as it does between launches), the makespan becomes sum / slots + about one job, and the arithmetic is
 // that of kp_step_kernel bit for bit.  Progress: indices are claimed in order, so a wave that waits for entry idx waits for a publish by
-// a wave that is running a job; if nothing is running every entry below n_envs * n_parts has been published.  A bounded spin turns
+// a wave that is running a job; if nothing is running every entry below n_envs * n_parts has been published.  A bounded wait (2 s) turns
 // any violation of that argument into an error flag (jobctr[2]) instead of a hung queue.
 // Memory ordering of the hand-over, two variants (model option "queue_fence"):
 //   1 (default)  the state arrays a later job reads are written / read as relaxed agent-scope atomics (sc1 write-through accesses), and the
@@ -2167,11 +2176,18 @@ __global__ __launch_bounds__(64, 2) void kp_step_queue_kernel(StepArgs A) {
         idx = (unsigned)__builtin_amdgcn_readfirstlane((int)idx);
         if (idx >= total) return;
         unsigned e, spins = 0;
+        unsigned long long t_wait = 0;
         while ((e = __hip_atomic_load(&A.jobq[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0xFFFFFFFFu) {
-            __builtin_amdgcn_s_sleep(32);
+            // Back-off: the first polls come 0.9 us apart (a job published mid-launch is picked up at once); a wave that has waited longer is in the
+            // launch's tail, where the work left is the costliest envs' chains that their own waves keep (queue_heavy) -- it polls every 3.4 ... 27 us.
+            // Every poll is a read that goes through to memory (agent-scope atomic) on behalf of a wave that has nothing to do.
+            if (spins < 16u) __builtin_amdgcn_s_sleep(32);
+            else for (unsigned k = 0; k <= min((spins - 16u) >> 3, 7u); k++) __builtin_amdgcn_s_sleep(127);
             // entries at and beyond total - jobctr[16] will never be published (the counter only grows): nothing left for this wave
             if (idx >= total - __hip_atomic_load(&A.jobctr[16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
-            if (++spins > (1u << 21)) { if (threadIdx.x == 0) atomicExch(&A.jobctr[2], 1u); return; }
+            // a bounded wait (2 s of the 100 MHz clock) turns any violation of the progress argument into an error flag instead of a hung queue
+            if (++spins == 1u) t_wait = __builtin_amdgcn_s_memrealtime();
+            else if ((spins & 63u) == 0u && __builtin_amdgcn_s_memrealtime() - t_wait > 200000000ull) { if (threadIdx.x == 0) atomicExch(&A.jobctr[2], 1u); return; }
         }
         asm volatile("" ::: "memory");                        // the job's (sc1) state loads stay behind the load that saw the entry
         if (A.queue_fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // memory-model variant: acquire side of the publish below
