@@ -23,6 +23,8 @@ $T 200 python tools/obj_bench.py > $E/obj_bench.log 2>&1
 $T 200 python tools/micro/obj_heavy.py > $E/obj_heavy_phases.log 2>&1
 ( KP_FINE=A $T 200 python tools/micro/obj_heavy2.py; KP_FINE=B $T 200 python tools/micro/obj_heavy2.py ) 2>&1 | grep -v amdgpu.ids > $E/obj_heavy_fine.log
 $T 200 python tools/micro/obj_tail.py > $E/obj_tail.log 2>&1
+( KP_PROFILE=1 $T 200 python tools/micro/obj_tail.py; KP_PROFILE=1 KP_OBJ_NEWTON=1 $T 200 python tools/micro/obj_tail.py ) 2>&1 | grep "cycles per substep\|launch ms" > $E/obj_tail_phases.log
+$T 200 python tools/micro/collide_profile.py 2>&1 | grep -v amdgpu.ids > $E/collide_profile.log
 $T 200 python tools/phase_profile.py > $E/phase_cycles.log 2>&1
 $T 200 python tools/micro/flip_profile.py 2>&1 | grep -v amdgpu.ids > $E/flip_profile.log
 $T 200 python tools/micro/factcost_profile.py 2>&1 | grep -v amdgpu.ids > $E/factorisation_cost.log
@@ -32,6 +34,7 @@ $T 900 tools/profile_bench.sh tracked > $E/profile_tracked.log 2>&1
 $T 900 tools/profile_bench.sh objects > $E/profile_objects.log 2>&1
 cp gpurun_out/r04_prof/summary/* $E/ 2>/dev/null
 cp gpurun_out/r04_prof/summary/pmc_bench_*.json profiles/r04/ 2>/dev/null      # bench.py reads the PMC summaries of ITS OWN command from there
+$T 900 tools/traffic_breakdown.sh > $E/traffic_with_and_without_queue_final.log 2>&1
 $T 600 python tools/launches_per_step.py objects $E/lps_objects > $E/launches_per_step_objects.csv 2> /dev/null
 $T 600 python tools/launches_per_step.py tracked $E/lps_tracked > $E/launches_per_step_tracked.csv 2> /dev/null
 $T 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r04_prof/update -o stats -- python tools/update_profile.py > $E/update_profile.log 2>&1
