@@ -225,7 +225,12 @@ class BatchedHumanoidAREnv:
             if has_obj and self._row_obj_qpos is None:             # the first clips with objects arrive through a masked load
                 self._alloc_objects(R)
                 self._bind_context()
-            self.write_context_rows(idx, {k: (v.to(self.device)[idx] if torch.is_tensor(v) and v.shape[:1] == (R,) else v) for k, v in ctx.items()})
+            sub = {}
+            for k, v in ctx.items():
+                if k in ("len", "take_ind", "fr_start") and not torch.is_tensor(v):
+                    v = torch.as_tensor(v)                      # per-row lists / arrays: sliced like the clips
+                sub[k] = v.to(self.device)[idx] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == R else v
+            self.write_context_rows(idx, sub)
 
     @property
     def ctx_len(self):

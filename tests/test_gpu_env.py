@@ -364,6 +364,10 @@ def test_ragged_episode_lengths():
     assert ended_at == [L - 1 for L in lens]
     with pytest.raises(ValueError):
         bad = dict(ctx); bad["len"] = torch.tensor([11, 6, 4, 10]); env.load_context(bad)
+    # masked reload of some envs' clips with their own lengths (a per-row list, as a caller that builds contexts on the host passes it)
+    ctx2 = dict(ctx); ctx2["len"] = [7, 9, 5, 3]
+    env.load_context(ctx2, env_mask=torch.tensor([False, True, False, True]))
+    assert env.row_len.cpu().tolist() == [9, 8, 3, 2]            # ar_context['len'] = frames - 1; rows 0 and 2 keep theirs
 
 
 def test_dataset_to_rollout_pipeline_with_objects(tmp_path):
