@@ -51,7 +51,7 @@ MFMA_FP32_PEAK_TFLOPS = 157.3       # dense fp32 matrix peak (spec sheet): the p
 PROFILE_DIR = os.path.join(ROOT, "profiles", "r04")
 
 
-def build_engine(device_index, seed, threads, workload="tracked"):
+def build_engine(device_index, seed, threads, workload="tracked", n_envs=None):
     from kinpoly_amd.env import BatchedHumanoidAREnv, standing_context
     from kinpoly_amd.nets import KinPolicy, enable_tuned_gemms
     from kinpoly_amd.rollout import VectorSampler
@@ -59,21 +59,22 @@ def build_engine(device_index, seed, threads, workload="tracked"):
     torch.manual_seed(seed)
     std = np.load(os.path.join(ROOT, "tests", "golden", "standing_neutral.npz"))
     wild = workload == "wild_eval"
+    n_envs = ENVS_PER_GPU if n_envs is None else int(n_envs)
     opts = {"threads_per_env": threads, **({"substeps_per_job": int(os.environ["KP_SUBSTEPS_PER_JOB"])} if "KP_SUBSTEPS_PER_JOB" in os.environ else {}),
             **({"lpt_order": int(os.environ["KP_LPT_ORDER"])} if "KP_LPT_ORDER" in os.environ else {}),
             **({"queue_heavy": int(os.environ["KP_QUEUE_HEAVY"])} if "KP_QUEUE_HEAVY" in os.environ else {}),
             **({"queue_prio": int(os.environ["KP_QUEUE_PRIO"])} if "KP_QUEUE_PRIO" in os.environ else {}),
             **({"queue_fence": int(os.environ["KP_QUEUE_FENCE"])} if "KP_QUEUE_FENCE" in os.environ else {})}
-    env = BatchedHumanoidAREnv(ENVS_PER_GPU, device_index, mode="test" if wild else "train", wild=wild, seed=seed, model_options=opts)
+    env = BatchedHumanoidAREnv(n_envs, device_index, mode="test" if wild else "train", wild=wild, seed=seed, model_options=opts)
     policy = KinPolicy().to(env.device).float()
     g = torch.Generator().manual_seed(seed)
-    headings = (torch.rand(ENVS_PER_GPU, generator=g) * 2 - 1) * np.pi
+    headings = (torch.rand(n_envs, generator=g) * 2 - 1) * np.pi
     if workload == "objects":
         ctx = object_contexts(env, std, seed)
     else:
-        ctx = standing_context(ENVS_PER_GPU, CLIP_LEN, std["qpos"], std["qvel"], env.sim, headings)
+        ctx = standing_context(n_envs, CLIP_LEN, std["qpos"], std["qvel"], env.sim, headings)
     if wild:            # the kinematic roll-out the fail-safe falls back to (ar_context['ar_qpos' / 'ar_qvel']): the clip itself
-        ctx["ar_qpos"], ctx["ar_qvel"] = ctx["qpos"].clone(), torch.zeros((ENVS_PER_GPU, CLIP_LEN, 75), device=env.device)
+        ctx["ar_qpos"], ctx["ar_qvel"] = ctx["qpos"].clone(), torch.zeros((n_envs, CLIP_LEN, 75), device=env.device)
     env.load_context(ctx)
     sampler = VectorSampler(env, policy, mean_action=wild)
     sampler.start()
@@ -89,8 +90,8 @@ def object_contexts(env, std, seed):
     from kinpoly_amd.sim import STEP_KPM
     takes = D.synthetic_takes(env.sim, std["qpos"], n_per_action=8, T_range=(CLIP_LEN + 10, CLIP_LEN + 60), body_mass=read_kpm(STEP_KPM)["body_mass"], seed=seed)
     ds = D.StateARDataset(takes, fr_num=CLIP_LEN, seed=seed, device=env.device)
-    ctx = ds.sample_batch(ENVS_PER_GPU, use_freq=False)
-    starts = ds.rng.randint(0, 10, ENVS_PER_GPU)
+    ctx = ds.sample_batch(env.n, use_freq=False)
+    starts = ds.rng.randint(0, 10, env.n)
     ctx = ds.batch(ctx["take_ind"].numpy(), starts, CLIP_LEN)
     ctx["init_qpos"], ctx["init_qvel"] = ctx["qpos"][:, 0].contiguous(), ctx["qvel"][:, 0].contiguous()
     return ctx

@@ -114,3 +114,22 @@ def test_default_queue_schedule_is_bit_identical_over_many_steps_with_objects():
         for k, (a_, b_) in enumerate(zip(r, g)):
             assert (a_ == b_).all() or (np.isnan(a_) == np.isnan(b_)).all() and (a_[~np.isnan(a_)] == b_[~np.isnan(b_)]).all(), (step, k)
     assert int((got[-1][5][:, 2] & 255).max()) == 0
+
+
+def test_pool_advance_kernel_matches_the_ring_arithmetic():
+    """kp_pool_advance (the device side of the episode pool) against the three lines of torch it replaces, over random done masks."""
+    from kinpoly_amd import sim as kpsim
+    n, D = 1000, 5
+    g = torch.Generator().manual_seed(0)
+    head = torch.randint(0, D, (n,), generator=g).to(torch.int32).cuda()
+    ahead = torch.randint(1, D, (n,), generator=g).to(torch.int32).cuda()
+    row = (head.long() * n + torch.arange(n, device="cuda")).to(torch.int32)
+    for _ in range(6):
+        done = (torch.rand(n, generator=g) < 0.4).cuda() & (ahead > 0)
+        want_head = torch.where(done, (head + 1) % D, head)
+        want_ahead = ahead - done.to(torch.int32)
+        want_row = (want_head.long() * n + torch.arange(n, device="cuda")).to(torch.int32)
+        kpsim.pool_advance(done, head, ahead, row, D)
+        assert torch.equal(head, want_head) and torch.equal(ahead, want_ahead) and torch.equal(row, want_row)
+    with pytest.raises(ValueError):
+        kpsim.pool_advance(done, head.long(), ahead, row, D)
