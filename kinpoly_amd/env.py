@@ -67,7 +67,6 @@ class BatchedHumanoidAREnv:
         self.row = None           # int32 [N]: context row every env reads (load_context / set_rows)
         self.row_len = None       # int32 [R]: ar_context['len'] of every row
         self.row_meta = None      # [R, 2]: take index, first frame of every row (v_meta of the reference's memory rows)
-        self.obj_qpos = None      # not None: the clips carry action objects and the simulator holds data.qpos[76:111] (sim.get('obj_qpos'))
         self.obj7 = None          # [N,7]  = get_obj_qpos(action_one_hot), kept by kp_sim_reset_rows / kp_sim_post_step
         self._row_obj_qpos = None  # [R,35] = convert_obj_qpos(action_one_hot, obj_pose[0]) of every context row
         self._ctx_struct = None
@@ -111,17 +110,16 @@ class BatchedHumanoidAREnv:
         self.row_len = torch.full((R,), T - 1, dtype=torch.int32, device=dev)
         self.row_meta = z(R, 2)
         self.row = torch.arange(self.n, device=dev, dtype=torch.int32)
-        self._row_obj_qpos = self.obj7 = self.obj_qpos = None
+        self._row_obj_qpos = self.obj7 = None
         if objects:
             self._alloc_objects(R)
         self._bind_context()
 
     def _alloc_objects(self, R):
         # data.qpos[76:111] of every row as reset_model builds it (convert_obj_qpos); obj7 [N,7] = get_obj_qpos(action_one_hot) per env, kept by
-        # kp_sim_reset_rows / kp_sim_post_step; obj_qpos: the flag "this env simulates objects" for callers (the poses live in the simulator: sim.get('obj_qpos'))
+        # kp_sim_reset_rows / kp_sim_post_step (the simulated poses themselves live in the simulator: the obj_qpos property)
         self._row_obj_qpos = convert_obj_qpos(torch.zeros((R, 4), device=self.device), torch.zeros((R, 7), device=self.device))[0]
         self.obj7 = torch.tensor([0.0, 0, 0, 1, 0, 0, 0], device=self.device).repeat(self.n, 1).contiguous()
-        self.obj_qpos = True
 
     def _bind_context(self):
         c = self.ctx
@@ -231,6 +229,16 @@ class BatchedHumanoidAREnv:
                     v = torch.as_tensor(v)                      # per-row lists / arrays: sliced like the clips
                 sub[k] = v.to(self.device)[idx] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == R else v
             self.write_context_rows(idx, sub)
+
+    @property
+    def has_objects(self):
+        """the loaded clips carry action objects (they are free bodies of the envs)"""
+        return self._row_obj_qpos is not None
+
+    @property
+    def obj_qpos(self):
+        """data.qpos[76:111] of every env [N, 35] (get_obj_qpos(), humanoid_ar_v1.py:466-477), or None when the clips carry no objects"""
+        return self.sim.get("obj_qpos") if self.has_objects else None
 
     @property
     def ctx_len(self):
@@ -527,7 +535,7 @@ class HumanoidAREnv:
 
     def get_obj_qpos(self, action_one_hot=None):
         """humanoid_ar_v1.py:466-477: the whole object block, or the pose of the action's (first) object."""
-        full = self._g("obj_qpos") if self.b.obj_qpos is not None else convert_obj_qpos(torch.zeros((1, 4)), torch.zeros((1, 7)))[0][0].double().numpy()
+        full = self._g("obj_qpos") if self.b.has_objects else convert_obj_qpos(torch.zeros((1, 4)), torch.zeros((1, 7)))[0][0].double().numpy()
         if action_one_hot is None:
             return full
         if np.sum(action_one_hot) == 0:
@@ -536,7 +544,7 @@ class HumanoidAREnv:
         return full[ACTION_INDEX_MAP[a]:ACTION_INDEX_MAP[a] + ACTION_LEN[a]][:7]
 
     def get_obj_qvel(self):
-        return self._g("obj_qvel") if self.b.obj_qpos is not None else np.zeros(30)
+        return self._g("obj_qvel") if self.b.has_objects else np.zeros(30)
 
     def ar_fail_safe(self):
         self.b.ar_fail_safe()

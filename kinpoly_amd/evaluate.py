@@ -26,7 +26,7 @@ def run_sequences(env, policy_net, keys, fail_safe=False, max_steps=100000):
     rec = {"target": [], "pred": [], "obj_pose": [], "active": []}
     for _ in range(max_steps):
         rec["target"].append(env.sim.get("target_qpos")); rec["pred"].append(env.get_humanoid_qpos())
-        rec["obj_pose"].append(env.sim.get("obj_qpos") if env.obj_qpos is not None else None); rec["active"].append(active.clone())
+        rec["obj_pose"].append(env.obj_qpos); rec["active"].append(active.clone())
         action, hx = policy_net.select_action(obs, hx, True, env.gen)
         obs, _, done, info = env.step(action.contiguous())
         newly = done & active

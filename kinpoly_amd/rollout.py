@@ -216,9 +216,13 @@ class VectorSampler:
         T = first["qpos"].shape[1]
         if self.source.dataset is not None:
             T = max(T, int(self.source.dataset.fr_num))
-        one_hot = first["action_one_hot"]
-        objects = "obj_pose" in first and (self.source.dataset.has_objects if self.source.dataset is not None and hasattr(self.source.dataset, "has_objects")
-                                           else bool((one_hot.reshape(-1, 4).sum(1) > 0).any()))
+        # do the clips carry action objects?  A data set knows (host side); a context_fn source is asked once, here
+        if "obj_pose" not in first:
+            objects = False
+        elif self.source.dataset is not None:
+            objects = bool(self.source.dataset.has_objects)
+        else:
+            objects = bool((first["action_one_hot"].reshape(-1, 4).sum(1) > 0).any())
         env.alloc_context(D * N, T, objects=objects, with_ar="ar_qpos" in first, obj_width=first["obj_pose"].shape[2] if "obj_pose" in first else 14)
         ar = torch.arange(N, device=dev)
         env.write_context_rows(ar, first)
