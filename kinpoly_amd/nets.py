@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 
 
-TUNED_GEMMS = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "assets", "tunableop_gfx950.csv")
+TUNED_GEMMS = __import__("os").environ.get("KP_TUNED_GEMMS") or __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "assets", "tunableop_gfx950.csv")
 
 
 def enable_tuned_gemms(path: str = TUNED_GEMMS) -> bool:
