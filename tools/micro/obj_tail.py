@@ -26,6 +26,8 @@ if os.environ.get("KP_PROFILE") == "1":
     top = order[:40]
     print("cycles per substep, mean over the 40 costliest envs:", {n_: int(v) for n_, v in zip(names8, pe[top].mean(0))})
     print("cycles per substep, median env:", {n_: int(v) for n_, v in zip(names8, np.median(pe, 0))})
+    for e in np.argsort(-pe[:, 7])[:4]:
+        print(f"cycles per substep, env {e}:", {n_: int(v) for n_, v in zip(names8, pe[e])}, "newton it/substep %.1f contacts %d" % (d[e, 1] / 15, d[e, 0]))
 for e in order[:16]:
     a = cls[e]
     print(f"env {e} class {names[a]} cost {cost[e] / np.median(cost):.1f}x median  contacts {d[e, 0]} (max {d[e, 3] & 255}) newton it/substep {d[e, 1] / 15:.1f} nfact/substep {(d[e, 3] >> 8) / 15:.1f} cap hits {d[e, 2] >> 8}"
