@@ -1619,16 +1619,19 @@ __device__ __forceinline__ void schur_columns(EnvLdsObj& s, const Params& P, uns
         const int jc = colok ? jl : 0;
         const int gcol = (cmask == 2u ? 6 : 0) + c0 + jc;        // column of the object system
         const int kcol = gcol / 6, icol = gcol - 6 * kcol;
-        for (int i = tid; i < 54 * ncmax; i += 64) ACC[i] = 0.f;
-        KP_SYNC();
-        // ---- leaves -> root: bias forces.  ACC[level][column][row] belongs to lane (column, row) alone.
+        // ---- leaves -> root: bias forces.  The per-depth accumulators belong to lane (column, row) alone and live in its registers (accd[depth], indexed by
+        // the wave-uniform depth of the body being visited): the walk is a serial chain over the path's bodies, and a read-modify-write of an LDS
+        // accumulator per body put two LDS round trips on that chain (round 4: the walk was latency-bound; 176 k cycles per substep on the env that ends the
+        // objects launch, whose path is the whole tree)
+        float accd[D_NLEV];
+#pragma unroll
+        for (int k = 0; k < D_NLEV; k++) accd[k] = 0.f;
         unsigned todo = path;
         while (todo) {
             const int b = 31 - __clz((int)todo);
             todo &= ~(1u << b);
-            const int d = s.bdep[b];
-            float* acc = ACC + (d * ncmax + jc) * 6;
-            float pA = (colok && rowok) ? acc[r] : 0.f;
+            const int d = __builtin_amdgcn_readfirstlane((int)s.bdep[b]);
+            float pA = accd[d];
             if ((touch >> b) & 1u) {                             // right-hand side: + (K_c e_icol)[r] for this hull's contacts on object kcol
                 V3 Pi, Pr;                                       // rows of P = [[p]x ; 1]: K_c = P M P^T, entry (r, i) = P_r . (M P_i)
                 for (int c = s.con_start[b]; c < s.con_start[b + 1]; c++) {
@@ -1654,20 +1657,19 @@ __device__ __forceinline__ void schur_columns(EnvLdsObj& s, const Params& P, uns
                     if (colok && r == 0) KP_UU(sl + j)[jc] = u;
                 }
             }
-            if (colok && rowok) {
-                acc[r] = 0.f;
-                if (b > 0) ACC[((d - 1) * ncmax + jc) * 6 + r] += pA;
-            }
+            accd[d] = 0.f;
+            if (b > 0) accd[d - 1] += (colok && rowok) ? pA : 0.f;
         }
         KP_SYNC();
-        // ---- root -> leaves: spatial accelerations (ACC now holds them per level); at a touching hull, H_oh z accumulates per object
+        // ---- root -> leaves: spatial accelerations (accd[depth] now holds the last visited body's at that depth: a body's parent is the last one
+        // visited one level up, bodies being in depth-first order); at a touching hull, H_oh z accumulates per object
         float cpl0 = 0.f, cpl1 = 0.f;
         todo = path;
         while (todo) {
             const int b = __ffs((int)todo) - 1;
             todo &= todo - 1u;
-            const int d = s.bdep[b];
-            float a = (b > 0 && colok && rowok) ? ACC[((d - 1) * ncmax + jc) * 6 + r] : 0.f;
+            const int d = __builtin_amdgcn_readfirstlane((int)s.bdep[b]);
+            float a = (b > 0 && colok && rowok) ? accd[d - 1] : 0.f;
             const int slot0 = b == 0 ? 0 : 3 + 3 * __popc(path & ((1u << b) - 1u));
             for (int g = 0; g < (b == 0 ? 2 : 1); g++) {
                 const int d0 = b == 0 ? (g == 0 ? 0 : 3) : 6 + 3 * (b - 1), sl = b == 0 ? d0 : slot0;
@@ -1678,10 +1680,12 @@ __device__ __forceinline__ void schur_columns(EnvLdsObj& s, const Params& P, uns
                     a += qdd * s.cdof[6 * dd + rc];
                 }
             }
-            if (colok && rowok) ACC[(d * ncmax + jc) * 6 + r] = a;
+            accd[d] = a;
             if ((touch >> b) & 1u) {
                 KP_SYNC();
-                const S6 ab = lds6(ACC + (d * ncmax + jc) * 6);             // the column's whole 6-vector (its six row lanes just stored it)
+                if (colok && rowok) ACC[jc * 6 + r] = a;                    // the column's whole 6-vector is needed by every lane of the column: through LDS, for the touching hulls only
+                KP_SYNC();
+                const S6 ab = lds6(ACC + jc * 6);
                 for (int c = s.con_start[b]; c < s.con_start[b + 1]; c++) {
                     const int B = s.con_b2[c];
                     if (B < D_NB) continue;
