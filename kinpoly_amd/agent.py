@@ -9,6 +9,9 @@
                       policy_net only -- leaves the UHC weights alone unless `train_uhc` is set (PPOTrainer)
     step_update       supervised one-step update x num_step_update (policy_ar.py:277-287) + its own LambdaLR (`step_lr`, :88-89)
     checkpoints       reference pickle layout (kinpoly_amd/checkpoint.py)
+    log / eval        LoggerRL statistics of every sample() call (`info['log']`, merged over ranks) and the `log_train` line (:243-262); `eval_policy`
+                      (:394-448): every take of a data set played whole with mean actions, coverage, freq_dict feedback, eval_dict_<mode>.pt;
+                      freq_dict.pt written after every iteration when a result_dir is given (:297) and read back at start (:228-234)
 
 Episodes come from a `StateARDataset` (the reference's feature-file sampler, kinpoly_amd/dataset.py) or, for the synthetic
 single-clip configs of SURVEY.md section 8(d), from a `context_fn(n) -> dict` callable.
@@ -26,7 +29,7 @@ from .context import PolicyARContext, TrajARNet
 from .env import BatchedHumanoidAREnv
 from .model_compiler import read_kpm
 from .nets import MLP, Value, enable_tuned_gemms
-from .rollout import EpisodeSource, PPOTrainer, VectorSampler, _allreduce_grads, lambda_lr
+from .rollout import EpisodeSource, LoggerRL, PPOTrainer, VectorSampler, _allreduce_grads, _collective_on, lambda_lr
 from .supervised import TorchFK, update_supervised_step
 
 
@@ -35,20 +38,20 @@ class AgentAR:
                  policy_lr=1e-5, value_lr=3e-4, supervised_lr=5e-4, num_optim_epoch=10, num_step_update=20, gamma=0.95, tau=0.95,
                  clip_epsilon=0.2, rl_update=True, step_update=True, model_options=None, dataset=None, sampling_temp=0.3, sampling_freq=0.5,
                  pool_depth=4, num_epoch_fix=100, num_epoch=10000, joint_controller=False, grad_joint=False, grad_alternate=False, train_uhc=False,
-                 cache_init_context=False):
+                 cache_init_context=False, log_std=-3.2, policy_weightdecay=0.0, value_weightdecay=0.0, smooth=True, result_dir=None, eval_envs=None):
         rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
         enable_tuned_gemms()          # library GEMM solution per shape (rollout and update shapes at 4096 envs); selection only
         torch.manual_seed(seed + rank)
         self.env = BatchedHumanoidAREnv(n_envs, device, mode="train", wild=wild, seed=seed + rank, model_options=model_options,
                                         joint_controller=joint_controller)
         self.device = self.env.device
-        self.policy_net = TrajARNet().to(self.device)
+        self.policy_net = TrajARNet(log_std=log_std).to(self.device)
         self.value_net = Value(MLP(105, (512, 256), "relu")).to(self.device)
         self._sync_params()
         self.kin_sim = kpsim.KpSim(self.env.model, n_envs, self.device.index)      # physics-free twin for the kinematic roll-out
         # a training episode reads init_qpos / init_qvel of its context only: the whole-clip kinematic roll-out and the [N, T, 1024] context
         # feature sequence of init_context are not computed (PolicyARContext; evaluate.py builds its own with need_rollout=True)
-        self.ctx_builder = PolicyARContext(self.policy_net, self.kin_sim, smooth=True, need_rollout=False, keep_context_feat=False)
+        self.ctx_builder = PolicyARContext(self.policy_net, self.kin_sim, smooth=smooth, need_rollout=False, keep_context_feat=False)
         # sampling_temp / sampling_freq: kin_poly.yml:67-68; freq_dict lives in the source (agent_ar.py:228-234)
         self.source = EpisodeSource(dataset=dataset, context_fn=context_fn if dataset is None else None,
                                     ctx_builder=self.ctx_builder if use_init_context else None,
@@ -56,7 +59,8 @@ class AgentAR:
         self.horizon, self.rl_update, self.step_update, self.num_step_update = horizon, rl_update, step_update, num_step_update
         self.grad_joint, self.grad_alternate = grad_joint, grad_alternate       # policy_specs.grad_joint / grad_alternate (agent_ar.py:703, 746-747)
         self.trainer = PPOTrainer(self.policy_net, self.value_net, gamma, tau, clip_epsilon, policy_lr, value_lr, num_optim_epoch,
-                                  num_epoch_fix=num_epoch_fix, num_epoch=num_epoch, cc_policy=self.env.cc_policy if joint_controller else None, train_uhc=train_uhc)
+                                  num_epoch_fix=num_epoch_fix, num_epoch=num_epoch, cc_policy=self.env.cc_policy if joint_controller else None, train_uhc=train_uhc,
+                                  policy_weightdecay=policy_weightdecay, value_weightdecay=value_weightdecay)
         self.opt_sup = torch.optim.Adam([p for p in self.policy_net.parameters() if p.requires_grad], lr=supervised_lr)
         self.sched_sup = lambda_lr(self.opt_sup, num_epoch_fix, num_epoch)          # PolicyAR.setup_optimizers / step_lr (policy_ar.py:45-62, 88-89)
         kpm = read_kpm(kpsim.DEFAULT_KPM)
@@ -64,6 +68,18 @@ class AgentAR:
         self.sampler = VectorSampler(self.env, self.policy_net, record_qpos=True, source=self.source, pool_depth=pool_depth,
                                      record_full=joint_controller)
         self.epoch = 0
+        self.result_dir, self.eval_envs, self.test_datasets, self._eval = result_dir, eval_envs, [], None
+        if result_dir is not None and dataset is not None:          # setup_logging (:228-234): resume the sampling history of an earlier run
+            import os
+            fp = os.path.join(result_dir, "freq_dict.pt")
+            if os.path.exists(fp):
+                try:
+                    import joblib
+                    got = joblib.load(fp)
+                    if set(got) == set(self.source.freq_dict):
+                        self.source.freq_dict = {k: [list(x) for x in v] for k, v in got.items()}
+                except Exception:                                    # "error parsing freq_dict, using empty one" (:232-234)
+                    pass
         self.sampler.start()
 
     @property
@@ -94,10 +110,71 @@ class AgentAR:
         t2 = time.time()
         self.epoch += 1
         n = batch.rewards.numel()
+        log = self.sampler.log
+        log.sample_time = t1 - t0
+        if _collective_on(self.trainer.group):                   # LoggerRL.merge over the workers (agent_ar.py:677) = over the ranks here
+            every = [None] * dist.get_world_size(self.trainer.group)
+            dist.all_gather_object(every, log, group=self.trainer.group)
+            log = LoggerRL.merge(every)
+        info["log"] = log
+        if self.result_dir is not None and self.source.dataset is not None and (not dist.is_initialized() or dist.get_rank() == 0):
+            import os
+            os.makedirs(self.result_dir, exist_ok=True)
+            self.source.save_freq_dict(os.path.join(self.result_dir, "freq_dict.pt"))       # joblib.dump(self.freq_dict, ...) after every iteration (:297)
         info.update(T_sample=t1 - t0, T_update=t2 - t1, T_total=time.time() - t0, num_steps=n, avg_reward=float(batch.rewards.mean()),
                     fail_rate=float(batch.fails.float().mean()), env_steps_per_s=n / (t1 - t0), episodes=len(batch.episodes.get("percent", ())),
                     pool_exhausted=self.sampler.pool_exhausted, clips_drawn=self.source.n_drawn, init_context_memo_hits=self.source.n_memo_hits, top_ups=self.sampler.top_ups, policy_lr=self.trainer.opt_p.param_groups[0]["lr"])
         return info
+
+    def log_train(self, info, cfg_id="kin_poly", max_iter_num=20000) -> str:
+        """The reference's per-iteration log line (agent_ar.py:243-255), from info['log']."""
+        log = info["log"]
+        done, left = self.epoch, max(max_iter_num - self.epoch, 0)
+        eta = left * info["T_total"]
+        eta_str = "%02d:%02d:%02d" % (eta // 3600, (eta % 3600) // 60, eta % 60)
+        c_info = ",".join("%.4f" % x for x in log.avg_c_info)
+        return (f"Ep: {done - 1}\t {cfg_id} \tT_s {info['T_sample']:.2f}\t T_u {info['T_update']:.2f}\tETA {eta_str} \texpert_R_avg {log.avg_c_reward:.4f} [{c_info}]"
+                f"\texpert_R_range ({log.min_c_reward:.4f}, {log.max_c_reward:.4f})\teps_len {log.avg_episode_len:.2f}")
+
+    def _eval_engine(self):
+        """A second, smaller engine for evaluation roll-outs (the training envs are in the middle of their episodes and of their clip rings):
+        test mode, its own kinematic twin for the whole-take roll-out of init_context.  The reference switches its one env to test mode
+        instead (eval_seq, :463-470)."""
+        if self._eval is None:
+            n = int(self.eval_envs or min(self.env.n, 256))
+            env = BatchedHumanoidAREnv(n, self.device.index, mode="test", wild=self.env.wild, seed=0, cc_policy=self.env.cc_policy, cc_running_state=self.env.cc_running_state)
+            env.reward_cfg.body_diff_thresh, env.reward_cfg.body_diff_gt_thresh = self.env.reward_cfg.body_diff_thresh, self.env.reward_cfg.body_diff_gt_thresh
+            builder = PolicyARContext(self.policy_net, kpsim.KpSim(env.model, n, self.device.index), smooth=self.ctx_builder.smooth, need_rollout=True, keep_context_feat=False)
+            self._eval = (env, builder)
+        return self._eval
+
+    def eval_policy(self, data_mode="train"):
+        """AgentAR.eval_policy (:394-448): every take of the training set (`train`) or of every set in `self.test_datasets` (`test`) is played whole
+        with mean actions; a take counts as covered when it runs to its end (`percent == 1`).  `train` feeds the result back into the sampling
+        history (one [percent, 0] entry for a covered take, three for a failed one, :427-433).  Writes / extends `eval_dict_<mode>.pt` under
+        result_dir.  Returns the reference's list of {"coverage_<name>": {"mean_coverage", "num_coverage", "all_coverage"}}."""
+        from .evaluate import eval_dataset
+        sets = [self.source.dataset] if data_mode == "train" else list(self.test_datasets)
+        env, builder = self._eval_engine()
+        out = []
+        for ds in sets:
+            res = eval_dataset(env, self.policy_net, builder, ds)
+            ok = {k: r["percent"] == 1 for k, r in res.items()}
+            if data_mode == "train":
+                for k, r in res.items():
+                    self.source.freq_dict[k].extend([[r["percent"], 0]] * (1 if ok[k] else 3))
+                self.source._probs = None
+            if self.result_dir is not None and (not dist.is_initialized() or dist.get_rank() == 0):
+                import os
+                import joblib
+                os.makedirs(self.result_dir, exist_ok=True)
+                path = os.path.join(self.result_dir, f"eval_dict_{data_mode}.pt")
+                hist = joblib.load(path) if os.path.exists(path) else {}
+                hist[self.epoch] = {k: r["percent"] for k, r in res.items()}
+                joblib.dump(hist, path)
+            name = getattr(ds, "name", data_mode)
+            out.append({f"coverage_{name}": {"mean_coverage": float(sum(ok.values())) / max(len(ok), 1), "num_coverage": int(sum(ok.values())), "all_coverage": len(ok)}})
+        return out
 
     def save_checkpoint(self, path):
         return ck.save_checkpoint(path, self.policy_net, self.value_net, None, self.env.cc_policy)

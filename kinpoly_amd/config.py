@@ -1,0 +1,127 @@
+"""The `config/statear/<id>.yml` reader: the part of kin_poly/utils/statear_smpl_config.py (`Config`, :14-128) the rollout / PPO path reads.
+
+    cfg = Config("kin_poly", config_root="/path/to/KinPoly")        # finds config/**/kin_poly.yml as the reference does (:26-29)
+    cfg = Config("/path/to/my_run.yml")                              # or a file
+    agent = AgentAR(n_envs, dataset=ds, **cfg.agent_kwargs())
+    cfg.apply_reward_weights(agent.env)
+
+Same directory layout as the reference (`results/all/statear/<id>/{models,models_policy,results,log}`, :33-41), same keys, same defaults where
+the reference gives one (`.get(key, default)` in Config / AgentAR).  What the engine does not take from the file, because the HIP path fixes it:
+`mujoco_model` (the compiled blobs of kinpoly_amd/assets are humanoid_smpl_neutral_mesh_all[_step].xml, agent_ar.py:165-169), `model_specs`
+of another architecture than TrajARNet's (checked: a mismatch raises), `policy_optimizer` other than Adam (checked), `obs_*` switches other than the
+kin_poly.yml values (checked).  Nothing here needs a GPU.
+"""
+from __future__ import annotations
+
+import glob
+import os
+
+import yaml
+
+ALL_ACTIONS = ("sit", "push", "avoid", "step")
+
+# what the kernels implement (kin_poly.yml); a config that asks for something else is refused instead of silently run differently
+# key: (what the kernels implement, the reference's default when the file omits the key -- statear_smpl_config.py:118-143)
+_FIXED = {"use_of": (False, True), "use_head": (True, True), "use_action": (True, True), "use_vel": (False, False), "use_context": (False, True),
+          "obs_coord": ("heading", "heading"), "root_deheading": (True, False), "obs_global": (True, False), "obs_quat": (True, False), "has_z": (True, True)}
+_FIXED_MODEL = {"model_v": 1, "rnn_hdim": 1024, "mlp_hsize": [1024, 512, 256], "mlp_htype": "relu", "rnn_type": "gru"}
+_FIXED_POLICY = {"policy_v": 1, "fix_std": True, "policy_htype": "relu", "policy_hsize": [512, 256], "value_htype": "relu", "value_hsize": [512, 256],
+                 "policy_optimizer": "Adam", "value_optimizer": "Adam", "reward_id": "dynamic_supervision_v1", "end_reward": False}
+
+
+class ConfigError(ValueError):
+    pass
+
+
+class Config:
+    def __init__(self, cfg_id: str, action: str = "all", wild: bool = False, base_dir: str = "results", config_root: str | None = None, create_dirs: bool = False):
+        if os.path.isfile(cfg_id):
+            path, cfg_id = cfg_id, os.path.splitext(os.path.basename(cfg_id))[0]
+        else:
+            files = glob.glob(os.path.join(config_root or os.getcwd(), "config", "**", f"{cfg_id}.yml"), recursive=True)
+            if len(files) != 1:
+                raise ConfigError(f"expected exactly one config/**/{cfg_id}.yml under {config_root or os.getcwd()}, found {len(files)}")
+            path = files[0]
+        with open(path) as f:
+            self.yaml_data = y = yaml.safe_load(f)
+        self.id, self.path, self.action, self.wild, self.all_actions = cfg_id, path, action, bool(wild), list(ALL_ACTIONS)
+        # ---- directories (:33-41)
+        self.base_dir = base_dir
+        self.data_dir = y.get("dataset_path", "datasets")
+        self.cfg_dir = os.path.join(base_dir, "all", "statear", cfg_id)
+        self.model_dir, self.policy_model_dir = os.path.join(self.cfg_dir, "models"), os.path.join(self.cfg_dir, "models_policy")
+        self.result_dir, self.log_dir = os.path.join(self.cfg_dir, "results"), os.path.join(self.cfg_dir, "log")
+        if create_dirs:
+            for d in (self.model_dir, self.policy_model_dir, self.result_dir, self.log_dir):
+                os.makedirs(d, exist_ok=True)
+        # ---- data (:47-54); the meta file with the take lists is read when it is there (:58-71)
+        self.data_file = y["data_wild_file"] if wild else y["data_file"]
+        self.meta_id = y["meta_wild_id"] if wild else y["meta_id"]
+        self.of_file = y.get("of_file_wild", "of_feat_wild_all") if wild else y.get("of_file", "of_feat_smpl_all")
+        self.meta, self.takes, self.take_actions = None, {"train": [], "test": []}, {}
+        meta_path = os.path.join(self.data_dir, "meta", self.meta_id + ".yml")
+        if os.path.exists(meta_path):
+            with open(meta_path) as f:
+                self.meta = yaml.safe_load(f)
+            self.take_actions = self.meta.get("action_type", {})
+            for mode in ("train", "test"):
+                self.takes[mode] = [t for t in self.meta.get(mode, []) if action == "all" or self.take_actions.get(t) == action]
+        # ---- scalars (:74-128, with the reference's defaults)
+        g = y.get
+        try:            # keys the reference indexes without a default (:82-93)
+            self.seed, self.fr_num, self.lr, self.num_epoch, self.save_model_interval = y["seed"], y["fr_num"], y["lr"], y["num_epoch"], y["save_model_interval"]
+        except KeyError as e:
+            raise ConfigError(f"{path}: required key {e} is missing") from None
+        self.smooth, self.weightdecay, self.num_epoch_fix = g("smooth", False), g("weightdecay", 0.0), g("num_epoch_fix", 100)
+        self.batch_size, self.noise_std, self.add_noise = g("batch_size", 128), g("noise_std", 0.0), g("add_noise", False)
+        self.model_specs, self.policy_specs = dict(g("model_specs", {})), dict(g("policy_specs", {}))
+        self.joint_controller = self.policy_specs.get("joint_controller", False)       # :149-150
+        self.reward_weights = dict(self.policy_specs.get("reward_weights", {}))
+        self._check_supported()
+
+    def _check_supported(self):
+        y = self.yaml_data
+        bad = [f"{k}: {y.get(k, ref)!r} (the HIP observation / step kernels implement {v!r})" for k, (v, ref) in _FIXED.items() if y.get(k, ref) != v]
+        bad += [f"model_specs.{k}: {self.model_specs[k]!r} (TrajARNet here is {v!r})" for k, v in _FIXED_MODEL.items() if k in self.model_specs and self.model_specs[k] != v]
+        bad += [f"policy_specs.{k}: {self.policy_specs[k]!r} (implemented: {v!r})" for k, v in _FIXED_POLICY.items() if k in self.policy_specs and self.policy_specs[k] != v]
+        if bad:
+            raise ConfigError(f"{self.path}: not supported by the batched engine -- " + "; ".join(bad))
+
+    # ------------------------------------------------------------------ what the engine is built from
+    def feature_path(self, data_file: str | None = None) -> str:
+        """<dataset_path>/features/<data_file>.p (DatasetAMASSBatch / StateARDataset, statear_smpl_dataset.py:38-39)"""
+        return os.path.join(self.data_dir, "features", (data_file or self.data_file) + ".p")
+
+    def agent_kwargs(self) -> dict:
+        """AgentAR(...) keyword arguments for this file (agent_ar.py:60-99, 184-225: the optimisers, schedules, PPO and sampling constants)."""
+        ps = self.policy_specs
+        missing = [k for k in ("num_optim_epoch", "gamma", "tau", "clip_epsilon", "policy_lr", "value_lr", "log_std") if k not in ps]     # indexed without a default (:88-91, 190, 204)
+        if missing:
+            raise ConfigError(f"{self.path}: policy_specs lacks {missing}")
+        return dict(seed=self.seed, wild=self.wild, policy_lr=ps.get("policy_lr", 1e-5), value_lr=ps.get("value_lr", 3e-4), supervised_lr=self.lr,
+                    num_optim_epoch=ps.get("num_optim_epoch", 10), num_step_update=ps.get("num_step_update", 10), gamma=ps.get("gamma", 0.95), tau=ps.get("tau", 0.95),
+                    clip_epsilon=ps.get("clip_epsilon", 0.2), rl_update=ps.get("rl_update", False), step_update=ps.get("step_update", False),
+                    sampling_temp=ps.get("sampling_temp", 0.5), sampling_freq=ps.get("sampling_freq", 0.9), num_epoch_fix=self.num_epoch_fix, num_epoch=self.num_epoch,
+                    joint_controller=bool(self.joint_controller), grad_joint=ps.get("grad_joint", False), grad_alternate=ps.get("grad_alternate", False),
+                    log_std=ps.get("log_std", -3.2), policy_weightdecay=ps.get("policy_weightdecay", 0.0), value_weightdecay=ps.get("value_weightdecay", 0.0),
+                    smooth=bool(self.smooth))
+
+    def horizon(self, n_envs: int, world_size: int = 1, floor: int = 1) -> int:
+        """Steps per env and iteration so that the job collects at least `min_batch_size` samples (agent_ar.py:277: `self.sample(min_batch_size)`;
+        the forked workers stop at min_batch_size / num_threads each, :516, 600)."""
+        need = int(self.policy_specs.get("min_batch_size", 10000))
+        return max(floor, -(-need // (n_envs * world_size)))
+
+    def apply_reward_weights(self, env):
+        """policy_specs.reward_weights -> the reward kernel's constants (dynamic_supervision_v1's `ws.get(key, default)`, reward_function.py:935-940)."""
+        defaults = {"w_hp": 1.0, "w_hq": 1.0, "w_p": 1.0, "w_jp": 1.0, "w_act_p": 1.0, "w_act_v": 1.0,
+                    "k_hp": 1.0, "k_hq": 1.0, "k_p": 1.0, "k_jp": 0.1, "k_act_p": 0.1, "k_act_v": 0.1}
+        for k, d in defaults.items():
+            setattr(env.reward_cfg, k, float(self.reward_weights.get(k, d)))
+        if int(self.reward_weights.get("v_ord", 2)) != 2:
+            raise ConfigError("reward_weights.v_ord must be 2 (the angular-velocity term of the reward kernel is the L2 norm)")
+        return env.reward_cfg
+
+    def checkpoint_path(self, i_iter: int) -> str:
+        """'%s/iter_%04d.p' % (policy_model_dir, epoch + 1)   (agent_ar.py:363)"""
+        return os.path.join(self.policy_model_dir, "iter_%04d.p" % i_iter)

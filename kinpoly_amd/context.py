@@ -142,6 +142,7 @@ class TrajARNet(KinPolicy):
         cell = self.context_rnn.rnn_f
         hx = torch.zeros((N, self.rnn_hdim), device=feat.device, dtype=feat.dtype)
         acc = torch.zeros_like(hx)
+        w = self._frame_weights(data, T, feat)                     # None unless the batch is ragged
         fast = feat.is_cuda and feat.dtype == torch.float32 and not torch.is_grad_enabled()
         ft = feat.transpose(0, 1).contiguous()                     # time-major: every step's input rows are contiguous
         for t in range(T):
@@ -151,14 +152,25 @@ class TrajARNet(KinPolicy):
                 hx = kpsim.gru_cell_step(gi, gh, cell.bias_ih, cell.bias_hh, hx)
             else:
                 hx = cell(ft[t], hx)
-            acc = acc + hx
-        return acc / T
+            acc = acc + (hx if w is None else hx * w[:, t, None])
+        return acc / T if w is None else acc
+
+    @staticmethod
+    def _frame_weights(data, T, like):
+        """Ragged batches (whole takes of different length padded to the longest, `data['ragged']` set by StateARDataset.batch): the reference
+        runs init_context on one unpadded sequence at a time, so a row's context mean is over its own `len` frames -- weights 1 / len on those
+        frames, 0 on the padding (the GRU runs forwards: the padding cannot reach the frames before it).  None for rectangular batches."""
+        if not data.get("ragged", False):
+            return None
+        ln = torch.as_tensor(data["len"], device=like.device).to(like.dtype)
+        return (torch.arange(T, device=like.device)[None, :] < ln[:, None]).to(like.dtype) / ln[:, None]
 
     def init_states(self, data, keep_feat: bool = True):
         """init_states (:180-201) + init_pred_qpos (:169-178): -> (init_qpos [N,76], init_qvel [N,75], context_feat_rnn or None)."""
         if keep_feat:
             ctx = self.get_context_feat(data)
-            mean = ctx.mean(1)
+            w = self._frame_weights(data, ctx.shape[1], ctx)
+            mean = ctx.mean(1) if w is None else (ctx * w[:, :, None]).sum(1)
         else:
             ctx, mean = None, self.get_context_mean(data)
         init = self.context_fc(self.context_mlp(mean))

@@ -199,6 +199,7 @@ class StateARDataset:
         idx_t = torch.as_tensor(idx, device=self.device)
         out = {k: v[idx_t] for k, v in flat.items()}
         out["len"] = torch.as_tensor(lens.astype(np.int32), device=self.device)
+        out["ragged"] = bool(lens.min() < T)           # host-side flag: rows are padded (init_context then averages every row over its own frames)
         out["take_ind"], out["fr_start"] = torch.as_tensor(inds), torch.as_tensor(starts)
         return out
 

@@ -493,7 +493,7 @@ class HumanoidAREnv:
 
     def load_context(self, data_dict):
         """data_dict: tensors [1, T, .] as produced by PolicyAR.init_context (policy_ar.py:124-182)."""
-        self.ar_context = {k: (v[0].detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)[0]) for k, v in data_dict.items()}
+        self.ar_context = {k: (v[0].detach().cpu().numpy() if torch.is_tensor(v) else (np.asarray(v)[0] if np.ndim(v) > 0 else v)) for k, v in data_dict.items()}
         self.ar_context["len"] = self.ar_context["qpos"].shape[0] - 1
         ctx = {k: torch.as_tensor(np.asarray(self.ar_context[k]), dtype=torch.float32)[None] for k in
                ("qpos", "head_pose", "head_vels", "obj_head_relative_poses", "action_one_hot", "obj_pose", "ar_qpos", "ar_qvel") if k in self.ar_context}

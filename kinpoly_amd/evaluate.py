@@ -53,6 +53,28 @@ def run_sequences(env, policy_net, keys, fail_safe=False, max_steps=100000):
     return out
 
 
+@torch.no_grad()
+def eval_dataset(env, policy_net, ctx_builder, dataset, fail_safe=False, inds=None):
+    """`eval_seq` for every take of a data set (agent_ar.py:463-503; eval_ar_policy.py's run_seq loop :178-262), env.n takes at a time: each
+    env plays one WHOLE take (`get_seq_by_ind(ind, full_sample=True)`), takes of different length share a batch padded to its longest
+    (`ctx['len']` ends every env on its own last frame; init_context averages every row's context over its own frames).  ctx_builder:
+    PolicyARContext (its kinematic twin may hold any number of rows: other batch sizes go through it in chunks); the kinematic roll-out is
+    computed (need_rollout=True: the fail-safe and ar_mode read it).  Returns {take name: seq_result} in the data set's order."""
+    inds = list(range(dataset.get_len())) if inds is None else [int(i) for i in inds]
+    out = {}
+    for i in range(0, len(inds), env.n):
+        chunk = inds[i:i + env.n]
+        rows = chunk + [chunk[-1]] * (env.n - len(chunk))                  # a short last chunk is filled with copies of its last take
+        data = dataset.batch(np.asarray(rows, np.int64), None, None)
+        data = {k: (v.to(env.device) if torch.is_tensor(v) else v) for k, v in data.items()}
+        ctx = ctx_builder.init_context(data, need_rollout=True)
+        env.load_context(ctx)
+        keys = [dataset.takes[j] for j in chunk] + [f"__fill_{j}" for j in range(env.n - len(chunk))]
+        res = run_sequences(env, policy_net, keys, fail_safe=fail_safe)
+        out.update({k: res[k] for k in keys[:len(chunk)]})
+    return out
+
+
 def write_coverage(results: dict, result_dir: str, iter_num: int, data_file: str):
     """Write `<iter>_<data_file>_coverage.pkl` / `_coverage_full.pkl` (eval_ar_policy.py:225-262); returns the coverage count."""
     import joblib

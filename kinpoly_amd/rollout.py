@@ -62,6 +62,78 @@ def _agree_status(status: int, device, group=None) -> int:
     return int(status)
 
 
+class LoggerRL:
+    """The sampling statistics of uhc/khrylib/rl/core/logger_rl.py (the object AgentAR.sample returns next to the batch and log_train prints,
+    agent_ar.py:243-262), for a lock-step sampler: built once per sample() call from the device buffers (`episode_log`), merged over ranks
+    with `merge` (LoggerRL.merge :51-70).  An episode that straddles two sample() calls is counted in the call it ends in, with its whole return.
+
+    Deviation kept out on purpose: the reference's merge takes `min_episode_reward = max(...)` over the workers (:60, a typo); `merge` here takes the min."""
+
+    FIELDS = ("num_steps", "num_episodes", "total_reward", "min_episode_reward", "max_episode_reward", "total_c_reward", "min_c_reward", "max_c_reward")
+
+    def __init__(self, **kw):
+        self.num_steps = self.num_episodes = 0
+        self.total_reward = self.total_c_reward = 0.0
+        self.min_episode_reward = self.min_c_reward = float("inf")
+        self.max_episode_reward = self.max_c_reward = float("-inf")
+        self.total_c_info = np.zeros(6)
+        self.sample_time = 0.0
+        for k, v in kw.items():
+            setattr(self, k, v)
+        self.end_sampling()
+
+    def end_sampling(self):
+        ne, ns = max(self.num_episodes, 1), max(self.num_steps, 1)        # a call in which no episode ended reports per-episode figures over 1
+        self.avg_episode_len = self.num_steps / ne
+        self.avg_episode_reward = self.total_reward / ne
+        self.avg_c_reward = self.total_c_reward / ns
+        self.avg_c_info = self.total_c_info / ns
+        self.avg_episode_c_reward = self.total_c_reward / ne
+        self.avg_episode_c_info = self.total_c_info / ne
+
+    @classmethod
+    def merge(cls, loggers):
+        loggers = list(loggers)
+        out = cls(num_steps=sum(x.num_steps for x in loggers), num_episodes=sum(x.num_episodes for x in loggers),
+                  total_reward=sum(x.total_reward for x in loggers), total_c_reward=sum(x.total_c_reward for x in loggers),
+                  total_c_info=sum(x.total_c_info for x in loggers),
+                  min_episode_reward=min(x.min_episode_reward for x in loggers), max_episode_reward=max(x.max_episode_reward for x in loggers),
+                  min_c_reward=min(x.min_c_reward for x in loggers), max_c_reward=max(x.max_c_reward for x in loggers))
+        out.sample_time = max(x.sample_time for x in loggers)
+        return out
+
+    def as_dict(self):
+        return {**{k: getattr(self, k) for k in self.FIELDS}, "total_c_info": self.total_c_info.tolist(), "avg_episode_len": self.avg_episode_len,
+                "avg_episode_reward": self.avg_episode_reward, "avg_c_reward": self.avg_c_reward, "avg_c_info": self.avg_c_info.tolist()}
+
+
+def episode_log(rewards: torch.Tensor, done: torch.Tensor, c_info: torch.Tensor | None, carry: torch.Tensor):
+    """LoggerRL's counters from one sample() call's buffers, without a per-step launch: rewards [N, T] (>= 0: sums of exponentials), done bool
+    [N, T], c_info [N, T, 6] or None, carry [N] = return collected so far by the episode every env was in when the call began.  Returns
+    (stats float64 [8 + 6] in LoggerRL.FIELDS order followed by total_c_info, new carry [N]).  Pure torch (CPU-testable).
+
+    The return of the episode that ends at (e, t) is cs[e, t] - cs[e, t'] with t' its predecessor's last row (cs = running sum over the call,
+    + carry when there is no predecessor in this call); rewards are non-negative, so cs at the latest done row is a running max."""
+    N, T = rewards.shape
+    r = rewards.double()
+    cs = torch.cumsum(r, 1)
+    at_done = torch.where(done, cs, torch.zeros_like(cs))
+    last = torch.cummax(at_done, 1).values                               # cs at the latest done row <= t
+    prev = torch.cat([torch.zeros((N, 1), dtype=cs.dtype, device=cs.device), last[:, :-1]], 1)     # ... < t
+    done_so_far = torch.cummax(done.to(torch.uint8), 1).values.bool()
+    seen = torch.cat([torch.zeros((N, 1), dtype=torch.bool, device=cs.device), done_so_far[:, :-1]], 1)    # a done row before t
+    ep_ret = cs - prev + torch.where(seen, torch.zeros_like(cs), carry.double()[:, None].expand(N, T))
+    inf = torch.full_like(cs, float("inf"))
+    n_ep = done.sum()
+    stats = torch.stack([torch.tensor(float(N * T), dtype=cs.dtype, device=cs.device), n_ep.double(),
+                         torch.where(done, ep_ret, torch.zeros_like(cs)).sum(), torch.where(done, ep_ret, inf).min(), torch.where(done, ep_ret, -inf).max(),
+                         r.sum(), r.min(), r.max()])
+    ci = c_info.double().sum((0, 1)) if c_info is not None else torch.zeros(6, dtype=cs.dtype, device=cs.device)
+    any_done = done_so_far[:, -1]
+    new_carry = (cs[:, -1] - last[:, -1] + torch.where(any_done, torch.zeros_like(carry.double()), carry.double())).to(carry.dtype)
+    return torch.cat([stats, ci]), new_carry
+
+
 class EpisodeSource:
     """`sample_seq` + `init_context` for n episodes at once (agent_ar.py:519-533).
 
@@ -160,9 +232,8 @@ class EpisodeSource:
 
     def save_freq_dict(self, path):
         """joblib.dump(self.freq_dict, 'freq_dict.pt') of the reference (agent_ar.py:297): a pickle of {take: [[percent, fr_start], ...]}."""
-        import pickle
-        with open(path, "wb") as f:
-            pickle.dump(self.freq_dict, f)
+        import joblib
+        joblib.dump(self.freq_dict, path)
 
 
 def ring_refill_plan(head: torch.Tensor, ahead: torch.Tensor, n_slots: int, total: int):
@@ -203,6 +274,8 @@ class VectorSampler:
         self.pool_exhausted = 0            # 0 by construction; kept as the counter callers report
         self.top_ups = 0                   # host reads of the ring state so far (one per pool_depth steps)
         self.group = None                  # process group of the job-wide freq_dict exchange (None = the default group)
+        self.ep_return = None              # [N] return collected so far by the episode every env is in (LoggerRL's episode_reward)
+        self.log = None                    # LoggerRL of the last sample() call (this rank's envs)
 
     # ------------------------------------------------------------------ episode pool
     @property
@@ -254,6 +327,7 @@ class VectorSampler:
         self.obs = self.env.reset().clone()
         self.hx = self.policy.init_hidden(self.env.n, self.env.device)
         self.fresh = torch.ones(self.env.n, dtype=torch.bool, device=self.env.device)
+        self.ep_return = torch.zeros(self.env.n, dtype=torch.float64, device=self.env.device)
 
     @torch.no_grad()
     def sample(self, T: int) -> RolloutBatch:
@@ -267,7 +341,7 @@ class VectorSampler:
         G = f(76) if self.record_qpos else None
         full = self.record_full
         NS, VM, RQ, CA, CS = (f(105), f(3), f(76), f(75), f(784)) if full else (None,) * 5
-        D = torch.empty((N, T), dtype=torch.bool, device=dev); PC = f(); MT = f(2)
+        D = torch.empty((N, T), dtype=torch.bool, device=dev); PC = f(); MT = f(2); CI = f(6)
         hx0 = self.hx.clone()
         fr_num = float(env.ctx["qpos"].shape[1])
         # exploration noise of both policies, NOISE_CHUNK steps per launch, only the columns a sampling policy reads: [chunk, N, 80 kinematic | 75 UHC]
@@ -291,7 +365,7 @@ class VectorSampler:
             A[:, t] = action
             R[:, t] = info["custom_reward"]
             F[:, t] = info["fail"]
-            D[:, t] = done; PC[:, t] = info["percent"]; MT[:, t] = meta
+            D[:, t] = done; PC[:, t] = info["percent"]; MT[:, t] = meta; CI[:, t] = info["custom_info"]
             if full:
                 NS[:, t] = obs; RQ[:, t] = env.sim.get("qpos"); CA[:, t] = info["cc_action"]; CS[:, t] = info["cc_state"]
                 VM[:, t, :2] = meta; VM[:, t, 2] = fr_num
@@ -310,6 +384,10 @@ class VectorSampler:
         # one host transfer per call: finished episodes -> freq_dict, launch status.  Every rank takes part in the job-wide exchanges BEFORE
         # any rank raises, so a stalled queue on one rank ends the job on all of them instead of leaving the others in a collective
         status = _agree_status(int(env.sim.status_tensor()[2]), dev, self.group)
+        stats, self.ep_return = episode_log(R, D, CI, self.ep_return)
+        st = stats.tolist()
+        self.log = LoggerRL(num_steps=int(st[0]), num_episodes=int(st[1]), total_reward=st[2], min_episode_reward=st[3], max_episode_reward=st[4],
+                            total_c_reward=st[5], min_c_reward=st[6], max_c_reward=st[7], total_c_info=np.asarray(st[8:14]))
         dm = D.cpu().numpy()
         eps = {"take_ind": MT[..., 0].cpu().numpy()[dm].astype(np.int64), "fr_start": MT[..., 1].cpu().numpy()[dm].astype(np.int64),
                "percent": PC.cpu().numpy()[dm].astype(np.float64)}

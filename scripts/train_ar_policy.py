@@ -2,7 +2,13 @@
 """Counterpart of the reference's scripts/train_ar_policy.py on the batched MI355X engine.
 
     python scripts/train_ar_policy.py --num_envs 4096 --iters 3
+    python scripts/train_ar_policy.py --cfg kin_poly --config_root /path/to/KinPoly [--iter 750] [--data train]      # the reference's command line
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 scripts/train_ar_policy.py
+
+With --cfg the run is configured by the reference's `config/statear/<cfg>.yml` (kinpoly_amd/config.py): optimisers, schedules, PPO and sampling
+constants, reward weights, the horizon from `min_batch_size`, `results/all/statear/<cfg>/` for checkpoints (`models_policy/iter_%04d.p`, every
+`save_model_interval` iterations, agent_ar.py:341-364), `freq_dict.pt`, `eval_dict_*.pt` and `log/log.txt`; `--iter N` resumes from that checkpoint
+(train_ar_policy.py:92-104); every `save_model_interval` iterations the test sets are evaluated (`eval_policy("test")`, agent_ar.py:291-293).
 
 The reference's MoCap dataset and trained UHC weights are not part of its repository (downlaod_data.sh), so this
 driver builds synthetic takes in the reference's feature-file schema (all four action classes with their objects, SURVEY.md
@@ -33,6 +39,12 @@ def main():
     ap.add_argument("--cache_init_context", action="store_true", help="look init_qpos / init_qvel of a window up once it has been computed under the same context-network parameters")
     ap.add_argument("--save", type=str, default="")
     ap.add_argument("--data", type=str, default="", help="feature file in the reference's schema (<data_dir>/features/<data_file>.p)")
+    ap.add_argument("--cfg", type=str, default=None, help="config id (config/**/<cfg>.yml under --config_root) or a .yml path, as the reference's --cfg")
+    ap.add_argument("--config_root", type=str, default=None, help="directory that holds config/ and the dataset_path of the yml (default: cwd)")
+    ap.add_argument("--iter", type=int, default=0, help="resume from models_policy/iter_%%04d.p (the reference's --iter)")
+    ap.add_argument("--wild", action="store_true")
+    ap.add_argument("--no_log", action="store_true")
+    ap.add_argument("--test_data", type=str, nargs="*", default=[], help="feature files of the test sets evaluated every save_model_interval iterations")
     args = ap.parse_args()
     world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
@@ -46,8 +58,17 @@ def main():
     from kinpoly_amd.model_compiler import read_kpm
     # the agent's kinematic twin sim doubles as the FK engine of the feature construction
     fk_sim = kpsim.KpSim(kpsim.KpModel(kpsim.STEP_KPM), args.num_envs, local)
+    cfg = None
+    if args.cfg:
+        from kinpoly_amd.config import Config
+        if args.config_root:
+            os.chdir(args.config_root)                 # the yml's dataset_path and the results/ tree are relative to it, as in the reference
+        cfg = Config(args.cfg, wild=args.wild, create_dirs=(rank == 0))
+        args.clip_len = int(cfg.fr_num)
+        if not args.data and os.path.exists(cfg.feature_path()):
+            args.data = cfg.feature_path()
     if args.data:
-        ds = D.StateARDataset(args.data, fr_num=args.clip_len, seed=4 + rank, device=fk_sim.device)
+        ds = D.StateARDataset(args.data, takes=(cfg.takes["train"] or None) if cfg else None, fr_num=args.clip_len, wild=args.wild, seed=4 + rank, device=fk_sim.device)
     else:       # the reference's MoCap features are not in its repository: same schema, synthetic takes.  ONE
         # data set for the whole job (take seed independent of the rank): the job-wide freq_dict is keyed by take name, so a name must
         # mean the same motion on every rank; only the draw stream (dataset seed) differs per rank
@@ -59,12 +80,34 @@ def main():
 
     # every episode draws its clip through data_loader.sample_seq(freq_dict, sampling_temp, sampling_freq) (agent_ar.py:519-523): the
     # agent keeps the freq_dict and feeds each finished episode's [percent, fr_start] back (random window starts, adaptive takes)
-    agent = AgentAR(args.num_envs, dataset=ds, device=local, horizon=args.horizon, num_optim_epoch=args.num_optim_epoch,
-                    num_step_update=args.num_step_update, sampling_temp=0.3, sampling_freq=0.5, pool_depth=args.pool_depth, cache_init_context=args.cache_init_context)
-    for it in range(args.iters):
+    if cfg is None:
+        agent = AgentAR(args.num_envs, dataset=ds, device=local, horizon=args.horizon, num_optim_epoch=args.num_optim_epoch,
+                        num_step_update=args.num_step_update, sampling_temp=0.3, sampling_freq=0.5, pool_depth=args.pool_depth, cache_init_context=args.cache_init_context)
+        first, last, interval = 0, args.iters, 0
+    else:
+        agent = AgentAR(args.num_envs, dataset=ds, device=local, horizon=cfg.horizon(args.num_envs, world), pool_depth=args.pool_depth,
+                        cache_init_context=args.cache_init_context, result_dir=cfg.result_dir, **cfg.agent_kwargs())
+        cfg.apply_reward_weights(agent.env)
+        agent.test_datasets = [D.StateARDataset(p, data_mode="test", fr_num=args.clip_len, wild=args.wild, seed=4, device=fk_sim.device) for p in args.test_data]
+        if args.iter > 0:                              # AgentAR(checkpoint_epoch=args.iter) -> load_checkpoint (agent_ar.py:72-73, 318-339)
+            agent.load_checkpoint(cfg.checkpoint_path(args.iter))
+            agent.epoch = args.iter
+            for _ in range(args.iter):                 # the LambdaLR schedules are functions of the epoch
+                agent.trainer.per_epoch_update(); agent.sched_sup.step()
+        first, last, interval = args.iter, (args.iter + args.iters if args.iters else int(cfg.num_epoch)), int(cfg.policy_specs.get("save_model_interval", cfg.save_model_interval))
+    log_file = open(os.path.join(cfg.log_dir, "log.txt"), "a") if (cfg is not None and rank == 0 and not args.no_log) else None
+    for it in range(first, last):
         info = agent.optimize_policy(it)
+        if interval and (it + 1) % interval == 0:      # optimize_policy's periodic test-set evaluation, then train_ar_policy.py:95-97
+            info["log_eval"] = agent.eval_policy("test")
+            if rank == 0:
+                agent.save_checkpoint(cfg.checkpoint_path(it + 1))
         if rank == 0:
-            print(json.dumps({"iter": it, **{k: (round(v, 5) if isinstance(v, float) else v) for k, v in info.items()}}), flush=True)
+            log = info.pop("log")
+            line = agent.log_train({**info, "log": log}, cfg_id=cfg.id if cfg else "synthetic", max_iter_num=int(cfg.policy_specs.get("max_iter_num", last)) if cfg else last)
+            if log_file is not None:
+                log_file.write(line + "\n"); log_file.flush()
+            print(json.dumps({"iter": it, **{k: (round(v, 5) if isinstance(v, float) else v) for k, v in info.items()}, "log": log.as_dict()}), flush=True)
     if args.save and rank == 0:
         agent.save_checkpoint(args.save)
     if world > 1:
