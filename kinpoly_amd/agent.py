@@ -61,8 +61,8 @@ class AgentAR:
         self.trainer = PPOTrainer(self.policy_net, self.value_net, gamma, tau, clip_epsilon, policy_lr, value_lr, num_optim_epoch,
                                   num_epoch_fix=num_epoch_fix, num_epoch=num_epoch, cc_policy=self.env.cc_policy if joint_controller else None, train_uhc=train_uhc,
                                   policy_weightdecay=policy_weightdecay, value_weightdecay=value_weightdecay)
-        self.opt_sup = torch.optim.Adam([p for p in self.policy_net.parameters() if p.requires_grad], lr=supervised_lr)
-        self.sched_sup = lambda_lr(self.opt_sup, num_epoch_fix, num_epoch)          # PolicyAR.setup_optimizers / step_lr (policy_ar.py:45-62, 88-89)
+        self._sup_cfg = (supervised_lr, num_epoch_fix, num_epoch)
+        self._setup_supervised_optimizer()
         kpm = read_kpm(kpsim.DEFAULT_KPM)
         self.fk = TorchFK(kpm["body_pos"], kpm["body_parent"], self.device, sim=self.kin_sim)   # HIP forward / backward kernels for the loss FK
         self.sampler = VectorSampler(self.env, self.policy_net, record_qpos=True, source=self.source, pool_depth=pool_depth,
@@ -81,6 +81,26 @@ class AgentAR:
                 except Exception:                                    # "error parsing freq_dict, using empty one" (:232-234)
                     pass
         self.sampler.start()
+
+    def _setup_supervised_optimizer(self):
+        """PolicyAR.setup_optimizers / step_lr (policy_ar.py:45-62, 72-89): Adam(lr) over the kinematic policy + its LambdaLR"""
+        lr, fix, total = self._sup_cfg
+        self.opt_sup = torch.optim.Adam([p for p in self.policy_net.parameters() if p.requires_grad], lr=lr)
+        self.sched_sup = lambda_lr(self.opt_sup, fix, total)
+
+    def train_init(self, warm_update_init=500, warm_update_full=50, num_sample=2000, batch_size=256, scheduled_sampling=0.3, noise_std=0.0):
+        """AgentAR.train_init (agent_ar.py:366-385), run once before the first iteration of a fresh run: `update_init_supervised` x
+        warm_update_init epochs (the context network learns the clip's first pose), `train_full_supervised(scheduled_sampling=0.3)` x
+        warm_update_full epochs (whole-clip kinematic roll-outs against the GT clip), then fresh supervised optimiser / schedule
+        (`setup_optimizers`).  cfg.num_sample / cfg.batch_size clips per epoch; kinpoly_amd/pretrain.py.  Gradients are all-reduced over ranks."""
+        from . import pretrain as P
+        ds = self.source.dataset
+        assert ds is not None and "wbpos" in ds.data, "the warm start needs a training data set (GT joint positions)"
+        li = P.update_init_supervised(self.policy_net, self.opt_sup, self.fk, ds, warm_update_init, num_sample, batch_size, grad_allreduce=_allreduce_grads)
+        lf = P.train_full_supervised(self.policy_net, self.opt_sup, self.fk, ds, warm_update_full, scheduled_sampling, num_sample, batch_size,
+                                     noise_std=noise_std, scheduler=self.sched_sup, grad_allreduce=_allreduce_grads)
+        self._setup_supervised_optimizer()
+        return {"init_loss": li, "full_loss": lf}
 
     @property
     def freq_dict(self):

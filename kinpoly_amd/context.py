@@ -80,12 +80,21 @@ def get_qvel_fd_batch(cur_qpos, next_qpos, dt):
     v = (next_qpos[:, :3] - cur_qpos[:, :3]) / dt
     qrel = quat_mul(next_qpos[:, 3:7], quat_inv(cur_qpos[:, 3:7]))
     w = qrel[:, 0].clamp(-1.0, 1.0)
-    # sin(acos(w)) and 2 acos(w) of rotation_from_quaternion_batch (:109-130)
-    s = quat_sin_half(qrel)
-    small = s < 1e-5
+    # sin(acos(w)) and 2 acos(w) of rotation_from_quaternion_batch (:109-130).  Its safe_acos (:32-36) clamps w to +-(1 - 1e-7), so a rotation too
+    # small for 1 - w to be seen comes out as xyz / sin(acos(1 - 1e-7)) * 2 acos(1 - 1e-7) = 2 xyz, the right small-angle limit (and the `< 1e-5`
+    # branch can never be taken); fp64 keeps that form to the letter, fp32 gets the same limit from |xyz| and atan2
+    if qrel.dtype == torch.float64:
+        half = torch.acos(qrel[:, 0].clamp(-1.0 + 1e-7, 1.0 - 1e-7))
+        s = torch.sin(half)
+        small = s.abs() < 1e-5
+        two_half = 2 * half
+    else:
+        s = quat_sin_half(qrel)
+        small = s < 1e-5
+        two_half = 2 * quat_acos_w(qrel)
     s = s.clamp_min(1e-30)
     axis = torch.where(small[:, None], torch.tensor([1.0, 0.0, 0.0], device=w.device, dtype=w.dtype).expand_as(qrel[:, 1:]), qrel[:, 1:] / s[:, None])
-    angle = torch.where(small, torch.zeros_like(w), 2 * quat_acos_w(qrel))
+    angle = torch.where(small, torch.zeros_like(w), two_half)
     angle = torch.where(angle > math.pi, angle - 2 * math.pi, angle)
     angle = torch.where(angle < -math.pi, angle + 2 * math.pi, angle)
     rv = quat_rotate_t(cur_qpos[:, 3:7], axis * angle[:, None] / dt)

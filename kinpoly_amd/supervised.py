@@ -87,6 +87,10 @@ class TorchFK:
         return self.wbpos_torch(qpos)
 
     def wbpos_torch(self, qpos):
+        return self.chain_torch(qpos)[0]
+
+    def chain_torch(self, qpos):
+        """(wbpos [B,24,3], wbquat [B,24,4]) by differentiable torch ops (the observation of the supervised roll-out reads the head's quaternion too)"""
         B = qpos.shape[0]
         root_q = qpos[:, 3:7] / qpos[:, 3:7].norm(dim=1, keepdim=True)
         ang = qpos[:, 7:].view(B, 23, 3) * 0.5
@@ -103,7 +107,7 @@ class TorchFK:
             nq = quat_mul(pq, local[:, ids - 1])
             for k, i in enumerate(ids.tolist()):
                 pos[i], quat[i] = npos[:, k], nq[:, k]
-        return torch.stack(pos, 1)
+        return torch.stack(pos, 1), torch.stack(quat, 1)
 
 
 def compute_loss_lite(fk: TorchFK, pred_qpos, gt_qpos, w_rp=50.0, w_rr=50.0, w_p=1.0, w_ee=10.0, gt_wbpos=None):

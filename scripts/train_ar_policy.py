@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--cfg", type=str, default=None, help="config id (config/**/<cfg>.yml under --config_root) or a .yml path, as the reference's --cfg")
     ap.add_argument("--config_root", type=str, default=None, help="directory that holds config/ and the dataset_path of the yml (default: cwd)")
     ap.add_argument("--iter", type=int, default=0, help="resume from models_policy/iter_%%04d.p (the reference's --iter)")
+    ap.add_argument("--warm_start", action="store_true", help="AgentAR.train_init before the first iteration of a fresh run: supervised warm start of the kinematic policy "
+                    "(policy_specs.warm_update_init / warm_update_full epochs, default 500 / 50; the reference always runs it at --iter 0)")
     ap.add_argument("--wild", action="store_true")
     ap.add_argument("--no_log", action="store_true")
     ap.add_argument("--test_data", type=str, nargs="*", default=[], help="feature files of the test sets evaluated every save_model_interval iterations")
@@ -96,6 +98,15 @@ def main():
                 agent.trainer.per_epoch_update(); agent.sched_sup.step()
         first, last, interval = args.iter, (args.iter + args.iters if args.iters else int(cfg.num_epoch)), int(cfg.policy_specs.get("save_model_interval", cfg.save_model_interval))
     log_file = open(os.path.join(cfg.log_dir, "log.txt"), "a") if (cfg is not None and rank == 0 and not args.no_log) else None
+    if args.warm_start and first == 0:             # train_init (agent_ar.py:366-385), then save_checkpoint(0) -> iter_0001.p
+        ps = cfg.policy_specs if cfg is not None else {}
+        y = cfg.yaml_data if cfg is not None else {}
+        ws = agent.train_init(int(ps.get("warm_update_init", 500)), int(ps.get("warm_update_full", 50)), int(y.get("num_sample", 20000)), int(y.get("batch_size", 128)),
+                              noise_std=float(y.get("noise_std", 0.0)) if y.get("add_noise", False) else 0.0)
+        if rank == 0:
+            print(json.dumps({"warm_start": ws}), flush=True)
+            if cfg is not None:
+                agent.save_checkpoint(cfg.checkpoint_path(1))
     for it in range(first, last):
         info = agent.optimize_policy(it)
         if interval and (it + 1) % interval == 0:      # optimize_policy's periodic test-set evaluation, then train_ar_policy.py:95-97

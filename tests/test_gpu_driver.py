@@ -179,3 +179,38 @@ def test_reference_command_line_of_the_scripts(tmp_path):
     assert "Coverage of" in r.stdout and "out of 2" in r.stdout
     full = joblib.load(str(base / "results" / "0004_mocap_annotations_coverage_full.pkl"))
     assert set(full) == set(names[:2]) and all(len(v["pred"]) >= 1 and v["pred"][0].shape == (76,) for v in full.values())
+
+
+def test_warm_start_trains_the_policy_and_its_rollout_equals_the_hip_rollout():
+    """AgentAR.train_init (agent_ar.py:366-385) on the device in fp32: both supervised phases move the networks and end finite, the supervised optimiser is
+    rebuilt afterwards (setup_optimizers); and the differentiable torch roll-out the warm start trains through (pretrain.forward_supervised) is the same
+    computation as the tape-free HIP roll-out init_context uses (TrajARNet.rollout: kp_kin_advance / obs_ar / FK kernels)."""
+    from kinpoly_amd import dataset as D
+    from kinpoly_amd import pretrain as P
+    from kinpoly_amd.agent import AgentAR
+    n, fr = 8, 12
+    takes, fk_sim = _takes(n, fr)
+    ds = D.StateARDataset(takes, fr_num=fr, seed=3, device=fk_sim.device)
+    agent = AgentAR(n, dataset=ds, device=0, horizon=4)
+    net = agent.policy_net
+    data = next(P.sampling_batches(ds, n, n, agent.device))
+    with torch.no_grad():
+        pred = P.forward_supervised(net, agent.fk, data)
+        iq, iv, _ = net.init_states(data, keep_feat=False)
+        Q, V, A = net.rollout(data, agent.kin_sim, iq.contiguous(), iv.contiguous())
+    np.testing.assert_allclose(pred["qpos"].cpu().numpy(), Q.cpu().numpy(), atol=2e-4)
+    np.testing.assert_allclose(pred["action"].cpu().numpy(), A.cpu().numpy(), atol=5e-4)
+    np.testing.assert_allclose(pred["qvel"].cpu().numpy(), V.cpu().numpy(), atol=2e-2)            # finite differences over 1 / 30 s of fp32 poses
+    before = {k: v.detach().clone() for k, v in net.named_parameters()}
+    old_opt = agent.opt_sup
+    l0, _ = P.compute_loss(P.forward_supervised(net, agent.fk, data), data)
+    out = agent.train_init(warm_update_init=4, warm_update_full=6, num_sample=16, batch_size=8)
+    assert np.isfinite(out["init_loss"]) and np.isfinite(out["full_loss"])
+    moved = {k: float((v.detach() - before[k]).abs().max()) for k, v in net.named_parameters() if v.requires_grad}
+    assert moved["context_fc.weight"] > 0 and moved["action_fc.weight"] > 0 and moved["action_rnn.rnn_f.weight_hh"] > 0
+    assert agent.opt_sup is not old_opt and len(agent.opt_sup.state) == 0
+    with torch.no_grad():
+        l1, _ = P.compute_loss(P.forward_supervised(net, agent.fk, data), data)
+    assert float(l1) < float(l0)
+    info = agent.optimize_policy(0)                      # and the RL iteration runs on the warm-started networks
+    assert info["num_steps"] == n * 4

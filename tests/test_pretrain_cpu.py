@@ -1,0 +1,120 @@
+"""CPU (fp64 torch): the supervised warm start (kinpoly_amd/pretrain.py) against tests/golden/pretrain.npz, which tools/make_golden.py::gen_pretrain
+wrote by running the reference's TrajARNet.forward (train form, with and without scheduled sampling), compute_loss, compute_loss_init and their
+backward passes on seeded weights."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_oracle as O
+
+
+class _Coins:
+    """scripted stand-in for np.random.binomial(1, gt_rate): the draws the fixture was generated with"""
+
+    def __init__(self, seq):
+        self.seq = iter(int(x) for x in seq)
+
+    def binomial(self, n, p):
+        return next(self.seq)
+
+
+def _setup(g, dtype=torch.float64):
+    from kinpoly_amd.context import TrajARNet
+    from kinpoly_amd.model_compiler import DEFAULT_KPM, read_kpm
+    from kinpoly_amd.supervised import TorchFK
+    net = TrajARNet(state_dim=int(g["state_dim"]), context_dim=int(g["context_dim"])).to(dtype)
+    shapes = [tuple(int(x) for x in row if x > 0) for row in g["shapes"]]
+    sd = O.seeded_state_dict(list(zip([str(k) for k in g["keys"]], shapes)), int(g["seed"]))
+    for k in sd:
+        if k.startswith(("action_fc", "context_fc")):
+            sd[k] = sd[k] * 0.05
+    missing = net.load_state_dict({k: torch.tensor(v, dtype=dtype) for k, v in sd.items()}, strict=False)
+    assert not missing.unexpected_keys and set(missing.missing_keys) <= {"action_log_std"}
+    kpm = read_kpm(DEFAULT_KPM)
+    fk = TorchFK(kpm["body_pos"], kpm["body_parent"], "cpu", dtype=dtype)
+    data = {k[3:]: torch.tensor(g[k], dtype=dtype) for k in g.files if k.startswith("in_")}
+    return net, fk, data
+
+
+@pytest.mark.parametrize("tag,rate", [("", 0.0), ("_gt", 0.3)])
+def test_supervised_rollout_loss_and_gradients_match_reference(golden, tag, rate):
+    from kinpoly_amd.pretrain import compute_loss, forward_supervised
+    g = golden("pretrain")
+    net, fk, data = _setup(g)
+    pred = forward_supervised(net, fk, data, gt_rate=rate, rng=_Coins(g["coins"]))
+    for k in ("qpos", "qvel", "action", "obj_2_head", "pred_wbpos"):
+        # qvel is a finite difference over dt = 1 / 30 of poses that agree to 1e-11: 30 x that.  Some GT root quaternions of the fixture are unit to
+        # 3e-7 only (|q| = 0.99999969): where scheduled sampling puts the pose on such a frame, R(q) v of the next step differs by that much
+        # between the reference's un-normalised rotation (quat_mul_vec_batch) and the normalised one here
+        tol = dict(rtol=5e-6, atol=1e-7) if (k == "qvel" or rate > 0) else dict(rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(pred[k].detach().numpy(), g[k + tag].reshape(pred[k].shape), err_msg=k, **tol)
+    loss, idv = compute_loss(pred, data)
+    np.testing.assert_allclose(float(loss.detach()), float(g["loss" + tag]), rtol=1e-9 if rate == 0 else 1e-6)
+    np.testing.assert_allclose([float(x.detach()) for x in idv], g["loss_idv" + tag], rtol=1e-8 if rate == 0 else 1e-5, atol=1e-12)
+    loss.backward()
+    params = dict(net.named_parameters())
+    n = 0
+    for key in g.files:
+        if key.startswith(f"grad{tag}:"):
+            np.testing.assert_allclose(params[key.split(":", 1)[1]].grad.numpy(), g[key], rtol=1e-7 if rate == 0 else 1e-5, atol=1e-10 if rate == 0 else 1e-8, err_msg=key)
+            n += 1
+    assert n == 4
+    if rate > 0:          # scheduled sampling really replaced frames by the GT pose where the coin said so (coins[0]: the initial state, coins[t]: after step t - 1)
+        coins = g["coins"]
+        for t in range(1, data["qpos"].shape[1]):
+            same = np.allclose(pred["qpos"][:, t].detach().numpy(), data["qpos"][:, t].numpy())
+            assert same == bool(coins[t]), t
+
+
+def test_init_loss_and_gradients_match_reference(golden):
+    from kinpoly_amd.pretrain import compute_loss_init
+    g = golden("pretrain")
+    net, fk, data = _setup(g)
+    pred_qpos, _, _ = net.init_states(data, keep_feat=False)
+    loss, idv = compute_loss_init(fk, pred_qpos, data["qpos"][:, 0])
+    np.testing.assert_allclose(float(loss.detach()), float(g["loss_init"]), rtol=1e-10)
+    np.testing.assert_allclose([float(x.detach()) for x in idv], g["loss_init_idv"], rtol=1e-9, atol=1e-12)
+    loss.backward()
+    params = dict(net.named_parameters())
+    for key in ("context_fc.bias", "context_mlp.affine_layers.0.bias"):
+        np.testing.assert_allclose(params[key].grad.numpy(), g["grad_init:" + key], rtol=1e-7, atol=1e-10, err_msg=key)
+    assert params["action_fc.bias"].grad is None            # the action network is not on the path of the init loss
+
+
+def test_warm_start_loops_lower_their_losses():
+    """update_init_supervised / train_full_supervised on a small synthetic feature set (fp64 CPU, tiny budgets): the sampling generator serves
+    fr_num-frame windows inside their takes and both losses go down."""
+    from kinpoly_amd import dataset as D
+    from kinpoly_amd import pretrain as P
+    from kinpoly_amd.context import TrajARNet
+    from kinpoly_amd.model_compiler import DEFAULT_KPM, read_kpm
+    from kinpoly_amd.supervised import TorchFK
+    torch.manual_seed(0)
+    rng = np.random.default_rng(1)
+    kpm = read_kpm(DEFAULT_KPM)
+    fk = TorchFK(kpm["body_pos"], kpm["body_parent"], "cpu", dtype=torch.float64)
+    feats = {}
+    for i, T in enumerate((14, 19)):
+        q = np.zeros((T, 76)); q[:, 2] = 0.9; q[:, 3] = 1.0; q[:, 7:] = 0.1 * np.sin(np.arange(T)[:, None] * 0.3 + rng.uniform(0, 6, 69))
+        wb = fk.wbpos(torch.tensor(q)).reshape(T, 72).numpy()
+        hp = np.concatenate([wb[:, 39:42], np.tile([1.0, 0, 0, 0], (T, 1))], 1)
+        feats[f"sit-{i}"] = dict(qpos=q, qvel=np.zeros((T, 75)), head_pose=hp, head_vels=np.zeros((T, 6)), action_one_hot=np.tile([1.0, 0, 0, 0], (T, 1)),
+                                 obj_head_relative_poses=np.tile([0.5, 0, 0, 1.0, 0, 0, 0], (T, 1)), obj_pose=np.tile([0.5, 0, 0.4, 1.0, 0, 0, 0], (T, 1)),
+                                 wbpos=wb, wbquat=np.zeros((T, 96)), bquat=np.zeros((T, 96)), of_files=["x"] * T)
+    ds = D.StateARDataset(feats, fr_num=8, seed=3)
+    ds.data = {k: [x.double() for x in v] for k, v in ds.data.items()}
+    batches = list(P.sampling_batches(ds, 10, 4, "cpu"))
+    assert [b["qpos"].shape[0] for b in batches] == [4, 4, 2] and all(b["qpos"].shape[1] == 8 for b in batches)
+    for b in batches:
+        for r in range(b["qpos"].shape[0]):
+            i, s0 = int(b["take_ind"][r]), int(b["fr_start"][r])
+            assert 0 <= s0 <= ds.get_seq_len(i) - 8 and torch.equal(b["qpos"][r], ds.data["qpos"][i][s0:s0 + 8])
+    net = TrajARNet(rnn_hdim=32, mlp_hsize=(32, 16)).double()
+    opt = torch.optim.Adam(net.parameters(), lr=5e-3)
+    first = P.update_init_supervised(net, opt, fk, ds, num_epoch=1, num_sample=8, batch_size=8)
+    last = P.update_init_supervised(net, opt, fk, ds, num_epoch=30, num_sample=8, batch_size=8)
+    assert last < 0.5 * first
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda e: 1.0)
+    f1 = P.train_full_supervised(net, opt, fk, ds, num_epoch=1, scheduled_sampling=0.3, num_sample=8, batch_size=8, scheduler=sched, rng=np.random.RandomState(0))
+    f2 = P.train_full_supervised(net, opt, fk, ds, num_epoch=25, scheduled_sampling=0.3, num_sample=8, batch_size=8, scheduler=sched, rng=np.random.RandomState(0))
+    assert f2 < 0.7 * f1

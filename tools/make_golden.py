@@ -378,6 +378,66 @@ def gen_traj_ar_net(hum):
     np.savez(os.path.join(OUT, "smooth_effective.npz"), x=x_eff, y=ar_qpos.numpy())
 
 
+def gen_pretrain(hum):
+    """The warm start of AgentAR.train_init (agent_ar.py:366-385): TrajARNet.forward in train form (traj_ar_smpl_net.py:346-383; the differentiable
+    kinematic roll-out incl. scheduled sampling), compute_loss (:390-457), compute_loss_init (:499-527) and the gradients both losses leave on a few
+    small parameters, with seeded weights and kin_poly.yml's model_specs weights.  add_noise is off here (the observation noise is random)."""
+    import kin_poly.models.traj_ar_smpl_net as tn
+    import kin_poly.utils.torch_smpl_humanoid as tsh
+    tsh.load_model_from_path = lambda f: fake_mj_model()
+    cfg = types.SimpleNamespace(model_specs=dict(model_v=1, rnn_hdim=1024, mlp_hsize=[1024, 512, 256], mlp_htype="relu", rnn_type="gru",
+                                                 w_rp=50.0, w_rr=50.0, w_p=1.0, w_v=1.0, w_ee=10.0, w_op=1.0, w_or=10.0),
+                                mujoco_model_file="unused.xml", use_of=False, use_head=True, use_action=True, use_vel=False, use_context=False,
+                                add_noise=False, noise_std=0.01, has_z=True, data_dir=os.path.join(REF, "sample_data"))
+    rng = np.random.default_rng(206)
+    B, T = 3, 6
+    qpos = np.stack([[rand_qpos(rng, 0.15) for _ in range(T)] for _ in range(B)])
+    data = dict(qpos=qpos, qvel=rng.normal(size=(B, T, 75)) * 0.1, target=rng.normal(size=(B, T, 80)) * 0.1,
+                head_pose=np.concatenate([rng.normal(size=(B, T, 3)), np.stack([[rand_quat(rng) for _ in range(T)] for _ in range(B)])], 2),
+                head_vels=rng.normal(size=(B, T, 6)) * 0.3, obj_head_relative_poses=rng.normal(size=(B, T, 7)) * 0.3,
+                obj_pose=np.concatenate([rng.normal(size=(B, T, 3)), np.stack([[rand_quat(rng) for _ in range(T)] for _ in range(B)])], 2),
+                action_one_hot=np.tile(np.array([0, 1.0, 0, 0]), (B, T, 1)), wbpos=rng.normal(size=(B, T, 72)))
+    data_t = {k: torch.tensor(v) for k, v in data.items()}
+    net = tn.TrajARNet(cfg, data_sample=data_t, device=torch.device("cpu"), dtype=torch.float64, mode="train", as_policy=True)
+    sd = seeded_state_dict(net, 19)
+    for k in sd:
+        if k.startswith(("action_fc", "context_fc")):
+            sd[k] = sd[k] * 0.05
+    net.load_state_dict(sd)
+    out = {}
+    watch = ("action_fc.bias", "context_fc.bias", "action_mlp.affine_layers.2.bias", "context_mlp.affine_layers.0.bias")
+    params = dict(net.named_parameters())
+    coins = [0, 0, 1, 0, 1, 0]           # scheduled sampling's draws (np.random.binomial(1, gt_rate) at the initial state and after every step), scripted
+    out["coins"] = np.array(coins)
+    for tag, rate in (("", 0.0), ("_gt", 0.3)):
+        net.set_schedule_sampling(rate)
+        net.zero_grad()
+        seq, orig = iter(coins), np.random.binomial
+        np.random.binomial = lambda n, p: next(seq)
+        try:
+            fp = net.forward({k: v.clone() for k, v in data_t.items()})
+        finally:
+            np.random.binomial = orig
+        loss, idv = net.compute_loss(fp, data_t)
+        loss.backward()
+        out.update({f"qpos{tag}": fp["qpos"].detach().numpy(), f"qvel{tag}": fp["qvel"].detach().numpy(), f"action{tag}": fp["action"].detach().numpy(),
+                    f"obj_2_head{tag}": fp["obj_2_head"].detach().numpy(), f"pred_wbpos{tag}": fp["pred_wbpos"].detach().numpy(),
+                    f"loss{tag}": float(loss), f"loss_idv{tag}": np.array(idv)})
+        for w in watch:
+            out[f"grad{tag}:{w}"] = params[w].grad.numpy().copy()
+    net.set_schedule_sampling(0.0)
+    net.zero_grad()
+    d1 = net.init_states({k: v.clone() for k, v in data_t.items()})
+    loss_i, idv_i = net.compute_loss_init(d1["init_qpos"], data_t["qpos"][:, 0], d1["init_qvel"], data_t["qvel"][:, 0])
+    loss_i.backward()
+    out.update(loss_init=float(loss_i), loss_init_idv=np.array(idv_i))
+    for w in ("context_fc.bias", "context_mlp.affine_layers.0.bias"):
+        out[f"grad_init:{w}"] = params[w].grad.numpy().copy()
+    np.savez(os.path.join(OUT, "pretrain.npz"), seed=19, keys=np.array(list(net.state_dict().keys())),
+             shapes=np.array([list(v.shape) + [0] * (2 - v.dim()) for v in net.state_dict().values()]),
+             state_dim=net.state_dim, context_dim=net.context_dim, **{"in_" + k: v for k, v in data.items()}, **out)
+
+
 def gen_loss_and_checkpoint(hum):
     """TrajARNet.step + compute_loss_lite (traj_ar_smpl_net.py:292-330, 459-497) on seeded poses, and a small pickle in
     the reference's checkpoint layout written with the reference's own ZFilter class (agent_ar.py:341-364)."""
@@ -568,12 +628,18 @@ if __name__ == "__main__" and os.environ.get("KP_GOLDEN_ONLY") is None:
     gen_gae_zfilter()
     gen_policies()
     gen_traj_ar_net(hum)
+    gen_pretrain(hum)
     gen_loss_and_checkpoint(hum)
     gen_ppo_loss()
     gen_uhc_expert_reward()
     gen_dataset_features(hum)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__" and os.environ.get("KP_GOLDEN_ONLY") == "pretrain":
+    gen_pretrain(make_humanoid())
+    print("pretrain.npz", os.path.getsize(os.path.join(OUT, "pretrain.npz")))
 
 
 if __name__ == "__main__" and os.environ.get("KP_GOLDEN_ONLY") == "traj":
