@@ -28,8 +28,8 @@ def _one_hot_at(data, t):
 def observe(fk: TorchFK, qpos, data, t, noise_std=0.0, generator=None):
     """TrajARNet.get_obs (:203-290) for kin_poly.yml (use_head, use_action; no use_vel / use_of / use_context), differentiable in qpos.
     Returns (obs [B, 105], features: pred_wbpos [B,72], obj_2_head [B,7])."""
-    wbpos, wbquat = fk.chain_torch(qpos)
-    hpos, hrot = wbpos[:, HEAD], wbquat[:, HEAD]
+    wbpos = fk.wbpos(qpos)                     # float32 device rows: k_target_fk forward / k_fk_wbpos_grad backward (supervised.TorchFK)
+    hpos, hrot = wbpos[:, HEAD], fk.body_quat(qpos, HEAD)
     local = torch.cat([qpos[:, 2:3], quat_mul(quat_inv(heading_q(qpos[:, 3:7])), qpos[:, 3:7]), qpos[:, 7:]], 1)        # height, de-headed root, pose: 74
     t_hpos, t_hrot = data["head_pose"][:, t, :3], data["head_pose"][:, t, 3:]
     t_hlvel, t_havel = data["head_vels"][:, t, :3], data["head_vels"][:, t, 3:]

@@ -89,6 +89,26 @@ class TorchFK:
     def wbpos_torch(self, qpos):
         return self.chain_torch(qpos)[0]
 
+    def body_quat(self, qpos, body):
+        """world quaternion of ONE body [B, 4], differentiable: the product of the local 'rzyx' quaternions along its root path only (the
+        supervised roll-out's observation reads the head's orientation every frame; the full tree walk is 23 bodies, the head's path 5)"""
+        path = []
+        b = int(body)
+        while b > 0:
+            path.append(b); b = self.parents[b]
+        q = qpos[:, 3:7] / qpos[:, 3:7].norm(dim=1, keepdim=True)
+        if not path:
+            return q
+        ids = torch.tensor(path[::-1], device=qpos.device)
+        ang = qpos[:, 7:].view(qpos.shape[0], 23, 3)[:, ids - 1] * 0.5                      # [B, n, 3]
+        s, c = torch.sin(ang), torch.cos(ang)
+        z = torch.zeros_like(c[..., 0])
+        qz = torch.stack([c[..., 0], z, z, s[..., 0]], -1); qy = torch.stack([c[..., 1], z, s[..., 1], z], -1); qx = torch.stack([c[..., 2], s[..., 2], z, z], -1)
+        local = quat_mul(quat_mul(qz, qy), qx)
+        for k in range(len(path)):
+            q = quat_mul(q, local[:, k])
+        return q
+
     def chain_torch(self, qpos):
         """(wbpos [B,24,3], wbquat [B,24,4]) by differentiable torch ops (the observation of the supervised roll-out reads the head's quaternion too)"""
         B = qpos.shape[0]
