@@ -38,7 +38,9 @@ class AgentAR:
                  policy_lr=1e-5, value_lr=3e-4, supervised_lr=5e-4, num_optim_epoch=10, num_step_update=20, gamma=0.95, tau=0.95,
                  clip_epsilon=0.2, rl_update=True, step_update=True, model_options=None, dataset=None, sampling_temp=0.3, sampling_freq=0.5,
                  pool_depth=4, num_epoch_fix=100, num_epoch=10000, joint_controller=False, grad_joint=False, grad_alternate=False, train_uhc=False,
-                 cache_init_context=False, log_std=-3.2, policy_weightdecay=0.0, value_weightdecay=0.0, smooth=True, result_dir=None, eval_envs=None):
+                 cache_init_context=False, log_std=-3.2, policy_weightdecay=0.0, value_weightdecay=0.0, smooth=True, result_dir=None, eval_envs=None,
+                 init_update=False, num_init_update=5, step_update_dyna=False, num_step_dyna_update=10, full_update=False, num_sample=20000, batch_size=128,
+                 noise_std=0.0):
         rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
         enable_tuned_gemms()          # library GEMM solution per shape (rollout and update shapes at 4096 envs); selection only
         torch.manual_seed(seed + rank)
@@ -58,6 +60,9 @@ class AgentAR:
                                     sampling_temp=sampling_temp, sampling_freq=sampling_freq, fix_height=False, cache_init_context=cache_init_context)
         self.horizon, self.rl_update, self.step_update, self.num_step_update = horizon, rl_update, step_update, num_step_update
         self.grad_joint, self.grad_alternate = grad_joint, grad_alternate       # policy_specs.grad_joint / grad_alternate (agent_ar.py:703, 746-747)
+        # the optional supervised branches of update_params (agent_ar.py:711-745; all off in kin_poly.yml)
+        self.init_update, self.num_init_update, self.step_update_dyna, self.num_step_dyna_update, self.full_update = init_update, num_init_update, step_update_dyna, num_step_dyna_update, full_update
+        self.num_sample, self.batch_size, self.noise_std = num_sample, batch_size, noise_std
         self.trainer = PPOTrainer(self.policy_net, self.value_net, gamma, tau, clip_epsilon, policy_lr, value_lr, num_optim_epoch,
                                   num_epoch_fix=num_epoch_fix, num_epoch=num_epoch, cc_policy=self.env.cc_policy if joint_controller else None, train_uhc=train_uhc,
                                   policy_weightdecay=policy_weightdecay, value_weightdecay=value_weightdecay)
@@ -66,9 +71,9 @@ class AgentAR:
         kpm = read_kpm(kpsim.DEFAULT_KPM)
         self.fk = TorchFK(kpm["body_pos"], kpm["body_parent"], self.device, sim=self.kin_sim)   # HIP forward / backward kernels for the loss FK
         self.sampler = VectorSampler(self.env, self.policy_net, record_qpos=True, source=self.source, pool_depth=pool_depth,
-                                     record_full=joint_controller)
+                                     record_full=joint_controller or step_update_dyna)
         self.epoch = 0
-        self.result_dir, self.eval_envs, self.test_datasets, self._eval = result_dir, eval_envs, [], None
+        self.result_dir, self.eval_envs, self.test_datasets, self._eval = result_dir, eval_envs, [], {}
         if result_dir is not None and dataset is not None:          # setup_logging (:228-234): resume the sampling history of an earlier run
             import os
             fp = os.path.join(result_dir, "freq_dict.pt")
@@ -123,8 +128,18 @@ class AgentAR:
         else:
             if self.rl_update:
                 info.update(self.trainer.update(batch))
+            if self.init_update:             # :711-718
+                from . import pretrain as P
+                info["init_loss"] = P.update_init_supervised(self.policy_net, self.opt_sup, self.fk, self.source.dataset, self.num_init_update, self.num_sample, self.batch_size,
+                                                             grad_allreduce=_allreduce_grads)
             if self.step_update:
                 info["step_loss"] = update_supervised_step(self.policy_net, self.opt_sup, self.fk, batch, self.num_step_update, _allreduce_grads)
+            if self.step_update_dyna:        # :728-734: the same step regressed onto the pose the simulation reached
+                info["step_dyna_loss"] = update_supervised_step(self.policy_net, self.opt_sup, self.fk, batch, self.num_step_dyna_update, _allreduce_grads, target=batch.res_qpos)
+            if self.full_update:             # :736-744
+                from . import pretrain as P
+                info["full_loss"] = P.train_full_supervised(self.policy_net, self.opt_sup, self.fk, self.source.dataset, 1, 0.3, self.num_sample, self.batch_size,
+                                                            noise_std=self.noise_std, grad_allreduce=_allreduce_grads)
         self.sched_sup.step()
         torch.cuda.synchronize(self.device)
         t2 = time.time()
@@ -156,17 +171,18 @@ class AgentAR:
         return (f"Ep: {done - 1}\t {cfg_id} \tT_s {info['T_sample']:.2f}\t T_u {info['T_update']:.2f}\tETA {eta_str} \texpert_R_avg {log.avg_c_reward:.4f} [{c_info}]"
                 f"\texpert_R_range ({log.min_c_reward:.4f}, {log.max_c_reward:.4f})\teps_len {log.avg_episode_len:.2f}")
 
-    def _eval_engine(self):
+    def _eval_engine(self, wild=None):
         """A second, smaller engine for evaluation roll-outs (the training envs are in the middle of their episodes and of their clip rings):
         test mode, its own kinematic twin for the whole-take roll-out of init_context.  The reference switches its one env to test mode
         instead (eval_seq, :463-470)."""
-        if self._eval is None:
+        wild = bool(self.env.wild if wild is None else wild)          # `curr_env = self.env if not loader.cfg.wild else self.env_wild` (:464)
+        if wild not in self._eval:
             n = int(self.eval_envs or min(self.env.n, 256))
-            env = BatchedHumanoidAREnv(n, self.device.index, mode="test", wild=self.env.wild, seed=0, cc_policy=self.env.cc_policy, cc_running_state=self.env.cc_running_state)
+            env = BatchedHumanoidAREnv(n, self.device.index, mode="test", wild=wild, seed=0, cc_policy=self.env.cc_policy, cc_running_state=self.env.cc_running_state)
             env.reward_cfg.body_diff_thresh, env.reward_cfg.body_diff_gt_thresh = self.env.reward_cfg.body_diff_thresh, self.env.reward_cfg.body_diff_gt_thresh
             builder = PolicyARContext(self.policy_net, kpsim.KpSim(env.model, n, self.device.index), smooth=self.ctx_builder.smooth, need_rollout=True, keep_context_feat=False)
-            self._eval = (env, builder)
-        return self._eval
+            self._eval[wild] = (env, builder)
+        return self._eval[wild]
 
     def eval_policy(self, data_mode="train"):
         """AgentAR.eval_policy (:394-448): every take of the training set (`train`) or of every set in `self.test_datasets` (`test`) is played whole
@@ -175,9 +191,9 @@ class AgentAR:
         result_dir.  Returns the reference's list of {"coverage_<name>": {"mean_coverage", "num_coverage", "all_coverage"}}."""
         from .evaluate import eval_dataset
         sets = [self.source.dataset] if data_mode == "train" else list(self.test_datasets)
-        env, builder = self._eval_engine()
         out = []
         for ds in sets:
+            env, builder = self._eval_engine(getattr(ds, "wild", None))
             res = eval_dataset(env, self.policy_net, builder, ds)
             ok = {k: r["percent"] == 1 for k, r in res.items()}
             if data_mode == "train":

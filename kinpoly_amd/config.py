@@ -104,7 +104,10 @@ class Config:
                     sampling_temp=ps.get("sampling_temp", 0.5), sampling_freq=ps.get("sampling_freq", 0.9), num_epoch_fix=self.num_epoch_fix, num_epoch=self.num_epoch,
                     joint_controller=bool(self.joint_controller), grad_joint=ps.get("grad_joint", False), grad_alternate=ps.get("grad_alternate", False),
                     log_std=ps.get("log_std", -3.2), policy_weightdecay=ps.get("policy_weightdecay", 0.0), value_weightdecay=ps.get("value_weightdecay", 0.0),
-                    smooth=bool(self.smooth))
+                    smooth=bool(self.smooth), init_update=ps.get("init_update", False), num_init_update=int(ps.get("num_init_update", 5)),
+                    step_update_dyna=ps.get("step_update_dyna", False), num_step_dyna_update=int(ps.get("num_step_dyna_update", 10)), full_update=ps.get("full_update", False),
+                    num_sample=int(self.yaml_data.get("num_sample", 20000)), batch_size=int(self.batch_size),
+                    noise_std=float(self.noise_std) if self.add_noise else 0.0)
 
     def horizon(self, n_envs: int, world_size: int = 1, floor: int = 1) -> int:
         """Steps per env and iteration so that the job collects at least `min_batch_size` samples (agent_ar.py:277: `self.sample(min_batch_size)`;

@@ -142,10 +142,11 @@ def compute_loss_lite(fk: TorchFK, pred_qpos, gt_qpos, w_rp=50.0, w_rr=50.0, w_p
     return loss, [r_pos.mean(), r_rot.mean(), p_rot.mean(), ee.mean()]
 
 
-def update_supervised_step(policy, optimizer, fk: TorchFK, batch, num_epoch=20, grad_allreduce=None):
-    """batch: RolloutBatch with curr_qpos / gt_target_qpos recorded by VectorSampler(record_qpos=True)."""
+def update_supervised_step(policy, optimizer, fk: TorchFK, batch, num_epoch=20, grad_allreduce=None, target=None):
+    """batch: RolloutBatch with curr_qpos / gt_target_qpos recorded by VectorSampler(record_qpos=True).  target: another [N, T, 76] pose to regress
+    the kinematic step onto -- `batch.res_qpos`, the pose the simulation reached, makes this PolicyAR.update_supervised_dyna (policy_ar.py:289-301)."""
     N, T, _ = batch.states.shape
-    curr, tgt = batch.curr_qpos.reshape(N * T, 76), batch.gt_target_qpos.reshape(N * T, 76)
+    curr, tgt = batch.curr_qpos.reshape(N * T, 76), (batch.gt_target_qpos if target is None else target).reshape(N * T, 76)
     loss_val = None
     with torch.no_grad():
         tgt_wbpos = fk.wbpos(tgt)              # the GT side of the end-effector term does not change between epochs

@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--wild", action="store_true")
     ap.add_argument("--no_log", action="store_true")
     ap.add_argument("--test_data", type=str, nargs="*", default=[], help="feature files of the test sets evaluated every save_model_interval iterations")
+    ap.add_argument("--test_data_wild", type=str, nargs="*", default=[], help="the same for --wild test sets (evaluated on the ..._mesh_all.xml engine, agent_ar.py:305-314, 464)")
     args = ap.parse_args()
     world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
@@ -90,7 +91,8 @@ def main():
         agent = AgentAR(args.num_envs, dataset=ds, device=local, horizon=cfg.horizon(args.num_envs, world), pool_depth=args.pool_depth,
                         cache_init_context=args.cache_init_context, result_dir=cfg.result_dir, **cfg.agent_kwargs())
         cfg.apply_reward_weights(agent.env)
-        agent.test_datasets = [D.StateARDataset(p, data_mode="test", fr_num=args.clip_len, wild=args.wild, seed=4, device=fk_sim.device) for p in args.test_data]
+        agent.test_datasets = ([D.StateARDataset(p, data_mode="test", fr_num=args.clip_len, wild=args.wild, seed=4, device=fk_sim.device) for p in args.test_data]
+                               + [D.StateARDataset(p, data_mode="test", fr_num=args.clip_len, wild=True, seed=4, device=fk_sim.device) for p in args.test_data_wild])
         if args.iter > 0:                              # AgentAR(checkpoint_epoch=args.iter) -> load_checkpoint (agent_ar.py:72-73, 318-339)
             agent.load_checkpoint(cfg.checkpoint_path(args.iter))
             agent.epoch = args.iter

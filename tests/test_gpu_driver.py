@@ -211,6 +211,32 @@ def test_warm_start_trains_the_policy_and_its_rollout_equals_the_hip_rollout():
     assert agent.opt_sup is not old_opt and len(agent.opt_sup.state) == 0
     with torch.no_grad():
         l1, _ = P.compute_loss(P.forward_supervised(net, agent.fk, data), data)
-    assert float(l1) < float(l0)
+    assert float(l1) < float(l0.detach())
     info = agent.optimize_policy(0)                      # and the RL iteration runs on the warm-started networks
     assert info["num_steps"] == n * 4
+
+
+def test_optional_supervised_branches_of_update_params():
+    """update_params' other supervised branches (agent_ar.py:711-745; off in kin_poly.yml, on in other statear configs): init_update,
+    step_update_dyna (the one-step loss against the pose the SIMULATION reached: res_qpos is recorded for it) and full_update."""
+    from kinpoly_amd import dataset as D
+    from kinpoly_amd.agent import AgentAR
+    n, fr = 8, 12
+    takes, fk_sim = _takes(n, fr)
+    ds = D.StateARDataset(takes, fr_num=fr, seed=3, device=fk_sim.device)
+    agent = AgentAR(n, dataset=ds, device=0, horizon=4, num_optim_epoch=1, num_step_update=1, init_update=True, num_init_update=1, step_update_dyna=True,
+                    num_step_dyna_update=2, full_update=True, num_sample=8, batch_size=8)
+    before = agent.policy_net.context_fc.weight.detach().clone()
+    info = agent.optimize_policy(0)
+    for k in ("init_loss", "step_loss", "step_dyna_loss", "full_loss", "surr_loss"):
+        assert k in info and np.isfinite(info[k]), k
+    assert float((agent.policy_net.context_fc.weight.detach() - before).abs().max()) > 0          # only the init / full branches reach the context network
+    # the dyna target is what the simulation produced, not the clip: the two one-step losses differ
+    assert info["step_dyna_loss"] != info["step_loss"]
+    # a --wild test set is evaluated on the wild engine (no GT termination, ..._mesh_all.xml), the training set on the training model
+    ds_w = D.StateARDataset(takes, data_mode="test", fr_num=fr, wild=True, seed=5, device=fk_sim.device); ds_w.name = "wild"
+    agent.test_datasets = [ds_w]
+    agent.eval_envs = 4
+    out = agent.eval_policy("test")
+    assert list(out[0]) == ["coverage_wild"] and out[0]["coverage_wild"]["all_coverage"] == 4
+    assert set(agent._eval) == {True} and agent._eval[True][0].wild is True
