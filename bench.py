@@ -426,6 +426,7 @@ def relaunch_under_torchrun(n_gpus):
 
 
 def main():
+    global ENVS_PER_GPU                 # the envs_per_gpu_8192 block of the default run changes it for two extra rollouts
     if len(sys.argv) >= 3 and sys.argv[1] == "--cpu-baseline-worker":
         std = np.load(os.path.join(ROOT, "tests", "golden", "standing_neutral.npz"))
         r = cpu_baseline(std, float(sys.argv[2]))
@@ -602,6 +603,21 @@ def main():
                     torch.cuda.empty_cache()
                 except Exception as ex:
                     out["secondary_workloads"][wl] = {"error": f"{type(ex).__name__}: {ex}"[:200]}
+            # the same two rollouts with twice the envs on the GPU (NOT the metric: BASELINE's figure is at 4096 envs per GPU).  The control-step launch ends
+            # on the serial chain of its costliest env, which does not grow with the batch: what more envs buy is the idle tail
+            out["envs_per_gpu_8192"] = {}
+            for wl in ("tracked", "objects"):
+                try:
+                    ENVS_PER_GPU = 8192
+                    r2, e2, p2, s2, _ = run_workload(wl, local_rank, 4 + rank, args.threads_per_env, 30, 10)
+                    out["envs_per_gpu_8192"][wl] = {"value": 8192 * 30 / r2["elapsed"], "unit": "env-steps/s", "ms_per_step": r2["elapsed"] / 30 * 1e3, "launch_ms": r2["kern_s"] * 1e3,
+                                                    "steps": 30, "warmup": 10}
+                    del r2, e2, p2, s2
+                except Exception as ex:
+                    out["envs_per_gpu_8192"][wl] = {"error": f"{type(ex).__name__}: {ex}"[:200]}
+                finally:
+                    ENVS_PER_GPU = 4096
+                    torch.cuda.empty_cache()
             # the headline's workload is named at top level, next to the other workloads' rates (round 1's headline was random_init)
             out["workload_id"] = args.workload
             out["values_by_workload"] = {args.workload: value, **{k: v.get("value") for k, v in out["secondary_workloads"].items()}}
