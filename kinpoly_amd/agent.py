@@ -40,13 +40,15 @@ class AgentAR:
                  pool_depth=4, num_epoch_fix=100, num_epoch=10000, joint_controller=False, grad_joint=False, grad_alternate=False, train_uhc=False,
                  cache_init_context=False, log_std=-3.2, policy_weightdecay=0.0, value_weightdecay=0.0, smooth=True, result_dir=None, eval_envs=None,
                  init_update=False, num_init_update=5, step_update_dyna=False, num_step_dyna_update=10, full_update=False, num_sample=20000, batch_size=128,
-                 noise_std=0.0):
+                 noise_std=0.0, cc_checkpoint=None):
         rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
         enable_tuned_gemms()          # library GEMM solution per shape (rollout and update shapes at 4096 envs); selection only
         torch.manual_seed(seed + rank)
         self.env = BatchedHumanoidAREnv(n_envs, device, mode="train", wild=wild, seed=seed + rank, model_options=model_options,
                                         joint_controller=joint_controller)
         self.device = self.env.device
+        if cc_checkpoint is not None:      # the pre-trained UHC the env is built around (humanoid_ar_v1.py:60-81)
+            self.env.load_uhc_checkpoint(cc_checkpoint, load_policy=not joint_controller)
         self.policy_net = TrajARNet(log_std=log_std).to(self.device)
         self.value_net = Value(MLP(105, (512, 256), "relu")).to(self.device)
         self._sync_params()

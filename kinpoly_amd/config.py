@@ -125,6 +125,19 @@ class Config:
             raise ConfigError("reward_weights.v_ord must be 2 (the angular-velocity term of the reward kernel is the L2 norm)")
         return env.reward_cfg
 
+    def cc_checkpoint_path(self, cc_iter: int | None = None, proj_name: str = "motion_im"):
+        """The UHC checkpoint the env loads (humanoid_ar_v1.py:69-76): results/<proj_name>/<cc_cfg>/models/iter_%04d.p, cc_iter -1 = the latest in that
+        directory.  None when there is none."""
+        d = os.path.join(self.base_dir, proj_name, self.policy_specs.get("cc_cfg", "uhc"), "models")
+        it = self.policy_specs.get("cc_iter", -1) if cc_iter is None else cc_iter
+        if it == -1:
+            have = [int(f.split("_")[-1].split(".")[0]) for f in (os.listdir(d) if os.path.isdir(d) else []) if f.startswith("iter_") and f.endswith(".p")]
+            if not have:
+                return None
+            it = max(have)
+        p = os.path.join(d, "iter_%04d.p" % it)
+        return p if os.path.exists(p) else None
+
     def checkpoint_path(self, i_iter: int) -> str:
         """'%s/iter_%04d.p' % (policy_model_dir, epoch + 1)   (agent_ar.py:363)"""
         return os.path.join(self.policy_model_dir, "iter_%04d.p" % i_iter)

@@ -230,6 +230,20 @@ class BatchedHumanoidAREnv:
                 sub[k] = v.to(self.device)[idx] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == R else v
             self.write_context_rows(idx, sub)
 
+    def load_uhc_checkpoint(self, path, load_policy=True):
+        """The trained UHC of the reference's constructor (humanoid_ar_v1.py:60-81): `running_state` (ZFilter of the 784-d observation) always,
+        `policy_dict` into cc_policy unless the run trains the controller jointly (`if not kin_cfg.joint_controller`, :79-81).  `path`: a pickle in
+        the reference's layout ({'policy_dict', 'value_dict', 'running_state'}; scripts/train_uhc.py --save writes one)."""
+        from . import checkpoint as ck
+        cp = ck.load_checkpoint(path)
+        arr = ck.running_state_arrays(cp.get("running_state"))
+        if arr is not None:
+            self.cc_running_state = RunningState(arr[0], arr[1], arr[2], self.device)
+        if load_policy:
+            self.cc_policy.load_state_dict({k: (v if torch.is_tensor(v) else torch.as_tensor(v)) for k, v in cp["policy_dict"].items()})
+            self.cc_policy.to(self.device).float()
+        return cp
+
     @property
     def has_objects(self):
         """the loaded clips carry action objects (they are free bodies of the envs)"""

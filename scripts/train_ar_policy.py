@@ -44,6 +44,10 @@ def main():
     ap.add_argument("--iter", type=int, default=0, help="resume from models_policy/iter_%%04d.p (the reference's --iter)")
     ap.add_argument("--warm_start", action="store_true", help="AgentAR.train_init before the first iteration of a fresh run: supervised warm start of the kinematic policy "
                     "(policy_specs.warm_update_init / warm_update_full epochs, default 500 / 50; the reference always runs it at --iter 0)")
+    ap.add_argument("--warm_update_init", type=int, default=None); ap.add_argument("--warm_update_full", type=int, default=None)
+    ap.add_argument("--num_sample", type=int, default=None); ap.add_argument("--batch_size", type=int, default=None)
+    ap.add_argument("--cc_ckpt", type=str, default="", help="trained UHC checkpoint in the reference's layout (scripts/train_uhc.py --save); with --cfg the default is "
+                    "results/motion_im/<cc_cfg>/models/iter_<cc_iter>.p as in the reference")
     ap.add_argument("--wild", action="store_true")
     ap.add_argument("--no_log", action="store_true")
     ap.add_argument("--test_data", type=str, nargs="*", default=[], help="feature files of the test sets evaluated every save_model_interval iterations")
@@ -83,13 +87,16 @@ def main():
 
     # every episode draws its clip through data_loader.sample_seq(freq_dict, sampling_temp, sampling_freq) (agent_ar.py:519-523): the
     # agent keeps the freq_dict and feeds each finished episode's [percent, fr_start] back (random window starts, adaptive takes)
+    cc_ckpt = args.cc_ckpt or (cfg.cc_checkpoint_path() if cfg is not None else None) or None
+    if rank == 0 and cc_ckpt:
+        print(f"loading model from checkpoint: {cc_ckpt}", flush=True)
     if cfg is None:
-        agent = AgentAR(args.num_envs, dataset=ds, device=local, horizon=args.horizon, num_optim_epoch=args.num_optim_epoch,
+        agent = AgentAR(args.num_envs, dataset=ds, device=local, horizon=args.horizon, num_optim_epoch=args.num_optim_epoch, cc_checkpoint=cc_ckpt,
                         num_step_update=args.num_step_update, sampling_temp=0.3, sampling_freq=0.5, pool_depth=args.pool_depth, cache_init_context=args.cache_init_context)
         first, last, interval = 0, args.iters, 0
     else:
         agent = AgentAR(args.num_envs, dataset=ds, device=local, horizon=cfg.horizon(args.num_envs, world), pool_depth=args.pool_depth,
-                        cache_init_context=args.cache_init_context, result_dir=cfg.result_dir, **cfg.agent_kwargs())
+                        cache_init_context=args.cache_init_context, result_dir=cfg.result_dir, cc_checkpoint=cc_ckpt, **cfg.agent_kwargs())
         cfg.apply_reward_weights(agent.env)
         agent.test_datasets = ([D.StateARDataset(p, data_mode="test", fr_num=args.clip_len, wild=args.wild, seed=4, device=fk_sim.device) for p in args.test_data]
                                + [D.StateARDataset(p, data_mode="test", fr_num=args.clip_len, wild=True, seed=4, device=fk_sim.device) for p in args.test_data_wild])
@@ -103,7 +110,9 @@ def main():
     if args.warm_start and first == 0:             # train_init (agent_ar.py:366-385), then save_checkpoint(0) -> iter_0001.p
         ps = cfg.policy_specs if cfg is not None else {}
         y = cfg.yaml_data if cfg is not None else {}
-        ws = agent.train_init(int(ps.get("warm_update_init", 500)), int(ps.get("warm_update_full", 50)), int(y.get("num_sample", 20000)), int(y.get("batch_size", 128)),
+        pick = lambda a, d: d if a is None else a      # noqa: E731
+        ws = agent.train_init(pick(args.warm_update_init, int(ps.get("warm_update_init", 500))), pick(args.warm_update_full, int(ps.get("warm_update_full", 50))),
+                              pick(args.num_sample, int(y.get("num_sample", 20000))), pick(args.batch_size, int(y.get("batch_size", 128))),
                               noise_std=float(y.get("noise_std", 0.0)) if y.get("add_noise", False) else 0.0)
         if rank == 0:
             print(json.dumps({"warm_start": ws}), flush=True)
