@@ -128,6 +128,13 @@ def test_config_reads_the_statear_schema(tmp_path):
     assert cfg.takes == {"train": ["a-1", "b-1"], "test": ["a-2"]}
     assert Config("kin_poly", action="push", config_root=str(root)).takes["train"] == ["b-1"]
     assert Config("kin_poly", wild=True, config_root=str(root)).data_file == "real_annotations"
+    # the UHC checkpoint the env is built around (humanoid_ar_v1.py:69-76): cc_iter -1 = the latest under results/motion_im/<cc_cfg>/models
+    assert cfg.cc_checkpoint_path() is None
+    mdir = tmp_path / "results" / "motion_im" / "uhc" / "models"
+    mdir.mkdir(parents=True)
+    for it in (5, 100, 20):
+        (mdir / ("iter_%04d.p" % it)).write_bytes(b"x")
+    assert cfg.cc_checkpoint_path().endswith("motion_im/uhc/models/iter_0100.p") and cfg.cc_checkpoint_path(20).endswith("iter_0020.p") and cfg.cc_checkpoint_path(7) is None
     kw = cfg.agent_kwargs()
     assert kw["policy_lr"] == 2e-5 and kw["tau"] == 0.9 and kw["supervised_lr"] == 5e-4 and kw["num_step_update"] == 20 and kw["rl_update"] and kw["step_update"]
     assert kw["sampling_temp"] == 0.3 and kw["sampling_freq"] == 0.5 and kw["num_epoch"] == 10000 and kw["num_epoch_fix"] == 100 and kw["log_std"] == -3.2 and kw["smooth"] is True

@@ -240,3 +240,34 @@ def test_optional_supervised_branches_of_update_params():
     out = agent.eval_policy("test")
     assert list(out[0]) == ["coverage_wild"] and out[0]["coverage_wild"]["all_coverage"] == 4
     assert set(agent._eval) == {True} and agent._eval[True][0].wild is True
+
+
+def test_env_loads_a_uhc_checkpoint_in_the_reference_layout(tmp_path):
+    """humanoid_ar_v1.py:60-81: running_state always, policy_dict unless the controller is trained jointly; the pickle is what
+    scripts/train_uhc.py --save writes (reference class paths: a ZFilter holding a RunningStat)."""
+    import pickle
+    from kinpoly_amd import checkpoint as ck
+    from kinpoly_amd.agent import AgentAR
+    from kinpoly_amd.env import BatchedHumanoidAREnv
+    from kinpoly_amd.nets import PolicyMCP
+    torch.manual_seed(11)
+    src = PolicyMCP()
+    rs = ck.ZFilter((784,)); rs.rs._n = 10
+    rng = np.random.default_rng(0)
+    rs.rs._M = rng.normal(size=784); rs.rs._S = rng.uniform(1.0, 4.0, size=784) * 9
+    path = str(tmp_path / "iter_0100.p")
+    with ck._RefModulePath(), open(path, "wb") as f:
+        pickle.dump({"policy_dict": {k: v.cpu() for k, v in src.state_dict().items()}, "value_dict": {}, "running_state": rs}, f)
+    env = BatchedHumanoidAREnv(4, 0, mode="train", seed=0)
+    env.load_uhc_checkpoint(path)
+    for k, v in src.state_dict().items():
+        assert torch.equal(env.cc_policy.state_dict()[k].cpu(), v), k
+    np.testing.assert_allclose(env.cc_running_state.mean.cpu().numpy(), rs.rs.mean, rtol=1e-6)
+    np.testing.assert_allclose(env.cc_running_state.std.cpu().numpy(), rs.rs.std, rtol=1e-6)
+    assert env.cc_running_state.clip == rs.clip
+    # joint_controller: the controller's weights are the run's own, only the observation filter is taken (:79-81)
+    from kinpoly_amd.env import standing_context
+    agent = AgentAR(4, context_fn=lambda n: standing_context(n, 10, STD["qpos"], STD["qvel"], env.sim), device=0, horizon=2, use_init_context=False,
+                    joint_controller=True, cc_checkpoint=path)
+    assert not all(torch.equal(agent.env.cc_policy.state_dict()[k].cpu(), v) for k, v in src.state_dict().items() if v.dim() > 1)
+    np.testing.assert_allclose(agent.env.cc_running_state.mean.cpu().numpy(), rs.rs.mean, rtol=1e-6)
