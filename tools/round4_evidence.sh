@@ -51,6 +51,11 @@ KP_BENCH_SHARED_DEVICE=1 $T 600 python bench.py --gpus 2 --steps 20 --warmup 5 -
 # soaks: the control-step launch on mixed scenes, and the training pipeline (every episode on a fresh clip, pool top-ups, update) for 40 iterations
 $T 400 python tools/soak.py 180 > $E/soak.log 2>&1
 $T 600 python scripts/train_ar_policy.py --num_envs 4096 --iters 40 --horizon 24 2>&1 | grep -v "amdgpu.ids\|Warning\|sched_" | tail -3 >> $E/soak.log
+# env count, warm start, and the end-to-end learning check from random init
+$T 500 python tools/envs_sweep.py > $E/envs_sweep.log 2>/dev/null
+$T 500 python tools/warm_start_time.py 3 2>&1 | grep -v amdgpu.ids > $E/warm_start_time.log
+$T 1500 tools/learning_demo.sh 2>&1 | grep -v amdgpu.ids > $E/learning_demo.log
+mkdir -p $E/learning_demo && cp gpurun_out/learning_demo/*.log $E/learning_demo/ 2>/dev/null
 find gpurun_out/r04_prof $E -type f -size +2000k -delete
 for f in pytest_gpu smoke floor_fuzz obj_fuzz contact_compare obj_bench update_bench flip_profile factorisation_cost; do echo "== $f"; grep -v Warn $E/$f.log | tail -4 | cut -c1-400; done
 cut -c1-600 $E/bench_default.json
