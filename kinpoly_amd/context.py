@@ -90,7 +90,7 @@ def get_qvel_fd_batch(cur_qpos, next_qpos, dt):
         two_half = 2 * half
     else:
         s = quat_sin_half(qrel)
-        small = s < 1e-5
+        small = ~(s > 0)
         two_half = 2 * quat_acos_w(qrel)
     s = s.clamp_min(1e-30)
     axis = torch.where(small[:, None], torch.tensor([1.0, 0.0, 0.0], device=w.device, dtype=w.dtype).expand_as(qrel[:, 1:]), qrel[:, 1:] / s[:, None])

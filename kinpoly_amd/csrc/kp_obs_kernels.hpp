@@ -104,9 +104,12 @@ __global__ void k_kin_advance(int n, const float* __restrict__ qpos, const float
     // qrel = next (x) inverse(cur), inverse = conjugate / |cur|^2
     const float c2 = rot.w * rot.w + rot.x * rot.x + rot.y * rot.y + rot.z * rot.z;
     const Q4 qrel = qmul(nr, Q4{rot.w / c2, -rot.x / c2, -rot.y / c2, -rot.z / c2});
-    // sin(acos(w)) and 2 acos(w) of the reference (fp64 there) without the fp32 cancellation of 1 - w^2: for the unit quaternion qrel the sine is |xyz|
+    // sin(acos(w)) and 2 acos(w) of the reference (fp64 there) without the fp32 cancellation of 1 - w^2: for the unit quaternion qrel the sine is |xyz|.
+    // The reference's `sin < 1e-5 -> no rotation` branch (rotation_from_quaternion_batch, torch_utils.py:126-128) is dead code there: its safe_acos
+    // clamps w to +-(1 - 1e-7) (:32-36), so the sine it tests is never below 4.5e-4 and a rotation too small for 1 - w to show comes out as
+    // xyz / sin(acos(1 - 1e-7)) * 2 acos(1 - 1e-7) = 2 xyz -- which is what |xyz| and atan2 give; only the exact zero needs a guard.
     float sn = sqrtf(qrel.x * qrel.x + qrel.y * qrel.y + qrel.z * qrel.z);
-    const bool small = sn < 1e-5f;
+    const bool small = !(sn > 0.0f);
     sn = fmaxf(sn, 1e-30f);
     const V3 axis = small ? v3(1.f, 0.f, 0.f) : v3(qrel.x / sn, qrel.y / sn, qrel.z / sn);
     float angle = small ? 0.0f : 2.0f * atan2f(sn, qrel.w);

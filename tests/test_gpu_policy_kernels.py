@@ -125,22 +125,23 @@ def test_kin_advance_is_step_ar_plus_finite_difference_velocity():
     qpos = rng.normal(0, 0.4, (n, 76)); qpos[:, 2] += 0.9
     qpos[:, 3:7] = rng.normal(0, 1, (n, 4)); qpos[:, 3:7] /= np.linalg.norm(qpos[:, 3:7], axis=1, keepdims=True)
     act = rng.normal(0, 0.5, (n, 80))
-    act[:100, 77:80] *= 10.0 ** rng.uniform(-3, -1, (100, 1))             # slow turns: the kernel takes sin / angle from |xyz| and atan2, not from 1 - w^2 and acos
+    act[:100, 77:80] *= 10.0 ** rng.uniform(-3, -1, (100, 1))             # slow turns: the kernel takes sin / angle from |xyz| and atan2, not from 1 - w^2 and acos;
+    # the slowest of them (1e-5 rad per frame) are below the reference's own `sin < 1e-5` test, which its clamped acos never lets it take: 2 xyz / dt there and here
     act[-1, 77:80] = 0.0                                                 # the 'small' branch: exactly no rotation
     nxt, qv = kpsim.kin_advance(torch.tensor(qpos, dtype=torch.float32, device="cuda"), torch.tensor(act, dtype=torch.float32, device="cuda"), dt)
     torch.cuda.synchronize()
     q32 = torch.tensor(qpos, dtype=torch.float32).double().numpy(); a32 = torch.tensor(act, dtype=torch.float32).double().numpy()
     want = np.stack([O.step_ar(q32[i], a32[i], dt) for i in range(n)])
     want[:, 3:7] /= np.linalg.norm(want[:, 3:7], axis=1, keepdims=True)
-    # the reference holds unit quaternions to 1e-16; the fp32 rows are unit to 3e-8, which is enough to push w of a 1e-4 rad turn past 1 in ITS formula
-    # (clamped: zero velocity).  Give the fp64 evaluation the renormalised rows.
+    # the reference holds unit quaternions to 1e-16; the fp32 rows are unit to 3e-8, which moves w of a 1e-4 rad turn by more than 1 - w itself in ITS
+    # formula.  Give the fp64 evaluation the renormalised rows.
     q32n = q32.copy(); q32n[:, 3:7] /= np.linalg.norm(q32n[:, 3:7], axis=1, keepdims=True)
     wantv = get_qvel_fd_batch(torch.tensor(q32n), torch.tensor(want), dt).numpy()
     assert np.abs(nxt.cpu().numpy() - want).max() < 2e-6
     got = qv.cpu().numpy()
     assert np.abs(got[:, :3] - wantv[:, :3]).max() < 1e-4 and np.abs(got[:, 6:] - wantv[:, 6:]).max() < 1e-4
     assert np.abs(got[:-1, 3:6] - wantv[:-1, 3:6]).max() < 3e-5         # rotation vector / dt: 1e-7 of the quaternion product x 2 / dt
-    assert np.all(got[-1, 3:6] == 0.0)
+    assert np.abs(got[-1, 3:6]).max() < 6e-6           # no rotation asked for: what is left is the fp32 rounding of next (x) cur^-1 (1e-7) x 2 / dt, as 1e-15 is in the reference's fp64
     # in-place record layout of the roll-out: outputs are rows of time-major buffers
     Q = torch.zeros((2, n, 76), device="cuda"); V = torch.zeros((2, n, 75), device="cuda")
     Q[0].copy_(torch.tensor(qpos, dtype=torch.float32))
