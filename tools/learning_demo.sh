@@ -8,14 +8,14 @@ set -u
 export TMPDIR=/tmp
 O=gpurun_out/learning_demo; mkdir -p $O
 T="timeout -s KILL"
-UHC_ITERS=${UHC_ITERS:-300}; AR_ITERS=${AR_ITERS:-40}
+UHC_ITERS=${UHC_ITERS:-300}; AR_ITERS=${AR_ITERS:-40}      # VARIANTS="trained_uhc_warm_start" AR_ITERS=250 for a longer curve of the working configuration
 $T 900 python scripts/train_uhc.py --num_envs 4096 --iters $UHC_ITERS --save /tmp/uhc_demo.p 2>&1 | grep '^{' > $O/uhc.log
 python - <<PY
 import json
 r=[json.loads(l) for l in open("$O/uhc.log")]
 print("UHC PPO: iter 0 avg_reward %.3f fail_rate %.4f -> iter %d avg_reward %.3f fail_rate %.4f" % (r[0]["avg_reward"], r[0]["fail_rate"], r[-1]["iter"], r[-1]["avg_reward"], r[-1]["fail_rate"]))
 PY
-for variant in trained_uhc_warm_start trained_uhc_only random_uhc; do
+for variant in ${VARIANTS:-trained_uhc_warm_start trained_uhc_only random_uhc}; do
   case $variant in
     trained_uhc_warm_start) FLAGS="--cc_ckpt /tmp/uhc_demo.p --warm_start --warm_update_init 150 --warm_update_full 12 --num_sample 2000 --batch_size 256";;
     trained_uhc_only) FLAGS="--cc_ckpt /tmp/uhc_demo.p";;
