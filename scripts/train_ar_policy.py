@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--pool_depth", type=int, default=4, help="clips kept queued behind every env's current one (one host read per pool_depth steps)")
     ap.add_argument("--cache_init_context", action="store_true", help="look init_qpos / init_qvel of a window up once it has been computed under the same context-network parameters")
     ap.add_argument("--save", type=str, default="")
+    ap.add_argument("--result_dir", type=str, default="", help="without --cfg: where freq_dict.pt / eval_dict_*.pt go (with --cfg: results/all/statear/<cfg>/results)")
     ap.add_argument("--data", type=str, default="", help="feature file in the reference's schema (<data_dir>/features/<data_file>.p)")
     ap.add_argument("--cfg", type=str, default=None, help="config id (config/**/<cfg>.yml under --config_root) or a .yml path, as the reference's --cfg")
     ap.add_argument("--config_root", type=str, default=None, help="directory that holds config/ and the dataset_path of the yml (default: cwd)")
@@ -91,7 +92,7 @@ def main():
     if rank == 0 and cc_ckpt:
         print(f"loading model from checkpoint: {cc_ckpt}", flush=True)
     if cfg is None:
-        agent = AgentAR(args.num_envs, dataset=ds, device=local, horizon=args.horizon, num_optim_epoch=args.num_optim_epoch, cc_checkpoint=cc_ckpt,
+        agent = AgentAR(args.num_envs, dataset=ds, device=local, horizon=args.horizon, num_optim_epoch=args.num_optim_epoch, cc_checkpoint=cc_ckpt, result_dir=args.result_dir or None,
                         num_step_update=args.num_step_update, sampling_temp=0.3, sampling_freq=0.5, pool_depth=args.pool_depth, cache_init_context=args.cache_init_context)
         first, last, interval = 0, args.iters, 0
     else:

@@ -17,7 +17,7 @@ print("UHC PPO: iter 0 avg_reward %.3f fail_rate %.4f -> iter %d avg_reward %.3f
 PY
 for variant in ${VARIANTS:-trained_uhc_warm_start trained_uhc_only random_uhc}; do
   case $variant in
-    trained_uhc_warm_start) FLAGS="--cc_ckpt /tmp/uhc_demo.p --warm_start --warm_update_init 150 --warm_update_full 12 --num_sample 2000 --batch_size 256";;
+    trained_uhc_warm_start) FLAGS="--cc_ckpt /tmp/uhc_demo.p --warm_start --warm_update_init ${WARM_INIT:-150} --warm_update_full ${WARM_FULL:-12} --num_sample 2000 --batch_size 256";;
     trained_uhc_only) FLAGS="--cc_ckpt /tmp/uhc_demo.p";;
     random_uhc) FLAGS="";;
   esac
