@@ -107,7 +107,14 @@ class AgentAR:
         lf = P.train_full_supervised(self.policy_net, self.opt_sup, self.fk, ds, warm_update_full, scheduled_sampling, num_sample, batch_size,
                                      noise_std=noise_std, scheduler=self.sched_sup, grad_allreduce=_allreduce_grads)
         self._setup_supervised_optimizer()
+        self.restart_sampler()
         return {"init_loss": li, "full_loss": lf}
+
+    def restart_sampler(self):
+        """Throw the queued clips away and start every env on a fresh episode: the ring's rows carry init_qpos / init_qvel computed by the context
+        network AS IT WAS when they were drawn (INTEGRATION deviation 2), which is fine across PPO iterations (nothing there trains the context
+        network) but not across a warm start or a checkpoint load that replaces it."""
+        self.sampler.start()
 
     @property
     def freq_dict(self):
@@ -223,4 +230,5 @@ class AgentAR:
         self.value_net.load_state_dict(cp["value_dict"])
         if "cc_dict" in cp:
             self.env.cc_policy.load_state_dict(cp["cc_dict"])
+        self.restart_sampler()
         return cp

@@ -217,11 +217,12 @@ class StateARDataset:
 
 
 # ------------------------------------------------------------------ synthetic stand-in for the absent MoCap set
-def synthetic_takes(sim, std_qpos, n_per_action=2, T_range=(110, 160), body_mass=None, seed=0, with_objects=True):
+def synthetic_takes(sim, std_qpos, n_per_action=2, T_range=(110, 160), body_mass=None, seed=0, with_objects=True, amp_max=0.3):
     """standing -> seeded smooth joint-space sinusoids (amplitude <= 0.3 rad, <= 1 Hz), four action
     classes with their object(s) at constant poses in front of / behind the humanoid, yaw U(-pi, pi).  with_objects=False: the same
     motions as takes without an action (obj_pose = [0,0,0,1,0,0,0], action_one_hot = 0; process_smpl.py:223-225) -- config 3's
-    object-free MoCap clips."""
+    object-free MoCap clips.  amp_max: the sinusoids' amplitude bound (0.3 rad = SURVEY's figure; the pelvis does not move, so at that amplitude the
+    legs swing the feet through the floor and no controller can follow the clip for long -- fine as a workload, not as a learning target)."""
     rng = np.random.default_rng(seed)
     std_qpos = np.asarray(std_qpos, np.float64)
     obj_local = {"sit": [[0.0, -0.6, 0.3805]], "push": [[0.0, 0.8, 0.921], [0.0, 0.8, 0.7905]], "avoid": [[0.0, 1.0, 0.69]], "step": [[0.0, 0.8, 0.3705]]}
@@ -234,7 +235,7 @@ def synthetic_takes(sim, std_qpos, n_per_action=2, T_range=(110, 160), body_mass
             q = np.tile(std_qpos, (T, 1))
             w, x, y, z = std_qpos[3:7]
             q[:, 3:7] = [qz[0] * w - qz[3] * z, qz[0] * x - qz[3] * y, qz[0] * y + qz[3] * x, qz[0] * z + qz[3] * w]     # qz (x) q_root
-            amp, fr, ph = rng.uniform(0, 0.3, 69), rng.uniform(0.1, 1.0, 69), rng.uniform(0, 2 * np.pi, 69)
+            amp, fr, ph = rng.uniform(0, amp_max, 69), rng.uniform(0.1, 1.0, 69), rng.uniform(0, 2 * np.pi, 69)
             tt = np.arange(T)[:, None] / 30.0
             q[:, 7:] += amp * (np.sin(2 * np.pi * fr * tt + ph) - np.sin(ph)) * np.minimum(tt / 0.5, 1.0)
             c, s_ = np.cos(yaw), np.sin(yaw)

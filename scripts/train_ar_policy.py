@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--pool_depth", type=int, default=4, help="clips kept queued behind every env's current one (one host read per pool_depth steps)")
     ap.add_argument("--cache_init_context", action="store_true", help="look init_qpos / init_qvel of a window up once it has been computed under the same context-network parameters")
     ap.add_argument("--save", type=str, default="")
+    ap.add_argument("--synthetic_amp", type=float, default=0.3, help="amplitude bound (rad) of the synthetic takes' joint sinusoids")
     ap.add_argument("--result_dir", type=str, default="", help="without --cfg: where freq_dict.pt / eval_dict_*.pt go (with --cfg: results/all/statear/<cfg>/results)")
     ap.add_argument("--data", type=str, default="", help="feature file in the reference's schema (<data_dir>/features/<data_file>.p)")
     ap.add_argument("--cfg", type=str, default=None, help="config id (config/**/<cfg>.yml under --config_root) or a .yml path, as the reference's --cfg")
@@ -81,7 +82,7 @@ def main():
         # data set for the whole job (take seed independent of the rank): the job-wide freq_dict is keyed by take name, so a name must
         # mean the same motion on every rank; only the draw stream (dataset seed) differs per rank
         takes = D.synthetic_takes(fk_sim, std["qpos"], n_per_action=4, T_range=(args.clip_len + 10, args.clip_len + 60),
-                                  body_mass=read_kpm(kpsim.STEP_KPM)["body_mass"], seed=4)
+                                  body_mass=read_kpm(kpsim.STEP_KPM)["body_mass"], seed=4, amp_max=args.synthetic_amp)
         ds = D.StateARDataset(takes, fr_num=args.clip_len, seed=4 + rank, device=fk_sim.device)
     if rank == 0:
         print(f"dataset: {ds.get_len()} takes, {len(ds.freq_indices)} windows of {args.clip_len} frames", flush=True)

@@ -204,7 +204,10 @@ def test_warm_start_trains_the_policy_and_its_rollout_equals_the_hip_rollout():
     before = {k: v.detach().clone() for k, v in net.named_parameters()}
     old_opt = agent.opt_sup
     l0, _ = P.compute_loss(P.forward_supervised(net, agent.fk, data), data)
+    drawn = agent.source.n_drawn
     out = agent.train_init(warm_update_init=4, warm_update_full=6, num_sample=16, batch_size=8)
+    # the clips queued before the warm start carried init_qpos / init_qvel of the UNTRAINED context network: the ring is drawn again
+    assert agent.source.n_drawn == drawn + agent.sampler.n_slots * n and int(agent.sampler.head.abs().sum()) == 0 and bool(agent.sampler.fresh.all())
     assert np.isfinite(out["init_loss"]) and np.isfinite(out["full_loss"])
     moved = {k: float((v.detach() - before[k]).abs().max()) for k, v in net.named_parameters() if v.requires_grad}
     assert moved["context_fc.weight"] > 0 and moved["action_fc.weight"] > 0 and moved["action_rnn.rnn_f.weight_hh"] > 0

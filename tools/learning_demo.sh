@@ -3,6 +3,8 @@
 #   1. scripts/train_uhc.py: PPO on the UHC (PolicyMCP) against standing + small-sinusoid clips          -> a UHC that holds and tracks
 #   2. scripts/train_ar_policy.py --cc_ckpt <that UHC> --warm_start: supervised warm start of the kinematic policy (AgentAR.train_init, shortened),
 #      then dynamics-regulated PPO + supervised step updates on the synthetic takes; and the same WITHOUT the trained UHC / the warm start for contrast.
+# The synthetic takes' joint sinusoids are bounded by AMP (default 0.1 rad, the range the four-minute UHC was trained on; at SURVEY's 0.3 rad the fixed pelvis makes the
+# legs swing the feet through the floor and no episode outlives ~30 frames, with any controller).
 # Prints one line per stage; gpurun_out/learning_demo/*.log hold the per-iteration records.
 set -u
 export TMPDIR=/tmp
@@ -21,7 +23,7 @@ for variant in ${VARIANTS:-trained_uhc_warm_start trained_uhc_only random_uhc}; 
     trained_uhc_only) FLAGS="--cc_ckpt /tmp/uhc_demo.p";;
     random_uhc) FLAGS="";;
   esac
-  $T 1200 python scripts/train_ar_policy.py --num_envs 4096 --horizon 24 --iters $AR_ITERS $FLAGS 2>&1 | grep '^{' > $O/ar_$variant.log
+  $T 1200 python scripts/train_ar_policy.py --num_envs 4096 --horizon 24 --iters $AR_ITERS --synthetic_amp ${AMP:-0.1} $FLAGS 2>&1 | grep '^{' > $O/ar_$variant.log
   python - <<PY
 import json
 rows=[json.loads(l) for l in open("$O/ar_$variant.log")]
