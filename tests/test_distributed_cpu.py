@@ -99,3 +99,38 @@ def test_single_process_normalisation_matches_reference_golden(golden):
     raw = torch.tensor(g["ret"] - g["values"])
     nadv, _, _ = normalize_advantages_global(raw, torch.tensor(g["ret"]))
     np.testing.assert_allclose(nadv.numpy(), g["adv"], atol=1e-10)
+
+
+def _logger_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from kinpoly_amd.rollout import LoggerRL, _agree_status, episode_log
+    g = torch.Generator().manual_seed(50 + rank)
+    R, D, CI = torch.rand(6, 9, generator=g), torch.rand(6, 9, generator=g) < 0.3, torch.rand(6, 9, 6, generator=g)
+    st, _ = episode_log(R, D, CI, torch.zeros(6, dtype=torch.float64))
+    st = st.tolist()
+    mine = LoggerRL(num_steps=int(st[0]), num_episodes=int(st[1]), total_reward=st[2], min_episode_reward=st[3], max_episode_reward=st[4],
+                    total_c_reward=st[5], min_c_reward=st[6], max_c_reward=st[7], total_c_info=np.asarray(st[8:14]))
+    every = [None] * world
+    dist.all_gather_object(every, mine)                        # what AgentAR.optimize_policy does with the ranks' loggers
+    m = LoggerRL.merge(every)
+    status = _agree_status(7 if rank == 1 else 0, "cpu")       # one rank's stalled queue is every rank's status
+    q.put((rank, m.num_steps, m.num_episodes, m.total_c_reward, m.min_c_reward, m.max_episode_reward, float(m.avg_c_info.sum()), mine.num_episodes, mine.total_c_reward, status))
+    dist.destroy_process_group()
+
+
+def test_logger_statistics_merge_over_ranks_world2():
+    """LoggerRL.merge over the ranks' loggers (the reference merges its workers', logger_rl.py:44-70): every rank ends up with the same job-wide record."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_logger_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+    a, b = res
+    assert a[1:7] == b[1:7] and a[1] == 2 * 54                                   # identical merged records, 2 x 6 x 9 steps
+    assert a[2] == a[7] + b[7] and a[3] == pytest.approx(a[8] + b[8])            # episodes and reward sums add up
+    assert a[9] == b[9] == 7
