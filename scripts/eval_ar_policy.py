@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--result_dir", type=str, default="results/eval")
     ap.add_argument("--data_file", type=str, default="synthetic_standing")
     ap.add_argument("--data", type=str, default="", help="feature file in the reference's schema, or train / test with --cfg")
+    ap.add_argument("--metrics", action="store_true", help="with --data: root_dist / mpjpe / accel_dist / vel_dist / head_dist / succ over the takes (eval_pose_all.py's kinematic metrics)")
     ap.add_argument("--cfg", type=str, default=None)
     ap.add_argument("--config_root", type=str, default=None)
     args = ap.parse_args()
@@ -73,6 +74,15 @@ def main():
         cov = write_coverage(res, args.result_dir, args.iter, args.data_file if args.cfg else os.path.splitext(os.path.basename(args.data))[0])
         pct = np.array([r["percent"] for r in res.values()])
         print(f"Coverage of {cov} out of {len(res)} | mean percent {pct.mean():.3f} | fail-safe used in {sum(r['fail_safe'] for r in res.values())}")
+        if args.metrics:                            # the kinematic metrics of scripts/eval_pose_all.py --mode stats (kinpoly_amd/metrics.py)
+            from kinpoly_amd import metrics as M
+            from kinpoly_amd.model_compiler import DEFAULT_KPM, read_kpm
+            from kinpoly_amd.supervised import TorchFK
+            kpm = read_kpm(DEFAULT_KPM)
+            tfk = TorchFK(kpm["body_pos"], kpm["body_parent"], "cpu", dtype=torch.float64)
+            gt = {k: {"qpos": ds.data["qpos"][i].double().numpy(), "head_pose": ds.data["head_pose"][i].double().numpy()} for i, k in enumerate(ds.takes)}
+            m = M.coverage_metrics(res, gt, lambda q: tuple(x.numpy() for x in tfk.chain_torch(torch.as_tensor(q))))
+            print("".join(f"{k}:{v:.3f} \t " for k, v in m.items() if k != "per_take"))
         return
     g = torch.Generator().manual_seed(0)
     ctx = standing_context(n, T, std["qpos"], std["qvel"], env.sim, (torch.rand(n, generator=g) * 2 - 1) * np.pi)

@@ -438,6 +438,38 @@ def gen_pretrain(hum):
              state_dim=net.state_dim, context_dim=net.context_dim, **{"in_" + k: v for k, v in data.items()}, **out)
 
 
+def gen_metrics():
+    """The kinematic paper metrics (kin_poly/utils/metrics.py + compute_error_accel / the mpjpe lines of scripts/eval_pose_all.py:45-74, 140-172) on a
+    seeded pair of pose sequences; joint positions are inputs (MuJoCo's body_xpos in the reference)."""
+    import importlib
+    import kin_poly.utils.metrics as M
+    rng = np.random.default_rng(321)
+    T = 12
+    def seq():
+        q = np.stack([rand_qpos(rng, 0.2) for _ in range(T)])
+        q[1:, :3] = q[0, :3] + np.cumsum(rng.normal(size=(T - 1, 3)) * 0.01, 0)
+        base = q[0, 3:7].copy()
+        for t in range(1, T):                      # small frame-to-frame root rotations (incl. one exactly repeated frame: the 1e-6 branch)
+            d = quaternion_from_euler(*(rng.normal(size=3) * 0.05))
+            q[t, 3:7] = quaternion_multiply(d, q[t - 1, 3:7]) if t != 5 else q[t - 1, 3:7]
+        return q
+    pred, gt = seq(), seq()
+    jp, jg = rng.normal(size=(T, 24, 3)), rng.normal(size=(T, 24, 3))
+    hp = np.concatenate([rng.normal(size=(T, 3)), np.stack([rand_quat(rng) for _ in range(T)])], 1)
+    hg = np.concatenate([rng.normal(size=(T, 3)), np.stack([rand_quat(rng) for _ in range(T)])], 1)
+    dt = 1 / 30
+    vp, vg = M.get_joint_vels(pred, dt), M.get_joint_vels(gt, dt)
+    src = open(os.path.join(REF, "scripts", "eval_pose_all.py")).read()
+    ns = {"np": np}
+    exec(src[src.index("def compute_error_accel"):src.index("def compute_vel")], ns)          # the function's own text, run here, nothing of it is stored
+    accel = np.mean(ns["compute_error_accel"](jp.copy(), jg.copy())) * 1000
+    a, b = jp - jp[:, 0:1], jg - jg[:, 0:1]
+    np.savez(os.path.join(OUT, "metrics.npz"), pred=pred, gt=gt, jpos_pred=jp, jpos_gt=jg, head_pred=hp, head_gt=hg, dt=dt, vels_pred=vp, vels_gt=vg,
+             root_dist=M.get_frobenious_norm(M.get_root_matrix(pred), M.get_root_matrix(gt)), head_dist=M.get_frobenious_norm(M.get_root_matrix(hp), M.get_root_matrix(hg)),
+             vel_dist=M.get_mean_dist(vp, vg), accel_dist=accel, mpjpe=np.linalg.norm(a - b, axis=2).mean() * 1000,
+             accels_abs=M.get_mean_abs(M.get_joint_accels(vp, dt)))
+
+
 def gen_loss_and_checkpoint(hum):
     """TrajARNet.step + compute_loss_lite (traj_ar_smpl_net.py:292-330, 459-497) on seeded poses, and a small pickle in
     the reference's checkpoint layout written with the reference's own ZFilter class (agent_ar.py:341-364)."""
@@ -629,12 +661,18 @@ if __name__ == "__main__" and os.environ.get("KP_GOLDEN_ONLY") is None:
     gen_policies()
     gen_traj_ar_net(hum)
     gen_pretrain(hum)
+    gen_metrics()
     gen_loss_and_checkpoint(hum)
     gen_ppo_loss()
     gen_uhc_expert_reward()
     gen_dataset_features(hum)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__" and os.environ.get("KP_GOLDEN_ONLY") == "metrics":
+    gen_metrics()
+    print("metrics.npz", os.path.getsize(os.path.join(OUT, "metrics.npz")))
 
 
 if __name__ == "__main__" and os.environ.get("KP_GOLDEN_ONLY") == "pretrain":

@@ -10,6 +10,6 @@ takes = D.synthetic_takes(fk, std["qpos"], n_per_action=1, T_range=(30, 50), bod
 D.write_features("/tmp/feats.p", takes)
 print("features written", sorted(takes))
 PY
-timeout -s KILL 200 python scripts/eval_ar_policy.py --data /tmp/feats.p --num_seq 3 --clip_len 20 --result_dir /tmp/ev1 2>&1 | grep -v amdgpu | tail -2
+timeout -s KILL 200 python scripts/eval_ar_policy.py --data /tmp/feats.p --num_seq 3 --clip_len 20 --result_dir /tmp/ev1 --metrics 2>&1 | grep -v amdgpu | tail -3
 timeout -s KILL 200 python scripts/eval_ar_policy.py --data /tmp/feats.p --num_seq 4 --clip_len 20 --result_dir /tmp/ev2 --fail_safe --wild 2>&1 | grep -v amdgpu | tail -2
 ls /tmp/ev1 /tmp/ev2
