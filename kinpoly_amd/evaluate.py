@@ -24,7 +24,7 @@ def run_sequences(env, policy_net, keys, fail_safe=False, max_steps=100000):
     used_fs = torch.zeros(n, dtype=torch.bool, device=env.device)
     percent = torch.zeros(n, device=env.device)
     rec = {"target": [], "pred": [], "obj_pose": [], "active": []}
-    for _ in range(max_steps):
+    for step in range(max_steps):
         rec["target"].append(env.sim.get("target_qpos")); rec["pred"].append(env.get_humanoid_qpos())
         rec["obj_pose"].append(env.obj_qpos); rec["active"].append(active.clone())
         action, hx = policy_net.select_action(obs, hx, True, env.gen)
@@ -32,13 +32,13 @@ def run_sequences(env, policy_net, keys, fail_safe=False, max_steps=100000):
         newly = done & active
         percent = torch.where(newly, info["percent"], percent)
         early = newly & (info["percent"] != 1)
-        if fail_safe and bool(early.any()):
+        if fail_safe:                               # masked on the device (no host read per step): envs that ended early go back onto the kinematic roll-out
             used_fs |= early
             env.ar_fail_safe(early)
             obs = env.sim.obs_ar(env._ctx_struct, env._obs)
             newly = newly & ~early
         active = active & ~newly
-        if not bool(active.any()):
+        if step % 8 == 7 and not bool(active.any()):      # one host read every 8 steps; the records of finished envs are dropped by `active` below
             break
     act = torch.stack(rec["active"], 0).cpu().numpy()                       # [steps, n]
     tgt = torch.stack(rec["target"], 0).double().cpu().numpy(); pred = torch.stack(rec["pred"], 0).double().cpu().numpy()
