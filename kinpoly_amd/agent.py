@@ -29,8 +29,8 @@ from .context import PolicyARContext, TrajARNet
 from .env import BatchedHumanoidAREnv
 from .model_compiler import read_kpm
 from .nets import MLP, Value, enable_tuned_gemms
-from .rollout import EpisodeSource, LoggerRL, PPOTrainer, VectorSampler, _allreduce_grads, _collective_on, lambda_lr
-from .supervised import TorchFK, update_supervised_step
+from .rollout import EpisodeSource, LoggerRL, VectorSampler, _allreduce_grads, _collective_on
+from .update import ParamUpdate
 
 
 class AgentAR:
@@ -40,7 +40,10 @@ class AgentAR:
                  pool_depth=4, num_epoch_fix=100, num_epoch=10000, joint_controller=False, grad_joint=False, grad_alternate=False, train_uhc=False,
                  cache_init_context=False, log_std=-3.2, policy_weightdecay=0.0, value_weightdecay=0.0, smooth=True, result_dir=None, eval_envs=None,
                  init_update=False, num_init_update=5, step_update_dyna=False, num_step_dyna_update=10, full_update=False, num_sample=20000, batch_size=128,
-                 noise_std=0.0, cc_checkpoint=None):
+                 noise_std=0.0, cc_checkpoint=None, update_dtype=None, reference_bugs=True):
+        """update_dtype: None = the update runs on the fp32 roll-out modules (fused HIP re-unroll); torch.float64 = the reference's training
+        precision on fp64 master copies (kinpoly_amd/update.py).  reference_bugs: reproduce the reference's generator-consumed gradient clip
+        (PPOTrainer) and LoggerRL.merge's max-of-mins; False = the corrected forms."""
         rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
         enable_tuned_gemms()          # library GEMM solution per shape (rollout and update shapes at 4096 envs); selection only
         torch.manual_seed(seed + rank)
@@ -60,18 +63,16 @@ class AgentAR:
         self.source = EpisodeSource(dataset=dataset, context_fn=context_fn if dataset is None else None,
                                     ctx_builder=self.ctx_builder if use_init_context else None,
                                     sampling_temp=sampling_temp, sampling_freq=sampling_freq, fix_height=False, cache_init_context=cache_init_context)
-        self.horizon, self.rl_update, self.step_update, self.num_step_update = horizon, rl_update, step_update, num_step_update
-        self.grad_joint, self.grad_alternate = grad_joint, grad_alternate       # policy_specs.grad_joint / grad_alternate (agent_ar.py:703, 746-747)
-        # the optional supervised branches of update_params (agent_ar.py:711-745; all off in kin_poly.yml)
-        self.init_update, self.num_init_update, self.step_update_dyna, self.num_step_dyna_update, self.full_update = init_update, num_init_update, step_update_dyna, num_step_dyna_update, full_update
-        self.num_sample, self.batch_size, self.noise_std = num_sample, batch_size, noise_std
-        self.trainer = PPOTrainer(self.policy_net, self.value_net, gamma, tau, clip_epsilon, policy_lr, value_lr, num_optim_epoch,
-                                  num_epoch_fix=num_epoch_fix, num_epoch=num_epoch, cc_policy=self.env.cc_policy if joint_controller else None, train_uhc=train_uhc,
-                                  policy_weightdecay=policy_weightdecay, value_weightdecay=value_weightdecay)
-        self._sup_cfg = (supervised_lr, num_epoch_fix, num_epoch)
-        self._setup_supervised_optimizer()
+        self.horizon = horizon
         kpm = read_kpm(kpsim.DEFAULT_KPM)
-        self.fk = TorchFK(kpm["body_pos"], kpm["body_parent"], self.device, sim=self.kin_sim)   # HIP forward / backward kernels for the loss FK
+        self.upd = ParamUpdate(self.policy_net, self.value_net, kpm["body_pos"], kpm["body_parent"], kin_sim=self.kin_sim, update_dtype=update_dtype,
+                               reference_bugs=reference_bugs, policy_lr=policy_lr, value_lr=value_lr, supervised_lr=supervised_lr, num_optim_epoch=num_optim_epoch,
+                               num_step_update=num_step_update, gamma=gamma, tau=tau, clip_epsilon=clip_epsilon, rl_update=rl_update, step_update=step_update,
+                               num_epoch_fix=num_epoch_fix, num_epoch=num_epoch, grad_joint=grad_joint, grad_alternate=grad_alternate,
+                               cc_policy=self.env.cc_policy if joint_controller else None, train_uhc=train_uhc, policy_weightdecay=policy_weightdecay,
+                               value_weightdecay=value_weightdecay, init_update=init_update, num_init_update=num_init_update, step_update_dyna=step_update_dyna,
+                               num_step_dyna_update=num_step_dyna_update, full_update=full_update, num_sample=num_sample, batch_size=batch_size, noise_std=noise_std)
+        self.reference_bugs = bool(reference_bugs)
         self.sampler = VectorSampler(self.env, self.policy_net, record_qpos=True, source=self.source, pool_depth=pool_depth,
                                      record_full=joint_controller or step_update_dyna)
         self.epoch = 0
@@ -89,24 +90,34 @@ class AgentAR:
                     pass
         self.sampler.start()
 
+    # the update's state lives in self.upd (kinpoly_amd/update.py); the names the callers and tools know are kept
+    trainer = property(lambda self: self.upd.trainer)
+    opt_sup = property(lambda self: self.upd.opt_sup)
+    sched_sup = property(lambda self: self.upd.sched_sup)
+    fk = property(lambda self: self.upd.fk)
+    rl_update = property(lambda self: self.upd.rl_update)
+    step_update = property(lambda self: self.upd.step_update)
+    num_step_update = property(lambda self: self.upd.num_step_update)
+
     def _setup_supervised_optimizer(self):
-        """PolicyAR.setup_optimizers / step_lr (policy_ar.py:45-62, 72-89): Adam(lr) over the kinematic policy + its LambdaLR"""
-        lr, fix, total = self._sup_cfg
-        self.opt_sup = torch.optim.Adam([p for p in self.policy_net.parameters() if p.requires_grad], lr=lr)
-        self.sched_sup = lambda_lr(self.opt_sup, fix, total)
+        self.upd.setup_supervised_optimizer()
 
     def train_init(self, warm_update_init=500, warm_update_full=50, num_sample=2000, batch_size=256, scheduled_sampling=0.3, noise_std=0.0):
         """AgentAR.train_init (agent_ar.py:366-385), run once before the first iteration of a fresh run: `update_init_supervised` x
         warm_update_init epochs (the context network learns the clip's first pose), `train_full_supervised(scheduled_sampling=0.3)` x
         warm_update_full epochs (whole-clip kinematic roll-outs against the GT clip), then fresh supervised optimiser / schedule
-        (`setup_optimizers`).  cfg.num_sample / cfg.batch_size clips per epoch; kinpoly_amd/pretrain.py.  Gradients are all-reduced over ranks."""
+        (`setup_optimizers`).  cfg.num_sample / cfg.batch_size clips per epoch; kinpoly_amd/pretrain.py.  Gradients are all-reduced over ranks
+        (over a fixed parameter list); the scheduled-sampling coins come from ONE job-wide stream, so every rank throws the same frames back
+        onto the GT clip and the same parameters get a gradient everywhere."""
         from . import pretrain as P
         ds = self.source.dataset
         assert ds is not None and "wbpos" in ds.data, "the warm start needs a training data set (GT joint positions)"
-        li = P.update_init_supervised(self.policy_net, self.opt_sup, self.fk, ds, warm_update_init, num_sample, batch_size, grad_allreduce=_allreduce_grads)
-        lf = P.train_full_supervised(self.policy_net, self.opt_sup, self.fk, ds, warm_update_full, scheduled_sampling, num_sample, batch_size,
-                                     noise_std=noise_std, scheduler=self.sched_sup, grad_allreduce=_allreduce_grads)
-        self._setup_supervised_optimizer()
+        u = self.upd
+        li = P.update_init_supervised(u.policy, u.opt_sup, u.fk, ds, warm_update_init, num_sample, batch_size, grad_allreduce=_allreduce_grads)
+        lf = P.train_full_supervised(u.policy, u.opt_sup, u.fk, ds, warm_update_full, scheduled_sampling, num_sample, batch_size,
+                                     noise_std=noise_std, scheduler=u.sched_sup, grad_allreduce=_allreduce_grads, rng=P.job_wide_rng(-1))
+        u.setup_supervised_optimizer()
+        u.sync_rollout()
         self.restart_sampler()
         return {"init_loss": li, "full_loss": lf}
 
@@ -125,31 +136,17 @@ class AgentAR:
             for p in list(self.policy_net.parameters()) + list(self.value_net.parameters()):
                 dist.broadcast(p.data, 0)
 
+    def update_params(self, batch):
+        """AgentAR.update_params (agent_ar.py:682-752): kinpoly_amd/update.py::ParamUpdate.update_params on this iteration's batch."""
+        return self.upd.update_params(batch, self.epoch, self.source.dataset)
+
     def optimize_policy(self, i_iter=None):
         t0 = time.time()
         self.trainer.per_epoch_update()
         batch = self.sampler.sample(self.horizon)
         torch.cuda.synchronize(self.device)
         t1 = time.time()
-        info = {}
-        if self.grad_joint:               # update_params' other branch (agent_ar.py:746-747): surrogate + supervised loss in one step
-            info.update(self.trainer.update_joint(batch, self.fk, self.grad_alternate, self.epoch, self.opt_sup))
-        else:
-            if self.rl_update:
-                info.update(self.trainer.update(batch))
-            if self.init_update:             # :711-718
-                from . import pretrain as P
-                info["init_loss"] = P.update_init_supervised(self.policy_net, self.opt_sup, self.fk, self.source.dataset, self.num_init_update, self.num_sample, self.batch_size,
-                                                             grad_allreduce=_allreduce_grads)
-            if self.step_update:
-                info["step_loss"] = update_supervised_step(self.policy_net, self.opt_sup, self.fk, batch, self.num_step_update, _allreduce_grads)
-            if self.step_update_dyna:        # :728-734: the same step regressed onto the pose the simulation reached
-                info["step_dyna_loss"] = update_supervised_step(self.policy_net, self.opt_sup, self.fk, batch, self.num_step_dyna_update, _allreduce_grads, target=batch.res_qpos)
-            if self.full_update:             # :736-744
-                from . import pretrain as P
-                info["full_loss"] = P.train_full_supervised(self.policy_net, self.opt_sup, self.fk, self.source.dataset, 1, 0.3, self.num_sample, self.batch_size,
-                                                            noise_std=self.noise_std, grad_allreduce=_allreduce_grads)
-        self.sched_sup.step()
+        info = self.update_params(batch)
         torch.cuda.synchronize(self.device)
         t2 = time.time()
         self.epoch += 1
@@ -228,6 +225,7 @@ class AgentAR:
         cp = ck.load_checkpoint(path)
         self.policy_net.load_state_dict(ck.split_policy_dict(cp["policy_dict"]), strict=False)
         self.value_net.load_state_dict(cp["value_dict"])
+        self.upd.load_from_rollout()
         if "cc_dict" in cp:
             self.env.cc_policy.load_state_dict(cp["cc_dict"])
         self.restart_sampler()

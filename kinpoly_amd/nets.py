@@ -183,6 +183,18 @@ class KinPolicy(nn.Module):
         self.action_mlp = MLP(rnn_hdim + state_dim, mlp_hsize, htype)
         self.action_fc = nn.Linear(mlp_hsize[-1], action_dim)
         self.action_log_std = nn.Parameter(torch.ones(1, action_dim) * log_std, requires_grad=False)
+        self.log_std_init = float(log_std)
+
+    @torch.no_grad()
+    def refresh_log_std(self):
+        """After a change of dtype: the reference builds `action_log_std = ones * log_std` directly in its training dtype (fp64: exactly -3.2), while a
+        module built in fp32 and cast up carries fp32(-3.2) = -3.2000000477, a 1e-7 relative error of the variance that the PPO ratio sees
+        (8e-9 in the surrogate of tests/golden/update_params.npz).  Re-evaluates the constant in the current dtype -- only while it still is the
+        constructor's value (a checkpoint's own action_log_std is left alone)."""
+        p = self.action_log_std
+        if bool((p.float() == torch.tensor(self.log_std_init, dtype=torch.float32, device=p.device)).all()):
+            p.fill_(self.log_std_init)
+        return self
 
     def init_hidden(self, n, device=None):
         return torch.zeros((n, self.rnn_hdim), device=device or self.action_fc.weight.device, dtype=self.action_fc.weight.dtype)

@@ -113,6 +113,13 @@ def compute_loss_init(fk: TorchFK, pred_qpos, gt_qpos, weights=None):
     return w["w_rp"] * r_pos + w["w_rr"] * r_rot + w["w_p"] * p_rot + w["w_ee"] * ee, [r_pos, r_rot, p_rot, ee]
 
 
+def job_wide_rng(epoch, seed=4):
+    """The scheduled-sampling coins of one call of train_full_supervised, identical on every rank: a RandomState seeded by (seed, epoch) with NO rank
+    offset.  The reference draws them from numpy's global generator in its single process; with one process per GPU every rank must throw the
+    same frames back onto the GT clip, or ranks disagree on which parameters got a gradient.  epoch -1 = the warm start."""
+    return np.random.RandomState((int(seed) * 1000003 + int(epoch) + 2) % (2 ** 31 - 1))
+
+
 def sampling_batches(dataset, num_samples, batch_size, device):
     """DatasetBatch.sampling_generator (statear_smpl_dataset.py:378-399): `num_samples` takes drawn with replacement from freq_indices (a take is
     listed once per fr_num frames of its length), a uniform window of fr_num frames each, served in shuffled batches of `batch_size`."""

@@ -67,7 +67,10 @@ class LoggerRL:
     agent_ar.py:243-262), for a lock-step sampler: built once per sample() call from the device buffers (`episode_log`), merged over ranks
     with `merge` (LoggerRL.merge :51-70).  An episode that straddles two sample() calls is counted in the call it ends in, with its whole return.
 
-    Deviation kept out on purpose: the reference's merge takes `min_episode_reward = max(...)` over the workers (:60, a typo); `merge` here takes the min."""
+    `merge` reproduces the reference as it is: `min_episode_reward = max(...)` over the workers (logger_rl.py:60 -- a typo there, but "results identical
+    to the reference's" is the bar); `LoggerRL.REFERENCE_BUGS = False` (or `merge(..., reference_bugs=False)`) takes the min."""
+
+    REFERENCE_BUGS = True
 
     FIELDS = ("num_steps", "num_episodes", "total_reward", "min_episode_reward", "max_episode_reward", "total_c_reward", "min_c_reward", "max_c_reward")
 
@@ -92,12 +95,13 @@ class LoggerRL:
         self.avg_episode_c_info = self.total_c_info / ne
 
     @classmethod
-    def merge(cls, loggers):
+    def merge(cls, loggers, reference_bugs=None):
         loggers = list(loggers)
+        min_of_mins = max if (cls.REFERENCE_BUGS if reference_bugs is None else reference_bugs) else min
         out = cls(num_steps=sum(x.num_steps for x in loggers), num_episodes=sum(x.num_episodes for x in loggers),
                   total_reward=sum(x.total_reward for x in loggers), total_c_reward=sum(x.total_c_reward for x in loggers),
                   total_c_info=sum(x.total_c_info for x in loggers),
-                  min_episode_reward=min(x.min_episode_reward for x in loggers), max_episode_reward=max(x.max_episode_reward for x in loggers),
+                  min_episode_reward=min_of_mins(x.min_episode_reward for x in loggers), max_episode_reward=max(x.max_episode_reward for x in loggers),
                   min_c_reward=min(x.min_c_reward for x in loggers), max_c_reward=max(x.max_c_reward for x in loggers))
         out.sample_time = max(x.sample_time for x in loggers)
         return out
@@ -427,26 +431,61 @@ def normalize_advantages_global(adv: torch.Tensor, ret: torch.Tensor, group=None
     return (adv - all_adv.mean()) / all_adv.std(), ret, all_ret
 
 
+def gae_scan(rewards, masks, values, gamma, tau, last_values=None):
+    """estimate_advantages' recurrence (common.py:11-19) as a reverse scan over the time axis of env-major [N, T] tensors, in the tensors' own
+    dtype: the fp64 update (`update_dtype=torch.float64`) and CPU tensors go through this; fp32 device tensors through k_gae.  The reference
+    scans one flat batch whose workers' rows end on `masks == 0`; an env's row here may be cut by the horizon, then `last_values` [N] = V of
+    the state after the last row enters as the value behind it (kp_gae_bootstrap's rule)."""
+    N, T = rewards.shape
+    adv = torch.empty_like(values)
+    prev_v = torch.zeros(N, dtype=values.dtype, device=values.device) if last_values is None else last_values.to(values.dtype)
+    prev_a = torch.zeros(N, dtype=values.dtype, device=values.device)
+    for t in range(T - 1, -1, -1):
+        delta = rewards[:, t] + gamma * prev_v * masks[:, t] - values[:, t]
+        prev_a = delta + gamma * tau * prev_a * masks[:, t]
+        adv[:, t] = prev_a
+        prev_v = values[:, t]
+    return adv, values + adv
+
+
 def estimate_advantages(rewards, masks, values, gamma, tau, group=None, last_values=None):
-    """GAE on the device (k_gae, env-major reverse scan) + the global normalisation above."""
-    adv, ret = kpsim.gae(rewards.contiguous(), masks.contiguous(), values.contiguous(), gamma, tau,
-                         None if last_values is None else last_values.contiguous())
+    """GAE on the device (k_gae, env-major reverse scan; `gae_scan` for fp64 / CPU tensors) + the global normalisation above."""
+    if values.is_cuda and values.dtype == torch.float32:
+        adv, ret = kpsim.gae(rewards.contiguous(), masks.contiguous(), values.contiguous(), gamma, tau,
+                             None if last_values is None else last_values.contiguous())
+    else:
+        adv, ret = gae_scan(rewards.to(values.dtype), masks.to(values.dtype), values, gamma, tau, last_values)
     adv, ret, _ = normalize_advantages_global(adv, ret, group)
     return adv, ret
 
 
 def _allreduce_grads(params, group=None):
+    """Mean of the ranks' gradients over a FIXED parameter list: every rank sends one flat buffer of the same length whatever its own backward
+    reached (a parameter without a gradient on this rank -- scheduled sampling threw the context network's output away here but not there --
+    contributes zeros), plus one flag per parameter, so that a parameter NO rank has a gradient for keeps `grad = None` and its optimiser state
+    untouched, exactly as in a single process (ranks with different None sets used to call all_reduce with different lengths)."""
     if not _collective_on(group):
         return
-    grads = [p.grad for p in params if p.grad is not None]
-    if not grads:
+    params = [p for p in params if p.requires_grad]
+    if not params:
         return
-    flat = torch.cat([g.reshape(-1) for g in grads])
+    ref = params[0]
+    flat = torch.cat([(p.grad.reshape(-1) if p.grad is not None else torch.zeros(p.numel(), dtype=p.dtype, device=p.device)).to(ref.dtype) for p in params]
+                     + [torch.tensor([0.0 if p.grad is None else 1.0 for p in params], dtype=ref.dtype, device=ref.device)])
     dist.all_reduce(flat, group=group)
-    flat /= dist.get_world_size(group)
+    n_flags = len(params)
+    have = (flat[-n_flags:] > 0).tolist()
+    flat = flat[:-n_flags] / dist.get_world_size(group)
     off = 0
-    for g in grads:
-        g.copy_(flat[off:off + g.numel()].view_as(g)); off += g.numel()
+    for p, h in zip(params, have):
+        n = p.numel()
+        if h:
+            g = flat[off:off + n].view_as(p).to(p.dtype)
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
+        off += n
 
 
 def ppo_surrogate(log_probs, fixed_log_probs, advantages, clip_epsilon=0.2, ind=None):
@@ -476,8 +515,17 @@ class PPOTrainer:
 
     def __init__(self, policy: KinPolicy, value: Value, gamma=0.95, tau=0.95, clip_epsilon=0.2, policy_lr=1e-5, value_lr=3e-4,
                  num_optim_epoch=10, policy_grad_clip=40.0, group=None, num_epoch_fix=100, num_epoch=10000, value_opt_niter=1,
-                 cc_policy=None, policy_weightdecay=0.0, value_weightdecay=0.0, train_uhc=False):
+                 cc_policy=None, policy_weightdecay=0.0, value_weightdecay=0.0, train_uhc=False, reference_bugs=True):
+        """policy / value: the modules the optimisers own.  Their dtype is the update's dtype: fp32 modules on the device run the fused HIP re-unroll
+        and k_gae; fp64 modules (the reference trains in fp64, scripts/train_ar_policy.py:76-77) run the same update through the GRUCell loop and
+        `gae_scan` -- `AgentAR(update_dtype=torch.float64)` keeps such fp64 master copies and writes them back into the fp32 roll-out modules.
+
+        reference_bugs (default True: results identical to the reference's): the gradient clip acts on the FIRST optimiser step of a run only.
+        The reference hands `policy_grad_clip=[(self.policy_net.parameters(), 40)]` (agent_ar.py:92-93) -- a generator -- to
+        clip_policy_grad (agent_ppo.py:53-56); the first clip_grad_norm_ consumes it, every later call sees no parameters and returns 0
+        (tests/golden/update_params.npz holds the norms the reference's calls reported: 45.99, 0, 0, ...).  False clips every step."""
         self.policy, self.value, self.group, self.cc_policy = policy, value, group, cc_policy
+        self.reference_bugs, self._clip_calls, self.clip_norms = bool(reference_bugs), 0, []
         self.gamma, self.tau, self.clip_epsilon, self.num_optim_epoch, self.policy_grad_clip = gamma, tau, clip_epsilon, num_optim_epoch, policy_grad_clip
         self.value_opt_niter = value_opt_niter
         self.opt_p = torch.optim.Adam([p for p in policy.parameters() if p.requires_grad], lr=policy_lr, weight_decay=policy_weightdecay)
@@ -501,21 +549,34 @@ class PPOTrainer:
     def _clip(self, opt=None):
         params = [p for g in (opt or self.opt_p).param_groups for p in g["params"]]
         _allreduce_grads(params, self.group)
-        torch.nn.utils.clip_grad_norm_(params, self.policy_grad_clip)
+        self._clip_calls += 1
+        if self.reference_bugs and self._clip_calls > 1:       # the reference's generator of parameters was consumed by the run's first call
+            return
+        norm = torch.nn.utils.clip_grad_norm_(params, self.policy_grad_clip)
+        if self._clip_calls == 1:
+            self.clip_norms.append(norm.detach())              # kept on the device (read by tests / the update fixture)
+
+    def _cast(self, t):
+        """batch tensors in the update's dtype (the roll-out records fp32; an fp64 update reads them as fp64 like the reference's `.to(self.dtype)`, agent_ar.py:685-695)"""
+        dt = next(self.policy.parameters()).dtype
+        return None if t is None else (t if t.dtype == dt or not t.dtype.is_floating_point else t.to(dt))
 
     def _value_epochs(self, flat_states, ret, n_steps):
         """the value net's regression steps of all epochs: `update_value` (agent_ppo.py:53-56) x n_steps.  They share nothing with the policy
         passes (fixed targets `ret`, own optimiser)."""
         vloss = None
+        self.vloss_history = []
         for _ in range(n_steps):
             vloss = (self.value(flat_states) - ret).pow(2).mean()
+            self.vloss_history.append(vloss.detach())
             self.opt_v.zero_grad(); vloss.backward(); _allreduce_grads(list(self.value.parameters()), self.group); self.opt_v.step()
         return vloss
 
     def update(self, batch: RolloutBatch, bootstrap: bool = True):
         N, T, _ = batch.states.shape
-        flat_states = batch.states.reshape(N * T, -1)
-        flat_actions = batch.actions.reshape(N * T, -1)
+        states, hx0 = self._cast(batch.states), self._cast(batch.hx0)
+        flat_states = states.reshape(N * T, -1)
+        flat_actions = self._cast(batch.actions).reshape(N * T, -1)
         ind = None
         if batch.exps is not None:                # `ind = exps.nonzero()` (agent_ar.py:763): the rows the surrogate is taken over
             ind = batch.exps.reshape(-1).nonzero(as_tuple=False).squeeze(1)
@@ -523,9 +584,10 @@ class PPOTrainer:
                 ind = None
         with torch.no_grad():
             values = self.value(flat_states).view(N, T)
-            last_v = self.value(batch.last_states).view(N) if (bootstrap and batch.last_states is not None) else None
-        adv, ret = estimate_advantages(batch.rewards, batch.masks, values, self.gamma, self.tau, self.group, last_v)
+            last_v = self.value(self._cast(batch.last_states)).view(N) if (bootstrap and batch.last_states is not None) else None
+        adv, ret = estimate_advantages(self._cast(batch.rewards), self._cast(batch.masks), values, self.gamma, self.tau, self.group, last_v)
         adv, ret = adv.reshape(-1, 1), ret.reshape(-1, 1)
+        self.last_adv, self.last_ret = adv, ret
         # the value net's steps of all epochs first: they share nothing with the policy passes (fixed targets, own optimiser).  Running them on a
         # side stream underneath the policy epochs was tried in round 4 (at most 15 of 850 ms to gain) and DEADLOCKED in the second or third
         # iteration on ROCm 7.2 / torch 2.10 (two autograd backward passes in flight on two streams; tools/micro/dbg_train_hang.py,
@@ -534,12 +596,14 @@ class PPOTrainer:
         # fixed_log_probs (agent_ar.py:758-759) is the policy's forward at the parameters the update starts from: epoch 0's own forward, reused
         # (the reference evaluates it twice; one of its 11 policy forwards is redundant), so epoch 0's ratio is exactly 1 as it is there
         fixed_log_probs, surr = None, None
+        self.surr_history = []                     # every epoch's surrogate, on the device (one host read at the end)
         for _ in range(self.num_optim_epoch):
-            means = self.policy.unroll(batch.states, batch.episode_start, batch.hx0)
+            means = self.policy.unroll(states, batch.episode_start, hx0)
             log_probs = self.policy.log_prob(means.reshape(N * T, -1), flat_actions)
             if fixed_log_probs is None:
                 fixed_log_probs = log_probs.detach()
             surr = ppo_surrogate(log_probs, fixed_log_probs, adv, self.clip_epsilon, ind)
+            self.surr_history.append(surr.detach())
             self.opt_p.zero_grad(); surr.backward()
             self._clip()
             self.opt_p.step()
@@ -556,8 +620,9 @@ class PPOTrainer:
         from .supervised import compute_loss_lite, kinematic_step
         assert batch.curr_qpos is not None and batch.gt_target_qpos is not None, "sample with record_qpos=True"
         N, T, _ = batch.states.shape
-        flat_states = batch.states.reshape(N * T, -1)
-        curr, tgt = batch.curr_qpos.reshape(N * T, 76), batch.gt_target_qpos.reshape(N * T, 76)
+        states, hx0, actions = self._cast(batch.states), self._cast(batch.hx0), self._cast(batch.actions)
+        flat_states = states.reshape(N * T, -1)
+        curr, tgt = self._cast(batch.curr_qpos).reshape(N * T, 76), self._cast(batch.gt_target_qpos).reshape(N * T, 76)
         ind = None
         if batch.exps is not None:                # `ind = exps.nonzero()` (agent_ar.py:813): the rows the surrogate is taken over
             ind = batch.exps.reshape(-1).nonzero(as_tuple=False).squeeze(1)
@@ -565,16 +630,16 @@ class PPOTrainer:
                 ind = None
         with torch.no_grad():
             values = self.value(flat_states).view(N, T)
-            last_v = self.value(batch.last_states).view(N) if (bootstrap and batch.last_states is not None) else None
+            last_v = self.value(self._cast(batch.last_states)).view(N) if (bootstrap and batch.last_states is not None) else None
             tgt_wbpos = fk.wbpos(tgt)
-        adv, ret = estimate_advantages(batch.rewards, batch.masks, values, self.gamma, self.tau, self.group, last_v)
+        adv, ret = estimate_advantages(self._cast(batch.rewards), self._cast(batch.masks), values, self.gamma, self.tau, self.group, last_v)
         adv, ret = adv.reshape(-1, 1), ret.reshape(-1, 1)
         stats, fixed_log_probs = {}, None
         for _ in range(self.num_optim_epoch):
             vloss = (self.value(flat_states) - ret).pow(2).mean()
             self.opt_v.zero_grad(); vloss.backward(); _allreduce_grads(list(self.value.parameters()), self.group); self.opt_v.step()
-            means = self.policy.unroll(batch.states, batch.episode_start, batch.hx0).reshape(N * T, -1)
-            log_probs = self.policy.log_prob(means, batch.actions.reshape(N * T, -1))
+            means = self.policy.unroll(states, batch.episode_start, hx0).reshape(N * T, -1)
+            log_probs = self.policy.log_prob(means, actions.reshape(N * T, -1))
             if fixed_log_probs is None:            # the forward at the starting parameters is epoch 0's own (see update())
                 fixed_log_probs = log_probs.detach()
             surr = ppo_surrogate(log_probs, fixed_log_probs, adv, self.clip_epsilon, ind)
@@ -602,8 +667,10 @@ class PPOTrainer:
         gradients are None and the step changes nothing, so its num_optim_epoch passes all evaluate the same loss -- computed once here
         and reported.  (Under torch < 2.0 the same code takes ten zero-gradient Adam steps on policy_net, i.e. momentum drift; not
         reproduced.)  With `train_uhc` the epochs run on the UHC's own optimiser."""
-        cs, ca = batch.cc_state.reshape(-1, batch.cc_state.shape[-1]), batch.cc_action.reshape(-1, batch.cc_action.shape[-1])
         pol = self.cc_policy
+        dt = next(pol.parameters()).dtype
+        cs, ca = batch.cc_state.reshape(-1, batch.cc_state.shape[-1]).to(dt), batch.cc_action.reshape(-1, batch.cc_action.shape[-1]).to(dt)
+        adv = adv.to(dt)
 
         def logp(x, a):
             mean, log_std = pol.forward(x)

@@ -22,12 +22,13 @@ def _qmat(q):
 
 
 def _qrot(q, v):
-    """R(q / |q|) v without materialising the matrix (a [B,3,3] x [B,3,1] batched GEMM of 98 k tiny matrices costs over a
-    millisecond each way): v + 2 w (u x v) + 2 u x (u x v)."""
-    qn = q / q.norm(dim=-1, keepdim=True)
-    u = qn[..., 1:]
-    t2 = 2.0 * torch.cross(u, v, dim=-1)
-    return v + qn[..., :1] * t2 + torch.cross(u, t2, dim=-1)
+    """quat_mul_vec_batch (kin_poly/utils/torch_utils.py): v + 2 (w (u x v) + u x (u x v)) with q AS IT IS -- the reference does not normalise
+    here, so a root quaternion that is unit to 1e-7 only (the data set's are) rotates the angular velocity with that error; reproduced
+    (3.5e-7 on the fixture's poses, visible in fp64).  No matrix: a [B,3,3] x [B,3,1] batched GEMM of 98 k tiny matrices costs over a
+    millisecond each way."""
+    u = q[..., 1:]
+    uv = torch.cross(u, v, dim=-1)
+    return v + 2.0 * (q[..., :1] * uv + torch.cross(u, uv, dim=-1))
 
 
 def quat_from_expmap(e):
@@ -142,17 +143,23 @@ def compute_loss_lite(fk: TorchFK, pred_qpos, gt_qpos, w_rp=50.0, w_rr=50.0, w_p
     return loss, [r_pos.mean(), r_rot.mean(), p_rot.mean(), ee.mean()]
 
 
-def update_supervised_step(policy, optimizer, fk: TorchFK, batch, num_epoch=20, grad_allreduce=None, target=None):
+def update_supervised_step(policy, optimizer, fk: TorchFK, batch, num_epoch=20, grad_allreduce=None, target=None, history=None):
     """batch: RolloutBatch with curr_qpos / gt_target_qpos recorded by VectorSampler(record_qpos=True).  target: another [N, T, 76] pose to regress
-    the kinematic step onto -- `batch.res_qpos`, the pose the simulation reached, makes this PolicyAR.update_supervised_dyna (policy_ar.py:289-301)."""
+    the kinematic step onto -- `batch.res_qpos`, the pose the simulation reached, makes this PolicyAR.update_supervised_dyna (policy_ar.py:289-301).
+    The update runs in the policy's dtype (fp64 master copies: the batch is read as fp64, `fk` must be an fp64 TorchFK).  history: a list that
+    receives every epoch's loss (device scalars)."""
     N, T, _ = batch.states.shape
-    curr, tgt = batch.curr_qpos.reshape(N * T, 76), (batch.gt_target_qpos if target is None else target).reshape(N * T, 76)
+    dt = next(policy.parameters()).dtype
+    states, hx0 = batch.states.to(dt), (None if batch.hx0 is None else batch.hx0.to(dt))
+    curr, tgt = batch.curr_qpos.to(dt).reshape(N * T, 76), (batch.gt_target_qpos if target is None else target).to(dt).reshape(N * T, 76)
     loss_val = None
     with torch.no_grad():
         tgt_wbpos = fk.wbpos(tgt)              # the GT side of the end-effector term does not change between epochs
     for _ in range(num_epoch):
-        means = policy.unroll(batch.states, batch.episode_start, batch.hx0).reshape(N * T, -1)
+        means = policy.unroll(states, batch.episode_start, hx0).reshape(N * T, -1)
         loss, _ = compute_loss_lite(fk, kinematic_step(curr, means), tgt, gt_wbpos=tgt_wbpos)
+        if history is not None:
+            history.append(loss.detach())
         optimizer.zero_grad()
         loss.backward()
         if grad_allreduce is not None:

@@ -470,6 +470,149 @@ def gen_metrics():
              accels_abs=M.get_mean_abs(M.get_joint_accels(vp, dt)))
 
 
+def gen_update_params(hum):
+    """AgentAR.optimize_policy's update half, run by the reference itself (kin_poly/core/agent_ar.py:264-269 per_epoch_update, :682-752 update_params,
+    :756-772 update_policy, :852-870 ppo_loss / update_value; uhc/khrylib/rl/agents/agent_ppo.py:53-56 clip_policy_grad;
+    kin_poly/models/policy_ar.py:72-89 optimiser + step_lr, :104-122 initialize_rnn, :216-240 forward(train), :277-287 update_supervised_step;
+    uhc/khrylib/rl/core/common.py:5-25 estimate_advantages) for TWO consecutive iterations in fp64 on a recorded batch, with kin_poly.yml's
+    update switches and rates (rl_update + step_update, 10 PPO epochs, 20 step updates, policy_lr 1e-5, value_lr 3e-4, lr 5e-4, clip 40, eps 0.2).
+
+    A real PolicyAR (two TrajARNets, its own Adam + LambdaLR) and Value are built; AgentAR is built by __new__ with exactly the attributes
+    update_params reads (its __init__ needs the data set and MuJoCo).  The LambdaLR horizon is shortened (num_epoch_fix 0, num_epoch 4) so
+    that two iterations see the decay.  The fixture holds the batch, the seeds of the weights, and -- per iteration -- the advantages / returns,
+    every epoch's surrogate, value loss and step loss, the gradient norms clip_grad_norm_ reported (the generator-consumed clip: only the
+    very first call sees parameters), the learning rates, and a handful of parameter tensors after each iteration."""
+    import kin_poly.models.traj_ar_smpl_net as tn
+    import kin_poly.models.policy_ar as par
+    import kin_poly.core.agent_ar as aar
+    import kin_poly.utils.torch_smpl_humanoid as tsh
+    tsh.load_model_from_path = lambda f: fake_mj_model()
+    policy_specs = dict(policy_v=1, log_std=-3.2, fix_std=True, gamma=0.95, tau=0.95, policy_lr=1e-5, value_lr=3e-4, clip_epsilon=0.2,
+                        rl_update=True, init_update=False, step_update=True, full_update=False, num_step_update=20, num_optim_epoch=10)
+    cfg = types.SimpleNamespace(model_specs=dict(model_v=1, rnn_hdim=1024, mlp_hsize=[1024, 512, 256], mlp_htype="relu", rnn_type="gru",
+                                                 w_rp=50.0, w_rr=50.0, w_p=1.0, w_v=1.0, w_ee=10.0, w_op=1.0, w_or=10.0),
+                                policy_specs=policy_specs, mujoco_model_file="unused.xml", use_of=False, use_head=True, use_action=True, use_vel=False,
+                                use_context=False, add_noise=False, noise_std=0.01, has_z=True, data_dir=os.path.join(REF, "sample_data"),
+                                lr=5e-4, num_epoch_fix=0, num_epoch=4, smooth=True, model_dir="unused", joint_controller=False)
+    cfg.get = lambda k, dflt=None: getattr(cfg, k, dflt)
+    rng = np.random.default_rng(306)
+    Bd, Td = 2, 4
+    data = dict(qpos=np.stack([[rand_qpos(rng, 0.15) for _ in range(Td)] for _ in range(Bd)]), qvel=rng.normal(size=(Bd, Td, 75)) * 0.1,
+                target=rng.normal(size=(Bd, Td, 80)) * 0.1,
+                head_pose=np.concatenate([rng.normal(size=(Bd, Td, 3)), np.stack([[rand_quat(rng) for _ in range(Td)] for _ in range(Bd)])], 2),
+                head_vels=rng.normal(size=(Bd, Td, 6)) * 0.3, obj_head_relative_poses=rng.normal(size=(Bd, Td, 7)) * 0.3,
+                obj_pose=np.tile(np.array([0.3, 0.2, 0.1, 1.0, 0, 0, 0]), (Bd, Td, 1)), action_one_hot=np.tile(np.array([0, 0, 1.0, 0]), (Bd, Td, 1)))
+    data_t = {k: torch.tensor(v) for k, v in data.items()}
+    dev, dt = torch.device("cpu"), torch.float64
+    pol = par.PolicyAR(cfg, data_t, dev, dt, mode="train")
+    sd = seeded_state_dict(pol.traj_ar_net, 29)
+    for k in sd:
+        if k.startswith(("action_fc", "context_fc")):
+            sd[k] = sd[k] * 0.05
+    pol.traj_ar_net.load_state_dict(sd)
+    from uhc.khrylib.rl.core.critic import Value as RefValue
+    val = RefValue(MLP(pol.state_dim, [512, 256], "relu"))
+    val.load_state_dict(seeded_state_dict(val, 30))
+
+    ag = aar.AgentAR.__new__(aar.AgentAR)
+    ag.cfg, ag.dtype, ag.device, ag.policy_net, ag.value_net = cfg, dt, dev, pol, val
+    ag.update_modules = [pol, val]
+    ag.gamma, ag.tau, ag.clip_epsilon, ag.opt_num_epochs, ag.value_opt_niter = 0.95, 0.95, 0.2, 10, 1
+    ag.optimizer_policy = torch.optim.Adam(pol.parameters(), lr=policy_specs["policy_lr"], weight_decay=0.0)            # setup_optimizer :184-199
+    ag.optimizer_value = torch.optim.Adam(val.parameters(), lr=policy_specs["value_lr"], weight_decay=0.0)
+    from kin_poly.utils.torch_ext import get_scheduler
+    ag.scheduler_policy = get_scheduler(ag.optimizer_policy, policy="lambda", nepoch_fix=cfg.num_epoch_fix, nepoch=cfg.num_epoch)
+    ag.scheduler_value = get_scheduler(ag.optimizer_value, policy="lambda", nepoch_fix=cfg.num_epoch_fix, nepoch=cfg.num_epoch)
+    ag.policy_grad_clip = [(pol.parameters(), 40)]                                                                      # :92-93: a generator
+    ag.epoch = 0
+
+    # the recorded batch: 8 workers' rows back to back, 12 rows each, every worker's rows made of whole episodes (masks == 0 on their last rows)
+    N, T = 8, 12
+    ep_lens = [[12], [5, 7], [3, 4, 5], [12], [1, 11], [6, 6], [2, 2, 8], [9, 3]]
+    B = N * T
+    masks = np.ones(B)
+    off = 0
+    for lens in ep_lens:
+        assert sum(lens) == T
+        for L in lens:
+            off += L
+            masks[off - 1] = 0
+    out = dict(seed_policy=29, seed_value=30, N=N, T=T, masks=masks, policy_lr=1e-5, value_lr=3e-4, sup_lr=5e-4, num_epoch_fix=0, num_epoch=4,
+               keys=np.array(list(pol.traj_ar_net.state_dict().keys())),
+               shapes=np.array([list(v.shape) + [0] * (2 - v.dim()) for v in pol.traj_ar_net.state_dict().values()]),
+               value_keys=np.array(list(val.state_dict().keys())),
+               value_shapes=np.array([list(v.shape) + [0] * (2 - v.dim()) for v in val.state_dict().values()]),
+               state_dim=pol.state_dim, context_dim=pol.traj_ar_net.context_dim)
+    watch_p = ("action_fc.bias", "action_mlp.affine_layers.2.bias", "action_rnn.rnn_f.bias_hh", "action_fc.weight")
+    watch_v = ("value_head.weight", "net.affine_layers.1.bias")
+    params_p, params_v = dict(pol.traj_ar_net.named_parameters()), dict(val.named_parameters())
+
+    rec = {}
+    orig_ppo, orig_uv, orig_lite, orig_clip, orig_est = aar.AgentAR.ppo_loss, aar.AgentAR.update_value, pol.traj_ar_net.compute_loss_lite, torch.nn.utils.clip_grad_norm_, aar.estimate_advantages
+
+    def ppo_loss(self, log_probs, advantages, fixed_log_probs, ind):
+        loss, ratio = orig_ppo(self, log_probs, advantages, fixed_log_probs, ind)
+        rec["surr"].append(float(loss)); rec["ratio_mean"].append(float(ratio.mean()))
+        return loss, ratio
+
+    def update_value(self, states, returns):
+        with torch.no_grad():
+            rec["vloss"].append(float((self.value_net(states) - returns).pow(2).mean()))
+        return orig_uv(self, states, returns)
+
+    def lite(pred, gt, return_mean=True):
+        loss, idv = orig_lite(pred, gt, return_mean)
+        rec["step"].append(float(loss))
+        return loss, idv
+
+    def clip(params, max_norm, *a, **k):
+        r = orig_clip(params, max_norm, *a, **k)
+        rec["clip_norm"].append(float(r))
+        return r
+
+    def est(rewards, masks_, values, gamma, tau):
+        adv, ret = orig_est(rewards, masks_, values, gamma, tau)
+        rec["adv"], rec["ret"] = adv.numpy().copy(), ret.numpy().copy()
+        return adv, ret
+
+    aar.AgentAR.ppo_loss, aar.AgentAR.update_value, pol.traj_ar_net.compute_loss_lite, aar.estimate_advantages = ppo_loss, update_value, lite, est
+    torch.nn.utils.clip_grad_norm_ = clip
+    try:
+        for it in range(2):
+            states = rng.normal(size=(B, pol.state_dim)) * 0.5
+            # actions: the behaviour policy's own samples at the parameters this iteration starts from (epoch 0's ratio is then 1)
+            pol.set_mode("train")
+            pol.initialize_rnn((torch.tensor(masks), torch.zeros((B, 3))))
+            with torch.no_grad():
+                _, mean0, _ = pol.forward(torch.tensor(states))
+            actions = mean0.numpy() + np.exp(-3.2) * rng.normal(size=(B, 80))
+            curr = np.stack([rand_qpos(rng, 0.2) for _ in range(B)])
+            gt = curr.copy(); gt[:, :3] += rng.normal(size=(B, 3)) * 0.02; gt[:, 7:] += rng.normal(size=(B, 69)) * 0.05
+            gt[:, 3:7] = np.stack([quaternion_multiply(q, quat_from_expmap(rng.normal(size=3) * 0.05)) for q in curr[:, 3:7]])
+            batch = types.SimpleNamespace(states=states, actions=actions, rewards=rng.uniform(0.2, 0.9, size=B), masks=masks.copy(), exps=np.ones(B),
+                                          v_metas=np.zeros((B, 3)), gt_target_qpos=gt, curr_qpos=curr, res_qpos=curr.copy(),
+                                          cc_action=np.zeros((B, 75)), cc_state=np.zeros((B, 4)))
+            rec.update(surr=[], ratio_mean=[], vloss=[], step=[], clip_norm=[])
+            ag.epoch = it
+            ag.per_epoch_update(it)                                      # optimize_policy :264-269: the schedulers step BEFORE the iteration's update
+            lr_p, lr_v, lr_s = ag.optimizer_policy.param_groups[0]["lr"], ag.optimizer_value.param_groups[0]["lr"], pol.optimizer.param_groups[0]["lr"]
+            ag.update_params(batch)
+            tag = f"it{it}_"
+            out.update({tag + "states": states, tag + "actions": actions, tag + "rewards": batch.rewards, tag + "curr_qpos": curr, tag + "gt_target_qpos": gt,
+                        tag + "mean0": mean0.numpy(), tag + "adv": rec["adv"], tag + "ret": rec["ret"], tag + "surr": np.array(rec["surr"]),
+                        tag + "ratio_mean": np.array(rec["ratio_mean"]), tag + "vloss": np.array(rec["vloss"]), tag + "step": np.array(rec["step"]),
+                        tag + "clip_norm": np.array(rec["clip_norm"]), tag + "lr": np.array([lr_p, lr_v, lr_s])})
+            for w in watch_p:
+                out[tag + "p:" + w] = params_p[w].detach().numpy().copy()
+            for w in watch_v:
+                out[tag + "v:" + w] = params_v[w].detach().numpy().copy()
+    finally:
+        aar.AgentAR.ppo_loss, aar.AgentAR.update_value, pol.traj_ar_net.compute_loss_lite, aar.estimate_advantages = orig_ppo, orig_uv, orig_lite, orig_est
+        torch.nn.utils.clip_grad_norm_ = orig_clip
+    np.savez(os.path.join(OUT, "update_params.npz"), **out)
+    print("update_params: clip norms it0", out["it0_clip_norm"][:3], "... it1", out["it1_clip_norm"][:3], "surr it0", out["it0_surr"], "lr", out["it0_lr"], out["it1_lr"])
+
+
 def gen_loss_and_checkpoint(hum):
     """TrajARNet.step + compute_loss_lite (traj_ar_smpl_net.py:292-330, 459-497) on seeded poses, and a small pickle in
     the reference's checkpoint layout written with the reference's own ZFilter class (agent_ar.py:341-364)."""
@@ -661,6 +804,7 @@ if __name__ == "__main__" and os.environ.get("KP_GOLDEN_ONLY") is None:
     gen_policies()
     gen_traj_ar_net(hum)
     gen_pretrain(hum)
+    gen_update_params(hum)
     gen_metrics()
     gen_loss_and_checkpoint(hum)
     gen_ppo_loss()
@@ -683,3 +827,8 @@ if __name__ == "__main__" and os.environ.get("KP_GOLDEN_ONLY") == "pretrain":
 if __name__ == "__main__" and os.environ.get("KP_GOLDEN_ONLY") == "traj":
     gen_traj_ar_net(make_humanoid())
     print("traj_ar_net.npz", os.path.getsize(os.path.join(OUT, "traj_ar_net.npz")))
+
+
+if __name__ == "__main__" and os.environ.get("KP_GOLDEN_ONLY") == "update":
+    gen_update_params(make_humanoid())
+    print("update_params.npz", os.path.getsize(os.path.join(OUT, "update_params.npz")))
