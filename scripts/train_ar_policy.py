@@ -51,6 +51,14 @@ def main():
     ap.add_argument("--cc_ckpt", type=str, default="", help="trained UHC checkpoint in the reference's layout (scripts/train_uhc.py --save); with --cfg the default is "
                     "results/motion_im/<cc_cfg>/models/iter_<cc_iter>.p as in the reference")
     ap.add_argument("--wild", action="store_true")
+    ap.add_argument("--update_dtype", choices=("fp32", "fp64"), default="fp32", help="fp64: the reference's training precision (train_ar_policy.py:76-77) on fp64 master copies of the "
+                    "policy / value nets (GRUCell loop + torch FK instead of the fused HIP re-unroll); the roll-out stays fp32")
+    ap.add_argument("--no_reference_bugs", action="store_true", help="corrected forms instead of the reference's behaviour: gradient clip at every PPO step (the reference's "
+                    "generator-consumed clip acts on a run's first step only), LambdaLR continued on --iter N (the reference restarts its decay), min of the workers' min_episode_reward")
+    ap.add_argument("--rl_update", type=int, default=1, help="without --cfg: policy_specs.rl_update (PPO epochs)"); ap.add_argument("--step_update", type=int, default=1, help="without --cfg: policy_specs.step_update")
+    ap.add_argument("--load", type=str, default="", help="start from this checkpoint (reference layout) instead of seeded random init; schedules and optimiser state start fresh")
+    ap.add_argument("--min_horizon", type=int, default=0, help="with --cfg: lower bound of the per-env horizon derived from min_batch_size (0 = fr_num / 4; ADVICE r4: 10000 / 4096 envs "
+                    "would be 3-step fragments that hang on the V bootstrap)")
     ap.add_argument("--no_log", action="store_true")
     ap.add_argument("--test_data", type=str, nargs="*", default=[], help="feature files of the test sets evaluated every save_model_interval iterations")
     ap.add_argument("--test_data_wild", type=str, nargs="*", default=[], help="the same for --wild test sets (evaluated on the ..._mesh_all.xml engine, agent_ar.py:305-314, 464)")
@@ -92,12 +100,19 @@ def main():
     cc_ckpt = args.cc_ckpt or (cfg.cc_checkpoint_path() if cfg is not None else None) or None
     if rank == 0 and cc_ckpt:
         print(f"loading model from checkpoint: {cc_ckpt}", flush=True)
+    upd_kw = dict(update_dtype=torch.float64 if args.update_dtype == "fp64" else None, reference_bugs=not args.no_reference_bugs)
     if cfg is None:
-        agent = AgentAR(args.num_envs, dataset=ds, device=local, horizon=args.horizon, num_optim_epoch=args.num_optim_epoch, cc_checkpoint=cc_ckpt, result_dir=args.result_dir or None,
-                        num_step_update=args.num_step_update, sampling_temp=0.3, sampling_freq=0.5, pool_depth=args.pool_depth, cache_init_context=args.cache_init_context)
+        agent = AgentAR(args.num_envs, dataset=ds, device=local, horizon=args.horizon, **upd_kw, num_optim_epoch=args.num_optim_epoch, cc_checkpoint=cc_ckpt, result_dir=args.result_dir or None,
+                        num_step_update=args.num_step_update, sampling_temp=0.3, sampling_freq=0.5, pool_depth=args.pool_depth, cache_init_context=args.cache_init_context,
+                        rl_update=bool(args.rl_update), step_update=bool(args.step_update))
         first, last, interval = 0, args.iters, 0
     else:
-        agent = AgentAR(args.num_envs, dataset=ds, device=local, horizon=cfg.horizon(args.num_envs, world), pool_depth=args.pool_depth,
+        # the reference collects min_batch_size steps of WHOLE episodes (~ fr_num frames each); a lock-step sampler with thousands of envs would meet
+        # that count with a handful of steps per env, so the horizon gets a floor (fr_num / 4 unless --min_horizon says otherwise)
+        horizon = cfg.horizon(args.num_envs, world, floor=args.min_horizon or max(1, int(cfg.fr_num) // 4))
+        if rank == 0:
+            print(f"horizon {horizon} steps per env = {horizon * args.num_envs * world} samples per iteration (min_batch_size {cfg.policy_specs.get('min_batch_size', 10000)})", flush=True)
+        agent = AgentAR(args.num_envs, dataset=ds, device=local, horizon=horizon, pool_depth=args.pool_depth, **upd_kw,
                         cache_init_context=args.cache_init_context, result_dir=cfg.result_dir, cc_checkpoint=cc_ckpt, **cfg.agent_kwargs())
         cfg.apply_reward_weights(agent.env)
         agent.test_datasets = ([D.StateARDataset(p, data_mode="test", fr_num=args.clip_len, wild=args.wild, seed=4, device=fk_sim.device) for p in args.test_data]
@@ -105,9 +120,13 @@ def main():
         if args.iter > 0:                              # AgentAR(checkpoint_epoch=args.iter) -> load_checkpoint (agent_ar.py:72-73, 318-339)
             agent.load_checkpoint(cfg.checkpoint_path(args.iter))
             agent.epoch = args.iter
-            for _ in range(args.iter):                 # the LambdaLR schedules are functions of the epoch
+            # the reference builds FRESH LambdaLR schedulers on resume (setup_optimizer runs before load_checkpoint and nothing restores them,
+            # agent_ar.py:60-73, 215-225): a resumed run restarts its learning-rate decay at epoch 0.  Reproduced; --no_reference_bugs continues it
+            for _ in range(args.iter if args.no_reference_bugs else 0):
                 agent.trainer.per_epoch_update(); agent.sched_sup.step()
         first, last, interval = args.iter, (args.iter + args.iters if args.iters else int(cfg.num_epoch)), int(cfg.policy_specs.get("save_model_interval", cfg.save_model_interval))
+    if args.load:
+        agent.load_checkpoint(args.load)
     log_file = open(os.path.join(cfg.log_dir, "log.txt"), "a") if (cfg is not None and rank == 0 and not args.no_log) else None
     if args.warm_start and first == 0:             # train_init (agent_ar.py:366-385), then save_checkpoint(0) -> iter_0001.p
         ps = cfg.policy_specs if cfg is not None else {}
@@ -131,7 +150,7 @@ def main():
             line = agent.log_train({**info, "log": log}, cfg_id=cfg.id if cfg else "synthetic", max_iter_num=int(cfg.policy_specs.get("max_iter_num", last)) if cfg else last)
             if log_file is not None:
                 log_file.write(line + "\n"); log_file.flush()
-            print(json.dumps({"iter": it, **{k: (round(v, 5) if isinstance(v, float) else v) for k, v in info.items()}, "log": log.as_dict()}), flush=True)
+            print(json.dumps({"iter": it, **{k: (float("%.6g" % v) if isinstance(v, float) else v) for k, v in info.items()}, "log": log.as_dict()}), flush=True)
     if args.save and rank == 0:
         agent.save_checkpoint(args.save)
     if world > 1:

@@ -136,7 +136,7 @@ policy_specs:
   reward_weights: {{w_hp: 0.15, w_hq: 0.15, w_p: 0.2, w_jp: 0.2, w_act_p: 0.2, w_act_v: 0.1, k_hp: 45, k_hq: 45, k_p: 50, k_jp: 50, k_act_p: 5, k_act_v: 0.005}}
 lr: 5.e-4
 num_epoch: 4
-num_epoch_fix: 100
+num_epoch_fix: 0
 save_model_interval: 2
 """
 
@@ -173,6 +173,14 @@ def test_reference_command_line_of_the_scripts(tmp_path):
     recs = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert [x["iter"] for x in recs] == [2, 3] and (base / "models_policy" / "iter_0004.p").exists()
     assert len((base / "log" / "log.txt").read_text().splitlines()) == 4
+    # the reference's resumed run builds fresh LambdaLR schedulers (agent_ar.py:215-225 run before load_checkpoint, nothing restores them): its decay
+    # restarts -- reproduced by default; --no_reference_bugs continues the schedule (num_epoch_fix 0, num_epoch 4: factor 1 - epoch / 5)
+    np.testing.assert_allclose([x["policy_lr"] for x in recs], [0.8e-5, 0.6e-5], rtol=1e-5)
+    r = run(os.path.join(ROOT, "scripts", "train_ar_policy.py"), "--cfg", "mini", "--config_root", str(root), "--num_envs", "64", "--iter", "2", "--iters", "1", "--no_reference_bugs", "--update_dtype", "fp64")
+    assert r.returncode == 0, r.stderr[-3000:]
+    recs = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    np.testing.assert_allclose([x["policy_lr"] for x in recs], [0.4e-5], rtol=1e-5)
+    assert len((base / "log" / "log.txt").read_text().splitlines()) == 5
     # evaluation of the test takes of the meta file with that checkpoint
     r = run(os.path.join(ROOT, "scripts", "eval_ar_policy.py"), "--cfg", "mini", "--config_root", str(root), "--iter", "4", "--num_seq", "3", "--data", "test")
     assert r.returncode == 0, r.stderr[-3000:]
