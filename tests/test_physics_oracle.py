@@ -9,6 +9,8 @@ from kinpoly_amd.model_compiler import DEFAULT_KPM, read_kpm
 from oracle import np_oracle as O
 from oracle.kpo import OracleSim
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 KPM = read_kpm(DEFAULT_KPM)
 STD = np.load(os.path.join(os.path.dirname(__file__), "golden", "standing_neutral.npz"))
 PARENT = KPM["body_parent"]; BODY_POS = KPM["body_pos"].reshape(24, 3); BODY_IPOS = KPM["body_ipos"].reshape(24, 3)
@@ -492,3 +494,81 @@ def test_known_answer_set0_constants_of_the_compiled_model():
         inert = kpm["obj_inertial"].reshape(-1, 13)[i]
         wt, wr = K.object_invweight(i)
         assert float(inert[10]) == pytest.approx(wt, rel=1e-9) and float(inert[11]) == pytest.approx(wr, rel=1e-9)
+
+
+# ---------------------------------------------------------------------------------------------- the dormant MuJoCo pin harness (tests/mujoco_pin.py)
+def test_mjcf_written_from_the_blob_is_the_reference_scene():
+    """mjcf_from_kpm: local-coordinate MJCF of the reference scene from the compiled blob (what a MuJoCo binding that no longer reads
+    coordinate="global" would be handed).  Checked structurally here; MuJoCo's own reading of it is the live pin."""
+    import xml.etree.ElementTree as ET
+    import mujoco_pin as MP
+    from kinpoly_amd.model_compiler import DEFAULT_KPM, read_kpm
+    from kinpoly_amd import sim as kpsim
+    kpm = read_kpm(DEFAULT_KPM)
+    root = ET.fromstring(MP.mjcf_from_kpm(kpm))
+    assert root.find("compiler").attrib.get("coordinate") is None and root.find("compiler").attrib["angle"] == "radian"
+    assert float(root.find("option").attrib["timestep"]) == float(kpm["opt"][0])
+    bodies = {}
+
+    def walk(el, origin):
+        for b in el.findall("body"):
+            p = origin + np.array([float(x) for x in b.attrib["pos"].split()])
+            bodies[b.attrib["name"]] = (p, b)
+            walk(b, p)
+    walk(root.find("worldbody"), np.zeros(3))
+    assert list(bodies) == MP.NAMES                                   # depth-first order = the blob's body order
+    got = np.stack([bodies[n][0] for n in MP.NAMES])
+    np.testing.assert_allclose(got, kpm["body_gpos0"].reshape(24, 3), atol=1e-12)      # local offsets add up to the XML's global positions
+    hinges = [j for n in MP.NAMES for j in bodies[n][1].findall("joint") if j.attrib["type"] == "hinge"]
+    assert len(hinges) == 69 and [j.attrib["axis"] for j in hinges[:3]] == ["0 0 1", "0 1 0", "1 0 0"]
+    np.testing.assert_allclose([[float(x) for x in j.attrib["range"].split()] for j in hinges], kpm["jnt_range"].reshape(-1, 2))
+    free = [j for j in bodies["Pelvis"][1].findall("joint")]
+    assert len(free) == 1 and free[0].attrib["type"] == "free" and free[0].attrib["armature"] == "0"
+    motors = root.find("actuator").findall("motor")
+    assert [m.attrib["joint"] for m in motors] == [j.attrib["name"] for j in hinges] and all(m.attrib["gear"] == "1" for m in motors)
+    meshes = root.find("asset").findall("mesh")
+    assert [len(m.attrib["vertex"].split()) // 3 for m in meshes] == list(np.diff(kpm["vert_adr"]))
+    floor = root.find("worldbody").find("geom")
+    assert floor.attrib["type"] == "plane" and floor.attrib["condim"] == "3" and floor.attrib["friction"].split()[0] in ("1.", "1", "1.0")
+    # free fall: contacts disabled by flag; with the free objects of ..._all_step.xml
+    assert 'contact="disable"' in MP.mjcf_from_kpm(kpm, contact=False)
+    k2 = read_kpm(kpsim.STEP_KPM)
+    r2 = ET.fromstring(MP.mjcf_from_kpm(k2, objects=True))
+    objs = [b for b in r2.find("worldbody").findall("body") if b.attrib["name"] != "Pelvis"]
+    assert len(objs) == int(k2["dims"][6]) == 5 and sum(len(b.findall("geom")) for b in objs) == int(k2["dims"][7])
+    assert all(b.find("joint").attrib["type"] == "free" for b in objs)
+    # the model comparison of the pin, fed with the blob's own arrays, reports zeros
+    same = MP.compare_model({k: kpm[k] for k in ("body_mass", "body_ipos", "body_inertia", "body_invweight0", "dof_invweight0")}, kpm)
+    assert max(same.values()) == 0.0
+
+
+def test_pin_harness_runs_end_to_end_with_the_oracle_in_mujocos_seat():
+    """The harness's stepping logic (do_simulation's loop around a backend's qM / qfrc_bias, the free-fall and contact protocols, the report)
+    exercised with OracleBackend where MuJoCo will sit: the Python control loop around the backend equals the C oracle's own do_simulation,
+    two oracle backends never part, and without a MuJoCo binding the report is None (bench.py prints "mujoco_pin": null)."""
+    import mujoco_pin as MP
+    from kinpoly_amd.model_compiler import DEFAULT_KPM, read_kpm
+    kpm = read_kpm(DEFAULT_KPM)
+    std = np.load(os.path.join(ROOT, "tests", "golden", "standing_neutral.npz"))
+    b = MP.OracleBackend()
+    b.set_state(std["qpos"], std["qvel"])
+    o = OracleSim()
+    o.reset(std["qpos"], std["qvel"])
+    rng = np.random.default_rng(5)
+    for t in range(3):
+        a = rng.normal(size=75) * 0.1
+        for _ in range(15):
+            MP.control_substep(b, a, std["qpos"], kpm)
+        o.do_simulation(a, std["qpos"], 15)
+        np.testing.assert_allclose(b.qpos(), o.get("qpos"), rtol=0, atol=1e-10)      # scipy's Cholesky vs the C oracle's: 1e-12
+    assert len(b.contacts()) > 0 and all(0 <= body < 24 for body, _ in b.contacts())
+    rep = MP.run_pin("contact", MP.OracleBackend(), {"oracle": MP.OracleBackend()}, kpm, std["qpos"], std["qvel"], n_steps=2,
+                     hip=lambda q, v, acts, tgt: np.tile(q, (len(acts), 1)))
+    assert rep["oracle"]["max_dqpos"] == 0.0 and rep["oracle"]["contact_set_diffs"] == 0 and rep["oracle"]["first_step_above_1e-3"] is None
+    assert rep["hip"]["max_dqpos"] > 0                                                 # the stand-in "product" (frozen pose) is seen to part
+    ff = MP.run_pin("free_fall", MP.OracleBackend(contact=False), {"oracle": MP.OracleBackend(contact=False)}, kpm, std["qpos"], std["qvel"], n_steps=20)
+    assert ff["oracle"]["max_dqpos"] == 0.0
+    q, v = MP.free_fall_state(std["qpos"])
+    assert q[2] > 10 and abs(np.linalg.norm(q[3:7]) - 1) < 1e-6 and np.abs(q[7:]).max() <= np.pi
+    if MP.find_mujoco() is None:
+        assert MP.pin_report() is None
