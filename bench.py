@@ -48,7 +48,7 @@ TRAIN_HORIZON = 24                  # env-steps per env and iteration of the tra
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8.0 TB/s spec
 VALU_FP32_PEAK_TFLOPS = 157.3       # 256 CUs x 4 SIMDs x 64 lanes x 2 (FMA) x 2.4 GHz (vector fp32; MI355X spec sheet)
 MFMA_FP32_PEAK_TFLOPS = 157.3       # dense fp32 matrix peak (spec sheet): the policy / value GEMMs run in fp32
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r04")
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r05")
 
 
 def build_engine(device_index, seed, threads, workload="tracked", n_envs=None):
@@ -150,6 +150,10 @@ def parity_summary(workload):
     if not os.path.exists(path):
         return None
     lines = open(path).read().splitlines()
+    from kinpoly_amd.build import kernel_source_sha256
+    stamp = [ln.split()[1] for ln in lines if ln.startswith("kernel_source_sha256 ") and len(ln.split()) > 1]
+    if not stamp or stamp[0] != kernel_source_sha256():          # a log of another kernel does not ride on this record (parity_live is this run's own)
+        return {"stale": True, "source": os.path.relpath(path, ROOT), "kernel_source_sha256_of_the_log": stamp[0] if stamp else None}
     for i, ln in enumerate(lines):
         if ln.startswith(f"bench:{workload}:") and i + 1 < len(lines):
             m = re.search(r"differ between the two sides at the same state: (\d+) of (\d+)", lines[i + 1])
@@ -163,6 +167,44 @@ def parity_summary(workload):
                                 "MuJoCo's own contact rules (dist == margin, level hull vertices), where per-step agreement to 1e-3 rad does not hold on either side",
                         "source": os.path.relpath(path, ROOT)}
     return None
+
+
+def parity_live(env, sampler, workload, a_track, n=256):
+    """One-substep parity measured IN THIS RUN on the engine that was just timed: one more env-step is taken (its UHC action and target recorded), `n`
+    envs' states after it are handed to tools/substep_parity.run, which restarts the HIP kernel and the fp64 oracle from a common fp32-rounded state at
+    each of the 15 substeps of a control step and, where their contact sets differ (a knife edge of MuJoCo's contact rules), follows both sides to the
+    end of the control step.  The oracle is the checker here, as in cpu_baseline; nothing of it is on the timed path."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import substep_parity
+    keep, orig = {}, env.step
+
+    def recording_step(*a, **k):
+        out = orig(*a, **k); keep["info"] = out[3]; return out
+    env.step = recording_step
+    try:
+        rollout_steps(sampler, 1, a_track, False, workload == "objects")
+    finally:
+        env.step = orig
+    t0 = time.perf_counter()
+    S = substep_parity.states_from_engine(env, keep["info"]["cc_action"], n, workload == "objects")
+    R = substep_parity.run("bench:" + workload, states=S, nsub=15)
+    out = substep_parity.summary(R)
+    out.update(envs=n, seconds=time.perf_counter() - t0,
+               note="measured in this run: HIP kernel vs fp64 oracle, one substep at a time from common states of this engine after the timed region; flip_* = both sides "
+                    "followed free-running for the rest of the control step from a substep whose contact sets differed")
+    return out
+
+
+def mujoco_pin_report():
+    """null until a MuJoCo binding is importable on the box; then the live pin of tests/mujoco_pin.py (model arrays, free fall, contact workload)"""
+    try:
+        sys.path.insert(1, os.path.join(ROOT, "tests"))
+        import mujoco_pin
+        if mujoco_pin.find_mujoco() is None:
+            return None
+        return mujoco_pin.pin_report(n_free_fall=300, n_contact=30)
+    except Exception as ex:
+        return {"error": f"{type(ex).__name__}: {ex}"[:200]}
 
 
 def policy_gemm_probe(env, policy, iters=30):
@@ -290,6 +332,7 @@ def run_workload(workload, device_index, seed, threads, steps, warmup, barrier=N
     a_track = None
     if workload in ("tracked", "wild_eval"):
         a_track = tracking_action(env)
+        env._a_track = a_track if workload == "tracked" else None
         sampler.start()
     wild, follow = workload == "wild_eval", workload == "objects"
     if workload in ("tracked", "objects"):
@@ -441,6 +484,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads and the GEMM probe (profiling runs)")
     ap.add_argument("--workload", choices=tuple(WORKLOAD_DESC), default="tracked")
+    ap.add_argument("--no-parity-live", action="store_true", help="skip the live one-substep parity sample against the fp64 oracle (profiling runs)")
     args = ap.parse_args()
     train = args.workload == "train_iter"
     if args.steps is None:
@@ -448,6 +492,12 @@ def main():
     if args.warmup is None:
         args.warmup = 1 if train else 20
 
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    if args.gpus > torch.cuda.device_count() and os.environ.get("KP_BENCH_SHARED_DEVICE") != "1":
+        # fail fast, before any rendezvous: ranks without a device would hang the others in init_process_group
+        raise SystemExit(f"bench.py --gpus {args.gpus}: this node shows {torch.cuda.device_count()} HIP device(s); one rank per GPU is the only layout "
+                         "(KP_BENCH_SHARED_DEVICE=1 puts all ranks on device 0 for plumbing tests)")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:        # no launcher around us: become one
         raise SystemExit(relaunch_under_torchrun(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -500,9 +550,15 @@ def main():
         elapsed = float(t.item())
 
     train_n = None
+    live = None
     if not train:       # read what the line needs from the engine before it is torn down
         cost = env.sim.launch_cost().astype(np.float64)
         spj = int(env.model.get_option("substeps_per_job"))
+        if rank == 0 and world == 1 and not args.no_parity_live and args.workload in ("tracked", "random_init", "objects"):
+            try:
+                live = parity_live(env, sampler, args.workload, getattr(env, "_a_track", None))
+            except Exception as ex:
+                live = {"error": f"{type(ex).__name__}: {ex}"[:300]}
     if world > 1 and not train and not args.no_secondary:
         # the Amdahl term of a training job on N GPUs: one whole optimize_policy (sampling + all-gather of advantages / returns + data-parallel update with
         # gradient all-reduces) timed on every rank, max over ranks
@@ -534,14 +590,18 @@ def main():
         # HBM bytes / instruction counts: ONLY from a rocprofv3 --pmc pass of this same command and workload (tools/profile_bench.sh writes
         # profiles/r03/pmc_bench_<workload>.json); otherwise null -- nothing canned from another workload enters the line
         traffic, traffic_src, valu = None, None, None
+        from kinpoly_amd.build import kernel_source_sha256
+        sha_now = kernel_source_sha256()
         pmc_path = os.path.join(PROFILE_DIR, f"pmc_bench_{args.workload}.json")
         if os.path.exists(pmc_path):
             pj = json.load(open(pmc_path))
-            traffic = pj.get("hbm_bytes_per_launch")
+            fresh = pj.get("kernel_source_sha256") == sha_now          # profiled on THIS device code (csrc/* + flags)?  otherwise the figures are nulled
+            traffic = pj.get("hbm_bytes_per_launch") if fresh else None
             traffic_src = {"file": os.path.relpath(pmc_path, ROOT), "command": pj.get("command"), "launch_ms_in_those_passes": pj.get("launch_ms"),
+                           "kernel_source_sha256_of_the_profile": pj.get("kernel_source_sha256"), "kernel_source_sha256_now": sha_now, "stale": not fresh,
                            "note": "separate rocprofv3 --pmc passes of this command (FETCH_SIZE x2 per the guide's gfx950 correction, WRITE_SIZE as reported), "
-                                   "median per launch of the same kernel; not measured in this run"}
-            valu = pj.get("issue")
+                                   "median per launch of the same kernel; not measured in this run; nulled when the device code has changed since (stale)"}
+            valu = pj.get("issue") if fresh else None
         # instruction issue: instructions per env-step from that PMC pass, wave cycles per env-step live from this run's last
         # launch (kp_sim_launch_cost), against what two waves per SIMD can issue (tools/micro/valu_probe.hip: one instruction per 2.9 SIMD cycles)
         issue, valu_active = None, None
@@ -550,8 +610,12 @@ def main():
             cyc = float(cost.mean())
             issue = {"wave_insts_per_env_step": insts, "wave_cycles_per_env_step": cyc, "wave_cycles_per_inst": cyc / insts, "waves_per_simd": 2,
                      "simd_cycles_per_inst": cyc / insts / 2.0, "attainable_simd_cycles_per_inst_at_2_waves": 2.9, "frac_of_attainable_issue": 2.9 / (cyc / insts / 2.0),
+                     # the kernel's own arithmetic throughput: VALU wave-instructions it executes per launch / this run's launch time, against one VALU
+                     # wave-instruction per 4 cycles per SIMD (1024 SIMDs x 2.4 GHz / 4 = 614.4 G/s)
+                     "valu_wave_insts_per_s_G": valu["valu_insts_per_launch"] / kern_s / 1e9, "valu_wave_inst_peak_G": 614.4,
+                     "valu_issue_frac": valu["valu_insts_per_launch"] / kern_s / 1e9 / 614.4,
                      "note": "instructions: VALU + SALU + LDS wave-instructions of the PMC pass named in traffic_source; cycles: shader clock inside the jobs of this run's last launch "
-                             "(hand-overs included, tail of the launch excluded); a third wave per SIMD buys ~1 % (profiles/r02/occupancy_premise.log)"}
+                             "(hand-overs included, tail of the launch excluded)"}
             valu_active = valu.get("valu_active_frac_of_launch")
         out = {
             "metric": "env-steps/sec (whole node) at 4096 envs/GPU, 69-DoF SMPL", "value": value, "unit": "env-steps/s",
@@ -574,7 +638,9 @@ def main():
             "hessian_factorisations_per_substep": float((diag[:, 3] >> 8).mean() / 15.0),
             "bad_envs": int(((diag[:, 2] & 255) != 0).sum()), "newton_cap_hits": int((diag[:, 2] >> 8).sum()),
             "episodes_ended_per_step_frac": rec["n_done"] / (ENVS_PER_GPU * args.steps),
+            "parity_live": live,
             "parity": parity_summary(args.workload),
+            "mujoco_pin": mujoco_pin_report(),
             # per-env shader-clock cycles of the last launch (kp_sim_launch_cost): what the launch would take if its waves were perfectly
             # packed on the resident slots vs its longest env
             "launch_balance": {"substeps_per_job": spj, "sum_env_cycles_over_2048_slots_ms": float(cost.sum() / 2048 / 2.38e6),
@@ -650,10 +716,11 @@ def main():
             # algorithmic FLOPs of the reference formulation (counted in the fp64 oracle on its rollout) x the GPU's env-step rate
             fl = out["cpu_baseline"].get("physics_flops_per_env_step")
             if fl:
-                out["roofline"]["valu_flops"] = {"physics_flops_per_env_step_oracle": fl, "achieved_tflops": fl * value / world / 1e12, "peak_tflops": VALU_FP32_PEAK_TFLOPS,
-                                                 "frac": fl * value / world / 1e12 / VALU_FP32_PEAK_TFLOPS,
-                                                 "note": "FLOPs counted at the loop bodies of the fp64 oracle (dense stable-PD Cholesky, sparse L'DL, dense Newton Hessian: the arithmetic "
-                                                         "the reference + MuJoCo execute) on the CPU baseline's run of the same workload; the HIP kernel's matrix-free passes do fewer"}
+                out["roofline"]["reference_algorithm_flops"] = {"physics_flops_per_env_step_oracle": fl, "reference_algorithm_tflops_at_this_rate": fl * value / world / 1e12,
+                                                                "peak_tflops": VALU_FP32_PEAK_TFLOPS, "frac_if_the_kernel_executed_them": fl * value / world / 1e12 / VALU_FP32_PEAK_TFLOPS,
+                                                                "note": "NOT the kernel's FLOPs: counted at the loop bodies of the fp64 oracle (dense stable-PD Cholesky, sparse L'DL, dense Newton Hessian: the "
+                                                                        "arithmetic the reference + MuJoCo execute) on the CPU baseline's run of the same workload; the HIP kernel's matrix-free passes execute "
+                                                                        "fewer, so this figure flatters -- the kernel's own throughput is roofline.issue.valu_issue_frac (instruction-derived)"}
         print(json.dumps(out), flush=True)
     if in_group:
         dist.barrier()

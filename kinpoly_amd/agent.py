@@ -184,8 +184,14 @@ class AgentAR:
         wild = bool(self.env.wild if wild is None else wild)          # `curr_env = self.env if not loader.cfg.wild else self.env_wild` (:464)
         if wild not in self._eval:
             n = int(self.eval_envs or min(self.env.n, 256))
-            env = BatchedHumanoidAREnv(n, self.device.index, mode="test", wild=wild, seed=0, cc_policy=self.env.cc_policy, cc_running_state=self.env.cc_running_state)
-            env.reward_cfg.body_diff_thresh, env.reward_cfg.body_diff_gt_thresh = self.env.reward_cfg.body_diff_thresh, self.env.reward_cfg.body_diff_gt_thresh
+            env = BatchedHumanoidAREnv(n, self.device.index, mode="test", wild=wild, seed=0, cc_policy=self.env.cc_policy, cc_running_state=self.env.cc_running_state,
+                                       model_options=getattr(self.env, "model_options", None))
+            import copy
+            gt_term = env.reward_cfg.use_gt_term                         # a property of the mode (test: no GT-diff termination), not of the configuration
+            env.reward_cfg = copy.deepcopy(self.env.reward_cfg)          # thresholds AND the reward weights cfg.apply_reward_weights put on the training env
+            env.reward_cfg.use_gt_term = gt_term
+            if hasattr(self.env, "env_episode_len"):
+                env.env_episode_len = self.env.env_episode_len
             builder = PolicyARContext(self.policy_net, kpsim.KpSim(env.model, n, self.device.index), smooth=self.ctx_builder.smooth, need_rollout=True, keep_context_feat=False)
             self._eval[wild] = (env, builder)
         return self._eval[wild]
@@ -201,6 +207,13 @@ class AgentAR:
         for ds in sets:
             env, builder = self._eval_engine(getattr(ds, "wild", None))
             res = eval_dataset(env, self.policy_net, builder, ds)
+            if _collective_on(self.trainer.group):
+                # every rank plays the takes (replicas are identical), but run-to-run differences of the device arithmetic could flip a `percent == 1` on one
+                # rank only and the job-wide sampling history would part: rank 0's percents are everybody's
+                box = [{k: r["percent"] for k, r in res.items()}]
+                dist.broadcast_object_list(box, src=0, group=self.trainer.group)
+                for k, pc in box[0].items():
+                    res[k]["percent"] = pc
             ok = {k: r["percent"] == 1 for k, r in res.items()}
             if data_mode == "train":
                 for k, r in res.items():

@@ -22,6 +22,18 @@ def _dependencies():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(inc, "*.h")))
 
 
+def kernel_source_sha256() -> str:
+    """One fingerprint of what the device code is compiled from (csrc/*.hip|*.hpp + the flag list): profiles under profiles/ are stamped with it, and
+    bench.py nulls PMC-derived figures whose stamp is not the current one (a profile of another kernel must not ride on a fresh driver record)."""
+    import hashlib
+    h = hashlib.sha256()
+    for p in _dependencies():
+        if p.startswith(CSRC):
+            h.update(os.path.basename(p).encode()); h.update(open(p, "rb").read())
+    h.update(" ".join(_flags()).encode())
+    return h.hexdigest()[:16]
+
+
 # Optimisation flags of the product build (tools that compile instrumented variants of the library use the same list).  -O2 without the loop and SLP
 # vectorisers: on the one-wavefront-per-env kernels their packed fp32 operations (v_pk_fma_f32 and friends need even-aligned register pairs) cost more
 # in moves and register pressure than they save -- control-step launch 2.785 -> 2.695 ms (floor), 5.16 -> 5.03 ms (objects) against -O3 with both on

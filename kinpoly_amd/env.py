@@ -48,7 +48,8 @@ class BatchedHumanoidAREnv:
         self.ar_mode = bool(ar_mode)
         if kpm_path is None:  # agent_ar.py:165-169: mocap training uses ..._all_step.xml, --wild uses ..._all.xml
             kpm_path = kpsim.DEFAULT_KPM if wild else kpsim.STEP_KPM
-        self.model = kpsim.KpModel(kpm_path, **(model_options or {}))
+        self.model_options = dict(model_options or {})
+        self.model = kpsim.KpModel(kpm_path, **self.model_options)
         self.sim = kpsim.KpSim(self.model, self.n, device)
         self.device = self.sim.device
         self.mode, self.wild, self.joint_controller = mode, wild, joint_controller
@@ -165,7 +166,8 @@ class BatchedHumanoidAREnv:
         c["gt_bquat"].index_copy_(0, rows, gt["bquat"].view(m, T, 96))
         c["gt_wbpos"].index_copy_(0, rows, gt["wbpos"].view(m, T, 72))
         lens = data.get("len")
-        new_len = torch.full((m,), T - 1, dtype=torch.int32, device=dev) if lens is None else torch.as_tensor(lens, device=dev).to(torch.int32) - 1
+        # no `len`: the clip runs over its OWN frames (data['qpos'].shape[1]), not over the padding up to the tables' T
+        new_len = torch.full((m,), data["qpos"].shape[1] - 1, dtype=torch.int32, device=dev) if lens is None else torch.as_tensor(lens, device=dev).to(torch.int32) - 1
         self.row_len.index_copy_(0, rows, new_len)
         meta = torch.stack([torch.as_tensor(data[k]).to(dev, torch.float32) if k in data else torch.zeros(m, device=dev) for k in ("take_ind", "fr_start")], 1)
         self.row_meta.index_copy_(0, rows, meta)
@@ -363,19 +365,18 @@ ACTION_INDEX_MAP, ACTION_LEN = (0, 7, 21, 28), (7, 14, 7, 7)   # sit / push / av
 
 def convert_obj_qpos(action_one_hot: torch.Tensor, obj_pose0: torch.Tensor):
     """HumanoidAREnv.convert_obj_qpos (humanoid_ar_v1.py:479-496) batched: every object parked at [(i+1)*100, 100, 0]
-    with a zero quaternion, the active action's slice overwritten by obj_pose.  Returns ([N,35], [N,7] active slice)."""
+    with a zero quaternion, the active action's slice overwritten by obj_pose.  Returns ([N,35], [N,7] active slice).
+    Branch-free (masked selects over the four action slots): no host read, so the sampler's ring top-up keeps its one read per pool_depth steps."""
     n, dev = action_one_hot.shape[0], action_one_hot.device
     blk = torch.zeros((n, 35), device=dev)
     for i in range(5):
         blk[:, 7 * i] = (i + 1) * 100.0; blk[:, 7 * i + 1] = 100.0
     obj7 = torch.tensor([0.0, 0, 0, 1, 0, 0, 0], device=dev).repeat(n, 1)
     for a in range(4):
-        m = action_one_hot[:, a] > 0
-        if bool(m.any()):
-            st, ln = ACTION_INDEX_MAP[a], ACTION_LEN[a]
-            ln = min(ln, obj_pose0.shape[1])
-            blk[m, st:st + ln] = obj_pose0[m, :ln]
-            obj7[m] = blk[m, st:st + 7]
+        m = (action_one_hot[:, a] > 0).unsqueeze(1)
+        st, ln = ACTION_INDEX_MAP[a], min(ACTION_LEN[a], obj_pose0.shape[1])
+        blk[:, st:st + ln] = torch.where(m, obj_pose0[:, :ln], blk[:, st:st + ln])
+        obj7 = torch.where(m, blk[:, st:st + 7], obj7)
     return blk.contiguous(), obj7.contiguous()
 
 

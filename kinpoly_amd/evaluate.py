@@ -17,6 +17,8 @@ import torch
 def run_sequences(env, policy_net, keys, fail_safe=False, max_steps=100000):
     """env: BatchedHumanoidAREnv with its context loaded (one sequence per env, mode 'test').  Returns {key: seq_result}."""
     n = env.n
+    if fail_safe and "ar_qpos" not in env.ctx:            # checked once, up front: the fail-safe runs (masked) every step, whether or not an env ended early
+        raise ValueError("run_sequences(fail_safe=True) needs the kinematic roll-out in the context (ctx['ar_qpos'] / ['ar_qvel']: PolicyARContext(need_rollout=True))")
     env.set_mode("test")
     obs = env.reset()
     hx = policy_net.init_hidden(n, env.device)

@@ -40,7 +40,9 @@ ms, calls = launch_ms()
 fs, ws = counters("FETCH_SIZE"), counters("WRITE_SIZE")
 iss = counters("SQ_INSTS_VALU+SQ_INSTS_SALU+SQ_INSTS_LDS")
 cyc = counters("SQ_WAVE_CYCLES+SQ_BUSY_CYCLES+SQ_ACTIVE_INST_VALU")
-out = {"kernel": KERNEL, "workload": wl, "command": cmd, "launch_ms": ms, "launches_in_stats_pass": calls}
+sys.path.insert(0, ROOT)
+from kinpoly_amd.build import kernel_source_sha256  # noqa: E402
+out = {"kernel": KERNEL, "workload": wl, "command": cmd, "launch_ms": ms, "launches_in_stats_pass": calls, "kernel_source_sha256": kernel_source_sha256()}
 if "FETCH_SIZE" in fs and "WRITE_SIZE" in ws:
     # FETCH_SIZE / WRITE_SIZE are in KB; gfx950 FETCH_SIZE counts 64 B per 128-B request: x2 (MI355X_MICROARCH.md, HBM section)
     out.update(FETCH_SIZE_KB_median=fs["FETCH_SIZE"], WRITE_SIZE_KB_median=ws["WRITE_SIZE"],

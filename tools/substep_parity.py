@@ -43,11 +43,21 @@ def bench_states(workload, n, seed):
         bench.rollout_steps(sampler, 10, a_track, False, False)
     else:
         bench.rollout_steps(sampler, 1, None, False, workload == "objects")
+    S = states_from_engine(env, keep["info"]["cc_action"], n, workload == "objects")
+    del env, sampler, policy
+    torch.cuda.empty_cache()
+    return S
+
+
+def states_from_engine(env, cc_action, n, objects=False):
+    """n envs' states of a live BatchedHumanoidAREnv (evenly spaced over its envs) after its last step, with that step's UHC action and target, as scenes
+    of run(): what bench.py hands over for its `parity_live` block (the driver's own run, the same engine it just timed)."""
     sim = env.sim
     pick = np.linspace(0, env.n - 1, n).astype(int)
     g = lambda k: sim.get(k).double().cpu().numpy()[pick]  # noqa: E731
     qpos, qvel, target = g("qpos"), g("qvel"), g("target_qpos")
-    action = keep["info"]["cc_action"].double().cpu().numpy()[pick]
+    action = cc_action.double().cpu().numpy()[pick]
+    workload = "objects" if objects else "floor"
     blk = np.zeros((n, 35)); bv = np.zeros((n, 30))
     for i in range(5):
         blk[:, 7 * i: 7 * i + 3] = [(i + 1) * 100, 100, 0]
@@ -59,16 +69,20 @@ def bench_states(workload, n, seed):
                 if abs(blk[e, 7 * oi]) < 50 and abs(blk[e, 7 * oi + 1]) < 50:            # not parked (convert_obj_qpos parks the inactive ones 100+ m away)
                     objects[e][oi] = blk[e, 7 * oi: 7 * oi + 7].copy()
             objects[e] = dict(list(objects[e].items())[:2])
-    del env, sampler, policy
-    torch.cuda.empty_cache()
     return dict(qpos=qpos, qvel=qvel, action=action, target=target, kind=np.zeros(n, int), objects=objects, blk=blk, bv=bv)
 
 
-def run(mode="floor", n=64, seed=None, nsub=45):
-    """-> dict(eq, ev, eo [nsub, n], differ [nsub, n] bool, ncon, scenes)"""
+def run(mode="floor", n=64, seed=None, nsub=45, states=None, follow_flips=True):
+    """-> dict(eq, ev, eo [nsub, n], differ [nsub, n] bool, ncon, scenes, flips).  states: scenes handed in (states_from_engine) instead of built here.
+    follow_flips: where the two sides' contact sets differ at a common state (a knife edge of MuJoCo's contact rules), BOTH sides continue free-running
+    from their own post-substep states for the rest of a control step (14 more substeps, same action and target), and `flips` records how far apart
+    they are at its end: (substep, scene, one-substep |dqpos|, |dqpos| after the control step) -- is a flip damped or amplified?"""
     seed = (2024 if mode == "floor" else 0) if seed is None else seed
     obj = mode != "floor"
-    if mode.startswith("bench:"):
+    if states is not None:
+        S = states
+        n = len(S["qpos"])
+    elif mode.startswith("bench:"):
         S = bench_states(mode.split(":")[1], n, seed)
     else:
         S = _scenes.object_scenes(n, seed) if obj else _scenes.floor_scenes(n, seed)
@@ -93,6 +107,7 @@ def run(mode="floor", n=64, seed=None, nsub=45):
     eq = np.zeros((nsub, n)); ev = np.zeros((nsub, n)); eo = np.zeros((nsub, n)); differ = np.zeros((nsub, n), bool); ncon = np.zeros((nsub, n), int)
     nit_o = np.zeros((nsub, n), int); nit_h = np.zeros((nsub, n), int); vertex = np.zeros((nsub, n), bool); klass = np.full((nsub, n), "", dtype=object)
     nang = np.zeros((nsub, n)); ddist = np.zeros((nsub, n))
+    flips, side, o2 = [], None, None
     for k in range(nsub):
         q = np.stack([r32(o.get("qpos")) for o in oracles]); v = np.stack([r32(o.get("qvel")) for o in oracles])
         if obj:
@@ -131,6 +146,29 @@ def run(mode="floor", n=64, seed=None, nsub=45):
                 so, sh = sorted(ob.tolist()), sorted(hc[e]["body"].tolist())
                 cb, cp, hk = ob.tolist(), op, hc[e]["body"].tolist()
             differ[k, e] = so != sh; ncon[k, e] = len(so)
+            if so != sh and follow_flips and len(flips) < 64:
+                # the rest of the control step from each side's OWN state after the flipped substep (a 1-env simulator / a second oracle, so that the walk
+                # along the oracle's trajectory is not disturbed); both sides are restarted the same way (set_state + forward)
+                if side is None:
+                    side = KpSim(KpModel(STEP_KPM) if obj else KpModel(), 1)
+                    o2 = OracleSim(kpm=STEP_KPM, ls_exact=LS_EXACT) if obj else OracleSim(ls_exact=LS_EXACT)
+                if obj:
+                    b1 = S["blk"][e:e + 1].copy(); bv1 = np.zeros((1, 30))
+                    o2.clear_objects()
+                    for slot, oi in enumerate(sorted(S["objects"][e])):
+                        oq, ov = o.get_object(slot)
+                        o2.set_object(slot, kpm, oi, oq, ov)
+                        b1[0, 7 * oi: 7 * oi + 7] = hob[e, 7 * oi: 7 * oi + 7]
+                    hobv = sim.get("obj_qvel").double().cpu().numpy()
+                    for oi in sorted(S["objects"][e]):
+                        bv1[0, 6 * oi: 6 * oi + 6] = hobv[e, 6 * oi: 6 * oi + 6]
+                    side.set_objects(dev(b1)); side.set_obj_state(dev(b1), dev(bv1))
+                side.set_state(dev(hq[e:e + 1]), dev(hv[e:e + 1])); side.set_target(dev(S["target"][e:e + 1]))
+                side.step_ctrl(dev(S["action"][e:e + 1]), 14)
+                o2.reset(o.get("qpos"), wv)
+                o2.do_simulation(S["action"][e], S["target"][e], 14)
+                end = float(np.abs(o2.get("qpos") - side.get("qpos")[0].double().cpu().numpy()).max())
+                flips.append((int(k), int(e), float(eq[k, e]), end))
             if so != sh:
                 # which rule's threshold does the difference sit on?  'margin': a one-sided contact within 1e-6 of dist == margin; 'support': the hull's first
                 # contact (mjc_PlaneConvex's support vertex) is another vertex at the same height, which also changes the neighbours that follow it;
@@ -168,7 +206,19 @@ def run(mode="floor", n=64, seed=None, nsub=45):
                     elif obj:            # the same point: how far apart are the two normals (MPR's direction for the hull - primitive pairs) and distances?
                         nang[k, e] = max(nang[k, e], float(np.arctan2(np.linalg.norm(np.cross(c["normal"][i], hc[e]["normal"][j])), np.dot(c["normal"][i], hc[e]["normal"][j]))))     # not acos(dot): the hip normal is unit to 1e-7 only
                         ddist[k, e] = max(ddist[k, e], abs(c["dist"][i] - hc[e]["dist"][j]))
-    return dict(eq=eq, ev=ev, eo=eo, differ=differ, ncon=ncon, scenes=S, seed=seed, nit_o=nit_o, nit_h=nit_h, vertex=vertex, klass=klass, nang=nang, ddist=ddist)
+    return dict(eq=eq, ev=ev, eo=eo, differ=differ, ncon=ncon, scenes=S, seed=seed, nit_o=nit_o, nit_h=nit_h, vertex=vertex, klass=klass, nang=nang, ddist=ddist, flips=flips)
+
+
+def summary(R):
+    """the figures bench.py prints as `parity_live` / the committed logs hold, from run()'s arrays"""
+    err = np.maximum(R["eq"], R["eo"])
+    same = ~R["differ"] & ~R["vertex"]
+    fl = R.get("flips", [])
+    return {"substeps": int(err.size), "contact_set_diffs": int(R["differ"].sum()), "same_entities_other_hull_vertex": int(R["vertex"].sum()),
+            "max_same_set_dqpos": float(err[same].max()) if same.any() else None, "median_dqpos": float(np.median(err)), "p99_dqpos": float(np.quantile(err, .99)),
+            "flips_followed": len(fl), "flip_one_substep_dqpos_max": max((f[2] for f in fl), default=None),
+            "flip_dqpos_after_one_control_step_max": max((f[3] for f in fl), default=None),
+            "flip_dqpos_after_one_control_step_median": float(np.median([f[3] for f in fl])) if fl else None}
 
 
 if __name__ == "__main__":
@@ -188,6 +238,11 @@ if __name__ == "__main__":
           + (" [" + ", ".join(f"{nm}: {int((R['klass'] == nm).sum())}" for nm in sorted(set(R['klass'][differ].tolist()))) + "]" if differ.any() else "")
           + f"; same entities but another vertex of a hull at the same height (to 1e-7): {int(vertex.sum())}" + (f" (|dqpos| max {err[vertex].max():.1e})" if vertex.any() else "")
           + f"; with the same contact points: max |dqpos| {err[same].max():.1e}, above 1e-6: {int((err[same] > 1e-6).sum())}, above 1e-5: {int((err[same] > 1e-5).sum())}")
+    if R["flips"]:
+        fl = np.array([(f[2], f[3]) for f in R["flips"]])
+        print(f"   knife-edge flips followed for the rest of their control step (14 more substeps, both sides free-running from their own states): {len(fl)}; "
+              f"|dqpos| right after the flipped substep median {np.median(fl[:, 0]):.1e} max {fl[:, 0].max():.1e} -> at the end of the control step median {np.median(fl[:, 1]):.1e} max {fl[:, 1].max():.1e}; "
+              f"amplified (end > 2 x start) in {int((fl[:, 1] > 2 * fl[:, 0]).sum())}, damped (end < start / 2) in {int((fl[:, 1] < 0.5 * fl[:, 0]).sum())}")
     if R["nang"].any():
         print(f"   matched contacts of the same point: |d dist| max {R['ddist'].max():.1e}; angle between the two normals max {R['nang'].max():.1e} rad, above 1e-4 rad in {int((R['nang'] > 1e-4).sum())} substeps, above 1e-3 in {int((R['nang'] > 1e-3).sum())}")
     order = np.dstack(np.unravel_index(np.argsort(-err, axis=None)[:6], err.shape))[0]
