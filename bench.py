@@ -403,6 +403,87 @@ def object_scene_launches(device_index, threads):
     return out
 
 
+def sampler_regime(device_index, seed, horizon=TRAIN_HORIZON, calls=4, warm=2, threads=64, amp=0.05, profile=False):
+    """`VectorSampler.sample(horizon)` in the regime of a policy that has learnt to track: every episode on a clip drawn from a
+    StateARDataset through init_context (ring of pool_depth + 1 rows per env, on-demand top-up), all twelve memory fields' worth of per-step records,
+    and a kinematic policy whose GEMMs run but whose output is replaced by the clip's next pose + N(0, e^-3.2) noise -- so episodes last, a few per cent
+    of the envs end per step (clip ends + failures), and what is timed is the sampler around the env-step, not init_context at fail rate 1.
+    Returns T_sample per call, the bare env-steps' time for the same number of steps (rollout_steps on the same engine), and the done / fail rates."""
+    from kinpoly_amd import dataset as D
+    from kinpoly_amd import sim as kpsim
+    from kinpoly_amd.context import PolicyARContext, TrajARNet
+    from kinpoly_amd.env import BatchedHumanoidAREnv
+    from kinpoly_amd.model_compiler import read_kpm
+    from kinpoly_amd.nets import enable_tuned_gemms
+    from kinpoly_amd.rollout import EpisodeSource, VectorSampler
+    enable_tuned_gemms()
+    torch.manual_seed(seed)
+    std = np.load(os.path.join(ROOT, "tests", "golden", "standing_neutral.npz"))
+    env = BatchedHumanoidAREnv(ENVS_PER_GPU, device_index, mode="train", seed=seed, model_options={"threads_per_env": threads})
+    kin_sim = kpsim.KpSim(env.model, ENVS_PER_GPU, device_index)
+    takes = D.synthetic_takes(kin_sim, std["qpos"], n_per_action=8, T_range=(CLIP_LEN + 10, CLIP_LEN + 60), body_mass=read_kpm(kpsim.STEP_KPM)["body_mass"],
+                              seed=seed, with_objects=False, amp_max=amp)
+    ds = D.StateARDataset(takes, fr_num=CLIP_LEN, seed=seed, device=env.device)
+
+    class Tracking(TrajARNet):
+        """the policy's own GEMMs, then the action a converged policy would emit: the clip's next frame in step_ar's encoding + exploration noise"""
+
+        def select_action(self, state, hx, mean_action=False, generator=None, noise=None):
+            _, hx = self.get_action(state, hx)
+            row = env.row.long()
+            q = env.ctx["qpos"][row, torch.minimum(env.cur_t.long() + 1, env.row_len[row].long())]
+            a = torch.cat([q[:, 2:3], state[:, 1:5], q[:, 7:], torch.zeros((q.shape[0], 6), device=q.device)], 1)
+            if noise is None:
+                noise = torch.randn(a.shape, device=a.device, generator=generator)
+            return torch.addcmul(a, self.std(), noise), hx
+    pol = Tracking().to(env.device)
+    builder = PolicyARContext(pol, kin_sim, smooth=True, need_rollout=False, keep_context_feat=False)
+    # init_qpos / init_qvel of an episode = the clip's own first frame (what a trained context network predicts), through the real init_context call
+    src = EpisodeSource(dataset=ds, ctx_builder=builder, sampling_temp=0.3, sampling_freq=0.5)
+    orig_draw = src.draw
+
+    def draw(n, device):
+        data = orig_draw(n, device)
+        data["init_qpos"], data["init_qvel"] = data["qpos"][:, 0].contiguous(), data["qvel"][:, 0].contiguous()
+        return data
+    src.draw = draw
+    sampler = VectorSampler(env, pol, record_qpos=True, source=src, pool_depth=4)
+    sampler.start()
+    for _ in range(warm):
+        sampler.sample(horizon)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    done = fail = 0.0
+    prof = None
+    if profile:
+        prof = torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU, torch.profiler.ProfilerActivity.CUDA])
+        prof.__enter__()
+    for _ in range(calls):
+        b = sampler.sample(horizon)
+        done += float((1 - b.masks).mean()); fail += float(b.fails.float().mean())
+    torch.cuda.synchronize()
+    ts = (time.perf_counter() - t0) / calls
+    if prof is not None:
+        prof.__exit__(None, None, None)
+    # the same number of bare env-steps on the same engine and states (no records, no ring, no top-up)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(calls):
+        rollout_steps(sampler, horizon, None, False, False)
+    torch.cuda.synchronize()
+    tb = (time.perf_counter() - t0) / calls
+    out = {"T_sample": ts, "T_bare_env_steps": tb, "overhead": ts / tb, "horizon": horizon, "envs": ENVS_PER_GPU, "calls": calls, "done_per_step_frac": done / calls, "fail_per_step_frac": fail / calls,
+           "top_ups_per_call": sampler.top_ups / (calls + warm), "clips_drawn_per_call": src.n_drawn / (calls + warm), "pool_exhausted": sampler.pool_exhausted,
+           "env_steps_per_s": ENVS_PER_GPU * horizon / ts,
+           "note": "VectorSampler.sample with a tracking stand-in policy (its GEMMs run; output = clip's next pose + noise): dataset-driven episodes through init_context, ring top-ups, "
+                   "per-step records of all memory fields; T_bare_env_steps = rollout_steps on the same engine (random-init policy output, episodes end more often: an upper bound of the bare cost)"}
+    if prof is not None:
+        out["_profile_table"] = prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=45, max_name_column_width=70)
+    del sampler, env, kin_sim
+    torch.cuda.empty_cache()
+    return out
+
+
 def train_iteration(device_index, seed, horizon, iters, warm, barrier=None, threads=64, objects=False, rank=0, cache_init_context=False):
     """`iters` timed AgentAR.optimize_policy calls (after `warm` untimed) at ENVS_PER_GPU x horizon env-steps per rank, the way
     scripts/train_ar_policy.py runs them: every episode draws its clip from a StateARDataset (adaptive take sampling, freq_dict feedback) and goes
@@ -697,6 +778,7 @@ def main():
                                                 (f"4096x{TRAIN_HORIZON}_init_context_memo", TRAIN_HORIZON, 2, False, True)):
                     r3 = train_iteration(local_rank, 4, hz, it, 1, objects=obj, cache_init_context=memo)
                     out["train_iteration"][name] = {k: r3[k] for k in TRAIN_KEYS}
+                out["train_iteration"]["sampler_tracking_regime"] = sampler_regime(local_rank, 4)
                 out["train_iteration"]["note"] = ("random-init networks: (almost) every episode fails after one step, so every env-step draws a clip and runs it through init_context "
                                                   "(context GRU over its 100 frames) -- the worst case of the episode source; `_init_context_memo` is the opt-in lookup of windows "
                                                   "already computed under the same context-network parameters (EpisodeSource.cache_init_context; the synthetic set has few windows, a MoCap set has ~1e5)")

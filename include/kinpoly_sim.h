@@ -199,6 +199,29 @@ int kp_sim_reset_rows(kp_sim*, const float* init_qpos, const float* init_qvel, c
  * (the int32 [n] buffer kp_ctx.row points to).  A pure function of its device arrays (no simulator handle); follow with kp_sim_reset_rows(done). */
 int kp_pool_advance(int n, int n_slots, const uint8_t* done, int32_t* head, int32_t* ahead, int32_t* row, void* hip_stream);
 
+/* The sampler's per-step record: Memory.push of sample_worker (kin_poly/core/agent_ar.py:582-597; TrajBatchEgo's twelve fields,
+ * kin_poly/core/trajbatch_ego.py:5-14) for all n envs in one launch per half-step, into env-major [n, T, .] device buffers at time index t.
+ * Every destination may be NULL (field not recorded); a destination needs its source.  bool-like arrays are uint8.
+ *   pre  (before the env step): states <- obs [n,105]; episode_start <- fresh [n]; curr_qpos <- qpos [n,76] (get_humanoid_qpos, :571);
+ *        gt_target_qpos <- ctx_qpos[row[e], min(cur_t[e] + 1, row_len[row[e]])] (ar_context['qpos'][cur_t + 1], :572; ctx_qpos is [R, ctx_T, 76]);
+ *        meta [n,T,2] <- row_meta[row[e]] = (take_ind, fr_start) of the clip the env is on (:627-631).  row may be NULL (row = env).
+ *   post (after the env step, before the episode turnover): actions, rewards, fails, dones, percents, c_infos [n,T,6] and, for the full record,
+ *        next_states <- obs, res_qpos <- qpos, cc_actions [75], cc_states [784], v_metas [n,T,3] <- (meta[.., t, :], fr_num). */
+typedef struct {
+    int n, T, t, ctx_T;
+    const float* obs; const uint8_t* fresh; const float* qpos; const float* ctx_qpos; const int32_t* row; const int32_t* cur_t; const int32_t* row_len; const float* row_meta;
+    float* states; uint8_t* episode_start; float* curr_qpos; float* gt_target_qpos; float* meta;
+} kp_record_pre;
+typedef struct {
+    int n, T, t; float fr_num;
+    const float* action; const float* reward; const uint8_t* fail; const uint8_t* done; const float* percent; const float* c_info;
+    const float* obs; const float* qpos; const float* cc_action; const float* cc_state; const float* meta;     /* meta: the [n,T,2] buffer `pre` wrote */
+    float* actions; float* rewards; uint8_t* fails; uint8_t* dones; float* percents; float* c_infos;
+    float* next_states; float* res_qpos; float* cc_actions; float* cc_states; float* v_metas;
+} kp_record_post;
+int kp_rollout_record_pre(const kp_record_pre*, void* hip_stream);
+int kp_rollout_record_post(const kp_record_post*, void* hip_stream);
+
 /* estimate_advantages before normalisation (uhc/khrylib/rl/core/common.py:5-20) on an env-major
  * [N,T] layout (each env's T rows contiguous, time increasing).  All pointers device, float32. */
 int kp_gae(int n_envs, int T, const float* rewards, const float* masks, const float* values, float gamma, float tau,
@@ -280,6 +303,10 @@ typedef enum {
 } kp_field;
 int kp_field_dim(int field);
 int kp_sim_get(kp_sim*, int field, float* out);
+/* Device address of a STORED per-env field ([N, kp_field_dim(field)] float32 rows: KP_QPOS, KP_QVEL, KP_XPOS, KP_XQUAT, KP_XIPOS, KP_TARGET_QPOS,
+ * KP_QPOS_D, KP_QVEL_D, KP_OBJ_QPOS, KP_OBJ_QVEL), NULL for derived read-outs.  The zero-copy counterpart of kp_sim_get (`data.qpos` as a view,
+ * humanoid_im.py:193): valid for the life of the handle, contents ordered by the handle's stream, overwritten by the next step. */
+const float* kp_sim_field_device(kp_sim*, int field);
 
 /* per-env diagnostics of the last kp_sim_step_ctrl: int32 [N,4] = {contacts in last substep,
  * Newton iterations (sum over substeps), flags (bit 0 = non-finite state) | number of substeps whose Newton solve stopped at the

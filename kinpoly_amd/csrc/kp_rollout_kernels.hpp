@@ -209,6 +209,67 @@ __global__ void k_pool_advance(int n, int n_slots, const uint8_t* __restrict__ d
     row[e] = h * n + e;
 }
 
+// The sampler's per-step record (Memory.push of sample_worker, kin_poly/core/agent_ar.py:582-597) for all envs at once: every row of the env-major
+// [N, T, .] rollout buffers at time t in ONE launch per half-step instead of a dozen strided copies.  `pre` (before env.step): states <- obs,
+// episode_start <- fresh, curr_qpos <- the simulator's qpos, gt_target_qpos <- ar_context['qpos'][cur_t + 1] of the env's context row (clamped to the
+// clip's last frame), meta <- (take_ind, fr_start) of that row.  `post` (after env.step, before the episode turnover): actions, reward, fail, done,
+// percent, custom_info and -- for the full 12-field record -- next_states, res_qpos, cc_action, cc_state, v_metas.  One workgroup per env, lanes over
+// the row's floats; every destination pointer may be null (field not recorded).
+struct RecordPre {
+    int n, T, t, ctx_T;
+    const float* obs; const uint8_t* fresh; const float* qpos; const float* ctx_qpos; const int* row; const int* cur_t; const int* row_len; const float* row_meta;
+    float* states; uint8_t* episode_start; float* curr_qpos; float* gt_target_qpos; float* meta;
+};
+struct RecordPost {
+    int n, T, t; float fr_num;
+    const float* action; const float* reward; const uint8_t* fail; const uint8_t* done; const float* percent; const float* c_info;
+    const float* obs; const float* qpos; const float* cc_action; const float* cc_state; const float* meta_t;      // meta_t: this step's [n, 2] rows of `meta` (pre wrote them)
+    float* actions; float* rewards; uint8_t* fails; uint8_t* dones; float* percents; float* c_infos;
+    float* next_states; float* res_qpos; float* cc_actions; float* cc_states; float* v_metas;
+};
+
+__device__ __forceinline__ void copy_row(float* __restrict__ dst, const float* __restrict__ src, int dim) {
+    for (int i = threadIdx.x; i < dim; i += blockDim.x) dst[i] = src[i];
+}
+
+__global__ void k_record_pre(RecordPre R) {
+    const int e = blockIdx.x;
+    if (e >= R.n) return;
+    const size_t at = (size_t)e * R.T + R.t;
+    if (R.states) copy_row(R.states + at * 105, R.obs + (size_t)e * 105, 105);
+    if (R.curr_qpos) copy_row(R.curr_qpos + at * 76, R.qpos + (size_t)e * 76, 76);
+    const int r = R.row ? R.row[e] : e;
+    if (R.gt_target_qpos) {
+        int f = R.cur_t[e] + 1;
+        const int last = R.row_len[r];
+        if (f > last) f = last;
+        copy_row(R.gt_target_qpos + at * 76, R.ctx_qpos + ((size_t)r * R.ctx_T + f) * 76, 76);
+    }
+    if (threadIdx.x == 0) {
+        if (R.episode_start) R.episode_start[at] = R.fresh[e];
+        if (R.meta) { R.meta[at * 2] = R.row_meta[(size_t)r * 2]; R.meta[at * 2 + 1] = R.row_meta[(size_t)r * 2 + 1]; }
+    }
+}
+
+__global__ void k_record_post(RecordPost R) {
+    const int e = blockIdx.x;
+    if (e >= R.n) return;
+    const size_t at = (size_t)e * R.T + R.t;
+    if (R.actions) copy_row(R.actions + at * 80, R.action + (size_t)e * 80, 80);
+    if (R.next_states) copy_row(R.next_states + at * 105, R.obs + (size_t)e * 105, 105);
+    if (R.res_qpos) copy_row(R.res_qpos + at * 76, R.qpos + (size_t)e * 76, 76);
+    if (R.cc_actions) copy_row(R.cc_actions + at * 75, R.cc_action + (size_t)e * 75, 75);
+    if (R.cc_states) copy_row(R.cc_states + at * 784, R.cc_state + (size_t)e * 784, 784);
+    if (R.c_infos && threadIdx.x < 6) R.c_infos[at * 6 + threadIdx.x] = R.c_info[(size_t)e * 6 + threadIdx.x];
+    if (threadIdx.x == 0) {
+        if (R.rewards) R.rewards[at] = R.reward[e];
+        if (R.fails) R.fails[at] = R.fail[e];
+        if (R.dones) R.dones[at] = R.done[e];
+        if (R.percents) R.percents[at] = R.percent[e];
+        if (R.v_metas) { R.v_metas[at * 3] = R.meta_t[at * 2]; R.v_metas[at * 3 + 1] = R.meta_t[at * 2 + 1]; R.v_metas[at * 3 + 2] = R.fr_num; }
+    }
+}
+
 // reverse scan per env over an env-major [N, T] layout (time contiguous per env), masks cut episodes
 // last_values (optional, [n]): V(s_T) of the state after each env's last row -- the bootstrap of an episode the horizon cut (the row's
 // mask is 1 there); null = 0, the reference's flat-batch recursion whose last row always ends an episode

@@ -649,6 +649,23 @@ __global__ void k_head(int n, const float* __restrict__ xpos, const float* __res
     for (int k = 0; k < 4; k++) out[(size_t)e * 7 + 3 + k] = xquat[(size_t)e * 96 + 4 * hb + k];
 }
 
+const float* kp_sim_field_device(kp_sim* s, int field) {
+    if (!s) return nullptr;
+    switch (field) {
+        case KP_QPOS: return s->qpos;
+        case KP_QVEL: return s->qvel;
+        case KP_XPOS: return s->xpos;
+        case KP_XQUAT: return s->xquat;
+        case KP_XIPOS: return s->xipos;
+        case KP_TARGET_QPOS: return s->t_qpos;
+        case KP_QPOS_D: return s->qpos_d;
+        case KP_QVEL_D: return s->qvel_d;
+        case KP_OBJ_QPOS: return s->obj_qpos;
+        case KP_OBJ_QVEL: return s->obj_qvel;
+        default: return nullptr;
+    }
+}
+
 int kp_sim_get(kp_sim* s, int field, float* out) {
     if (!s || !out) return fail("kp_sim_get: null argument");
     HIP_OK(hipSetDevice(s->device));
@@ -776,6 +793,31 @@ int kp_gae(int n, int T, const float* rewards, const float* masks, const float* 
 int kp_pool_advance(int n, int n_slots, const uint8_t* done, int32_t* head, int32_t* ahead, int32_t* row, void* stream) {
     if (n <= 0 || n_slots <= 0 || !done || !head || !ahead || !row) return fail("kp_pool_advance: bad arguments");
     hipLaunchKernelGGL(kp::k_pool_advance, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, n_slots, done, head, ahead, row);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int kp_rollout_record_pre(const kp_record_pre* r, void* stream) {
+    if (!r || r->n <= 0 || r->T <= 0 || r->t < 0 || r->t >= r->T) return fail("kp_rollout_record_pre: bad arguments");
+    if ((r->states && !r->obs) || (r->episode_start && !r->fresh) || (r->curr_qpos && !r->qpos) || (r->meta && !r->row_meta) ||
+        (r->gt_target_qpos && (!r->ctx_qpos || !r->cur_t || !r->row_len || r->ctx_T <= 0)))
+        return fail("kp_rollout_record_pre: a destination without its source");
+    kp::RecordPre R{r->n, r->T, r->t, r->ctx_T, r->obs, r->fresh, r->qpos, r->ctx_qpos, r->row, r->cur_t, r->row_len, r->row_meta,
+                    r->states, r->episode_start, r->curr_qpos, r->gt_target_qpos, r->meta};
+    hipLaunchKernelGGL(kp::k_record_pre, dim3(r->n), dim3(128), 0, (hipStream_t)stream, R);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int kp_rollout_record_post(const kp_record_post* r, void* stream) {
+    if (!r || r->n <= 0 || r->T <= 0 || r->t < 0 || r->t >= r->T) return fail("kp_rollout_record_post: bad arguments");
+    if ((r->actions && !r->action) || (r->rewards && !r->reward) || (r->fails && !r->fail) || (r->dones && !r->done) || (r->percents && !r->percent) ||
+        (r->c_infos && !r->c_info) || (r->next_states && !r->obs) || (r->res_qpos && !r->qpos) || (r->cc_actions && !r->cc_action) ||
+        (r->cc_states && !r->cc_state) || (r->v_metas && !r->meta))
+        return fail("kp_rollout_record_post: a destination without its source");
+    kp::RecordPost R{r->n, r->T, r->t, r->fr_num, r->action, r->reward, r->fail, r->done, r->percent, r->c_info, r->obs, r->qpos, r->cc_action, r->cc_state, r->meta,
+                     r->actions, r->rewards, r->fails, r->dones, r->percents, r->c_infos, r->next_states, r->res_qpos, r->cc_actions, r->cc_states, r->v_metas};
+    hipLaunchKernelGGL(kp::k_record_post, dim3(r->n), dim3(128), 0, (hipStream_t)stream, R);
     HIP_OK(hipGetLastError());
     return 0;
 }

@@ -269,9 +269,15 @@ class VectorSampler:
     NOISE_CHUNK = 16          # exploration noise is drawn for this many steps at a time (memory does not grow with the horizon)
 
     def __init__(self, env: BatchedHumanoidAREnv, policy: KinPolicy, record_qpos: bool = False, mean_action: bool = False,
-                 source: EpisodeSource | None = None, pool_depth: int = 4, record_full: bool = False):
+                 source: EpisodeSource | None = None, pool_depth: int = 4, record_full: bool = False, lagged: bool = True):
+        """lagged (default): the ring's one host read per pool_depth steps is taken ONE PERIOD LATE -- the counts are copied to pinned memory when a
+        period ends and read when the next one does, by which time the copy has long completed, so sample() never waits for the device and the
+        top-up's host work (the draw, init_context's launches, the row writes) overlaps the queued env-steps.  A refill then restores what was
+        missing a period ago, so an env can be 2 x pool_depth episodes ahead of its last refill: the ring holds 2 x pool_depth + 1 rows per env
+        instead of pool_depth + 1 (HBM: 0.11 MB per row).  lagged=False: the round-4 form, one blocking read per period."""
         self.env, self.policy, self.record_qpos, self.mean_action = env, policy, record_qpos or record_full, mean_action
         self.source, self.pool_depth, self.record_full = source, max(1, int(pool_depth)), record_full
+        self.lagged, self._pending = bool(lagged), None
         self.obs = self.hx = self.fresh = None
         self.head = self.ahead = None      # int32 [N]: ring slot every env is playing / fresh clips queued behind it
         self._since = 0                    # steps since the last top-up
@@ -284,7 +290,7 @@ class VectorSampler:
     # ------------------------------------------------------------------ episode pool
     @property
     def n_slots(self):
-        return self.pool_depth + 1
+        return (2 * self.pool_depth if self.lagged else self.pool_depth) + 1
 
     def _pool_init(self):
         """The ring: slot 0 = the clips the first episodes run on, slots 1 .. pool_depth = their successors, all freshly drawn."""
@@ -307,22 +313,40 @@ class VectorSampler:
             env.write_context_rows(ar + s * N, self.source.draw(N, dev))
         self.head = torch.zeros(N, dtype=torch.int32, device=dev)
         self.ahead = torch.full((N,), D - 1, dtype=torch.int32, device=dev)
-        self._since = 0
+        self._since, self._pending = 0, None
 
     def _top_up(self):
-        """Replace the queued clips the envs used up since the last call: one host read (how many), one batched draw, in-place row writes."""
+        """Replace the queued clips the envs used up: one host read (how many), one batched draw, in-place row writes.  Lagged form: the read is of
+        the counts copied out ONE period ago (no wait), the refill restores the ring to the level it had then; see __init__."""
         env, D = self.env, self.n_slots
         self._since = 0
         self.top_ups += 1
-        deficit = (D - 1) - self.ahead
-        total, low = torch.stack([deficit.sum(), self.ahead.min()]).tolist()
-        if low < 0:            # cannot happen: an env ends at most one episode per step and had pool_depth clips pool_depth steps ago
+        if not self.lagged:
+            deficit = (D - 1) - self.ahead
+            total, low = torch.stack([deficit.sum(), self.ahead.min()]).tolist()
+            self._refill(self.head, self.ahead, deficit, int(total), int(low))
+            return
+        if self._pending is not None:
+            head_s, ahead_s, deficit_s, host, ev = self._pending
+            ev.synchronize()                       # recorded a whole period of env-steps ago: complete unless the host has run that far ahead
+            total, low = host.tolist()
+            self._refill(head_s, ahead_s, deficit_s, int(total), int(low))
+        # this period's snapshot (after the refill above): the slots behind every env's current one that are free NOW stay free until they are rewritten
+        head_s, ahead_s = self.head.clone(), self.ahead.clone()
+        deficit_s = (D - 1) - ahead_s
+        host = torch.empty(2, dtype=torch.int64, pin_memory=True)
+        host.copy_(torch.stack([deficit_s.sum(), self.ahead.min().to(torch.int64)]), non_blocking=True)
+        ev = torch.cuda.Event(); ev.record()
+        self._pending = (head_s, ahead_s, deficit_s, host, ev)
+
+    def _refill(self, head, ahead, deficit, total, low):
+        if low < 0:            # cannot happen: an env ends at most one episode per step and the ring is sized for the periods between its refills
             self.pool_exhausted += 1
             raise kpsim.KinPolyNativeError("episode pool underflow: an env finished more episodes than steps since the last top-up")
         if total == 0:
             return
-        env_idx, rows = ring_refill_plan(self.head, self.ahead, D, int(total))
-        env.write_context_rows(rows, self.source.draw(int(total), env.device))
+        env_idx, rows = ring_refill_plan(head, ahead, self.n_slots, total)
+        self.env.write_context_rows(rows, self.source.draw(total, self.env.device))
         self.ahead.add_(deficit)
 
     def start(self):
@@ -352,38 +376,34 @@ class VectorSampler:
         cc_mean = env.mode == "test" or (env.mode == "train" and env.joint_controller)
         n_kin, n_cc = (0 if self.mean_action else 80), (0 if cc_mean else 75)
         noise = None
+        qview = env.sim.view("qpos") if (self.record_qpos or full) else None          # the simulator's own rows: the record kernels read them in place
         for t in range(T):
             if (n_kin + n_cc) and t % self.NOISE_CHUNK == 0:
                 noise = torch.randn((min(self.NOISE_CHUNK, T - t), N, n_kin + n_cc), device=dev, generator=env.gen)
             nz = None if noise is None else noise[t % self.NOISE_CHUNK]
-            S[:, t] = self.obs
-            E[:, t] = self.fresh
+            # Memory.push, first half (one launch): state, episode start, the pose before the step, the GT pose of the clip's next frame, (take, fr_start)
+            kpsim.record_pre(t, T, obs=self.obs, fresh=self.fresh, qpos=qview if self.record_qpos else None, ctx_qpos=env.ctx["qpos"] if self.record_qpos else None,
+                             row=env.row, cur_t=env.cur_t, row_len=env.row_len, row_meta=env.row_meta,
+                             states=S, episode_start=E, curr_qpos=Q, gt_target_qpos=G, meta=MT)
             action, self.hx = pol.select_action(self.obs, self.hx, self.mean_action, env.gen, nz[:, :n_kin] if n_kin else None)
             action = action.contiguous()
-            row = env.row.long()
-            if self.record_qpos:
-                Q[:, t] = env.sim.get("qpos")
-                G[:, t] = env.ctx["qpos"][row, torch.minimum(env.cur_t.long() + 1, env.row_len[row].long())]
-            meta = env.row_meta[row]
             obs, _, done, info = env.step(action, need_obs=full, cc_noise=nz[:, n_kin:] if n_cc else None)
-            A[:, t] = action
-            R[:, t] = info["custom_reward"]
-            F[:, t] = info["fail"]
-            D[:, t] = done; PC[:, t] = info["percent"]; MT[:, t] = meta; CI[:, t] = info["custom_info"]
-            if full:
-                NS[:, t] = obs; RQ[:, t] = env.sim.get("qpos"); CA[:, t] = info["cc_action"]; CS[:, t] = info["cc_state"]
-                VM[:, t, :2] = meta; VM[:, t, 2] = fr_num
+            # second half (one launch): action, reward, flags, custom_info and -- full record -- next state, pose after the step, UHC action / state, v_meta
+            kpsim.record_post(t, T, fr_num, action=action, reward=info["custom_reward"], fail=info["fail"], done=done, percent=info["percent"], c_info=info["custom_info"],
+                              obs=obs if full else None, qpos=qview if full else None, cc_action=info["cc_action"] if full else None, cc_state=info["cc_state"] if full else None,
+                              meta=MT, actions=A, rewards=R, fails=F, dones=D, percents=PC, c_infos=CI, next_states=NS, res_qpos=RQ, cc_actions=CA, cc_states=CS, v_metas=VM)
             # device-side episode turnover: a finished env moves to the next clip of its ring (env.row in place), then the masked reset
             if self.source is not None:
                 kpsim.pool_advance(done, self.head, self.ahead, env.row, self.n_slots)
             # env._obs: step() writes its own observation elsewhere, so this stays valid through the next step; the same launch zeroes the GRU state
             # of the finished envs in place (self.hx is this step's fresh output of select_action; hx0 above is a copy)
             self.obs = env.reset(done, policy_state=self.hx)
-            self.fresh = D[:, t]                # `done` itself lives in a buffer the step after next reuses
+            self.fresh = done                   # read by the next step's record_pre, before that step reuses the buffer (step() keeps two alternating sets)
             if self.source is not None:
                 self._since += 1
                 if self._since >= self.pool_depth:
                     self._top_up()
+        self.fresh = self.fresh.clone()         # across calls the env's buffers may be reused by others (evaluation, bare env-steps)
         M = (~D).float()
         # one host transfer per call: finished episodes -> freq_dict, launch status.  Every rank takes part in the job-wide exchanges BEFORE
         # any rank raises, so a stalled queue on one rank ends the job on all of them instead of leaving the others in a collective

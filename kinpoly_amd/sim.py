@@ -36,7 +36,7 @@ ABI_SYMBOLS = [
     "kp_sim_launch_cost", "kp_job_schedule", "kp_sim_fk_backward", "kp_sim_set_stream", "kp_sim_status_device", "kp_sim_mass_matrix",
     "kp_sim_contacts", "kp_gae_bootstrap", "kp_gru_gates_forward", "kp_gru_gates_backward", "kp_sim_phase_cycles_env",
     "kp_sim_post_step", "kp_sim_reset_rows", "kp_mcp_compose", "kp_sim_step_head", "kp_model_compile", "kp_model_load_xml",
-    "kp_mcp_tail", "kp_gru_cell_step", "kp_kin_advance", "kp_pool_advance",
+    "kp_mcp_tail", "kp_gru_cell_step", "kp_kin_advance", "kp_pool_advance", "kp_rollout_record_pre", "kp_rollout_record_post",
 ]
 
 
@@ -45,6 +45,19 @@ class KpCtx(C.Structure):
     _fields_ = [("T", C.c_int), ("head_pose", C.c_void_p), ("head_vels", C.c_void_p), ("obj_head_relative_poses", C.c_void_p),
                 ("action_one_hot", C.c_void_p), ("gt_bquat", C.c_void_p), ("gt_wbpos", C.c_void_p), ("obj_qpos", C.c_void_p),
                 ("cur_t", C.c_void_p), ("row", C.c_void_p)]
+
+
+class KpRecordPre(C.Structure):
+    """mirror of kp_record_pre (include/kinpoly_sim.h)"""
+    _fields_ = [(k, C.c_int) for k in ("n", "T", "t", "ctx_T")] + [(k, C.c_void_p) for k in (
+        "obs", "fresh", "qpos", "ctx_qpos", "row", "cur_t", "row_len", "row_meta", "states", "episode_start", "curr_qpos", "gt_target_qpos", "meta")]
+
+
+class KpRecordPost(C.Structure):
+    """mirror of kp_record_post"""
+    _fields_ = [("n", C.c_int), ("T", C.c_int), ("t", C.c_int), ("fr_num", C.c_float)] + [(k, C.c_void_p) for k in (
+        "action", "reward", "fail", "done", "percent", "c_info", "obs", "qpos", "cc_action", "cc_state", "meta",
+        "actions", "rewards", "fails", "dones", "percents", "c_infos", "next_states", "res_qpos", "cc_actions", "cc_states", "v_metas")]
 
 
 class KpRewardCfg(C.Structure):
@@ -97,6 +110,9 @@ def load_library(path: str | None = None):
     L.kp_sim_post_step.argtypes = [P, C.POINTER(KpCtx), C.POINTER(KpRewardCfg), C.c_void_p, C.c_void_p, C.c_int, F, F, U8, F, U8, U8, F, C.c_void_p, F]; L.kp_sim_post_step.restype = C.c_int
     L.kp_sim_reset_rows.argtypes = [P, F, F, C.c_void_p, U8, C.c_void_p, C.c_int, F, C.c_int, F, F, F]; L.kp_sim_reset_rows.restype = C.c_int
     L.kp_pool_advance.argtypes = [C.c_int, C.c_int, U8, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]; L.kp_pool_advance.restype = C.c_int
+    L.kp_sim_field_device.argtypes = [P, C.c_int]; L.kp_sim_field_device.restype = C.c_void_p
+    L.kp_rollout_record_pre.argtypes = [C.POINTER(KpRecordPre), C.c_void_p]; L.kp_rollout_record_pre.restype = C.c_int
+    L.kp_rollout_record_post.argtypes = [C.POINTER(KpRecordPost), C.c_void_p]; L.kp_rollout_record_post.restype = C.c_int
     L.kp_mcp_tail.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, F, F, F, C.c_int, F, F, F, C.c_int, F, F, C.c_void_p]; L.kp_mcp_tail.restype = C.c_int
     L.kp_kin_advance.argtypes = [C.c_int, F, F, C.c_float, F, F, C.c_void_p]; L.kp_kin_advance.restype = C.c_int
     L.kp_gru_cell_step.argtypes = [C.c_int, C.c_int, C.c_int, F, F, F, F, F, F, F, F, C.c_void_p]; L.kp_gru_cell_step.restype = C.c_int
@@ -279,6 +295,21 @@ class KpSim:
         _check(self.L.kp_sim_get(self.h, fid, _ptr(out, self.n, dim)), "kp_sim_get")
         return out
 
+    def view(self, field: str) -> torch.Tensor:
+        """Zero-copy [N, dim] device view of a STORED field (kp_sim_field_device: qpos, qvel, xpos, ..., obj_qpos; not the derived read-outs).  The
+        view follows the simulator: it shows the state as of the work enqueued before the reader on the same stream, and is overwritten by the next step --
+        for a consumer that copies the rows it needs in its own launch (the sampler's record kernel), not for keeping."""
+        cache = self.__dict__.setdefault("_views", {})
+        if field not in cache:
+            fid = FIELDS[field]
+            ptr = self.L.kp_sim_field_device(self.h, fid)
+            if not ptr:
+                raise KinPolyNativeError(f"kp_sim_field_device: '{field}' is not a stored field")
+            dim = self.L.kp_field_dim(fid)
+            iface = {"shape": (self.n, dim), "typestr": "<f4", "data": (int(ptr), False), "version": 3, "strides": None}
+            cache[field] = torch.as_tensor(type("_KpField", (), {"__cuda_array_interface__": iface})(), device=self.device)
+        return cache[field]
+
     def set_full_state(self, qpos, qvel, qpos_d, qvel_d, env_mask=None):
         _check(self.L.kp_sim_set_full_state(self.h, _ptr(qpos, self.n, NQ), _ptr(qvel, self.n, NV), _ptr(qpos_d, self.n, NQ),
                                             _ptr(qvel_d, self.n, NV), _mask_ptr(env_mask, self.n)), "kp_sim_set_full_state")
@@ -408,6 +439,44 @@ def job_schedule(n_substeps: int, substeps_per_job: int = 4, taper: int = 1) -> 
     if n < 0:
         raise KinPolyNativeError(f"kp_job_schedule: {L.kp_last_error().decode()}")
     return list(out[:n])
+
+
+def _dptr(t, dtype=None, name="tensor"):
+    """device pointer of a contiguous tensor (None -> NULL); bool tensors are passed as their uint8 storage"""
+    if t is None:
+        return None
+    if t.dtype == torch.bool:
+        t = t.view(torch.uint8)
+    if not (t.is_cuda and t.is_contiguous()) or (dtype is not None and t.dtype != dtype):
+        raise ValueError(f"{name}: expected a contiguous {dtype} device tensor, got {t.dtype} {'contiguous' if t.is_contiguous() else 'strided'} on {t.device}")
+    return t.data_ptr()
+
+
+def record_pre(t: int, T: int, obs=None, fresh=None, qpos=None, ctx_qpos=None, row=None, cur_t=None, row_len=None, row_meta=None,
+               states=None, episode_start=None, curr_qpos=None, gt_target_qpos=None, meta=None):
+    """kp_rollout_record_pre: the before-the-step half of the sampler's per-step record, one launch (see include/kinpoly_sim.h)."""
+    L = load_library()
+    first = next(x for x in (obs, qpos, fresh) if x is not None)
+    f32, i32, u8 = torch.float32, torch.int32, torch.uint8
+    r = KpRecordPre(first.shape[0], int(T), int(t), 0 if ctx_qpos is None else int(ctx_qpos.shape[1]),
+                    _dptr(obs, f32, "obs"), _dptr(fresh, u8, "fresh"), _dptr(qpos, f32, "qpos"), _dptr(ctx_qpos, f32, "ctx_qpos"), _dptr(row, i32, "row"), _dptr(cur_t, i32, "cur_t"),
+                    _dptr(row_len, i32, "row_len"), _dptr(row_meta, f32, "row_meta"), _dptr(states, f32, "states"), _dptr(episode_start, u8, "episode_start"),
+                    _dptr(curr_qpos, f32, "curr_qpos"), _dptr(gt_target_qpos, f32, "gt_target_qpos"), _dptr(meta, f32, "meta"))
+    _check(L.kp_rollout_record_pre(C.byref(r), C.c_void_p(torch.cuda.current_stream(first.device).cuda_stream)), "kp_rollout_record_pre")
+
+
+def record_post(t: int, T: int, fr_num=0.0, action=None, reward=None, fail=None, done=None, percent=None, c_info=None, obs=None, qpos=None, cc_action=None, cc_state=None, meta=None,
+                actions=None, rewards=None, fails=None, dones=None, percents=None, c_infos=None, next_states=None, res_qpos=None, cc_actions=None, cc_states=None, v_metas=None):
+    """kp_rollout_record_post: the after-the-step half (one launch)."""
+    L = load_library()
+    first = next(x for x in (action, reward, done) if x is not None)
+    f32, u8 = torch.float32, torch.uint8
+    r = KpRecordPost(first.shape[0], int(T), int(t), float(fr_num), _dptr(action, f32, "action"), _dptr(reward, f32, "reward"), _dptr(fail, u8, "fail"), _dptr(done, u8, "done"),
+                     _dptr(percent, f32, "percent"), _dptr(c_info, f32, "c_info"), _dptr(obs, f32, "obs"), _dptr(qpos, f32, "qpos"), _dptr(cc_action, f32, "cc_action"),
+                     _dptr(cc_state, f32, "cc_state"), _dptr(meta, f32, "meta"), _dptr(actions, f32, "actions"), _dptr(rewards, f32, "rewards"), _dptr(fails, u8, "fails"),
+                     _dptr(dones, u8, "dones"), _dptr(percents, f32, "percents"), _dptr(c_infos, f32, "c_infos"), _dptr(next_states, f32, "next_states"), _dptr(res_qpos, f32, "res_qpos"),
+                     _dptr(cc_actions, f32, "cc_actions"), _dptr(cc_states, f32, "cc_states"), _dptr(v_metas, f32, "v_metas"))
+    _check(L.kp_rollout_record_post(C.byref(r), C.c_void_p(torch.cuda.current_stream(first.device).cuda_stream)), "kp_rollout_record_post")
 
 
 def pool_advance(done: torch.Tensor, head: torch.Tensor, ahead: torch.Tensor, row: torch.Tensor, n_slots: int):

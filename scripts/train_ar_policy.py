@@ -56,6 +56,8 @@ def main():
     ap.add_argument("--no_reference_bugs", action="store_true", help="corrected forms instead of the reference's behaviour: gradient clip at every PPO step (the reference's "
                     "generator-consumed clip acts on a run's first step only), LambdaLR continued on --iter N (the reference restarts its decay), min of the workers' min_episode_reward")
     ap.add_argument("--rl_update", type=int, default=1, help="without --cfg: policy_specs.rl_update (PPO epochs)"); ap.add_argument("--step_update", type=int, default=1, help="without --cfg: policy_specs.step_update")
+    ap.add_argument("--eval_first_last", action="store_true", help="play every training take whole with mean actions before the first and after the last iteration (no freq_dict "
+                    "feedback) and print mean percent / coverage / joint-angle error: a like-for-like measure of what the updates did to the policy")
     ap.add_argument("--load", type=str, default="", help="start from this checkpoint (reference layout) instead of seeded random init; schedules and optimiser state start fresh")
     ap.add_argument("--min_horizon", type=int, default=0, help="with --cfg: lower bound of the per-env horizon derived from min_batch_size (0 = fr_num / 4; ADVICE r4: 10000 / 4096 envs "
                     "would be 3-step fragments that hang on the V bootstrap)")
@@ -139,6 +141,16 @@ def main():
             print(json.dumps({"warm_start": ws}), flush=True)
             if cfg is not None:
                 agent.save_checkpoint(cfg.checkpoint_path(1))
+    def fixed_eval(tag):
+        from kinpoly_amd.evaluate import eval_dataset
+        env_e, builder = agent._eval_engine(None)
+        res = eval_dataset(env_e, agent.policy_net, builder, ds)
+        pc = np.array([r["percent"] for r in res.values()])
+        err = np.mean([np.abs(np.asarray(r["pred"])[:, 7:] - np.asarray(r["target"])[:, 7:]).mean() for r in res.values()])
+        if rank == 0:
+            print(json.dumps({"fixed_eval": tag, "takes": len(pc), "mean_percent": float(pc.mean()), "coverage": int((pc == 1).sum()), "mean_abs_joint_err": float(err)}), flush=True)
+    if args.eval_first_last:
+        fixed_eval("before")
     for it in range(first, last):
         info = agent.optimize_policy(it)
         if interval and (it + 1) % interval == 0:      # optimize_policy's periodic test-set evaluation, then train_ar_policy.py:95-97
@@ -151,6 +163,8 @@ def main():
             if log_file is not None:
                 log_file.write(line + "\n"); log_file.flush()
             print(json.dumps({"iter": it, **{k: (float("%.6g" % v) if isinstance(v, float) else v) for k, v in info.items()}, "log": log.as_dict()}), flush=True)
+    if args.eval_first_last:
+        fixed_eval("after")
     if args.save and rank == 0:
         agent.save_checkpoint(args.save)
     if world > 1:

@@ -70,7 +70,8 @@ def test_update_loop_fp32_hip_path_follows_the_reference_fixture(golden):
     for it in range(2):
         tag = f"it{it}_"
         assert rep[tag + "adv"] < 2e-5 and rep[tag + "ret"] < 2e-5, rep          # normalised advantages / returns (measured 5e-7)
-        assert rep[tag + "surr"] < 5e-4, rep                                      # surrogate values of -0.09 ... -0.17
+        assert rep[tag + "surr"] < (2e-5, 5e-3)[it], rep                          # surrogate values of -0.09 ... -0.17: measured 1.3e-6 in iteration 0, 8e-4 in iteration 1 (whose start
+                                                                                  # is iteration 0's fp32 result: 20 supervised Adam steps at 5e-4 downstream of fp32 gradients)
         assert rep[tag + "vloss_rel"] < 1e-5 and rep[tag + "step_rel"] < 1e-2, rep      # measured 3e-7 / 1.2e-3
         for key, v in rep.items():
             # Adam's step is lr * g / (|g| + eps): an entry whose gradient is rounding noise in fp32 takes a full +-lr step either way, so single
@@ -122,3 +123,52 @@ def test_mujoco_live_pin():
     assert rep["contact"]["oracle"]["first_step_above_1e-3"] is None, rep["contact"]
     first = rep["contact"]["hip"]["first_step_above_1e-3"]        # free-running trajectories part at contact knife edges sooner or later:
     assert first is None or first >= 10, rep["contact"]["hip"]      # the per-step bound is asked of the first ten control steps, the rest is reported
+
+
+def test_fused_record_kernels_equal_the_row_copies():
+    """kp_rollout_record_pre / _post (Memory.push for all envs, agent_ar.py:582-597): every field at time t equals the strided torch copies they replace,
+    including the GT pose looked up at min(cur_t + 1, row_len) of the env's context row and fields that are not recorded (NULL destinations)."""
+    from kinpoly_amd import sim as kpsim
+    g = torch.Generator(device="cuda").manual_seed(0)
+    N, T, R, Tc = 50, 7, 120, 9
+    r = lambda *s: torch.randn(*s, device="cuda", generator=g)       # noqa: E731
+    b = lambda *s: torch.rand(*s, device="cuda", generator=g) < 0.4   # noqa: E731
+    ctx_qpos, row_meta = r(R, Tc, 76), r(R, 2)
+    row = torch.randint(0, R, (N,), device="cuda", generator=g, dtype=torch.int32)
+    row_len = torch.randint(2, Tc, (R,), device="cuda", generator=g, dtype=torch.int32)
+    S, E, Q, G, MT = torch.zeros(N, T, 105, device="cuda"), torch.zeros(N, T, dtype=torch.bool, device="cuda"), torch.zeros(N, T, 76, device="cuda"), torch.zeros(N, T, 76, device="cuda"), torch.zeros(N, T, 2, device="cuda")
+    A, Rw, F, D, PC, CI = torch.zeros(N, T, 80, device="cuda"), torch.zeros(N, T, device="cuda"), torch.zeros(N, T, dtype=torch.bool, device="cuda"), torch.zeros(N, T, dtype=torch.bool, device="cuda"), torch.zeros(N, T, device="cuda"), torch.zeros(N, T, 6, device="cuda")
+    NS, RQ, CA, CS, VM = torch.zeros(N, T, 105, device="cuda"), torch.zeros(N, T, 76, device="cuda"), torch.zeros(N, T, 75, device="cuda"), torch.zeros(N, T, 784, device="cuda"), torch.zeros(N, T, 3, device="cuda")
+    want = {k: v.clone() for k, v in dict(S=S, E=E, Q=Q, G=G, MT=MT, A=A, Rw=Rw, F=F, D=D, PC=PC, CI=CI, NS=NS, RQ=RQ, CA=CA, CS=CS, VM=VM).items()}
+    for t in (0, 3, 6):
+        obs, fresh, qpos = r(N, 105), b(N), r(N, 76)
+        cur_t = torch.randint(0, Tc, (N,), device="cuda", generator=g, dtype=torch.int32)
+        kpsim.record_pre(t, T, obs=obs, fresh=fresh, qpos=qpos, ctx_qpos=ctx_qpos, row=row, cur_t=cur_t, row_len=row_len, row_meta=row_meta,
+                         states=S, episode_start=E, curr_qpos=Q, gt_target_qpos=G, meta=MT)
+        rl = row.long()
+        want["S"][:, t] = obs; want["E"][:, t] = fresh; want["Q"][:, t] = qpos; want["MT"][:, t] = row_meta[rl]
+        want["G"][:, t] = ctx_qpos[rl, torch.minimum(cur_t.long() + 1, row_len[rl].long())]
+        act, rew, fail, done, pc, ci = r(N, 80), r(N), b(N), b(N), r(N), r(N, 6)
+        obs2, qpos2, cca, ccs = r(N, 105), r(N, 76), r(N, 75), r(N, 784)
+        kpsim.record_post(t, T, 100.0, action=act, reward=rew, fail=fail, done=done, percent=pc, c_info=ci, obs=obs2, qpos=qpos2, cc_action=cca, cc_state=ccs, meta=MT,
+                          actions=A, rewards=Rw, fails=F, dones=D, percents=PC, c_infos=CI, next_states=NS, res_qpos=RQ, cc_actions=CA, cc_states=CS, v_metas=VM)
+        want["A"][:, t] = act; want["Rw"][:, t] = rew; want["F"][:, t] = fail; want["D"][:, t] = done; want["PC"][:, t] = pc; want["CI"][:, t] = ci
+        want["NS"][:, t] = obs2; want["RQ"][:, t] = qpos2; want["CA"][:, t] = cca; want["CS"][:, t] = ccs
+        want["VM"][:, t, :2] = row_meta[rl]; want["VM"][:, t, 2] = 100.0
+    got = dict(S=S, E=E, Q=Q, G=G, MT=MT, A=A, Rw=Rw, F=F, D=D, PC=PC, CI=CI, NS=NS, RQ=RQ, CA=CA, CS=CS, VM=VM)
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
+    # the short record (no pose / full fields): NULL destinations are left alone, the others written
+    S2 = torch.zeros_like(S)
+    kpsim.record_pre(1, T, obs=obs, fresh=fresh, row=row, cur_t=cur_t, row_len=row_len, row_meta=row_meta, states=S2, episode_start=E, meta=MT)
+    assert torch.equal(S2[:, 1], obs) and float(S2[:, 0].abs().sum()) == 0
+    with pytest.raises(Exception):
+        kpsim.record_pre(T, T, obs=obs, states=S2)             # t out of range
+    # the simulator's own rows as a zero-copy source
+    sim = kpsim.KpSim(kpsim.KpModel(), N, 0)
+    std = np.load(os.path.join(ROOT, "tests", "golden", "standing_neutral.npz"))
+    q0 = torch.tensor(np.tile(std["qpos"], (N, 1)), dtype=torch.float32, device="cuda"); q0[:, 0] += torch.arange(N, device="cuda")
+    sim.set_state(q0, torch.zeros(N, 75, device="cuda"))
+    assert torch.equal(sim.view("qpos"), sim.get("qpos")) and torch.equal(sim.view("qpos"), q0)
+    kpsim.record_pre(2, T, qpos=sim.view("qpos"), curr_qpos=Q)
+    assert torch.equal(Q[:, 2], q0)

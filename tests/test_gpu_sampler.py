@@ -84,7 +84,8 @@ def test_every_episode_draws_a_new_clip_and_feeds_freq_dict():
         np.testing.assert_allclose(b.curr_qpos[e, t].cpu().numpy()[7:], ds.data["qpos"][ti][fs].numpy()[7:], atol=1e-6)
 
 
-def test_every_episode_runs_on_a_fresh_clip_at_fail_rate_one():
+@pytest.mark.parametrize("lagged", [True, False])
+def test_every_episode_runs_on_a_fresh_clip_at_fail_rate_one(lagged):
     """random-init networks fail (almost) every episode after one step; every one of those episodes must still run on its own
     freshly drawn clip through init_context (agent_ar.py:518-535), the pool must not run dry (it cannot, by construction), every done flag is one
     episode in freq_dict, and unused queued clips survive the sample() calls instead of being re-drawn."""
@@ -99,9 +100,9 @@ def test_every_episode_runs_on_a_fresh_clip_at_fail_rate_one():
     env = BatchedHumanoidAREnv(n, 0, mode="train", seed=3)
     net = TrajARNet().to(env.device)
     src = EpisodeSource(dataset=ds, ctx_builder=PolicyARContext(net, fk_sim, need_rollout=False, keep_context_feat=False), sampling_temp=0.3, sampling_freq=0.5)
-    sampler = VectorSampler(env, net, source=src, pool_depth=depth, record_full=True)
+    sampler = VectorSampler(env, net, source=src, pool_depth=depth, record_full=True, lagged=lagged)
     sampler.start()
-    D = depth + 1
+    D = (2 * depth if lagged else depth) + 1          # lagged: the host read of the ring is taken one period late, the ring holds two periods' worth of clips
     assert src.n_drawn == D * n and env.ctx["qpos"].shape[0] == D * n and "ar_qpos" not in env.ctx
     n_done_total, pairs, first_meta = 0, [], None
     for call in range(3):
@@ -111,8 +112,9 @@ def test_every_episode_runs_on_a_fresh_clip_at_fail_rate_one():
         assert float(b.fails.float().mean()) > 0.9, "random-init networks should fail nearly every step"
         assert sampler.pool_exhausted == 0 and int(sampler.ahead.min()) >= 0
         assert len(b.episodes["percent"]) == n_done, "every done flag is one recorded episode (no replays to leave out)"
-        # T is a multiple of pool_depth: the last top-up of the call has replaced every clip used so far, and nothing more
-        assert src.n_drawn == D * n + n_done_total and int(sampler.ahead.min()) == depth
+        # T is a multiple of pool_depth: the last top-up of the call has replaced every clip used so far (lagged: used up to one period ago), and nothing more
+        lag_done = int(dn[:, -depth:].sum()) if lagged else 0
+        assert src.n_drawn == D * n + n_done_total - lag_done and int(sampler.ahead.min()) == depth
         meta = vm[..., 0].astype(np.int64) * 100000 + vm[..., 1].astype(np.int64)          # (take, fr_start) of the clip every row ran on
         if first_meta is not None:      # the envs' clips continue across calls (same episode unless the last row of the previous call ended it)
             cont = ~last_done

@@ -62,3 +62,39 @@ def test_refill_plan_orders_an_envs_new_clips_behind_its_queue():
     np.testing.assert_array_equal(env_idx.numpy(), [0, 0, 0, 2, 2, 2, 2])
     # env 0: playing slot 4, slot 0 queued -> new clips in slots 1, 2, 3; env 2: playing slot 2, nothing queued -> slots 3, 4, 0, 1
     np.testing.assert_array_equal((rows // N).numpy(), [1, 2, 3, 3, 4, 0, 1])
+
+
+@pytest.mark.parametrize("depth", [1, 2, 4])
+def test_lagged_ring_never_runs_dry_and_never_rewrites_a_row_in_play(depth):
+    """VectorSampler(lagged=True): the counts a top-up acts on are those of the PREVIOUS period (the host reads them without waiting for the device), so a
+    refill restores the ring to the level it had a period ago; with 2 * depth + 1 rows per env an env that ends an episode on every step still always
+    finds a queued clip, and the rows a late refill writes -- planned from the old snapshot -- are never the one in play nor a queued, unplayed one."""
+    from kinpoly_amd.rollout import ring_refill_plan
+    N, D = 29, 2 * depth + 1
+    g = torch.Generator().manual_seed(10 + depth)
+    head = torch.zeros(N, dtype=torch.int32); ahead = torch.full((N,), D - 1, dtype=torch.int32)
+    clip = torch.arange(D * N).clone()
+    next_id = D * N
+    played = [(e, int(clip[e])) for e in range(N)]
+    pending = None
+    for step in range(1, 10 * depth + 1):
+        p = [1.0, 1.0, 0.3, 0.0][(step // (2 * depth)) % 4]      # stretches where EVERY env ends an episode on every step
+        done = torch.rand(N, generator=g) < p
+        head, ahead = _advance(head, ahead, done, D)
+        assert int(ahead.min()) >= 0, "the ring ran dry"
+        for e in done.nonzero().flatten().tolist():
+            played.append((e, int(clip[int(head[e]) * N + e])))
+        if step % depth == 0:
+            if pending is not None:
+                head_s, ahead_s, deficit_s = pending
+                total = int(deficit_s.sum())
+                env_idx, rows = ring_refill_plan(head_s, ahead_s, D, total)
+                in_play = head.long() * N + torch.arange(N)
+                assert not set(rows.tolist()) & set(in_play.tolist()), "a late refill overwrote the clip an env is on"
+                queued = {((int(head[e]) + k) % D) * N + e for e in range(N) for k in range(1, int(ahead[e]) + 1)}
+                assert not set(rows.tolist()) & queued, "a late refill overwrote a queued clip that was never played"
+                clip[rows] = torch.arange(next_id, next_id + total); next_id += total
+                ahead = ahead + deficit_s
+            pending = (head.clone(), ahead.clone(), (D - 1) - ahead)
+    ids = [c for _, c in played]
+    assert len(ids) == len(set(ids)), "an env played the same drawn clip twice"
