@@ -196,10 +196,10 @@ def parity_live(env, sampler, workload, a_track, n=256):
 
 
 def mujoco_pin_report():
-    """null until a MuJoCo binding is importable on the box; then the live pin of tests/mujoco_pin.py (model arrays, free fall, contact workload)"""
+    """null until a MuJoCo binding is importable on the box; then the live pin of tests/mj_pin.py (model arrays, free fall, contact workload)"""
     try:
         sys.path.insert(1, os.path.join(ROOT, "tests"))
-        import mujoco_pin
+        import mj_pin as mujoco_pin
         if mujoco_pin.find_mujoco() is None:
             return None
         return mujoco_pin.pin_report(n_free_fall=300, n_contact=30)
@@ -403,7 +403,7 @@ def object_scene_launches(device_index, threads):
     return out
 
 
-def sampler_regime(device_index, seed, horizon=TRAIN_HORIZON, calls=4, warm=2, threads=64, amp=0.05, profile=False):
+def sampler_regime(device_index, seed, horizon=TRAIN_HORIZON, calls=4, warm=2, threads=64, amp=0.05, profile=False, pool_depth=4, lagged=True):
     """`VectorSampler.sample(horizon)` in the regime of a policy that has learnt to track: every episode on a clip drawn from a
     StateARDataset through init_context (ring of pool_depth + 1 rows per env, on-demand top-up), all twelve memory fields' worth of per-step records,
     and a kinematic policy whose GEMMs run but whose output is replaced by the clip's next pose + N(0, e^-3.2) noise -- so episodes last, a few per cent
@@ -447,7 +447,7 @@ def sampler_regime(device_index, seed, horizon=TRAIN_HORIZON, calls=4, warm=2, t
         data["init_qpos"], data["init_qvel"] = data["qpos"][:, 0].contiguous(), data["qvel"][:, 0].contiguous()
         return data
     src.draw = draw
-    sampler = VectorSampler(env, pol, record_qpos=True, source=src, pool_depth=4)
+    sampler = VectorSampler(env, pol, record_qpos=True, source=src, pool_depth=pool_depth, lagged=lagged)
     sampler.start()
     for _ in range(warm):
         sampler.sample(horizon)
@@ -455,6 +455,7 @@ def sampler_regime(device_index, seed, horizon=TRAIN_HORIZON, calls=4, warm=2, t
     t0 = time.perf_counter()
     done = fail = 0.0
     prof = None
+    drawn0, tops0 = src.n_drawn, sampler.top_ups
     if profile:
         prof = torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU, torch.profiler.ProfilerActivity.CUDA])
         prof.__enter__()
@@ -473,7 +474,7 @@ def sampler_regime(device_index, seed, horizon=TRAIN_HORIZON, calls=4, warm=2, t
     torch.cuda.synchronize()
     tb = (time.perf_counter() - t0) / calls
     out = {"T_sample": ts, "T_bare_env_steps": tb, "overhead": ts / tb, "horizon": horizon, "envs": ENVS_PER_GPU, "calls": calls, "done_per_step_frac": done / calls, "fail_per_step_frac": fail / calls,
-           "top_ups_per_call": sampler.top_ups / (calls + warm), "clips_drawn_per_call": src.n_drawn / (calls + warm), "pool_exhausted": sampler.pool_exhausted,
+           "top_ups_per_call": (sampler.top_ups - tops0) / calls, "pool_depth": pool_depth, "lagged_ring_read": lagged, "ring_rows_per_env": sampler.n_slots, "clips_drawn_per_call": (src.n_drawn - drawn0) / calls, "pool_exhausted": sampler.pool_exhausted,
            "env_steps_per_s": ENVS_PER_GPU * horizon / ts,
            "note": "VectorSampler.sample with a tracking stand-in policy (its GEMMs run; output = clip's next pose + noise): dataset-driven episodes through init_context, ring top-ups, "
                    "per-step records of all memory fields; T_bare_env_steps = rollout_steps on the same engine (random-init policy output, episodes end more often: an upper bound of the bare cost)"}

@@ -147,21 +147,37 @@ class TrajARNet(KinPolicy):
         sequence itself is the `use_context` / `use_of` observation block (humanoid_ar_v1.py:151-155), off in kin_poly.yml, and 4096 clips of 100
         frames would be 1.7 GB of it per draw.  On the device every step is the two gate GEMMs + kp_gru_cell_step (as the rollout's GRU step)."""
         feat = self._context_input(data)
-        N, T = feat.shape[:2]
+        N0, T = feat.shape[:2]
         cell = self.context_rnn.rnn_f
-        hx = torch.zeros((N, self.rnn_hdim), device=feat.device, dtype=feat.dtype)
-        acc = torch.zeros_like(hx)
         w = self._frame_weights(data, T, feat)                     # None unless the batch is ragged
         fast = feat.is_cuda and feat.dtype == torch.float32 and not torch.is_grad_enabled()
+        if fast and N0 % 256:
+            # a sampler's top-up draws however many clips were used up (497, 530, ...): the T recurrent GEMMs [N, H] x [H, 3H] then run on whatever kernel the
+            # library's heuristics pick for that odd N (48 TFLOP/s picks were seen).  Rows are independent, so the batch is padded with zero rows to the next
+            # multiple of 256 -- a handful of regular shapes -- and the padding is dropped at the end (at most 255 wasted rows)
+            pad = 256 - N0 % 256
+            feat = torch.cat([feat, feat.new_zeros((pad, T, feat.shape[2]))], 0)
+            if w is not None:
+                w = torch.cat([w, w.new_zeros((pad, T))], 0)
+        N = feat.shape[0]
+        hx = torch.zeros((N, self.rnn_hdim), device=feat.device, dtype=feat.dtype)
+        acc = torch.zeros_like(hx)
         ft = feat.transpose(0, 1).contiguous()                     # time-major: every step's input rows are contiguous
+        CH = max(1, min(T, (1 << 27) // max(1, N * 3 * self.rnn_hdim)))      # input-gate GEMM for CH frames at a time (<= 512 MB of gates): one launch instead of CH
+        gi_chunk = None
         for t in range(T):
             if fast:
-                gi = torch.nn.functional.linear(ft[t], cell.weight_ih)
+                if t % CH == 0:
+                    gi_chunk = torch.nn.functional.linear(ft[t:t + CH].reshape(-1, ft.shape[2]), cell.weight_ih).view(-1, N, 3 * self.rnn_hdim)
                 gh = torch.nn.functional.linear(hx, cell.weight_hh)
-                hx = kpsim.gru_cell_step(gi, gh, cell.bias_ih, cell.bias_hh, hx)
+                hx = kpsim.gru_cell_step(gi_chunk[t % CH], gh, cell.bias_ih, cell.bias_hh, hx)
             else:
                 hx = cell(ft[t], hx)
-            acc = acc + (hx if w is None else hx * w[:, t, None])
+            if w is None:
+                acc.add_(hx)
+            else:
+                acc.add_(hx * w[:, t, None])
+        acc = acc[:N0]
         return acc / T if w is None else acc
 
     @staticmethod

@@ -347,6 +347,37 @@ __device__ __forceinline__ void aba_elim3(EnvLds& s, const Lane8& L, const float
         rh[j] = rhs[d];
     }
     float Uo[3], Do[3], uo[3];
+#if defined(KP_PK_ELIM) && KP_PK_ELIM
+    // Round-5 experiment (VERDICT r4 #5a): the two 8-term blocks of a joint elimination -- the row product U_r = sum_k IA[r][k] s[k] and the rank-1
+    // update IA[r][k] -= (U_r / D) U[k] -- as hand-placed packed fp32 operations (v_pk_mul_f32 / v_pk_fma_f32 on register pairs), everything else
+    // unchanged.  The blanket SLP vectoriser lost to register pairing on this kernel (build.py OPT_FLAGS); here the operands of a pair are adjacent by
+    // construction.  NOT the default: see DESIGN section 6 for the measurement.  (The pairwise row product sums in another order: not bit-identical.)
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 IA2[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) IA2[k] = f2{IAx[2 * k], IAx[2 * k + 1]};
+#pragma unroll
+    for (int j = 2; j >= 0; j--) {
+        f2 acc = IA2[0] * f2{sxa[j][0], sxa[j][1]};
+#pragma unroll
+        for (int k = 1; k < 4; k++) acc = __builtin_elementwise_fma(IA2[k], f2{sxa[j][2 * k], sxa[j][2 * k + 1]}, acc);
+        const float Ur = acc.x + acc.y;
+        const float sr = sxa[j][0];
+        const float dsum = sum8(sr * Ur), usum = sum8(sr * pA);
+        const float D = dsc[j] + dsum, u = rh[j] - usum;
+        const float Dinv = rcp_nr(D);
+        float Ux[8];
+        gather8(Ur, Ux);
+        const float ur = -(Ur * Dinv);
+        const f2 ur2 = f2{ur, ur};
+#pragma unroll
+        for (int k = 0; k < 4; k++) IA2[k] = __builtin_elementwise_fma(ur2, f2{Ux[2 * k], Ux[2 * k + 1]}, IA2[k]);
+        pA += Ur * (u * Dinv);
+        Uo[j] = Ur; Do[j] = Dinv; uo[j] = u;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) { IAx[2 * k] = IA2[k].x; IAx[2 * k + 1] = IA2[k].y; }
+#else
 #pragma unroll
     for (int j = 2; j >= 0; j--) {
         float Ur = 0.f;
@@ -364,6 +395,7 @@ __device__ __forceinline__ void aba_elim3(EnvLds& s, const Lane8& L, const float
         pA += Ur * (u * Dinv);
         Uo[j] = Ur; Do[j] = Dinv; uo[j] = u;
     }
+#endif
     if (store_ok && rowok) {
 #pragma unroll
         for (int j = 0; j < 3; j++) s.U[6 * (d0 + j) + r] = Uo[j];

@@ -108,11 +108,11 @@ def test_mujoco_live_pin():
     """The pin against MuJoCo itself (humanoid_im.py:527; mujoco_env.py:23-24): SKIPS -- does not pass -- while no MuJoCo binding is importable.  With one:
     compiled-model arrays within 1e-6, free fall (1500 substeps) within 1e-6 of the oracle's fp64 trajectory, the product within north_star's
     1e-3 rad per control step on BASELINE configs[2]."""
-    import mujoco_pin as MP
+    import mj_pin as MP
     if MP.find_mujoco() is None:
         pytest.skip("no MuJoCo binding importable (mujoco / mujoco_py): parity stays unpinned at the MuJoCo boundary")
     sys.path.insert(0, os.path.join(ROOT, "tools"))
-    from mujoco_pin import pin_report
+    from mj_pin import pin_report
     import importlib.util
     spec = importlib.util.spec_from_file_location("kp_pin_cli", os.path.join(ROOT, "tools", "mujoco_pin.py"))
     cli = importlib.util.module_from_spec(spec); spec.loader.exec_module(cli)
@@ -172,3 +172,18 @@ def test_fused_record_kernels_equal_the_row_copies():
     assert torch.equal(sim.view("qpos"), sim.get("qpos")) and torch.equal(sim.view("qpos"), q0)
     kpsim.record_pre(2, T, qpos=sim.view("qpos"), curr_qpos=Q)
     assert torch.equal(Q[:, 2], q0)
+
+
+@pytest.mark.parametrize("k,mask", [(2, 2), (3, 2)])
+def test_concurrent_handles_on_their_own_streams_are_bit_identical_to_serial_runs(k, mask):
+    """include/kinpoly_sim.h's threading contract allows several kp_sim handles of a process on several streams (AgentAR.eval_policy builds a second
+    engine): K handles of 4096 envs (one of them with the scene's free objects), each on its own HIP stream, stepped for 50 control steps with no host
+    synchronisation in between, end in the same states bit for bit as when they run one after the other, with clean status words.  Run in a child
+    process under a hard time limit: a hung queue kernel fails the test instead of the suite (profiles/r04/pipeline_streams.log saw S = 3 hang)."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "micro", "concurrent_handles.py"), str(k), "4096", "50", str(mask)],
+                           capture_output=True, text=True, timeout=240)
+    except subprocess.TimeoutExpired:
+        pytest.fail(f"{k} concurrent handles did not finish 50 control steps in 240 s")
+    assert r.returncode == 0 and "CONCURRENT_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-800:])

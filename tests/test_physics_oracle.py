@@ -496,12 +496,12 @@ def test_known_answer_set0_constants_of_the_compiled_model():
         assert float(inert[10]) == pytest.approx(wt, rel=1e-9) and float(inert[11]) == pytest.approx(wr, rel=1e-9)
 
 
-# ---------------------------------------------------------------------------------------------- the dormant MuJoCo pin harness (tests/mujoco_pin.py)
+# ---------------------------------------------------------------------------------------------- the dormant MuJoCo pin harness (tests/mj_pin.py)
 def test_mjcf_written_from_the_blob_is_the_reference_scene():
     """mjcf_from_kpm: local-coordinate MJCF of the reference scene from the compiled blob (what a MuJoCo binding that no longer reads
     coordinate="global" would be handed).  Checked structurally here; MuJoCo's own reading of it is the live pin."""
     import xml.etree.ElementTree as ET
-    import mujoco_pin as MP
+    import mj_pin as MP
     from kinpoly_amd.model_compiler import DEFAULT_KPM, read_kpm
     from kinpoly_amd import sim as kpsim
     kpm = read_kpm(DEFAULT_KPM)
@@ -546,7 +546,7 @@ def test_pin_harness_runs_end_to_end_with_the_oracle_in_mujocos_seat():
     """The harness's stepping logic (do_simulation's loop around a backend's qM / qfrc_bias, the free-fall and contact protocols, the report)
     exercised with OracleBackend where MuJoCo will sit: the Python control loop around the backend equals the C oracle's own do_simulation,
     two oracle backends never part, and without a MuJoCo binding the report is None (bench.py prints "mujoco_pin": null)."""
-    import mujoco_pin as MP
+    import mj_pin as MP
     from kinpoly_amd.model_compiler import DEFAULT_KPM, read_kpm
     kpm = read_kpm(DEFAULT_KPM)
     std = np.load(os.path.join(ROOT, "tests", "golden", "standing_neutral.npz"))

@@ -3,7 +3,7 @@
 
     python tools/mujoco_pin.py [--free_fall 1500] [--contact 150] [--no_hip] [--write_xml scene.xml]
 
-The harness itself is test infrastructure (tests/mujoco_pin.py: MJCF from the compiled blob, model comparison, BASELINE configs[1] / configs[2]
+The harness itself is test infrastructure (tests/mj_pin.py: MJCF from the compiled blob, model comparison, BASELINE configs[1] / configs[2]
 stepped on MuJoCo, on the fp64 oracle and on the HIP simulator); this is its command line.  Reference call sites: uhc/envs/humanoid_im.py:527,
 uhc/khrylib/rl/envs/common/mujoco_env.py:23-24."""
 import argparse
@@ -35,7 +35,7 @@ def main():
     ap.add_argument("--free_fall", type=int, default=1500); ap.add_argument("--contact", type=int, default=150)
     ap.add_argument("--no_hip", action="store_true"); ap.add_argument("--write_xml", type=str, default="")
     args = ap.parse_args()
-    import mujoco_pin as MP
+    import mj_pin as MP
     if args.write_xml:
         from kinpoly_amd.model_compiler import DEFAULT_KPM, read_kpm
         open(args.write_xml, "w").write(MP.mjcf_from_kpm(read_kpm(DEFAULT_KPM)))
