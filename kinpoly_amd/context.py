@@ -151,11 +151,11 @@ class TrajARNet(KinPolicy):
         cell = self.context_rnn.rnn_f
         w = self._frame_weights(data, T, feat)                     # None unless the batch is ragged
         fast = feat.is_cuda and feat.dtype == torch.float32 and not torch.is_grad_enabled()
-        if fast and N0 % 256:
+        if fast and N0 % 64:
             # a sampler's top-up draws however many clips were used up (497, 530, ...): the T recurrent GEMMs [N, H] x [H, 3H] then run on whatever kernel the
             # library's heuristics pick for that odd N (48 TFLOP/s picks were seen).  Rows are independent, so the batch is padded with zero rows to the next
-            # multiple of 256 -- a handful of regular shapes -- and the padding is dropped at the end (at most 255 wasted rows)
-            pad = 256 - N0 % 256
+            # multiple of 64 (regular tile counts) and the padding is dropped at the end (at most 63 wasted rows)
+            pad = 64 - N0 % 64
             feat = torch.cat([feat, feat.new_zeros((pad, T, feat.shape[2]))], 0)
             if w is not None:
                 w = torch.cat([w, w.new_zeros((pad, T))], 0)

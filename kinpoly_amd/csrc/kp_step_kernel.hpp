@@ -335,6 +335,9 @@ struct Lane8 {
 // out = (M + diag(s.extra) [+ J^T D_active J])^-1 rhs.  Leaves s.sv[b] = sum over ancestor dofs cdof_d out_d
 // (the spatial "acceleration" of every body induced by out).  rhs/out are LDS vectors (may alias).
 // eliminate the three dofs d0+2, d0+1, d0 of one body from its articulated inertia (row r in XOR order)
+#ifndef KP_PK_ELIM
+#define KP_PK_ELIM 1
+#endif
 __device__ __forceinline__ void aba_elim3(EnvLds& s, const Lane8& L, const float* rhs, int d0, bool store_ok, float* IAx, float& pA) {
     const int r = L.r;
     const bool rowok = r < 6;
@@ -347,11 +350,13 @@ __device__ __forceinline__ void aba_elim3(EnvLds& s, const Lane8& L, const float
         rh[j] = rhs[d];
     }
     float Uo[3], Do[3], uo[3];
-#if defined(KP_PK_ELIM) && KP_PK_ELIM
-    // Round-5 experiment (VERDICT r4 #5a): the two 8-term blocks of a joint elimination -- the row product U_r = sum_k IA[r][k] s[k] and the rank-1
-    // update IA[r][k] -= (U_r / D) U[k] -- as hand-placed packed fp32 operations (v_pk_mul_f32 / v_pk_fma_f32 on register pairs), everything else
-    // unchanged.  The blanket SLP vectoriser lost to register pairing on this kernel (build.py OPT_FLAGS); here the operands of a pair are adjacent by
-    // construction.  NOT the default: see DESIGN section 6 for the measurement.  (The pairwise row product sums in another order: not bit-identical.)
+#if KP_PK_ELIM
+    // Round 5 (VERDICT r4 #5a): the two 8-term blocks of a joint elimination -- the row product U_r = sum_k IA[r][k] s[k] and the rank-1 update
+    // IA[r][k] -= (U_r / D) U[k] -- as hand-placed packed fp32 operations (v_pk_mul_f32 / v_pk_fma_f32 on register pairs), everything else unchanged.
+    // The blanket SLP vectoriser lost to register pairing on this kernel (build.py OPT_FLAGS); here the operands of a pair are adjacent by construction:
+    // 576 scalar fp32 instructions become 324 packed ones, no extra v_mov, 208 -> 212 VGPRs (floor kernel), launch 2.665 -> 2.611 ms on the metric's
+    // workload in three A/B pairs (profiles/r05/pk_elim_ab.log), objects 4.79 -> 4.78 ms.  -DKP_PK_ELIM=0 builds the scalar form (the pairwise row
+    // product sums in another order: the two builds are not bit-identical; every parity test and sweep was re-run on this one).
     typedef float f2 __attribute__((ext_vector_type(2)));
     f2 IA2[4];
 #pragma unroll

@@ -119,6 +119,8 @@ def episode_log(rewards: torch.Tensor, done: torch.Tensor, c_info: torch.Tensor 
     The return of the episode that ends at (e, t) is cs[e, t] - cs[e, t'] with t' its predecessor's last row (cs = running sum over the call,
     + carry when there is no predecessor in this call); rewards are non-negative, so cs at the latest done row is a running max."""
     N, T = rewards.shape
+    if carry is None:                          # a caller that drives the sampler's pieces by hand and never went through start(): every env begins an episode
+        carry = torch.zeros(N, dtype=torch.float64, device=rewards.device)
     r = rewards.double()
     cs = torch.cumsum(r, 1)
     at_done = torch.where(done, cs, torch.zeros_like(cs))
@@ -617,6 +619,12 @@ class PPOTrainer:
         # (the reference evaluates it twice; one of its 11 policy forwards is redundant), so epoch 0's ratio is exactly 1 as it is there
         fixed_log_probs, surr = None, None
         self.surr_history = []                     # every epoch's surrogate, on the device (one host read at the end)
+        if __import__("os").environ.get("KP_DEBUG_RESET_PPO_MOMENTUM") == "1":
+            # diagnosis only (tools/update_ablation.sh): Adam's first moment of the policy optimiser is zeroed at the start of every iteration,
+            # to tell a stale momentum (built at parameters the supervised step updates have since moved) from a wrong gradient
+            for st in self.opt_p.state.values():
+                if "exp_avg" in st:
+                    st["exp_avg"].zero_()
         for _ in range(self.num_optim_epoch):
             means = self.policy.unroll(states, batch.episode_start, hx0)
             log_probs = self.policy.log_prob(means.reshape(N * T, -1), flat_actions)
@@ -628,6 +636,13 @@ class PPOTrainer:
             self._clip()
             self.opt_p.step()
         stats = {"value_loss": float(vloss.detach()), "surr_loss": float(surr.detach())} if surr is not None else {}
+        if surr is not None:
+            # how far the epochs moved the policy on its own batch: the log-ratio of the LAST epoch's forward against the behaviour policy (one host read for
+            # the three numbers).  A surrogate that ends above 0 is the signature of a log-ratio spread far beyond the clip range: min(r A, clip(r) A) caps the
+            # gain of a sample the step moved the right way at 0.2 |A| and leaves the loss of one it moved the wrong way unbounded
+            lr_ = (log_probs.detach() - fixed_log_probs).reshape(-1)
+            d = torch.stack([lr_.std(), (lr_.abs() > 0.2).float().mean(), (means.detach().reshape(N * T, -1) - flat_actions).abs().mean()]).tolist()
+            stats.update(ppo_log_ratio_std=d[0], ppo_frac_outside_clip=d[1])
         if self.cc_policy is not None and batch.cc_state is not None:
             stats["cc_surr_loss"] = self.update_controller(batch, adv, ind)
         return stats

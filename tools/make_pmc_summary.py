@@ -9,7 +9,7 @@ import sys
 
 src, wl, cmd = sys.argv[1], sys.argv[2], sys.argv[3]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-dst = os.path.join(ROOT, "gpurun_out", os.environ.get("KP_ROUND", "r04") + "_prof", "summary")
+dst = os.path.join(ROOT, "gpurun_out", os.environ.get("KP_ROUND", "r05") + "_prof", "summary")
 os.makedirs(dst, exist_ok=True)
 KERNEL = "kp_step_queue_kernel"
 N_SIMD, CLOCK_GHZ = 1024, 2.35          # 256 CUs x 4 SIMDs; shader clock under this kernel (tools/micro/queue_timeline.py)
@@ -28,7 +28,7 @@ def counters(tag):
 
 def launch_ms():
     for path in glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True):
-        shutil.copy(path, os.path.join(dst, os.environ.get("KP_ROUND", "r04") + f"_kernel_stats_{wl}.csv"))
+        shutil.copy(path, os.path.join(dst, os.environ.get("KP_ROUND", "r05") + f"_kernel_stats_{wl}.csv"))
         with open(path) as f:
             for row in csv.DictReader(f):
                 if KERNEL in row.get("Name", ""):
