@@ -15,6 +15,23 @@
  *     kp_sim_diag() which synchronises that stream;
  *   - return value 0 = ok, negative = error (kp_last_error() gives the text, thread-local);
  *   - handles are opaque; one kp_sim is used by one host thread at a time.
+ *
+ * Several handles in one process
+ *   Any number of kp_sim handles (of the same or of different models) may live in a process and run at the same time on different
+ *   HIP streams (kp_sim_create's stream / kp_sim_set_stream): a handle owns every array its kernels write -- state, job queue and its
+ *   counters, status words, timing events -- and the library keeps no process-wide device state (no __constant__ / __device__ symbols),
+ *   so launches of different handles do not interact except by sharing the machine.  The persistent job-queue kernel of the control step
+ *   (kp_step_queue_kernel) waits only for jobs that a RUNNING wavefront of the same launch is about to publish, never for a wavefront that
+ *   has yet to become resident, so co-scheduled launches cannot starve each other into a deadlock; a wait that exceeds 2 s raises the
+ *   handle's stall flag (kp_sim_status_device word 2 -> the next host-synchronising call fails) instead of hanging.
+ *   Measured on MI355X (tests/test_gpu_round5.py::test_concurrent_handles_...; tools/micro/concurrent_handles.py, profiles/r05): two and
+ *   three handles of 4096 envs each -- floor scenes and scenes with free objects, in any mix -- stepped 50 control steps on their own
+ *   streams with no host synchronisation end in the same states, bit for bit, as when they run one after the other, with clean status
+ *   words; the round of launches is 5 ... 20 % shorter than the serial one (the launches' tails overlap).  (The device hang that rounds
+ *   3 / 4 saw with THREE sub-batched env-steps on three streams involves the library GEMMs of the policies between these launches at
+ *   1365 = 4096 / 3 rows, not these kernels: DESIGN.md section 6.)
+ *   What is NOT supported: two host threads in one handle at once; one handle on two streams at once (kp_sim_set_stream moves it, the
+ *   caller orders the old stream's work before the new stream's).
  */
 #ifndef KINPOLY_SIM_H
 #define KINPOLY_SIM_H

@@ -10,7 +10,7 @@ import bench
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "objects"
 Ss = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "1,2,3,4").split(",")]
-N = bench.ENVS_PER_GPU
+N = int(os.environ.get("KP_PIPE_N", bench.ENVS_PER_GPU))      # KP_PIPE_N=3072: three sub-batches of 1024 instead of 1365
 for S in Ss:
     streams = [torch.cuda.Stream() for _ in range(S)]
     parts = []

@@ -46,3 +46,7 @@ $T 200 python tools/mujoco_pin.py > $E/mujoco_pin.log 2>&1
 find gpurun_out/r05_prof $E -type f -size +2000k -delete
 for f in pytest_gpu smoke floor_fuzz obj_fuzz contact_compare concurrent_handles soak; do echo "== $f"; grep -v Warn $E/$f.log | tail -4 | cut -c1-400; done
 cut -c1-500 $E/bench_default.json
+# the update ablation: one UHC, one warm start, then {none, PPO, step, both} in fp32 and `both` in fp64 from the same checkpoint, with the fixed evaluation
+$T 2400 bash -c "DTYPES=fp32 bash tools/update_ablation.sh; DTYPES=fp64 VARIANTS=both bash tools/update_ablation.sh" > $E/update_ablation.log 2>&1
+mkdir -p $E/update_ablation && cp gpurun_out/update_ablation/*.log gpurun_out/update_ablation/table.txt $E/update_ablation/
+tail -8 $E/update_ablation/table.txt | cut -c1-400
