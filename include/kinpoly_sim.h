@@ -28,8 +28,8 @@
  *   three handles of 4096 envs each -- floor scenes and scenes with free objects, in any mix -- stepped 50 control steps on their own
  *   streams with no host synchronisation end in the same states, bit for bit, as when they run one after the other, with clean status
  *   words; the round of launches is 5 ... 20 % shorter than the serial one (the launches' tails overlap).  (The device hang that rounds
- *   3 / 4 saw with THREE sub-batched env-steps on three streams involves the library GEMMs of the policies between these launches at
- *   1365 = 4096 / 3 rows, not these kernels: DESIGN.md section 6.)
+ *   3 / 4 saw with THREE sub-batched env-steps on three streams is reproduced by the policies' library GEMMs ALONE at 1365 = 4096 / 3 rows on
+ *   three streams -- no kernel of this library in the loop -- and not at 1024 rows: profiles/r05/gemm_streams_probe.log)
  *   What is NOT supported: two host threads in one handle at once; one handle on two streams at once (kp_sim_set_stream moves it, the
  *   caller orders the old stream's work before the new stream's).
  */

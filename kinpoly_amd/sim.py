@@ -36,7 +36,7 @@ ABI_SYMBOLS = [
     "kp_sim_launch_cost", "kp_job_schedule", "kp_sim_fk_backward", "kp_sim_set_stream", "kp_sim_status_device", "kp_sim_mass_matrix",
     "kp_sim_contacts", "kp_gae_bootstrap", "kp_gru_gates_forward", "kp_gru_gates_backward", "kp_sim_phase_cycles_env",
     "kp_sim_post_step", "kp_sim_reset_rows", "kp_mcp_compose", "kp_sim_step_head", "kp_model_compile", "kp_model_load_xml",
-    "kp_mcp_tail", "kp_gru_cell_step", "kp_kin_advance", "kp_pool_advance", "kp_rollout_record_pre", "kp_rollout_record_post",
+    "kp_mcp_tail", "kp_gru_cell_step", "kp_kin_advance", "kp_pool_advance", "kp_rollout_record_pre", "kp_rollout_record_post", "kp_sim_field_device",
 ]
 
 

@@ -52,10 +52,11 @@ def test_episode_log_equals_the_row_by_row_logger_across_calls():
             assert log.num_episodes == 0 and log.min_episode_reward == math.inf
         assert log.avg_c_reward == pytest.approx(want["total_c_reward"] / (N * T))
         logs.append(log)
-    m = LoggerRL.merge(logs)                                                     # LoggerRL.merge (:44-70): sums, min of mins, max of maxes
+    m = LoggerRL.merge(logs, reference_bugs=False)                               # LoggerRL.merge (:44-70): sums, min of mins, max of maxes (the corrected form)
     assert m.num_steps == 4 * N * T and m.num_episodes == sum(x.num_episodes for x in logs)
     assert m.min_c_reward == min(x.min_c_reward for x in logs) and m.max_episode_reward == max(x.max_episode_reward for x in logs)
     assert m.min_episode_reward == min(x.min_episode_reward for x in logs)
+    assert LoggerRL.merge(logs).min_episode_reward == max(x.min_episode_reward for x in logs)      # the default reproduces the reference's max of mins (logger_rl.py:60)
     assert m.avg_c_reward == pytest.approx(sum(x.total_c_reward for x in logs) / m.num_steps)
     assert set(m.as_dict()) >= {"num_steps", "avg_episode_len", "avg_c_info", "avg_c_reward"}
 
