@@ -156,7 +156,7 @@ class AgentAR:
         if _collective_on(self.trainer.group):                   # LoggerRL.merge over the workers (agent_ar.py:677) = over the ranks here
             every = [None] * dist.get_world_size(self.trainer.group)
             dist.all_gather_object(every, log, group=self.trainer.group)
-            log = LoggerRL.merge(every)
+            log = LoggerRL.merge(every, self.reference_bugs)
         info["log"] = log
         if self.result_dir is not None and self.source.dataset is not None and (not dist.is_initialized() or dist.get_rank() == 0):
             import os
