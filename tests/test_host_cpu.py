@@ -2,6 +2,7 @@
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -249,3 +250,29 @@ def test_parity_tool_scene_generators_are_deterministic_and_fp32_valued():
     f = _scenes.floor_scenes(20)
     assert f["qpos"].shape == (20, 76) and f["target"].shape == (20, 76) and set(f["kind"]) == {0, 1, 2, 3, 4}
     assert np.abs(np.linalg.norm(f["qpos"][:, 3:7], axis=1) - 1).max() < 1e-6 and f["blk"] is None and all(o == {} for o in f["objects"])
+
+
+def test_profile_stamps_null_stale_figures(tmp_path, monkeypatch):
+    """bench.py reads PMC / parity summaries from profiles/ only when they were taken on THIS device code: kernel_source_sha256 (csrc/* + flags) is
+    stable, changes with the flag list, and a committed parity log with another stamp comes back as {"stale": true} instead of as figures."""
+    import importlib
+    from kinpoly_amd import build as kpbuild
+    a = kpbuild.kernel_source_sha256()
+    assert a == kpbuild.kernel_source_sha256() and len(a) == 16
+    monkeypatch.setenv("KP_HIPCC_FLAGS", "-DKP_SOMETHING=1")
+    assert kpbuild.kernel_source_sha256() != a
+    monkeypatch.delenv("KP_HIPCC_FLAGS")
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    monkeypatch.setattr(bench, "PROFILE_DIR", str(tmp_path))
+    body = ("bench:tracked: 2048 scenes (seed 4) x 45 substeps, every substep from a common fp32-rounded state: one-substep |dqpos| median 4.9e-08 p99 1.1e-07 max 1.0e-03\n"
+            "   substeps whose contact sets differ between the two sides at the same state: 22 of 92160; same entities but another vertex of a hull at the same height (to 1e-7): 13; "
+            "with the same contact points: max |dqpos| 4.3e-07, above 1e-6: 0\n")
+    (tmp_path / "substep_parity_bench.log").write_text("kernel_source_sha256 0000000000000000\n" + body)
+    got = bench.parity_summary("tracked")
+    assert got["stale"] is True and "substeps" not in got
+    (tmp_path / "substep_parity_bench.log").write_text(f"kernel_source_sha256 {a}\n" + body)
+    got = bench.parity_summary("tracked")
+    assert got["substeps"] == 92160 and got["contact_set_diffs"] == 22 and got["same_entities_other_hull_vertex"] == 13 and got["max_same_set_dqpos"] == 4.3e-07
+    (tmp_path / "substep_parity_bench.log").write_text(body)             # no stamp at all (a log of an earlier round): stale
+    assert bench.parity_summary("tracked")["stale"] is True
