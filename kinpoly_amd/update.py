@@ -78,6 +78,8 @@ class ParamUpdate:
             for dst, src in ((self.policy, self.rollout_policy), (self.value, self.rollout_value)):
                 for d, s in zip(dst.parameters(), src.parameters()):
                     d.copy_(s)
+            if hasattr(self.policy, "refresh_log_std"):
+                self.policy.refresh_log_std()          # the constructor's log_std in the master's precision again (an fp32 copy of -3.2 is -3.2000000477)
 
     def update_params(self, batch, epoch=0, dataset=None):
         """AgentAR.update_params (agent_ar.py:682-752) on a RolloutBatch; returns the losses it saw."""
