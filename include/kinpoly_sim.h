@@ -78,7 +78,12 @@ void kp_model_free(kp_model*);
  * env's next job itself instead of queueing it -- the costliest envs are the ones a launch ends on, and with two envs per slot every trip through the
  * FIFO costs them about one job's length of waiting (objects workload 6.49 -> 5.78 ms per launch; bit-identical results);
  * "lpt_order" (1 / 0 / -1 = default: on when free objects are simulated): longest-env-first order of the workgroups (plain launch) or of the
- * envs' first jobs in the FIFO, from the previous control step's per-env cycles. */
+ * envs' first jobs in the FIFO, from the previous control step's per-env cycles;
+ * "warm_extrap" (beta; default -1 = automatic: 0.75 when the scene's free objects are simulated, 0 otherwise): starting point of the constraint solve.  0 is
+ * MuJoCo's: the previous substep's solution a_{k-1} (mjData.qacc_warmstart).  beta != 0 starts from a_{k-1} + beta (a_{k-1} - a_{k-2}) from the second substep
+ * of a kp_sim_step_ctrl call on (every call begins with the plain warm start).  Same strictly convex problem, same minimiser, same termination tests: only the
+ * iteration path changes (fewer Newton iterations where accelerations change smoothly -- falls, impacts; more on quiet standing states); results do not
+ * depend on how a control step is cut into jobs. */
 int kp_model_set_option(kp_model*, const char* name, double value);
 double kp_model_get_option(const kp_model*, const char* name);
 

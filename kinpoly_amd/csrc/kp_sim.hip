@@ -28,6 +28,7 @@ int fail(const std::string& m) { g_err = m; return -1; }
 struct kp_model {
     kp::HostModel h;
     int contact = 1, limits = 1, stale = 1, solver_iter = 100, threads = 64, dynamic_objects = 1, lpt_order = -1, substeps_per_job = 4, queue_slots = 0, job_taper = 1, queue_fence = 1, queue_heavy = 160, queue_prio = 0;
+    float warm_extrap = -1.f;      // < 0: automatic (0.75 when the scene's free objects are simulated, 0 otherwise); see kp_step_kernel.hpp
     int planemesh_max = 3; double planemesh_tol = 0.3;   // mjc_PlaneConvex's maxplanemesh / tolplanemesh (the blob's `planemesh`)
     int actuation = 1;            // 0: no stable-PD torque, no residual force (ctrl = qfrc_applied = 0): torque-free flight for the energy test
     double solver_tol = 1e-8, gravity_z = -9.81, gravity_x = 0.0, gravity_y = 0.0;   // solver_iter / solver_tol: mjOption.iterations / tolerance of the reference model (kp_model_load)
@@ -40,7 +41,7 @@ struct kp_sim {
     std::vector<void*> allocs;
     kp::DevTables T{};
     kp::Params P{};
-    float *qpos = nullptr, *qvel = nullptr, *qpos_d = nullptr, *qvel_d = nullptr, *warm = nullptr;
+    float *qpos = nullptr, *qvel = nullptr, *qpos_d = nullptr, *qvel_d = nullptr, *warm = nullptr, *warm2 = nullptr;
     float *xpos = nullptr, *xquat = nullptr, *xipos = nullptr, *scratch = nullptr;
     float *prev_bquat = nullptr, *prev_hpos = nullptr, *diffw = nullptr;
     float *t_qpos = nullptr, *t_wbpos = nullptr, *t_wbquat = nullptr, *t_bquat = nullptr, *t_com = nullptr;
@@ -224,9 +225,9 @@ int job_schedule(int nsub, int spj, int taper, int* sizes) {
 }
 
 int launch_step(kp_sim* s, const float* action, int nsub, const uint8_t* mask, bool time_it) {
-    kp::StepArgs A;
+    kp::StepArgs A{};
     A.T = s->T; A.P = s->P; A.n_envs = s->n; A.n_substeps = nsub;
-    A.qpos = s->qpos; A.qvel = s->qvel; A.qpos_d = s->qpos_d; A.qvel_d = s->qvel_d; A.warm = s->warm;
+    A.qpos = s->qpos; A.qvel = s->qvel; A.qpos_d = s->qpos_d; A.qvel_d = s->qvel_d; A.warm = s->warm; A.warm2 = s->warm2;
     A.target_qpos = s->t_qpos; A.action = action; A.env_mask = mask;
     A.xpos = s->xpos; A.xquat = s->xquat; A.xipos = s->xipos; A.diag = s->diag; A.prof = s->prof;
     A.geoms = s->geoms; A.ngeom = s->ngeom; A.dbg_contacts = s->dbg_contacts;
@@ -234,6 +235,7 @@ int launch_step(kp_sim* s, const float* action, int nsub, const uint8_t* mask, b
     A.order = nullptr; A.cost = s->cost;
     const bool obj = s->has_objects;
     if (obj && s->model->threads != 64) return fail("object contact needs threads_per_env = 64");
+    A.warm_extrap = s->model->warm_extrap < 0.f ? (obj ? 0.75f : 0.f) : s->model->warm_extrap;      // the Newton solve's starting point (kp_step_kernel.hpp)
     size_t lds = obj ? sizeof(kp::EnvLdsObj) : sizeof(kp::EnvLds);
     hipEvent_t e0 = s->ev0, e1 = s->ev1;
     if (time_it) {      // a launch that is being captured into a hipGraph carries no timing events (they could not be read back)
@@ -349,6 +351,7 @@ int kp_model_set_option(kp_model* m, const char* name, double v) {
     else if (k == "queue_fence") m->queue_fence = v != 0;
     else if (k == "queue_heavy") m->queue_heavy = std::max(0, (int)v);
     else if (k == "queue_prio") m->queue_prio = v != 0;
+    else if (k == "warm_extrap") m->warm_extrap = (float)v;
     else if (k == "queue_slots") { if (v < 0) return fail("queue_slots must be >= 0 (0 = resident wave slots of the device)"); m->queue_slots = (int)v; }
     else if (k == "substeps_per_job") { if (v < 0 || v > 255) return fail("substeps_per_job must be 0 (whole control step per workgroup) .. 255"); m->substeps_per_job = (int)v; }
     else if (k == "threads_per_env") { if (v != 64 && v != 128 && v != 256) return fail("threads_per_env must be 64, 128 or 256"); m->threads = (int)v; }
@@ -377,6 +380,7 @@ double kp_model_get_option(const kp_model* m, const char* name) {
     if (k == "queue_fence") return m->queue_fence;
     if (k == "queue_heavy") return m->queue_heavy;
     if (k == "queue_prio") return m->queue_prio;
+    if (k == "warm_extrap") return m->warm_extrap;
     if (k == "threads_per_env") return m->threads;
     if (k == "timestep") return m->h.opt[kp::OPT_TIMESTEP];
     if (k == "lds_bytes_per_env") return (double)sizeof(kp::EnvLds);
@@ -394,7 +398,7 @@ kp_sim* kp_sim_create(const kp_model* m, int n_envs, int device_id, void* stream
     bool ok = build_tables(s);
     size_t N = n_envs;
     s->qpos = dalloc(s, N * 76, &ok); s->qvel = dalloc(s, N * 75, &ok); s->qpos_d = dalloc(s, N * 76, &ok);
-    s->qvel_d = dalloc(s, N * 75, &ok); s->warm = dalloc(s, N * 75, &ok);
+    s->qvel_d = dalloc(s, N * 75, &ok); s->warm = dalloc(s, N * 75, &ok); s->warm2 = dalloc(s, N * 75, &ok);
     s->xpos = dalloc(s, N * 72, &ok); s->xquat = dalloc(s, N * 96, &ok); s->xipos = dalloc(s, N * 72, &ok);
     s->t_qpos = dalloc(s, N * 76, &ok); s->t_wbpos = dalloc(s, N * 72, &ok); s->t_wbquat = dalloc(s, N * 96, &ok);
     s->t_bquat = dalloc(s, N * 96, &ok); s->t_com = dalloc(s, N * 72, &ok);

@@ -50,6 +50,8 @@ struct StepArgs {
     int n_envs, n_substeps;
     // per-env state (HBM, row-major [N, dim])
     float *qpos, *qvel, *qpos_d, *qvel_d, *warm;
+    float *warm2;              // [N][75] hand-over of the previous-but-one solution between the jobs of a control step (warm_extrap)
+    float warm_extrap;         // beta of the extrapolated Newton start a_{k-1} + beta (a_{k-1} - a_{k-2}); 0 = MuJoCo's plain warm start
     const float *target_qpos, *action;
     const uint8_t* env_mask;  // optional: envs with mask==0 are skipped
     // outputs: kinematics of the last forward pass (x_14 in stale mode)
@@ -1969,6 +1971,12 @@ __device__ __forceinline__ void step_body(const StepArgs& A, const int env_in, c
     KP_SYNC();
     float qd_save_q[(D_NQ + NT - 1) / NT], qd_save_v[(D_NV + NT - 1) / NT];
     int niter_total = 0, maxcon = 0, nfact_total = 0, ncap_total = 0;
+    // Extrapolated start of the Newton solve (model option warm_extrap; round 5): see the solve's call site below.  The previous-but-one solution is
+    // available from the control step's second substep on -- within a job in the words of qacc_s, across jobs through A.warm2 -- so whether a
+    // substep extrapolates depends on its index in the control step only, never on how the control step is cut into jobs.
+    const float beta = A.warm_extrap;
+    bool have_prev = false;
+    if (beta != 0.f && Q && part > 0 && A.warm2) { for (int i = tid; i < D_NV; i += NT) s.qacc_s[i] = gld<Q>(A.warm2 + (size_t)env * D_NV + (unsigned)(i)); have_prev = true; }
     unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
     const bool prof = A.prof != nullptr;
 #define KP_T(i) if (prof) { t1 = __builtin_readcyclecounter(); pc[i] += t1 - t0; t0 = t1; }
@@ -2042,12 +2050,38 @@ __device__ __forceinline__ void step_body(const StepArgs& A, const int env_in, c
         for (int i = tid; i < D_NV; i += NT) s.extra[i] = 0.f;
         KP_SYNC();
         Lane8 L8; L8.init(kp_launder(tid), T.sched8);          // lives through the Newton solve
+        // Start of the Newton solve.  MuJoCo starts from the previous substep's solution a_{k-1} (qacc_warmstart); with warm_extrap = beta != 0 the start is
+        // a_{k-1} + beta (a_{k-1} - a_{k-2}).  The problem is strictly convex: the minimiser and the termination tests do not depend on the starting point, only
+        // the path does (INTEGRATION deviation 6 already starts from the warm start where MuJoCo might pick qacc_smooth).  Where accelerations change
+        // smoothly from substep to substep -- falls, impacts, a humanoid going down on the table -- the extrapolated point is closer to the solution and has its
+        // active set more often; on quiet standing states the change is contact chatter and extrapolating it gains nothing or costs.  Measured (MI355X, 60 timed
+        // steps, profiles/r05/warm_extrap_*.log), launch ms / Newton iterations per substep at beta = 0 | 0.5 | 0.75 | 1: objects 4.77 / 1.95 | 4.61 / 1.87 |
+        // 4.52 / 1.87 | 4.62 / 1.94; random_init 3.17 / 2.96 | 2.75 / 2.30 | 2.51 / 1.88 | 2.75 / 2.27; tracked (the metric) 2.616 / 2.06 | 2.621 / 2.02 | 2.636 / 2.05 |
+        // 2.697 / 2.14; wild_eval + 2 ... 4 % at 0.5 - 0.75.  Extrapolating only across large changes (a threshold on max |a_{k-1} - a_{k-2}|) is worse than either:
+        // the large changes are the contact events, where the extrapolation is wrong.  Defaults: 0.75 when the scene's free objects are simulated, 0 (MuJoCo's
+        // start) for floor scenes -- a caller whose envs are mostly falling (a policy at random init) sets 0.75.  a_{k-2} rides in the words of qacc_s between
+        // solves (dead outside the
+        // solve, where they hold the gradient); a_{k-1} is kept in two registers across the solve.  Humanoid dofs only; the objects keep their own warm start.
+        float keep0 = 0.f, keep1 = 0.f;
+        if (beta != 0.f) {
+            const int i0 = tid, i1 = tid + NT;
+            if (i0 < D_NV) { keep0 = s.qacc[i0]; if (have_prev) s.qacc[i0] = keep0 + beta * (keep0 - s.qacc_s[i0]); }
+            if (NT < D_NV && i1 < D_NV) { keep1 = s.qacc[i1]; if (have_prev) s.qacc[i1] = keep1 + beta * (keep1 - s.qacc_s[i1]); }
+            KP_SYNC();
+        }
         if constexpr (OBJ) {
             KP_T(4)                                            // no smooth solve: the Newton solve starts from the warm start (solve_constraints_direct)
             niter_total += solve_constraints_obj<NT>(s, P, L8, depth, tid, nfact_total, ncap_total);
         } else {
             KP_T(4)
             niter_total += solve_constraints_direct<NT>(s, P, L8, depth, tid, nfact_total, ncap_total);
+        }
+        if (beta != 0.f) {
+            const int i0 = tid, i1 = tid + NT;
+            if (i0 < D_NV) s.qacc_s[i0] = keep0;
+            if (NT < D_NV && i1 < D_NV) s.qacc_s[i1] = keep1;
+            have_prev = true;
+            KP_SYNC();
         }
         KP_T(5)
         maxcon = max(maxcon, s.ncon);
@@ -2078,7 +2112,7 @@ __device__ __forceinline__ void step_body(const StepArgs& A, const int env_in, c
     const int envS = kp_launder_uniform(env);
     bool bad = false;
     for (int i = tidS; i < D_NQ; i += NT) { float v = s.qpos[i]; bad |= !(fabsf(v) < 1e10f); if (n_substeps > 0) gst<Q>(A.qpos + (size_t)envS * D_NQ + (unsigned)(i), v); }
-    for (int i = tidS; i < D_NV; i += NT) { float v = s.qvel[i]; bad |= !(fabsf(v) < 1e10f); if (n_substeps > 0) { gst<Q>(A.qvel + (size_t)envS * D_NV + (unsigned)(i), v); gst<Q>(A.warm + (size_t)envS * D_NV + (unsigned)(i), s.qacc[i]); } }
+    for (int i = tidS; i < D_NV; i += NT) { float v = s.qvel[i]; bad |= !(fabsf(v) < 1e10f); if (n_substeps > 0) { gst<Q>(A.qvel + (size_t)envS * D_NV + (unsigned)(i), v); gst<Q>(A.warm + (size_t)envS * D_NV + (unsigned)(i), s.qacc[i]); if (Q && beta != 0.f && A.warm2 && part >= 0 && part + 1 < A.n_parts) gst<Q>(A.warm2 + (size_t)envS * D_NV + (unsigned)(i), s.qacc_s[i]); } }
     if (!torque_out) {       // the derived state is read by the control step's NEXT first job only (a job that hands its torque over has no reader for it)
 #pragma unroll
         for (int n = 0; n < (D_NQ + NT - 1) / NT; n++) { int i = tidS + n * NT; if (i < D_NQ) gst<Q>(A.qpos_d + (size_t)envS * D_NQ + (unsigned)(i), qd_save_q[n]); }

@@ -236,9 +236,15 @@ def test_job_queue_schedule_is_bit_identical(kp):
     for a_, b_ in zip(refm, gotm):
         assert (a_ == b_).all()
     assert (drefm == dgm).all() and (refm[0][mask == 0] == np.float32(qpos)[mask == 0]).all()
-    split, dsp = _run_sched(kp, kp.KpModel(substeps_per_job=0), n, qpos, qvel, act, split=[5, 5, 5])
-    for a_, b_ in zip(ref[:5], split):
+    # a control step launched as 5 + 5 + 5 substeps equals one launch of 15 -- with MuJoCo's plain warm start: the extrapolated start (warm_extrap, round 5)
+    # begins anew with every kp_sim_step_ctrl call, so three calls extrapolate on other substeps than one call does (same minimisers, other rounding)
+    ref0, _ = _run_sched(kp, kp.KpModel(substeps_per_job=0, warm_extrap=0), n, qpos, qvel, act)
+    split, dsp = _run_sched(kp, kp.KpModel(substeps_per_job=0, warm_extrap=0), n, qpos, qvel, act, split=[5, 5, 5])
+    for a_, b_ in zip(ref0[:5], split):
         assert (a_ == b_).all(), "5+5+5 substeps must equal one launch of 15"
+    one_e, _ = _run_sched(kp, kp.KpModel(substeps_per_job=0, warm_extrap=0.75), n, qpos, qvel, act)
+    split_e, _ = _run_sched(kp, kp.KpModel(substeps_per_job=0, warm_extrap=0.75), n, qpos, qvel, act, split=[5, 5, 5])
+    assert np.abs(split_e[0] - one_e[0]).max() < 5e-5
     # real slot count
     n = 4096
     qpos, qvel = make_states(n, 43, lift=0.0, vel=0.5, noise=0.2)
