@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--rl_update", type=int, default=1, help="without --cfg: policy_specs.rl_update (PPO epochs)"); ap.add_argument("--step_update", type=int, default=1, help="without --cfg: policy_specs.step_update")
     ap.add_argument("--eval_first_last", action="store_true", help="play every training take whole with mean actions before the first and after the last iteration (no freq_dict "
                     "feedback) and print mean percent / coverage / joint-angle error: a like-for-like measure of what the updates did to the policy")
+    ap.add_argument("--eval_every", type=int, default=0, help="with --eval_first_last: also after every N-th iteration")
     ap.add_argument("--load", type=str, default="", help="start from this checkpoint (reference layout) instead of seeded random init; schedules and optimiser state start fresh")
     ap.add_argument("--min_horizon", type=int, default=0, help="with --cfg: lower bound of the per-env horizon derived from min_batch_size (0 = fr_num / 4; ADVICE r4: 10000 / 4096 envs "
                     "would be 3-step fragments that hang on the V bootstrap)")
@@ -152,6 +153,8 @@ def main():
     if args.eval_first_last:
         fixed_eval("before")
     for it in range(first, last):
+        if args.eval_first_last and args.eval_every and it > first and (it - first) % args.eval_every == 0:
+            fixed_eval(f"iter{it}")
         info = agent.optimize_policy(it)
         if interval and (it + 1) % interval == 0:      # optimize_policy's periodic test-set evaluation, then train_ar_policy.py:95-97
             info["log_eval"] = agent.eval_policy("test")
