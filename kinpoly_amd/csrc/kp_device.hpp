@@ -95,6 +95,7 @@ struct __attribute__((aligned(16))) EnvLdsObj : EnvLds {
     float oI[D_MAXOBJ * 10], oIe[D_MAXOBJ * 10];   // spatial inertia (true / with the free-joint armature)
     float ofb[D_MAXOBJ * 6];            // bias wrench
     float oqa[D_MAXOBJ * 6];            // joint-space acceleration of the last solve (warm start, integration)
+    float oqa_prev[D_MAXOBJ * 6];       // the solve before it (extrapolated start, warm_extrap)
     float oas[D_MAXOBJ * 6], oa[D_MAXOBJ * 6], omres[D_MAXOBJ * 6], osrch[D_MAXOBJ * 6], oMv[D_MAXOBJ * 6], ogr[D_MAXOBJ * 6], ot[D_MAXOBJ * 6];
     float Sm[6 * D_MAXOBJ * (6 * D_MAXOBJ + 1)];   // dense object system [n][n + 1] (last column: right-hand side)
     float cM[D_MAXCON * 6];             // per contact: D F G F^T of the active pyramid rows (world, xx yy zz xy xz yz)

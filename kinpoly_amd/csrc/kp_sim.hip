@@ -54,7 +54,7 @@ struct kp_sim {
     unsigned long long* prof = nullptr;
     float* dbg_contacts = nullptr;
     float *obj_qpos = nullptr, *geoms = nullptr;      // [N,35], [N,8,17]
-    float *obj_qvel = nullptr, *obj_warm = nullptr;   // [N,30], [N,12]
+    float *obj_qvel = nullptr, *obj_warm = nullptr, *obj_warm2 = nullptr;   // [N,30], [N,12], [N,12]
     signed char* obj_slot = nullptr;                  // [N,2]
     int* ngeom = nullptr;
     const float* d_obj_geoms = nullptr; const float* d_obj_mass = nullptr; int n_obj_geoms = 0, n_obj = 0;
@@ -231,7 +231,7 @@ int launch_step(kp_sim* s, const float* action, int nsub, const uint8_t* mask, b
     A.target_qpos = s->t_qpos; A.action = action; A.env_mask = mask;
     A.xpos = s->xpos; A.xquat = s->xquat; A.xipos = s->xipos; A.diag = s->diag; A.prof = s->prof;
     A.geoms = s->geoms; A.ngeom = s->ngeom; A.dbg_contacts = s->dbg_contacts;
-    A.obj_slot = s->obj_slot; A.obj_qpos = s->obj_qpos; A.obj_qvel = s->obj_qvel; A.obj_warm = s->obj_warm;
+    A.obj_slot = s->obj_slot; A.obj_qpos = s->obj_qpos; A.obj_qvel = s->obj_qvel; A.obj_warm = s->obj_warm; A.obj_warm2 = s->obj_warm2;
     A.order = nullptr; A.cost = s->cost;
     const bool obj = s->has_objects;
     if (obj && s->model->threads != 64) return fail("object contact needs threads_per_env = 64");
@@ -412,7 +412,7 @@ kp_sim* kp_sim_create(const kp_model* m, int n_envs, int device_id, void* stream
         if (hipGetDeviceProperties(&prop, s->device) == hipSuccess && prop.multiProcessorCount > 0) s->wave_slots = prop.multiProcessorCount * 8;
     }
     s->obj_qpos = dalloc(s, N * 35, &ok); s->geoms = dalloc(s, N * kp::D_MAXGEOM * 17, &ok); s->ngeom = (int*)dalloc(s, N, &ok);
-    s->obj_qvel = dalloc(s, N * 30, &ok); s->obj_warm = dalloc(s, N * 6 * kp::D_MAXOBJ, &ok); s->obj_slot = (signed char*)dalloc(s, (N * kp::D_MAXOBJ + 3) / 4 + 1, &ok);
+    s->obj_qvel = dalloc(s, N * 30, &ok); s->obj_warm = dalloc(s, N * 6 * kp::D_MAXOBJ, &ok); s->obj_warm2 = dalloc(s, N * 6 * kp::D_MAXOBJ, &ok); s->obj_slot = (signed char*)dalloc(s, (N * kp::D_MAXOBJ + 3) / 4 + 1, &ok);
     if (!m->h.obj_geoms.empty()) {
         s->d_obj_geoms = upload<float>(s, m->h.obj_geoms, &ok); s->d_obj_mass = upload<float>(s, m->h.obj_mass, &ok);
         s->n_obj_geoms = (int)(m->h.obj_geoms.size() / 18); s->n_obj = (int)m->h.obj_mass.size();

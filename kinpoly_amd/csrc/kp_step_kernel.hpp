@@ -64,6 +64,7 @@ struct StepArgs {
     // OBJ kernels, dynamic free objects: slot -> object index of the scene (-1 = empty), free-joint state of all objects
     const signed char* obj_slot;   // [N, D_MAXOBJ]
     float *obj_qpos, *obj_qvel, *obj_warm;   // [N, 35], [N, 30], [N, 6 * D_MAXOBJ]
+    float *obj_warm2;                         // [N, 6 * D_MAXOBJ] the objects' a_{k-2} between the jobs of a control step (warm_extrap)
     // launch order (longest-processing-time first): workgroup i simulates env order[i]; cost[env] = shader-clock cycles >> 10 this
     // launch spent on env.  Both optional.  The result of an env does not depend on the workgroup that computes it.
     const int* order;
@@ -1960,7 +1961,8 @@ __device__ __forceinline__ void step_body(const StepArgs& A, const int env_in, c
             if (oi < 0 || oi >= T.n_obj) break;
             nobj = k + 1;
             if (tid < 7) s.oq[7 * k + tid] = gld<Q>(A.obj_qpos + (size_t)env * 35 + (unsigned)(7 * oi + tid));
-            if (tid < 6) { s.ov[6 * k + tid] = gld<Q>(A.obj_qvel + (size_t)env * 30 + (unsigned)(6 * oi + tid)); s.oqa[6 * k + tid] = gld<Q>(A.obj_warm + (size_t)env * 6 * D_MAXOBJ + (unsigned)(6 * k + tid)); }
+            if (tid < 6) { s.ov[6 * k + tid] = gld<Q>(A.obj_qvel + (size_t)env * 30 + (unsigned)(6 * oi + tid)); s.oqa[6 * k + tid] = gld<Q>(A.obj_warm + (size_t)env * 6 * D_MAXOBJ + (unsigned)(6 * k + tid));
+                           s.oqa_prev[6 * k + tid] = (A.warm_extrap != 0.f && Q && part > 0 && A.obj_warm2) ? gld<Q>(A.obj_warm2 + (size_t)env * 6 * D_MAXOBJ + (unsigned)(6 * k + tid)) : 0.f; }
             if (tid < 13) s.oc[13 * k + tid] = T.obj_inertial[13 * oi + tid];
             for (int gi = T.obj_geom_adr[oi]; gi < T.obj_geom_adr[oi + 1] && ng < D_MAXGEOM; gi++, ng++) {
                 if (tid == 0) { s.gobj[ng] = (signed char)k; s.ggi[ng] = (unsigned char)gi; }
@@ -2030,7 +2032,13 @@ __device__ __forceinline__ void step_body(const StepArgs& A, const int env_in, c
             continue;
         }
         if (!substep) continue;         // fresh mode's exit pass: outputs are the kinematics of the final state
-        if constexpr (OBJ) obj_forward(s, T, P, tid);
+        if constexpr (OBJ) {
+            if (beta != 0.f) {          // the objects' share of the extrapolated start, in their joint coordinates (obj_forward turns oqa into the spatial start oa)
+                if (tid < 6 * s.nobj) { const float cur = s.oqa[tid]; if (have_prev) s.oqa[tid] = cur + beta * (cur - s.oqa_prev[tid]); s.oqa_prev[tid] = cur; }
+                KP_SYNC();
+            }
+            obj_forward(s, T, P, tid);
+        }
         KP_T(1)
         collide<NT, OBJ>(s, T, P, tid);
         if (A.dbg_contacts && sub == n_substeps - 1) {      // test hook: the contact set of the last collision pass (con_D still holds the distance)
@@ -2061,7 +2069,7 @@ __device__ __forceinline__ void step_body(const StepArgs& A, const int env_in, c
         // the large changes are the contact events, where the extrapolation is wrong.  Defaults: 0.75 when the scene's free objects are simulated, 0 (MuJoCo's
         // start) for floor scenes -- a caller whose envs are mostly falling (a policy at random init) sets 0.75.  a_{k-2} rides in the words of qacc_s between
         // solves (dead outside the
-        // solve, where they hold the gradient); a_{k-1} is kept in two registers across the solve.  Humanoid dofs only; the objects keep their own warm start.
+        // solve, where they hold the gradient); a_{k-1} is kept in two registers across the solve.  The objects' accelerations likewise (oqa / oqa_prev, in their joint coordinates).
         float keep0 = 0.f, keep1 = 0.f;
         if (beta != 0.f) {
             const int i0 = tid, i1 = tid + NT;
@@ -2132,7 +2140,8 @@ __device__ __forceinline__ void step_body(const StepArgs& A, const int env_in, c
             for (int k = 0; k < s.nobj; k++) {
                 const int oi = A.obj_slot[(size_t)envS * D_MAXOBJ + k];
                 if (tidS < 7) { const float v = s.oq[7 * k + tidS]; bad |= !(fabsf(v) < 1e10f); gst<Q>(A.obj_qpos + (size_t)envS * 35 + (unsigned)(7 * oi + tidS), v); }
-                if (tidS < 6) { gst<Q>(A.obj_qvel + (size_t)envS * 30 + (unsigned)(6 * oi + tidS), s.ov[6 * k + tidS]); gst<Q>(A.obj_warm + (size_t)envS * 6 * D_MAXOBJ + (unsigned)(6 * k + tidS), s.oqa[6 * k + tidS]); }
+                if (tidS < 6) { gst<Q>(A.obj_qvel + (size_t)envS * 30 + (unsigned)(6 * oi + tidS), s.ov[6 * k + tidS]); gst<Q>(A.obj_warm + (size_t)envS * 6 * D_MAXOBJ + (unsigned)(6 * k + tidS), s.oqa[6 * k + tidS]);
+                                if (Q && A.warm_extrap != 0.f && A.obj_warm2 && part >= 0 && part + 1 < A.n_parts) gst<Q>(A.obj_warm2 + (size_t)envS * 6 * D_MAXOBJ + (unsigned)(6 * k + tidS), s.oqa_prev[6 * k + tidS]); }
             }
         }
     }

@@ -25,6 +25,12 @@ $T 200 python tools/obs_reward_errors.py 2>&1 | grep -v amdgpu.ids > $E/obs_rewa
 $T 300 python tools/sampler_regime.py --profile 2>/dev/null > $E/sampler_regime_profile.log
 $T 200 python tools/obj_bench.py > $E/obj_bench.log 2>&1
 $T 200 python tools/phase_profile.py > $E/phase_cycles.log 2>&1
+# the constraint solve's starting point (model option warm_extrap): beta sweep on three workloads, 60 timed steps each
+( for we in 0 0.5 0.75 1; do for wl in objects tracked random_init wild_eval; do KP_WARM_EXTRAP=$we $T 300 python bench.py --workload $wl --steps 60 --warmup 20 --no-secondary --no-cpu-baseline --no-parity-live 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('$wl warm_extrap=$we value %.0f launch_ms %.4f newton/substep %.3f fact/substep %.3f' % (d['value'], d['roofline']['launch_ms'], d['newton_iters_per_substep'], d['hessian_factorisations_per_substep']))"
+done; done ) > $E/warm_extrap_sweep.log 2>&1
 # rocprofv3: kernel trace + stats, then the --pmc passes (never combined with trace domains), per workload
 $T 900 tools/profile_bench.sh tracked > $E/profile_tracked.log 2>&1
 $T 900 tools/profile_bench.sh objects > $E/profile_objects.log 2>&1
@@ -46,7 +52,3 @@ $T 200 python tools/mujoco_pin.py > $E/mujoco_pin.log 2>&1
 find gpurun_out/r05_prof $E -type f -size +2000k -delete
 for f in pytest_gpu smoke floor_fuzz obj_fuzz contact_compare concurrent_handles soak; do echo "== $f"; grep -v Warn $E/$f.log | tail -4 | cut -c1-400; done
 cut -c1-500 $E/bench_default.json
-# the update ablation: one UHC, one warm start, then {none, PPO, step, both} in fp32 and `both` in fp64 from the same checkpoint, with the fixed evaluation
-$T 2400 bash -c "DTYPES=fp32 bash tools/update_ablation.sh; DTYPES=fp64 VARIANTS=both bash tools/update_ablation.sh" > $E/update_ablation.log 2>&1
-mkdir -p $E/update_ablation && cp gpurun_out/update_ablation/*.log gpurun_out/update_ablation/table.txt $E/update_ablation/
-tail -8 $E/update_ablation/table.txt | cut -c1-400
