@@ -45,6 +45,10 @@ for it in range(n_launch):
     if os.environ.get("KP_PROFILE") == "1":        # per-phase cycles of the LAST job of the control step (run with KP_SUBSTEPS_PER_JOB=15: the whole step is one job)
         pc = env.sim.phase_cycles_env()
         ph = ("spd", "kin_bias", "collide", "constraint", "smooth", "contact", "integrate", "total")
+        if len(sys.argv) > 2 and sys.argv[2] == "solve":          # the library built by tools/micro/solve_instr.py
+            ph = ("gradient", "factorisation", "schur_columns", "object_system+back_subst", "rows+quad_forms", "line_search", "other_in_solve", "total")
+        if len(sys.argv) > 2 and sys.argv[2] == "collide":        # tools/micro/collide_instr.py, variant A
+            ph = ("mpr_queries", "mpr_hits", "mpr_cycles", "object_object+object_floor_cycles", "floor_hull_cycles", "box_box_calls", "box_box_cycles", "total")
         order_ = np.argsort(-pc[:, 7])
         for nm, sel in (("24 costliest", order_[:24]), ("next 200", order_[24:224]), ("median 400", order_[1848:2248])):
             print(f"   phases / substep, {nm}: " + ", ".join(f"{k} {pc[sel, j].mean() / 15:.0f}" for j, k in enumerate(ph)) + f"; newton it / substep {nit[sel].mean() / 15:.2f}, contacts {maxcon[sel].mean():.1f}")
