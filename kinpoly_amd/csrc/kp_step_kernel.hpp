@@ -1653,6 +1653,13 @@ __device__ __forceinline__ void schur_columns(EnvLdsObj& s, const Params& P, uns
     const int s0 = (D_SCHUR_SCRATCH - 54 * ncmax) / ncmax;
 #define KP_UU(slot) ((slot) < s0 ? UUa + (slot) * ncmax : UUb + ((slot) - s0) * ncmax)
     const int nobj = s.nobj;
+    struct Fac3 { float c[3], U[3], Di[3]; };                     // motion axis, U = IA s and 1 / D of a body's three dofs: this lane's row
+    auto ldfac = [&](int d0) {
+        Fac3 f;
+#pragma unroll
+        for (int j = 0; j < 3; j++) { f.c[j] = s.cdof[6 * (d0 + j) + rc]; f.U[j] = s.U[6 * (d0 + j) + rc]; f.Di[j] = s.Dinv[d0 + j]; }
+        return f;
+    };
     for (int c0 = 0; c0 < ncols; c0 += ncmax) {
         const int nc = min(ncmax, ncols - c0);
         const bool colok = jl < nc;
@@ -1666,11 +1673,20 @@ __device__ __forceinline__ void schur_columns(EnvLdsObj& s, const Params& P, uns
         float accd[D_NLEV];
 #pragma unroll
         for (int k = 0; k < D_NLEV; k++) accd[k] = 0.f;
+        // The walk is a serial chain over the path's bodies and every body needs nine factor words (cdof, U, 1 / D of its three dofs) + its depth from LDS:
+        // loaded at the top of the body's own turn they put one LDS round trip per body on the chain (16 - 20 bodies x two directions x one or two rounds
+        // x every factorisation on the envs the objects launch ends on).  They do not depend on the chain: the NEXT body's words are requested
+        // before the current body's arithmetic and have arrived when its turn comes (same operations on the same values: results unchanged).
         unsigned todo = path;
-        while (todo) {
-            const int b = 31 - __clz((int)todo);
+        int b = 31 - __clz((int)todo);
+        Fac3 cur = ldfac(b == 0 ? 3 : 6 + 3 * (b - 1));
+        int dv = (int)s.bdep[b];
+        while (true) {
             todo &= ~(1u << b);
-            const int d = __builtin_amdgcn_readfirstlane((int)s.bdep[b]);
+            const int nb = todo ? 31 - __clz((int)todo) : 0;
+            const Fac3 nxt = ldfac(nb == 0 ? 3 : 6 + 3 * (nb - 1));
+            const int ndv = (int)s.bdep[nb];
+            const int d = __builtin_amdgcn_readfirstlane(dv);
             float pA = accd[d];
             if ((touch >> b) & 1u) {                             // right-hand side: + (K_c e_icol)[r] for this hull's contacts on object kcol
                 V3 Pi, Pr;                                       // rows of P = [[p]x ; 1]: K_c = P M P^T, entry (r, i) = P_r . (M P_i)
@@ -1688,36 +1704,52 @@ __device__ __forceinline__ void schur_columns(EnvLdsObj& s, const Params& P, uns
             }
             const int slot0 = b == 0 ? 0 : 3 + 3 * __popc(path & ((1u << b) - 1u));
             for (int g = 0; g < (b == 0 ? 2 : 1); g++) {
-                const int d0 = b == 0 ? (g == 0 ? 3 : 0) : 6 + 3 * (b - 1), sl = b == 0 ? d0 : slot0;
+                const int sl = b == 0 ? (g == 0 ? 3 : 0) : slot0;
+                const Fac3 f = g == 0 ? cur : ldfac(0);          // the root's second group (its translations) is loaded in its turn
 #pragma unroll
                 for (int j = 2; j >= 0; j--) {
-                    const int dd = d0 + j;
-                    const float u = -sum8(rmask * s.cdof[6 * dd + rc] * pA);
-                    pA += rmask * s.U[6 * dd + rc] * (u * s.Dinv[dd]);
+                    const float u = -sum8(rmask * f.c[j] * pA);
+                    pA += rmask * f.U[j] * (u * f.Di[j]);
                     if (colok && r == 0) KP_UU(sl + j)[jc] = u;
                 }
             }
             accd[d] = 0.f;
             if (b > 0) accd[d - 1] += (colok && rowok) ? pA : 0.f;
+            if (!todo) break;
+            b = nb; cur = nxt; dv = ndv;
         }
         KP_SYNC();
         // ---- root -> leaves: spatial accelerations (accd[depth] now holds the last visited body's at that depth: a body's parent is the last one
         // visited one level up, bodies being in depth-first order); at a touching hull, H_oh z accumulates per object
         float cpl0 = 0.f, cpl1 = 0.f;
         todo = path;
-        while (todo) {
-            const int b = __ffs((int)todo) - 1;
+        b = __ffs((int)todo) - 1;
+        auto ldrhs = [&](int bb, int g, float* uu) {                // the joint-space right-hand sides of a body's group, this lane's column
+            const int sl = bb == 0 ? (g == 0 ? 0 : 3) : 3 + 3 * __popc(path & ((1u << bb) - 1u));
+#pragma unroll
+            for (int j = 0; j < 3; j++) uu[j] = KP_UU(sl + j)[jc];
+        };
+        cur = ldfac(b == 0 ? 0 : 6 + 3 * (b - 1));
+        float cuu[3];
+        ldrhs(b, 0, cuu);
+        dv = (int)s.bdep[b];
+        while (true) {
             todo &= todo - 1u;
-            const int d = __builtin_amdgcn_readfirstlane((int)s.bdep[b]);
+            const int nb = todo ? __ffs((int)todo) - 1 : b;
+            const Fac3 nxt = ldfac(nb == 0 ? 0 : 6 + 3 * (nb - 1));
+            float nuu[3];
+            ldrhs(nb, 0, nuu);
+            const int ndv = (int)s.bdep[nb];
+            const int d = __builtin_amdgcn_readfirstlane(dv);
             float a = (b > 0 && colok && rowok) ? accd[d - 1] : 0.f;
-            const int slot0 = b == 0 ? 0 : 3 + 3 * __popc(path & ((1u << b) - 1u));
             for (int g = 0; g < (b == 0 ? 2 : 1); g++) {
-                const int d0 = b == 0 ? (g == 0 ? 0 : 3) : 6 + 3 * (b - 1), sl = b == 0 ? d0 : slot0;
+                Fac3 f = cur;
+                float uu[3] = {cuu[0], cuu[1], cuu[2]};
+                if (g == 1) { f = ldfac(3); ldrhs(0, 1, uu); }
 #pragma unroll
                 for (int j = 0; j < 3; j++) {
-                    const int dd = d0 + j;
-                    const float qdd = (KP_UU(sl + j)[jc] - sum8(rmask * s.U[6 * dd + rc] * a)) * s.Dinv[dd];
-                    a += qdd * s.cdof[6 * dd + rc];
+                    const float qdd = (uu[j] - sum8(rmask * f.U[j] * a)) * f.Di[j];
+                    a += qdd * f.c[j];
                 }
             }
             accd[d] = a;
@@ -1734,6 +1766,9 @@ __device__ __forceinline__ void schur_columns(EnvLdsObj& s, const Params& P, uns
                     if (B == D_NB) cpl0 += wr; else cpl1 += wr;
                 }
             }
+            if (!todo) break;
+            b = nb; cur = nxt; dv = ndv;
+            cuu[0] = nuu[0]; cuu[1] = nuu[1]; cuu[2] = nuu[2];
         }
         if (colok && rowok) {
             s.Sm[r * ST + gcol] += cpl0;
