@@ -50,6 +50,12 @@ for it in range(n_launch):
         if len(sys.argv) > 2 and sys.argv[2] == "collide":        # tools/micro/collide_instr.py, variant A
             ph = ("mpr_queries", "mpr_hits", "mpr_cycles", "object_object+object_floor_cycles", "floor_hull_cycles", "box_box_calls", "box_box_cycles", "total")
         order_ = np.argsort(-pc[:, 7])
+        if len(sys.argv) > 2 and sys.argv[2] == "flips":          # tools/micro/flip_instr.py: rows that change state between two Newton iterations
+            for nm, sel in (("24 costliest", order_[:24]), ("next 200", order_[24:224]), ("median 400", order_[1848:2248]), ("all", order_)):
+                t = pc[sel, 0].sum()
+                print(f"   active-set tests after a line search, {nm}: {pc[sel, 0].mean() / 15:.2f} per substep; no flip {pc[sel, 1].sum() / t:.1%}, one row {pc[sel, 2].sum() / t:.1%}, "
+                      f"two {pc[sel, 3].sum() / t:.1%}, three or four {pc[sel, 4].sum() / t:.1%}, five or more {pc[sel, 5].sum() / t:.1%}; rows per test {pc[sel, 6].sum() / t:.2f}")
+            continue
         for nm, sel in (("24 costliest", order_[:24]), ("next 200", order_[24:224]), ("median 400", order_[1848:2248])):
             print(f"   phases / substep, {nm}: " + ", ".join(f"{k} {pc[sel, j].mean() / 15:.0f}" for j, k in enumerate(ph)) + f"; newton it / substep {nit[sel].mean() / 15:.2f}, contacts {maxcon[sel].mean():.1f}")
     print(f"   corr(cycles, newton iterations) {np.corrcoef(c, nit)[0, 1]:.3f}; corr(cycles, max contacts) {np.corrcoef(c, maxcon)[0, 1]:.3f}", flush=True)
