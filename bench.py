@@ -46,7 +46,9 @@ ALGO_BYTES_PER_ENV_STEP = 2772      # humanoid-only compulsory f
 ALGO_BYTES_PER_ENV_STEP_OBJ = 3292  # with the object block (nq 111 / nv 105)
 TRAIN_HORIZON = 24                  # env-steps per env and iteration of the train_iter workload (4096 x 24 = 98 304 samples; kin_poly.yml asks for >= 10 000)
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8.0 TB/s spec
-VALU_FP32_PEAK_TFLOPS = 157.3       # 256 CUs x 4 SIMDs x 64 lanes x 2 (FMA) x 2.4 GHz (vector fp32; MI355X spec sheet)
+VALU_FP32_PEAK_TFLOPS = 157.3       # spec-sheet vector fp32 = the PACKED rate (v_pk_fma_f32): 256 CUs x 4 SIMDs x 16 lanes per clock x 2 (packed pair) x 2 (FMA) x 2.4 GHz.
+                                    # Un-packed VALU fp32 -- what kp_step_kernel issues -- tops out at half of it, 78.6 TF = one wave-instruction per 4 cycles per SIMD =
+                                    # 614.4 G wave-instructions/s, the ceiling roofline.issue.valu_issue_frac is measured against
 MFMA_FP32_PEAK_TFLOPS = 157.3       # dense fp32 matrix peak (spec sheet): the policy / value GEMMs run in fp32
 PROFILE_DIR = os.path.join(ROOT, "profiles", "r05")
 
@@ -327,7 +329,7 @@ TRAIN_KEYS = ("T_sample", "T_update", "samples_per_s_per_gpu", "samples_per_iter
               "clips_drawn_per_iter", "clips_through_init_context_per_iter", "pool_exhausted", "update_tflops", "update_mfma_frac", "update_flops_per_iter", "episode_source")
 
 
-def run_workload(workload, device_index, seed, threads, steps, warmup, barrier=None):
+def run_workload(workload, device_index, seed, threads, steps, warmup, barrier=None, repeats=1):
     """Build the engine for `workload`, run `warmup` untimed + `steps` timed env-steps.  Returns (record, env, policy, sampler, std)."""
     env, policy, sampler, std = build_engine(device_index, seed, threads, workload)
     a_track = None
@@ -339,21 +341,28 @@ def run_workload(workload, device_index, seed, threads, steps, warmup, barrier=N
     if workload in ("tracked", "objects"):
         stagger_episodes(env, sampler, seed, follow)
     rollout_steps(sampler, warmup, a_track, wild, follow)
-    env.sim.timing_reset()
-    if barrier is not None:
-        barrier()
-    else:
-        torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    n_done = rollout_steps(sampler, steps, a_track, wild, follow)
-    if barrier is not None:
-        barrier()
-    else:
-        torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    kern_s, n_launch = env.sim.timing_mean_seconds()
+    # `repeats` timed blocks of exactly `steps` env-steps each, every block bracketed by barrier + synchronize on both sides (the contract's timed region,
+    # repeated inside one command so that the line carries its own spread).  The caller reports the median block.
+    el_blocks, kern_blocks, done_blocks, n_launch = [], [], [], 0
+    for _ in range(max(1, repeats)):
+        env.sim.timing_reset()
+        if barrier is not None:
+            barrier()
+        else:
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n_done = rollout_steps(sampler, steps, a_track, wild, follow)
+        if barrier is not None:
+            barrier()
+        else:
+            torch.cuda.synchronize()
+        el_blocks.append(time.perf_counter() - t0)
+        kern_s, n_launch = env.sim.timing_mean_seconds()
+        kern_blocks.append(kern_s); done_blocks.append(float(n_done.item()))
     diag = env.sim.diag()
-    rec = {"elapsed": elapsed, "kern_s": kern_s, "n_launch": n_launch, "diag": diag, "n_done": float(n_done.item())}
+    mid = int(np.argsort(el_blocks)[len(el_blocks) // 2])
+    rec = {"elapsed": el_blocks[mid], "kern_s": kern_blocks[mid], "n_launch": n_launch, "diag": diag, "n_done": done_blocks[mid],
+           "elapsed_blocks": el_blocks, "kern_s_blocks": kern_blocks, "n_done_blocks": done_blocks}
     return rec, env, policy, sampler, std
 
 
@@ -567,6 +576,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads and the GEMM probe (profiling runs)")
     ap.add_argument("--workload", choices=tuple(WORKLOAD_DESC), default="tracked")
+    ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps env-steps inside this command; value / ms_per_step = the median block (rollout workloads)")
     ap.add_argument("--no-parity-live", action="store_true", help="skip the live one-substep parity sample against the fp64 oracle (profiling runs)")
     args = ap.parse_args()
     train = args.workload == "train_iter"
@@ -621,16 +631,21 @@ def main():
         env = policy = sampler = None
         std = np.load(os.path.join(ROOT, "tests", "golden", "standing_neutral.npz"))
     else:
-        rec, env, policy, sampler, std = run_workload(args.workload, local_rank, 4 + rank, args.threads_per_env, args.steps, args.warmup, barrier)
-    elapsed = rec["elapsed"]
-    per_rank_ms = [elapsed / args.steps * 1e3]
+        rec, env, policy, sampler, std = run_workload(args.workload, local_rank, 4 + rank, args.threads_per_env, args.steps, args.warmup, barrier, args.repeats)
+    # per timed block: max over ranks; the line reports the MEDIAN block (its ms_per_step x steps is that block's bracketed wall time) and the spread
+    blocks = list(rec.get("elapsed_blocks", [rec["elapsed"]]))
+    per_rank_ms = [float(np.median(blocks)) / args.steps * 1e3]
     if in_group:
-        t = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
+        t = torch.tensor(blocks, device=cdev, dtype=torch.float64)
         every = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(every, t)
-        per_rank_ms = [float(x.item()) / args.steps * 1e3 for x in every]
+        per_rank_ms = [float(x.median().item()) / args.steps * 1e3 for x in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        blocks = [float(x) for x in t.tolist()]
+    mid = int(np.argsort(blocks)[len(blocks) // 2])
+    elapsed = blocks[mid]
+    if "kern_s_blocks" in rec:
+        rec["kern_s"], rec["n_done"] = rec["kern_s_blocks"][mid], rec["n_done_blocks"][mid]
 
     train_n = None
     live = None
@@ -703,6 +718,8 @@ def main():
         out = {
             "metric": "env-steps/sec (whole node) at 4096 envs/GPU, 69-DoF SMPL", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "repeats": len(blocks), "ms_per_step_min": min(blocks) / args.steps * 1e3, "ms_per_step_max": max(blocks) / args.steps * 1e3,
+            "ms_per_step_blocks": [b / args.steps * 1e3 for b in blocks],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": WORKLOAD_DESC[args.workload], "workload_id": args.workload, "envs_per_gpu": ENVS_PER_GPU, "substeps": 15, "clip_len": CLIP_LEN,
                        "threads_per_env": args.threads_per_env, "parallelism": f"env-sharded x{world}",
@@ -712,7 +729,8 @@ def main():
             # contract asks for are kept: achieved = algorithmic bytes / launch, traffic = PMC bytes / launch, traffic_over_algorithmic = their ratio
             "roofline": {"bound": "valu-issue", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_over_algorithmic": (traffic / algo_bytes) if traffic else None, "traffic_source": traffic_src,
-                         "kernel": kernel_name, "launch_ms": kern_s * 1e3, "launches_timed": n_launch, "algorithmic_bytes_per_launch": algo_bytes,
+                         "kernel": kernel_name, "launch_ms": kern_s * 1e3, "launch_ms_min": min(rec["kern_s_blocks"]) * 1e3, "launch_ms_max": max(rec["kern_s_blocks"]) * 1e3,
+                         "launches_timed": n_launch, "algorithmic_bytes_per_launch": algo_bytes,
                          "valu_active_frac_of_launch": valu_active, "frac_of_attainable_issue": issue["frac_of_attainable_issue"] if issue else None,
                          "limiter": "wave-level instruction issue: the SIMDs are saturated by their two resident waves (state lives in LDS, so the compulsory HBM traffic is tiny by construction; DESIGN.md section 6)",
                          "valu": valu, "issue": issue},

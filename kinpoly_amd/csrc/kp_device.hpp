@@ -48,7 +48,47 @@ struct Params {
     int max_iter, contact, limits, stale, actuation;
 };
 
+// Experiment build (tools/micro/occupancy_lean.py): -DKP_LEAN_FREEFALL=1 compiles the free-fall instantiation only (BASELINE configs[1]:
+// no contact, no joint limits, no Newton solve) with every array that instantiation never reads folded into ONE union, so that an env takes
+// 12 736 B = 10 LDS granules and 12 envs fit a CU (3 waves on every SIMD; KP_WAVES_PER_SIMD=3 sets the register budget to match).  Not a product
+// build: the contact / limit / object paths and kp_mass_kernel would alias live data.
+#ifndef KP_LEAN_FREEFALL
+#define KP_LEAN_FREEFALL 0
+#endif
+#ifndef KP_WAVES_PER_SIMD
+#define KP_WAVES_PER_SIMD 2
+#endif
+
 // ------------------------------------------------------------------ LDS layout: 18 128 B (15 allocation granules of 1 280 B; 8 envs per CU)
+#if KP_LEAN_FREEFALL
+struct __attribute__((aligned(16))) EnvLds {
+    float qpos[76], qvel[76];
+    float xpos[72], xquat[96];
+    float cinert[240];
+    float cdof[450];
+    float sv[156];
+    float U[450], Dinv[76], uj[76];
+    float IAa[25 * 22], pAa[25 * 6];
+    float arm[76];
+    float fb[144];
+    float qacc[76], extra[76];
+    float applied_pad[2], applied[6], ctrl[72];
+    // phases of a free-fall substep that own this block, in order: spd_torque_rfc (search, x), forward_kin_bias (sa = cacc), make_constraint
+    // (zeros into lim_jv / lim_D); everything else is never touched when contact = limits = 0 and warm_extrap = 0
+    union {
+        struct { float search[76], x[76]; };
+        float sa[144];
+        float con_pos[D_MAXCON * 3], jar3[D_MAXCON * 3], jv3[D_MAXCON * 3], con_D[D_MAXCON];
+        float qacc_s[76], Mv[76], mres[76], sw[144], lim_D[72], lim_jar[72], lim_jv[72];
+    };
+    float red[8];
+    unsigned char bpar[D_NB], bsub[D_NB], bdep[D_NB], dbody[76];
+    union { unsigned char con_act[D_MAXCON]; unsigned char con_body[D_MAXCON]; };
+    unsigned char con_start[D_NB + 4];
+    int ncon, nlim, flag;
+};
+static_assert(sizeof(EnvLds) <= 10 * 1280, "the lean layout must fit 10 LDS granules (12 envs per CU)");
+#else
 struct __attribute__((aligned(16))) EnvLds {
     float qpos[76], qvel[76];             // PD targets and actions are read from their HBM rows once per substep (spd_torque_rfc)
     float xpos[72], xquat[96];            // body COMs (xipos) are recomputed where they are read: collision centres, the read-out
@@ -78,6 +118,7 @@ struct __attribute__((aligned(16))) EnvLds {
     unsigned char con_start[D_NB + 4];    // contacts are grouped by that entity: 24 hulls, then the object slots (values <= D_MAXCON)
     int ncon, nlim, flag;
 };
+#endif
 
 // extension used only by the kernel instantiation that simulates object contact (kp_step_kernel<NT, true>)
 constexpr int D_MAXGEOM = 8;            // must equal MAXGEOM in oracle/kp_oracle.c

@@ -265,7 +265,12 @@ int launch_step(kp_sim* s, const float* action, int nsub, const uint8_t* mask, b
     // resident wave per slot (kp_step_queue_kernel) instead of one workgroup per env, which ends on a long tail
     const int spj = s->model->substeps_per_job;
     // resident waves: LDS is allocated in 1 280-byte granules, 128 per CU (tools/micro/lds_granule_probe.hip); 256 VGPRs allow 8 waves per CU
-    const int per_cu = std::min(8, 128 / (int)((lds + 1279) / 1280));
+#if KP_LEAN_FREEFALL
+    // experiment build (kp_device.hpp): free fall only; KP_LDS_PAD pads the allocation so that the same binary can be run at fewer envs per CU
+    if (obj || s->model->contact || s->model->limits || A.warm_extrap != 0.f || s->model->threads != 64) return fail("KP_LEAN_FREEFALL build: contact = 0, limits = 0, warm_extrap = 0, threads_per_env = 64 only");
+    if (const char* e = std::getenv("KP_LDS_PAD")) lds = std::max<size_t>(lds, (size_t)std::atoi(e));
+#endif
+    const int per_cu = std::min(4 * KP_WAVES_PER_SIMD, 128 / (int)((lds + 1279) / 1280));
     const int slots = s->model->queue_slots > 0 ? s->model->queue_slots : s->wave_slots / 8 * per_cu;
     int sizes[16], parts = 0;
     if (spj > 0 && nsub > 0) {
@@ -290,14 +295,20 @@ int launch_step(kp_sim* s, const float* action, int nsub, const uint8_t* mask, b
         const unsigned total = (unsigned)s->n * (unsigned)parts;
         hipLaunchKernelGGL(kp::k_queue_init, dim3((total + 255) / 256), dim3(256), 0, s->stream, s->n, total, s->jobq, s->jobctr, A.order);   // inside the timed bracket
         A.order = nullptr;                                              // the queue kernel addresses envs by their queue entry
+#if !KP_LEAN_FREEFALL
         if (obj) hipLaunchKernelGGL((kp::kp_step_queue_kernel<true>), dim3(slots), dim3(64), lds, s->stream, A);
-        else hipLaunchKernelGGL((kp::kp_step_queue_kernel<false>), dim3(slots), dim3(64), lds, s->stream, A);
+        else
+#endif
+        hipLaunchKernelGGL((kp::kp_step_queue_kernel<false>), dim3(slots), dim3(64), lds, s->stream, A);
     } else
     switch (s->model->threads) {
         case 64:
+#if !KP_LEAN_FREEFALL
             if (obj && nsub > 0) hipLaunchKernelGGL((kp::kp_step_kernel<64, true>), dim3(s->n), dim3(64), lds, s->stream, A);
             else if (obj) hipLaunchKernelGGL((kp::kp_forward_kernel<64, true>), dim3(s->n), dim3(64), lds, s->stream, A);
-            else KP_LAUNCH(64);
+            else
+#endif
+            KP_LAUNCH(64);
             break;
         case 128: KP_LAUNCH(128); break;
         case 256: KP_LAUNCH(256); break;

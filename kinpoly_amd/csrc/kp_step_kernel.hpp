@@ -1622,8 +1622,10 @@ __device__ __forceinline__ void obj_integrate(EnvLdsObj& s, const Params& P, int
 // [9][nc][6] + the joint-space right-hand sides u of the path's dofs [npd][nc]; nc = columns per round is what fits.
 constexpr int D_SCHUR_SCRATCH = D_MAXCON * 3 + 72 + 144 + 144;
 __device__ __forceinline__ void schur_columns(EnvLdsObj& s, const Params& P, unsigned cmask, int tid) {
+#if !KP_LEAN_FREEFALL
     static_assert(offsetof(EnvLds, lim_jv) == offsetof(EnvLds, jv3) + sizeof(float) * D_MAXCON * 3 && offsetof(EnvLds, sa) == offsetof(EnvLds, lim_jv) + sizeof(float) * 72 &&
                   offsetof(EnvLds, sw) == offsetof(EnvLds, sa) + sizeof(float) * 144, "jv3 | lim_jv | sa | sw must be contiguous");
+#endif
     constexpr int ST = 6 * D_MAXOBJ + 1;
     const int jl = tid >> 3, r = tid & 7;
     const bool rowok = r < 6;
@@ -2075,6 +2077,12 @@ __device__ __forceinline__ void step_body(const StepArgs& A, const int env_in, c
             obj_forward(s, T, P, tid);
         }
         KP_T(1)
+#if KP_LEAN_FREEFALL
+        // experiment build (kp_device.hpp): no collision pass, no constraint rows, no Newton solve -- qacc = M^-1 qfrc_smooth is one articulated-body solve
+        for (int i = tid; i < D_NV; i += NT) s.extra[i] = 0.f;
+        KP_SYNC();
+        { Lane8 L8; L8.init(kp_launder(tid), T.sched8); aba_solve<NT, false>(s, P, L8, s.applied, s.qacc, false, tid, D_NLEV, s.fb); }
+#else
         collide<NT, OBJ>(s, T, P, tid);
         if (A.dbg_contacts && sub == n_substeps - 1) {      // test hook: the contact set of the last collision pass (con_D still holds the distance)
             float* o = A.dbg_contacts + (size_t)env * (1 + D_MAXCON * 9);
@@ -2126,6 +2134,7 @@ __device__ __forceinline__ void step_body(const StepArgs& A, const int env_in, c
             have_prev = true;
             KP_SYNC();
         }
+#endif      // KP_LEAN_FREEFALL
         KP_T(5)
         maxcon = max(maxcon, s.ncon);
         // ---- semi-implicit Euler (mj_Euler, no damping)
@@ -2259,11 +2268,11 @@ __global__ __launch_bounds__(1024) void k_lpt_order(int n, const unsigned* __res
 }
 
 template <int NT, bool OBJ>
-__global__ __launch_bounds__(NT, (NT == 64 ? 2 : 1)) void kp_step_kernel(StepArgs A) {
+__global__ __launch_bounds__(NT, (NT == 64 ? KP_WAVES_PER_SIMD : 1)) void kp_step_kernel(StepArgs A) {
     step_body<NT, OBJ, false>(A, A.order ? A.order[blockIdx.x] : (int)blockIdx.x, -1);
 }
 template <int NT, bool OBJ>
-__global__ __launch_bounds__(NT, (NT == 64 ? 2 : 1)) void kp_forward_kernel(StepArgs A) { step_body<NT, OBJ, true>(A, (int)blockIdx.x, -1); }
+__global__ __launch_bounds__(NT, (NT == 64 ? KP_WAVES_PER_SIMD : 1)) void kp_forward_kernel(StepArgs A) { step_body<NT, OBJ, true>(A, (int)blockIdx.x, -1); }
 
 // Same control step, scheduled in finer grains.  4096 envs on 8 x 256 wave slots are two rounds of whole-control-step jobs whose
 // lengths spread 2.9 M .. 5.4 M cycles, so a third of a kp_step_kernel launch is its tail (tools/launch_balance.py).  Here one
@@ -2283,7 +2292,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 2 : 1)) void kp_forward_kernel(Step
 // (tools/queue_fence_bench.py, profiles/r02/queue_fence_bench.log): 3.818 ms (0) vs 3.837 ms (1) per launch -- the fences cost 0.5 %, so
 // the variant that is correct by construction is the default.
 template <bool OBJ>
-__global__ __launch_bounds__(64, 2) void kp_step_queue_kernel(StepArgs A) {
+__global__ __launch_bounds__(64, KP_WAVES_PER_SIMD) void kp_step_queue_kernel(StepArgs A) {
     // jobctr: [0] head (claimed), [1] tail (published), [2] stalled flag; on cache lines of their own, away from the head / tail every claim and publish hits:
     //         [16] jobs that were never queued because the finishing wave ran them itself; [32] time (40 ns units) and [33] substeps of the jobs finished so
     //         far in this launch; [48], [49] the same sums of the previous launch (the mean behind "heavy": constant during the launch, read once per wave)

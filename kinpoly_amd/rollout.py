@@ -360,7 +360,9 @@ class VectorSampler:
         self.ep_return = torch.zeros(self.env.n, dtype=torch.float64, device=self.env.device)
 
     @torch.no_grad()
-    def sample(self, T: int) -> RolloutBatch:
+    def sample(self, T: int, noise: torch.Tensor | None = None) -> RolloutBatch:
+        """noise (optional) [T, N, 80 + 75]: the standard-normal exploration draws of both policies, made by the caller instead of drawn here from env.gen
+        (a parity run feeds the same draws to the CPU episode loop; columns a policy that acts with its mean would not read are ignored)."""
         env, pol, N, dev = self.env, self.policy, self.env.n, self.env.device
         if self.obs is None:
             self.start()
@@ -377,12 +379,17 @@ class VectorSampler:
         # exploration noise of both policies, NOISE_CHUNK steps per launch, only the columns a sampling policy reads: [chunk, N, 80 kinematic | 75 UHC]
         cc_mean = env.mode == "test" or (env.mode == "train" and env.joint_controller)
         n_kin, n_cc = (0 if self.mean_action else 80), (0 if cc_mean else 75)
+        given = noise
+        if given is not None and tuple(given.shape) != (T, N, 155):
+            raise ValueError(f"sample(noise=...): expected shape ({T}, {N}, 155), got {tuple(given.shape)}")
         noise = None
         qview = env.sim.view("qpos") if (self.record_qpos or full) else None          # the simulator's own rows: the record kernels read them in place
         for t in range(T):
-            if (n_kin + n_cc) and t % self.NOISE_CHUNK == 0:
+            if given is None and (n_kin + n_cc) and t % self.NOISE_CHUNK == 0:
                 noise = torch.randn((min(self.NOISE_CHUNK, T - t), N, n_kin + n_cc), device=dev, generator=env.gen)
             nz = None if noise is None else noise[t % self.NOISE_CHUNK]
+            if given is not None and (n_kin + n_cc):
+                nz = torch.cat([given[t, :, :n_kin], given[t, :, 80:80 + n_cc]], 1)
             # Memory.push, first half (one launch): state, episode start, the pose before the step, the GT pose of the clip's next frame, (take, fr_start)
             kpsim.record_pre(t, T, obs=self.obs, fresh=self.fresh, qpos=qview if self.record_qpos else None, ctx_qpos=env.ctx["qpos"] if self.record_qpos else None,
                              row=env.row, cur_t=env.cur_t, row_len=env.row_len, row_meta=env.row_meta,

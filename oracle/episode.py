@@ -56,10 +56,13 @@ class EpisodeOracle:
         x = {k: self.sim.get(k) for k in ("qpos", "qvel", "xpos", "xquat", "xipos")}
         return x["qpos"], x["qvel"], x["xpos"].reshape(24, 3), x["xquat"].reshape(24, 4), x["xipos"].reshape(24, 3)
 
-    def rollout(self, ctx, T, v_meta=(0.0, 0.0)):
+    def rollout(self, ctx, T, v_meta=(0.0, 0.0), noise=None):
         """ctx: numpy dict of ONE clip (qpos [L, 76], head_pose [L, 7], head_vels [L, 6], obj_head_relative_poses [L, 7], action_one_hot [4],
         init_qpos [76], init_qvel [75]; optional obj_pose [L, 7 k]: with a non-zero action_one_hot the action's objects are free bodies of the scene).  Runs T env-steps, starting a new episode on the same clip after every `done`.  Returns the
-        memory fields as arrays [T, .] plus 'done' / 'fail' / 'percent'."""
+        memory fields as arrays [T, .] plus 'done' / 'fail' / 'percent'.
+        noise (optional) [T, 155] standard-normal draws: the exploration of a sampling run, row t = [80 kinematic | 75 UHC] -- the kinematic action is
+        mean + exp(log_std) * eps (select_action, agent_ar.py:545-549 with mean_action False) and so is the UHC's (humanoid_ar_v1.py:267-268: the UHC samples in
+        'train' mode unless joint_controller); without it both act with their means."""
         L = ctx["qpos"].shape[0]
         clip_len = L - 1                                            # ar_context['len'] (humanoid_ar_v1.py:84-88)
         gt = [O.qpos_fk(q, self.bp, self.bi, self.par) for q in ctx["qpos"]]
@@ -78,6 +81,8 @@ class EpisodeOracle:
             with torch.no_grad():
                 a, hx = self.kin.select_action(torch.from_numpy(state)[None], hx, True)
             a = a[0].numpy()
+            if noise is not None:
+                a = a + self.kin.std().detach().numpy().reshape(-1) * noise[len(rows["state"]), :80]
             gt_qpos = ctx["qpos"][min(cur_t + 1, L - 1)]
             qpos, qvel, xp, xq, xi = self._x()
             curr_qpos = qpos.copy()
@@ -87,6 +92,8 @@ class EpisodeOracle:
             cc_obs = O.zfilter(O.obs_cc(qpos, qvel, xp, xq, xi, tgt), 0.0, 1.0, 5.0)
             with torch.no_grad():
                 cc_a = self.mcp.action_mean(torch.from_numpy(cc_obs)[None])[0].numpy()
+            if noise is not None:
+                cc_a = cc_a + np.exp(self.mcp.action_log_std.detach().numpy().reshape(-1)) * noise[len(rows["state"]), 80:155]
             self.sim.do_simulation(cc_a, tgt["qpos"], 15)
             cur_t += 1
             qpos, qvel, xp, xq, xi = self._x()

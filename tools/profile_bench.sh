@@ -8,7 +8,7 @@ WL=${1:-tracked}
 OUT=gpurun_out/${KP_ROUND:-r05}_prof/$WL
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-CMD="python bench.py --workload $WL --steps 30 --warmup 10 --no-cpu-baseline --no-secondary --no-parity-live"
+CMD="python bench.py --workload $WL --steps 30 --warmup 10 --no-cpu-baseline --no-secondary --no-parity-live --repeats 1"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- $CMD > "$OUT/bench_stats.log" 2>&1
 for C in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU"; do
     TAG=$(echo "$C" | tr ' ' '+')
