@@ -68,6 +68,8 @@ def build_engine(device_index, seed, threads, workload="tracked", n_envs=None):
             **({"queue_prio": int(os.environ["KP_QUEUE_PRIO"])} if "KP_QUEUE_PRIO" in os.environ else {}),
             **({"queue_fence": int(os.environ["KP_QUEUE_FENCE"])} if "KP_QUEUE_FENCE" in os.environ else {}),
             **({"queue_slots": int(os.environ["KP_QUEUE_SLOTS"])} if "KP_QUEUE_SLOTS" in os.environ else {}),
+            **({"lean_queue": int(os.environ["KP_LEAN_QUEUE"])} if "KP_LEAN_QUEUE" in os.environ else {}),
+            **({"lds_pad": int(os.environ["KP_LDS_PAD"])} if "KP_LDS_PAD" in os.environ else {}),
             **({"warm_extrap": float(os.environ["KP_WARM_EXTRAP"])} if "KP_WARM_EXTRAP" in os.environ else {})}
     env = BatchedHumanoidAREnv(n_envs, device_index, mode="test" if wild else "train", wild=wild, seed=seed, model_options=opts)
     policy = KinPolicy().to(env.device).float()

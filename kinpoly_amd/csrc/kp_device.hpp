@@ -48,48 +48,15 @@ struct Params {
     int max_iter, contact, limits, stale, actuation;
 };
 
-// Experiment build (tools/micro/occupancy_lean.py): -DKP_LEAN_FREEFALL=1 compiles the free-fall instantiation only (BASELINE configs[1]:
-// no contact, no joint limits, no Newton solve) with every array that instantiation never reads folded into ONE union, so that an env takes
-// 12 736 B = 10 LDS granules and 12 envs fit a CU (3 waves on every SIMD; KP_WAVES_PER_SIMD=3 sets the register budget to match).  Not a product
-// build: the contact / limit / object paths and kp_mass_kernel would alias live data.
-#ifndef KP_LEAN_FREEFALL
-#define KP_LEAN_FREEFALL 0
-#endif
-#ifndef KP_WAVES_PER_SIMD
-#define KP_WAVES_PER_SIMD 2
-#endif
-
-// ------------------------------------------------------------------ LDS layout: 18 128 B (15 allocation granules of 1 280 B; 8 envs per CU)
-#if KP_LEAN_FREEFALL
+// ------------------------------------------------------------------ LDS layouts
+// EnvLds      the full layout, 18 128 B (15 allocation granules of 1 280 B; 8 envs per CU = 2 waves per SIMD): every launch form except the floor scenes' job queue
+// EnvLdsLean  the floor scenes' job-queue kernel: 3 waves on every SIMD need <= 12 800 B per env (the free-fall instantiation at 12 instead of
+//             8 envs per CU is 18 - 19 % faster).  Same arithmetic, same code; what differs is where a few vectors live (see the struct) and the number of
+//             contacts the block holds (32: an env that needs more is handed to the full-layout kernel, kp_step_overflow_kernel)
+// EnvLdsObj   EnvLds + the free objects' block
 struct __attribute__((aligned(16))) EnvLds {
-    float qpos[76], qvel[76];
-    float xpos[72], xquat[96];
-    float cinert[240];
-    float cdof[450];
-    float sv[156];
-    float U[450], Dinv[76], uj[76];
-    float IAa[25 * 22], pAa[25 * 6];
-    float arm[76];
-    float fb[144];
-    float qacc[76], extra[76];
-    float applied_pad[2], applied[6], ctrl[72];
-    // phases of a free-fall substep that own this block, in order: spd_torque_rfc (search, x), forward_kin_bias (sa = cacc), make_constraint
-    // (zeros into lim_jv / lim_D); everything else is never touched when contact = limits = 0 and warm_extrap = 0
-    union {
-        struct { float search[76], x[76]; };
-        float sa[144];
-        float con_pos[D_MAXCON * 3], jar3[D_MAXCON * 3], jv3[D_MAXCON * 3], con_D[D_MAXCON];
-        float qacc_s[76], Mv[76], mres[76], sw[144], lim_D[72], lim_jar[72], lim_jv[72];
-    };
-    float red[8];
-    unsigned char bpar[D_NB], bsub[D_NB], bdep[D_NB], dbody[76];
-    union { unsigned char con_act[D_MAXCON]; unsigned char con_body[D_MAXCON]; };
-    unsigned char con_start[D_NB + 4];
-    int ncon, nlim, flag;
-};
-static_assert(sizeof(EnvLds) <= 10 * 1280, "the lean layout must fit 10 LDS granules (12 envs per CU)");
-#else
-struct __attribute__((aligned(16))) EnvLds {
+    static constexpr bool LEAN = false;
+    static constexpr int MAXCON = D_MAXCON;   // contacts the block holds
     float qpos[76], qvel[76];             // PD targets and actions are read from their HBM rows once per substep (spd_torque_rfc)
     float xpos[72], xquat[96];            // body COMs (xipos) are recomputed where they are read: collision centres, the read-out
     float cinert[240];                    // body spatial inertia about o, world axes (10 floats / body)
@@ -118,7 +85,49 @@ struct __attribute__((aligned(16))) EnvLds {
     unsigned char con_start[D_NB + 4];    // contacts are grouped by that entity: 24 hulls, then the object slots (values <= D_MAXCON)
     int ncon, nlim, flag;
 };
-#endif
+
+// The floor scenes' job-queue layout.  Differences from EnvLds, each with the reason it is safe (phases of a substep, in order: spd_torque_rfc, forward_kin_bias,
+// collide, make_constraint, Newton solve = { gradient (wrench_project), factorisation / solve (aba_solve | aba_resolve), row evaluation, line search, update }, Euler):
+//   * MAXCON = 32 contacts (con_pos, con_D, jar3, jv3, con_act, con_body): floor scenes hold 7 - 10 on average; collide() reports an env that needs more and
+//     the job is re-run by kp_step_overflow_kernel on the full layout (no state of the job has reached HBM at that point);
+//   * ONE vector for the Newton step's gradient, right-hand side, joint-space bias u_j and search direction (search = x = qacc_s = uj): the gradient is negated in
+//     place, the leaves->root pass replaces x_d by u_d (read and written by the 8 lanes that own dof d, in that order), the root->leaves pass replaces u_d by
+//     the solution.  The object solver re-uses x after the solve (back-substitution) and keeps the four apart;
+//   * sa | sw (the gradient's body wrenches and their subtree sums, forward_kin_bias' velocity-product accelerations) share their words with jv3 | lim_jv | search:
+//     J search and the search direction are dead while a gradient is formed (its result lands in the words of sw, which is dead by then), sa is dead outside;
+//   * the stable-PD position error rides in lim_jar (dead outside the Newton solve), a_{k-2} of warm_extrap in the env's HBM row (kp_sim: warm2);
+//   * sv without the two object slots.
+struct __attribute__((aligned(16))) EnvLdsLean {
+    static constexpr bool LEAN = true;
+    static constexpr int MAXCON = 32;
+    float qpos[76], qvel[76];
+    float xpos[72], xquat[96];
+    float cinert[240];
+    float cdof[450];
+    float sv[144];
+    float U[450], Dinv[76];
+    float IAa[25 * 22], pAa[25 * 6];
+    float arm[76];
+    float fb[144];
+    float qacc[76], extra[76];
+    float Mv[76], mres[76];
+    float applied_pad[2], applied[6], ctrl[72];
+    float con_pos[MAXCON * 3], con_D[MAXCON];
+    float jar3[MAXCON * 3];
+    float lim_D[72], lim_jar[72];
+    union {
+        struct { float jv3[MAXCON * 3], lim_jv[72]; union { float search[76], x[76], qacc_s[76], uj[76]; }; };
+        struct { float sa[144], sw[144]; };
+    };
+    float red[8];
+    unsigned char bpar[D_NB], bsub[D_NB], bdep[D_NB], dbody[76];
+    unsigned char con_act[MAXCON], con_body[MAXCON];
+    unsigned char con_start[D_NB + 4];
+    int ncon, nlim, flag;
+};
+static_assert(offsetof(EnvLdsLean, search) >= offsetof(EnvLdsLean, sw) && offsetof(EnvLdsLean, search) + 76 * sizeof(float) <= offsetof(EnvLdsLean, sw) + 144 * sizeof(float),
+              "the search direction must lie inside sw (wrench_project writes the gradient there once sw is dead) and clear of sa");
+static_assert(offsetof(EnvLdsLean, U) % 8 == 0, "s.U must be 8-byte aligned");
 
 // extension used only by the kernel instantiation that simulates object contact (kp_step_kernel<NT, true>)
 constexpr int D_MAXGEOM = 8;            // must equal MAXGEOM in oracle/kp_oracle.c

@@ -27,7 +27,7 @@ int fail(const std::string& m) { g_err = m; return -1; }
 
 struct kp_model {
     kp::HostModel h;
-    int contact = 1, limits = 1, stale = 1, solver_iter = 100, threads = 64, dynamic_objects = 1, lpt_order = -1, substeps_per_job = 4, queue_slots = 0, job_taper = 1, queue_fence = 1, queue_heavy = 160, queue_prio = 0;
+    int contact = 1, limits = 1, stale = 1, solver_iter = 100, threads = 64, dynamic_objects = 1, lpt_order = -1, substeps_per_job = 4, queue_slots = 0, job_taper = 1, queue_fence = 1, queue_heavy = 160, queue_prio = 0, lean_queue = 1, lds_pad = 0;
     float warm_extrap = -1.f;      // < 0: automatic (0.75 when the scene's free objects are simulated, 0 otherwise); see kp_step_kernel.hpp
     int planemesh_max = 3; double planemesh_tol = 0.3;   // mjc_PlaneConvex's maxplanemesh / tolplanemesh (the blob's `planemesh`)
     int actuation = 1;            // 0: no stable-PD torque, no residual force (ctrl = qfrc_applied = 0): torque-free flight for the energy test
@@ -47,7 +47,8 @@ struct kp_sim {
     float *t_qpos = nullptr, *t_wbpos = nullptr, *t_wbquat = nullptr, *t_bquat = nullptr, *t_com = nullptr;
     int* diag = nullptr;
     int* order = nullptr; unsigned* cost = nullptr;   // launch order of the control-step kernel (k_lpt_order)
-    unsigned *jobq = nullptr, *jobctr = nullptr;      // job FIFO of kp_step_queue_kernel
+    unsigned *jobq = nullptr, *jobctr = nullptr, *ovfq = nullptr;      // ovfq: jobs handed from the lean queue kernel to kp_step_overflow_kernel
+    float* warm3 = nullptr;      // job FIFO of kp_step_queue_kernel
     float* spd_next = nullptr;                        // [N, 80] torque hand-over between the jobs of a control step
     int jobq_cap = 0, wave_slots = 2048;
     int q_nsub = -1, q_obj = -1;                      // what the queue's "heavy job" yardstick (jobctr[32..33] -> [48..49]) was measured on
@@ -265,12 +266,12 @@ int launch_step(kp_sim* s, const float* action, int nsub, const uint8_t* mask, b
     // resident wave per slot (kp_step_queue_kernel) instead of one workgroup per env, which ends on a long tail
     const int spj = s->model->substeps_per_job;
     // resident waves: LDS is allocated in 1 280-byte granules, 128 per CU (tools/micro/lds_granule_probe.hip); 256 VGPRs allow 8 waves per CU
-#if KP_LEAN_FREEFALL
-    // experiment build (kp_device.hpp): free fall only; KP_LDS_PAD pads the allocation so that the same binary can be run at fewer envs per CU
-    if (obj || s->model->contact || s->model->limits || A.warm_extrap != 0.f || s->model->threads != 64) return fail("KP_LEAN_FREEFALL build: contact = 0, limits = 0, warm_extrap = 0, threads_per_env = 64 only");
-    if (const char* e = std::getenv("KP_LDS_PAD")) lds = std::max<size_t>(lds, (size_t)std::atoi(e));
-#endif
-    const int per_cu = std::min(4 * KP_WAVES_PER_SIMD, 128 / (int)((lds + 1279) / 1280));
+    // floor scenes: the job queue runs on the lean layout (EnvLdsLean) with a register budget for three waves per SIMD; model option lean_queue = 0 keeps the
+    // full layout (two waves per SIMD; A / B measurements).  lds_pad: allocate at least that many bytes per env (experiments: fewer envs per CU with the same binary)
+    const bool lean = !obj && s->model->lean_queue && s->model->threads == 64;
+    size_t lds_q = lean ? sizeof(kp::EnvLdsLean) : lds;
+    if (s->model->lds_pad > 0) lds_q = std::max(lds_q, (size_t)s->model->lds_pad);
+    const int per_cu = std::min(lean ? 12 : 8, 128 / (int)((lds_q + 1279) / 1280));
     const int slots = s->model->queue_slots > 0 ? s->model->queue_slots : s->wave_slots / 8 * per_cu;
     int sizes[16], parts = 0;
     if (spj > 0 && nsub > 0) {
@@ -282,33 +283,32 @@ int launch_step(kp_sim* s, const float* action, int nsub, const uint8_t* mask, b
         }
     }
     const bool queue = nsub > 0 && parts > 1 && s->model->threads == 64 && s->n > slots && s->n <= 0xFFFFFF && !s->prof;   // env ids take 24 bits of a queue entry
-    A.jobq = s->jobq; A.jobctr = s->jobctr; A.spd_next = s->spd_next; A.n_parts = queue ? parts : 1; A.queue_fence = s->model->queue_fence; A.queue_heavy = s->model->queue_heavy; A.queue_prio = s->model->queue_prio; A.order_valid = A.order != nullptr;
+    A.jobq = s->jobq; A.jobctr = s->jobctr; A.ovfq = s->ovfq; A.warm3 = s->warm3; A.spd_next = s->spd_next; A.n_parts = queue ? parts : 1; A.queue_fence = s->model->queue_fence; A.queue_heavy = s->model->queue_heavy; A.queue_prio = s->model->queue_prio; A.order_valid = A.order != nullptr;
     A.part_sub_lo = A.part_sub_hi = 0;
     for (int k = 0; queue && k < parts; k++) (k < 8 ? A.part_sub_lo : A.part_sub_hi) |= (unsigned long long)(sizes[k] & 255) << (8 * (k & 7));
     if (queue) {
         // the yardstick of queue_heavy is the previous launch's mean job time per substep: it only means something for the same kernel on the same
         // schedule, so a change of the substep count or of the kernel instantiation starts it from nothing (that launch keeps no env)
-        if (nsub != s->q_nsub || (int)obj != s->q_obj) {
+        if (nsub != s->q_nsub || (int)obj + 2 * (int)lean != s->q_obj) {
             HIP_OK(hipMemsetAsync(s->jobctr + 32, 0, 2 * sizeof(unsigned), s->stream));
-            s->q_nsub = nsub; s->q_obj = (int)obj;
+            s->q_nsub = nsub; s->q_obj = (int)obj + 2 * (int)lean;
         }
         const unsigned total = (unsigned)s->n * (unsigned)parts;
         hipLaunchKernelGGL(kp::k_queue_init, dim3((total + 255) / 256), dim3(256), 0, s->stream, s->n, total, s->jobq, s->jobctr, A.order);   // inside the timed bracket
         A.order = nullptr;                                              // the queue kernel addresses envs by their queue entry
-#if !KP_LEAN_FREEFALL
-        if (obj) hipLaunchKernelGGL((kp::kp_step_queue_kernel<true>), dim3(slots), dim3(64), lds, s->stream, A);
-        else
-#endif
-        hipLaunchKernelGGL((kp::kp_step_queue_kernel<false>), dim3(slots), dim3(64), lds, s->stream, A);
+        if (obj) hipLaunchKernelGGL((kp::kp_step_queue_kernel<true>), dim3(slots), dim3(64), lds_q, s->stream, A);
+        else if (!lean) hipLaunchKernelGGL((kp::kp_step_queue_kernel<false>), dim3(slots), dim3(64), lds_q, s->stream, A);
+        else {
+            hipLaunchKernelGGL((kp::kp_step_queue_kernel<false, true>), dim3(slots), dim3(64), lds_q, s->stream, A);
+            // the jobs whose contacts did not fit the lean layout (normally none: every wave leaves at its first read)
+            hipLaunchKernelGGL(kp::kp_step_overflow_kernel, dim3(std::min(s->n, s->wave_slots / 8)), dim3(64), lds, s->stream, A);
+        }
     } else
     switch (s->model->threads) {
         case 64:
-#if !KP_LEAN_FREEFALL
             if (obj && nsub > 0) hipLaunchKernelGGL((kp::kp_step_kernel<64, true>), dim3(s->n), dim3(64), lds, s->stream, A);
             else if (obj) hipLaunchKernelGGL((kp::kp_forward_kernel<64, true>), dim3(s->n), dim3(64), lds, s->stream, A);
-            else
-#endif
-            KP_LAUNCH(64);
+            else KP_LAUNCH(64);
             break;
         case 128: KP_LAUNCH(128); break;
         case 256: KP_LAUNCH(256); break;
@@ -363,6 +363,8 @@ int kp_model_set_option(kp_model* m, const char* name, double v) {
     else if (k == "queue_heavy") m->queue_heavy = std::max(0, (int)v);
     else if (k == "queue_prio") m->queue_prio = v != 0;
     else if (k == "warm_extrap") m->warm_extrap = (float)v;
+    else if (k == "lean_queue") m->lean_queue = v != 0;
+    else if (k == "lds_pad") { if (v < 0 || v > 65536) return fail("lds_pad must be 0 .. 65536 bytes"); m->lds_pad = (int)v; }
     else if (k == "queue_slots") { if (v < 0) return fail("queue_slots must be >= 0 (0 = resident wave slots of the device)"); m->queue_slots = (int)v; }
     else if (k == "substeps_per_job") { if (v < 0 || v > 255) return fail("substeps_per_job must be 0 (whole control step per workgroup) .. 255"); m->substeps_per_job = (int)v; }
     else if (k == "threads_per_env") { if (v != 64 && v != 128 && v != 256) return fail("threads_per_env must be 64, 128 or 256"); m->threads = (int)v; }
@@ -387,6 +389,9 @@ double kp_model_get_option(const kp_model* m, const char* name) {
     if (k == "lpt_order") return m->lpt_order;
     if (k == "substeps_per_job") return m->substeps_per_job;
     if (k == "queue_slots") return m->queue_slots;
+    if (k == "lean_queue") return m->lean_queue;
+    if (k == "lds_pad") return m->lds_pad;
+    if (k == "lds_bytes_per_env_lean") return (double)sizeof(kp::EnvLdsLean);
     if (k == "job_taper") return m->job_taper;
     if (k == "queue_fence") return m->queue_fence;
     if (k == "queue_heavy") return m->queue_heavy;
@@ -417,7 +422,7 @@ kp_sim* kp_sim_create(const kp_model* m, int n_envs, int device_id, void* stream
     s->prev_bquat = dalloc(s, N * 96, &ok); s->prev_hpos = dalloc(s, N * 7, &ok);
     s->diag = (int*)dalloc(s, N * 4, &ok);
     s->order = (int*)dalloc(s, N, &ok); s->cost = (unsigned*)dalloc(s, N, &ok);
-    s->jobq_cap = (int)N * 16; s->jobq = (unsigned*)dalloc(s, (size_t)s->jobq_cap, &ok); s->jobctr = (unsigned*)dalloc(s, 64, &ok); s->spd_next = (float*)dalloc(s, N * 80, &ok);
+    s->jobq_cap = (int)N * 16; s->jobq = (unsigned*)dalloc(s, (size_t)s->jobq_cap, &ok); s->jobctr = (unsigned*)dalloc(s, 128, &ok); s->ovfq = (unsigned*)dalloc(s, N, &ok); s->warm3 = dalloc(s, N * 75, &ok); s->spd_next = (float*)dalloc(s, N * 80, &ok);
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, s->device) == hipSuccess && prop.multiProcessorCount > 0) s->wave_slots = prop.multiProcessorCount * 8;

@@ -44,12 +44,17 @@ namespace kp {
 __device__ __forceinline__ int kp_launder(int x) { asm volatile("" : "+v"(x)); return x; }
 __device__ __forceinline__ int kp_launder_uniform(int x) { asm volatile("" : "+s"(x)); return x; }      // the same for a wave-uniform value (stays in an SGPR)
 
+// the object extension of an env's LDS block.  Only reached under OBJ (a compile-time constant), where SL is EnvLdsObj itself; the other layouts never execute it
+template <class SL> __device__ __forceinline__ EnvLdsObj& as_obj(SL& s) { return reinterpret_cast<EnvLdsObj&>(s); }
+template <class SL> __device__ __forceinline__ const EnvLdsObj& as_obj(const SL& s) { return reinterpret_cast<const EnvLdsObj&>(s); }
+
 struct StepArgs {
     DevTables T;
     Params P;
     int n_envs, n_substeps;
     // per-env state (HBM, row-major [N, dim])
     float *qpos, *qvel, *qpos_d, *qvel_d, *warm;
+    float *warm3;              // [N][75] lean layout: the same vector between the solves of one job (step_body)
     float *warm2;              // [N][75] hand-over of the previous-but-one solution between the jobs of a control step (warm_extrap)
     float warm_extrap;         // beta of the extrapolated Newton start a_{k-1} + beta (a_{k-1} - a_{k-2}); 0 = MuJoCo's plain warm start
     const float *target_qpos, *action;
@@ -73,6 +78,7 @@ struct StepArgs {
     // wave through HBM.  jobq [n_envs * n_parts] entries (env | part << 24, 0xFFFFFFFF = not yet published), jobctr = {head, tail, stalled}
     unsigned* jobq;
     unsigned* jobctr;
+    unsigned* ovfq;            // [n_envs] lean queue kernel: (env | part << 24) of the jobs whose contacts did not fit its layout; jobctr[64] = count, [65] = claimed (kp_step_overflow_kernel)
     float* spd_next;           // [N, 80]: qfrc_applied ++ qfrc_actuator (78 floats) of an env's NEXT substep, computed by the job that ran the substep before it
     int n_parts;
     int queue_heavy;           // > 0: a wave that finds its env heavy (this job's cycles per substep > queue_heavy % of the launch's running mean) runs the env's next job itself
@@ -109,8 +115,8 @@ __device__ __forceinline__ float wave_min(float v) {
 
 __device__ __forceinline__ float wave_max_f(float v) { return -wave_min(-v); }
 
-template <int NT>
-__device__ __forceinline__ float block_sum(EnvLds& s, float v, int tid) {
+template <int NT, class SL>
+__device__ __forceinline__ float block_sum(SL& s, float v, int tid) {
     v = wave_sum(v);
     if (NT > 64) {
         KP_SYNC();
@@ -139,10 +145,10 @@ __device__ __forceinline__ V3 to_frame(V3 v) { return v3(v.z, v.y, -v.x); }  // 
 
 // contact frame (n, t1, t2).  Floor-only kernels: the constant plane frame; OBJ kernels: mju_makeFrame of the stored normal.
 struct Frame { V3 n, t1, t2; };
-template <bool OBJ>
-__device__ __forceinline__ Frame contact_frame(const EnvLds& s, int c) {
+template <bool OBJ, class SL>
+__device__ __forceinline__ Frame contact_frame(const SL& s, int c) {
     if (!OBJ) return Frame{v3(0.f, 0.f, 1.f), v3(0.f, 1.f, 0.f), v3(-1.f, 0.f, 0.f)};
-    const float* cn = static_cast<const EnvLdsObj&>(s).con_n + 3 * c;
+    const float* cn = as_obj(s).con_n + 3 * c;
     const V3 n = ld3(cn);
     V3 y = fabsf(n.y) < 0.5f ? v3(0.f, 1.f, 0.f) : v3(0.f, 0.f, 1.f);
     y = y - dot(n, y) * n;
@@ -161,8 +167,8 @@ __device__ __forceinline__ V3 frame_world(const Frame& f, V3 c) { return c.x * f
 //      (mj_kinematics + mj_comVel + the forward half of mj_rne);
 //   B. body-parallel (24 lanes at once): COM, world inertia about o, body wrench fb = I a + v x* I v.  qfrc_bias itself
 //      (backward half of mj_rne: subtree sums + projection on the dofs) is never formed: the solves take fb as bias force.
-template <int NT>
-__device__ __forceinline__ void forward_kin_bias(EnvLds& s, const DevTables& T, const Params& P, int depth, V3 bpos, int tid) {
+template <int NT, class SL>
+__device__ __forceinline__ void forward_kin_bias(SL& s, const DevTables& T, const Params& P, int depth, V3 bpos, int tid) {
     float* sc = s.U;              // scratch (free outside the ABA passes): [0, 138) half-angle sin/cos, [144, 384) per-body joint frames
     float* jf = s.U + 144;        // per body: local rotation qz (x) qy (x) qx (4), second axis R(qz) e_y (3), third axis R(qz qy) e_x (3)
     for (int i = tid; i < D_NU; i += NT) { float sn, cs; sincosf(0.5f * s.qpos[7 + i], &sn, &cs); sc[2 * i] = sn; sc[2 * i + 1] = cs; }
@@ -341,7 +347,8 @@ struct Lane8 {
 #ifndef KP_PK_ELIM
 #define KP_PK_ELIM 1
 #endif
-__device__ __forceinline__ void aba_elim3(EnvLds& s, const Lane8& L, const float* rhs, int d0, bool store_ok, float* IAx, float& pA) {
+template <class SL>
+__device__ __forceinline__ void aba_elim3(SL& s, const Lane8& L, const float* rhs, int d0, bool store_ok, float* IAx, float& pA) {
     const int r = L.r;
     const bool rowok = r < 6;
     float sxa[3][8], dsc[3], rh[3];
@@ -414,7 +421,8 @@ __device__ __forceinline__ void aba_elim3(EnvLds& s, const Lane8& L, const float
     }
 }
 
-__device__ __forceinline__ float aba_fwd3(EnvLds& s, const Lane8& L, float* out, int d0, bool store_ok, float a) {
+template <class SL>
+__device__ __forceinline__ float aba_fwd3(SL& s, const Lane8& L, float* out, int d0, bool store_ok, float a) {
     const int r = L.r;
     const int rc = r < 6 ? r : 5;
     const float rmask = r < 6 ? 1.f : 0.f;
@@ -440,7 +448,8 @@ __device__ __forceinline__ float aba_fwd3(EnvLds& s, const Lane8& L, float* out,
 }
 
 // root->leaves pass: joint accelerations from (U, 1/D, u) and the parent's spatial acceleration; leaves them in sv
-__device__ __forceinline__ void aba_forward(EnvLds& s, const Lane8& L, float* out, int lev_max = D_NLEV - 1) {
+template <class SL>
+__device__ __forceinline__ void aba_forward(SL& s, const Lane8& L, float* out, int lev_max = D_NLEV - 1) {
     const int r = L.r;
     const bool rowok = r < 6;
 #pragma nounroll
@@ -463,7 +472,8 @@ __device__ __forceinline__ void aba_forward(EnvLds& s, const Lane8& L, float* ou
 
 // bit lev set: the body this lane serves at tree level lev has contacts (con_start is fixed for the substep, so the Newton
 // factorisations test a register instead of reading two LDS words per level)
-__device__ __forceinline__ unsigned contact_levels(const EnvLds& s, const Lane8& L) {
+template <class SL>
+__device__ __forceinline__ unsigned contact_levels(const SL& s, const Lane8& L) {
     unsigned m = 0;
 #pragma unroll
     for (int lev = 0; lev < D_NLEV; lev++) {
@@ -473,11 +483,11 @@ __device__ __forceinline__ unsigned contact_levels(const EnvLds& s, const Lane8&
     return m;
 }
 
-template <int NT, bool OBJ>
+template <int NT, bool OBJ, class SL>
 // lev_clean: tree levels >= lev_clean carry no active contact row and no active joint limit, so their articulated inertias, U and
 // 1/D are the ones the substep's first Newton factorisation (which walks every level; same M, no extra armature there) left in LDS:
 // only the bias-force half runs there.
-__device__ __forceinline__ void aba_solve(EnvLds& s, const Params& P, const Lane8& L, const float* rhs, float* out, bool contact_inertia, int tid, int lev_clean = D_NLEV, const float* bwrench = nullptr,
+__device__ __forceinline__ void aba_solve(SL& s, const Params& P, const Lane8& L, const float* rhs, float* out, bool contact_inertia, int tid, int lev_clean = D_NLEV, const float* bwrench = nullptr,
                                           unsigned conlev = 0xFFFFFFFFu) {
     const int r = L.r;
     const bool rowok = r < 6;
@@ -538,7 +548,7 @@ __device__ __forceinline__ void aba_solve(EnvLds& s, const Params& P, const Lane
                     // object kernels: M_c = D F G F^T of every contact's active rows is already in LDS for this iterate (con_prepare, lane = contact, which
                     // also feeds the object rows of the Hessian), so a row of K = P M_c P^T is one symmetric 3 x 3 product and a cross product -- no
                     // mju_makeFrame, no frame round trip per contact, body row and factorisation
-                    const float* cM = static_cast<const EnvLdsObj&>(s).cM;
+                    const float* cM = as_obj(s).cM;
                     V3 pn = ld3(s.con_pos + 3 * c0);
                     float mn[6];
 #pragma unroll
@@ -615,7 +625,8 @@ __device__ __forceinline__ void aba_solve(EnvLds& s, const Params& P, const Lane
 // leaves->root pass only (no inertia updates), then the usual root->leaves pass.  rhs / wrench ([24][6], about o) may be null.
 // lev_max < D_NLEV - 1: the caller knows that rhs and wrench vanish on every body below tree level lev_max and only needs the
 // accelerations (sv) / out entries down to that level: the deeper levels would carry exact zeros up and are skipped in both halves.
-__device__ __forceinline__ void aba_resolve(EnvLds& s, const Lane8& L, const float* rhs, const float* wrench, float* out, int lev_max = D_NLEV - 1) {
+template <class SL>
+__device__ __forceinline__ void aba_resolve(SL& s, const Lane8& L, const float* rhs, const float* wrench, float* out, int lev_max = D_NLEV - 1) {
     const int r = L.r;
     const bool rowok = r < 6;
     const int rc = rowok ? r : 5;
@@ -657,9 +668,10 @@ __device__ __forceinline__ void aba_resolve(EnvLds& s, const Lane8& L, const flo
 }
 
 // ---------------------------------------------------------------- stable-PD torque + residual force (reference controller)
-template <int NT, bool OBJ>
+template <int NT, bool OBJ, class SL>
 // tq / act: this env's rows of the PD target and the action in HBM (null: zeros); read here once per substep instead of living in LDS
-__device__ __forceinline__ void spd_torque_rfc(EnvLds& s, const DevTables& T, const Params& P, const Lane8& L8, int tid, const float* __restrict__ tq, const float* __restrict__ act) {
+__device__ __forceinline__ void spd_torque_rfc(SL& s, const DevTables& T, const Params& P, const Lane8& L8, int tid, const float* __restrict__ tq, const float* __restrict__ act) {
+    float* const epv = SL::LEAN ? s.lim_jar - 6 : s.search;      // the position error of dof i >= 6 (lean layout: search is the solve's own vector, lim_jar is dead here)
     for (int i = tid; i < D_NV; i += NT) {
         float ep = 0.f, kp = 0.f, kd = 0.f;
         if (i >= 6) {
@@ -675,14 +687,14 @@ __device__ __forceinline__ void spd_torque_rfc(EnvLds& s, const DevTables& T, co
             ep = q + s.qvel[i] * P.h - target;
         }
         s.extra[i] = kd * P.h;                      // (M + K_d dt): K_d dt is extra joint armature
-        s.search[i] = ep;
+        if (!SL::LEAN || i >= 6) epv[i] = ep;
         s.x[i] = -kp * ep - kd * s.qvel[i];
     }
     KP_SYNC();
     aba_solve<NT, OBJ>(s, P, L8, s.x, s.x, false, tid, D_NLEV, s.fb);
     for (int j = tid; j < D_NU; j += NT) {
         int i = j + 6;
-        float tau = -T.kp[j] * s.search[i] - T.kd[j] * (s.qvel[i] + s.x[i] * P.h);
+        float tau = -T.kp[j] * epv[i] - T.kd[j] * (s.qvel[i] + s.x[i] * P.h);
         float lim = T.tlim[j];
         s.ctrl[j] = fminf(fmaxf(tau, -lim), lim);
     }
@@ -720,32 +732,34 @@ __device__ __forceinline__ float geom_rbound(const float* g) { return g[0] == 0.
 
 // one lane appends a contact: vertex-side entity A (0..23 hull, 24 + k object slot), surface-side entity B (-1 world / static geom),
 // normal pointing from B's geom into A's
-template <bool OBJ>
+template <bool OBJ, class SL>
 // B: entity carrying the surface (-1 floor, -2 - g static geom g, 24 + k object slot k); its invweight0 is looked up by make_constraint
-__device__ __forceinline__ void put_contact(EnvLds& s, int c, V3 pos, float dist, V3 nrm, int A, int B) {
+__device__ __forceinline__ void put_contact(SL& s, int c, V3 pos, float dist, V3 nrm, int A, int B) {
     st3(s.con_pos + 3 * c, pos);
     s.con_D[c] = dist; s.con_body[c] = (unsigned char)A;          // con_D holds the distance until make_constraint
     if constexpr (OBJ) {
-        EnvLdsObj& so = static_cast<EnvLdsObj&>(s);
+        EnvLdsObj& so = as_obj(s);
         st3(so.con_n + 3 * c, nrm); so.con_b2[c] = (signed char)B;
     }
 }
 
 // LDS scratch of the MPR query (witnesses of the portal vertices, 30 doubles) inside s.U, which is free outside the ABA passes:
 // U[0, 96) box-box polygon, U[96, 152) contact records of a pair, U[160, 220) this, U[232, 247) hull record of the support functor
-__device__ __forceinline__ double* mpr_scratch(EnvLds& s) {
-    static_assert(offsetof(EnvLds, U) % 8 == 0, "s.U must be 8-byte aligned for the fp64 MPR scratch");
+template <class SL>
+__device__ __forceinline__ double* mpr_scratch(SL& s) {
+    static_assert(offsetof(SL, U) % 8 == 0, "s.U must be 8-byte aligned for the fp64 MPR scratch");
     return reinterpret_cast<double*>(s.U + 160);
 }
 
 // mj_collision of the scene.  Mid phase in parallel: lane = hull body (then lane = object geom) tests all its targets (bit 0 = floor,
 // bit j = geom j - 1) with bounding spheres; the serial part visits only the pairs that passed, in the oracle's order (entity-major,
 // floor first), so contact indices and the con_start[] grouping are the oracle's.  Narrow phases: kp_collide.hpp.
-template <int NT, bool OBJ>
-__device__ __forceinline__ void collide(EnvLds& s, const DevTables& T, const Params& P, int tid) {
+template <int NT, bool OBJ, class SL>
+__device__ __forceinline__ void collide(SL& s, const DevTables& T, const Params& P, int tid) {
     if (tid < 64) {
         int ncon = 0, next_b = 0;
-        const int ngeom = OBJ ? static_cast<EnvLdsObj&>(s).ngeom : 0;
+        bool over = false;           // wave-uniform: a pair found more contacts than the layout has room for (the lean layout reports it: ncon = MAXCON + 1)
+        const int ngeom = OBJ ? as_obj(s).ngeom : 0;
         unsigned mybits = 0;
         if (tid < D_NB && P.contact) {
             const V3 xb = ld3(s.xpos + 3 * tid);
@@ -753,7 +767,7 @@ __device__ __forceinline__ void collide(EnvLds& s, const DevTables& T, const Par
             if (!(xb.z - rb > P.margin)) mybits = 1u;
             if constexpr (OBJ) {
                 for (int gi = 0; gi < ngeom; gi++) {
-                    const float* g = static_cast<EnvLdsObj&>(s).geom + 17 * gi;
+                    const float* g = as_obj(s).geom + 17 * gi;
                     const V3 dx = xb - ld3(g + 4);
                     if (sqrtf(dot(dx, dx)) - rb - geom_rbound(g) > P.margin) continue;
                     // second, exact-safe cull: the hull lies inside the sphere (body origin, rbound) and a signed distance is 1-Lipschitz, so
@@ -801,13 +815,14 @@ __device__ __forceinline__ void collide(EnvLds& s, const DevTables& T, const Par
                     const int rank = __popcll(m & ((1ull << tid) - 1ull));
                     const int extra = P.pm_max - 1;
                     const int cnt = 1 + min(__popcll(m), extra);
-                    const int room = D_MAXCON - ncon;
+                    const int room = SL::MAXCON - ncon;
+                    over |= cnt > room;
                     if (tid == idx && room > 0) put_contact<OBJ>(s, ncon, v3(xw.x, xw.y, xw.z - 0.5f * xw.z), xw.z, v3(0.f, 0.f, 1.f), b, -1);
                     if (ok && rank < extra && 1 + rank < room) put_contact<OBJ>(s, ncon + 1 + rank, v3(xj.x, xj.y, xj.z - 0.5f * xj.z), xj.z, v3(0.f, 0.f, 1.f), b, -1);
                     ncon += min(cnt, max(room, 0));
                 } else if constexpr (OBJ) {
                     // mjc_Convex (libccd MPR): geom 1 = the box / cylinder, geom 2 = the hull; one contact, normal into the hull
-                    EnvLdsObj& so = static_cast<EnvLdsObj&>(s);
+                    EnvLdsObj& so = as_obj(s);
                     const float* g = so.geom + 17 * gi;
                     // Third, exact-safe cull before the MPR query (round 4: on the envs that end the `objects` launch 13 of 15 queries per substep
                     // found nothing and cost 5 - 6 k cycles each): a separating PLANE.  lane = hull vertex (xw, already in registers); if every
@@ -843,7 +858,7 @@ __device__ __forceinline__ void collide(EnvLds& s, const DevTables& T, const Par
                     hull_support_store(hrec, xb, xb + mulmat(R, ld3(T.body_ipos + 3 * b)), R);       // centre = the body's COM (xipos)
                     const HullSupport hb(hrec, v, tid < nvb);
                     Contact c;
-                    if (convex_pair(ga, hb, P.margin, c, mpr_scratch(s)) && ncon < D_MAXCON) {
+                    if (convex_pair(ga, hb, P.margin, c, mpr_scratch(s)) && ncon < SL::MAXCON) {
                         if (tid == 0) put_contact<OBJ>(s, ncon, c.pos, c.dist, c.n, b, so.gobj[gi] < 0 ? -2 - gi : D_NB + so.gobj[gi]);
                         ncon++;
                     }
@@ -853,7 +868,7 @@ __device__ __forceinline__ void collide(EnvLds& s, const DevTables& T, const Par
         if (tid == 0) for (int bb = next_b; bb <= D_NB; bb++) s.con_start[bb] = ncon;
         if constexpr (OBJ) {
             // dynamic objects in slot order: every geom against the floor, then against the geoms of the objects in higher slots
-            EnvLdsObj& so = static_cast<EnvLdsObj&>(s);
+            EnvLdsObj& so = as_obj(s);
             float* rec = s.U + 96;                             // contact records of one pair; s.U is free outside the ABA passes
             int slot_done = 0;
             unsigned gbits = 0;
@@ -911,31 +926,31 @@ __device__ __forceinline__ void collide(EnvLds& s, const DevTables& T, const Par
                             if (n && tid == 0) put_rec(rec, 0, c.dist, c.pos, c.n);
                         }
                     }
-                    n = min(n, D_MAXCON - ncon);
+                    n = min(n, SL::MAXCON - ncon);
                     if (tid < n) put_contact<OBJ>(s, ncon + tid, ld3(rec + 7 * tid + 1), rec[7 * tid], sgn * ld3(rec + 7 * tid + 4), D_NB + ka, entB);
                     ncon += n;
                 }
             }
             while (slot_done < D_MAXOBJ) { slot_done++; if (tid == 0) s.con_start[D_NB + slot_done] = ncon; }
         }
-        if (tid == 0) { s.ncon = ncon; s.nlim = 0; }
+        if (tid == 0) { s.ncon = (SL::LEAN && over) ? SL::MAXCON + 1 : ncon; s.nlim = 0; }
     }
     KP_SYNC();
 }
 
 // efc_D and the reference acceleration of every constraint row.  aref (contact-frame 3-vector) goes to jv3.
-template <int NT, bool OBJ>
-__device__ __forceinline__ void make_constraint(EnvLds& s, const DevTables& T, const Params& P, int tid) {
+template <int NT, bool OBJ, class SL>
+__device__ __forceinline__ void make_constraint(SL& s, const DevTables& T, const Params& P, int tid) {
     const V3 o = ld3(s.xpos);
     for (int c = tid; c < s.ncon; c += NT) {
         int b = s.con_body[c];
         float r = s.con_D[c] - P.margin;                    // collide() left the distance here
         float imp = impedance(P, r);
         float iwA = T.body_invw[b < D_NB ? b : 0];
-        if (OBJ && b >= D_NB) iwA = static_cast<EnvLdsObj&>(s).oc[13 * (b - D_NB) + 10];
+        if (OBJ && b >= D_NB) iwA = as_obj(s).oc[13 * (b - D_NB) + 10];
         float iwB = 0.f;
         if (OBJ) {                                         // invweight0 of the surface's entity: static geom / object slot / floor (0)
-            const EnvLdsObj& so = static_cast<const EnvLdsObj&>(s);
+            const EnvLdsObj& so = as_obj(s);
             const int b2 = so.con_b2[c];
             if (b2 >= D_NB) iwB = so.oc[13 * (b2 - D_NB) + 10]; else if (b2 < -1) iwB = so.geom[17 * (-2 - b2) + 16];
         }
@@ -945,7 +960,7 @@ __device__ __forceinline__ void make_constraint(EnvLds& s, const DevTables& T, c
         S6 cv = lds6(s.sv + 6 * b);                         // sv still holds cvel from forward_kin_bias (objects: obj_forward)
         V3 vp = cv.l + cross(cv.a, ld3(s.con_pos + 3 * c) - o);
         if (OBJ) {
-            const int b2 = static_cast<EnvLdsObj&>(s).con_b2[c];
+            const int b2 = as_obj(s).con_b2[c];
             if (b2 >= 0) { const S6 c2 = lds6(s.sv + 6 * b2); vp = vp - (c2.l + cross(c2.a, ld3(s.con_pos + 3 * c) - o)); }
         }
         V3 vf = frame_comp(contact_frame<OBJ>(s, c), vp);
@@ -972,15 +987,15 @@ __device__ __forceinline__ void make_constraint(EnvLds& s, const DevTables& T, c
 // contact-frame residuals of all rows for the body spatial accelerations in acc (default: sv) and the generalized vector vec [- vec_b]:
 // out3 = frame^T (point accel) [- aref] [+ jar3];  sub_aref: subtract the reference acceleration (jv3 / lim_jv);  add_base: add the
 // residuals already in jar3 / lim_jar (rows are linear: residual(q + dq) = residual(q) + J dq)
-template <int NT, bool OBJ>
-__device__ __forceinline__ void eval_rows(EnvLds& s, const float* vec, float* out3, float* lim_rows, bool sub_aref, int tid, const float* acc = nullptr, const float* vec_b = nullptr, bool add_base = false) {
+template <int NT, bool OBJ, class SL>
+__device__ __forceinline__ void eval_rows(SL& s, const float* vec, float* out3, float* lim_rows, bool sub_aref, int tid, const float* acc = nullptr, const float* vec_b = nullptr, bool add_base = false) {
     const V3 o = ld3(s.xpos);
     if (!acc) acc = s.sv;
     for (int c = tid; c < s.ncon; c += NT) {
         S6 S = lds6(acc + 6 * s.con_body[c]);
         V3 ap = S.l + cross(S.a, ld3(s.con_pos + 3 * c) - o);
         if (OBJ) {
-            const int b2 = static_cast<const EnvLdsObj&>(s).con_b2[c];
+            const int b2 = as_obj(s).con_b2[c];
             if (b2 >= 0) { const S6 S2 = lds6(acc + 6 * b2); ap = ap - (S2.l + cross(S2.a, ld3(s.con_pos + 3 * c) - o)); }
         }
         V3 a = frame_comp(contact_frame<OBJ>(s, c), ap);
@@ -999,8 +1014,8 @@ __device__ __forceinline__ void eval_rows(EnvLds& s, const float* vec, float* ou
 // ascending body order.  The trip count is wave-uniform (the largest subtree among the wave's items) and the LDS reads go out in
 // batches of 8 before the first add: a per-lane loop over its own subtree pays one LDS round trip per element (24 for the root).
 // Reads past the subtree (at most 7 records, still inside EnvLds) are discarded by the select.
-template <int NT>
-__device__ __forceinline__ void subtree_sums(EnvLds& s, int tid) {
+template <int NT, class SL>
+__device__ __forceinline__ void subtree_sums(SL& s, int tid) {
     for (int base = 0; base < D_NB * 6; base += NT) {
         const int it = base + tid;
         const bool ok = it < D_NB * 6;
@@ -1020,11 +1035,11 @@ __device__ __forceinline__ void subtree_sums(EnvLds& s, int tid) {
 }
 
 // out = M (va - vb) (with_inertia; acc6 [24][6] must hold the body spatial accelerations of va - vb) - J^T f(jar) (with_forces)
-template <int NT, bool OBJ>
+template <int NT, bool OBJ, class SL>
 // forces (optional): the contacts' world forces at the current residuals, [ncon][3], already evaluated (object kernels: con_prepare, lane = contact)
 // bias / rhs (optional): body wrenches [24][6] added to, and a generalized force [75] subtracted from, the result: with the bias wrenches fb and
 // rhs = qfrc_applied + qfrc_actuator, out = M va - qfrc_smooth - J^T f, the gradient of the primal problem without a detour through qacc_smooth
-__device__ __forceinline__ void wrench_project(EnvLds& s, const Params& P, const float* acc6, const float* va, const float* vb, float* out, bool with_inertia, bool with_forces, int tid,
+__device__ __forceinline__ void wrench_project(SL& s, const Params& P, const float* acc6, const float* va, const float* vb, float* out, bool with_inertia, bool with_forces, int tid,
                                                const float* forces = nullptr, const float* bias = nullptr, const float* rhs = nullptr) {
     if (tid < D_NB) {
         const int b = tid;
@@ -1077,8 +1092,8 @@ __device__ __forceinline__ void wrench_project(EnvLds& s, const Params& P, const
 
 // 0.5 a^T I_b b summed over the bodies + 0.5 arm x y over the dofs: lane partial of  0.5 x^T M y  for the generalized vectors x, y
 // whose body spatial accelerations are acca / accb (xa - xb and ya - yb give the dof vectors; xb / yb may be null)
-template <int NT>
-__device__ __forceinline__ float quad_form_M(const EnvLds& s, const float* acca, const float* accb, const float* xa, const float* xb, const float* ya, const float* yb, int tid) {
+template <int NT, class SL>
+__device__ __forceinline__ float quad_form_M(const SL& s, const float* acca, const float* accb, const float* xa, const float* xb, const float* ya, const float* yb, int tid) {
     float c = 0.f;
     if (tid < D_NB) c += 0.5f * dot6(lds6(acca + 6 * tid), inert_mul(s.cinert + 10 * tid, lds6(accb + 6 * tid)));
     for (int i = tid; i < D_NV; i += NT) c += 0.5f * s.arm[i] * (xa[i] - (xb ? xb[i] : 0.f)) * (ya[i] - (yb ? yb[i] : 0.f));
@@ -1087,8 +1102,8 @@ __device__ __forceinline__ float quad_form_M(const EnvLds& s, const float* acca,
 
 // spatial "acceleration" of every body induced by a generalized vector (what aba_solve leaves in sv).  Each body's own share
 // da_b = sum_j vec_j cdof_j is formed body-parallel first, so the level-synchronous chain is one 6-vector add per level (as in the kinematics).
-template <int NT>
-__device__ __forceinline__ void spatial_accumulate(EnvLds& s, const float* vec, int depth, int tid, float* out = nullptr) {
+template <int NT, class SL>
+__device__ __forceinline__ void spatial_accumulate(SL& s, const float* vec, int depth, int tid, float* out = nullptr) {
     if (!out) out = s.sv;
     S6 da = S6{v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f)};
     if (tid < D_NB) {
@@ -1106,8 +1121,8 @@ __device__ __forceinline__ void spatial_accumulate(EnvLds& s, const float* vec, 
 
 // records the active pyramid rows of every contact; returns 1 on the lanes that saw a change since the last call.  deep: running
 // maximum of the tree level of the hulls that carry an active row (first_clean_level's contact half, from the same row values)
-template <int NT>
-__device__ __forceinline__ float active_set_changed(EnvLds& s, const Params& P, int tid, float& deep) {
+template <int NT, class SL>
+__device__ __forceinline__ float active_set_changed(SL& s, const Params& P, int tid, float& deep) {
     float changed = 0.f;
     for (int c = tid; c < s.ncon; c += NT) {
         const float jn = s.jar3[3 * c], jt1 = s.jar3[3 * c + 1], jt2 = s.jar3[3 * c + 2];
@@ -1125,8 +1140,8 @@ __device__ __forceinline__ float active_set_changed(EnvLds& s, const Params& P, 
 // first tree level below every active constraint: 1 + the deepest level holding a body with an active contact row or a dof with
 // an active joint limit (jar < 0); the root level always counts as dirty.  deep: per-lane maxima gathered by active_set_changed and
 // the gradient loop
-template <int NT>
-__device__ __forceinline__ int first_clean_level(EnvLds& s, float deep, int tid) {
+template <int NT, class SL>
+__device__ __forceinline__ int first_clean_level(SL& s, float deep, int tid) {
     float m = -wave_min(-deep);
     if (NT > 64) {
         KP_SYNC();
@@ -1146,11 +1161,11 @@ __device__ __forceinline__ int first_clean_level(EnvLds& s, float deep, int tid)
 // FMAs per row and two wave sums, without LDS traffic.  rowcost: the rows' share of the cost at the returned alpha.
 // ROWCOST = false leaves rowcost alone (rounds 1 - 2: the object kernel kept its full cost evaluation because three more live values across
 // the search moved spills into its articulated-body loops; since the round-3 register discipline both solvers take the closed form)
-template <int NT, bool ROWCOST = true>
+template <int NT, bool ROWCOST = true, class SL>
 // want_rc0: rc0 receives the rows' share of the cost at alpha = 0, i.e. at the iterate the search starts from (the solve's first iteration has no
 // previous line search to take it from)
-__device__ __forceinline__ float line_search(EnvLds& s, const Params& P, float g0, float h0, int tid, float& rowcost, bool want_rc0, float& rc0) {
-    static_assert(D_MAXCON <= 64 && NT >= 64, "one contact per lane");
+__device__ __forceinline__ float line_search(SL& s, const Params& P, float g0, float h0, int tid, float& rowcost, bool want_rc0, float& rc0) {
+    static_assert(SL::MAXCON <= 64 && NT >= 64, "one contact per lane");
     float ra[4], rb[4], rD[4], Dc;
     {
         const bool ok = tid < s.ncon;
@@ -1220,8 +1235,8 @@ __device__ __forceinline__ float line_search(EnvLds& s, const Params& P, float g
 // factorisations of the substep reuse exactly as they reused the smooth solve's.  Without constraint rows qacc = M^-1 qfrc_smooth is one plain solve.
 // Results agree with the two-candidate form to the solver's tolerance; the iteration path is MuJoCo's whenever MuJoCo starts from its warm start.
 // On entry: s.qacc = warm start, jv3 / lim_jv = aref, s.applied ++ s.ctrl = qfrc_applied + qfrc_actuator, s.fb = bias wrenches.
-template <int NT>
-__device__ __forceinline__ int solve_constraints_direct(EnvLds& s, const Params& P, const Lane8& L8, int depth, int tid, int& nfact, int& ncap) {
+template <int NT, class SL>
+__device__ __forceinline__ int solve_constraints_direct(SL& s, const Params& P, const Lane8& L8, int depth, int tid, int& nfact, int& ncap) {
     if (s.ncon == 0 && s.nlim == 0) {
         aba_solve<NT, false>(s, P, L8, s.applied, s.qacc, false, tid, D_NLEV, s.fb);
         return 0;
@@ -1622,10 +1637,8 @@ __device__ __forceinline__ void obj_integrate(EnvLdsObj& s, const Params& P, int
 // [9][nc][6] + the joint-space right-hand sides u of the path's dofs [npd][nc]; nc = columns per round is what fits.
 constexpr int D_SCHUR_SCRATCH = D_MAXCON * 3 + 72 + 144 + 144;
 __device__ __forceinline__ void schur_columns(EnvLdsObj& s, const Params& P, unsigned cmask, int tid) {
-#if !KP_LEAN_FREEFALL
     static_assert(offsetof(EnvLds, lim_jv) == offsetof(EnvLds, jv3) + sizeof(float) * D_MAXCON * 3 && offsetof(EnvLds, sa) == offsetof(EnvLds, lim_jv) + sizeof(float) * 72 &&
                   offsetof(EnvLds, sw) == offsetof(EnvLds, sa) + sizeof(float) * 144, "jv3 | lim_jv | sa | sw must be contiguous");
-#endif
     constexpr int ST = 6 * D_MAXOBJ + 1;
     const int jl = tid >> 3, r = tid & 7;
     const bool rowok = r < 6;
@@ -1945,12 +1958,16 @@ template <bool Q, typename V> __device__ __forceinline__ void gst(V* p, V v) {
     else *p = v;
 }
 
-template <int NT, bool OBJ, bool FWD, bool Q = false>
-__device__ __forceinline__ void step_body(const StepArgs& A, const int env_in, const int part) {
+// LEAN: the floor scenes' job-queue layout (EnvLdsLean).  Returns 1 when the lean layout could not hold a substep's contacts: the job has written nothing to HBM at
+// that point and is re-run on the full layout (kp_step_overflow_kernel); 0 otherwise.
+template <int NT, bool OBJ, bool FWD, bool Q = false, bool LEAN = false>
+__device__ __forceinline__ int step_body(const StepArgs& A, const int env_in, const int part) {
+    static_assert(!LEAN || (Q && !OBJ && !FWD && NT == 64), "the lean layout serves the floor scenes' job queue only");
     // this job's share of the control step; A stays the kernel's read-only argument block (a by-value copy that the job modifies is a private copy per job)
     const int n_substeps = FWD ? 0 : (part >= 0 ? (int)(((part < 8 ? A.part_sub_lo >> (8 * part) : A.part_sub_hi >> (8 * (part - 8)))) & 255ull) : A.n_substeps);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    typename std::conditional<OBJ, EnvLdsObj, EnvLds>::type& s = *reinterpret_cast<typename std::conditional<OBJ, EnvLdsObj, EnvLds>::type*>(smem_raw);
+    using SL = typename std::conditional<OBJ, EnvLdsObj, typename std::conditional<LEAN, EnvLdsLean, EnvLds>::type>::type;
+    SL& s = *reinterpret_cast<SL*>(smem_raw);
     const int tid0 = threadIdx.x;
     // laundered per job: the per-lane table addresses of the load section below are invariant over the queue kernel's job loop, so LLVM formed them all at
     // kernel entry and kept ~20 of them (64-bit, per lane) in scratch for the whole launch, reloading them in every job.  With the store section's
@@ -1959,8 +1976,8 @@ __device__ __forceinline__ void step_body(const StepArgs& A, const int env_in, c
     // 45 MB).  Now 176 B per lane and 101 MB per launch (profiles/r04/traffic_with_and_without_queue.log).
     const int tid = kp_launder(tid0);
     const int env = env_in;
-    if (env >= A.n_envs) return;
-    if (A.env_mask && !A.env_mask[env]) return;
+    if (env >= A.n_envs) return 0;
+    if (A.env_mask && !A.env_mask[env]) return 0;
     const unsigned long long t_launch = __builtin_readcyclecounter();
     const DevTables& T = A.T;
     const Params& P = A.P;
@@ -2015,7 +2032,15 @@ __device__ __forceinline__ void step_body(const StepArgs& A, const int env_in, c
     // substep extrapolates depends on its index in the control step only, never on how the control step is cut into jobs.
     const float beta = A.warm_extrap;
     bool have_prev = false;
-    if (beta != 0.f && Q && part > 0 && A.warm2) { for (int i = tid; i < D_NV; i += NT) s.qacc_s[i] = gld<Q>(A.warm2 + (size_t)env * D_NV + (unsigned)(i)); have_prev = true; }
+    // lean layout (qacc_s is the solve's own vector there): a_{k-2} rides in a second HBM row of the env (A.warm3) between the solves of a job; the hand-over row
+    // A.warm2 is read at the job's start and written at its end only, so that a job cut short by a contact overflow leaves no trace
+    if (beta != 0.f && Q && part > 0 && A.warm2) {
+        for (int i = tid; i < D_NV; i += NT) {
+            const float v = gld<Q>(A.warm2 + (size_t)env * D_NV + (unsigned)(i));
+            if constexpr (LEAN) gst<Q>(A.warm3 + (size_t)env * D_NV + (unsigned)(i), v); else s.qacc_s[i] = v;
+        }
+        have_prev = true;
+    }
     unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
     const bool prof = A.prof != nullptr;
 #define KP_T(i) if (prof) { t1 = __builtin_readcyclecounter(); pc[i] += t1 - t0; t0 = t1; }
@@ -2077,20 +2102,15 @@ __device__ __forceinline__ void step_body(const StepArgs& A, const int env_in, c
             obj_forward(s, T, P, tid);
         }
         KP_T(1)
-#if KP_LEAN_FREEFALL
-        // experiment build (kp_device.hpp): no collision pass, no constraint rows, no Newton solve -- qacc = M^-1 qfrc_smooth is one articulated-body solve
-        for (int i = tid; i < D_NV; i += NT) s.extra[i] = 0.f;
-        KP_SYNC();
-        { Lane8 L8; L8.init(kp_launder(tid), T.sched8); aba_solve<NT, false>(s, P, L8, s.applied, s.qacc, false, tid, D_NLEV, s.fb); }
-#else
         collide<NT, OBJ>(s, T, P, tid);
+        if constexpr (LEAN) { if (s.ncon > SL::MAXCON) return 1; }      // wave-uniform; nothing of this job has been stored yet
         if (A.dbg_contacts && sub == n_substeps - 1) {      // test hook: the contact set of the last collision pass (con_D still holds the distance)
             float* o = A.dbg_contacts + (size_t)env * (1 + D_MAXCON * 9);
             if (tid == 0) o[0] = (float)s.ncon;
             for (int c = tid; c < s.ncon; c += NT) {
                 float* r = o + 1 + 9 * c;
                 r[0] = (float)s.con_body[c]; r[2] = s.con_D[c]; r[3] = s.con_pos[3 * c]; r[4] = s.con_pos[3 * c + 1]; r[5] = s.con_pos[3 * c + 2];
-                if constexpr (OBJ) { const EnvLdsObj& so = static_cast<const EnvLdsObj&>(s); r[1] = so.con_b2[c] < 0 ? -1.f : (float)so.con_b2[c]; r[6] = so.con_n[3 * c]; r[7] = so.con_n[3 * c + 1]; r[8] = so.con_n[3 * c + 2]; }
+                if constexpr (OBJ) { const EnvLdsObj& so = as_obj(s); r[1] = so.con_b2[c] < 0 ? -1.f : (float)so.con_b2[c]; r[6] = so.con_n[3 * c]; r[7] = so.con_n[3 * c + 1]; r[8] = so.con_n[3 * c + 2]; }
                 else { r[1] = -1.f; r[6] = 0.f; r[7] = 0.f; r[8] = 1.f; }
             }
         }
@@ -2116,8 +2136,9 @@ __device__ __forceinline__ void step_body(const StepArgs& A, const int env_in, c
         float keep0 = 0.f, keep1 = 0.f;
         if (beta != 0.f) {
             const int i0 = tid, i1 = tid + NT;
-            if (i0 < D_NV) { keep0 = s.qacc[i0]; if (have_prev) s.qacc[i0] = keep0 + beta * (keep0 - s.qacc_s[i0]); }
-            if (NT < D_NV && i1 < D_NV) { keep1 = s.qacc[i1]; if (have_prev) s.qacc[i1] = keep1 + beta * (keep1 - s.qacc_s[i1]); }
+            auto prev = [&](int i) { if constexpr (LEAN) return gld<Q>(A.warm3 + (size_t)env * D_NV + (unsigned)(i)); else return s.qacc_s[i]; };
+            if (i0 < D_NV) { keep0 = s.qacc[i0]; if (have_prev) s.qacc[i0] = keep0 + beta * (keep0 - prev(i0)); }
+            if (NT < D_NV && i1 < D_NV) { keep1 = s.qacc[i1]; if (have_prev) s.qacc[i1] = keep1 + beta * (keep1 - prev(i1)); }
             KP_SYNC();
         }
         if constexpr (OBJ) {
@@ -2129,12 +2150,16 @@ __device__ __forceinline__ void step_body(const StepArgs& A, const int env_in, c
         }
         if (beta != 0.f) {
             const int i0 = tid, i1 = tid + NT;
-            if (i0 < D_NV) s.qacc_s[i0] = keep0;
-            if (NT < D_NV && i1 < D_NV) s.qacc_s[i1] = keep1;
+            if constexpr (LEAN) {
+                if (i0 < D_NV) gst<Q>(A.warm3 + (size_t)env * D_NV + (unsigned)(i0), keep0);
+                if (NT < D_NV && i1 < D_NV) gst<Q>(A.warm3 + (size_t)env * D_NV + (unsigned)(i1), keep1);
+            } else {
+                if (i0 < D_NV) s.qacc_s[i0] = keep0;
+                if (NT < D_NV && i1 < D_NV) s.qacc_s[i1] = keep1;
+            }
             have_prev = true;
             KP_SYNC();
         }
-#endif      // KP_LEAN_FREEFALL
         KP_T(5)
         maxcon = max(maxcon, s.ncon);
         // ---- semi-implicit Euler (mj_Euler, no damping)
@@ -2164,7 +2189,7 @@ __device__ __forceinline__ void step_body(const StepArgs& A, const int env_in, c
     const int envS = kp_launder_uniform(env);
     bool bad = false;
     for (int i = tidS; i < D_NQ; i += NT) { float v = s.qpos[i]; bad |= !(fabsf(v) < 1e10f); if (n_substeps > 0) gst<Q>(A.qpos + (size_t)envS * D_NQ + (unsigned)(i), v); }
-    for (int i = tidS; i < D_NV; i += NT) { float v = s.qvel[i]; bad |= !(fabsf(v) < 1e10f); if (n_substeps > 0) { gst<Q>(A.qvel + (size_t)envS * D_NV + (unsigned)(i), v); gst<Q>(A.warm + (size_t)envS * D_NV + (unsigned)(i), s.qacc[i]); if (Q && beta != 0.f && A.warm2 && part >= 0 && part + 1 < A.n_parts) gst<Q>(A.warm2 + (size_t)envS * D_NV + (unsigned)(i), s.qacc_s[i]); } }
+    for (int i = tidS; i < D_NV; i += NT) { float v = s.qvel[i]; bad |= !(fabsf(v) < 1e10f); if (n_substeps > 0) { gst<Q>(A.qvel + (size_t)envS * D_NV + (unsigned)(i), v); gst<Q>(A.warm + (size_t)envS * D_NV + (unsigned)(i), s.qacc[i]); if (Q && beta != 0.f && A.warm2 && part >= 0 && part + 1 < A.n_parts) { float pv; if constexpr (LEAN) pv = gld<Q>(A.warm3 + (size_t)envS * D_NV + (unsigned)(i)); else pv = s.qacc_s[i]; gst<Q>(A.warm2 + (size_t)envS * D_NV + (unsigned)(i), pv); } } }
     if (!torque_out) {       // the derived state is read by the control step's NEXT first job only (a job that hands its torque over has no reader for it)
 #pragma unroll
         for (int n = 0; n < (D_NQ + NT - 1) / NT; n++) { int i = tidS + n * NT; if (i < D_NQ) gst<Q>(A.qpos_d + (size_t)envS * D_NQ + (unsigned)(i), qd_save_q[n]); }
@@ -2202,6 +2227,7 @@ __device__ __forceinline__ void step_body(const StepArgs& A, const int env_in, c
     }
     if (tidS == 0 && A.cost && n_substeps > 0)
         gst<Q>(A.cost + envS, (part > 0 ? gld<Q>(A.cost + envS) : 0u) + (unsigned)((__builtin_readcyclecounter() - t_launch) >> 10));
+    return 0;
 }
 
 // mj_fullM(model, M, data.qM)[:75, :75] and data.qfrc_bias[:75] as the reference's compute_desired_accel reads them
@@ -2268,11 +2294,11 @@ __global__ __launch_bounds__(1024) void k_lpt_order(int n, const unsigned* __res
 }
 
 template <int NT, bool OBJ>
-__global__ __launch_bounds__(NT, (NT == 64 ? KP_WAVES_PER_SIMD : 1)) void kp_step_kernel(StepArgs A) {
+__global__ __launch_bounds__(NT, (NT == 64 ? 2 : 1)) void kp_step_kernel(StepArgs A) {
     step_body<NT, OBJ, false>(A, A.order ? A.order[blockIdx.x] : (int)blockIdx.x, -1);
 }
 template <int NT, bool OBJ>
-__global__ __launch_bounds__(NT, (NT == 64 ? KP_WAVES_PER_SIMD : 1)) void kp_forward_kernel(StepArgs A) { step_body<NT, OBJ, true>(A, (int)blockIdx.x, -1); }
+__global__ __launch_bounds__(NT, (NT == 64 ? 2 : 1)) void kp_forward_kernel(StepArgs A) { step_body<NT, OBJ, true>(A, (int)blockIdx.x, -1); }
 
 // Same control step, scheduled in finer grains.  4096 envs on 8 x 256 wave slots are two rounds of whole-control-step jobs whose
 // lengths spread 2.9 M .. 5.4 M cycles, so a third of a kp_step_kernel launch is its tail (tools/launch_balance.py).  Here one
@@ -2291,8 +2317,10 @@ __global__ __launch_bounds__(NT, (NT == 64 ? KP_WAVES_PER_SIMD : 1)) void kp_for
 // Both are bit-identical in results (test_job_queue_schedule_is_bit_identical).  Measured on MI355X, 4096 envs standing + contact
 // (tools/queue_fence_bench.py, profiles/r02/queue_fence_bench.log): 3.818 ms (0) vs 3.837 ms (1) per launch -- the fences cost 0.5 %, so
 // the variant that is correct by construction is the default.
-template <bool OBJ>
-__global__ __launch_bounds__(64, KP_WAVES_PER_SIMD) void kp_step_queue_kernel(StepArgs A) {
+// LEAN (floor scenes): the EnvLdsLean layout and a register budget for three waves per SIMD; a job whose contacts do not fit the layout is handed, with the env's
+// remaining jobs, to kp_step_overflow_kernel (launched right behind this kernel, same stream).
+template <bool OBJ, bool LEAN = false>
+__global__ __launch_bounds__(64, (LEAN ? 3 : 2)) void kp_step_queue_kernel(StepArgs A) {
     // jobctr: [0] head (claimed), [1] tail (published), [2] stalled flag; on cache lines of their own, away from the head / tail every claim and publish hits:
     //         [16] jobs that were never queued because the finishing wave ran them itself; [32] time (40 ns units) and [33] substeps of the jobs finished so
     //         far in this launch; [48], [49] the same sums of the previous launch (the mean behind "heavy": constant during the launch, read once per wave)
@@ -2329,9 +2357,18 @@ __global__ __launch_bounds__(64, KP_WAVES_PER_SIMD) void kp_step_queue_kernel(St
         if (A.queue_prio > 0) { if (A.order_valid && part == 0 && idx < (unsigned)A.n_envs / 16u) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); }
         for (;;) {
             const unsigned long long tj = __builtin_amdgcn_s_memrealtime();          // 100 MHz ticks: only ratios of job times are used
-            step_body<64, OBJ, false, true>(A, env, part);
+            const int overflow = step_body<64, OBJ, false, true, LEAN>(A, env, part);
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // every lane's write-through state store has been acknowledged ...
             if (A.queue_fence) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // memory-model variant: release all of this wave's stores at agent scope
+            if (LEAN && overflow) {
+                // more contacts than the lean layout holds: this job (which has stored nothing) and the env's later jobs go to the overflow list; none of them
+                // will be published to this queue, which the waiting waves learn from jobctr[16] like they do for jobs a wave kept
+                if (threadIdx.x == 0) {
+                    A.ovfq[atomicAdd(&A.jobctr[64], 1u)] = (unsigned)env | ((unsigned)part << 24);
+                    atomicAdd(&A.jobctr[16], (unsigned)(A.n_parts - 1 - part));
+                }
+                break;
+            }
             if (part + 1 >= A.n_parts) break;
             // An env whose jobs run long is the one the launch will end on: with two envs per slot every hand-over through the FIFO costs it about one
             // job's length of waiting.  The wave that finds its env heavy -- cycles per substep above queue_heavy % of the launch's running mean --
@@ -2361,12 +2398,31 @@ __global__ __launch_bounds__(64, KP_WAVES_PER_SIMD) void kp_step_queue_kernel(St
     }
 }
 
+// The jobs the lean queue kernel could not hold (more than EnvLdsLean::MAXCON contacts in a substep), run on the full layout: a wave claims an entry and runs that
+// job and the env's remaining jobs itself.  Launched behind every lean queue launch; with an empty list (the rule: floor scenes hold 7 - 10 contacts) every wave
+// leaves at its first read.  The arithmetic is step_body's: which kernel ran a job changes nothing but the contact capacity.
+__global__ __launch_bounds__(64, 2) void kp_step_overflow_kernel(StepArgs A) {
+    for (;;) {
+        unsigned idx = 0;
+        if (threadIdx.x == 0) idx = atomicAdd(&A.jobctr[65], 1u);
+        idx = (unsigned)__builtin_amdgcn_readfirstlane((int)idx);
+        if (idx >= __hip_atomic_load(&A.jobctr[64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+        const unsigned e = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&A.ovfq[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        const int env = (int)(e & 0xFFFFFFu);
+        for (int part = (int)(e >> 24); part < A.n_parts; part++) {
+            step_body<64, false, false, true, false>(A, env, part);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            if (A.queue_fence) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+        }
+    }
+}
+
 // order (optional): the envs' first jobs enter the FIFO longest-env-first (k_lpt_order on the previous control step's cycles) instead of in
 // env order, so that the env whose three jobs take longest does not also start last
 __global__ void k_queue_init(int n_envs, unsigned total, unsigned* __restrict__ jobq, unsigned* __restrict__ jobctr, const int* __restrict__ order) {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < total) jobq[i] = i < (unsigned)n_envs ? (order ? (unsigned)order[i] : i) : 0xFFFFFFFFu;
-    if (i == 0) { jobctr[0] = 0u; jobctr[1] = (unsigned)n_envs; jobctr[16] = 0u; jobctr[48] = jobctr[32]; jobctr[49] = jobctr[33]; jobctr[32] = 0u; jobctr[33] = 0u; }
+    if (i == 0) { jobctr[0] = 0u; jobctr[1] = (unsigned)n_envs; jobctr[16] = 0u; jobctr[64] = 0u; jobctr[65] = 0u; jobctr[48] = jobctr[32]; jobctr[49] = jobctr[33]; jobctr[32] = 0u; jobctr[33] = 0u; }
 }
 
 }  // namespace kp

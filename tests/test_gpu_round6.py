@@ -1,0 +1,109 @@
+"""Round 6, on the device: the floor scenes' job queue on the lean LDS layout (EnvLdsLean: three waves per SIMD) against the full layout -- same bits --,
+the contact-overflow hand-over to kp_step_overflow_kernel, whole-episode parity against the CPU episode loop."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+pytestmark = pytest.mark.gpu
+STD = np.load(os.path.join(ROOT, "tests", "golden", "standing_neutral.npz"))
+
+
+def dev(a):
+    return torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device="cuda")
+
+
+def _run(kp, n, qpos, qvel, act, steps, **opts):
+    sim = kp.KpSim(kp.KpModel(**opts), n)
+    sim.set_state(dev(qpos), dev(qvel)); sim.set_target(dev(np.tile(STD["qpos"], (n, 1))))
+    a = dev(act)
+    for _ in range(steps):
+        sim.step_ctrl(a, 15)
+    return [sim.get(k).cpu().numpy() for k in ("qpos", "qvel", "xpos", "xquat", "xipos", "qpos_d")], sim.diag(), sim
+
+
+@pytest.fixture(scope="module")
+def kp():
+    from kinpoly_amd import sim as kpsim
+    return kpsim
+
+
+def _states(n, seed, lying_every=0):
+    rng = np.random.default_rng(seed)
+    qpos = np.tile(STD["qpos"], (n, 1)); qpos[:, 7:] += np.clip(rng.normal(size=(n, 69)) * 0.2, -np.pi, np.pi)
+    qvel = rng.normal(size=(n, 75)) * 0.5
+    if lying_every:
+        # every lying_every-th env lies on the floor (rolled about a horizontal axis by a seeded angle, pelvis 12 - 20 cm up): its hulls touch the plane all along
+        # the body -- more contacts than the lean layout's 32
+        idx = np.arange(0, n, lying_every)
+        ang = rng.uniform(-np.pi, np.pi, idx.size)
+        for k, e in enumerate(idx):
+            c, s_ = np.cos(np.pi / 4), np.sin(np.pi / 4)             # 90 degrees about x: on the back / front ...
+            q1 = np.array([c, s_, 0.0, 0.0])
+            cz, sz = np.cos(ang[k] / 2), np.sin(ang[k] / 2)          # ... then any heading
+            q2 = np.array([cz, 0.0, 0.0, sz])
+            w1, x1, y1, z1 = q2; w2, x2, y2, z2 = q1
+            qpos[e, 3:7] = [w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2, w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2]
+            qpos[e, 2] = rng.uniform(0.12, 0.2)
+            qpos[e, 7:] = STD["qpos"][7:] + rng.normal(size=69) * 0.05
+            qvel[e] *= 0.2
+    return qpos, qvel
+
+
+def test_lean_queue_layout_is_the_full_layout_bit_for_bit(kp):
+    """4096 floor envs, 3 control steps: kp_step_queue_kernel<false, true> (EnvLdsLean, 168 VGPRs, 10+ envs per CU) against the same queue on the full layout
+    (lean_queue = 0) and against one workgroup per env -- every state, read-out and diagnostic identical; also with warm_extrap = 0.75, whose a_{k-2} the lean
+    layout keeps in an HBM row."""
+    n = 4096
+    qpos, qvel = _states(n, 61)
+    act = np.random.default_rng(62).normal(size=(n, 75)) * 0.2
+    for extra in ({}, {"warm_extrap": 0.75}):
+        lean, dl, sim = _run(kp, n, qpos, qvel, act, 3, lean_queue=1, **extra)
+        assert sim.model.get_option("lds_bytes_per_env_lean") <= 12 * 1280
+        full, df, _ = _run(kp, n, qpos, qvel, act, 3, lean_queue=0, **extra)
+        for a_, b_ in zip(lean, full):
+            assert (a_ == b_).all(), extra
+        assert (dl == df).all()
+        assert (dl[:, 3] & 255).max() <= 32 and (dl[:, 2] & 255).max() == 0
+    one, d1, _ = _run(kp, n, qpos, qvel, act, 3, substeps_per_job=0)
+    for a_, b_ in zip(lean[:5], one[:5]):
+        assert (a_ == b_).all()
+
+
+def test_contact_overflow_goes_to_the_full_layout(kp):
+    """Every 8th of 4096 envs lies on the floor: more than 32 contacts in some substep, which the lean layout cannot hold.  Those jobs (and the env's later ones)
+    must come out of kp_step_overflow_kernel exactly as the full-layout queue computes them, the other envs untouched by the detour, the queue drained and
+    the status word clean; the envs that overflowed are the ones whose contact maximum exceeds 32."""
+    n = 4096
+    qpos, qvel = _states(n, 71, lying_every=8)
+    act = np.random.default_rng(72).normal(size=(n, 75)) * 0.1
+    lean, dl, sim = _run(kp, n, qpos, qvel, act, 4, lean_queue=1)
+    full, df, _ = _run(kp, n, qpos, qvel, act, 4, lean_queue=0)
+    maxcon = df[:, 3] & 255
+    assert (maxcon > 32).sum() >= 16, f"the scene must overflow the lean layout somewhere (max contacts {maxcon.max()}, envs above 32: {(maxcon > 32).sum()})"
+    assert (dl == df).all()
+    for a_, b_ in zip(lean, full):
+        assert (a_ == b_).all()
+    assert int(sim.status_tensor()[2]) == 0
+    assert np.isfinite(lean[0]).all() and (dl[:, 2] & 255).max() == 0
+
+
+@pytest.mark.timeout(900, method="thread")
+def test_whole_episodes_match_the_cpu_episode_loop():
+    """128 envs x 99 control steps of the configs[2] rollout, VectorSampler against oracle/episode.py with the same clips, weights and exploration
+    noise.  Outcomes: the step of every env's first termination, failures, mean reward; and |dqpos| along the episodes stays inside north_star's 1e-3 rad for
+    all but the rows that follow a contact knife-edge flip (bounded in number)."""
+    import episode_parity
+    r = episode_parity.run(n=128, T=99, seed=7, objects=False, workers=min(32, os.cpu_count() or 1))
+    print(r)
+    assert r["bad_envs"] == 0
+    assert r["first_termination_step_equal_frac"] >= 0.95
+    assert r["mean_reward"]["rel_diff"] < 0.01
+    assert abs(r["failures"]["hip"] - r["failures"]["oracle"]) <= max(2, int(0.02 * r["failures"]["oracle"]))
+    assert r["dqpos_aligned_rows"]["p50"] < 1e-5 and r["dqpos_aligned_rows"]["p99"] < 1e-3
