@@ -95,28 +95,33 @@ struct __attribute__((aligned(16))) EnvLds {
 //     the solution.  The object solver re-uses x after the solve (back-substitution) and keeps the four apart;
 //   * sa | sw (the gradient's body wrenches and their subtree sums, forward_kin_bias' velocity-product accelerations) share their words with jv3 | lim_jv | search:
 //     J search and the search direction are dead while a gradient is formed (its result lands in the words of sw, which is dead by then), sa is dead outside;
+//   * the Newton solve's body accelerations of the iterate (sacc, 144 floats) live in the words of qpos | qvel, which nothing reads between make_constraint and the
+//     Euler step: step_body restores both from the registers that hold the forward pass' state anyway (qd_save_q / qd_save_v) when the solve returns;
+//   * the contact residuals jar3 live in the words of xquat, dead once collide() has run: the read-outs (xpos, xquat, xipos of the control step's last forward
+//     pass) are stored right after the last substep's collision pass instead of at the job's end;
+//   * the bias forces handed up the tree (pAa) live in the words of jv3 | lim_jv, dead during every factorisation / solve (the object kernel's Schur columns use
+//     the same gap); their zero record is re-written at the top of a solve;
 //   * the stable-PD position error rides in lim_jar (dead outside the Newton solve), a_{k-2} of warm_extrap in the env's HBM row (kp_sim: warm2);
 //   * sv without the two object slots.
 struct __attribute__((aligned(16))) EnvLdsLean {
     static constexpr bool LEAN = true;
     static constexpr int MAXCON = 32;
     float qpos[76], qvel[76];
-    float xpos[72], xquat[96];
+    float xpos[72];
+    union { float xquat[96]; float jar3[MAXCON * 3]; };
     float cinert[240];
     float cdof[450];
     float sv[144];
     float U[450], Dinv[76];
-    float IAa[25 * 22], pAa[25 * 6];
+    float IAa[25 * 22];
     float arm[76];
     float fb[144];
     float qacc[76], extra[76];
-    float Mv[76], mres[76];
     float applied_pad[2], applied[6], ctrl[72];
     float con_pos[MAXCON * 3], con_D[MAXCON];
-    float jar3[MAXCON * 3];
     float lim_D[72], lim_jar[72];
     union {
-        struct { float jv3[MAXCON * 3], lim_jv[72]; union { float search[76], x[76], qacc_s[76], uj[76]; }; };
+        struct { union { struct { float jv3[MAXCON * 3], lim_jv[72]; }; float pAa[25 * 6]; }; union { float search[76], x[76], qacc_s[76], uj[76]; }; };
         struct { float sa[144], sw[144]; };
     };
     float red[8];

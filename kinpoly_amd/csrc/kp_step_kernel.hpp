@@ -491,6 +491,10 @@ __device__ __forceinline__ void aba_solve(SL& s, const Params& P, const Lane8& L
                                           unsigned conlev = 0xFFFFFFFFu) {
     const int r = L.r;
     const bool rowok = r < 6;
+    if constexpr (SL::LEAN) {              // pAa shares its words with J search there: the zero record absent children read is written anew for this solve
+        if (tid < 6) s.pAa[6 * 24 + tid] = 0.f;
+        KP_SYNC();
+    }
 #pragma nounroll
     for (int lev = D_NLEV - 1; lev >= 0; lev--) {
         const int sh = 5 * lev;
@@ -631,6 +635,10 @@ __device__ __forceinline__ void aba_resolve(SL& s, const Lane8& L, const float* 
     const bool rowok = r < 6;
     const int rc = rowok ? r : 5;
     const float rmask = rowok ? 1.f : 0.f;
+    if constexpr (SL::LEAN) {              // see aba_solve
+        if (threadIdx.x < 6) s.pAa[6 * 24 + threadIdx.x] = 0.f;
+        KP_SYNC();
+    }
     if (lev_max < D_NLEV - 1) {            // the skipped children hand up zero bias forces
         for (int i = threadIdx.x; i < 24 * 6; i += 64) s.pAa[i] = 0.f;
         KP_SYNC();
@@ -1241,7 +1249,8 @@ __device__ __forceinline__ int solve_constraints_direct(SL& s, const Params& P, 
         aba_solve<NT, false>(s, P, L8, s.applied, s.qacc, false, tid, D_NLEV, s.fb);
         return 0;
     }
-    float* sacc = s.Mv;        // [24][6] over Mv + mres: spatial accelerations of the bodies induced by the iterate qacc
+    float* sacc;               // [24][6] spatial accelerations of the bodies induced by the iterate qacc: over Mv + mres; lean layout: over qpos | qvel (restored by step_body)
+    if constexpr (SL::LEAN) sacc = s.qpos; else sacc = s.Mv;
     float* grad = s.qacc_s;    // the words qacc_smooth would occupy
     spatial_accumulate<NT>(s, s.qacc, depth, tid, sacc);
     eval_rows<NT, false>(s, s.qacc, s.jar3, s.lim_jar, true, tid, sacc);
@@ -2041,6 +2050,14 @@ __device__ __forceinline__ int step_body(const StepArgs& A, const int env_in, co
         }
         have_prev = true;
     }
+    auto store_readouts = [&](int lane, int e) {
+        for (int i = lane; i < 72; i += NT) A.xpos[(size_t)e * 72 + (unsigned)(i)] = s.xpos[i];
+        if (lane < D_NB) {                   // xipos = xpos + R ipos of the same forward pass
+            const V3 xi = ld3(s.xpos + 3 * lane) + qrot(Q4{s.xquat[4 * lane], s.xquat[4 * lane + 1], s.xquat[4 * lane + 2], s.xquat[4 * lane + 3]}, ld3(T.body_ipos + 3 * lane));
+            st3(A.xipos + (size_t)e * 72 + (unsigned)(3 * lane), xi);
+        }
+        for (int i = lane; i < 96; i += NT) A.xquat[(size_t)e * 96 + (unsigned)(i)] = s.xquat[i];
+    };
     unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
     const bool prof = A.prof != nullptr;
 #define KP_T(i) if (prof) { t1 = __builtin_readcyclecounter(); pc[i] += t1 - t0; t0 = t1; }
@@ -2103,7 +2120,11 @@ __device__ __forceinline__ int step_body(const StepArgs& A, const int env_in, co
         }
         KP_T(1)
         collide<NT, OBJ>(s, T, P, tid);
-        if constexpr (LEAN) { if (s.ncon > SL::MAXCON) return 1; }      // wave-uniform; nothing of this job has been stored yet
+        if constexpr (LEAN) {
+            if (s.ncon > SL::MAXCON) return 1;      // wave-uniform; nothing of this job has been stored yet
+            // stale kinematics: the control step's read-outs are those of its last substep's forward pass; the solve below re-uses the words of xquat
+            if (P.stale && sub == n_substeps - 1 && part == A.n_parts - 1) store_readouts(tid, env);
+        }
         if (A.dbg_contacts && sub == n_substeps - 1) {      // test hook: the contact set of the last collision pass (con_D still holds the distance)
             float* o = A.dbg_contacts + (size_t)env * (1 + D_MAXCON * 9);
             if (tid == 0) o[0] = (float)s.ncon;
@@ -2147,6 +2168,17 @@ __device__ __forceinline__ int step_body(const StepArgs& A, const int env_in, co
         } else {
             KP_T(4)
             niter_total += solve_constraints_direct<NT>(s, P, L8, depth, tid, nfact_total, ncap_total);
+            if constexpr (LEAN) {
+                // the solve's body accelerations lived in the words of qpos | qvel: both come back from the registers that hold this substep's forward-pass state,
+                // the root quaternion normalised as forward_kin_bias left it
+#pragma unroll
+                for (int n = 0; n < (D_NQ + NT - 1) / NT; n++) { int i = tid + n * NT; if (i < D_NQ) s.qpos[i] = qd_save_q[n]; }
+#pragma unroll
+                for (int n = 0; n < (D_NV + NT - 1) / NT; n++) { int i = tid + n * NT; if (i < D_NV) s.qvel[i] = qd_save_v[n]; }
+                KP_SYNC();
+                if (tid == 0) { const Q4 q = qnormalize(Q4{s.qpos[3], s.qpos[4], s.qpos[5], s.qpos[6]}); s.qpos[3] = q.w; s.qpos[4] = q.x; s.qpos[5] = q.y; s.qpos[6] = q.z; }
+                KP_SYNC();
+            }
         }
         if (beta != 0.f) {
             const int i0 = tid, i1 = tid + NT;
@@ -2196,14 +2228,8 @@ __device__ __forceinline__ int step_body(const StepArgs& A, const int env_in, co
 #pragma unroll
         for (int n = 0; n < (D_NV + NT - 1) / NT; n++) { int i = tidS + n * NT; if (i < D_NV) gst<Q>(A.qvel_d + (size_t)envS * D_NV + (unsigned)(i), qd_save_v[n]); }
     }
-    if (!Q || part == A.n_parts - 1) {      // read-outs: the last job of the control step only (earlier jobs' copies could land later from another L2)
-        for (int i = tidS; i < 72; i += NT) A.xpos[(size_t)envS * 72 + (unsigned)(i)] = s.xpos[i];
-        if (tidS < D_NB) {                   // xipos = xpos + R ipos of the same forward pass
-            const V3 xi = ld3(s.xpos + 3 * tidS) + qrot(Q4{s.xquat[4 * tidS], s.xquat[4 * tidS + 1], s.xquat[4 * tidS + 2], s.xquat[4 * tidS + 3]}, ld3(T.body_ipos + 3 * tidS));
-            st3(A.xipos + (size_t)envS * 72 + (unsigned)(3 * tidS), xi);
-        }
-        for (int i = tidS; i < 96; i += NT) A.xquat[(size_t)envS * 96 + (unsigned)(i)] = s.xquat[i];
-    }
+    // read-outs: the last job of the control step only (earlier jobs' copies could land later from another L2); lean layout in stale mode: already stored (above)
+    if ((!Q || part == A.n_parts - 1) && !(LEAN && P.stale && n_substeps > 0)) store_readouts(tidS, envS);
     if constexpr (OBJ) {
         if (n_substeps > 0) {
             for (int k = 0; k < s.nobj; k++) {

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 6, call 2: the lean queue layout (stage B: 10 envs per CU) -- its new tests first, then every GPU test, then the A/B on the metric's workload
+# round 6, calls 2+: the lean queue layout (stage given by the tree) -- its new tests first, then every GPU test, then the A/B on the metric's workload
 set -u
 export TMPDIR=/tmp
 O=gpurun_out/r06; mkdir -p $O
@@ -10,5 +10,4 @@ for r in 1 2 3; do for v in 0 1; do
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('tracked KP_LEAN_QUEUE=$v value %.0f ms_per_step %.3f [%.3f %.3f] launch_ms %.3f contacts %.2f newton %.2f bad %d' % (d['value'], d['ms_per_step'], d['ms_per_step_min'], d['ms_per_step_max'], d['roofline']['launch_ms'], d['contacts_mean'], d['newton_iters_per_substep'], d['bad_envs']))"
-done; done 2>&1 | tee $O/lean_queue_ab_stageB.log
-timeout 1200 python tools/episode_parity.py --envs 128 --steps 99 --json $O/episode_parity_floor.json > $O/episode_parity_floor.log 2>&1; tail -40 $O/episode_parity_floor.log | head -60
+done; done 2>&1 | tee $O/lean_queue_ab_stageC.log
