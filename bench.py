@@ -50,7 +50,7 @@ VALU_FP32_PEAK_TFLOPS = 157.3       # spec-sheet vector fp32 = the PACKED rate (
                                     # Un-packed VALU fp32 -- what kp_step_kernel issues -- tops out at half of it, 78.6 TF = one wave-instruction per 4 cycles per SIMD =
                                     # 614.4 G wave-instructions/s, the ceiling roofline.issue.valu_issue_frac is measured against
 MFMA_FP32_PEAK_TFLOPS = 157.3       # dense fp32 matrix peak (spec sheet): the policy / value GEMMs run in fp32
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r05")
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r06")
 
 
 def build_engine(device_index, seed, threads, workload="tracked", n_envs=None):
@@ -654,6 +654,10 @@ def main():
     if not train:       # read what the line needs from the engine before it is torn down
         cost = env.sim.launch_cost().astype(np.float64)
         spj = int(env.model.get_option("substeps_per_job"))
+        per_cu = min(12 if env.model.get_option("lean_queue") and args.workload != "objects" else 8, 128 // -(-int(env.model.get_option("lds_bytes_per_env_objects" if args.workload == "objects" else ("lds_bytes_per_env_lean" if env.model.get_option("lean_queue") else "lds_bytes_per_env"))) // 1280))
+        slots = int(os.environ.get("KP_QUEUE_SLOTS", 0)) or torch.cuda.get_device_properties(local_rank).multi_processor_count * per_cu
+        qctr = {**env.sim.queue_counters(), "envs_per_cu": per_cu, "lean_layout": bool(env.model.get_option("lean_queue")), "lds_bytes_per_env": int(env.model.get_option("lds_bytes_per_env_lean" if env.model.get_option("lean_queue") else "lds_bytes_per_env")),
+                "lean_max_contacts": int(env.model.get_option("lean_max_contacts"))}
         if rank == 0 and world == 1 and not args.no_parity_live and args.workload in ("tracked", "random_init", "objects"):
             try:
                 live = parity_live(env, sampler, args.workload, getattr(env, "_a_track", None))
@@ -708,8 +712,8 @@ def main():
         if valu and valu.get("valu_insts_per_launch"):
             insts = (valu["valu_insts_per_launch"] + valu.get("salu_insts_per_launch", 0.0) + valu.get("lds_insts_per_launch", 0.0)) / ENVS_PER_GPU
             cyc = float(cost.mean())
-            issue = {"wave_insts_per_env_step": insts, "wave_cycles_per_env_step": cyc, "wave_cycles_per_inst": cyc / insts, "waves_per_simd": 2,
-                     "simd_cycles_per_inst": cyc / insts / 2.0, "attainable_simd_cycles_per_inst_at_2_waves": 2.9, "frac_of_attainable_issue": 2.9 / (cyc / insts / 2.0),
+            issue = {"wave_insts_per_env_step": insts, "wave_cycles_per_env_step": cyc, "wave_cycles_per_inst": cyc / insts, "waves_per_simd": per_cu / 4.0,
+                     "simd_cycles_per_inst": cyc / insts / (per_cu / 4.0), "attainable_simd_cycles_per_inst_at_2_waves": 2.9, "frac_of_attainable_issue": 2.9 / (cyc / insts / (per_cu / 4.0)),
                      # the kernel's own arithmetic throughput: VALU wave-instructions it executes per launch / this run's launch time, against one VALU
                      # wave-instruction per 4 cycles per SIMD (1024 SIMDs x 2.4 GHz / 4 = 614.4 G/s)
                      "valu_wave_insts_per_s_G": valu["valu_insts_per_launch"] / kern_s / 1e9, "valu_wave_inst_peak_G": 614.4,
@@ -734,10 +738,11 @@ def main():
                          "kernel": kernel_name, "launch_ms": kern_s * 1e3, "launch_ms_min": min(rec["kern_s_blocks"]) * 1e3, "launch_ms_max": max(rec["kern_s_blocks"]) * 1e3,
                          "launches_timed": n_launch, "algorithmic_bytes_per_launch": algo_bytes,
                          "valu_active_frac_of_launch": valu_active, "frac_of_attainable_issue": issue["frac_of_attainable_issue"] if issue else None,
-                         "limiter": "wave-level instruction issue: the SIMDs are saturated by their two resident waves (state lives in LDS, so the compulsory HBM traffic is tiny by construction; DESIGN.md section 6)",
+                         "limiter": "wave-level instruction issue of latency-bound dependent chains: residency (LDS bytes per env) sets how many waves hide them -- three per SIMD on the lean layout of floor scenes, two on the full layout (state lives in LDS, so the compulsory HBM traffic is tiny by construction; DESIGN.md section 6)",
                          "valu": valu, "issue": issue},
             "kernel_share_of_step": kern_s / (elapsed / args.steps),
-            "contacts_mean": float(diag[:, 0].mean()), "newton_iters_per_substep": float(diag[:, 1].mean() / 15.0),
+            "contacts_mean": float(diag[:, 0].mean()), "contacts_max_in_a_substep": int((diag[:, 3] & 255).max()), "newton_iters_per_substep": float(diag[:, 1].mean() / 15.0),
+            "queue": qctr,
             "hessian_factorisations_per_substep": float((diag[:, 3] >> 8).mean() / 15.0),
             "bad_envs": int(((diag[:, 2] & 255) != 0).sum()), "newton_cap_hits": int((diag[:, 2] >> 8).sum()),
             "episodes_ended_per_step_frac": rec["n_done"] / (ENVS_PER_GPU * args.steps),
@@ -746,7 +751,7 @@ def main():
             "mujoco_pin": mujoco_pin_report(),
             # per-env shader-clock cycles of the last launch (kp_sim_launch_cost): what the launch would take if its waves were perfectly
             # packed on the resident slots vs its longest env
-            "launch_balance": {"substeps_per_job": spj, "sum_env_cycles_over_2048_slots_ms": float(cost.sum() / 2048 / 2.38e6),
+            "launch_balance": {"substeps_per_job": spj, "slots": slots, "sum_env_cycles_over_slots_ms": float(cost.sum() / slots / 2.38e6),
                                "longest_env_ms": float(cost.max() / 2.38e6), "median_env_ms": float(np.median(cost) / 2.38e6)},
         }
         if world == 1 and not args.no_secondary:

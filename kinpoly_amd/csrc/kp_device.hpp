@@ -52,7 +52,7 @@ struct Params {
 // EnvLds      the full layout, 18 128 B (15 allocation granules of 1 280 B; 8 envs per CU = 2 waves per SIMD): every launch form except the floor scenes' job queue
 // EnvLdsLean  the floor scenes' job-queue kernel: 3 waves on every SIMD need <= 12 800 B per env (the free-fall instantiation at 12 instead of
 //             8 envs per CU is 18 - 19 % faster).  Same arithmetic, same code; what differs is where a few vectors live (see the struct) and the number of
-//             contacts the block holds (32: an env that needs more is handed to the full-layout kernel, kp_step_overflow_kernel)
+//             contacts the block holds (24: an env that needs more is handed to the full-layout kernel, kp_step_overflow_kernel)
 // EnvLdsObj   EnvLds + the free objects' block
 struct __attribute__((aligned(16))) EnvLds {
     static constexpr bool LEAN = false;
@@ -88,8 +88,9 @@ struct __attribute__((aligned(16))) EnvLds {
 
 // The floor scenes' job-queue layout.  Differences from EnvLds, each with the reason it is safe (phases of a substep, in order: spd_torque_rfc, forward_kin_bias,
 // collide, make_constraint, Newton solve = { gradient (wrench_project), factorisation / solve (aba_solve | aba_resolve), row evaluation, line search, update }, Euler):
-//   * MAXCON = 32 contacts (con_pos, con_D, jar3, jv3, con_act, con_body): floor scenes hold 7 - 10 on average; collide() reports an env that needs more and
-//     the job is re-run by kp_step_overflow_kernel on the full layout (no state of the job has reached HBM at that point);
+//   * MAXCON = 24 contacts (con_pos, con_D, jar3, jv3, con_act, con_body): floor scenes hold 7 - 10 on average, a humanoid lying flat 12 (mjc_PlaneConvex keeps
+//     at most 3 per hull and drops neighbours within 0.3 rbound); collide() reports an env that needs more and the job is re-run by kp_step_overflow_kernel on
+//     the full layout (no state of the job has reached HBM at that point);
 //   * ONE vector for the Newton step's gradient, right-hand side, joint-space bias u_j and search direction (search = x = qacc_s = uj): the gradient is negated in
 //     place, the leaves->root pass replaces x_d by u_d (read and written by the 8 lanes that own dof d, in that order), the root->leaves pass replaces u_d by
 //     the solution.  The object solver re-uses x after the solve (back-substitution) and keeps the four apart;
@@ -101,11 +102,12 @@ struct __attribute__((aligned(16))) EnvLds {
 //     pass) are stored right after the last substep's collision pass instead of at the job's end;
 //   * the bias forces handed up the tree (pAa) live in the words of jv3 | lim_jv, dead during every factorisation / solve (the object kernel's Schur columns use
 //     the same gap); their zero record is re-written at the top of a solve;
+//   * no copy of the dof armature: the eliminations read it folded into `extra` (same sum, formed once), the two products with M read the model table;
 //   * the stable-PD position error rides in lim_jar (dead outside the Newton solve), a_{k-2} of warm_extrap in the env's HBM row (kp_sim: warm2);
 //   * sv without the two object slots.
 struct __attribute__((aligned(16))) EnvLdsLean {
     static constexpr bool LEAN = true;
-    static constexpr int MAXCON = 32;
+    static constexpr int MAXCON = 24;
     float qpos[76], qvel[76];
     float xpos[72];
     union { float xquat[96]; float jar3[MAXCON * 3]; };
@@ -114,12 +116,11 @@ struct __attribute__((aligned(16))) EnvLdsLean {
     float sv[144];
     float U[450], Dinv[76];
     float IAa[25 * 22];
-    float arm[76];
     float fb[144];
-    float qacc[76], extra[76];
+    float qacc[76], extra[76];            // extra: dof armature + the solve's extra armature (K_d h, active joint limits): the sum the eliminations read
     float applied_pad[2], applied[6], ctrl[72];
     float con_pos[MAXCON * 3], con_D[MAXCON];
-    float lim_D[72], lim_jar[72];
+    float lim_D[D_NU], lim_jar[D_NU];
     union {
         struct { union { struct { float jv3[MAXCON * 3], lim_jv[72]; }; float pAa[25 * 6]; }; union { float search[76], x[76], qacc_s[76], uj[76]; }; };
         struct { float sa[144], sw[144]; };

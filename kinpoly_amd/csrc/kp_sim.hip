@@ -27,7 +27,7 @@ int fail(const std::string& m) { g_err = m; return -1; }
 
 struct kp_model {
     kp::HostModel h;
-    int contact = 1, limits = 1, stale = 1, solver_iter = 100, threads = 64, dynamic_objects = 1, lpt_order = -1, substeps_per_job = 4, queue_slots = 0, job_taper = 1, queue_fence = 1, queue_heavy = 160, queue_prio = 0, lean_queue = 1, lds_pad = 0;
+    int contact = 1, limits = 1, stale = 1, solver_iter = 100, threads = 64, dynamic_objects = 1, lpt_order = -1, substeps_per_job = 4, queue_slots = 0, job_taper = 1, queue_fence = 1, queue_heavy = 160, queue_prio = 0, lean_queue = 1, lds_pad = 0, lean_cap = kp::EnvLdsLean::MAXCON;
     float warm_extrap = -1.f;      // < 0: automatic (0.75 when the scene's free objects are simulated, 0 otherwise); see kp_step_kernel.hpp
     int planemesh_max = 3; double planemesh_tol = 0.3;   // mjc_PlaneConvex's maxplanemesh / tolplanemesh (the blob's `planemesh`)
     int actuation = 1;            // 0: no stable-PD torque, no residual force (ctrl = qfrc_applied = 0): torque-free flight for the energy test
@@ -283,7 +283,7 @@ int launch_step(kp_sim* s, const float* action, int nsub, const uint8_t* mask, b
         }
     }
     const bool queue = nsub > 0 && parts > 1 && s->model->threads == 64 && s->n > slots && s->n <= 0xFFFFFF && !s->prof;   // env ids take 24 bits of a queue entry
-    A.jobq = s->jobq; A.jobctr = s->jobctr; A.ovfq = s->ovfq; A.warm3 = s->warm3; A.spd_next = s->spd_next; A.n_parts = queue ? parts : 1; A.queue_fence = s->model->queue_fence; A.queue_heavy = s->model->queue_heavy; A.queue_prio = s->model->queue_prio; A.order_valid = A.order != nullptr;
+    A.jobq = s->jobq; A.jobctr = s->jobctr; A.ovfq = s->ovfq; A.lean_cap = s->model->lean_cap; A.warm3 = s->warm3; A.spd_next = s->spd_next; A.n_parts = queue ? parts : 1; A.queue_fence = s->model->queue_fence; A.queue_heavy = s->model->queue_heavy; A.queue_prio = s->model->queue_prio; A.order_valid = A.order != nullptr;
     A.part_sub_lo = A.part_sub_hi = 0;
     for (int k = 0; queue && k < parts; k++) (k < 8 ? A.part_sub_lo : A.part_sub_hi) |= (unsigned long long)(sizes[k] & 255) << (8 * (k & 7));
     if (queue) {
@@ -364,6 +364,7 @@ int kp_model_set_option(kp_model* m, const char* name, double v) {
     else if (k == "queue_prio") m->queue_prio = v != 0;
     else if (k == "warm_extrap") m->warm_extrap = (float)v;
     else if (k == "lean_queue") m->lean_queue = v != 0;
+    else if (k == "lean_max_contacts") { if (v < 0 || v > kp::EnvLdsLean::MAXCON) return fail("lean_max_contacts must be 0 .. " + std::to_string(kp::EnvLdsLean::MAXCON)); m->lean_cap = (int)v; }
     else if (k == "lds_pad") { if (v < 0 || v > 65536) return fail("lds_pad must be 0 .. 65536 bytes"); m->lds_pad = (int)v; }
     else if (k == "queue_slots") { if (v < 0) return fail("queue_slots must be >= 0 (0 = resident wave slots of the device)"); m->queue_slots = (int)v; }
     else if (k == "substeps_per_job") { if (v < 0 || v > 255) return fail("substeps_per_job must be 0 (whole control step per workgroup) .. 255"); m->substeps_per_job = (int)v; }
@@ -390,6 +391,7 @@ double kp_model_get_option(const kp_model* m, const char* name) {
     if (k == "substeps_per_job") return m->substeps_per_job;
     if (k == "queue_slots") return m->queue_slots;
     if (k == "lean_queue") return m->lean_queue;
+    if (k == "lean_max_contacts") return m->lean_cap;
     if (k == "lds_pad") return m->lds_pad;
     if (k == "lds_bytes_per_env_lean") return (double)sizeof(kp::EnvLdsLean);
     if (k == "job_taper") return m->job_taper;

@@ -78,6 +78,7 @@ struct StepArgs {
     // wave through HBM.  jobq [n_envs * n_parts] entries (env | part << 24, 0xFFFFFFFF = not yet published), jobctr = {head, tail, stalled}
     unsigned* jobq;
     unsigned* jobctr;
+    int lean_cap;              // contacts a lean job accepts before it hands the env over (<= EnvLdsLean::MAXCON; model option lean_max_contacts)
     unsigned* ovfq;            // [n_envs] lean queue kernel: (env | part << 24) of the jobs whose contacts did not fit its layout; jobctr[64] = count, [65] = claimed (kp_step_overflow_kernel)
     float* spd_next;           // [N, 80]: qfrc_applied ++ qfrc_actuator (78 floats) of an env's NEXT substep, computed by the job that ran the substep before it
     int n_parts;
@@ -356,7 +357,7 @@ __device__ __forceinline__ void aba_elim3(SL& s, const Lane8& L, const float* rh
     for (int j = 0; j < 3; j++) {
         const int d = d0 + j;
         gather8(rowok ? s.cdof[6 * d + r] : 0.f, sxa[j]);    // lane r fetches its own component, the 8-lane all-gather lands in XOR order
-        dsc[j] = s.arm[d] + s.extra[d];
+        if constexpr (SL::LEAN) dsc[j] = s.extra[d]; else dsc[j] = s.arm[d] + s.extra[d];      // lean layout: extra holds armature + extra (see step_body)
         rh[j] = rhs[d];
     }
     float Uo[3], Do[3], uo[3];
@@ -694,7 +695,9 @@ __device__ __forceinline__ void spd_torque_rfc(SL& s, const DevTables& T, const 
             kp = T.kp[j]; kd = T.kd[j];
             ep = q + s.qvel[i] * P.h - target;
         }
-        s.extra[i] = kd * P.h;                      // (M + K_d dt): K_d dt is extra joint armature
+        float kdh = kd * P.h;                         // (M + K_d dt): K_d dt is extra joint armature
+        if constexpr (SL::LEAN) { asm volatile("" : "+v"(kdh)); kdh = T.dof_armature[i] + kdh; }      // the rounded product, then the sum aba_elim3 forms on the full layout (no fused multiply-add across the two)
+        s.extra[i] = kdh;
         if (!SL::LEAN || i >= 6) epv[i] = ep;
         s.x[i] = -kp * ep - kd * s.qvel[i];
     }
@@ -1048,7 +1051,7 @@ template <int NT, bool OBJ, class SL>
 // bias / rhs (optional): body wrenches [24][6] added to, and a generalized force [75] subtracted from, the result: with the bias wrenches fb and
 // rhs = qfrc_applied + qfrc_actuator, out = M va - qfrc_smooth - J^T f, the gradient of the primal problem without a detour through qacc_smooth
 __device__ __forceinline__ void wrench_project(SL& s, const Params& P, const float* acc6, const float* va, const float* vb, float* out, bool with_inertia, bool with_forces, int tid,
-                                               const float* forces = nullptr, const float* bias = nullptr, const float* rhs = nullptr) {
+                                               const float* arm, const float* forces = nullptr, const float* bias = nullptr, const float* rhs = nullptr) {
     if (tid < D_NB) {
         const int b = tid;
         S6 W = with_inertia ? inert_mul(s.cinert + 10 * b, lds6(acc6 + 6 * b)) : S6{v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f)};
@@ -1090,7 +1093,7 @@ __device__ __forceinline__ void wrench_project(SL& s, const Params& P, const flo
     subtree_sums<NT>(s, tid);
     for (int d = tid; d < D_NV; d += NT) {
         float v = dot6(lds6(s.cdof + 6 * d), lds6(s.sa + 6 * s.dbody[d]));
-        if (with_inertia) v += s.arm[d] * (va[d] - (vb ? vb[d] : 0.f));
+        if (with_inertia) v += arm[d] * (va[d] - (vb ? vb[d] : 0.f));
         if (with_forces && d >= 6) { float jr = s.lim_jar[d - 6]; if (jr < 0.f) v += s.lim_D[d - 6] * jr; }      // - sign * (-D jar): lim_D is signed
         if (rhs) v -= rhs[d];
         out[d] = v;
@@ -1101,10 +1104,11 @@ __device__ __forceinline__ void wrench_project(SL& s, const Params& P, const flo
 // 0.5 a^T I_b b summed over the bodies + 0.5 arm x y over the dofs: lane partial of  0.5 x^T M y  for the generalized vectors x, y
 // whose body spatial accelerations are acca / accb (xa - xb and ya - yb give the dof vectors; xb / yb may be null)
 template <int NT, class SL>
-__device__ __forceinline__ float quad_form_M(const SL& s, const float* acca, const float* accb, const float* xa, const float* xb, const float* ya, const float* yb, int tid) {
+// arm: the dof armature (the layout's own copy, or the model table where the layout keeps none)
+__device__ __forceinline__ float quad_form_M(const SL& s, const float* arm, const float* acca, const float* accb, const float* xa, const float* xb, const float* ya, const float* yb, int tid) {
     float c = 0.f;
     if (tid < D_NB) c += 0.5f * dot6(lds6(acca + 6 * tid), inert_mul(s.cinert + 10 * tid, lds6(accb + 6 * tid)));
-    for (int i = tid; i < D_NV; i += NT) c += 0.5f * s.arm[i] * (xa[i] - (xb ? xb[i] : 0.f)) * (ya[i] - (yb ? yb[i] : 0.f));
+    for (int i = tid; i < D_NV; i += NT) c += 0.5f * arm[i] * (xa[i] - (xb ? xb[i] : 0.f)) * (ya[i] - (yb ? yb[i] : 0.f));
     return c;
 }
 
@@ -1244,7 +1248,7 @@ __device__ __forceinline__ float line_search(SL& s, const Params& P, float g0, f
 // Results agree with the two-candidate form to the solver's tolerance; the iteration path is MuJoCo's whenever MuJoCo starts from its warm start.
 // On entry: s.qacc = warm start, jv3 / lim_jv = aref, s.applied ++ s.ctrl = qfrc_applied + qfrc_actuator, s.fb = bias wrenches.
 template <int NT, class SL>
-__device__ __forceinline__ int solve_constraints_direct(SL& s, const Params& P, const Lane8& L8, int depth, int tid, int& nfact, int& ncap) {
+__device__ __forceinline__ int solve_constraints_direct(SL& s, const Params& P, const Lane8& L8, int depth, int tid, int& nfact, int& ncap, const float* arm) {
     if (s.ncon == 0 && s.nlim == 0) {
         aba_solve<NT, false>(s, P, L8, s.applied, s.qacc, false, tid, D_NLEV, s.fb);
         return 0;
@@ -1264,8 +1268,9 @@ __device__ __forceinline__ int solve_constraints_direct(SL& s, const Params& P, 
         changed = 0.f; deep = 0.f;
         for (int i = tid; i < D_NV; i += NT) {
             const float ex = (i >= 6 && s.lim_jar[i - 6] < 0.f) ? fabsf(s.lim_D[i - 6]) : 0.f;
-            if (ex != s.extra[i]) changed = 1.f;
-            s.extra[i] = ex;
+            const float st = SL::LEAN ? arm[i] + ex : ex;          // lean layout: extra holds armature + extra, the sum aba_elim3 forms on the full layout
+            if (st != s.extra[i]) changed = 1.f;
+            s.extra[i] = st;
             if (ex != 0.f) deep = fmaxf(deep, (float)s.bdep[s.dbody[i]]);     // active joint limit: its body's level is dirty
         }
         changed += active_set_changed<NT>(s, P, tid, deep);
@@ -1274,7 +1279,7 @@ __device__ __forceinline__ int solve_constraints_direct(SL& s, const Params& P, 
     };
     active_set();
     for (; it < P.max_iter; it++) {
-        wrench_project<NT, false>(s, P, sacc, s.qacc, nullptr, grad, true, true, tid, nullptr, s.fb, s.applied);
+        wrench_project<NT, false>(s, P, sacc, s.qacc, nullptr, grad, true, true, tid, arm, nullptr, s.fb, s.applied);
         float g2 = 0.f;
         for (int i = tid; i < D_NV; i += NT) { const float g = grad[i]; g2 += g * g; s.x[i] = -g; }
         g2 = block_sum<NT>(s, g2, tid);
@@ -1290,8 +1295,8 @@ __device__ __forceinline__ int solve_constraints_direct(SL& s, const Params& P, 
         else aba_resolve(s, L8, s.x, nullptr, s.search);
         eval_rows<NT, false>(s, s.search, s.jv3, s.lim_jv, false, tid);           // aref (in jv3) is folded into jar3 by now
         // phi(alpha) = cost(qacc + alpha search): smooth part g0 = search^T (M qacc - qfrc_smooth), h0 = search^T M search, in body form
-        float g0 = 2.0f * quad_form_M<NT>(s, s.sv, sacc, s.search, nullptr, s.qacc, nullptr, tid);
-        float h0 = 2.0f * quad_form_M<NT>(s, s.sv, s.sv, s.search, nullptr, s.search, nullptr, tid);
+        float g0 = 2.0f * quad_form_M<NT>(s, arm, s.sv, sacc, s.search, nullptr, s.qacc, nullptr, tid);
+        float h0 = 2.0f * quad_form_M<NT>(s, arm, s.sv, s.sv, s.search, nullptr, s.search, nullptr, tid);
         for (int i = tid; i < D_NB * 6; i += NT) g0 += s.sv[i] * s.fb[i];
         for (int i = tid; i < D_NV; i += NT) g0 -= s.search[i] * s.applied[i];
         g0 = block_sum<NT>(s, g0, tid); h0 = block_sum<NT>(s, h0, tid);
@@ -1807,7 +1812,7 @@ __device__ __forceinline__ void schur_columns(EnvLdsObj& s, const Params& P, uns
 // (q_humanoid, a_object...).  The Newton system is solved exactly by block elimination: the articulated-body pass factorises
 // the humanoid block, 6 n_obj + 1 bias-only passes form the Schur complement on the objects when a hull touches one.
 template <int NT>
-__device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params& P, const Lane8& L8, int depth, int tid, int& nfact, int& ncap) {
+__device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params& P, const Lane8& L8, int depth, int tid, int& nfact, int& ncap, const float* arm) {
     constexpr int ST = 6 * D_MAXOBJ + 1;
     const int nobj = s.nobj, no6 = 6 * nobj;
     // smooth acceleration of the objects: I_eff a = -bias wrench
@@ -1865,7 +1870,7 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
     for (; it < P.max_iter; it++) {
         // gradient: humanoid dofs (mres - J^T f) and object wrenches
         con_prepare<NT>(s, P, tid);                  // lane = contact: M_c at this iterate (object rows of the Hessian AND the hulls' contact inertia in aba_solve) and the contact force
-        wrench_project<NT, true>(s, P, sacc, s.qacc, nullptr, grad, true, true, tid, s.jv3, s.fb, s.applied);
+        wrench_project<NT, true>(s, P, sacc, s.qacc, nullptr, grad, true, true, tid, arm, s.jv3, s.fb, s.applied);
         if (nobj > 0) obj_gradient(s, tid);
         float g2 = 0.f;
         for (int i = tid; i < D_NV; i += NT) { const float g = grad[i]; g2 += g * g; s.x[i] = -g; }
@@ -1924,8 +1929,8 @@ __device__ __forceinline__ int solve_constraints_obj(EnvLdsObj& s, const Params&
         eval_rows<NT, true>(s, s.search, s.jv3, s.lim_jv, false, tid);
         if (tid < nobj) sts6(s.oMv + 6 * tid, inert_mul(s.oIe + 10 * tid, lds6(s.osrch + 6 * tid)));
         KP_SYNC();
-        float g0 = 2.0f * quad_form_M<NT>(s, s.sv, sacc, s.search, nullptr, s.qacc, nullptr, tid);      // search^T (M qacc - qfrc_smooth) for the hulls ...
-        float h0 = 2.0f * quad_form_M<NT>(s, s.sv, s.sv, s.search, nullptr, s.search, nullptr, tid);
+        float g0 = 2.0f * quad_form_M<NT>(s, arm, s.sv, sacc, s.search, nullptr, s.qacc, nullptr, tid);      // search^T (M qacc - qfrc_smooth) for the hulls ...
+        float h0 = 2.0f * quad_form_M<NT>(s, arm, s.sv, s.sv, s.search, nullptr, s.search, nullptr, tid);
         for (int i = tid; i < D_NB * 6; i += NT) g0 += s.sv[i] * s.fb[i];
         for (int i = tid; i < D_NV; i += NT) g0 -= s.search[i] * s.applied[i];
         if (tid < no6) { g0 += s.osrch[tid] * s.omres[tid]; h0 += s.osrch[tid] * s.oMv[tid]; }                // ... and search^T I_eff (oa - oas) for the objects
@@ -2004,7 +2009,8 @@ __device__ __forceinline__ int step_body(const StepArgs& A, const int env_in, co
     for (int i = tid; i < D_NQ; i += NT) s.qpos[i] = gld<Q>((torque_in ? A.qpos : A.qpos_d) + (size_t)env * D_NQ + (unsigned)(i));
     for (int i = tid; i < D_NV; i += NT) {
         s.qvel[i] = gld<Q>((torque_in ? A.qvel : A.qvel_d) + (size_t)env * D_NV + (unsigned)(i));
-        s.arm[i] = T.dof_armature[i]; s.dbody[i] = T.dof_body[i]; s.extra[i] = 0.f; s.qacc[i] = gld<Q>(A.warm + (size_t)env * D_NV + (unsigned)(i));
+        if constexpr (LEAN) s.extra[i] = T.dof_armature[i]; else { s.arm[i] = T.dof_armature[i]; s.extra[i] = 0.f; }
+        s.dbody[i] = T.dof_body[i]; s.qacc[i] = gld<Q>(A.warm + (size_t)env * D_NV + (unsigned)(i));
     }
     if (tid < D_NB) { s.bpar[tid] = (unsigned char)(T.body_parent[tid] < 0 ? 0 : T.body_parent[tid]); s.bsub[tid] = T.body_subtree[tid]; s.bdep[tid] = T.body_depth[tid]; }
     if (tid < 6) s.applied[tid] = 0.f;
@@ -2050,6 +2056,8 @@ __device__ __forceinline__ int step_body(const StepArgs& A, const int env_in, co
         }
         have_prev = true;
     }
+    const float* armv;            // dof armature as the solve reads it: the layout's copy, or the model table (lean layout: folded into extra for the eliminations)
+    if constexpr (LEAN) armv = T.dof_armature; else armv = s.arm;
     auto store_readouts = [&](int lane, int e) {
         for (int i = lane; i < 72; i += NT) A.xpos[(size_t)e * 72 + (unsigned)(i)] = s.xpos[i];
         if (lane < D_NB) {                   // xipos = xpos + R ipos of the same forward pass
@@ -2121,7 +2129,7 @@ __device__ __forceinline__ int step_body(const StepArgs& A, const int env_in, co
         KP_T(1)
         collide<NT, OBJ>(s, T, P, tid);
         if constexpr (LEAN) {
-            if (s.ncon > SL::MAXCON) return 1;      // wave-uniform; nothing of this job has been stored yet
+            if (s.ncon > min(SL::MAXCON, A.lean_cap)) return 1;      // wave-uniform; nothing of this job has been stored yet (lean_cap: model option, tests lower it to exercise the hand-over)
             // stale kinematics: the control step's read-outs are those of its last substep's forward pass; the solve below re-uses the words of xquat
             if (P.stale && sub == n_substeps - 1 && part == A.n_parts - 1) store_readouts(tid, env);
         }
@@ -2139,7 +2147,7 @@ __device__ __forceinline__ int step_body(const StepArgs& A, const int env_in, co
         make_constraint<NT, OBJ>(s, T, P, tid);                 // needs sv = cvel: before any aba_solve
         KP_T(3)
         if (!P.stale && P.actuation) { Lane8 La; La.init(kp_launder(tid), T.sched8); spd_torque_rfc<NT, OBJ>(s, T, P, La, tid, tq_row, act_row); }
-        for (int i = tid; i < D_NV; i += NT) s.extra[i] = 0.f;
+        for (int i = tid; i < D_NV; i += NT) s.extra[i] = LEAN ? T.dof_armature[i] : 0.f;
         KP_SYNC();
         Lane8 L8; L8.init(kp_launder(tid), T.sched8);          // lives through the Newton solve
         // Start of the Newton solve.  MuJoCo starts from the previous substep's solution a_{k-1} (qacc_warmstart); with warm_extrap = beta != 0 the start is
@@ -2164,10 +2172,10 @@ __device__ __forceinline__ int step_body(const StepArgs& A, const int env_in, co
         }
         if constexpr (OBJ) {
             KP_T(4)                                            // no smooth solve: the Newton solve starts from the warm start (solve_constraints_direct)
-            niter_total += solve_constraints_obj<NT>(s, P, L8, depth, tid, nfact_total, ncap_total);
+            niter_total += solve_constraints_obj<NT>(s, P, L8, depth, tid, nfact_total, ncap_total, s.arm);
         } else {
             KP_T(4)
-            niter_total += solve_constraints_direct<NT>(s, P, L8, depth, tid, nfact_total, ncap_total);
+            niter_total += solve_constraints_direct<NT>(s, P, L8, depth, tid, nfact_total, ncap_total, armv);
             if constexpr (LEAN) {
                 // the solve's body accelerations lived in the words of qpos | qvel: both come back from the registers that hold this substep's forward-pass state,
                 // the root quaternion normalised as forward_kin_bias left it
@@ -2292,7 +2300,7 @@ __global__ __launch_bounds__(64) void kp_mass_kernel(StepArgs A, float* __restri
         for (int i = tid; i < D_NV; i += NT) s.x[i] = i == j ? 1.f : 0.f;
         KP_SYNC();
         spatial_accumulate<NT>(s, s.x, depth, tid);
-        wrench_project<NT, false>(s, P, s.sv, s.x, nullptr, s.qacc_s, true, false, tid);
+        wrench_project<NT, false>(s, P, s.sv, s.x, nullptr, s.qacc_s, true, false, tid, s.arm);
         for (int d = tid; d < D_NV; d += NT) Mout[((size_t)env * D_NV + d) * D_NV + j] = s.qacc_s[d];
         KP_SYNC();
     }

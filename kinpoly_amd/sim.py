@@ -228,6 +228,17 @@ class KpSim:
             self._status = torch.as_tensor(holder, device=self.device)
         return self._status
 
+    def queue_counters(self) -> dict:
+        """Counters of the last job-queue launch (host read): jobs claimed / published, jobs a wave kept instead of queueing, and the jobs the lean
+        layout handed to kp_step_overflow_kernel (more contacts than EnvLdsLean::MAXCON)."""
+        if getattr(self, "_qctr", None) is None:
+            ptr = self.L.kp_sim_status_device(self.h)
+            iface = {"shape": (128,), "typestr": "<i4", "data": (int(ptr), False), "version": 3, "strides": None}
+            holder = type("_KpQueueCounters", (), {"__cuda_array_interface__": iface})()
+            self._qctr = torch.as_tensor(holder, device=self.device)
+        c = self._qctr.cpu().numpy()
+        return {"claimed": int(c[0]), "published": int(c[1]), "stalled": int(c[2]), "kept_by_their_wave": int(c[16]), "lean_overflow_jobs": int(c[64])}
+
     def record_contacts(self):
         """Arm the contact read-out (kp_sim_contacts): later step_ctrl launches keep the contact set of their last collision pass."""
         _check(self.L.kp_sim_contacts(self.h, None), "kp_sim_contacts")

@@ -70,7 +70,7 @@ def test_lean_queue_layout_is_the_full_layout_bit_for_bit(kp):
         for a_, b_ in zip(lean, full):
             assert (a_ == b_).all(), extra
         assert (dl == df).all()
-        assert (dl[:, 3] & 255).max() <= 32 and (dl[:, 2] & 255).max() == 0
+        assert (dl[:, 3] & 255).max() <= 24 and (dl[:, 2] & 255).max() == 0
         if not extra:
             one, d1, _ = _run(kp, n, qpos, qvel, act, 3, substeps_per_job=0)
             for a_, b_ in zip(lean[:5], one[:5]):
@@ -78,16 +78,17 @@ def test_lean_queue_layout_is_the_full_layout_bit_for_bit(kp):
 
 
 def test_contact_overflow_goes_to_the_full_layout(kp):
-    """Every 8th of 4096 envs lies on the floor: more than 32 contacts in some substep, which the lean layout cannot hold.  Those jobs (and the env's later ones)
-    must come out of kp_step_overflow_kernel exactly as the full-layout queue computes them, the other envs untouched by the detour, the queue drained and
-    the status word clean; the envs that overflowed are the ones whose contact maximum exceeds 32."""
+    """A lean job that finds more contacts than its layout holds (24) hands the env to kp_step_overflow_kernel.  Floor scenes do not get there on their own (a
+    humanoid lying flat has 12: mjc_PlaneConvex keeps at most 3 per hull), so the limit is lowered to 8 (model option lean_max_contacts): every 8th of 4096 envs
+    lies on the floor and crosses it in some substep.  Those jobs (and the env's later ones) must come out of the overflow kernel exactly as the full-layout queue
+    computes them, the other envs untouched by the detour, the queue drained and the status word clean."""
     n = 4096
     qpos, qvel = _states(n, 71, lying_every=8)
     act = np.random.default_rng(72).normal(size=(n, 75)) * 0.1
-    lean, dl, sim = _run(kp, n, qpos, qvel, act, 4, lean_queue=1)
+    lean, dl, sim = _run(kp, n, qpos, qvel, act, 4, lean_queue=1, lean_max_contacts=8)
     full, df, _ = _run(kp, n, qpos, qvel, act, 4, lean_queue=0)
     maxcon = df[:, 3] & 255
-    assert (maxcon > 32).sum() >= 16, f"the scene must overflow the lean layout somewhere (max contacts {maxcon.max()}, envs above 32: {(maxcon > 32).sum()})"
+    assert (maxcon > 8).sum() >= 64 and (maxcon <= 8).sum() >= 1024, f"some envs must cross the lowered limit and most must not (max contacts {maxcon.max()}, envs above 8: {(maxcon > 8).sum()})"
     assert (dl == df).all()
     for a_, b_ in zip(lean, full):
         assert (a_ == b_).all()

@@ -10,4 +10,4 @@ for r in 1 2 3; do for v in 0 1; do
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('tracked KP_LEAN_QUEUE=$v value %.0f ms_per_step %.3f [%.3f %.3f] launch_ms %.3f contacts %.2f newton %.2f bad %d' % (d['value'], d['ms_per_step'], d['ms_per_step_min'], d['ms_per_step_max'], d['roofline']['launch_ms'], d['contacts_mean'], d['newton_iters_per_substep'], d['bad_envs']))"
-done; done 2>&1 | tee $O/lean_queue_ab_stageC.log
+done; done 2>&1 | tee $O/lean_queue_ab_stageD.log
