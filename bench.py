@@ -53,6 +53,9 @@ MFMA_FP32_PEAK_TFLOPS = 157.3       # dense fp32 matrix peak (spec sheet): the p
 PROFILE_DIR = os.path.join(ROOT, "profiles", "r06")
 
 
+POLICY_CKPT = CC_CKPT = None       # --policy-ckpt / --cc-ckpt: the networks of the `trained` workload (reference checkpoint layout, kinpoly_amd/checkpoint.py)
+
+
 def build_engine(device_index, seed, threads, workload="tracked", n_envs=None):
     from kinpoly_amd.env import BatchedHumanoidAREnv, standing_context
     from kinpoly_amd.nets import KinPolicy, enable_tuned_gemms
@@ -66,13 +69,21 @@ def build_engine(device_index, seed, threads, workload="tracked", n_envs=None):
             **({"lpt_order": int(os.environ["KP_LPT_ORDER"])} if "KP_LPT_ORDER" in os.environ else {}),
             **({"queue_heavy": int(os.environ["KP_QUEUE_HEAVY"])} if "KP_QUEUE_HEAVY" in os.environ else {}),
             **({"queue_prio": int(os.environ["KP_QUEUE_PRIO"])} if "KP_QUEUE_PRIO" in os.environ else {}),
+            **({"queue_late": int(os.environ["KP_QUEUE_LATE"])} if "KP_QUEUE_LATE" in os.environ else {}),
             **({"queue_fence": int(os.environ["KP_QUEUE_FENCE"])} if "KP_QUEUE_FENCE" in os.environ else {}),
             **({"queue_slots": int(os.environ["KP_QUEUE_SLOTS"])} if "KP_QUEUE_SLOTS" in os.environ else {}),
             **({"lean_queue": int(os.environ["KP_LEAN_QUEUE"])} if "KP_LEAN_QUEUE" in os.environ else {}),
             **({"lds_pad": int(os.environ["KP_LDS_PAD"])} if "KP_LDS_PAD" in os.environ else {}),
             **({"warm_extrap": float(os.environ["KP_WARM_EXTRAP"])} if "KP_WARM_EXTRAP" in os.environ else {})}
-    env = BatchedHumanoidAREnv(n_envs, device_index, mode="test" if wild else "train", wild=wild, seed=seed, model_options=opts)
-    policy = KinPolicy().to(env.device).float()
+    trained = None
+    if workload == "trained":
+        from kinpoly_amd.checkpoint import load_bench_policies
+        if not POLICY_CKPT:
+            raise SystemExit("--workload trained needs --policy-ckpt (and --cc-ckpt for the UHC's ZFilter)")
+        trained = load_bench_policies(POLICY_CKPT, CC_CKPT, torch.device("cuda", device_index))
+    env = BatchedHumanoidAREnv(n_envs, device_index, mode="test" if wild else "train", wild=wild, seed=seed, model_options=opts,
+                               **({"cc_policy": trained["cc_policy"], "cc_running_state": trained["cc_running_state"]} if trained else {}))
+    policy = trained["kin_policy"] if trained else KinPolicy().to(env.device).float()
     g = torch.Generator().manual_seed(seed)
     headings = (torch.rand(n_envs, generator=g) * 2 - 1) * np.pi
     if workload == "objects":
@@ -322,11 +333,13 @@ WORKLOAD_DESC = {
                  "termination, fail-safe on), batched inference, standing clip",
     "objects": "BASELINE configs[3] on one GPU: same env-step with the scene's free objects simulated (sit: chair, push: box on table, avoid: Can, step: step box; "
                "SURVEY 8(d) config 4 synthetic takes, four action classes evenly over the envs), kinematic policy's output replaced by the clip's next pose + noise",
+    "trained": "BASELINE configs[2] rollout with NOTHING overridden: the kinematic policy and the UHC of --policy-ckpt / --cc-ckpt (trained by this engine: tools/learning_demo.sh), "
+               "the policy's own sampled output drives env.step, episodes end when the policy fails or the clip ends",
     "train_iter": "one AgentAR.optimize_policy per step: sample 4096 x 24 env-steps of the configs[2] rollout (random-init TrajARNet; every episode on a clip drawn from a "
                   "StateARDataset of synthetic takes and run through init_context, as scripts/train_ar_policy.py does), GAE, all-gather of "
                   "advantages / returns, 10 PPO epochs + 20 supervised step updates, gradients all-reduced (kin_poly.yml:36-71)",
 }
-ROLLOUT_WORKLOADS = ("tracked", "random_init", "wild_eval", "objects")
+ROLLOUT_WORKLOADS = ("tracked", "random_init", "wild_eval", "objects")       # the default line's workloads (`trained` runs when its checkpoint is given)
 TRAIN_KEYS = ("T_sample", "T_update", "samples_per_s_per_gpu", "samples_per_iter_per_gpu", "iters", "avg_reward", "fail_rate", "episodes_per_iter",
               "clips_drawn_per_iter", "clips_through_init_context_per_iter", "pool_exhausted", "update_tflops", "update_mfma_frac", "update_flops_per_iter", "episode_source")
 
@@ -340,7 +353,7 @@ def run_workload(workload, device_index, seed, threads, steps, warmup, barrier=N
         env._a_track = a_track if workload == "tracked" else None
         sampler.start()
     wild, follow = workload == "wild_eval", workload == "objects"
-    if workload in ("tracked", "objects"):
+    if workload in ("tracked", "objects", "trained"):
         stagger_episodes(env, sampler, seed, follow)
     rollout_steps(sampler, warmup, a_track, wild, follow)
     # `repeats` timed blocks of exactly `steps` env-steps each, every block bracketed by barrier + synchronize on both sides (the contract's timed region,
@@ -579,8 +592,12 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads and the GEMM probe (profiling runs)")
     ap.add_argument("--workload", choices=tuple(WORKLOAD_DESC), default="tracked")
     ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps env-steps inside this command; value / ms_per_step = the median block (rollout workloads)")
+    ap.add_argument("--policy-ckpt", default=None, help="kinematic policy checkpoint (reference layout) of --workload trained")
+    ap.add_argument("--cc-ckpt", default=None, help="UHC checkpoint (reference layout: weights + ZFilter) of --workload trained")
     ap.add_argument("--no-parity-live", action="store_true", help="skip the live one-substep parity sample against the fp64 oracle (profiling runs)")
     args = ap.parse_args()
+    global POLICY_CKPT, CC_CKPT
+    POLICY_CKPT, CC_CKPT = args.policy_ckpt, args.cc_ckpt
     train = args.workload == "train_iter"
     if args.steps is None:
         args.steps = 3 if train else 60
@@ -657,7 +674,9 @@ def main():
         per_cu = min(12 if env.model.get_option("lean_queue") and args.workload != "objects" else 8, 128 // -(-int(env.model.get_option("lds_bytes_per_env_objects" if args.workload == "objects" else ("lds_bytes_per_env_lean" if env.model.get_option("lean_queue") else "lds_bytes_per_env"))) // 1280))
         slots = int(os.environ.get("KP_QUEUE_SLOTS", 0)) or torch.cuda.get_device_properties(local_rank).multi_processor_count * per_cu
         qctr = {**env.sim.queue_counters(), "envs_per_cu": per_cu, "lean_layout": bool(env.model.get_option("lean_queue")), "lds_bytes_per_env": int(env.model.get_option("lds_bytes_per_env_lean" if env.model.get_option("lean_queue") else "lds_bytes_per_env")),
-                "lean_max_contacts": int(env.model.get_option("lean_max_contacts"))}
+                "lean_max_contacts": int(env.model.get_option("lean_max_contacts")),
+                "schedule": ("5+5+5 substeps, issue priority by remaining substeps (queue_prio 3), late envs kept by their wave (queue_late)" if (env.model.get_option("lean_queue") and env.model.get_option("job_auto") and args.workload != "objects" and "KP_JOB_SCHEDULE" not in os.environ)
+                             else f"substeps_per_job {spj}, job_taper {int(env.model.get_option('job_taper'))}, queue_prio {int(env.model.get_option('queue_prio'))}, queue_late {int(env.model.get_option('queue_late'))}" + (f", KP_JOB_SCHEDULE={os.environ['KP_JOB_SCHEDULE']}" if "KP_JOB_SCHEDULE" in os.environ else ""))}
         if rank == 0 and world == 1 and not args.no_parity_live and args.workload in ("tracked", "random_init", "objects"):
             try:
                 live = parity_live(env, sampler, args.workload, getattr(env, "_a_track", None))

@@ -238,7 +238,7 @@ class AgentAR:
 
     def load_checkpoint(self, path):
         cp = ck.load_checkpoint(path)
-        self.policy_net.load_state_dict(ck.split_policy_dict(cp["policy_dict"]), strict=False)
+        ck.load_state_strict(self.policy_net, ck.split_policy_dict(cp["policy_dict"]), what=str(path))      # missing / unknown keys raise (allow-list: checkpoint.py)
         self.value_net.load_state_dict(cp["value_dict"])
         self.upd.load_from_rollout()
         if "cc_dict" in cp:

@@ -105,3 +105,47 @@ def save_checkpoint(path, traj_ar_net: torch.nn.Module, value_net: torch.nn.Modu
     with _RefModulePath(), open(path, "wb") as f:
         pickle.dump(cp, f)
     return cp
+
+
+# Keys a reference checkpoint may legitimately lack when it is loaded into this repository's modules (everything else missing or unexpected is an error: a
+# silently half-loaded policy trains and evaluates without complaint).  PolicyAR.state_dict() = traj_ar_net.* + action_log_std (+ old_arnet.*, which
+# split_policy_dict drops): TrajARNet here holds exactly those parameters (tests/golden/traj_ar_net.npz: the reference's own key list), so nothing is allowed to be absent.
+ALLOWED_MISSING_POLICY_KEYS = frozenset()
+
+
+def load_state_strict(module: torch.nn.Module, state: dict, allow_missing=ALLOWED_MISSING_POLICY_KEYS, what="checkpoint"):
+    """load_state_dict that names what does not fit: keys missing from `state` (beyond `allow_missing`) or not known to `module` raise."""
+    state = {k: (v if torch.is_tensor(v) else torch.as_tensor(v)) for k, v in state.items()}
+    own = set(module.state_dict().keys())
+    missing = sorted(own - set(state) - set(allow_missing))
+    unexpected = sorted(set(state) - own)
+    if missing or unexpected:
+        raise KeyError(f"{what}: does not match {type(module).__name__} -- missing {missing[:8]}{' ...' if len(missing) > 8 else ''}, unexpected {unexpected[:8]}{' ...' if len(unexpected) > 8 else ''}")
+    module.load_state_dict(state, strict=False)          # strict=False only for the allow-listed keys, checked above
+    return module
+
+
+def load_bench_policies(policy_ckpt: str, cc_ckpt: str | None = None, device="cuda"):
+    """The networks of a finished training run, as the reference's evaluation builds them (eval_ar_policy.py: policy checkpoint `iter_XXXX.p` of the
+    kinematic policy + the UHC checkpoint the env is built around, humanoid_ar_v1.py:60-81): returns {"kin_policy": TrajARNet, "cc_policy": PolicyMCP,
+    "cc_running_state": RunningState | None}.  policy_ckpt: {'policy_dict', 'value_dict', 'running_state' [, 'cc_dict']} (AgentAR.save_checkpoint);
+    cc_ckpt: the UHC's {'policy_dict', 'value_dict', 'running_state'} (scripts/train_uhc.py --save) -- its ZFilter always, its weights unless the policy
+    checkpoint carries the jointly trained controller (cc_dict)."""
+    from .context import TrajARNet
+    from .env import RunningState
+    from .nets import PolicyMCP
+    cp = load_checkpoint(policy_ckpt)
+    net = load_state_strict(TrajARNet(), split_policy_dict(cp["policy_dict"]), what=policy_ckpt).to(device).float()
+    mcp, rs = PolicyMCP(), None
+    cc_weights = cp.get("cc_dict")
+    if cc_ckpt:
+        ccp = load_checkpoint(cc_ckpt)
+        arr = running_state_arrays(ccp.get("running_state"))
+        if arr is not None:
+            rs = RunningState(arr[0], arr[1], arr[2], device)
+        if cc_weights is None:
+            cc_weights = ccp["policy_dict"]
+    if cc_weights is None:
+        raise KeyError(f"{policy_ckpt} holds no controller weights (cc_dict) and no UHC checkpoint was given")
+    load_state_strict(mcp, cc_weights, allow_missing=(), what=cc_ckpt or policy_ckpt)
+    return {"kin_policy": net.eval(), "cc_policy": mcp.to(device).float().eval(), "cc_running_state": rs}

@@ -27,7 +27,7 @@ int fail(const std::string& m) { g_err = m; return -1; }
 
 struct kp_model {
     kp::HostModel h;
-    int contact = 1, limits = 1, stale = 1, solver_iter = 100, threads = 64, dynamic_objects = 1, lpt_order = -1, substeps_per_job = 4, queue_slots = 0, job_taper = 1, queue_fence = 1, queue_heavy = 160, queue_prio = 0, lean_queue = 1, lds_pad = 0, lean_cap = kp::EnvLdsLean::MAXCON;
+    int contact = 1, limits = 1, stale = 1, solver_iter = 100, threads = 64, dynamic_objects = 1, lpt_order = -1, substeps_per_job = 4, queue_slots = 0, job_taper = 1, queue_fence = 1, queue_heavy = 160, queue_prio = -1, queue_late = -1, job_auto = 1, lean_queue = 1, lds_pad = 0, lean_cap = kp::EnvLdsLean::MAXCON;
     float warm_extrap = -1.f;      // < 0: automatic (0.75 when the scene's free objects are simulated, 0 otherwise); see kp_step_kernel.hpp
     int planemesh_max = 3; double planemesh_tol = 0.3;   // mjc_PlaneConvex's maxplanemesh / tolplanemesh (the blob's `planemesh`)
     int actuation = 1;            // 0: no stable-PD torque, no residual force (ctrl = qfrc_applied = 0): torque-free flight for the energy test
@@ -264,7 +264,11 @@ int launch_step(kp_sim* s, const float* action, int nsub, const uint8_t* mask, b
                             else hipLaunchKernelGGL((kp::kp_forward_kernel<NT_, false>), dim3(s->n), dim3(NT_), lds, s->stream, A); } while (0)
     // more envs than resident wave slots: schedule the control step as jobs of substeps_per_job substeps pulled from a FIFO by one
     // resident wave per slot (kp_step_queue_kernel) instead of one workgroup per env, which ends on a long tail
-    const int spj = s->model->substeps_per_job;
+    // Schedule defaults.  Full layout (objects; floor with lean_queue = 0): 6 + 5 + 4 substeps, FIFO, no issue priorities (rounds 2 - 5).  Lean layout: 3072 slots hold
+    // three quarters of BASELINE's 4096 envs, so a quarter of the envs start one job late and the launch ends on them (sum of env cycles / slots 1.83 ms, launch
+    // 2.44 ms).  Three measures take the launch to 2.19 ms (profiles/r06/lean_schedule_knobs*.log): equal jobs 5 + 5 + 5 (the late envs start earlier), a late
+    // env is never queued again (queue_late), and every wave's issue priority follows its env's distance from the end of the control step (queue_prio = 3).
+    // Options the caller sets (substeps_per_job / job_taper, queue_prio, queue_late) are obeyed.
     // resident waves: LDS is allocated in 1 280-byte granules, 128 per CU (tools/micro/lds_granule_probe.hip); 256 VGPRs allow 8 waves per CU
     // floor scenes: the job queue runs on the lean layout (EnvLdsLean) with a register budget for three waves per SIMD; model option lean_queue = 0 keeps the
     // full layout (two waves per SIMD; A / B measurements).  lds_pad: allocate at least that many bytes per env (experiments: fewer envs per CU with the same binary)
@@ -273,9 +277,11 @@ int launch_step(kp_sim* s, const float* action, int nsub, const uint8_t* mask, b
     if (s->model->lds_pad > 0) lds_q = std::max(lds_q, (size_t)s->model->lds_pad);
     const int per_cu = std::min(lean ? 12 : 8, 128 / (int)((lds_q + 1279) / 1280));
     const int slots = s->model->queue_slots > 0 ? s->model->queue_slots : s->wave_slots / 8 * per_cu;
+    const bool lean_auto = lean && s->model->job_auto;
+    const int spj = lean_auto ? 5 : s->model->substeps_per_job, taper = lean_auto ? 0 : s->model->job_taper;
     int sizes[16], parts = 0;
     if (spj > 0 && nsub > 0) {
-        parts = job_schedule(nsub, spj, s->model->job_taper, sizes);
+        parts = job_schedule(nsub, spj, taper, sizes);
         if (const char* e = std::getenv("KP_JOB_SCHEDULE")) {      // experiments: explicit comma-separated job sizes
             int tmp[16], np = 0, sum = 0;
             for (const char* c = e; *c && np < 16;) { tmp[np] = std::atoi(c); sum += tmp[np++]; while (*c && *c != ',') c++; if (*c) c++; }
@@ -283,7 +289,7 @@ int launch_step(kp_sim* s, const float* action, int nsub, const uint8_t* mask, b
         }
     }
     const bool queue = nsub > 0 && parts > 1 && s->model->threads == 64 && s->n > slots && s->n <= 0xFFFFFF && !s->prof;   // env ids take 24 bits of a queue entry
-    A.jobq = s->jobq; A.jobctr = s->jobctr; A.ovfq = s->ovfq; A.lean_cap = s->model->lean_cap; A.warm3 = s->warm3; A.spd_next = s->spd_next; A.n_parts = queue ? parts : 1; A.queue_fence = s->model->queue_fence; A.queue_heavy = s->model->queue_heavy; A.queue_prio = s->model->queue_prio; A.order_valid = A.order != nullptr;
+    A.jobq = s->jobq; A.jobctr = s->jobctr; A.ovfq = s->ovfq; A.lean_cap = s->model->lean_cap; A.warm3 = s->warm3; A.spd_next = s->spd_next; A.n_parts = queue ? parts : 1; A.queue_fence = s->model->queue_fence; A.queue_heavy = s->model->queue_heavy; A.queue_prio = s->model->queue_prio >= 0 ? s->model->queue_prio : (lean ? 3 : 0); A.queue_late = s->model->queue_late >= 0 ? s->model->queue_late : (lean ? 1 : 0); A.order_valid = A.order != nullptr;
     A.part_sub_lo = A.part_sub_hi = 0;
     for (int k = 0; queue && k < parts; k++) (k < 8 ? A.part_sub_lo : A.part_sub_hi) |= (unsigned long long)(sizes[k] & 255) << (8 * (k & 7));
     if (queue) {
@@ -358,16 +364,17 @@ int kp_model_set_option(kp_model* m, const char* name, double v) {
     else if (k == "planemesh_max") { if (v < 1 || v > 8) return fail("planemesh_max must be 1 .. 8"); m->planemesh_max = (int)v; }
     else if (k == "planemesh_tol") { if (v < 0) return fail("planemesh_tol must be >= 0"); m->planemesh_tol = v; }
     else if (k == "lpt_order") m->lpt_order = v < 0 ? -1 : (v != 0);
-    else if (k == "job_taper") m->job_taper = std::max(0, std::min(8, (int)v));
+    else if (k == "job_taper") { m->job_taper = std::max(0, std::min(8, (int)v)); m->job_auto = 0; }
     else if (k == "queue_fence") m->queue_fence = v != 0;
     else if (k == "queue_heavy") m->queue_heavy = std::max(0, (int)v);
-    else if (k == "queue_prio") m->queue_prio = v != 0;
+    else if (k == "queue_late") m->queue_late = v < 0 ? -1 : (v != 0);
+    else if (k == "queue_prio") m->queue_prio = std::max(-1, std::min(3, (int)v));
     else if (k == "warm_extrap") m->warm_extrap = (float)v;
     else if (k == "lean_queue") m->lean_queue = v != 0;
     else if (k == "lean_max_contacts") { if (v < 0 || v > kp::EnvLdsLean::MAXCON) return fail("lean_max_contacts must be 0 .. " + std::to_string(kp::EnvLdsLean::MAXCON)); m->lean_cap = (int)v; }
     else if (k == "lds_pad") { if (v < 0 || v > 65536) return fail("lds_pad must be 0 .. 65536 bytes"); m->lds_pad = (int)v; }
     else if (k == "queue_slots") { if (v < 0) return fail("queue_slots must be >= 0 (0 = resident wave slots of the device)"); m->queue_slots = (int)v; }
-    else if (k == "substeps_per_job") { if (v < 0 || v > 255) return fail("substeps_per_job must be 0 (whole control step per workgroup) .. 255"); m->substeps_per_job = (int)v; }
+    else if (k == "substeps_per_job") { if (v < 0 || v > 255) return fail("substeps_per_job must be 0 (whole control step per workgroup) .. 255"); m->substeps_per_job = (int)v; m->job_auto = 0; }
     else if (k == "threads_per_env") { if (v != 64 && v != 128 && v != 256) return fail("threads_per_env must be 64, 128 or 256"); m->threads = (int)v; }
     else return fail("kp_model_set_option: unknown option " + k);
     return 0;
@@ -395,9 +402,11 @@ double kp_model_get_option(const kp_model* m, const char* name) {
     if (k == "lds_pad") return m->lds_pad;
     if (k == "lds_bytes_per_env_lean") return (double)sizeof(kp::EnvLdsLean);
     if (k == "job_taper") return m->job_taper;
+    if (k == "job_auto") return m->job_auto;       // 1: the job sizes are the layout's defaults (lean queue: 5 + 5 + 5; otherwise substeps_per_job / job_taper = 6 + 5 + 4)
     if (k == "queue_fence") return m->queue_fence;
     if (k == "queue_heavy") return m->queue_heavy;
     if (k == "queue_prio") return m->queue_prio;
+    if (k == "queue_late") return m->queue_late;
     if (k == "warm_extrap") return m->warm_extrap;
     if (k == "threads_per_env") return m->threads;
     if (k == "timestep") return m->h.opt[kp::OPT_TIMESTEP];

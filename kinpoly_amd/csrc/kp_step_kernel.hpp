@@ -84,6 +84,7 @@ struct StepArgs {
     int n_parts;
     int queue_heavy;           // > 0: a wave that finds its env heavy (this job's cycles per substep > queue_heavy % of the launch's running mean) runs the env's next job itself
     int queue_fence;           // 1: the hand-over is a release (publish) / acquire (consume) pair at agent scope instead of relaxed sc1 accesses + s_waitcnt
+    int queue_late;            // 1: a wave whose env's FIRST job came from beyond the resident slots (it started late) runs that env's later jobs itself, at once
     int queue_prio;            // > 0: waves running jobs of envs known to be heavy raise their issue priority (s_setprio)
     int order_valid;           // the first jobs were queued longest-env-first
     unsigned long long part_sub_lo, part_sub_hi;   // substeps of job 0 .. 15, one byte each (sum = n_substeps); packed so that no lookup indexes the kernel argument
@@ -2075,6 +2076,8 @@ __device__ __forceinline__ int step_body(const StepArgs& A, const int env_in, co
     // pass n is the forward pass on the final state.  Running the entry pass through the SAME code as a substep's forward pass is what
     // makes a control step cut into jobs bit-identical to an uncut one (two inlined copies need not contract their FMAs alike), and it
     // keeps the kernel's code a third shorter.
+    int rem_after = 0;          // substeps of the control step's later jobs (queue_prio = 3)
+    if constexpr (Q) for (int p = part + 1; p < A.n_parts; p++) rem_after += (int)(((p < 8 ? A.part_sub_lo >> (8 * p) : A.part_sub_hi >> (8 * (p - 8)))) & 255ull);
     const int last_pass = (n_substeps > 0 && (!P.stale || torque_out)) ? n_substeps : n_substeps - 1;
     for (int sub = torque_in ? 0 : -1; sub <= last_pass; sub++) {
         // per-lane invariants are re-derived from a laundered lane index every pass (see kp_launder): table addresses, the body's tree
@@ -2083,6 +2086,14 @@ __device__ __forceinline__ int step_body(const StepArgs& A, const int env_in, co
         const int depth = tid < D_NB ? (int)s.bdep[tid] : -1;
         const V3 bpos = tid < D_NB ? ld3(T.body_pos + 3 * tid) : v3(0.f, 0.f, 0.f);
         const bool substep = sub >= 0 && sub < n_substeps;
+        if constexpr (Q) {
+            // queue_prio = 3: issue priority by the env's distance from the end of its control step, set anew at every substep -- the waves of a SIMD then progress
+            // together: an env that started late or runs heavy (and so has more substeps left than its neighbours) is preferred until it has caught up
+            if (A.queue_prio == 3 && substep) {
+                const int lvl = (4 * (rem_after + n_substeps - sub) - 1) / A.n_substeps;
+                if (lvl >= 3) __builtin_amdgcn_s_setprio(3); else if (lvl == 2) __builtin_amdgcn_s_setprio(2); else if (lvl == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+            }
+        }
         if (prof && sub == 0) tstart = __builtin_readcyclecounter();
         if (prof) t0 = __builtin_readcyclecounter();
         // stale mode: the controller sees M / bias of the previous forward pass (cinert, cdof, bias still in LDS)
@@ -2384,11 +2395,17 @@ __global__ __launch_bounds__(64, (LEAN ? 3 : 2)) void kp_step_queue_kernel(StepA
         e = (unsigned)__builtin_amdgcn_readfirstlane((int)e);
         const int env = (int)(e & 0xFFFFFFu);
         int part = (int)(e >> 24);
+        // With more envs than slots the launch ends on the envs whose first job had to wait for a slot: their chain starts one job late, and every pass through
+        // the FIFO (behind the early envs' later jobs) delays it further.  queue_late: such an env is never queued again.
+        const bool late = A.queue_late && part == 0 && idx >= gridDim.x;
         // Issue priority: the launch ends on its costliest envs' serial chains, and a wave shares its SIMD's issue slots with one other wave.  A wave that
         // runs a job of an env known to be heavy -- one of the first queue entries when the first jobs were queued longest-env-first (k_lpt_order), or an
         // env it kept because its last job ran long (below) -- raises its own priority, so the SIMD's arbiter prefers it over its neighbour
         // (s_setprio: scheduling only, results do not depend on it); every other job runs at the default priority.
-        if (A.queue_prio > 0) { if (A.order_valid && part == 0 && idx < (unsigned)A.n_envs / 16u) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); }
+        if (A.queue_prio == 1) { if (A.order_valid && part == 0 && idx < (unsigned)A.n_envs / 16u) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); }
+        // queue_prio = 2: most remaining work first.  With more envs than slots the envs whose first job starts late are the ones the launch ends on; a wave on an
+        // env's first job outranks its SIMD neighbours on second jobs, those outrank last jobs (at the launch's start every wave is on a first job: no preference)
+        if (A.queue_prio == 2) { if (part == 0) __builtin_amdgcn_s_setprio(2); else if (part + 1 < A.n_parts) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
         for (;;) {
             const unsigned long long tj = __builtin_amdgcn_s_memrealtime();          // 100 MHz ticks: only ratios of job times are used
             const int overflow = step_body<64, OBJ, false, true, LEAN>(A, env, part);
@@ -2417,7 +2434,7 @@ __global__ __launch_bounds__(64, (LEAN ? 3 : 2)) void kp_step_queue_kernel(StepA
                 // iteration in one substep is + 25 %)
                 keep = prev_cnt >= 512u && nsub >= 4u && (unsigned long long)dt * prev_cnt * 100ull > (unsigned long long)prev_tot * nsub * (unsigned)A.queue_heavy;
             }
-            keep = __builtin_amdgcn_readfirstlane(keep);
+            keep = __builtin_amdgcn_readfirstlane(keep) | (int)late;
             if (!keep) {
                 if (threadIdx.x == 0) {                                    // ... before the env's next job becomes visible
                     const unsigned pos = atomicAdd(&A.jobctr[1], 1u);
@@ -2426,8 +2443,9 @@ __global__ __launch_bounds__(64, (LEAN ? 3 : 2)) void kp_step_queue_kernel(StepA
                 break;
             }
             if (threadIdx.x == 0) atomicAdd(&A.jobctr[16], 1u);
-            if (A.queue_prio > 0) __builtin_amdgcn_s_setprio(3);
+            if (A.queue_prio == 1) __builtin_amdgcn_s_setprio(3);
             part++;
+            if (A.queue_prio == 2) { if (part + 1 < A.n_parts) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1); }      // a kept (heavy) env stays one rank above its part
         }
     }
 }

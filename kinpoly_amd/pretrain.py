@@ -120,7 +120,7 @@ def job_wide_rng(epoch, seed=4):
     return np.random.RandomState((int(seed) * 1000003 + int(epoch) + 2) % (2 ** 31 - 1))
 
 
-def sampling_batches(dataset, num_samples, batch_size, device):
+def sampling_batches(dataset, num_samples, batch_size, device, dtype=None):
     """DatasetBatch.sampling_generator (statear_smpl_dataset.py:378-399): `num_samples` takes drawn with replacement from freq_indices (a take is
     listed once per fr_num frames of its length), a uniform window of fr_num frames each, served in shuffled batches of `batch_size`."""
     inds = dataset.rng.choice(dataset.freq_indices, size=num_samples)
@@ -130,7 +130,8 @@ def sampling_batches(dataset, num_samples, batch_size, device):
     for i in range(0, num_samples, batch_size):
         sel = order[i:i + batch_size]
         b = dataset.batch(inds[sel], starts[sel], dataset.fr_num)
-        yield {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in b.items()}
+        # dtype: the network's (fp64 master copies of --update_dtype fp64 read fp32 data sets: floating tensors are cast, index tensors are not)
+        yield {k: ((v.to(device, dtype) if (dtype is not None and v.is_floating_point()) else v.to(device)) if torch.is_tensor(v) else v) for k, v in b.items()}
 
 
 def update_init_supervised(net, optimizer, fk: TorchFK, dataset, num_epoch=500, num_sample=2000, batch_size=256, weights=None, grad_allreduce=None):
@@ -138,7 +139,7 @@ def update_init_supervised(net, optimizer, fk: TorchFK, dataset, num_epoch=500, 
     dev = next(net.parameters()).device
     last = None
     for _ in range(num_epoch):
-        for data in sampling_batches(dataset, num_sample, batch_size, dev):
+        for data in sampling_batches(dataset, num_sample, batch_size, dev, next(net.parameters()).dtype):
             pred_qpos, _, _ = net.init_states(data, keep_feat=False)
             loss, _ = compute_loss_init(fk, pred_qpos, data["qpos"][:, 0], weights)
             optimizer.zero_grad(); loss.backward()
@@ -155,7 +156,7 @@ def train_full_supervised(net, optimizer, fk: TorchFK, dataset, num_epoch=50, sc
     dev = next(net.parameters()).device
     last = None
     for _ in range(num_epoch):
-        for data in sampling_batches(dataset, num_sample, batch_size, dev):
+        for data in sampling_batches(dataset, num_sample, batch_size, dev, next(net.parameters()).dtype):
             pred = forward_supervised(net, fk, data, scheduled_sampling, rng, noise_std)
             loss, _ = compute_loss(pred, data, weights)
             optimizer.zero_grad(); loss.backward()

@@ -27,13 +27,14 @@ from .kpo import OracleSim
 class EpisodeOracle:
     ACTION_OBJECTS = ((0,), (1, 2), (3,), (4,))      # sit -> chair, push -> box + table, avoid -> Can, step -> step (humanoid_ar_v1.py:37-39, XML body order)
 
-    def __init__(self, kpm, kin_policy, cc_policy, body_diff_thresh=10.0, body_diff_gt_thresh=12.0, dt=1.0 / 30.0, kpm_path=None):
+    def __init__(self, kpm, kin_policy, cc_policy, body_diff_thresh=10.0, body_diff_gt_thresh=12.0, dt=1.0 / 30.0, kpm_path=None, zfilter=None):
         """kin_policy / cc_policy: fp64 CPU copies of kinpoly_amd.nets.KinPolicy / PolicyMCP (the networks under test are not the subject
         here; their forward is pinned by tests/golden/policies.npz and traj_ar_net.npz)."""
         self.bp, self.bi, self.par = kpm["body_pos"].reshape(24, 3), kpm["body_ipos"].reshape(24, 3), kpm["body_parent"]
         self.diffw = kpm["body_diffw"]
         self.kin, self.mcp = kin_policy, cc_policy
         self.th, self.th_gt, self.dt = body_diff_thresh, body_diff_gt_thresh, dt
+        self.zf = zfilter if zfilter is not None else (0.0, 1.0, 5.0)          # (mean, std, clip) of cc_running_state (humanoid_ar_v1.py:265-266, update=False); default: identity
         self.kpm = kpm
         self.sim = OracleSim() if kpm_path is None else OracleSim(kpm=kpm_path)      # kpm_path: the scene the objects come from (mocap training: ..._all_step.xml)
 
@@ -89,7 +90,7 @@ class EpisodeOracle:
             # ---- env.step
             prev_bquat = O.get_body_quat(qpos); prev_hpos = np.concatenate([xp[13], xq[13]])
             tgt = O.qpos_fk(O.step_ar(qpos, a), self.bp, self.bi, self.par)
-            cc_obs = O.zfilter(O.obs_cc(qpos, qvel, xp, xq, xi, tgt), 0.0, 1.0, 5.0)
+            cc_obs = O.zfilter(O.obs_cc(qpos, qvel, xp, xq, xi, tgt), *self.zf)
             with torch.no_grad():
                 cc_a = self.mcp.action_mean(torch.from_numpy(cc_obs)[None])[0].numpy()
             if noise is not None:

@@ -118,3 +118,31 @@ def test_warm_start_loops_lower_their_losses():
     f1 = P.train_full_supervised(net, opt, fk, ds, num_epoch=1, scheduled_sampling=0.3, num_sample=8, batch_size=8, scheduler=sched, rng=np.random.RandomState(0))
     f2 = P.train_full_supervised(net, opt, fk, ds, num_epoch=25, scheduled_sampling=0.3, num_sample=8, batch_size=8, scheduler=sched, rng=np.random.RandomState(0))
     assert f2 < 0.7 * f1
+
+
+def test_fp64_master_networks_read_the_fp32_data_set():
+    """`--update_dtype fp64 --warm_start` (and cfgs with init_update / full_update) hand an fp64 master copy of the policy to the supervised
+    loops while StateARDataset stores float32: the sampled batches are cast to the network's dtype (index tensors stay integers), so both loops run."""
+    from kinpoly_amd import dataset as D
+    from kinpoly_amd import pretrain as P
+    from kinpoly_amd.context import TrajARNet
+    from kinpoly_amd.model_compiler import DEFAULT_KPM, read_kpm
+    from kinpoly_amd.supervised import TorchFK
+    torch.manual_seed(0)
+    kpm = read_kpm(DEFAULT_KPM)
+    fk = TorchFK(kpm["body_pos"], kpm["body_parent"], "cpu", dtype=torch.float64)
+    T = 12
+    q = np.zeros((T, 76)); q[:, 2] = 0.9; q[:, 3] = 1.0; q[:, 7:] = 0.05 * np.sin(np.arange(T)[:, None] * 0.3)
+    wb = fk.wbpos(torch.tensor(q)).reshape(T, 72).numpy()
+    hp = np.concatenate([wb[:, 39:42], np.tile([1.0, 0, 0, 0], (T, 1))], 1)
+    feats = {"sit-0": dict(qpos=q, qvel=np.zeros((T, 75)), head_pose=hp, head_vels=np.zeros((T, 6)), action_one_hot=np.tile([1.0, 0, 0, 0], (T, 1)),
+                           obj_head_relative_poses=np.tile([0.5, 0, 0, 1.0, 0, 0, 0], (T, 1)), obj_pose=np.tile([0.5, 0, 0.4, 1.0, 0, 0, 0], (T, 1)),
+                           wbpos=wb, wbquat=np.zeros((T, 96)), bquat=np.zeros((T, 96)), of_files=["x"] * T)}
+    ds = D.StateARDataset(feats, fr_num=8, seed=3)
+    assert ds.data["qpos"][0].dtype == torch.float32
+    b = next(iter(P.sampling_batches(ds, 4, 4, "cpu", torch.float64)))
+    assert b["qpos"].dtype == torch.float64 and not b["take_ind"].is_floating_point()
+    net = TrajARNet(rnn_hdim=16, mlp_hsize=(16, 8)).double()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    assert np.isfinite(P.update_init_supervised(net, opt, fk, ds, num_epoch=1, num_sample=4, batch_size=4))
+    assert np.isfinite(P.train_full_supervised(net, opt, fk, ds, num_epoch=1, scheduled_sampling=0.3, num_sample=4, batch_size=4, rng=np.random.RandomState(0)))

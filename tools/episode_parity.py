@@ -34,15 +34,15 @@ CTX_KEYS = ("qpos", "head_pose", "head_vels", "obj_head_relative_poses", "action
 _W = {}
 
 
-def _worker_init(kin_sd, mcp_sd, kpm_path):
+def _worker_init(kin_sd, mcp_sd, kpm_path, zf=None):
     import torch
     torch.set_num_threads(1)
     from kinpoly_amd.model_compiler import read_kpm
     from kinpoly_amd.nets import KinPolicy, PolicyMCP
     from oracle.episode import EpisodeOracle
     kin, mcp = KinPolicy().double(), PolicyMCP().double()
-    kin.load_state_dict({k: torch.from_numpy(v).double() for k, v in kin_sd.items()}); mcp.load_state_dict({k: torch.from_numpy(v).double() for k, v in mcp_sd.items()})
-    _W["ep"] = EpisodeOracle(read_kpm(kpm_path), kin, mcp, kpm_path=kpm_path)
+    kin.load_state_dict({k: torch.from_numpy(v).double() for k, v in kin_sd.items() if not k.startswith("context_")}); mcp.load_state_dict({k: torch.from_numpy(v).double() for k, v in mcp_sd.items()})
+    _W["ep"] = EpisodeOracle(read_kpm(kpm_path), kin, mcp, kpm_path=kpm_path, zfilter=zf)
 
 
 def _worker_run(job):
@@ -64,7 +64,7 @@ def tracking_policy(env, ctx, seed):
     return pol
 
 
-def run(n=128, T=99, seed=7, objects=False, workers=32, policy_ckpt=None, device=0, clip_len=100):
+def run(n=128, T=99, seed=7, objects=False, workers=32, policy_ckpt=None, device=0, clip_len=100, cc_ckpt=None):
     import torch
     from kinpoly_amd.env import BatchedHumanoidAREnv, standing_context
     from kinpoly_amd.rollout import VectorSampler
@@ -73,8 +73,8 @@ def run(n=128, T=99, seed=7, objects=False, workers=32, policy_ckpt=None, device
     torch.manual_seed(seed)
     cc_policy = cc_rs = None
     if policy_ckpt:
-        from kinpoly_amd.checkpoint import load_bench_checkpoint
-        ck = load_bench_checkpoint(policy_ckpt, device)
+        from kinpoly_amd.checkpoint import load_bench_policies
+        ck = load_bench_policies(policy_ckpt, cc_ckpt, torch.device("cuda", device))
         cc_policy, cc_rs = ck["cc_policy"], ck["cc_running_state"]
     env = BatchedHumanoidAREnv(n, device, mode="train", seed=seed, cc_policy=cc_policy, cc_running_state=cc_rs)
     g = torch.Generator().manual_seed(seed)
@@ -100,8 +100,7 @@ def run(n=128, T=99, seed=7, objects=False, workers=32, policy_ckpt=None, device
     bad = int(((env.sim.diag()[:, 2] & 255) != 0).sum())
     hip = {"res_qpos": b.res_qpos.double().cpu().numpy(), "reward": b.rewards.double().cpu().numpy(), "done": (b.masks == 0).cpu().numpy(), "fail": b.fails.cpu().numpy().astype(bool)}
     # ---- the same episodes on the CPU: fp64 copies of the networks (ZFilter identity unless the checkpoint carries one: EpisodeOracle applies zfilter(0, 1, 5))
-    if policy_ckpt and cc_rs is not None and (float(cc_rs.mean.abs().max()) != 0.0 or float((cc_rs.std - 1).abs().max()) != 0.0):
-        raise SystemExit("episode_parity: the CPU episode loop applies an identity ZFilter; a checkpoint with running statistics is not supported here")
+    zf = None if cc_rs is None else (cc_rs.mean.double().cpu().numpy(), cc_rs.std.double().cpu().numpy(), float(cc_rs.clip))
     sd = lambda m: {k: v.detach().double().cpu().numpy() for k, v in copy.deepcopy(m).state_dict().items()}       # noqa: E731
     c = {k: v.double().cpu().numpy() for k, v in ctx.items() if k in CTX_KEYS}
     nz = noise.double().cpu().numpy()
@@ -113,7 +112,7 @@ def run(n=128, T=99, seed=7, objects=False, workers=32, policy_ckpt=None, device
         jobs.append((e, one, T, nz[:, e]))
     t0 = time.perf_counter()
     want = [None] * n
-    with mp.get_context("spawn").Pool(min(workers, n), initializer=_worker_init, initargs=(sd(pol), sd(env.cc_policy), STEP_KPM)) as pool:
+    with mp.get_context("spawn").Pool(min(workers, n), initializer=_worker_init, initargs=(sd(pol), sd(env.cc_policy), STEP_KPM, zf)) as pool:
         for e, r in pool.imap_unordered(_worker_run, jobs):
             want[e] = r
     t_cpu = time.perf_counter() - t0
@@ -169,9 +168,9 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--envs", type=int, default=128); ap.add_argument("--steps", type=int, default=99); ap.add_argument("--seed", type=int, default=7)
     ap.add_argument("--objects", action="store_true"); ap.add_argument("--workers", type=int, default=min(32, os.cpu_count() or 1))
-    ap.add_argument("--policy-ckpt", default=None); ap.add_argument("--json", default=None)
+    ap.add_argument("--policy-ckpt", default=None); ap.add_argument("--cc-ckpt", default=None); ap.add_argument("--json", default=None)
     a = ap.parse_args()
-    r = run(a.envs, a.steps, a.seed, a.objects, a.workers, a.policy_ckpt)
+    r = run(a.envs, a.steps, a.seed, a.objects, a.workers, a.policy_ckpt, cc_ckpt=a.cc_ckpt)
     s = json.dumps(r, indent=1)
     print(s)
     if a.json:
