@@ -40,10 +40,15 @@ class AgentAR:
                  pool_depth=4, num_epoch_fix=100, num_epoch=10000, joint_controller=False, grad_joint=False, grad_alternate=False, train_uhc=False,
                  cache_init_context=False, log_std=-3.2, policy_weightdecay=0.0, value_weightdecay=0.0, smooth=True, result_dir=None, eval_envs=None,
                  init_update=False, num_init_update=5, step_update_dyna=False, num_step_dyna_update=10, full_update=False, num_sample=20000, batch_size=128,
-                 noise_std=0.0, cc_checkpoint=None, update_dtype=None, reference_bugs=True):
+                 noise_std=0.0, cc_checkpoint=None, update_dtype=None, reference_bugs=True, min_batch_size=0):
         """update_dtype: None = the update runs on the fp32 roll-out modules (fused HIP re-unroll); torch.float64 = the reference's training
         precision on fp64 master copies (kinpoly_amd/update.py).  reference_bugs: reproduce the reference's generator-consumed gradient clip
-        (PPOTrainer) and LoggerRL.merge's max-of-mins; False = the corrected forms."""
+        (PPOTrainer) and LoggerRL.merge's max-of-mins; False = the corrected forms.
+        min_batch_size (kin_poly.yml:56, 10 000 in the reference; 0 = off): the reference updates once per >= min_batch_size samples.  4096 envs x H steps are ten
+        times that, so one update per sample() call would spend a tenth of the reference's optimiser steps (and LambdaLR / Adam steps) per sample.  With
+        min_batch_size > 0 a call's batch is cut into ceil(N H / min_batch_size) whole-env slices and every slice is ONE reference iteration: per_epoch_update,
+        update_params (PPO epochs, value steps, supervised steps), epoch += 1.  Ratios are taken against the policy that sampled the rows (recorded before the
+        first slice moves it).  N H <= min_batch_size: one slice, exactly the path without the option."""
         rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
         enable_tuned_gemms()          # library GEMM solution per shape (rollout and update shapes at 4096 envs); selection only
         torch.manual_seed(seed + rank)
@@ -72,7 +77,7 @@ class AgentAR:
                                cc_policy=self.env.cc_policy if joint_controller else None, train_uhc=train_uhc, policy_weightdecay=policy_weightdecay,
                                value_weightdecay=value_weightdecay, init_update=init_update, num_init_update=num_init_update, step_update_dyna=step_update_dyna,
                                num_step_dyna_update=num_step_dyna_update, full_update=full_update, num_sample=num_sample, batch_size=batch_size, noise_std=noise_std)
-        self.reference_bugs = bool(reference_bugs)
+        self.reference_bugs, self.min_batch_size = bool(reference_bugs), int(min_batch_size)
         self.sampler = VectorSampler(self.env, self.policy_net, record_qpos=True, source=self.source, pool_depth=pool_depth,
                                      record_full=joint_controller or step_update_dyna)
         self.epoch = 0
@@ -140,16 +145,43 @@ class AgentAR:
         """AgentAR.update_params (agent_ar.py:682-752): kinpoly_amd/update.py::ParamUpdate.update_params on this iteration's batch."""
         return self.upd.update_params(batch, self.epoch, self.source.dataset)
 
+    def update_slices(self, batch):
+        """The whole-env slices one sample() call's batch is updated on (min_batch_size; see the constructor): [(lo, hi), ...] over this rank's envs."""
+        N, T = batch.rewards.shape
+        world = dist.get_world_size(self.trainer.group) if _collective_on(self.trainer.group) else 1
+        k = 1 if self.min_batch_size <= 0 else min(N, max(1, -(-N * T * world // self.min_batch_size)))
+        per = -(-N // k)
+        return [(lo, min(lo + per, N)) for lo in range(0, N, per)]
+
     def optimize_policy(self, i_iter=None):
         t0 = time.time()
         self.trainer.per_epoch_update()
         batch = self.sampler.sample(self.horizon)
         torch.cuda.synchronize(self.device)
         t1 = time.time()
-        info = self.update_params(batch)
+        slices = self.update_slices(batch)
+        if len(slices) == 1:
+            info = self.update_params(batch)
+            self.epoch += 1
+        else:
+            N, T, _ = batch.states.shape
+            with torch.no_grad():                               # the behaviour policy's log-probabilities of the whole batch, before any slice moves the parameters
+                pol, tr = self.upd.policy, self.trainer
+                means = pol.unroll(tr._cast(batch.states), batch.episode_start, tr._cast(batch.hx0))
+                batch.behaviour_log_probs = pol.log_prob(means.reshape(N * T, -1), tr._cast(batch.actions).reshape(N * T, -1)).detach()
+            infos = []
+            for k, (lo, hi) in enumerate(slices):
+                if k > 0:
+                    self.trainer.per_epoch_update()
+                infos.append(self.update_params(batch.env_slice(lo, hi)))
+                self.epoch += 1
+            info = dict(infos[-1])
+            info["update_slices"] = len(slices)
+            for key in ("surr_loss", "value_loss", "step_loss", "ppo_log_ratio_std"):
+                if all(key in x for x in infos):
+                    info[key + "_per_slice"] = [x[key] for x in infos]
         torch.cuda.synchronize(self.device)
         t2 = time.time()
-        self.epoch += 1
         n = batch.rewards.numel()
         log = self.sampler.log
         log.sample_time = t1 - t0

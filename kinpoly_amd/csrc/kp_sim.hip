@@ -288,7 +288,10 @@ int launch_step(kp_sim* s, const float* action, int nsub, const uint8_t* mask, b
             if (sum == nsub) { parts = np; std::copy(tmp, tmp + np, sizes); }
         }
     }
-    const bool queue = nsub > 0 && parts > 1 && s->model->threads == 64 && s->n > slots && s->n <= 0xFFFFFF && !s->prof;   // env ids take 24 bits of a queue entry
+    // the queue pays from the env count on that one-workgroup-per-env launches (full layout) cannot hold resident at once; the lean queue then runs with
+    // every env resident up to its own slot count and in rounds beyond it
+    const int resident_full = s->wave_slots / 8 * std::min(8, 128 / (int)((lds + 1279) / 1280));
+    const bool queue = nsub > 0 && parts > 1 && s->model->threads == 64 && s->n > std::min(slots, resident_full) && s->n <= 0xFFFFFF && !s->prof;   // env ids take 24 bits of a queue entry
     A.jobq = s->jobq; A.jobctr = s->jobctr; A.ovfq = s->ovfq; A.lean_cap = s->model->lean_cap; A.warm3 = s->warm3; A.spd_next = s->spd_next; A.n_parts = queue ? parts : 1; A.queue_fence = s->model->queue_fence; A.queue_heavy = s->model->queue_heavy; A.queue_prio = s->model->queue_prio >= 0 ? s->model->queue_prio : (lean ? 3 : 0); A.queue_late = s->model->queue_late >= 0 ? s->model->queue_late : (lean ? 1 : 0); A.order_valid = A.order != nullptr;
     A.part_sub_lo = A.part_sub_hi = 0;
     for (int k = 0; queue && k < parts; k++) (k < 8 ? A.part_sub_lo : A.part_sub_hi) |= (unsigned long long)(sizes[k] & 255) << (8 * (k & 7));

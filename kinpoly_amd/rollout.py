@@ -50,6 +50,17 @@ class RolloutBatch:
     hx0: torch.Tensor | None = None             # [N, H]      GRU state before row 0 (episodes continuing from the previous call)
     last_states: torch.Tensor | None = None     # [N, 105]    observation after the last row (bootstrap of cut episodes)
     episodes: dict = field(default_factory=dict)   # finished episodes: take_ind, fr_start, percent (numpy), for freq_dict
+    behaviour_log_probs: torch.Tensor | None = None   # [N * T, 1] log-probabilities of `actions` under the policy that SAMPLED them (set when the batch is updated on in
+                                                      # slices, AgentAR.min_batch_size: later slices start from parameters the earlier ones have moved)
+
+    def env_slice(self, lo: int, hi: int) -> "RolloutBatch":
+        """rows of the envs [lo, hi): a whole-env slice is a valid batch of its own (its own hx0 and bootstrap observations)"""
+        N, T = self.rewards.shape
+        cut = lambda x: None if x is None else x[lo:hi]      # noqa: E731
+        blp = None if self.behaviour_log_probs is None else self.behaviour_log_probs.view(N, T, -1)[lo:hi].reshape((hi - lo) * T, -1)
+        return RolloutBatch(cut(self.states), cut(self.actions), cut(self.rewards), cut(self.masks), cut(self.episode_start), cut(self.fails), cut(self.curr_qpos),
+                            cut(self.gt_target_qpos), cut(self.next_states), cut(self.exps), cut(self.v_metas), cut(self.res_qpos), cut(self.cc_action), cut(self.cc_state),
+                            cut(self.hx0), cut(self.last_states), self.episodes, blp)
 
 
 def _agree_status(status: int, device, group=None) -> int:
@@ -555,6 +566,7 @@ class PPOTrainer:
         (tests/golden/update_params.npz holds the norms the reference's calls reported: 45.99, 0, 0, ...).  False clips every step."""
         self.policy, self.value, self.group, self.cc_policy = policy, value, group, cc_policy
         self.reference_bugs, self._clip_calls, self.clip_norms = bool(reference_bugs), 0, []
+        self.debug_reset_momentum = __import__("os").environ.get("KP_DEBUG_RESET_PPO_MOMENTUM") == "1"      # tools/update_ablation.sh only; read once, not per update
         self.gamma, self.tau, self.clip_epsilon, self.num_optim_epoch, self.policy_grad_clip = gamma, tau, clip_epsilon, num_optim_epoch, policy_grad_clip
         self.value_opt_niter = value_opt_niter
         self.opt_p = torch.optim.Adam([p for p in policy.parameters() if p.requires_grad], lr=policy_lr, weight_decay=policy_weightdecay)
@@ -624,11 +636,13 @@ class PPOTrainer:
         vloss = self._value_epochs(flat_states, ret, self.num_optim_epoch * self.value_opt_niter)
         # fixed_log_probs (agent_ar.py:758-759) is the policy's forward at the parameters the update starts from: epoch 0's own forward, reused
         # (the reference evaluates it twice; one of its 11 policy forwards is redundant), so epoch 0's ratio is exactly 1 as it is there
-        fixed_log_probs, surr = None, None
+        # a batch updated on in slices carries the log-probabilities under the policy that sampled it (behaviour_log_probs): the ratio is then taken against
+        # those, not against parameters the earlier slices have already moved
+        fixed_log_probs, surr = self._cast(batch.behaviour_log_probs), None
         self.surr_history = []                     # every epoch's surrogate, on the device (one host read at the end)
-        if __import__("os").environ.get("KP_DEBUG_RESET_PPO_MOMENTUM") == "1":
-            # diagnosis only (tools/update_ablation.sh): Adam's first moment of the policy optimiser is zeroed at the start of every iteration,
-            # to tell a stale momentum (built at parameters the supervised step updates have since moved) from a wrong gradient
+        if self.debug_reset_momentum:
+            # diagnosis only (tools/update_ablation.sh, KP_DEBUG_RESET_PPO_MOMENTUM=1 read once by the constructor): Adam's first moment of the policy optimiser is
+            # zeroed at the start of every iteration, to tell a stale momentum (built at parameters the supervised step updates have since moved) from a wrong gradient
             for st in self.opt_p.state.values():
                 if "exp_avg" in st:
                     st["exp_avg"].zero_()
@@ -648,7 +662,7 @@ class PPOTrainer:
             # the three numbers).  A surrogate that ends above 0 is the signature of a log-ratio spread far beyond the clip range: min(r A, clip(r) A) caps the
             # gain of a sample the step moved the right way at 0.2 |A| and leaves the loss of one it moved the wrong way unbounded
             lr_ = (log_probs.detach() - fixed_log_probs).reshape(-1)
-            d = torch.stack([lr_.std(), (lr_.abs() > 0.2).float().mean(), (means.detach().reshape(N * T, -1) - flat_actions).abs().mean()]).tolist()
+            d = torch.stack([lr_.std(), (lr_.abs() > 0.2).float().mean()]).tolist()
             stats.update(ppo_log_ratio_std=d[0], ppo_frac_outside_clip=d[1])
         if self.cc_policy is not None and batch.cc_state is not None:
             stats["cc_surr_loss"] = self.update_controller(batch, adv, ind)

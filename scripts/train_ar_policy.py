@@ -62,6 +62,8 @@ def main():
     ap.add_argument("--load", type=str, default="", help="start from this checkpoint (reference layout) instead of seeded random init; schedules and optimiser state start fresh")
     ap.add_argument("--min_horizon", type=int, default=0, help="with --cfg: lower bound of the per-env horizon derived from min_batch_size (0 = fr_num / 4; ADVICE r4: 10000 / 4096 envs "
                     "would be 3-step fragments that hang on the V bootstrap)")
+    ap.add_argument("--min_batch_size", type=int, default=None, help="samples per update (the reference's policy_specs.min_batch_size; default: the cfg's, 0 without --cfg): a sample() call's "
+                    "batch is cut into whole-env slices of about this many samples and each slice is one reference iteration (schedules, PPO epochs, supervised steps, epoch += 1); 0 = one update per call")
     ap.add_argument("--no_log", action="store_true")
     ap.add_argument("--test_data", type=str, nargs="*", default=[], help="feature files of the test sets evaluated every save_model_interval iterations")
     ap.add_argument("--test_data_wild", type=str, nargs="*", default=[], help="the same for --wild test sets (evaluated on the ..._mesh_all.xml engine, agent_ar.py:305-314, 464)")
@@ -107,7 +109,7 @@ def main():
     if cfg is None:
         agent = AgentAR(args.num_envs, dataset=ds, device=local, horizon=args.horizon, **upd_kw, num_optim_epoch=args.num_optim_epoch, cc_checkpoint=cc_ckpt, result_dir=args.result_dir or None,
                         num_step_update=args.num_step_update, sampling_temp=0.3, sampling_freq=0.5, pool_depth=args.pool_depth, cache_init_context=args.cache_init_context,
-                        rl_update=bool(args.rl_update), step_update=bool(args.step_update))
+                        rl_update=bool(args.rl_update), step_update=bool(args.step_update), min_batch_size=args.min_batch_size or 0)
         first, last, interval = 0, args.iters, 0
     else:
         # the reference collects min_batch_size steps of WHOLE episodes (~ fr_num frames each); a lock-step sampler with thousands of envs would meet
@@ -116,7 +118,8 @@ def main():
         if rank == 0:
             print(f"horizon {horizon} steps per env = {horizon * args.num_envs * world} samples per iteration (min_batch_size {cfg.policy_specs.get('min_batch_size', 10000)})", flush=True)
         agent = AgentAR(args.num_envs, dataset=ds, device=local, horizon=horizon, pool_depth=args.pool_depth, **upd_kw,
-                        cache_init_context=args.cache_init_context, result_dir=cfg.result_dir, cc_checkpoint=cc_ckpt, **cfg.agent_kwargs())
+                        cache_init_context=args.cache_init_context, result_dir=cfg.result_dir, cc_checkpoint=cc_ckpt, **cfg.agent_kwargs(),
+                        min_batch_size=int(cfg.policy_specs.get("min_batch_size", 10000)) if args.min_batch_size is None else args.min_batch_size)
         cfg.apply_reward_weights(agent.env)
         agent.test_datasets = ([D.StateARDataset(p, data_mode="test", fr_num=args.clip_len, wild=args.wild, seed=4, device=fk_sim.device) for p in args.test_data]
                                + [D.StateARDataset(p, data_mode="test", fr_num=args.clip_len, wild=True, seed=4, device=fk_sim.device) for p in args.test_data_wild])
@@ -152,11 +155,17 @@ def main():
             print(json.dumps({"fixed_eval": tag, "takes": len(pc), "mean_percent": float(pc.mean()), "coverage": int((pc == 1).sum()), "mean_abs_joint_err": float(err)}), flush=True)
     if args.eval_first_last:
         fixed_eval("before")
-    for it in range(first, last):
-        if args.eval_first_last and args.eval_every and it > first and (it - first) % args.eval_every == 0:
-            fixed_eval(f"iter{it}")
-        info = agent.optimize_policy(it)
-        if interval and (it + 1) % interval == 0:      # optimize_policy's periodic test-set evaluation, then train_ar_policy.py:95-97
+    # one optimize_policy call = one sample() of num_envs x horizon steps = as many reference iterations as it has update slices (min_batch_size): `it` counts
+    # reference iterations (agent.epoch), which is what the schedules, the checkpoint names and --iters mean
+    agent.epoch = first
+    while agent.epoch < last:
+        it0 = agent.epoch
+        if args.eval_first_last and args.eval_every and it0 > first and (it0 - first) % args.eval_every < getattr(agent, "_last_slices", 1):
+            fixed_eval(f"iter{it0}")
+        info = agent.optimize_policy(it0)
+        it = agent.epoch - 1
+        agent._last_slices = agent.epoch - it0
+        if interval and (it + 1) // interval > it0 // interval:      # optimize_policy's periodic test-set evaluation, then train_ar_policy.py:95-97
             info["log_eval"] = agent.eval_policy("test")
             if rank == 0:
                 agent.save_checkpoint(cfg.checkpoint_path(it + 1))

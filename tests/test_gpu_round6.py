@@ -110,3 +110,39 @@ def test_whole_episodes_match_the_cpu_episode_loop():
     assert abs(r["failures"]["hip"] - r["failures"]["oracle"]) <= max(2, int(0.02 * r["failures"]["oracle"]))
     # measured (MI355X, round 6): p50 8.1e-7, p99 7.4e-4, 0.83 % of the 12 672 env-steps above 1e-3 rad (the rows after a contact knife-edge flip), max 2e-2
     assert r["dqpos_aligned_rows"]["p50"] < 1e-5 and r["dqpos_aligned_rows"]["p99"] < 3e-3 and r["dqpos_aligned_rows"]["frac_above_1e-3"] < 0.03
+
+
+def test_update_slices_are_reference_iterations():
+    """AgentAR(min_batch_size): a sample() call's batch is cut into whole-env slices of about min_batch_size samples and each slice is ONE reference iteration
+    (agent_ar.py:274-289: per_epoch_update -> sample(min_batch_size) -> update_params).  (i) a batch that fits min_batch_size takes the path
+    without the option, bit for bit; (ii) 32 envs x 6 steps at min_batch_size 48 = 4 slices of 8 envs: four LambdaLR steps, 4 x num_optim_epoch Adam steps of the
+    policy, 4 x num_step_update of the supervised optimiser, epoch += 4, and the ratios of the later slices are taken against the sampling policy."""
+    from kinpoly_amd.agent import AgentAR
+    from kinpoly_amd.env import standing_context
+    from kinpoly_amd import sim as kpsim
+    n, T = 32, 6
+    fk_sim = kpsim.KpSim(kpsim.KpModel(), n, 0)
+
+    def context_fn(m):
+        return standing_context(m, T + 2, STD["qpos"], STD["qvel"], fk_sim, torch.zeros(m))
+    kw = dict(device=0, horizon=T, num_optim_epoch=2, num_step_update=3, use_init_context=False, pool_depth=T, seed=11)
+    ends = []
+    for mbs in (0, n * T, 10 ** 6):
+        agent = AgentAR(n, context_fn, min_batch_size=mbs, **kw)
+        assert len(agent.update_slices(agent.sampler.sample(T))) == 1
+        agent.sampler.start()
+        agent.optimize_policy(0)
+        ends.append(torch.cat([p.detach().reshape(-1) for p in agent.policy_net.parameters()]).clone())
+        assert agent.epoch == 1
+        del agent
+    assert torch.equal(ends[0], ends[1]) and torch.equal(ends[0], ends[2])
+    agent = AgentAR(n, context_fn, min_batch_size=48, **kw)
+    info = agent.optimize_policy(0)
+    assert info["update_slices"] == 4 and agent.epoch == 4 and len(info["surr_loss_per_slice"]) == 4
+    assert agent.trainer.sched_p.last_epoch == 4 and agent.sched_sup.last_epoch == 4
+    step_p = {int(st["step"]) for st in agent.trainer.opt_p.state.values()}
+    step_s = {int(st["step"]) for st in agent.opt_sup.state.values()}
+    assert step_p == {4 * 2} and step_s <= {4 * 3} and 4 * 3 in step_s, (step_p, step_s)
+    assert np.isfinite(info["surr_loss_per_slice"]).all() and np.isfinite(info["step_loss_per_slice"]).all()
+    # two ranks' worth of slicing arithmetic: the job-wide sample count decides the number of slices
+    assert len(agent.update_slices(agent.sampler.sample(T))) == 4
