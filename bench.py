@@ -645,6 +645,15 @@ def main():
         dist.all_reduce(one)
         ranks_seen = int(one.item())
 
+    # which physical device every rank runs on: a scaling record must show N DISTINCT GPUs (uuid / PCI bus id from the runtime's device properties)
+    pr = torch.cuda.get_device_properties(local_rank)
+    me = {"rank": rank, "local_rank": local_rank, "name": pr.name, "uuid": str(getattr(pr, "uuid", "")), "pci_bus_id": getattr(pr, "pci_bus_id", None), "pci_device_id": getattr(pr, "pci_device_id", None)}
+    devices = [me]
+    if in_group:
+        devices = [None] * world
+        dist.all_gather_object(devices, me)
+    distinct = len({(d["uuid"], d["pci_bus_id"], d["pci_device_id"]) for d in devices})
+
     if train:
         rec = train_iteration(local_rank, 4, TRAIN_HORIZON, args.steps, args.warmup, barrier, args.threads_per_env, rank=rank)
         env = policy = sampler = None
@@ -700,7 +709,7 @@ def main():
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": WORKLOAD_DESC["train_iter"], "workload_id": "train_iter", "envs_per_gpu": ENVS_PER_GPU, "horizon": TRAIN_HORIZON,
                           "samples_per_step": per_step * world, "parallelism": f"env-sharded x{world}, data-parallel update"},
-               "ranks_seen": ranks_seen, "ms_per_step_per_rank": per_rank_ms, "collective_backend": (dist.get_backend() if in_group else None),
+               "ranks_seen": ranks_seen, "devices": devices, "distinct_devices": distinct, "ms_per_step_per_rank": per_rank_ms, "collective_backend": (dist.get_backend() if in_group else None),
                "train_iteration": {k: rec[k] for k in TRAIN_KEYS}}
         print(json.dumps(out), flush=True)
     elif rank == 0:
@@ -749,7 +758,7 @@ def main():
             "config": {"workload": WORKLOAD_DESC[args.workload], "workload_id": args.workload, "envs_per_gpu": ENVS_PER_GPU, "substeps": 15, "clip_len": CLIP_LEN,
                        "threads_per_env": args.threads_per_env, "parallelism": f"env-sharded x{world}",
                        "gemm_selection": "kinpoly_amd/assets/tunableop_gfx950.csv (rocBLAS / hipBLASLt solution per shape, fp32)" if getattr(build_engine, "tuned", False) else "library default"},
-            "ranks_seen": ranks_seen, "ms_per_step_per_rank": per_rank_ms, "collective_backend": (dist.get_backend() if in_group else None),
+            "ranks_seen": ranks_seen, "devices": devices, "distinct_devices": distinct, "ms_per_step_per_rank": per_rank_ms, "collective_backend": (dist.get_backend() if in_group else None),
             # the kernel is bound by wave-level instruction issue, not by HBM or MFMA (its state lives in LDS); the HBM figures the
             # contract asks for are kept: achieved = algorithmic bytes / launch, traffic = PMC bytes / launch, traffic_over_algorithmic = their ratio
             "roofline": {"bound": "valu-issue", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -286,6 +286,48 @@ def compare_model(arrays: dict, kpm: dict) -> dict:
     return out
 
 
+MODEL_ARRAY_TOL = 1e-6          # what the live pin asserts on every entry of compare_model (tests/test_gpu_round5.py)
+
+
+def model_table(arrays: dict, kpm: dict, tol: float = MODEL_ARRAY_TOL) -> list:
+    """The model-array comparison the pin asserts on, entry by entry instead of as one maximum per array: for every array the number of entries, how many are
+    beyond `tol`, and the worst entry with its index, both values and the (relative / absolute) difference -- so that the first run against a real binding
+    says WHERE the compiled blob and MuJoCo's compiler part (a body, a dof), not just that they do.  Rows are dicts; `format_model_table` prints them."""
+    rows = []
+    nb = int(kpm["dims"][0])
+    per = {"body_mass": 1, "body_ipos": 3, "body_inertia": 6, "body_invweight0": 2, "dof_invweight0": 1, "body_pos": 3}
+    for k, rel in (("body_mass", True), ("body_ipos", False), ("body_inertia", True), ("body_invweight0", True), ("dof_invweight0", True), ("body_pos", False)):
+        if k not in arrays:
+            rows.append({"array": k, "status": "not provided by this backend"})
+            continue
+        want = np.asarray(kpm[k], float).reshape(-1)
+        got = np.asarray(arrays[k], float).reshape(-1)
+        if k == "body_pos":
+            want = want.copy(); want[:3] = kpm["body_gpos0"].reshape(nb, 3)[0]
+        if got.shape != want.shape:
+            rows.append({"array": k, "status": f"shape {got.shape} vs {want.shape}"})
+            continue
+        d = np.abs(got - want)
+        e = d / np.maximum(np.abs(want), 1e-12) if rel else d
+        i = int(e.argmax())
+        rows.append({"array": k, "entries": int(e.size), "measure": "relative" if rel else "absolute", "tolerance": tol, "beyond_tolerance": int((e > tol).sum()),
+                     "worst": float(e[i]), "worst_index": i, "worst_item": f"{'dof' if k.startswith('dof') else 'body'} {i // per[k]} component {i % per[k]}",
+                     "backend_value": float(got[i]), "blob_value": float(want[i]), "status": "ok" if e[i] <= tol else "DIFFERS"})
+    if "meaninertia" in arrays:
+        rows.append({"array": "meaninertia (humanoid only)", "backend_value": float(arrays["meaninertia"]), "status": "reported (the blob's is the 105-dof scene's)"})
+    return rows
+
+
+def format_model_table(rows: list) -> str:
+    out = ["| array | entries | measure | tolerance | beyond | worst | at | backend | blob | status |", "|---|---|---|---|---|---|---|---|---|---|"]
+    for r in rows:
+        out.append("| {} | {} | {} | {} | {} | {} | {} | {} | {} | {} |".format(
+            r["array"], r.get("entries", ""), r.get("measure", ""), r.get("tolerance", ""), r.get("beyond_tolerance", ""),
+            "%.3g" % r["worst"] if "worst" in r else "", r.get("worst_item", ""), "%.9g" % r["backend_value"] if "backend_value" in r else "",
+            "%.9g" % r["blob_value"] if "blob_value" in r else "", r["status"]))
+    return "\n".join(out)
+
+
 def control_substep(backend: Backend, action, target_qpos, kpm: dict):
     """one pass of do_simulation's loop body (humanoid_im.py:509-529) on `backend`: stable-PD torque from the backend's CURRENT qpos / qvel and its
     qM / qfrc_bias as they stand (= of the previous mj_step's state, the staleness the reference lives with), clip, RFC, mj_step"""
@@ -373,6 +415,7 @@ def pin_report(kpm_path=None, n_free_fall=None, n_contact=None, hip=None) -> dic
     out = {"binding": found[0], "version": getattr(found[1], "__version__", "?")}
     b = open_backend(kpm)
     out["model"] = compare_model(b.model_arrays(), kpm)
+    out["model_table"] = model_table(b.model_arrays(), kpm)
     ff = open_backend(kpm, contact=False)
     out["free_fall"] = {k: {kk: vv for kk, vv in v.items() if kk != "max_dqpos_per_step"} for k, v in
                         run_pin("free_fall", ff, {"oracle": OracleBackend(kpm_path, contact=False)}, kpm, std["qpos"], std["qvel"], n_free_fall).items()}

@@ -572,3 +572,21 @@ def test_pin_harness_runs_end_to_end_with_the_oracle_in_mujocos_seat():
     assert q[2] > 10 and abs(np.linalg.norm(q[3:7]) - 1) < 1e-6 and np.abs(q[7:]).max() <= np.pi
     if MP.find_mujoco() is None:
         assert MP.pin_report() is None
+
+
+def test_model_table_names_the_entry_that_differs():
+    """tools/mujoco_pin.py --report: the model-array comparison entry by entry.  With one body's mass and one dof's invweight perturbed the table names exactly
+    those (array, body / dof, both values), every other row reads ok."""
+    import mj_pin as MP
+    from kinpoly_amd.model_compiler import DEFAULT_KPM, read_kpm
+    kpm = read_kpm(DEFAULT_KPM)
+    arrays = {k: np.array(kpm[k], float).copy() for k in ("body_mass", "body_ipos", "body_inertia", "body_invweight0", "dof_invweight0")}
+    arrays["body_mass"][7] *= 1.0 + 3e-5
+    arrays["dof_invweight0"][40] *= 1.0 - 2e-4
+    rows = {r["array"]: r for r in MP.model_table(arrays, kpm)}
+    assert rows["body_mass"]["status"] == "DIFFERS" and rows["body_mass"]["worst_item"] == "body 7 component 0" and rows["body_mass"]["beyond_tolerance"] == 1
+    assert rows["dof_invweight0"]["status"] == "DIFFERS" and rows["dof_invweight0"]["worst_item"] == "dof 40 component 0"
+    assert abs(rows["dof_invweight0"]["worst"] - 2e-4) < 1e-8
+    assert rows["body_ipos"]["status"] == "ok" and rows["body_inertia"]["status"] == "ok" and rows["body_pos"]["status"].startswith("not provided")
+    text = MP.format_model_table(list(rows.values()))
+    assert "body 7 component 0" in text and text.count("\n") == len(rows) + 1

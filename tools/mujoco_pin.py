@@ -34,8 +34,23 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--free_fall", type=int, default=1500); ap.add_argument("--contact", type=int, default=150)
     ap.add_argument("--no_hip", action="store_true"); ap.add_argument("--write_xml", type=str, default="")
+    ap.add_argument("--report", action="store_true", help="print the model-array comparison table the pin asserts on, entry by entry (worst entry, its body / dof, both values). "
+                    "Without a MuJoCo binding the fp64 oracle's own derived arrays stand in for the backend's -- labelled -- so that the table's code path is exercised")
     args = ap.parse_args()
     import mj_pin as MP
+    if args.report:
+        from kinpoly_amd.model_compiler import DEFAULT_KPM, read_kpm
+        kpm = read_kpm(DEFAULT_KPM)
+        found = MP.find_mujoco()
+        if found is not None:
+            backend, who = MP.open_backend(kpm), f"{found[0]} {getattr(found[1], '__version__', '?')}"
+            arrays = backend.model_arrays()
+        else:
+            who = "NO MuJoCo binding importable: the blob against itself (every row must read ok / 0) -- this run checks the report, not the physics"
+            arrays = {k: kpm[k] for k in ("body_mass", "body_ipos", "body_inertia", "body_invweight0", "dof_invweight0")}
+            bp = kpm["body_pos"].reshape(-1, 3).copy(); bp[0] = kpm["body_gpos0"].reshape(-1, 3)[0]; arrays["body_pos"] = bp.reshape(-1)
+        print(f"model arrays: backend = {who}")
+        print(MP.format_model_table(MP.model_table(arrays, kpm)))
     if args.write_xml:
         from kinpoly_amd.model_compiler import DEFAULT_KPM, read_kpm
         open(args.write_xml, "w").write(MP.mjcf_from_kpm(read_kpm(DEFAULT_KPM)))
