@@ -2398,6 +2398,8 @@ __global__ __launch_bounds__(64, (LEAN ? 3 : 2)) void kp_step_queue_kernel(StepA
         // With more envs than slots the launch ends on the envs whose first job had to wait for a slot: their chain starts one job late, and every pass through
         // the FIFO (behind the early envs' later jobs) delays it further.  queue_late: such an env is never queued again.
         const bool late = A.queue_late && part == 0 && idx >= gridDim.x;
+        // (running a late env's whole control step as ONE job, without the hand-overs between its parts, was measured and dropped: 2.216 vs 2.194 ms,
+        // profiles/r06/lean_schedule_knobs5.log)
         // Issue priority: the launch ends on its costliest envs' serial chains, and a wave shares its SIMD's issue slots with one other wave.  A wave that
         // runs a job of an env known to be heavy -- one of the first queue entries when the first jobs were queued longest-env-first (k_lpt_order), or an
         // env it kept because its last job ran long (below) -- raises its own priority, so the SIMD's arbiter prefers it over its neighbour

@@ -463,12 +463,24 @@ def _dptr(t, dtype=None, name="tensor"):
     return t.data_ptr()
 
 
+def _want(name, x, *shape):
+    """the record kernels index their buffers with fixed row widths (kp_rollout_kernels.hpp): a tensor of another shape would be read / written out of bounds"""
+    if x is not None and tuple(x.shape) != tuple(shape):
+        raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(x.shape)}")
+
+
 def record_pre(t: int, T: int, obs=None, fresh=None, qpos=None, ctx_qpos=None, row=None, cur_t=None, row_len=None, row_meta=None,
                states=None, episode_start=None, curr_qpos=None, gt_target_qpos=None, meta=None):
     """kp_rollout_record_pre: the before-the-step half of the sampler's per-step record, one launch (see include/kinpoly_sim.h)."""
     L = load_library()
     first = next(x for x in (obs, qpos, fresh) if x is not None)
     f32, i32, u8 = torch.float32, torch.int32, torch.uint8
+    n = first.shape[0]
+    _want("obs", obs, n, AR_OBS_DIM); _want("fresh", fresh, n); _want("qpos", qpos, n, 76); _want("row", row, n); _want("cur_t", cur_t, n)
+    _want("states", states, n, T, AR_OBS_DIM); _want("episode_start", episode_start, n, T); _want("curr_qpos", curr_qpos, n, T, 76)
+    _want("gt_target_qpos", gt_target_qpos, n, T, 76); _want("meta", meta, n, T, 2)
+    if ctx_qpos is not None and (ctx_qpos.dim() != 3 or ctx_qpos.shape[2] != 76):
+        raise ValueError(f"ctx_qpos: expected [R, T_ctx, 76], got {tuple(ctx_qpos.shape)}")
     r = KpRecordPre(first.shape[0], int(T), int(t), 0 if ctx_qpos is None else int(ctx_qpos.shape[1]),
                     _dptr(obs, f32, "obs"), _dptr(fresh, u8, "fresh"), _dptr(qpos, f32, "qpos"), _dptr(ctx_qpos, f32, "ctx_qpos"), _dptr(row, i32, "row"), _dptr(cur_t, i32, "cur_t"),
                     _dptr(row_len, i32, "row_len"), _dptr(row_meta, f32, "row_meta"), _dptr(states, f32, "states"), _dptr(episode_start, u8, "episode_start"),
@@ -482,6 +494,12 @@ def record_post(t: int, T: int, fr_num=0.0, action=None, reward=None, fail=None,
     L = load_library()
     first = next(x for x in (action, reward, done) if x is not None)
     f32, u8 = torch.float32, torch.uint8
+    n = first.shape[0]
+    _want("action", action, n, 80); _want("reward", reward, n); _want("fail", fail, n); _want("done", done, n); _want("percent", percent, n); _want("c_info", c_info, n, 6)
+    _want("obs", obs, n, AR_OBS_DIM); _want("qpos", qpos, n, 76); _want("cc_action", cc_action, n, CC_ACTION_DIM); _want("cc_state", cc_state, n, CC_OBS_DIM); _want("meta", meta, n, T, 2)
+    _want("actions", actions, n, T, 80); _want("rewards", rewards, n, T); _want("fails", fails, n, T); _want("dones", dones, n, T); _want("percents", percents, n, T)
+    _want("c_infos", c_infos, n, T, 6); _want("next_states", next_states, n, T, AR_OBS_DIM); _want("res_qpos", res_qpos, n, T, 76); _want("cc_actions", cc_actions, n, T, CC_ACTION_DIM)
+    _want("cc_states", cc_states, n, T, CC_OBS_DIM); _want("v_metas", v_metas, n, T, 3)
     r = KpRecordPost(first.shape[0], int(T), int(t), float(fr_num), _dptr(action, f32, "action"), _dptr(reward, f32, "reward"), _dptr(fail, u8, "fail"), _dptr(done, u8, "done"),
                      _dptr(percent, f32, "percent"), _dptr(c_info, f32, "c_info"), _dptr(obs, f32, "obs"), _dptr(qpos, f32, "qpos"), _dptr(cc_action, f32, "cc_action"),
                      _dptr(cc_state, f32, "cc_state"), _dptr(meta, f32, "meta"), _dptr(actions, f32, "actions"), _dptr(rewards, f32, "rewards"), _dptr(fails, u8, "fails"),
