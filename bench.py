@@ -211,6 +211,23 @@ def parity_live(env, sampler, workload, a_track, n=256):
     return out
 
 
+def episode_parity_live(envs=64, steps=99, workers=None):
+    """Whole-episode, outcome-level parity measured IN THIS RUN (tools/episode_parity.py): `envs` x `steps` control steps of the configs[2] rollout through
+    VectorSampler and through oracle/episode.py (fp64 CPU restatement of sample_worker, spawned single-threaded workers) with the same clips, weights and
+    exploration noise.  The oracle is the checker; this runs after the timed regions, on an engine of its own."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import episode_parity
+    t0 = time.perf_counter()
+    r = episode_parity.run(n=envs, T=steps, seed=7, objects=False, workers=workers or min(32, os.cpu_count() or 1))
+    keep = ("envs", "steps", "policy", "first_termination_step_equal_frac", "done_flags_equal_frac_of_rows", "episodes_ended", "failures", "failures_per_env_equal_frac", "mean_reward", "dqpos_aligned_rows", "bad_envs")
+    out = {k: r[k] for k in keep}
+    out["dqpos_p50_vs_control_step"] = {k: v["p50"] for k, v in r["dqpos_vs_control_step"].items()}
+    out["seconds"] = time.perf_counter() - t0
+    out["note"] = ("measured in this run: HIP sampler vs the fp64 CPU episode loop on the same episodes; |dqpos| over the rows whose done-flag history is identical on both sides "
+                   "(rows above 1e-3 rad follow a contact knife-edge flip in a falling humanoid)")
+    return out
+
+
 def mujoco_pin_report():
     """null until a MuJoCo binding is importable on the box; then the live pin of tests/mj_pin.py (model arrays, free fall, contact workload)"""
     try:
@@ -510,7 +527,7 @@ def sampler_regime(device_index, seed, horizon=TRAIN_HORIZON, calls=4, warm=2, t
     return out
 
 
-def train_iteration(device_index, seed, horizon, iters, warm, barrier=None, threads=64, objects=False, rank=0, cache_init_context=False):
+def train_iteration(device_index, seed, horizon, iters, warm, barrier=None, threads=64, objects=False, rank=0, cache_init_context=False, model_opts=None):
     """`iters` timed AgentAR.optimize_policy calls (after `warm` untimed) at ENVS_PER_GPU x horizon env-steps per rank, the way
     scripts/train_ar_policy.py runs them: every episode draws its clip from a StateARDataset (adaptive take sampling, freq_dict feedback) and goes
     through init_context (context GRU over the 100-frame clip -> init_qpos / init_qvel) -- inside the timed region, at whatever failure rate the
@@ -526,7 +543,7 @@ def train_iteration(device_index, seed, horizon, iters, warm, barrier=None, thre
                               seed=seed, with_objects=objects)
     ds = D.StateARDataset(takes, fr_num=CLIP_LEN, seed=seed + rank, device=fk_sim.device)
     agent = AgentAR(ENVS_PER_GPU, dataset=ds, device=device_index, horizon=horizon, seed=seed, use_init_context=True, pool_depth=4,
-                    model_options={"threads_per_env": threads}, sampling_temp=0.3, sampling_freq=0.5, cache_init_context=cache_init_context)
+                    model_options={"threads_per_env": threads, **(model_opts or {})}, sampling_temp=0.3, sampling_freq=0.5, cache_init_context=cache_init_context)
     for i in range(warm):
         agent.optimize_policy(i)
     (barrier or torch.cuda.synchronize)()
@@ -843,6 +860,11 @@ def main():
             del sampler, env, policy
             if train_n is not None:
                 out["train_iteration"] = {f"4096x{TRAIN_HORIZON}_x{world}gpus": train_n}
+        if world == 1 and not args.no_parity_live and not args.no_secondary:
+            try:
+                out["episode_parity"] = episode_parity_live()
+            except Exception as ex:
+                out["episode_parity"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
         if world == 1 and not args.no_cpu_baseline:
             workers = min(35, os.cpu_count() or 1)
             try:

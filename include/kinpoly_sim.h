@@ -342,6 +342,13 @@ int kp_sim_diag(kp_sim*, int32_t* out_host);
  * (launch / queue order only: results do not depend on it). */
 int kp_sim_launch_cost(kp_sim*, uint32_t* out_host);
 
+/* Floor scenes' job queue: which LDS layout the control-step launches run on.  out3[0] = 1 when the next queue launch would use the lean layout (12 envs per CU,
+ * 24 contact slots; model option "lean_queue"), out3[1] = how many times so far the handle has fallen back to the full layout for 64 launches because more than
+ * 1 / 64 of the envs needed more contact slots than the lean layout has (their jobs are re-run by a second kernel: cheaper to run everything on the full layout
+ * then; model option "lean_adaptive" = 0 keeps the lean layout regardless), out3[2] = control-step launches so far.  Host arithmetic only; no reference
+ * counterpart (launch policy: results do not depend on the layout). */
+int kp_sim_lean_state(kp_sim*, int32_t* out3);
+
 /* the job sizes kp_sim_step_ctrl uses for a control step of n_substeps when it schedules through the job queue (host arithmetic, no
  * device): sizes16[0 .. return value) sum to n_substeps, the last is substeps_per_job (or absorbs a smaller remainder), every earlier
  * one is `taper` substeps longer than the one after it (the first takes what is left).  Returns the number of jobs (<= 16) or a negative error. */

@@ -196,7 +196,7 @@ class AgentAR:
             self.source.save_freq_dict(os.path.join(self.result_dir, "freq_dict.pt"))       # joblib.dump(self.freq_dict, ...) after every iteration (:297)
         with torch.no_grad():       # size of the action network's weights (the supervised step updates at lr 5e-4 grow it; a fixed per-weight PPO step then moves the mean further)
             info["policy_param_norm"] = float(torch.sqrt(sum((p.float() ** 2).sum() for n_, p in self.upd.policy.named_parameters() if n_.startswith(("action_mlp", "action_fc", "action_rnn")))))
-        info.update(T_sample=t1 - t0, T_update=t2 - t1, T_total=time.time() - t0, num_steps=n, avg_reward=float(batch.rewards.mean()),
+        info.update(reference_bugs=self.reference_bugs, T_sample=t1 - t0, T_update=t2 - t1, T_total=time.time() - t0, num_steps=n, avg_reward=float(batch.rewards.mean()),
                     fail_rate=float(batch.fails.float().mean()), env_steps_per_s=n / (t1 - t0), episodes=len(batch.episodes.get("percent", ())),
                     pool_exhausted=self.sampler.pool_exhausted, clips_drawn=self.source.n_drawn, init_context_memo_hits=self.source.n_memo_hits, top_ups=self.sampler.top_ups, policy_lr=self.trainer.opt_p.param_groups[0]["lr"])
         return info

@@ -203,9 +203,15 @@ __global__ void k_reset_rows(int n, const float* __restrict__ init_qpos, const f
 __global__ void k_pool_advance(int n, int n_slots, const uint8_t* __restrict__ done, int* __restrict__ head, int* __restrict__ ahead, int* __restrict__ row) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n || !done[e]) return;
+    // an env with nothing queued behind it stays on the row it is on (it replays its clip) instead of moving onto a slot the host may be rewriting: by
+    // construction this cannot happen (one episode per step at most, the ring is sized for the periods between its refills); if it ever did, `ahead` still
+    // goes negative and the sampler's -- possibly one period late -- host check raises, but no env has read a stale or half-written row by then
+    const int a = ahead[e];
+    ahead[e] = a - 1;
+    if (a <= 0) return;
     int h = head[e] + 1;
     if (h >= n_slots) h = 0;
-    head[e] = h; ahead[e] -= 1;
+    head[e] = h;
     row[e] = h * n + e;
 }
 

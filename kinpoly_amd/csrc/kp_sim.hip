@@ -27,7 +27,7 @@ int fail(const std::string& m) { g_err = m; return -1; }
 
 struct kp_model {
     kp::HostModel h;
-    int contact = 1, limits = 1, stale = 1, solver_iter = 100, threads = 64, dynamic_objects = 1, lpt_order = -1, substeps_per_job = 4, queue_slots = 0, job_taper = 1, queue_fence = 1, queue_heavy = 160, queue_prio = -1, queue_late = -1, job_auto = 1, lean_queue = 1, lds_pad = 0, lean_cap = kp::EnvLdsLean::MAXCON;
+    int contact = 1, limits = 1, stale = 1, solver_iter = 100, threads = 64, dynamic_objects = 1, lpt_order = -1, substeps_per_job = 4, queue_slots = 0, job_taper = 1, queue_fence = 1, queue_heavy = 160, queue_prio = -1, queue_late = -1, job_auto = 1, lean_queue = 1, lean_adaptive = 1, lds_pad = 0, lean_cap = kp::EnvLdsLean::MAXCON;
     float warm_extrap = -1.f;      // < 0: automatic (0.75 when the scene's free objects are simulated, 0 otherwise); see kp_step_kernel.hpp
     int planemesh_max = 3; double planemesh_tol = 0.3;   // mjc_PlaneConvex's maxplanemesh / tolplanemesh (the blob's `planemesh`)
     int actuation = 1;            // 0: no stable-PD torque, no residual force (ctrl = qfrc_applied = 0): torque-free flight for the energy test
@@ -48,7 +48,13 @@ struct kp_sim {
     int* diag = nullptr;
     int* order = nullptr; unsigned* cost = nullptr;   // launch order of the control-step kernel (k_lpt_order)
     unsigned *jobq = nullptr, *jobctr = nullptr, *ovfq = nullptr;      // ovfq: jobs handed from the lean queue kernel to kp_step_overflow_kernel
-    float* warm3 = nullptr;      // job FIFO of kp_step_queue_kernel
+    float* warm3 = nullptr;
+    // how many envs the lean layout handed to the overflow kernel, read back WITHOUT waiting: every lean launch copies its count to pinned memory and records an
+    // event; a later launch whose predecessor's event has completed looks at the number.  When more than 1 / 64 of the envs overflow (a policy at random init resets
+    // every env onto a garbage pose, half buried, with 30 - 70 contacts) the overflow kernel's second pass over them costs more than the lean layout saves: the
+    // next 64 launches use the full layout, then the lean one is tried again.  Results do not depend on the layout.
+    unsigned* ovf_host = nullptr; hipEvent_t ovf_ev[2] = {nullptr, nullptr}; bool ovf_pending[2] = {false, false};
+    long launch_index = 0, lean_off_until = -1; int lean_fallbacks = 0;      // job FIFO of kp_step_queue_kernel
     float* spd_next = nullptr;                        // [N, 80] torque hand-over between the jobs of a control step
     int jobq_cap = 0, wave_slots = 2048;
     int q_nsub = -1, q_obj = -1;                      // what the queue's "heavy job" yardstick (jobctr[32..33] -> [48..49]) was measured on
@@ -272,7 +278,18 @@ int launch_step(kp_sim* s, const float* action, int nsub, const uint8_t* mask, b
     // resident waves: LDS is allocated in 1 280-byte granules, 128 per CU (tools/micro/lds_granule_probe.hip); 256 VGPRs allow 8 waves per CU
     // floor scenes: the job queue runs on the lean layout (EnvLdsLean) with a register budget for three waves per SIMD; model option lean_queue = 0 keeps the
     // full layout (two waves per SIMD; A / B measurements).  lds_pad: allocate at least that many bytes per env (experiments: fewer envs per CU with the same binary)
-    const bool lean = !obj && s->model->lean_queue && s->model->threads == 64;
+    bool lean = !obj && s->model->lean_queue && s->model->threads == 64;
+    bool capturing = false;
+    { hipStreamCaptureStatus cap = hipStreamCaptureStatusNone; capturing = hipStreamIsCapturing(s->stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone; }
+    if (lean && nsub > 0 && s->ovf_host && !capturing) {
+        for (int k = 0; k < 2; k++)
+            if (s->ovf_pending[k] && hipEventQuery(s->ovf_ev[k]) == hipSuccess) {
+                s->ovf_pending[k] = false;
+                if ((size_t)s->ovf_host[k] * 64 > (size_t)s->n) { s->lean_off_until = s->launch_index + 64; s->lean_fallbacks++; }
+            }
+        if (s->model->lean_adaptive && s->launch_index < s->lean_off_until) lean = false;
+    }
+    if (nsub > 0) s->launch_index++;
     size_t lds_q = lean ? sizeof(kp::EnvLdsLean) : lds;
     if (s->model->lds_pad > 0) lds_q = std::max(lds_q, (size_t)s->model->lds_pad);
     const int per_cu = std::min(lean ? 12 : 8, 128 / (int)((lds_q + 1279) / 1280));
@@ -310,7 +327,15 @@ int launch_step(kp_sim* s, const float* action, int nsub, const uint8_t* mask, b
         else {
             hipLaunchKernelGGL((kp::kp_step_queue_kernel<false, true>), dim3(slots), dim3(64), lds_q, s->stream, A);
             // the jobs whose contacts did not fit the lean layout (normally none: every wave leaves at its first read)
-            hipLaunchKernelGGL(kp::kp_step_overflow_kernel, dim3(std::min(s->n, s->wave_slots / 8)), dim3(64), lds, s->stream, A);
+            hipLaunchKernelGGL(kp::kp_step_overflow_kernel, dim3(std::min(s->n, resident_full)), dim3(64), lds, s->stream, A);
+            if (s->ovf_host && !capturing) {
+                const int k = (int)(s->launch_index & 1);
+                if (!s->ovf_pending[k]) {
+                    HIP_OK(hipMemcpyAsync(s->ovf_host + k, s->jobctr + 64, sizeof(unsigned), hipMemcpyDeviceToHost, s->stream));
+                    HIP_OK(hipEventRecord(s->ovf_ev[k], s->stream));
+                    s->ovf_pending[k] = true;
+                }
+            }
         }
     } else
     switch (s->model->threads) {
@@ -374,6 +399,7 @@ int kp_model_set_option(kp_model* m, const char* name, double v) {
     else if (k == "queue_prio") m->queue_prio = std::max(-1, std::min(3, (int)v));
     else if (k == "warm_extrap") m->warm_extrap = (float)v;
     else if (k == "lean_queue") m->lean_queue = v != 0;
+    else if (k == "lean_adaptive") m->lean_adaptive = v != 0;
     else if (k == "lean_max_contacts") { if (v < 0 || v > kp::EnvLdsLean::MAXCON) return fail("lean_max_contacts must be 0 .. " + std::to_string(kp::EnvLdsLean::MAXCON)); m->lean_cap = (int)v; }
     else if (k == "lds_pad") { if (v < 0 || v > 65536) return fail("lds_pad must be 0 .. 65536 bytes"); m->lds_pad = (int)v; }
     else if (k == "queue_slots") { if (v < 0) return fail("queue_slots must be >= 0 (0 = resident wave slots of the device)"); m->queue_slots = (int)v; }
@@ -401,6 +427,7 @@ double kp_model_get_option(const kp_model* m, const char* name) {
     if (k == "substeps_per_job") return m->substeps_per_job;
     if (k == "queue_slots") return m->queue_slots;
     if (k == "lean_queue") return m->lean_queue;
+    if (k == "lean_adaptive") return m->lean_adaptive;
     if (k == "lean_max_contacts") return m->lean_cap;
     if (k == "lds_pad") return m->lds_pad;
     if (k == "lds_bytes_per_env_lean") return (double)sizeof(kp::EnvLdsLean);
@@ -448,6 +475,8 @@ kp_sim* kp_sim_create(const kp_model* m, int n_envs, int device_id, void* stream
         s->n_obj_geoms = (int)(m->h.obj_geoms.size() / 18); s->n_obj = (int)m->h.obj_mass.size();
     }
     if (const char* e = std::getenv("KP_PROFILE")) if (e[0] == '1') s->prof = (unsigned long long*)dalloc(s, N * 16, &ok);
+    if (hipHostMalloc((void**)&s->ovf_host, 2 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess) s->ovf_host = nullptr;
+    else { s->ovf_host[0] = s->ovf_host[1] = 0u; if (hipEventCreateWithFlags(&s->ovf_ev[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s->ovf_ev[1], hipEventDisableTiming) != hipSuccess) { hipHostFree(s->ovf_host); s->ovf_host = nullptr; } }
     if (!ok || hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) {
         fail("kp_sim_create: device allocation / table build failed");
         kp_sim_destroy(s);
@@ -462,6 +491,7 @@ void kp_sim_destroy(kp_sim* s) {
     hipStreamSynchronize(s->stream);
     for (void* p : s->allocs) hipFree(p);
     for (hipEvent_t e : s->ring) hipEventDestroy(e);
+    if (s->ovf_host) { hipHostFree(s->ovf_host); for (hipEvent_t e : s->ovf_ev) if (e) hipEventDestroy(e); }
     if (s->ev0) hipEventDestroy(s->ev0);
     if (s->ev1) hipEventDestroy(s->ev1);
     delete s;
@@ -953,6 +983,14 @@ int kp_sim_diag(kp_sim* s, int32_t* out_host) {
 int kp_job_schedule(int n_substeps, int substeps_per_job, int taper, int* sizes16) {
     if (!sizes16 || n_substeps <= 0 || substeps_per_job <= 0 || n_substeps > 255) return fail("kp_job_schedule: need sizes16, 0 < n_substeps <= 255, substeps_per_job > 0");
     return job_schedule(n_substeps, substeps_per_job, taper, sizes16);
+}
+
+int kp_sim_lean_state(kp_sim* s, int32_t* out3) {
+    if (!s || !out3) return fail("kp_sim_lean_state: null argument");
+    const bool lean = !s->has_objects && s->model->lean_queue && s->model->threads == 64;
+    out3[0] = lean && !(s->model->lean_adaptive && s->launch_index < s->lean_off_until);
+    out3[1] = s->lean_fallbacks; out3[2] = (int32_t)s->launch_index;
+    return 0;
 }
 
 int kp_sim_launch_cost(kp_sim* s, uint32_t* out_host) {

@@ -37,6 +37,7 @@ ABI_SYMBOLS = [
     "kp_sim_contacts", "kp_gae_bootstrap", "kp_gru_gates_forward", "kp_gru_gates_backward", "kp_sim_phase_cycles_env",
     "kp_sim_post_step", "kp_sim_reset_rows", "kp_mcp_compose", "kp_sim_step_head", "kp_model_compile", "kp_model_load_xml",
     "kp_mcp_tail", "kp_gru_cell_step", "kp_kin_advance", "kp_pool_advance", "kp_rollout_record_pre", "kp_rollout_record_post", "kp_sim_field_device",
+    "kp_sim_lean_state",
 ]
 
 
@@ -128,6 +129,7 @@ def load_library(path: str | None = None):
     L.kp_sim_phase_cycles_env.argtypes = [P, C.c_void_p]; L.kp_sim_phase_cycles_env.restype = C.c_int
     L.kp_job_schedule.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]; L.kp_job_schedule.restype = C.c_int
     L.kp_sim_launch_cost.argtypes = [P, C.c_void_p]; L.kp_sim_launch_cost.restype = C.c_int
+    L.kp_sim_lean_state.argtypes = [P, C.c_void_p]; L.kp_sim_lean_state.restype = C.c_int
     L.kp_sim_set_objects.argtypes = [P, F, U8]; L.kp_sim_set_objects.restype = C.c_int
     L.kp_sim_set_obj_state.argtypes = [P, F, F, U8]; L.kp_sim_set_obj_state.restype = C.c_int
     L.kp_sim_fk.argtypes = [P, C.c_int, F, F, F, F, F, F]; L.kp_sim_fk.restype = C.c_int
@@ -237,7 +239,10 @@ class KpSim:
             holder = type("_KpQueueCounters", (), {"__cuda_array_interface__": iface})()
             self._qctr = torch.as_tensor(holder, device=self.device)
         c = self._qctr.cpu().numpy()
-        return {"claimed": int(c[0]), "published": int(c[1]), "stalled": int(c[2]), "kept_by_their_wave": int(c[16]), "lean_overflow_jobs": int(c[64])}
+        st = (C.c_int32 * 3)()
+        _check(self.L.kp_sim_lean_state(self.h, C.cast(st, C.c_void_p)), "kp_sim_lean_state")
+        return {"claimed": int(c[0]), "published": int(c[1]), "stalled": int(c[2]), "kept_by_their_wave": int(c[16]), "lean_overflow_jobs": int(c[64]),
+                "lean_layout_next_launch": bool(st[0]), "fallbacks_to_full_layout": int(st[1]), "control_step_launches": int(st[2])}
 
     def record_contacts(self):
         """Arm the contact read-out (kp_sim_contacts): later step_ctrl launches keep the contact set of their last collision pass."""

@@ -106,6 +106,9 @@ def main():
     if rank == 0 and cc_ckpt:
         print(f"loading model from checkpoint: {cc_ckpt}", flush=True)
     upd_kw = dict(update_dtype=torch.float64 if args.update_dtype == "fp64" else None, reference_bugs=not args.no_reference_bugs)
+    if rank == 0 and not args.no_reference_bugs:          # nothing at run time says so otherwise
+        print("note: reference_bugs = True (results identical to the reference's): the policy gradient is clipped on the run's FIRST optimiser step only, a resumed run "
+              "restarts its LambdaLR decay, LoggerRL.merge takes the max of the workers' min rewards; --no_reference_bugs selects the corrected forms", flush=True)
     if cfg is None:
         agent = AgentAR(args.num_envs, dataset=ds, device=local, horizon=args.horizon, **upd_kw, num_optim_epoch=args.num_optim_epoch, cc_checkpoint=cc_ckpt, result_dir=args.result_dir or None,
                         num_step_update=args.num_step_update, sampling_temp=0.3, sampling_freq=0.5, pool_depth=args.pool_depth, cache_init_context=args.cache_init_context,

@@ -54,7 +54,7 @@ def main():
         if rank == 0:
             print(json.dumps({"iter": it, **{k: (round(v, 5) if isinstance(v, float) else v) for k, v in stats.items()}}), flush=True)
     if args.save and rank == 0:
-        rs = ck.ZFilter((784,)); rs.rs._n = agent.running_state.count
+        rs = ck.ZFilter((784,), clip=agent.running_state.clip); rs.rs._n = agent.running_state.count      # the clip the controller was trained under (uhc.yml: 5)
         rs.rs._M = agent.running_state._mean64.cpu().numpy(); rs.rs._S = agent.running_state._m2.cpu().numpy()
         import pickle
         with ck._RefModulePath(), open(args.save, "wb") as f:

@@ -131,5 +131,11 @@ def test_pool_advance_kernel_matches_the_ring_arithmetic():
         want_row = (want_head.long() * n + torch.arange(n, device="cuda")).to(torch.int32)
         kpsim.pool_advance(done, head, ahead, row, D)
         assert torch.equal(head, want_head) and torch.equal(ahead, want_ahead) and torch.equal(row, want_row)
+    # an env with nothing queued (cannot happen by construction) stays on its row; `ahead` still goes negative for the host check
+    ahead.zero_()
+    h0, r0 = head.clone(), row.clone()
+    done = torch.ones(n, dtype=torch.bool, device="cuda")
+    kpsim.pool_advance(done, head, ahead, row, D)
+    assert torch.equal(head, h0) and torch.equal(row, r0) and bool((ahead == -1).all())
     with pytest.raises(ValueError):
         kpsim.pool_advance(done, head.long(), ahead, row, D)

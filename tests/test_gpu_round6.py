@@ -85,7 +85,8 @@ def test_contact_overflow_goes_to_the_full_layout(kp):
     n = 4096
     qpos, qvel = _states(n, 71, lying_every=8)
     act = np.random.default_rng(72).normal(size=(n, 75)) * 0.1
-    lean, dl, sim = _run(kp, n, qpos, qvel, act, 4, lean_queue=1, lean_max_contacts=8)
+    lean, dl, sim = _run(kp, n, qpos, qvel, act, 4, lean_queue=1, lean_max_contacts=8, lean_adaptive=0)      # every launch on the lean layout + the overflow kernel
+    assert sim.queue_counters()["lean_overflow_jobs"] >= 64
     full, df, _ = _run(kp, n, qpos, qvel, act, 4, lean_queue=0)
     maxcon = df[:, 3] & 255
     assert (maxcon > 8).sum() >= 64 and (maxcon <= 8).sum() >= 1024, f"some envs must cross the lowered limit and most must not (max contacts {maxcon.max()}, envs above 8: {(maxcon > 8).sum()})"
@@ -146,3 +147,32 @@ def test_update_slices_are_reference_iterations():
     assert np.isfinite(info["surr_loss_per_slice"]).all() and np.isfinite(info["step_loss_per_slice"]).all()
     # two ranks' worth of slicing arithmetic: the job-wide sample count decides the number of slices
     assert len(agent.update_slices(agent.sampler.sample(T))) == 4
+
+
+def test_many_overflows_send_the_next_launches_to_the_full_layout(kp):
+    """lean_adaptive (default): when more than 1 / 64 of the envs need more contact slots than the lean layout has -- a policy at random init resets every env onto
+    a garbage pose -- the handle runs its next 64 control steps on the full layout (the overflow kernel's second pass costs more than the lean layout saves), then
+    tries the lean one again.  The switch is a launch policy: states are those of either layout, bit for bit."""
+    n = 4096
+    qpos, qvel = _states(n, 81, lying_every=8)
+    act = np.random.default_rng(82).normal(size=(n, 75)) * 0.1
+    sim = kp.KpSim(kp.KpModel(lean_queue=1, lean_max_contacts=8), n)
+    sim.set_state(dev(qpos), dev(qvel)); sim.set_target(dev(np.tile(STD["qpos"], (n, 1))))
+    a = dev(act)
+    seen = []
+    for _ in range(6):
+        sim.step_ctrl(a, 15)
+        seen.append(sim.queue_counters())               # a host read: the count of the launch before is there when the next one is set up
+    assert seen[0]["lean_layout_next_launch"] or seen[0]["fallbacks_to_full_layout"] >= 1
+    assert seen[-1]["fallbacks_to_full_layout"] >= 1 and not seen[-1]["lean_layout_next_launch"] and seen[-1]["control_step_launches"] == 6
+    full, df, _ = _run(kp, n, qpos, qvel, act, 6, lean_queue=0)
+    for k, f in zip(("qpos", "qvel", "xpos", "xquat", "xipos", "qpos_d"), full):
+        assert (sim.get(k).cpu().numpy() == f).all(), k
+    assert (sim.diag() == df).all()
+    quiet = kp.KpSim(kp.KpModel(), 4096)                 # the metric's kind of scene never overflows: the lean layout stays
+    q2, v2 = _states(4096, 83)
+    quiet.set_state(dev(q2), dev(v2)); quiet.set_target(dev(np.tile(STD["qpos"], (4096, 1))))
+    for _ in range(4):
+        quiet.step_ctrl(a, 15)
+    c = quiet.queue_counters()
+    assert c["fallbacks_to_full_layout"] == 0 and c["lean_layout_next_launch"] and c["lean_overflow_jobs"] == 0

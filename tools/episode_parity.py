@@ -48,7 +48,9 @@ def _worker_init(kin_sd, mcp_sd, kpm_path, zf=None):
 def _worker_run(job):
     e, ctx, T, noise = job
     want = _W["ep"].rollout(ctx, T, noise=noise)
-    return e, {k: want[k] for k in ("res_qpos", "reward", "done", "fail", "mask", "percent", "episode_start")}
+    out = {k: want[k] for k in ("res_qpos", "reward", "done", "fail", "mask", "percent", "episode_start")}
+    out["first_row"] = {k: want[k][0] for k in ("state", "action", "cc_state", "cc_action")}       # the very first control step: no dynamics behind it yet
+    return e, out
 
 
 def tracking_policy(env, ctx, seed):
@@ -98,6 +100,8 @@ def run(n=128, T=99, seed=7, objects=False, workers=32, policy_ckpt=None, device
     torch.cuda.synchronize()
     t_hip = time.perf_counter() - t0
     bad = int(((env.sim.diag()[:, 2] & 255) != 0).sum())
+    first_hip = {"state": b.states[:, 0], "action": b.actions[:, 0], "cc_state": b.cc_state[:, 0], "cc_action": b.cc_action[:, 0]}
+    first_hip = {k: v.double().cpu().numpy() for k, v in first_hip.items()}
     hip = {"res_qpos": b.res_qpos.double().cpu().numpy(), "reward": b.rewards.double().cpu().numpy(), "done": (b.masks == 0).cpu().numpy(), "fail": b.fails.cpu().numpy().astype(bool)}
     # ---- the same episodes on the CPU: fp64 copies of the networks (ZFilter identity unless the checkpoint carries one: EpisodeOracle applies zfilter(0, 1, 5))
     zf = None if cc_rs is None else (cc_rs.mean.double().cpu().numpy(), cc_rs.std.double().cpu().numpy(), float(cc_rs.clip))
@@ -107,6 +111,8 @@ def run(n=128, T=99, seed=7, objects=False, workers=32, policy_ckpt=None, device
     jobs = []
     for e in range(n):
         one = {k: (c[k][e] if c[k].ndim > 1 else c[k]) for k in c}
+        if one["action_one_hot"].ndim == 2:                      # a data set's batch carries the one-hot per frame; it is constant over a take
+            one["action_one_hot"] = one["action_one_hot"][0]
         if not objects:
             one.pop("obj_pose", None)
         jobs.append((e, one, T, nz[:, e]))
@@ -117,7 +123,12 @@ def run(n=128, T=99, seed=7, objects=False, workers=32, policy_ckpt=None, device
             want[e] = r
     t_cpu = time.perf_counter() - t0
     ora = {k: np.stack([w[k] for w in want]) for k in ("res_qpos", "reward", "done", "fail")}
-    return summarise(hip, ora, dict(envs=n, steps=T, seed=seed, objects=bool(objects), policy=("checkpoint " + os.path.basename(policy_ckpt)) if policy_ckpt else "standing-pose tracker (scaled random GRU / MLP)",
+    # where a first-step difference comes from: the 784-d UHC observation AFTER the ZFilter ((x - mean) / (std + 1e-8): a feature that barely varied in training has
+    # a tiny std, which multiplies the fp32 rounding of x), the UHC action, the kinematic action
+    first = {k: float(np.abs(first_hip[k] - np.stack([w["first_row"][k] for w in want])).max()) for k in first_hip}
+    first["zfilter_min_std"] = None if zf is None else float(np.min(zf[1]))
+    first["zfilter_stds_below_1e-3"] = None if zf is None else int((zf[1] < 1e-3).sum())
+    return summarise(hip, ora, dict(first_control_step_max_abs_diff=first, envs=n, steps=T, seed=seed, objects=bool(objects), policy=("checkpoint " + os.path.basename(policy_ckpt)) if policy_ckpt else "standing-pose tracker (scaled random GRU / MLP)",
                                     seconds_hip=t_hip, seconds_oracle=t_cpu, oracle_workers=min(workers, n), bad_envs=bad))
 
 
