@@ -40,15 +40,19 @@ class AgentAR:
                  pool_depth=4, num_epoch_fix=100, num_epoch=10000, joint_controller=False, grad_joint=False, grad_alternate=False, train_uhc=False,
                  cache_init_context=False, log_std=-3.2, policy_weightdecay=0.0, value_weightdecay=0.0, smooth=True, result_dir=None, eval_envs=None,
                  init_update=False, num_init_update=5, step_update_dyna=False, num_step_dyna_update=10, full_update=False, num_sample=20000, batch_size=128,
-                 noise_std=0.0, cc_checkpoint=None, update_dtype=None, reference_bugs=True, min_batch_size=0):
+                 noise_std=0.0, cc_checkpoint=None, update_dtype=None, reference_bugs=True, min_batch_size=0, slice_ratio="slice_start"):
         """update_dtype: None = the update runs on the fp32 roll-out modules (fused HIP re-unroll); torch.float64 = the reference's training
         precision on fp64 master copies (kinpoly_amd/update.py).  reference_bugs: reproduce the reference's generator-consumed gradient clip
         (PPOTrainer) and LoggerRL.merge's max-of-mins; False = the corrected forms.
         min_batch_size (kin_poly.yml:56, 10 000 in the reference; 0 = off): the reference updates once per >= min_batch_size samples.  4096 envs x H steps are ten
         times that, so one update per sample() call would spend a tenth of the reference's optimiser steps (and LambdaLR / Adam steps) per sample.  With
         min_batch_size > 0 a call's batch is cut into ceil(N H / min_batch_size) whole-env slices and every slice is ONE reference iteration: per_epoch_update,
-        update_params (PPO epochs, value steps, supervised steps), epoch += 1.  Ratios are taken against the policy that sampled the rows (recorded before the
-        first slice moves it).  N H <= min_batch_size: one slice, exactly the path without the option."""
+        update_params (PPO epochs, value steps, supervised steps), epoch += 1.  N H <= min_batch_size: one slice, exactly the path without the option.
+        slice_ratio: what the PPO ratio of a later slice is taken against.  "slice_start" (default): the parameters that slice's update starts from -- plain
+        consecutive update_params calls, each the reference's own (fixed_log_probs at the top of update_policy, agent_ar.py:758-759); the rows were sampled up to
+        k - 1 updates earlier, which the ratio then ignores.  "behaviour": the log-probabilities under the policy that sampled the rows, recorded before the first
+        slice moves it -- the importance ratio PPO defines; while the supervised step updates move the policy far between slices (random init: step loss 77 -> 5
+        within one call) it leaves the clip range at once and the surrogate of the later slices has no gradient (profiles/r06/scripts_run.log)."""
         rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
         enable_tuned_gemms()          # library GEMM solution per shape (rollout and update shapes at 4096 envs); selection only
         torch.manual_seed(seed + rank)
@@ -78,6 +82,9 @@ class AgentAR:
                                value_weightdecay=value_weightdecay, init_update=init_update, num_init_update=num_init_update, step_update_dyna=step_update_dyna,
                                num_step_dyna_update=num_step_dyna_update, full_update=full_update, num_sample=num_sample, batch_size=batch_size, noise_std=noise_std)
         self.reference_bugs, self.min_batch_size = bool(reference_bugs), int(min_batch_size)
+        if slice_ratio not in ("slice_start", "behaviour"):
+            raise ValueError("slice_ratio must be 'slice_start' or 'behaviour'")
+        self.slice_ratio = slice_ratio
         self.sampler = VectorSampler(self.env, self.policy_net, record_qpos=True, source=self.source, pool_depth=pool_depth,
                                      record_full=joint_controller or step_update_dyna)
         self.epoch = 0
@@ -165,10 +172,11 @@ class AgentAR:
             self.epoch += 1
         else:
             N, T, _ = batch.states.shape
-            with torch.no_grad():                               # the behaviour policy's log-probabilities of the whole batch, before any slice moves the parameters
-                pol, tr = self.upd.policy, self.trainer
-                means = pol.unroll(tr._cast(batch.states), batch.episode_start, tr._cast(batch.hx0))
-                batch.behaviour_log_probs = pol.log_prob(means.reshape(N * T, -1), tr._cast(batch.actions).reshape(N * T, -1)).detach()
+            if self.slice_ratio == "behaviour":
+                with torch.no_grad():                           # the behaviour policy's log-probabilities of the whole batch, before any slice moves the parameters
+                    pol, tr = self.upd.policy, self.trainer
+                    means = pol.unroll(tr._cast(batch.states), batch.episode_start, tr._cast(batch.hx0))
+                    batch.behaviour_log_probs = pol.log_prob(means.reshape(N * T, -1), tr._cast(batch.actions).reshape(N * T, -1)).detach()
             infos = []
             for k, (lo, hi) in enumerate(slices):
                 if k > 0:

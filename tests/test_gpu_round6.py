@@ -147,6 +147,10 @@ def test_update_slices_are_reference_iterations():
     assert np.isfinite(info["surr_loss_per_slice"]).all() and np.isfinite(info["step_loss_per_slice"]).all()
     # two ranks' worth of slicing arithmetic: the job-wide sample count decides the number of slices
     assert len(agent.update_slices(agent.sampler.sample(T))) == 4
+    # the ratio against the sampling policy instead of the slice's starting parameters: same schedule arithmetic, finite losses
+    agent = AgentAR(n, context_fn, min_batch_size=48, slice_ratio="behaviour", **kw)
+    info = agent.optimize_policy(0)
+    assert info["update_slices"] == 4 and agent.epoch == 4 and np.isfinite(info["surr_loss_per_slice"]).all()
 
 
 def test_many_overflows_send_the_next_launches_to_the_full_layout(kp):

@@ -34,7 +34,8 @@ for S in [int(x) for x in os.environ.get('KP_PIPE_S', '1,2,4').split(',')]:
     for i, st in enumerate(streams):
         with torch.cuda.stream(st):
             n = N // S
-            env = BatchedHumanoidAREnv(n, 0, mode="train", seed=4 + i, cc_policy=cc)
+            opts = {k.lower()[3:]: int(v) for k, v in os.environ.items() if k in ("KP_QUEUE_SLOTS", "KP_LEAN_QUEUE", "KP_QUEUE_PRIO", "KP_QUEUE_LATE")}
+            env = BatchedHumanoidAREnv(n, 0, mode="train", seed=4 + i, cc_policy=cc, model_options=opts)
             cc = env.cc_policy
             g = torch.Generator().manual_seed(4 + i)
             headings = (torch.rand(n, generator=g) * 2 - 1) * np.pi
