@@ -54,7 +54,8 @@ struct kp_sim {
     // every env onto a garbage pose, half buried, with 30 - 70 contacts) the overflow kernel's second pass over them costs more than the lean layout saves: the
     // next 64 launches use the full layout, then the lean one is tried again.  Results do not depend on the layout.
     unsigned* ovf_host = nullptr; hipEvent_t ovf_ev[2] = {nullptr, nullptr}; bool ovf_pending[2] = {false, false};
-    long launch_index = 0, lean_off_until = -1; int lean_fallbacks = 0;      // job FIFO of kp_step_queue_kernel
+    long launch_index = 0, lean_off_until = -1; int lean_fallbacks = 0;
+    unsigned ovf_last = 0;            // the most recent count that has arrived: sizes the overflow kernel's grid (an empty 2048-workgroup launch costs 34 us)      // job FIFO of kp_step_queue_kernel
     float* spd_next = nullptr;                        // [N, 80] torque hand-over between the jobs of a control step
     int jobq_cap = 0, wave_slots = 2048;
     int q_nsub = -1, q_obj = -1;                      // what the queue's "heavy job" yardstick (jobctr[32..33] -> [48..49]) was measured on
@@ -285,6 +286,7 @@ int launch_step(kp_sim* s, const float* action, int nsub, const uint8_t* mask, b
         for (int k = 0; k < 2; k++)
             if (s->ovf_pending[k] && hipEventQuery(s->ovf_ev[k]) == hipSuccess) {
                 s->ovf_pending[k] = false;
+                s->ovf_last = s->ovf_host[k];
                 if ((size_t)s->ovf_host[k] * 64 > (size_t)s->n) { s->lean_off_until = s->launch_index + 64; s->lean_fallbacks++; }
             }
         if (s->model->lean_adaptive && s->launch_index < s->lean_off_until) lean = false;
@@ -327,7 +329,10 @@ int launch_step(kp_sim* s, const float* action, int nsub, const uint8_t* mask, b
         else {
             hipLaunchKernelGGL((kp::kp_step_queue_kernel<false, true>), dim3(slots), dim3(64), lds_q, s->stream, A);
             // the jobs whose contacts did not fit the lean layout (normally none: every wave leaves at its first read)
-            hipLaunchKernelGGL(kp::kp_step_overflow_kernel, dim3(std::min(s->n, resident_full)), dim3(64), lds, s->stream, A);
+            // grid: twice the overflow count last seen (the scenes that overflow keep doing so for a while), at least 128 workgroups -- an unexpected burst is
+            // slow once and sized right from the next-but-one launch on; launching full residency every time costs 34 us per control step for nothing
+            const int ovf_grid = std::min(std::min(s->n, resident_full), std::max(128, 2 * (int)std::min<unsigned>(s->ovf_last, 1u << 20)));
+            hipLaunchKernelGGL(kp::kp_step_overflow_kernel, dim3(ovf_grid), dim3(64), lds, s->stream, A);
             if (s->ovf_host && !capturing) {
                 const int k = (int)(s->launch_index & 1);
                 if (!s->ovf_pending[k]) {
