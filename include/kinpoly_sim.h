@@ -77,6 +77,13 @@ void kp_model_free(kp_model*);
  * "queue_heavy" (default 160; 0 = off): a wave whose job ran at more than that percentage of the launch's mean time per substep keeps its env and runs the
  * env's next job itself instead of queueing it -- the costliest envs are the ones a launch ends on, and with two envs per slot every trip through the
  * FIFO costs them about one job's length of waiting (objects workload 6.49 -> 5.78 ms per launch; bit-identical results);
+ * "lean_queue" (0/1, default 1): floor scenes' queue launches run on the lean LDS layout (12 784 B per env: 12 envs per CU = three waves per SIMD instead of 8 = two;
+ * same results bit for bit).  Its defaults, unless the caller sets the option: jobs of 5 + 5 + 5 substeps, "queue_late" (default -1 = automatic: on with the lean
+ * layout): an env whose first job had to wait for a slot is never queued again, its wave runs its later jobs itself; "queue_prio" (default -1 = automatic: 3 with
+ * the lean layout, else 0): a wave's issue priority (s_setprio) -- 1 envs known to be heavy, 2 by the env's remaining jobs, 3 by its remaining substeps, re-set at
+ * every substep.  "lean_max_contacts" (<= 24): a lean job that finds more contacts in a substep hands the env (before it has stored anything) to a second kernel
+ * on the full layout; "lean_adaptive" (0/1, default 1): when more than 1 / 64 of the envs did so, the next 64 control steps run on the full layout (kp_sim_lean_state).
+ * "lds_pad" (bytes): allocate at least that much LDS per env (experiments: fewer envs per CU with the same binary);
  * "lpt_order" (1 / 0 / -1 = default: on when free objects are simulated): longest-env-first order of the workgroups (plain launch) or of the
  * envs' first jobs in the FIFO, from the previous control step's per-env cycles;
  * "warm_extrap" (beta; default -1 = automatic: 0.75 when the scene's free objects are simulated, 0 otherwise): starting point of the constraint solve.  0 is

@@ -3,8 +3,9 @@
 // One workgroup = one environment.  All per-env dynamics state lives in LDS for the whole control
 // step (15 substeps); HBM is touched only at kernel entry (qpos/qvel/action/target) and exit
 // (qpos/qvel + stale kinematics for the observation kernels).  Lanes map to bodies (24), dofs (75),
-// hull vertices (<=64 per hull) or contacts depending on the phase.  The layout is sized so that
-// 8 environments (7 with free objects) fit in the 160 KiB LDS of one CU.
+// hull vertices (<=64 per hull) or contacts depending on the phase.  Three layouts (below): the full one
+// (8 envs in the 160 KiB LDS of a CU), the lean one of the floor scenes' job queue (12 envs = three waves on
+// every SIMD) and the one with the free objects' block (7 envs).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

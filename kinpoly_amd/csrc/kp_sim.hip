@@ -276,7 +276,8 @@ int launch_step(kp_sim* s, const float* action, int nsub, const uint8_t* mask, b
     // 2.44 ms).  Three measures take the launch to 2.19 ms (profiles/r06/lean_schedule_knobs*.log): equal jobs 5 + 5 + 5 (the late envs start earlier), a late
     // env is never queued again (queue_late), and every wave's issue priority follows its env's distance from the end of the control step (queue_prio = 3).
     // Options the caller sets (substeps_per_job / job_taper, queue_prio, queue_late) are obeyed.
-    // resident waves: LDS is allocated in 1 280-byte granules, 128 per CU (tools/micro/lds_granule_probe.hip); 256 VGPRs allow 8 waves per CU
+    // resident waves: LDS is allocated in 1 280-byte granules, 128 per CU (tools/micro/lds_granule_probe.hip); the register budgets allow 8 waves per CU
+    // (full layout, <= 256 VGPRs) and 12 (lean layout, 168 VGPRs)
     // floor scenes: the job queue runs on the lean layout (EnvLdsLean) with a register budget for three waves per SIMD; model option lean_queue = 0 keeps the
     // full layout (two waves per SIMD; A / B measurements).  lds_pad: allocate at least that many bytes per env (experiments: fewer envs per CU with the same binary)
     bool lean = !obj && s->model->lean_queue && s->model->threads == 64;

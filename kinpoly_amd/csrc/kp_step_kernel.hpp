@@ -24,7 +24,8 @@
 // Launch forms: kp_step_kernel (one workgroup = one wavefront per env and control step), kp_forward_kernel (sim.forward() only) and
 // kp_step_queue_kernel (the same step_body run by resident wavefronts that pull (env, few substeps) jobs from a FIFO in HBM, used
 // when there are more envs than wavefront slots; bit-identical results; the finishing job hands its successor the next stable-PD torque, and a wave
-// keeps an env it finds heavy).
+// keeps an env it finds heavy or that started late).  The functions are templates over the LDS layout (kp_device.hpp): floor scenes' queue launches run on
+// EnvLdsLean (12 envs per CU) and hand a job with more contacts than it holds to kp_step_overflow_kernel (full layout); same arithmetic, same bits.
 #pragma once
 #include <type_traits>
 
@@ -85,7 +86,7 @@ struct StepArgs {
     int queue_heavy;           // > 0: a wave that finds its env heavy (this job's cycles per substep > queue_heavy % of the launch's running mean) runs the env's next job itself
     int queue_fence;           // 1: the hand-over is a release (publish) / acquire (consume) pair at agent scope instead of relaxed sc1 accesses + s_waitcnt
     int queue_late;            // 1: a wave whose env's FIRST job came from beyond the resident slots (it started late) runs that env's later jobs itself, at once
-    int queue_prio;            // > 0: waves running jobs of envs known to be heavy raise their issue priority (s_setprio)
+    int queue_prio;            // issue priority (s_setprio) of a wave: 0 none; 1 envs known to be heavy; 2 by the env's remaining jobs; 3 by its remaining substeps, re-set at every substep
     int order_valid;           // the first jobs were queued longest-env-first
     unsigned long long part_sub_lo, part_sub_hi;   // substeps of job 0 .. 15, one byte each (sum = n_substeps); packed so that no lookup indexes the kernel argument
 };
